@@ -1,0 +1,317 @@
+// Fused multi-head self-attention core for the short DeepSVG sequences (S <= 64, head_dim = 32).
+// One workgroup owns one (sequence, head-group): the q|k|v slabs of the group are staged once in LDS
+// with coalesced 16-byte row loads, every lane owns one (head, query row) pair, K/V rows are LDS
+// broadcasts, the softmax row lives in registers, and no S x S tensor ever reaches HBM.  The backward
+// kernel recomputes the probabilities (flash-style two passes: query-major for dQ, key-major for dK/dV).
+// Replaces deepsvg/model/layers/functional.py:168,197-248 and its autograd backward.
+//
+// Row stride of the LDS image = 3*W elements + 16 bytes, i.e. == 4 dwords (mod 64): the 16 lanes of a
+// ds_read_b128 group that read 16 different rows hit 16 disjoint 4-bank slots (conflict-free); lanes
+// reading the same K/V row broadcast.
+#include "dsvg_common.h"
+#include "../../include/dsvg.h"
+
+template <typename T, int SP, int HG>
+struct AttnCfg {
+    static constexpr int HPW = 64 / SP;          // heads per wave
+    static constexpr int NW = HG / HPW;          // waves per workgroup
+    static constexpr int NT = NW * 64;
+    static constexpr int W = HG * 32;            // columns of one q/k/v slab of the head group
+    static constexpr int PAD = 16 / (int)sizeof(T);
+    static constexpr int LD = 3 * W + PAD;       // row stride of the qkv image
+    static constexpr int LDO = W + PAD;          // row stride of the dO image (backward)
+};
+
+template <typename T, int NT>
+__device__ __forceinline__ void tile_copy_in(T* dst, int ld_dst, const T* src, long long ld_src, int rows, int cols) {
+    typedef typename Elem<T>::raw4 raw4;
+    const int cpr = cols / 4;
+    for (int idx = threadIdx.x; idx < rows * cpr; idx += NT) {
+        const int r = idx / cpr, c = idx % cpr;
+        *reinterpret_cast<raw4*>(dst + r * ld_dst + 4 * c) = *reinterpret_cast<const raw4*>(src + r * ld_src + 4 * c);
+    }
+}
+template <typename T, int NT>
+__device__ __forceinline__ void tile_copy_out(T* dst, long long ld_dst, const T* src, int ld_src, int rows, int cols) {
+    typedef typename Elem<T>::raw4 raw4;
+    const int cpr = cols / 4;
+    for (int idx = threadIdx.x; idx < rows * cpr; idx += NT) {
+        const int r = idx / cpr, c = idx % cpr;
+        *reinterpret_cast<raw4*>(dst + r * ld_dst + 4 * c) = *reinterpret_cast<const raw4*>(src + r * ld_src + 4 * c);
+    }
+}
+
+template <typename T, int SP, int HG>
+__global__ __launch_bounds__(HG * SP) void attn_fwd_kernel(
+    const T* __restrict__ qkv, const uint64_t* __restrict__ key_mask, T* __restrict__ out, int S, int H, float scale,
+    float drop_p, uint32_t drop_site, const uint64_t* seed) {
+    typedef AttnCfg<T, SP, HG> C;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* tile = reinterpret_cast<T*>(smem_raw);
+    const int b = blockIdx.x, hg = blockIdx.y;
+    const int d = H * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hl = lane / SP, i = lane % SP;
+    const int hh = wave * C::HPW + hl;      // head inside the group
+    const int h = hg * HG + hh;             // global head
+    const T* src = qkv + (size_t)b * S * 3 * d + (size_t)hg * C::W;
+
+    tile_copy_in<T, C::NT>(tile, C::LD, src, 3LL * d, S, C::W);                          // q slab
+    tile_copy_in<T, C::NT>(tile + C::W, C::LD, src + d, 3LL * d, S, C::W);               // k slab
+    tile_copy_in<T, C::NT>(tile + 2 * C::W, C::LD, src + 2 * d, 3LL * d, S, C::W);       // v slab
+    __syncthreads();
+
+    const uint64_t km = key_mask ? key_mask[b] : ~0ull;
+    const DropCtx dc = drop_make(drop_p, seed, drop_site);
+    const bool active = i < S;
+    float o[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) o[c] = 0.f;
+
+    if (active) {
+        float q[32];
+        row32_load(tile + i * C::LD + hh * 32, q);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) q[c] *= scale;
+        float s[SP];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < SP; ++j) {
+            s[j] = -INFINITY;
+            if (j < S) {
+                float kr[32];
+                row32_load(tile + j * C::LD + C::W + hh * 32, kr);
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) acc = fmaf(q[c], kr[c], acc);
+                if ((km >> j) & 1ull) s[j] = acc;
+                m = fmaxf(m, s[j]);
+            }
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < SP; ++j) {
+            s[j] = (j < S) ? __expf(s[j] - m) : 0.f;
+            l += s[j];
+        }
+        const float inv = 1.f / l;
+        const uint64_t ebase = (((uint64_t)b * H + h) * S + i) * S;
+#pragma unroll
+        for (int j = 0; j < SP; ++j) {
+            if (j < S) {
+                const float pj = s[j] * inv * drop_mult(dc, ebase + j);
+                float vr[32];
+                row32_load(tile + j * C::LD + 2 * C::W + hh * 32, vr);
+#pragma unroll
+                for (int c = 0; c < 32; ++c) o[c] = fmaf(pj, vr[c], o[c]);
+            }
+        }
+        // each (row, head) q slot is private to its lane: reuse it as the output staging slot
+        row32_store(tile + i * C::LD + hh * 32, o);
+    }
+    __syncthreads();
+    tile_copy_out<T, C::NT>(out + (size_t)b * S * d + (size_t)hg * C::W, (long long)d, tile, C::LD, S, C::W);
+}
+
+template <typename T, int SP, int HG>
+__global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
+    const T* __restrict__ qkv, const uint64_t* __restrict__ key_mask, const T* __restrict__ dout, T* __restrict__ dqkv,
+    int S, int H, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed) {
+    typedef AttnCfg<T, SP, HG> C;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* tile = reinterpret_cast<T*>(smem_raw);                         // [S][LD]   q|k|v
+    T* dtile = tile + S * C::LD;                                      // [S][LDO]  dO
+    float* stat = reinterpret_cast<float*>(dtile + S * C::LDO);       // [HG][SP][2]  lse, D
+    const int b = blockIdx.x, hg = blockIdx.y;
+    const int d = H * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hl = lane / SP, i = lane % SP;
+    const int hh = wave * C::HPW + hl;
+    const int h = hg * HG + hh;
+    const T* src = qkv + (size_t)b * S * 3 * d + (size_t)hg * C::W;
+
+    tile_copy_in<T, C::NT>(tile, C::LD, src, 3LL * d, S, C::W);
+    tile_copy_in<T, C::NT>(tile + C::W, C::LD, src + d, 3LL * d, S, C::W);
+    tile_copy_in<T, C::NT>(tile + 2 * C::W, C::LD, src + 2 * d, 3LL * d, S, C::W);
+    tile_copy_in<T, C::NT>(dtile, C::LDO, dout + (size_t)b * S * d + (size_t)hg * C::W, (long long)d, S, C::W);
+    __syncthreads();
+
+    const uint64_t km = key_mask ? key_mask[b] : ~0ull;
+    const DropCtx dc = drop_make(drop_p, seed, drop_site);
+    const bool active = i < S;
+    const uint64_t hbase = ((uint64_t)b * H + h) * S;   // element id of (i, j) = (hbase + i) * S + j
+
+    float dq[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) dq[c] = 0.f;
+
+    // ---- pass 1: this lane is query row i --------------------------------------------------------------
+    if (active) {
+        float q[32], go[32];
+        row32_load(tile + i * C::LD + hh * 32, q);
+        row32_load(dtile + i * C::LDO + hh * 32, go);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) q[c] *= scale;
+        float s[SP];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < SP; ++j) {
+            s[j] = -INFINITY;
+            if (j < S) {
+                float kr[32];
+                row32_load(tile + j * C::LD + C::W + hh * 32, kr);
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) acc = fmaf(q[c], kr[c], acc);
+                if ((km >> j) & 1ull) s[j] = acc;
+                m = fmaxf(m, s[j]);
+            }
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < SP; ++j) {
+            s[j] = (j < S) ? __expf(s[j] - m) : 0.f;
+            l += s[j];
+        }
+        const float inv = 1.f / l;
+        const float lse = m + __logf(l);
+        float dp[SP];
+        float D = 0.f;
+#pragma unroll
+        for (int j = 0; j < SP; ++j) {
+            dp[j] = 0.f;
+            if (j < S) {
+                float vr[32];
+                row32_load(tile + j * C::LD + 2 * C::W + hh * 32, vr);
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) acc = fmaf(go[c], vr[c], acc);
+                s[j] *= inv;                                                  // P_ij
+                dp[j] = acc * drop_mult(dc, (hbase + i) * S + j);            // dP_ij
+                D = fmaf(s[j], dp[j], D);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SP; ++j) {
+            if (j < S) {
+                const float ds = s[j] * (dp[j] - D) * scale;
+                float kr[32];
+                row32_load(tile + j * C::LD + C::W + hh * 32, kr);
+#pragma unroll
+                for (int c = 0; c < 32; ++c) dq[c] = fmaf(ds, kr[c], dq[c]);
+            }
+        }
+        stat[(hh * SP + i) * 2 + 0] = lse;
+        stat[(hh * SP + i) * 2 + 1] = D;
+    }
+    __syncthreads();
+
+    // ---- pass 2: this lane is key row j = i --------------------------------------------------------------
+    float dk[32], dv[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+    if (active) {
+        const int j = i;
+        const bool kvalid = (km >> j) & 1ull;
+        float kr[32], vr[32];
+        row32_load(tile + j * C::LD + C::W + hh * 32, kr);
+        row32_load(tile + j * C::LD + 2 * C::W + hh * 32, vr);
+        if (kvalid) {
+            for (int r = 0; r < S; ++r) {
+                float q[32], go[32];
+                row32_load(tile + r * C::LD + hh * 32, q);
+                row32_load(dtile + r * C::LDO + hh * 32, go);
+                float sacc = 0.f, dacc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) { sacc = fmaf(q[c], kr[c], sacc); dacc = fmaf(go[c], vr[c], dacc); }
+                const float lse = stat[(hh * SP + r) * 2 + 0];
+                const float D = stat[(hh * SP + r) * 2 + 1];
+                const float mult = drop_mult(dc, (hbase + r) * S + j);
+                const float p = __expf(sacc * scale - lse);
+                const float pd = p * mult;                                   // dropped probability used in O = P~ V
+                const float ds = p * (dacc * mult - D) * scale;             // dS_rj * scale (q unscaled below)
+#pragma unroll
+                for (int c = 0; c < 32; ++c) { dv[c] = fmaf(pd, go[c], dv[c]); dk[c] = fmaf(ds, q[c], dk[c]); }
+            }
+        }
+    }
+    __syncthreads();   // every read of the q/k/v image is done: reuse it as the dq|dk|dv staging image
+    if (active) {
+        row32_store(tile + i * C::LD + hh * 32, dq);
+        row32_store(tile + i * C::LD + C::W + hh * 32, dk);
+        row32_store(tile + i * C::LD + 2 * C::W + hh * 32, dv);
+    }
+    __syncthreads();
+    T* dst = dqkv + (size_t)b * S * 3 * d + (size_t)hg * C::W;
+    tile_copy_out<T, C::NT>(dst, 3LL * d, tile, C::LD, S, C::W);
+    tile_copy_out<T, C::NT>(dst + d, 3LL * d, tile + C::W, C::LD, S, C::W);
+    tile_copy_out<T, C::NT>(dst + 2 * d, 3LL * d, tile + 2 * C::W, C::LD, S, C::W);
+}
+
+template <typename T, int SP, int HG>
+static int launch_fwd(const void* qkv, const uint64_t* km, void* out, int64_t n_seq, int S, int H, float scale,
+                      float drop_p, uint32_t site, const uint64_t* seed, hipStream_t st) {
+    typedef AttnCfg<T, SP, HG> C;
+    const size_t lds = (size_t)S * C::LD * sizeof(T);
+    if (lds > 160 * 1024) { dsvg_set_error("attention_fwd: LDS image too large (%zu B)", lds); return -1; }
+    auto kern = attn_fwd_kernel<T, SP, HG>;
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq, H / HG), dim3(C::NT), lds, st, (const T*)qkv, km, (T*)out, S, H,
+                       scale, drop_p, site, seed);
+    DSVG_LAUNCH_CHECK("attention_fwd");
+    return 0;
+}
+template <typename T, int SP, int HG>
+static int launch_bwd(const void* qkv, const uint64_t* km, const void* dout, void* dqkv, int64_t n_seq, int S, int H,
+                      float scale, float drop_p, uint32_t site, const uint64_t* seed, hipStream_t st) {
+    typedef AttnCfg<T, SP, HG> C;
+    const size_t lds = (size_t)S * (C::LD + C::LDO) * sizeof(T) + (size_t)HG * SP * 2 * sizeof(float);
+    if (lds > 160 * 1024) { dsvg_set_error("attention_bwd: LDS image too large (%zu B)", lds); return -1; }
+    auto kern = attn_bwd_kernel<T, SP, HG>;
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq, H / HG), dim3(C::NT), lds, st, (const T*)qkv, km, (const T*)dout,
+                       (T*)dqkv, S, H, scale, drop_p, site, seed);
+    DSVG_LAUNCH_CHECK("attention_bwd");
+    return 0;
+}
+
+// head-group choice: all 8 heads per workgroup while the LDS image fits, 4 heads for the 64-row variant
+#define DSVG_ATTN_DISPATCH(FN, T, ...)                                              \
+    do {                                                                            \
+        if (S <= 8 && n_heads % 8 == 0) return FN<T, 8, 8>(__VA_ARGS__);            \
+        if (S <= 16 && n_heads % 8 == 0) return FN<T, 16, 8>(__VA_ARGS__);          \
+        if (S <= 32 && n_heads % 8 == 0) return FN<T, 32, 8>(__VA_ARGS__);          \
+        if (S <= 32 && n_heads % 2 == 0) return FN<T, 32, 2>(__VA_ARGS__);          \
+        if (S <= 64 && n_heads % 4 == 0) return FN<T, 64, 4>(__VA_ARGS__);          \
+        if (S <= 64) return FN<T, 64, 1>(__VA_ARGS__);                              \
+    } while (0)
+
+extern "C" int dsvg_attention_fwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, void* out, int64_t n_seq,
+                                  int32_t S, int32_t n_heads, float scale, float drop_p, uint32_t drop_site,
+                                  const uint64_t* seed, void* stream) {
+    DSVG_CHECK_ARG(qkv && out && n_seq > 0 && S > 0 && S <= 64 && n_heads > 0, "attention_fwd: bad args (S=%d)", S);
+    DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_fwd: dropout needs a seed pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_F32) {
+        DSVG_ATTN_DISPATCH(launch_fwd, float, qkv, key_mask, out, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
+    } else if (dtype == DSVG_BF16) {
+        DSVG_ATTN_DISPATCH(launch_fwd, bf16_t, qkv, key_mask, out, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
+    }
+    dsvg_set_error("attention_fwd: unsupported dtype/shape (dtype=%d S=%d H=%d)", dtype, S, n_heads);
+    return -1;
+}
+
+extern "C" int dsvg_attention_bwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const void* dout,
+                                  void* dqkv, int64_t n_seq, int32_t S, int32_t n_heads, float scale, float drop_p,
+                                  uint32_t drop_site, const uint64_t* seed, void* stream) {
+    DSVG_CHECK_ARG(qkv && dout && dqkv && n_seq > 0 && S > 0 && S <= 64 && n_heads > 0, "attention_bwd: bad args");
+    DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_bwd: dropout needs a seed pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_F32) {
+        DSVG_ATTN_DISPATCH(launch_bwd, float, qkv, key_mask, dout, dqkv, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
+    } else if (dtype == DSVG_BF16) {
+        DSVG_ATTN_DISPATCH(launch_bwd, bf16_t, qkv, key_mask, dout, dqkv, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
+    }
+    dsvg_set_error("attention_bwd: unsupported dtype/shape (dtype=%d S=%d H=%d)", dtype, S, n_heads);
+    return -1;
+}

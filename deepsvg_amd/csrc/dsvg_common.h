@@ -1,0 +1,174 @@
+// Device-side helpers shared by every gfx950 kernel of the DeepSVG hot path.
+// gfx950 only: 64-lane wavefronts are hard-coded, no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+
+#define DSVG_F32 0
+#define DSVG_BF16 1
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits; arithmetic is always done in fp32
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing for the C-ABI (thread-local message, negative return codes)
+// ---------------------------------------------------------------------------------------------
+extern "C" const char* dsvg_last_error(void);
+void dsvg_set_error(const char* fmt, ...);
+
+#define DSVG_CHECK_ARG(cond, ...)                \
+    do {                                         \
+        if (!(cond)) {                           \
+            dsvg_set_error(__VA_ARGS__);         \
+            return -1;                           \
+        }                                        \
+    } while (0)
+
+#define DSVG_LAUNCH_CHECK(name)                                                        \
+    do {                                                                               \
+        hipError_t _e = hipGetLastError();                                             \
+        if (_e != hipSuccess) {                                                        \
+            dsvg_set_error("%s: launch failed: %s", name, hipGetErrorString(_e));      \
+            return -2;                                                                 \
+        }                                                                              \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// bf16 <-> fp32
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                           // round to nearest even
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    typedef float4 raw4;  // bit-copy of 4 consecutive elements
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+    // 4 consecutive elements, pointer must be 16-byte aligned
+    static __device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Elem<bf16_t> {
+    typedef uint2 raw4;
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+    // 4 consecutive elements, pointer must be 8-byte aligned
+    static __device__ __forceinline__ void ld4(const bf16_t* p, float (&v)[4]) {
+        uint2 t = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st4(bf16_t* p, const float (&v)[4]) {
+        uint2 t;
+        t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = t;
+    }
+};
+
+// 32 consecutive elements (one attention head row) -> fp32 registers; p must be 16-byte aligned
+__device__ __forceinline__ void row32_load(const float* p, float (&v)[32]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 t = reinterpret_cast<const float4*>(p)[i];
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+}
+__device__ __forceinline__ void row32_load(const bf16_t* p, float (&v)[32]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 t = reinterpret_cast<const uint4*>(p)[i];
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[8 * i + 2 * e] = __uint_as_float(w[e] << 16);
+            v[8 * i + 2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+        }
+    }
+}
+__device__ __forceinline__ void row32_store(float* p, const float (&v)[32]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+__device__ __forceinline__ void row32_store(bf16_t* p, const float (&v)[32]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            w[e] = (uint32_t)f2bf(v[8 * i + 2 * e]) | ((uint32_t)f2bf(v[8 * i + 2 * e + 1]) << 16);
+        reinterpret_cast<uint4*>(p)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based dropout RNG.  keep(seed, site, idx) is a pure function so that the backward pass
+// regenerates the forward mask instead of storing it.  `seed` lives in device memory so that a
+// captured hipGraph sees a new value on every replay.  The same hash is restated with int64 torch
+// ops in tests/torch_ops_ref.py.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dsvg_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+struct DropCtx {
+    uint32_t s0, s1;    // mixed seed words
+    uint32_t thresh;    // drop when hash < thresh
+    float scale;        // 1/(1-p)
+    bool on;
+};
+__device__ __forceinline__ DropCtx drop_make(float p, const uint64_t* seed_ptr, uint32_t site) {
+    DropCtx c;
+    c.on = (p > 0.f) && (seed_ptr != nullptr);
+    if (c.on) {
+        uint64_t seed = *seed_ptr;
+        c.s0 = dsvg_hash32((uint32_t)seed ^ (site * 0x9e3779b1u));
+        c.s1 = dsvg_hash32((uint32_t)(seed >> 32) + site * 0x85ebca77u + 0x165667b1u);
+        double t = (double)p * 4294967296.0;
+        c.thresh = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+        c.scale = 1.f / (1.f - p);
+    } else {
+        c.s0 = c.s1 = 0; c.thresh = 0; c.scale = 1.f;
+    }
+    return c;
+}
+// returns the multiplier (0 or 1/(1-p)) for element idx
+__device__ __forceinline__ float drop_mult(const DropCtx& c, uint64_t idx) {
+    if (!c.on) return 1.f;
+    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    uint32_t h = dsvg_hash32(lo ^ c.s0);
+    h = dsvg_hash32(h + hi * 0x9e3779b1u + c.s1);
+    return h < c.thresh ? 0.f : c.scale;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-level reductions (64 lanes) and width-limited group reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int dsvg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// out[j] = (accumulate ? out[j] : 0) + sum_{q<P} part[q*stride + j], j < n   (deterministic order; gemm.hip)
+int dsvg_reduce_partials_strided(const float* part, int64_t P, int64_t stride, int64_t n, float* out,
+                                 int32_t accumulate, hipStream_t st);

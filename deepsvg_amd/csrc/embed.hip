@@ -1,0 +1,479 @@
+// Mask construction, embedding gather/scatter, positional add, masked mean-pool and the broadcast add
+// of linear_global(z): the HBM-bound glue of the DeepSVG encoder/decoder (reference call sites in
+// include/dsvg.h).  All kernels are thread-per-feature-column with coalesced row accesses; parameter
+// gradients are accumulated privately (registers / LDS columns owned by one thread) and reduced through
+// per-workgroup partial rows -> no global atomics anywhere, bit-reproducible results.
+#include "dsvg_common.h"
+#include "../../include/dsvg.h"
+
+// ---------------------------------------------------------------------------------------------
+// masks (deepsvg/model/utils.py:7-66)
+// ---------------------------------------------------------------------------------------------
+__global__ void build_masks_kernel(const float* __restrict__ commands, long long n_seq, int S, int G, int eos,
+                                   uint64_t* __restrict__ key_mask, int* __restrict__ seq_visible,
+                                   uint64_t* __restrict__ group_mask) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_seq) return;
+    const float* row = commands + b * S;
+    uint64_t km = 0;
+    int n_eos = 0;
+    bool seen = false;
+    for (int s = 0; s < S; ++s) {
+        const bool is_eos = ((int)row[s] == eos);
+        seen |= is_eos;
+        n_eos += is_eos;
+        if (!seen) km |= (1ull << s);
+    }
+    if (key_mask) key_mask[b] = km;
+    if (seq_visible) seq_visible[b] = (n_eos < S - 1) ? 1 : 0;
+}
+__global__ void group_mask_kernel(const int* __restrict__ seq_visible, long long n_icons, int G,
+                                  uint64_t* __restrict__ group_mask) {
+    const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_icons) return;
+    uint64_t gm = 0;
+    for (int g = 0; g < G; ++g)
+        if (seq_visible[n * G + g]) gm |= (1ull << g);
+    group_mask[n] = gm;
+}
+
+extern "C" int dsvg_build_masks(const float* commands, int64_t n_seq, int32_t S, int32_t G, int32_t eos_id,
+                                uint64_t* key_mask, int32_t* seq_visible, uint64_t* group_mask, void* stream) {
+    DSVG_CHECK_ARG(commands && n_seq > 0 && S > 0 && S <= 64, "build_masks: bad args (S=%d)", S);
+    DSVG_CHECK_ARG(!group_mask || (seq_visible && G > 0 && G <= 64 && n_seq % G == 0), "build_masks: bad group args");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(build_masks_kernel, dim3(dsvg_cdiv(n_seq, 256)), dim3(256), 0, st, commands, (long long)n_seq, S,
+                       G, eos_id, key_mask, seq_visible, group_mask);
+    DSVG_LAUNCH_CHECK("build_masks");
+    if (group_mask) {
+        hipLaunchKernelGGL(group_mask_kernel, dim3(dsvg_cdiv(n_seq / G, 256)), dim3(256), 0, st, seq_visible,
+                           (long long)(n_seq / G), G, group_mask);
+        DSVG_LAUNCH_CHECK("group_mask");
+    }
+    return 0;
+}
+
+__global__ void group_index_kernel(const float* __restrict__ commands, long long n_seq, int S, int m_id,
+                                   int* __restrict__ groups) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_seq) return;
+    int cnt = 0;
+    for (int s = 0; s < S; ++s) {
+        cnt += ((int)commands[b * S + s] == m_id);
+        groups[b * S + s] = cnt;
+    }
+}
+extern "C" int dsvg_group_index(const float* commands, int64_t n_seq, int32_t S, int32_t m_id, int32_t* groups,
+                                void* stream) {
+    DSVG_CHECK_ARG(commands && groups && n_seq > 0 && S > 0, "group_index: bad args");
+    hipLaunchKernelGGL(group_index_kernel, dim3(dsvg_cdiv(n_seq, 256)), dim3(256), 0, (hipStream_t)stream, commands,
+                       (long long)n_seq, S, m_id, groups);
+    DSVG_LAUNCH_CHECK("group_index");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding gather (deepsvg/model/model.py:49-53)
+//   A[t, a*E + e] = arg_embed[args[t,a] + 1, e];   R[t, c] = command_embed[cmd[t], c] (+ group_embed[grp[t], c])
+// one thread per 4 output elements
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_gather_kernel(const float* __restrict__ commands, const float* __restrict__ args,
+                                    const float* __restrict__ command_embed, const float* __restrict__ arg_embed,
+                                    const float* __restrict__ group_embed, const int* __restrict__ groups,
+                                    T* __restrict__ A, T* __restrict__ R, long long T_tok, int n_args, int E, int d,
+                                    int n_cmd, int n_argvals) {
+    const int wa = n_args * E / 4, wr = d / 4;
+    const long long total = T_tok * (wa + wr);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long t = idx / (wa + wr);
+        const int c = (int)(idx % (wa + wr));
+        float v[4];
+        if (c < wa) {
+            const int a = (4 * c) / E, e = (4 * c) % E;
+            int iv = (int)args[t * n_args + a] + 1;
+            iv = min(max(iv, 0), n_argvals - 1);
+            const float4 w = *reinterpret_cast<const float4*>(arg_embed + (size_t)iv * E + e);
+            v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
+            Elem<T>::st4(A + t * (long long)(n_args * E) + 4 * c, v);
+        } else {
+            const int cc = 4 * (c - wa);
+            int ic = (int)commands[t];
+            ic = min(max(ic, 0), n_cmd - 1);
+            float4 w = *reinterpret_cast<const float4*>(command_embed + (size_t)ic * d + cc);
+            if (group_embed) {
+                const float4 g = *reinterpret_cast<const float4*>(group_embed + (size_t)groups[t] * d + cc);
+                w.x += g.x; w.y += g.y; w.z += g.z; w.w += g.w;
+            }
+            v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
+            Elem<T>::st4(R + t * (long long)d + cc, v);
+        }
+    }
+}
+
+extern "C" int dsvg_embed_gather(int32_t dtype, const float* commands, const float* args, const float* command_embed,
+                                 const float* arg_embed, const float* group_embed, const int32_t* groups, void* A,
+                                 void* R, int64_t T_tok, int32_t n_args, int32_t E, int32_t d, int32_t n_cmd,
+                                 int32_t n_argvals, void* stream) {
+    DSVG_CHECK_ARG(commands && args && command_embed && arg_embed && A && R, "embed_gather: null pointer");
+    DSVG_CHECK_ARG(T_tok > 0 && (E % 4) == 0 && (d % 4) == 0, "embed_gather: bad shape");
+    DSVG_CHECK_ARG(!group_embed || groups, "embed_gather: group_embed needs groups");
+    const long long total = T_tok * (long long)(n_args * E / 4 + d / 4);
+    const int nb = (int)min((long long)dsvg_cdiv(total, 256), 8192LL);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(nb), dim3(256), 0, st, commands, args, command_embed,
+                           arg_embed, group_embed, groups, (float*)A, (float*)R, (long long)T_tok, n_args, E, d, n_cmd,
+                           n_argvals);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(embed_gather_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, commands, args, command_embed,
+                           arg_embed, group_embed, groups, (bf16_t*)A, (bf16_t*)R, (long long)T_tok, n_args, E, d,
+                           n_cmd, n_argvals);
+    else { dsvg_set_error("embed_gather: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("embed_gather");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding scatter-add (autograd of the nn.Embedding lookups, aten::embedding_dense_backward)
+// Each workgroup owns a contiguous chunk of tokens and a private LDS copy of the gradient table
+// (arg table 257x64 fp32 = 66 KB; command/group tables (7+G)x256).  Gradient rows are streamed with
+// coalesced loads over the flattened (token, column) range and added with LDS atomics (ds_add_f32);
+// the per-workgroup tables are written to the workspace and reduced in a fixed order, so there are no
+// global atomics.  (LDS float atomics make the sum order inside one workgroup schedule-dependent, i.e.
+// reproducible to ~1e-7 relative, not bitwise.)
+// ---------------------------------------------------------------------------------------------
+constexpr int ES_TOK_PER_BLOCK = 256;
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_scatter_arg_kernel(const float* __restrict__ args, const T* __restrict__ dA,
+                                                                float* __restrict__ part, long long T_tok, int n_args,
+                                                                int E, int n_argvals) {
+    extern __shared__ float acc[];   // [n_argvals * E]
+    const int tab = n_argvals * E;
+    for (int i = threadIdx.x; i < tab; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const long long t0 = (long long)blockIdx.x * ES_TOK_PER_BLOCK;
+    const long long t1 = min(T_tok, t0 + ES_TOK_PER_BLOCK);
+    const int width = n_args * E;
+    const long long i0 = t0 * width, i1 = t1 * width;
+#pragma unroll 4
+    for (long long idx = i0 + threadIdx.x; idx < i1; idx += 256) {
+        const float g = Elem<T>::ld(dA + idx);
+        if (g != 0.f) {
+            const long long t = idx / width;
+            const int c = (int)(idx - t * width);
+            const int a = c / E, e = c - a * E;
+            int iv = (int)args[t * n_args + a] + 1;
+            iv = min(max(iv, 0), n_argvals - 1);
+            atomicAdd(&acc[iv * E + e], g);
+        }
+    }
+    __syncthreads();
+    float* dst = part + (size_t)blockIdx.x * tab;
+    for (int i = threadIdx.x; i < tab; i += 256) dst[i] = acc[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_scatter_row_kernel(const float* __restrict__ commands,
+                                                                const int* __restrict__ groups,
+                                                                const T* __restrict__ dR, float* __restrict__ part_cmd,
+                                                                float* __restrict__ part_grp, long long T_tok, int d,
+                                                                int n_cmd, int n_groups) {
+    extern __shared__ float acc[];   // [n_cmd * d] then [n_groups * d]
+    float* acc_c = acc;
+    float* acc_g = acc + n_cmd * d;
+    for (int i = threadIdx.x; i < (n_cmd + n_groups) * d; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const long long t0 = (long long)blockIdx.x * ES_TOK_PER_BLOCK;
+    const long long t1 = min(T_tok, t0 + ES_TOK_PER_BLOCK);
+    const long long i0 = t0 * d, i1 = t1 * d;
+#pragma unroll 4
+    for (long long idx = i0 + threadIdx.x; idx < i1; idx += 256) {
+        const float g = Elem<T>::ld(dR + idx);
+        if (g != 0.f) {
+            const long long t = idx / d;
+            const int c = (int)(idx - t * d);
+            int ic = (int)commands[t];
+            ic = min(max(ic, 0), n_cmd - 1);
+            atomicAdd(&acc_c[ic * d + c], g);
+            if (part_grp) atomicAdd(&acc_g[groups[t] * d + c], g);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_cmd * d; i += 256) part_cmd[(size_t)blockIdx.x * n_cmd * d + i] = acc_c[i];
+    if (part_grp)
+        for (int i = threadIdx.x; i < n_groups * d; i += 256) part_grp[(size_t)blockIdx.x * n_groups * d + i] = acc_g[i];
+}
+
+extern "C" int64_t dsvg_embed_scatter_workspace_bytes(int64_t T_tok, int32_t n_args, int32_t E, int32_t d,
+                                                      int32_t n_cmd, int32_t n_argvals, int32_t n_groups) {
+    const int64_t nb = dsvg_cdiv(T_tok, ES_TOK_PER_BLOCK);
+    return nb * ((int64_t)n_argvals * E + (int64_t)(n_cmd + n_groups) * d) * (int64_t)sizeof(float);
+}
+
+extern "C" int dsvg_embed_scatter(int32_t dtype, const float* commands, const float* args, const int32_t* groups,
+                                  const void* dA, const void* dR, float* d_arg_embed, float* d_command_embed,
+                                  float* d_group_embed, int64_t T_tok, int32_t n_args, int32_t E, int32_t d,
+                                  int32_t n_cmd, int32_t n_argvals, int32_t n_groups, float* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    DSVG_CHECK_ARG(commands && args && dA && dR && d_arg_embed && d_command_embed, "embed_scatter: null pointer");
+    DSVG_CHECK_ARG(!d_group_embed || (groups && n_groups > 0), "embed_scatter: group table needs groups");
+    if (!d_group_embed) n_groups = 0;
+    DSVG_CHECK_ARG(workspace && workspace_bytes >= dsvg_embed_scatter_workspace_bytes(T_tok, n_args, E, d, n_cmd,
+                                                                                     n_argvals, n_groups),
+                   "embed_scatter: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = dsvg_cdiv(T_tok, ES_TOK_PER_BLOCK);
+    const int tab = n_argvals * E;
+    float* part_arg = workspace;
+    float* part_cmd = part_arg + (size_t)nb * tab;
+    float* part_grp = n_groups ? part_cmd + (size_t)nb * n_cmd * d : nullptr;
+    const size_t lds_a = (size_t)tab * sizeof(float);
+    const size_t lds_r = (size_t)(n_cmd + n_groups) * d * sizeof(float);
+    DSVG_CHECK_ARG(lds_a <= 160 * 1024 && lds_r <= 160 * 1024, "embed_scatter: tables too large for LDS");
+    if (dtype == DSVG_F32) {
+        auto ka = embed_scatter_arg_kernel<float>;
+        auto kr = embed_scatter_row_kernel<float>;
+        if (lds_a > 64 * 1024) hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+        if (lds_r > 64 * 1024) hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+        hipLaunchKernelGGL(ka, dim3(nb), dim3(256), lds_a, st, args, (const float*)dA, part_arg, (long long)T_tok, n_args, E, n_argvals);
+        hipLaunchKernelGGL(kr, dim3(nb), dim3(256), lds_r, st, commands, groups, (const float*)dR, part_cmd, part_grp,
+                           (long long)T_tok, d, n_cmd, n_groups);
+    } else if (dtype == DSVG_BF16) {
+        auto ka = embed_scatter_arg_kernel<bf16_t>;
+        auto kr = embed_scatter_row_kernel<bf16_t>;
+        if (lds_a > 64 * 1024) hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+        if (lds_r > 64 * 1024) hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+        hipLaunchKernelGGL(ka, dim3(nb), dim3(256), lds_a, st, args, (const bf16_t*)dA, part_arg, (long long)T_tok, n_args, E, n_argvals);
+        hipLaunchKernelGGL(kr, dim3(nb), dim3(256), lds_r, st, commands, groups, (const bf16_t*)dR, part_cmd, part_grp,
+                           (long long)T_tok, d, n_cmd, n_groups);
+    } else { dsvg_set_error("embed_scatter: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("embed_scatter");
+    int rc = dsvg_reduce_partials_strided(part_arg, nb, tab, tab, d_arg_embed, 0, st);
+    if (rc) return rc;
+    rc = dsvg_reduce_partials_strided(part_cmd, nb, (int64_t)n_cmd * d, (int64_t)n_cmd * d, d_command_embed, 0, st);
+    if (rc) return rc;
+    if (n_groups) rc = dsvg_reduce_partials_strided(part_grp, nb, (int64_t)n_groups * d, (int64_t)n_groups * d, d_group_embed, 0, st);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = drop(x + pos[t % S])      (positional_encoding.py:40-43, model.py:70-73)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void add_pos_fwd_kernel(const T* __restrict__ x, const float* __restrict__ pos, T* __restrict__ y,
+                                   long long n_tok, int S, int d, float drop_p, uint32_t site, const uint64_t* seed) {
+    const DropCtx dc = drop_make(drop_p, seed, site);
+    const int vpr = d / 4;
+    const long long total = n_tok * vpr;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long t = idx / vpr;
+        const int c = 4 * (int)(idx % vpr);
+        const int s = (int)(t % S);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (x) Elem<T>::ld4(x + t * d + c, v);
+        const float4 pe = *reinterpret_cast<const float4*>(pos + (size_t)s * d + c);
+        const uint64_t e = (uint64_t)t * d + c;
+        v[0] = (v[0] + pe.x) * drop_mult(dc, e);
+        v[1] = (v[1] + pe.y) * drop_mult(dc, e + 1);
+        v[2] = (v[2] + pe.z) * drop_mult(dc, e + 2);
+        v[3] = (v[3] + pe.w) * drop_mult(dc, e + 3);
+        Elem<T>::st4(y + t * d + c, v);
+    }
+}
+
+// block = 256 threads owning 256 consecutive columns (blockIdx.y selects the column panel); each block
+// accumulates d_pos[s, c] over its chunk of sequences in registers-per-s via LDS columns it owns.
+constexpr int AP_SEQ_PER_BLOCK = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void add_pos_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx,
+                                                          float* __restrict__ part, long long n_seq, int S, int d,
+                                                          float drop_p, uint32_t site, const uint64_t* seed) {
+    extern __shared__ float acc[];   // [S][256]
+    const DropCtx dc = drop_make(drop_p, seed, site);
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    for (int s = 0; s < S; ++s) acc[s * 256 + threadIdx.x] = 0.f;
+    const long long b0 = (long long)blockIdx.x * AP_SEQ_PER_BLOCK;
+    const long long b1 = min(n_seq, b0 + AP_SEQ_PER_BLOCK);
+    if (c < d) {
+        for (long long b = b0; b < b1; ++b) {
+            for (int s = 0; s < S; ++s) {
+                const long long t = b * S + s;
+                const float g = Elem<T>::ld(dy + t * d + c) * drop_mult(dc, (uint64_t)t * d + c);
+                if (dx) Elem<T>::st(dx + t * d + c, g);
+                acc[s * 256 + threadIdx.x] += g;
+            }
+        }
+        float* dst = part + (size_t)blockIdx.x * S * d;
+        for (int s = 0; s < S; ++s) dst[(size_t)s * d + c] = acc[s * 256 + threadIdx.x];
+    }
+}
+
+extern "C" int dsvg_add_pos_fwd(int32_t dtype, const void* x, const float* pos, void* y, int64_t n_seq, int32_t S,
+                                int32_t d, float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream) {
+    DSVG_CHECK_ARG(pos && y && n_seq > 0 && S > 0 && (d % 4) == 0, "add_pos_fwd: bad args");
+    DSVG_CHECK_ARG(drop_p <= 0.f || seed, "add_pos_fwd: dropout needs a seed pointer");
+    const long long total = n_seq * S * (long long)(d / 4);
+    const int nb = (int)min((long long)dsvg_cdiv(total, 256), 8192LL);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(add_pos_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, pos, (float*)y,
+                           (long long)(n_seq * S), S, d, drop_p, drop_site, seed);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(add_pos_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, pos, (bf16_t*)y,
+                           (long long)(n_seq * S), S, d, drop_p, drop_site, seed);
+    else { dsvg_set_error("add_pos_fwd: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("add_pos_fwd");
+    return 0;
+}
+
+extern "C" int64_t dsvg_add_pos_bwd_workspace_bytes(int64_t n_seq, int32_t S, int32_t d) {
+    return (int64_t)dsvg_cdiv(n_seq, AP_SEQ_PER_BLOCK) * S * d * (int64_t)sizeof(float);
+}
+
+extern "C" int dsvg_add_pos_bwd(int32_t dtype, const void* dy, void* dx, float* d_pos, int32_t accumulate,
+                                int64_t n_seq, int32_t S, int32_t d, float drop_p, uint32_t drop_site,
+                                const uint64_t* seed, float* workspace, int64_t workspace_bytes, void* stream) {
+    DSVG_CHECK_ARG(dy && d_pos && n_seq > 0 && S > 0 && S <= 160 && d > 0, "add_pos_bwd: bad args");
+    DSVG_CHECK_ARG(drop_p <= 0.f || seed, "add_pos_bwd: dropout needs a seed pointer");
+    DSVG_CHECK_ARG(workspace && workspace_bytes >= dsvg_add_pos_bwd_workspace_bytes(n_seq, S, d),
+                   "add_pos_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = dsvg_cdiv(n_seq, AP_SEQ_PER_BLOCK);
+    const size_t lds = (size_t)S * 256 * sizeof(float);
+    dim3 grid(nb, dsvg_cdiv(d, 256));
+    if (dtype == DSVG_F32) {
+        auto k = add_pos_bwd_kernel<float>;
+        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, (const float*)dy, (float*)dx, workspace, (long long)n_seq, S, d,
+                           drop_p, drop_site, seed);
+    } else if (dtype == DSVG_BF16) {
+        auto k = add_pos_bwd_kernel<bf16_t>;
+        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, (const bf16_t*)dy, (bf16_t*)dx, workspace, (long long)n_seq, S,
+                           d, drop_p, drop_site, seed);
+    } else { dsvg_set_error("add_pos_bwd: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("add_pos_bwd");
+    return dsvg_reduce_partials_strided(workspace, nb, (int64_t)S * d, (int64_t)S * d, d_pos, accumulate, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// masked mean over the sequence axis (deepsvg/model/model.py:137,161); one block per sequence
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void masked_mean_fwd_kernel(const T* __restrict__ x, const uint64_t* __restrict__ mask, T* __restrict__ out,
+                                       int S, int d) {
+    const long long b = blockIdx.x;
+    const uint64_t m = mask[b];
+    const float inv = 1.f / (float)__popcll(m);
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < S; ++i)
+            if ((m >> i) & 1ull) s += Elem<T>::ld(x + (b * S + i) * d + c);
+        Elem<T>::st(out + b * d + c, s * inv);
+    }
+}
+template <typename T>
+__global__ void masked_mean_bwd_kernel(const T* __restrict__ dout, const uint64_t* __restrict__ mask,
+                                       T* __restrict__ dx, int S, int d) {
+    const long long b = blockIdx.x;
+    const uint64_t m = mask[b];
+    const float inv = 1.f / (float)__popcll(m);
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        const float g = Elem<T>::ld(dout + b * d + c) * inv;
+        for (int i = 0; i < S; ++i) Elem<T>::st(dx + (b * S + i) * d + c, ((m >> i) & 1ull) ? g : 0.f);
+    }
+}
+extern "C" int dsvg_masked_mean_fwd(int32_t dtype, const void* x, const uint64_t* mask, void* out, int64_t n_seq,
+                                    int32_t S, int32_t d, void* stream) {
+    DSVG_CHECK_ARG(x && mask && out && n_seq > 0 && S > 0 && S <= 64 && d > 0, "masked_mean_fwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(masked_mean_fwd_kernel<float>, dim3((unsigned)n_seq), dim3(256), 0, st, (const float*)x, mask,
+                           (float*)out, S, d);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(masked_mean_fwd_kernel<bf16_t>, dim3((unsigned)n_seq), dim3(256), 0, st, (const bf16_t*)x,
+                           mask, (bf16_t*)out, S, d);
+    else { dsvg_set_error("masked_mean_fwd: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("masked_mean_fwd");
+    return 0;
+}
+extern "C" int dsvg_masked_mean_bwd(int32_t dtype, const void* dout, const uint64_t* mask, void* dx, int64_t n_seq,
+                                    int32_t S, int32_t d, void* stream) {
+    DSVG_CHECK_ARG(dout && mask && dx && n_seq > 0 && S > 0 && S <= 64 && d > 0, "masked_mean_bwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(masked_mean_bwd_kernel<float>, dim3((unsigned)n_seq), dim3(256), 0, st, (const float*)dout,
+                           mask, (float*)dx, S, d);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(masked_mean_bwd_kernel<bf16_t>, dim3((unsigned)n_seq), dim3(256), 0, st, (const bf16_t*)dout,
+                           mask, (bf16_t*)dx, S, d);
+    else { dsvg_set_error("masked_mean_bwd: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("masked_mean_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// x[t] += drop(g[t / S])   (improved_transformer.py:131-136), one block per sequence
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bcast_add_fwd_kernel(T* __restrict__ x, const T* __restrict__ g, int S, int d, float drop_p,
+                                     uint32_t site, const uint64_t* seed) {
+    const DropCtx dc = drop_make(drop_p, seed, site);
+    const long long b = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        const float gv = Elem<T>::ld(g + b * d + c);
+        for (int i = 0; i < S; ++i) {
+            const long long t = b * S + i;
+            T* px = x + t * d + c;
+            Elem<T>::st(px, Elem<T>::ld(px) + gv * drop_mult(dc, (uint64_t)t * d + c));
+        }
+    }
+}
+template <typename T>
+__global__ void bcast_add_bwd_kernel(const T* __restrict__ dx, T* __restrict__ dg, int S, int d, float drop_p,
+                                     uint32_t site, const uint64_t* seed) {
+    const DropCtx dc = drop_make(drop_p, seed, site);
+    const long long b = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < S; ++i) {
+            const long long t = b * S + i;
+            s += Elem<T>::ld(dx + t * d + c) * drop_mult(dc, (uint64_t)t * d + c);
+        }
+        Elem<T>::st(dg + b * d + c, s);
+    }
+}
+extern "C" int dsvg_bcast_add_fwd(int32_t dtype, void* x, const void* g, int64_t n_seq, int32_t S, int32_t d,
+                                  float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream) {
+    DSVG_CHECK_ARG(x && g && n_seq > 0 && S > 0 && d > 0, "bcast_add_fwd: bad args");
+    DSVG_CHECK_ARG(drop_p <= 0.f || seed, "bcast_add_fwd: dropout needs a seed pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(bcast_add_fwd_kernel<float>, dim3((unsigned)n_seq), dim3(256), 0, st, (float*)x,
+                           (const float*)g, S, d, drop_p, drop_site, seed);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(bcast_add_fwd_kernel<bf16_t>, dim3((unsigned)n_seq), dim3(256), 0, st, (bf16_t*)x,
+                           (const bf16_t*)g, S, d, drop_p, drop_site, seed);
+    else { dsvg_set_error("bcast_add_fwd: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("bcast_add_fwd");
+    return 0;
+}
+extern "C" int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64_t n_seq, int32_t S, int32_t d,
+                                  float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream) {
+    DSVG_CHECK_ARG(dx && dg && n_seq > 0 && S > 0 && d > 0, "bcast_add_bwd: bad args");
+    DSVG_CHECK_ARG(drop_p <= 0.f || seed, "bcast_add_bwd: dropout needs a seed pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(bcast_add_bwd_kernel<float>, dim3((unsigned)n_seq), dim3(256), 0, st, (const float*)dx,
+                           (float*)dg, S, d, drop_p, drop_site, seed);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(bcast_add_bwd_kernel<bf16_t>, dim3((unsigned)n_seq), dim3(256), 0, st, (const bf16_t*)dx,
+                           (bf16_t*)dg, S, d, drop_p, drop_site, seed);
+    else { dsvg_set_error("bcast_add_bwd: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("bcast_add_bwd");
+    return 0;
+}

@@ -1,0 +1,372 @@
+// GEMM with fused prologue/epilogue for the DeepSVG hot path (gfx950).
+//   C = epi( sum_k A(m,k) * B(n,k) )
+// fp32 path : v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain), 128x128x32 tiles, LDS
+//             k-major so every operand layout (NT / NN / TN) shares one kernel.
+// bf16 path : see gemm_bf16.hip (v_mfma_f32_32x32x16_bf16).
+// Replaces aten::addmm/mm for every nn.Linear on the path and their autograd matmuls
+// (reference call sites are listed in include/dsvg.h).
+#include "dsvg_common.h"
+#include "../../include/dsvg.h"
+#include "gemm_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// reference kernel: one thread per output element (debug / odd-stride fallback)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void gemm_naive_kernel(dsvg_gemm_desc p, int k_begin, int k_end, float* part) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)p.M * p.N) return;
+    int m = (int)(idx / p.N), n = (int)(idx % p.N);
+    const T* A = (const T*)p.A;
+    const T* B = (const T*)p.B;
+    DropCtx adc = drop_make(p.a_drop_p, p.seed, p.a_drop_site);
+    float acc = 0.f;
+    for (int k = k_begin; k < k_end; ++k) {
+        float a, b;
+        if (p.a_kc) {
+            a = Elem<T>::ld(A + (size_t)m * p.lda + k);
+            a *= drop_mult(adc, (uint64_t)m * p.a_drop_ld + k);
+        } else {
+            a = Elem<T>::ld(A + (size_t)k * p.lda + m);
+            a *= drop_mult(adc, (uint64_t)k * p.a_drop_ld + m);
+        }
+        b = p.b_kc ? Elem<T>::ld(B + (size_t)n * p.ldb + k) : Elem<T>::ld(B + (size_t)k * p.ldb + n);
+        acc = fmaf(a, b, acc);
+    }
+    if (part) {
+        part[(size_t)m * p.N + n] = acc;
+    } else {
+        DropCtx dc = drop_make(p.drop_p, p.seed, p.drop_site);
+        gemm_epilogue<T>(p, dc, m, n, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 MFMA kernel
+//   block 256 threads = 4 waves (2x2), block tile 128x128, wave tile 64x64 = 2x2 MFMA 32x32 tiles
+//   LDS: As[k][m], Bs[k][n] (k-major): fragment reads are lane-contiguous ds_read_b32
+//   operand fragments (guide §3): A: lane l holds A[i=l&31][k=l>>5], B: B[k=l>>5][j=l&31]
+//   C/D: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+// ---------------------------------------------------------------------------------------------
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+
+__device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid) {
+    if (nvalid >= 4) return *reinterpret_cast<const float4*>(p);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nvalid > 0) r.x = p[0];
+    if (nvalid > 1) r.y = p[1];
+    if (nvalid > 2) r.z = p[2];
+    return r;
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
+                                                            int k_chunk, float* part) {
+    constexpr int LDA_S = AKC ? 129 : 132;
+    constexpr int LDB_S = BKC ? 129 : 132;
+    __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
+
+    // XCD-aware tile mapping (bijective): neighbouring column tiles of one row tile share an XCD's L2
+    const int bid = blockIdx.x;
+    const int q = nwg_mn / 8, r8 = nwg_mn % 8;
+    const int xcd = bid % 8, local = bid / 8;
+    const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+    const int tile_m = wgid / tiles_n, tile_n = wgid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kz = blockIdx.y;
+    const int k_begin = kz * k_chunk;
+    const int k_end = min(p.K, k_begin + k_chunk);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const float* A = (const float*)p.A;
+    const float* B = (const float*)p.B;
+    const DropCtx adc = drop_make(p.a_drop_p, p.seed, p.a_drop_site);
+
+    float4 ra[4], rb[4];
+
+    auto load_a = [&](int k0) {
+        if (AKC) {
+            const int c = tid & 7, r = tid >> 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gm = m0 + r + 32 * j, gk = k0 + 4 * c;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gm < p.M && gk < k_end) {
+                    v = ld4_guard(A + (size_t)gm * p.lda + gk, k_end - gk);
+                    if (adc.on) {
+                        const uint64_t e = (uint64_t)gm * p.a_drop_ld + gk;
+                        v.x *= drop_mult(adc, e); v.y *= drop_mult(adc, e + 1);
+                        v.z *= drop_mult(adc, e + 2); v.w *= drop_mult(adc, e + 3);
+                    }
+                }
+                ra[j] = v;
+            }
+        } else {
+            const int c = tid & 31, r = tid >> 5;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gk = k0 + r + 8 * j, gm = m0 + 4 * c;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gk < k_end && gm < p.M) {
+                    v = ld4_guard(A + (size_t)gk * p.lda + gm, p.M - gm);
+                    if (adc.on) {
+                        const uint64_t e = (uint64_t)gk * p.a_drop_ld + gm;
+                        v.x *= drop_mult(adc, e); v.y *= drop_mult(adc, e + 1);
+                        v.z *= drop_mult(adc, e + 2); v.w *= drop_mult(adc, e + 3);
+                    }
+                }
+                ra[j] = v;
+            }
+        }
+    };
+    auto load_b = [&](int k0) {
+        if (BKC) {
+            const int c = tid & 7, r = tid >> 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gn = n0 + r + 32 * j, gk = k0 + 4 * c;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gn < p.N && gk < k_end) v = ld4_guard(B + (size_t)gn * p.ldb + gk, k_end - gk);
+                rb[j] = v;
+            }
+        } else {
+            const int c = tid & 31, r = tid >> 5;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gk = k0 + r + 8 * j, gn = n0 + 4 * c;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gk < k_end && gn < p.N) v = ld4_guard(B + (size_t)gk * p.ldb + gn, p.N - gn);
+                rb[j] = v;
+            }
+        }
+    };
+    auto store_lds = [&]() {
+        if (AKC) {
+            const int c = tid & 7, r = tid >> 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = r + 32 * j;
+                As[(4 * c + 0) * LDA_S + m] = ra[j].x;
+                As[(4 * c + 1) * LDA_S + m] = ra[j].y;
+                As[(4 * c + 2) * LDA_S + m] = ra[j].z;
+                As[(4 * c + 3) * LDA_S + m] = ra[j].w;
+            }
+        } else {
+            const int c = tid & 31, r = tid >> 5;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(&As[(r + 8 * j) * LDA_S + 4 * c]) = ra[j];
+        }
+        if (BKC) {
+            const int c = tid & 7, r = tid >> 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = r + 32 * j;
+                Bs[(4 * c + 0) * LDB_S + n] = rb[j].x;
+                Bs[(4 * c + 1) * LDB_S + n] = rb[j].y;
+                Bs[(4 * c + 2) * LDB_S + n] = rb[j].z;
+                Bs[(4 * c + 3) * LDB_S + n] = rb[j].w;
+            }
+        } else {
+            const int c = tid & 31, r = tid >> 5;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(&Bs[(r + 8 * j) * LDB_S + 4 * c]) = rb[j];
+        }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (k_begin < k_end) {
+        load_a(k_begin);
+        load_b(k_begin);
+    }
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        store_lds();
+        __syncthreads();
+        if (k0 + BK < k_end) {  // register prefetch of the next K tile, overlapped with the MFMAs
+            load_a(k0 + BK);
+            load_b(k0 + BK);
+        }
+        const int arow = wm * 64 + (lane & 31);
+        const int bcol = wn * 64 + (lane & 31);
+        const int kh = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int k = 2 * kk + kh;
+            const float a0 = As[k * LDA_S + arow], a1 = As[k * LDA_S + arow + 32];
+            const float b0 = Bs[k * LDB_S + bcol], b1 = Bs[k * LDB_S + bcol + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const DropCtx dc = drop_make(p.drop_p, p.seed, p.drop_site);
+    float* my_part = part ? part + (size_t)kz * p.M * p.N : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+                if (m < p.M && n < p.N) {
+                    if (my_part) my_part[(size_t)m * p.N + n] = acc[i][j][r];
+                    else gemm_epilogue<float>(p, dc, m, n, acc[i][j][r]);
+                }
+            }
+}
+
+// ---------------------------------------------------------------------------------------------
+// deterministic reductions
+// ---------------------------------------------------------------------------------------------
+__global__ void reduce_partials_strided_kernel(const float* __restrict__ part, long long P, long long stride,
+                                               long long n, float* __restrict__ out, int accumulate) {
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float s = accumulate ? out[j] : 0.f;
+    for (long long q = 0; q < P; ++q) s += part[q * stride + j];
+    out[j] = s;
+}
+
+int dsvg_reduce_partials_strided(const float* part, int64_t P, int64_t stride, int64_t n, float* out,
+                                 int32_t accumulate, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3(dsvg_cdiv(n, 256)), dim3(256), 0, st, part, (long long)P,
+                       (long long)stride, (long long)n, out, accumulate);
+    DSVG_LAUNCH_CHECK("reduce_partials");
+    return 0;
+}
+
+// column sums of a [M, N] matrix (bias gradients): block handles ROWS_PER_BLOCK rows, thread owns columns
+constexpr int CS_ROWS = 256;
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ A, long long lda, long long M, int N,
+                              float* __restrict__ part, float drop_p, uint32_t site, const uint64_t* seed) {
+    const DropCtx dc = drop_make(drop_p, seed, site);
+    const long long r0 = (long long)blockIdx.x * CS_ROWS;
+    const long long r1 = min(M, r0 + CS_ROWS);
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+        float s = 0.f;
+        for (long long r = r0; r < r1; ++r)
+            s += Elem<T>::ld(A + r * lda + c) * drop_mult(dc, (uint64_t)r * N + c);
+        part[(long long)blockIdx.x * N + c] = s;
+    }
+}
+
+extern "C" int64_t dsvg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
+    if (split_k <= 1) return 0;
+    return (int64_t)split_k * M * N * (int64_t)sizeof(float);
+}
+
+extern "C" int dsvg_reduce_partials(const float* partial, int64_t P, int64_t n, float* out,
+                                    int32_t accumulate, void* stream) {
+    DSVG_CHECK_ARG(partial && out && P >= 0 && n >= 0, "reduce_partials: bad args");
+    return dsvg_reduce_partials_strided(partial, P, n, n, out, accumulate, (hipStream_t)stream);
+}
+
+extern "C" int64_t dsvg_colsum_workspace_bytes(int64_t M, int32_t N) {
+    return (int64_t)dsvg_cdiv(M, CS_ROWS) * N * (int64_t)sizeof(float);
+}
+
+extern "C" int dsvg_colsum(int32_t dtype, const void* A, int64_t lda, int64_t M, int32_t N, float* out,
+                           int32_t accumulate, float drop_p, uint32_t drop_site, const uint64_t* seed,
+                           float* workspace, int64_t workspace_bytes, void* stream) {
+    DSVG_CHECK_ARG(A && out && M > 0 && N > 0, "colsum: bad args");
+    DSVG_CHECK_ARG(workspace && workspace_bytes >= dsvg_colsum_workspace_bytes(M, N),
+                   "colsum: workspace too small (%lld < %lld)", (long long)workspace_bytes,
+                   (long long)dsvg_colsum_workspace_bytes(M, N));
+    const int nb = dsvg_cdiv(M, CS_ROWS);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)A, (long long)lda,
+                           (long long)M, N, workspace, drop_p, drop_site, seed);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)A, (long long)lda,
+                           (long long)M, N, workspace, drop_p, drop_site, seed);
+    else { dsvg_set_error("colsum: bad dtype %d", dtype); return -1; }
+    DSVG_LAUNCH_CHECK("colsum");
+    return dsvg_reduce_partials(workspace, nb, N, out, accumulate, stream);
+}
+
+int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, float* part, hipStream_t st);  // gemm_bf16.hip
+
+extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
+    DSVG_CHECK_ARG(dp, "gemm: null desc");
+    dsvg_gemm_desc d = *dp;
+    hipStream_t st = (hipStream_t)stream;
+    DSVG_CHECK_ARG(d.dtype == DSVG_F32 || d.dtype == DSVG_BF16, "gemm: bad dtype %d", d.dtype);
+    DSVG_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "gemm: bad shape %d %d %d", d.M, d.N, d.K);
+    DSVG_CHECK_ARG(d.A && d.B && d.C, "gemm: null operand");
+    DSVG_CHECK_ARG((d.drop_p <= 0.f && d.a_drop_p <= 0.f) || d.seed, "gemm: dropout needs a seed pointer");
+    if (d.dtype == DSVG_F32) d.c_f32 = 1;
+    const int split = d.split_k > 1 ? d.split_k : 1;
+    float* part = nullptr;
+    int k_chunk = d.K;
+    if (split > 1) {
+        DSVG_CHECK_ARG(d.c_f32, "gemm: split_k needs fp32 output");
+        DSVG_CHECK_ARG(!d.bias && !d.res && !d.gate && d.act == 0 && d.drop_p <= 0.f,
+                       "gemm: split_k does not support an epilogue");
+        DSVG_CHECK_ARG(d.workspace && d.workspace_bytes >= dsvg_gemm_workspace_bytes(d.M, d.N, split),
+                       "gemm: split_k workspace too small");
+        DSVG_CHECK_ARG(d.ldc == d.N, "gemm: split_k needs a dense C (ldc == N)");
+        part = d.workspace;
+        k_chunk = ((d.K + split - 1) / split + 63) / 64 * 64;
+    }
+    const int nsplit = (d.K + k_chunk - 1) / k_chunk;
+
+    bool use_naive = d.impl == 1;
+    if (d.dtype == DSVG_F32) {
+        // the MFMA kernel needs 16-byte aligned rows
+        if ((d.lda & 3) || (d.ldb & 3) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) use_naive = true;
+    } else {
+        if ((d.lda & 7) || (d.ldb & 7) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15) || (d.K & 7)) use_naive = true;
+        if (!d.a_kc && d.lda < ((d.M + 7) / 8) * 8) use_naive = true;
+        if (!d.b_kc && d.ldb < ((d.N + 7) / 8) * 8) use_naive = true;
+    }
+    if (use_naive) {
+        const long long total = (long long)d.M * d.N;
+        for (int z = 0; z < nsplit; ++z) {
+            const int kb = z * k_chunk, ke = min(d.K, kb + k_chunk);
+            float* pz = part ? part + (size_t)z * d.M * d.N : nullptr;
+            if (d.dtype == DSVG_F32)
+                hipLaunchKernelGGL(gemm_naive_kernel<float>, dim3(dsvg_cdiv(total, 256)), dim3(256), 0, st, d, kb, ke, pz);
+            else
+                hipLaunchKernelGGL(gemm_naive_kernel<bf16_t>, dim3(dsvg_cdiv(total, 256)), dim3(256), 0, st, d, kb, ke, pz);
+        }
+        DSVG_LAUNCH_CHECK("gemm_naive");
+    } else if (d.dtype == DSVG_F32) {
+        const int tiles_m = dsvg_cdiv(d.M, BM), tiles_n = dsvg_cdiv(d.N, BN);
+        const int nwg = tiles_m * tiles_n;
+        dim3 grid(nwg, nsplit);
+        if (d.a_kc && d.b_kc)
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
+        else if (d.a_kc && !d.b_kc)
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, false>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
+        else if (!d.a_kc && d.b_kc)
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
+        else
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
+        DSVG_LAUNCH_CHECK("gemm_f32_mfma");
+    } else {
+        int rc = dsvg_gemm_bf16_launch(d, k_chunk, part, st);
+        if (rc) return rc;
+    }
+    if (part) return dsvg_reduce_partials(part, nsplit, (int64_t)d.M * d.N, (float*)d.C, d.accumulate, stream);
+    return 0;
+}

@@ -1,0 +1,203 @@
+// LayerNorm forward / backward over rows of d features (d % 4 == 0, d <= 1024), one 64-lane wave per
+// row, 4 rows per 256-thread block, grid-stride over rows.  HBM-bound: every element is read once with
+// 16-byte (fp32) / 8-byte (bf16) lane accesses and kept in registers between the two passes.
+// Replaces torch.nn.LayerNorm at deepsvg/model/layers/improved_transformer.py:43,51,127,138 and
+// deepsvg/model/layers/transformer.py:185-186,239-240, plus native_layer_norm_backward.
+#include "dsvg_common.h"
+#include "../../include/dsvg.h"
+
+constexpr int LN_MAXV = 4;            // 4 x (64 lanes x 4 elements) = 1024 features max
+constexpr int LN_MAX_BLOCKS = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     long long rows, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nv = d / 256 + ((d % 256) ? 1 : 0);
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+        const T* xr = x + row * d;
+        float v[LN_MAXV][4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = i * 256 + lane * 4;
+            if (i < nv && c < d) {
+                Elem<T>::ld4(xr + c, v[i]);
+                s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            } else {
+                v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+            }
+        }
+        const float mu = wave_sum(s) / (float)d;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = i * 256 + lane * 4;
+            if (i < nv && c < d) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float t = v[i][e] - mu; s2 += t * t; }
+            }
+        }
+        const float var = wave_sum(s2) / (float)d;
+        const float rs = rsqrtf(var + eps);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        T* yr = y + row * d;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = i * 256 + lane * 4;
+            if (i < nv && c < d) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+                const float4 b = *reinterpret_cast<const float4*>(beta + c);
+                float o[4];
+                o[0] = (v[i][0] - mu) * rs * g.x + b.x;
+                o[1] = (v[i][1] - mu) * rs * g.y + b.y;
+                o[2] = (v[i][2] - mu) * rs * g.z + b.z;
+                o[3] = (v[i][3] - mu) * rs * g.w + b.w;
+                Elem<T>::st4(yr + c, o);
+            }
+        }
+    }
+}
+
+// dx = [res +] rstd * (g*dy - mean_d(g*dy) - xhat * mean_d(g*dy*xhat))
+// dgamma/dbeta: per-wave register accumulation over the wave's rows, combined per block in LDS, one
+// partial row per block -> workspace [gridDim.x][2][d]; reduced by dsvg_reduce_partials.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const T* res,
+                                                     T* dx, float* __restrict__ part,
+                                                     long long rows, int d) {
+    __shared__ float red[4][2][1024 / 4 + 1][4];  // [wave][dg/db][vec][elem]  (padded)
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nv = d / 256 + ((d % 256) ? 1 : 0);
+    float ag[LN_MAXV][4], ab[LN_MAXV][4];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; }
+
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[LN_MAXV][4], gd[LN_MAXV][4];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = i * 256 + lane * 4;
+            if (i < nv && c < d) {
+                float xv[4], dv[4];
+                Elem<T>::ld4(x + row * d + c, xv);
+                Elem<T>::ld4(dy + row * d + c, dv);
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+                const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xv[e] - mu) * rs;
+                    gd[i][e] = gg[e] * dv[e];
+                    c1 += gd[i][e];
+                    c2 += gd[i][e] * xh[i][e];
+                    ag[i][e] += dv[e] * xh[i][e];
+                    ab[i][e] += dv[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xh[i][e] = 0.f; gd[i][e] = 0.f; }
+            }
+        }
+        c1 = wave_sum(c1) / (float)d;
+        c2 = wave_sum(c2) / (float)d;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = i * 256 + lane * 4;
+            if (i < nv && c < d) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (gd[i][e] - c1 - xh[i][e] * c2);
+                if (res) {
+                    float rv[4];
+                    Elem<T>::ld4(res + row * d + c, rv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += rv[e];
+                }
+                Elem<T>::st4(dx + row * d + c, o);
+            }
+        }
+    }
+    // block combine of the parameter-gradient partials
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        if (i < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[wave][0][i * 64 + lane][e] = ag[i][e];
+                red[wave][1][i * 64 + lane][e] = ab[i][e];
+            }
+        }
+    }
+    __syncthreads();
+    float* pg = part + (size_t)blockIdx.x * 2 * d;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        const int vec = c >> 2, e = c & 3;
+        float sg = 0.f, sb = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { sg += red[w][0][vec][e]; sb += red[w][1][vec][e]; }
+        pg[c] = sg;
+        pg[d + c] = sb;
+    }
+}
+
+static int ln_grid(long long rows) {
+    long long nb = (rows + 3) / 4;
+    return (int)(nb < LN_MAX_BLOCKS ? nb : LN_MAX_BLOCKS);
+}
+
+extern "C" int dsvg_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y,
+                                  float* mean, float* rstd, int64_t rows, int32_t d, float eps, void* stream) {
+    DSVG_CHECK_ARG(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+    DSVG_CHECK_ARG(rows > 0 && d > 0 && (d % 4) == 0 && d <= 1024, "layernorm_fwd: bad shape rows=%lld d=%d",
+                   (long long)rows, d);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(ln_grid(rows)), dim3(256), 0, st, (const float*)x, gamma, beta,
+                           (float*)y, mean, rstd, (long long)rows, d, eps);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(ln_grid(rows)), dim3(256), 0, st, (const bf16_t*)x, gamma, beta,
+                           (bf16_t*)y, mean, rstd, (long long)rows, d, eps);
+    else { dsvg_set_error("layernorm_fwd: bad dtype %d", dtype); return -1; }
+    DSVG_LAUNCH_CHECK("layernorm_fwd");
+    return 0;
+}
+
+extern "C" int64_t dsvg_layernorm_bwd_workspace_bytes(int64_t rows, int32_t d) {
+    return (int64_t)ln_grid(rows) * 2 * d * (int64_t)sizeof(float);
+}
+
+extern "C" int dsvg_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* mean, const float* rstd,
+                                  const float* gamma, const void* res, void* dx, float* dgamma, float* dbeta,
+                                  int32_t accumulate, int64_t rows, int32_t d, float* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    DSVG_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
+    DSVG_CHECK_ARG(rows > 0 && d > 0 && (d % 4) == 0 && d <= 1024, "layernorm_bwd: bad shape");
+    DSVG_CHECK_ARG(workspace && workspace_bytes >= dsvg_layernorm_bwd_workspace_bytes(rows, d),
+                   "layernorm_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ln_grid(rows);
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dy, (const float*)x, mean,
+                           rstd, gamma, (const float*)res, (float*)dx, workspace, (long long)rows, d);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean,
+                           rstd, gamma, (const bf16_t*)res, (bf16_t*)dx, workspace, (long long)rows, d);
+    else { dsvg_set_error("layernorm_bwd: bad dtype %d", dtype); return -1; }
+    DSVG_LAUNCH_CHECK("layernorm_bwd");
+    // workspace rows are [dgamma(d) | dbeta(d)]: two strided deterministic reductions
+    int rc = 0;
+    rc = dsvg_reduce_partials_strided(workspace, nb, 2 * (int64_t)d, d, dgamma, accumulate, st);
+    if (rc) return rc;
+    rc = dsvg_reduce_partials_strided(workspace + d, nb, 2 * (int64_t)d, d, dbeta, accumulate, st);
+    return rc;
+}

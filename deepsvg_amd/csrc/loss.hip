@@ -1,0 +1,180 @@
+// SVGLoss pieces (deepsvg/model/loss.py:19-65): target/mask construction and a masked cross-entropy
+// that never gathers rows (the reference uses boolean-mask indexing = dynamic shapes + host syncs).
+// One 64-lane wave per logits row; rows with weight 0 are skipped entirely in the forward pass, so only
+// the ~15-20 % of args_logits rows enabled by CMD_ARGS_MASK are ever read.
+#include "dsvg_common.h"
+#include "../../include/dsvg.h"
+
+// ---------------------------------------------------------------------------------------------
+// targets and weights.  tgt_commands [n_seq, S1], tgt_args [n_seq, S1, n_args], S = S1 - 1.
+//   pm[s]  = no EOS at positions <= s                                   (model/utils.py:22-23)
+//   ext[s] = min(1, pm[s] + pm[s-3])   (canonical, non-aliased reading of model/utils.py:25-28)
+//   vis    = (#EOS < S1 - 1)                                            (model/utils.py:51)
+//   cmd_w[s'] = ext[s'+1] * vis, cmd_tgt[s'] = cmd[s'+1]                (loss.py:35-36,49,53)
+//   arg_w[s',a] = CMD_ARGS_MASK[cmd[s'+1], a], arg_tgt = arg[s'+1,a]+1  (loss.py:51,54)
+// ---------------------------------------------------------------------------------------------
+__global__ void loss_targets_kernel(const float* __restrict__ tc, const float* __restrict__ ta,
+                                    const float* __restrict__ cam, long long n_seq, int S1, int n_args, int n_cmd,
+                                    int eos, int* __restrict__ cmd_tgt, float* __restrict__ cmd_w,
+                                    int* __restrict__ arg_tgt, float* __restrict__ arg_w, int* __restrict__ vis_tgt) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_seq) return;
+    const int S = S1 - 1;
+    const float* row = tc + b * S1;
+    uint64_t pm = 0;   // S1 <= 64
+    int n_eos = 0;
+    bool seen = false;
+    for (int s = 0; s < S1; ++s) {
+        const bool e = ((int)row[s] == eos);
+        seen |= e;
+        n_eos += e;
+        if (!seen) pm |= (1ull << s);
+    }
+    const uint64_t ext = pm | (pm << 3);
+    const int vis = (n_eos < S1 - 1) ? 1 : 0;
+    vis_tgt[b] = vis;
+    for (int s = 0; s < S; ++s) {
+        int c = (int)row[s + 1];
+        c = min(max(c, 0), n_cmd - 1);
+        cmd_tgt[b * S + s] = c;
+        cmd_w[b * S + s] = (((ext >> (s + 1)) & 1ull) && vis) ? 1.f : 0.f;
+        for (int a = 0; a < n_args; ++a) {
+            arg_tgt[(b * S + s) * n_args + a] = (int)ta[(b * S1 + s + 1) * n_args + a] + 1;
+            arg_w[(b * S + s) * n_args + a] = cam[c * n_args + a];
+        }
+    }
+}
+
+extern "C" int dsvg_loss_targets(const float* tgt_commands, const float* tgt_args, const float* cmd_args_mask,
+                                 int64_t n_seq, int32_t S1, int32_t n_args, int32_t n_cmd, int32_t eos_id,
+                                 int32_t* cmd_tgt, float* cmd_w, int32_t* arg_tgt, float* arg_w, int32_t* vis_tgt,
+                                 void* stream) {
+    DSVG_CHECK_ARG(tgt_commands && tgt_args && cmd_args_mask && cmd_tgt && cmd_w && arg_tgt && arg_w && vis_tgt,
+                   "loss_targets: null pointer");
+    DSVG_CHECK_ARG(n_seq > 0 && S1 > 1 && S1 <= 61, "loss_targets: bad shape (S1=%d)", S1);
+    hipLaunchKernelGGL(loss_targets_kernel, dim3(dsvg_cdiv(n_seq, 64)), dim3(64), 0, (hipStream_t)stream, tgt_commands,
+                       tgt_args, cmd_args_mask, (long long)n_seq, S1, n_args, n_cmd, eos_id, cmd_tgt, cmd_w, arg_tgt,
+                       arg_w, vis_tgt);
+    DSVG_LAUNCH_CHECK("loss_targets");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// masked CE.  Row r of the logical [rows, C] matrix lives at logits + (r / group) * ld + (r % group) * C
+// (group = 11 arg slots per token for args_logits, 1 otherwise).
+// ---------------------------------------------------------------------------------------------
+constexpr int CE_MAX_BLOCKS = 2048;
+
+template <typename T>
+__global__ __launch_bounds__(256) void masked_ce_fwd_kernel(const T* __restrict__ logits, long long ld, int group,
+                                                            const int* __restrict__ target, const float* __restrict__ w,
+                                                            long long rows, int C, float* __restrict__ lse,
+                                                            float* __restrict__ part) {
+    __shared__ float red[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc_l = 0.f, acc_w = 0.f;
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
+        const float wr = w ? w[r] : 1.f;
+        if (wr == 0.f) { if (lane == 0) lse[r] = 0.f; continue; }
+        const T* p = logits + (r / group) * ld + (r % group) * (long long)C;
+        float m = -INFINITY;
+        for (int c = lane; c < C; c += 64) m = fmaxf(m, Elem<T>::ld(p + c));
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += __expf(Elem<T>::ld(p + c) - m);
+        s = wave_sum(s);
+        const float l = m + __logf(s);
+        if (lane == 0) {
+            lse[r] = l;
+            int t = target[r];
+            t = min(max(t, 0), C - 1);
+            acc_l += wr * (l - Elem<T>::ld(p + t));
+            acc_w += wr;
+        }
+    }
+    if (lane == 0) { red[wave][0] = acc_l; red[wave][1] = acc_w; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2 + 0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        part[blockIdx.x * 2 + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const T* __restrict__ logits, long long ld, int group,
+                                                            const int* __restrict__ target, const float* __restrict__ w,
+                                                            const float* __restrict__ lse,
+                                                            const float* __restrict__ sum_count,
+                                                            const float* __restrict__ gscale, float coef,
+                                                            T* __restrict__ dlogits, long long ld_d, long long rows,
+                                                            int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float g = coef * (gscale ? *gscale : 1.f) / sum_count[1];
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
+        const float wr = w ? w[r] : 1.f;
+        const long long tok = r / group;
+        const int slot = (int)(r % group);
+        T* q = dlogits + tok * ld_d + slot * (long long)C;
+        if (wr == 0.f) {
+            for (int c = lane; c < C; c += 64) Elem<T>::st(q + c, 0.f);
+        } else {
+            const T* p = logits + tok * ld + slot * (long long)C;
+            const float l = lse[r];
+            int t = target[r];
+            t = min(max(t, 0), C - 1);
+            for (int c = lane; c < C; c += 64) {
+                const float sm = __expf(Elem<T>::ld(p + c) - l);
+                Elem<T>::st(q + c, wr * g * (sm - (c == t ? 1.f : 0.f)));
+            }
+        }
+        if (slot == group - 1) {   // zero the row padding so padded-K GEMMs read zeros
+            for (long long c = (long long)group * C + lane; c < ld_d; c += 64) Elem<T>::st(dlogits + tok * ld_d + c, 0.f);
+        }
+    }
+}
+
+static int ce_grid(long long rows) {
+    long long nb = (rows + 3) / 4;
+    return (int)(nb < CE_MAX_BLOCKS ? nb : CE_MAX_BLOCKS);
+}
+
+extern "C" int64_t dsvg_masked_ce_workspace_bytes(int64_t rows) { return (int64_t)ce_grid(rows) * 2 * sizeof(float); }
+
+extern "C" int dsvg_masked_ce_fwd(int32_t dtype, const void* logits, int64_t ld, int32_t group, const int32_t* target,
+                                  const float* w, int64_t rows, int32_t C, float* lse, float* sum_count,
+                                  float* workspace, int64_t workspace_bytes, void* stream) {
+    DSVG_CHECK_ARG(logits && target && lse && sum_count && rows > 0 && C > 0 && group > 0, "masked_ce_fwd: bad args");
+    DSVG_CHECK_ARG(workspace && workspace_bytes >= dsvg_masked_ce_workspace_bytes(rows), "masked_ce_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ce_grid(rows);
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(masked_ce_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)logits, (long long)ld,
+                           group, target, w, (long long)rows, C, lse, workspace);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(masked_ce_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)logits,
+                           (long long)ld, group, target, w, (long long)rows, C, lse, workspace);
+    else { dsvg_set_error("masked_ce_fwd: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("masked_ce_fwd");
+    return dsvg_reduce_partials_strided(workspace, nb, 2, 2, sum_count, 0, st);
+}
+
+extern "C" int dsvg_masked_ce_bwd(int32_t dtype, const void* logits, int64_t ld, int32_t group, const int32_t* target,
+                                  const float* w, const float* lse, const float* sum_count, const float* gscale,
+                                  float coef, void* dlogits, int64_t ld_d, int64_t rows, int32_t C, void* stream) {
+    DSVG_CHECK_ARG(logits && target && lse && sum_count && dlogits && rows > 0 && C > 0 && group > 0,
+                   "masked_ce_bwd: bad args");
+    DSVG_CHECK_ARG(ld_d >= (int64_t)group * C, "masked_ce_bwd: ld_d too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ce_grid(rows);
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(masked_ce_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)logits, (long long)ld,
+                           group, target, w, lse, sum_count, gscale, coef, (float*)dlogits, (long long)ld_d,
+                           (long long)rows, C);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(masked_ce_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)logits,
+                           (long long)ld, group, target, w, lse, sum_count, gscale, coef, (bf16_t*)dlogits,
+                           (long long)ld_d, (long long)rows, C);
+    else { dsvg_set_error("masked_ce_bwd: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("masked_ce_bwd");
+    return 0;
+}

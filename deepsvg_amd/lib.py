@@ -1,0 +1,108 @@
+"""ctypes binding of libdsvg_hip.so (the C ABI declared in include/dsvg.h).
+
+The product path has no CPU fallback: if the shared library is missing or a tensor is not on a HIP
+device, the ops raise.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"``
+(or ``deepsvg_amd/csrc/build.sh``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libdsvg_hip.so")
+
+DSVG_F32 = 0
+DSVG_BF16 = 1
+
+c_i32, c_i64, c_u32, c_f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_float
+vp = C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    """mirror of ``dsvg_gemm_desc`` (include/dsvg.h)"""
+    _fields_ = [
+        ("dtype", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
+        ("A", vp), ("lda", c_i64), ("a_kc", c_i32),
+        ("B", vp), ("ldb", c_i64), ("b_kc", c_i32),
+        ("C", vp), ("ldc", c_i64), ("c_f32", c_i32),
+        ("bias", vp),
+        ("res", vp), ("ldres", c_i64), ("res_pre", c_i32),
+        ("act", c_i32),
+        ("gate", vp), ("ldgate", c_i64), ("gate_scale", c_f32),
+        ("drop_p", c_f32), ("drop_site", c_u32),
+        ("a_drop_p", c_f32), ("a_drop_site", c_u32), ("a_drop_ld", c_i64),
+        ("seed", vp),
+        ("accumulate", c_i32),
+        ("split_k", c_i32), ("workspace", vp), ("workspace_bytes", c_i64),
+        ("impl", c_i32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/dsvg.h
+SIGNATURES = {
+    "dsvg_last_error": (C.c_char_p, []),
+    "dsvg_version": (c_i32, []),
+    "dsvg_gemm": (c_i32, [C.POINTER(GemmDesc), vp]),
+    "dsvg_gemm_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "dsvg_reduce_partials": (c_i32, [vp, c_i64, c_i64, vp, c_i32, vp]),
+    "dsvg_colsum": (c_i32, [c_i32, vp, c_i64, c_i64, c_i32, vp, c_i32, c_f32, c_u32, vp, vp, c_i64, vp]),
+    "dsvg_colsum_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "dsvg_layernorm_fwd": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_f32, vp]),
+    "dsvg_layernorm_bwd": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i32, c_i64, c_i32, vp, c_i64, vp]),
+    "dsvg_layernorm_bwd_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "dsvg_attention_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
+    "dsvg_attention_bwd": (c_i32, [c_i32, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
+    "dsvg_build_masks": (c_i32, [vp, c_i64, c_i32, c_i32, c_i32, vp, vp, vp, vp]),
+    "dsvg_embed_gather": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, vp]),
+    "dsvg_embed_scatter": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                   c_i32, vp, c_i64, vp]),
+    "dsvg_embed_scatter_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "dsvg_group_index": (c_i32, [vp, c_i64, c_i32, c_i32, vp, vp]),
+    "dsvg_add_pos_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_u32, vp, vp]),
+    "dsvg_add_pos_bwd": (c_i32, [c_i32, vp, vp, vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_u32, vp, vp, c_i64, vp]),
+    "dsvg_add_pos_bwd_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32]),
+    "dsvg_masked_mean_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, vp]),
+    "dsvg_masked_mean_bwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, vp]),
+    "dsvg_bcast_add_fwd": (c_i32, [c_i32, vp, vp, c_i64, c_i32, c_i32, c_f32, c_u32, vp, vp]),
+    "dsvg_bcast_add_bwd": (c_i32, [c_i32, vp, vp, c_i64, c_i32, c_i32, c_f32, c_u32, vp, vp]),
+    "dsvg_loss_targets": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, vp]),
+    "dsvg_masked_ce_fwd": (c_i32, [c_i32, vp, c_i64, c_i32, vp, vp, c_i64, c_i32, vp, vp, vp, c_i64, vp]),
+    "dsvg_masked_ce_workspace_bytes": (c_i64, [c_i64]),
+    "dsvg_masked_ce_bwd": (c_i32, [c_i32, vp, c_i64, c_i32, vp, vp, vp, vp, vp, c_f32, vp, c_i64, c_i64, c_i32, vp]),
+    "dsvg_sumsq": (c_i32, [vp, c_i64, vp, vp, c_i64, vp]),
+    "dsvg_sumsq_workspace_bytes": (c_i64, [c_i64]),
+    "dsvg_adamw_step": (c_i32, [vp, vp, vp, vp, c_i64, vp, c_f32, c_f32, c_f32, c_f32, vp, vp, c_f32, c_f32, vp]),
+    "dsvg_cast_weights": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i64, vp]),
+    "dsvg_advance_step": (c_i32, [vp, vp, vp]),
+    "dsvg_gate_mul": (c_i32, [c_i32, vp, vp, vp, c_i64, c_f32, vp]),
+    "dsvg_probe_trread": (c_i32, [vp, vp, vp]),
+}
+
+_lib = None
+
+
+class DsvgError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and attach the signatures.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DsvgError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c \"import __graft_entry__ as g; "
+            f"g.build()\"` (needs hipcc); there is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().dsvg_last_error()
+        raise DsvgError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,442 @@
+"""Tensor-level wrappers over the C ABI (include/dsvg.h).  PyTorch is used for device memory and streams
+only: every op takes/returns torch tensors that live on a HIP device and enqueues hand-written gfx950
+kernels on the current stream.  No op has a CPU or aten fallback.
+"""
+import ctypes as C
+import torch
+
+from . import lib as _l
+
+F32, BF16 = _l.DSVG_F32, _l.DSVG_BF16
+RELU = 1
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise _l.DsvgError(f"unsupported dtype {t.dtype}")
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _l.DsvgError("deepsvg_amd ops need HIP device tensors (no CPU fallback)")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 4) // 4 + 1, dtype=torch.float32, device=device)
+
+
+def _rowmajor(t):
+    assert t.dim() == 2 and t.stride(1) == 1, f"need a row-major 2-D tensor, got strides {t.stride()}"
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=0, gate=None, gate_scale=1.0,
+         drop_p=0.0, drop_site=0, a_drop_p=0.0, a_drop_site=0, seed=None, out=None, out_dtype=None,
+         accumulate=False, split_k=1, impl=0):
+    """C[M,N] = epi(sum_k A(m,k) B(n,k)).  a: [M,K] if a_kc else [K,M]; b: [N,K] if b_kc else [K,N]."""
+    _chk(a, b, bias, res, gate, seed, out)
+    _rowmajor(a), _rowmajor(b)
+    assert a.dtype == b.dtype
+    M, K = (a.shape if a_kc else (a.shape[1], a.shape[0]))
+    N, Kb = (b.shape if b_kc else (b.shape[1], b.shape[0]))
+    assert K == Kb, f"gemm: inner dims differ ({K} vs {Kb})"
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)
+    _rowmajor(out)
+    assert tuple(out.shape) == (M, N)
+    assert out.dtype in (a.dtype, torch.float32)
+    d = _l.GemmDesc()
+    d.dtype = _dt(a)
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda, d.a_kc = a.data_ptr(), a.stride(0), int(a_kc)
+    d.B, d.ldb, d.b_kc = b.data_ptr(), b.stride(0), int(b_kc)
+    d.C, d.ldc, d.c_f32 = out.data_ptr(), out.stride(0), int(out.dtype == torch.float32)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+        d.bias = bias.data_ptr()
+    if res is not None:
+        _rowmajor(res)
+        assert res.dtype == a.dtype and tuple(res.shape) == (M, N)
+        d.res, d.ldres, d.res_pre = res.data_ptr(), res.stride(0), int(res_pre)
+    d.act = act
+    if gate is not None:
+        _rowmajor(gate)
+        assert gate.dtype == a.dtype and tuple(gate.shape) == (M, N)
+        d.gate, d.ldgate, d.gate_scale = gate.data_ptr(), gate.stride(0), float(gate_scale)
+    d.drop_p, d.drop_site = float(drop_p), int(drop_site)
+    d.a_drop_p, d.a_drop_site, d.a_drop_ld = float(a_drop_p), int(a_drop_site), a.shape[1]
+    if drop_p > 0 or a_drop_p > 0:
+        assert seed is not None and seed.dtype == torch.int64
+        d.seed = seed.data_ptr()
+    d.accumulate = int(accumulate)
+    d.impl = impl
+    ws = None
+    if split_k > 1:
+        assert out.dtype == torch.float32 and out.is_contiguous()
+        nbytes = _l.load().dsvg_gemm_workspace_bytes(M, N, split_k)
+        ws = _ws(nbytes, a.device)
+        d.split_k, d.workspace, d.workspace_bytes = split_k, ws.data_ptr(), ws.numel() * 4
+    _l.check(_l.load().dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
+    return out
+
+
+def split_k_for(M, N, K, target_blocks=768):
+    """split factor for the weight-gradient GEMMs (small M x N output, K = #tokens)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    s = max(1, target_blocks // tiles)
+    s = min(s, max(1, K // 256))
+    return s
+
+
+def colsum(a, *, out=None, accumulate=False, drop_p=0.0, drop_site=0, seed=None):
+    """out[n] (+)= sum_m drop(a[m,n])  (fp32)"""
+    _chk(a, out, seed)
+    _rowmajor(a)
+    M, N = a.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=a.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == N
+    L = _l.load()
+    ws = _ws(L.dsvg_colsum_workspace_bytes(M, N), a.device)
+    _l.check(L.dsvg_colsum(_dt(a), a.data_ptr(), a.stride(0), M, N, out.data_ptr(), int(accumulate), float(drop_p),
+                           int(drop_site), _p(seed) if drop_p > 0 else None, ws.data_ptr(), ws.numel() * 4,
+                           _stream()), "dsvg_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm
+# ------------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    _chk(x, gamma, beta)
+    assert x.is_contiguous() and x.dim() == 2
+    rows, d = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _l.check(_l.load().dsvg_layernorm_fwd(_dt(x), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                          mean.data_ptr(), rstd.data_ptr(), rows, d, float(eps), _stream()),
+             "dsvg_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, res=None, dgamma=None, dbeta=None, accumulate=False, dx=None):
+    """returns dx = [res +] LN'(dy), dgamma, dbeta (fp32)."""
+    _chk(dy, x, mean, rstd, gamma, res, dgamma, dbeta)
+    assert dy.is_contiguous() and x.is_contiguous() and dy.shape == x.shape
+    rows, d = x.shape
+    if dx is None:
+        dx = torch.empty_like(x)
+    if dgamma is None:
+        dgamma = torch.empty(d, dtype=torch.float32, device=x.device)
+    if dbeta is None:
+        dbeta = torch.empty(d, dtype=torch.float32, device=x.device)
+    if res is not None:
+        assert res.is_contiguous() and res.shape == x.shape and res.dtype == x.dtype
+    L = _l.load()
+    ws = _ws(L.dsvg_layernorm_bwd_workspace_bytes(rows, d), x.device)
+    _l.check(L.dsvg_layernorm_bwd(_dt(x), dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                  gamma.data_ptr(), _p(res), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                  int(accumulate), rows, d, ws.data_ptr(), ws.numel() * 4, _stream()),
+             "dsvg_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None):
+    _chk(qkv, key_mask, seed)
+    assert qkv.is_contiguous() and qkv.shape[0] == n_seq * S and qkv.shape[1] == 3 * 32 * n_heads, \
+        "attention needs head_dim == 32"
+    out = torch.empty((n_seq * S, 32 * n_heads), dtype=qkv.dtype, device=qkv.device)
+    _l.check(_l.load().dsvg_attention_fwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), out.data_ptr(), n_seq, S, n_heads,
+                                          float(scale), float(drop_p), int(drop_site),
+                                          _p(seed) if drop_p > 0 else None, _stream()), "dsvg_attention_fwd")
+    return out
+
+
+def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None):
+    _chk(qkv, key_mask, dout, seed)
+    assert qkv.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype
+    dqkv = torch.empty_like(qkv)
+    _l.check(_l.load().dsvg_attention_bwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), dout.data_ptr(), dqkv.data_ptr(),
+                                          n_seq, S, n_heads, float(scale), float(drop_p), int(drop_site),
+                                          _p(seed) if drop_p > 0 else None, _stream()), "dsvg_attention_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------------
+# masks / embedding / positional / pooling
+# ------------------------------------------------------------------------------------------------
+def build_masks(commands, S, G=0, eos_id=4, want_group_mask=False):
+    """commands: float32 [n_seq, S] -> key_mask int64[n_seq], seq_visible int32[n_seq], group_mask int64[n_seq/G]"""
+    _chk(commands)
+    assert commands.dtype == torch.float32 and commands.is_contiguous()
+    n_seq = commands.numel() // S
+    dev = commands.device
+    key_mask = torch.empty(n_seq, dtype=torch.int64, device=dev)
+    seq_visible = torch.empty(n_seq, dtype=torch.int32, device=dev)
+    group_mask = torch.empty(n_seq // G, dtype=torch.int64, device=dev) if want_group_mask else None
+    _l.check(_l.load().dsvg_build_masks(commands.data_ptr(), n_seq, S, G if want_group_mask else 1, eos_id,
+                                        key_mask.data_ptr(), seq_visible.data_ptr(), _p(group_mask), _stream()),
+             "dsvg_build_masks")
+    return key_mask, seq_visible, group_mask
+
+
+def group_index(commands, S, m_id=0):
+    _chk(commands)
+    assert commands.dtype == torch.float32 and commands.is_contiguous()
+    n_seq = commands.numel() // S
+    groups = torch.empty(n_seq * S, dtype=torch.int32, device=commands.device)
+    _l.check(_l.load().dsvg_group_index(commands.data_ptr(), n_seq, S, m_id, groups.data_ptr(), _stream()),
+             "dsvg_group_index")
+    return groups
+
+
+def embed_gather(commands, args, command_embed, arg_embed, dtype, group_embed=None, groups=None):
+    """commands float32 [T], args float32 [T, n_args] -> A [T, n_args*E], R [T, d] in `dtype`."""
+    _chk(commands, args, command_embed, arg_embed, group_embed, groups)
+    T = commands.numel()
+    n_args = args.numel() // T
+    n_argvals, E = arg_embed.shape
+    n_cmd, d = command_embed.shape
+    A = torch.empty((T, n_args * E), dtype=dtype, device=commands.device)
+    R = torch.empty((T, d), dtype=dtype, device=commands.device)
+    _l.check(_l.load().dsvg_embed_gather(_dt(A), commands.data_ptr(), args.data_ptr(), command_embed.data_ptr(),
+                                         arg_embed.data_ptr(), _p(group_embed), _p(groups), A.data_ptr(),
+                                         R.data_ptr(), T, n_args, E, d, n_cmd, n_argvals, _stream()),
+             "dsvg_embed_gather")
+    return A, R
+
+
+def embed_scatter(commands, args, dA, dR, d_arg_embed, d_command_embed, groups=None, d_group_embed=None):
+    """overwrites the fp32 gradient tables d_arg_embed [n_argvals,E], d_command_embed [n_cmd,d] (, d_group_embed)."""
+    _chk(commands, args, dA, dR, d_arg_embed, d_command_embed, groups, d_group_embed)
+    T = commands.numel()
+    n_args = args.numel() // T
+    n_argvals, E = d_arg_embed.shape
+    n_cmd, d = d_command_embed.shape
+    n_groups = d_group_embed.shape[0] if d_group_embed is not None else 0
+    assert dA.is_contiguous() and dR.is_contiguous()
+    L = _l.load()
+    ws = _ws(L.dsvg_embed_scatter_workspace_bytes(T, n_args, E, d, n_cmd, n_argvals, n_groups), dA.device)
+    _l.check(L.dsvg_embed_scatter(_dt(dA), commands.data_ptr(), args.data_ptr(), _p(groups), dA.data_ptr(),
+                                  dR.data_ptr(), d_arg_embed.data_ptr(), d_command_embed.data_ptr(),
+                                  _p(d_group_embed), T, n_args, E, d, n_cmd, n_argvals, n_groups, ws.data_ptr(),
+                                  ws.numel() * 4, _stream()), "dsvg_embed_scatter")
+
+
+def add_pos_fwd(x, pos, n_seq, S, dtype, drop_p=0.0, drop_site=0, seed=None):
+    """y[t] = drop((x[t] if x is not None else 0) + pos[t % S]); pos fp32 [>=S, d]"""
+    _chk(x, pos, seed)
+    d = pos.shape[1]
+    assert pos.shape[0] >= S and pos.is_contiguous()
+    y = torch.empty((n_seq * S, d), dtype=dtype, device=pos.device)
+    if x is not None:
+        assert x.is_contiguous() and x.dtype == dtype and tuple(x.shape) == (n_seq * S, d)
+    _l.check(_l.load().dsvg_add_pos_fwd(_dt(y), _p(x), pos.data_ptr(), y.data_ptr(), n_seq, S, d, float(drop_p),
+                                        int(drop_site), _p(seed) if drop_p > 0 else None, _stream()),
+             "dsvg_add_pos_fwd")
+    return y
+
+
+def add_pos_bwd(dy, n_seq, S, d_pos, *, want_dx=True, accumulate=False, drop_p=0.0, drop_site=0, seed=None):
+    """d_pos (fp32 [S, d] contiguous view) (+)= sum_b (dy*mask)[b*S+s]; returns dx = dy*mask (or None)."""
+    _chk(dy, d_pos, seed)
+    assert dy.is_contiguous()
+    d = dy.shape[1]
+    assert d_pos.is_contiguous() and d_pos.numel() == S * d
+    dx = torch.empty_like(dy) if want_dx else None
+    L = _l.load()
+    ws = _ws(L.dsvg_add_pos_bwd_workspace_bytes(n_seq, S, d), dy.device)
+    _l.check(L.dsvg_add_pos_bwd(_dt(dy), dy.data_ptr(), _p(dx), d_pos.data_ptr(), int(accumulate), n_seq, S, d,
+                                float(drop_p), int(drop_site), _p(seed) if drop_p > 0 else None, ws.data_ptr(),
+                                ws.numel() * 4, _stream()), "dsvg_add_pos_bwd")
+    return dx
+
+
+def masked_mean_fwd(x, mask, n_seq, S):
+    _chk(x, mask)
+    assert x.is_contiguous()
+    d = x.shape[1]
+    out = torch.empty((n_seq, d), dtype=x.dtype, device=x.device)
+    _l.check(_l.load().dsvg_masked_mean_fwd(_dt(x), x.data_ptr(), mask.data_ptr(), out.data_ptr(), n_seq, S, d,
+                                            _stream()), "dsvg_masked_mean_fwd")
+    return out
+
+
+def masked_mean_bwd(dout, mask, n_seq, S):
+    _chk(dout, mask)
+    assert dout.is_contiguous()
+    d = dout.shape[1]
+    dx = torch.empty((n_seq * S, d), dtype=dout.dtype, device=dout.device)
+    _l.check(_l.load().dsvg_masked_mean_bwd(_dt(dout), dout.data_ptr(), mask.data_ptr(), dx.data_ptr(), n_seq, S, d,
+                                            _stream()), "dsvg_masked_mean_bwd")
+    return dx
+
+
+def bcast_add_fwd_(x, g, n_seq, S, drop_p=0.0, drop_site=0, seed=None):
+    """in place: x[t] += drop(g[t // S])"""
+    _chk(x, g, seed)
+    assert x.is_contiguous() and g.is_contiguous() and g.dtype == x.dtype
+    d = x.shape[1]
+    _l.check(_l.load().dsvg_bcast_add_fwd(_dt(x), x.data_ptr(), g.data_ptr(), n_seq, S, d, float(drop_p),
+                                          int(drop_site), _p(seed) if drop_p > 0 else None, _stream()),
+             "dsvg_bcast_add_fwd")
+    return x
+
+
+def bcast_add_bwd(dx, n_seq, S, drop_p=0.0, drop_site=0, seed=None):
+    _chk(dx, seed)
+    assert dx.is_contiguous()
+    d = dx.shape[1]
+    dg = torch.empty((n_seq, d), dtype=dx.dtype, device=dx.device)
+    _l.check(_l.load().dsvg_bcast_add_bwd(_dt(dx), dx.data_ptr(), dg.data_ptr(), n_seq, S, d, float(drop_p),
+                                          int(drop_site), _p(seed) if drop_p > 0 else None, _stream()),
+             "dsvg_bcast_add_bwd")
+    return dg
+
+
+# ------------------------------------------------------------------------------------------------
+# loss
+# ------------------------------------------------------------------------------------------------
+def loss_targets(tgt_commands, tgt_args, cmd_args_mask, eos_id=4):
+    """tgt_commands float32 [n_seq, S1], tgt_args float32 [n_seq, S1, n_args], cmd_args_mask float32 [n_cmd,n_args]"""
+    _chk(tgt_commands, tgt_args, cmd_args_mask)
+    assert tgt_commands.is_contiguous() and tgt_args.is_contiguous() and cmd_args_mask.is_contiguous()
+    assert tgt_commands.dtype == torch.float32 and tgt_args.dtype == torch.float32
+    assert cmd_args_mask.dtype == torch.float32
+    n_seq, S1 = tgt_commands.shape
+    n_args = tgt_args.shape[-1]
+    n_cmd = cmd_args_mask.shape[0]
+    S = S1 - 1
+    dev = tgt_commands.device
+    cmd_tgt = torch.empty((n_seq, S), dtype=torch.int32, device=dev)
+    cmd_w = torch.empty((n_seq, S), dtype=torch.float32, device=dev)
+    arg_tgt = torch.empty((n_seq, S, n_args), dtype=torch.int32, device=dev)
+    arg_w = torch.empty((n_seq, S, n_args), dtype=torch.float32, device=dev)
+    vis_tgt = torch.empty(n_seq, dtype=torch.int32, device=dev)
+    _l.check(_l.load().dsvg_loss_targets(tgt_commands.data_ptr(), tgt_args.data_ptr(), cmd_args_mask.data_ptr(),
+                                         n_seq, S1, n_args, n_cmd, eos_id, cmd_tgt.data_ptr(), cmd_w.data_ptr(),
+                                         arg_tgt.data_ptr(), arg_w.data_ptr(), vis_tgt.data_ptr(), _stream()),
+             "dsvg_loss_targets")
+    return cmd_tgt, cmd_w, arg_tgt, arg_w, vis_tgt
+
+
+def masked_ce_fwd(logits2d, target, w, C_, group=1):
+    """logits2d: [n_tok, >= group*C] row-major (stride(0) = token stride); logical rows = n_tok*group.
+    returns lse [rows] fp32, sum_count fp32[2]"""
+    _chk(logits2d, target, w)
+    _rowmajor(logits2d)
+    rows = logits2d.shape[0] * group
+    assert target.numel() == rows and target.dtype == torch.int32 and target.is_contiguous()
+    if w is not None:
+        assert w.numel() == rows and w.dtype == torch.float32 and w.is_contiguous()
+    dev = logits2d.device
+    lse = torch.empty(rows, dtype=torch.float32, device=dev)
+    sc = torch.empty(2, dtype=torch.float32, device=dev)
+    L = _l.load()
+    ws = _ws(L.dsvg_masked_ce_workspace_bytes(rows), dev)
+    _l.check(L.dsvg_masked_ce_fwd(_dt(logits2d), logits2d.data_ptr(), logits2d.stride(0), group, target.data_ptr(),
+                                  _p(w), rows, C_, lse.data_ptr(), sc.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                  _stream()), "dsvg_masked_ce_fwd")
+    return lse, sc
+
+
+def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1, pad_to=8):
+    """returns dlogits as a [n_tok, group*C] view of a buffer whose token stride is padded to `pad_to` elements."""
+    _chk(logits2d, target, w, lse, sum_count, gscale)
+    n_tok = logits2d.shape[0]
+    rows = n_tok * group
+    width = group * C_
+    ld_d = (width + pad_to - 1) // pad_to * pad_to
+    buf = torch.empty((n_tok, ld_d), dtype=logits2d.dtype, device=logits2d.device)
+    assert gscale is None or (gscale.dtype == torch.float32 and gscale.numel() == 1)
+    _l.check(_l.load().dsvg_masked_ce_bwd(_dt(logits2d), logits2d.data_ptr(), logits2d.stride(0), group,
+                                          target.data_ptr(), _p(w), lse.data_ptr(), sum_count.data_ptr(), _p(gscale),
+                                          float(coef), buf.data_ptr(), ld_d, rows, C_, _stream()),
+             "dsvg_masked_ce_bwd")
+    return buf[:, :width]
+
+
+# ------------------------------------------------------------------------------------------------
+# optimizer / housekeeping
+# ------------------------------------------------------------------------------------------------
+def sumsq(x, out=None):
+    _chk(x, out)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+    L = _l.load()
+    ws = _ws(L.dsvg_sumsq_workspace_bytes(x.numel()), x.device)
+    _l.check(L.dsvg_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()),
+             "dsvg_sumsq")
+    return out
+
+
+def adamw_step_(p, g, m, v, lr, step, *, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, gnorm_sq=None,
+                max_norm=0.0, grad_scale=1.0):
+    """in-place AdamW (+ optional global-norm clip) on flat fp32 buffers; lr: float32[1], step: int64[1] on device."""
+    _chk(p, g, m, v, lr, step, gnorm_sq)
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    assert lr.dtype == torch.float32 and step.dtype == torch.int64
+    _l.check(_l.load().dsvg_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                       lr.data_ptr(), beta1, beta2, eps, weight_decay, step.data_ptr(),
+                                       _p(gnorm_sq), float(max_norm), float(grad_scale), _stream()),
+             "dsvg_adamw_step")
+
+
+def cast_weights(src, dst=None, dst_t=None):
+    """dst = cast(src [rows, cols]); dst_t = cast(src)^T"""
+    _chk(src, dst, dst_t)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    if src.dim() == 1:
+        rows, cols = 1, src.numel()
+    else:
+        rows, cols = src.shape
+    ref = dst if dst is not None else dst_t
+    _l.check(_l.load().dsvg_cast_weights(_dt(ref), src.data_ptr(), _p(dst), _p(dst_t), rows, cols, _stream()),
+             "dsvg_cast_weights")
+    return dst, dst_t
+
+
+def gate_mul(dy, y, scale=1.0):
+    """out = dy * scale where y > 0 else 0   (backward of relu [+ dropout] from the saved output)"""
+    _chk(dy, y)
+    assert dy.is_contiguous() and y.is_contiguous() and dy.shape == y.shape and dy.dtype == y.dtype
+    out = torch.empty_like(dy)
+    _l.check(_l.load().dsvg_gate_mul(_dt(dy), dy.data_ptr(), y.data_ptr(), out.data_ptr(), dy.numel(), float(scale),
+                                     _stream()), "dsvg_gate_mul")
+    return out
+
+
+def advance_step_(counter, seed):
+    _chk(counter, seed)
+    _l.check(_l.load().dsvg_advance_step(_p(counter), _p(seed), _stream()), "dsvg_advance_step")
+
+
+def probe_trread(off):
+    _chk(off)
+    assert off.dtype == torch.int32 and off.numel() == 64
+    out = torch.empty(256, dtype=torch.int16, device=off.device)
+    _l.check(_l.load().dsvg_probe_trread(off.data_ptr(), out.data_ptr(), _stream()), "dsvg_probe_trread")
+    return out

@@ -1,0 +1,220 @@
+/*
+ * dsvg.h — C ABI of libdsvg_hip.so: the gfx950 (MI355X) kernels behind the DeepSVG
+ * SVGTransformer forward/backward hot path.
+ *
+ * The reference (alexandre01/deepsvg) has no FFI for this path: every op is a stock aten op
+ * reached through torch.nn / torch.nn.functional.  Each entry point below therefore cites the
+ * reference call site (file:line under /root/reference) whose arithmetic it replaces.  The
+ * Python host (deepsvg_amd/ops.py) binds these with ctypes; see INTEGRATION.md.
+ *
+ * Conventions
+ *  - Every buffer is owned by the caller (PyTorch); the library allocates nothing persistent.
+ *  - All work is enqueued on `stream` (a hipStream_t passed as void*); no implicit syncs.
+ *  - Return 0 on success, <0 on error; dsvg_last_error() returns a thread-local message.
+ *  - dtype: DSVG_F32 (parity path, exact-fp32 MFMA) or DSVG_BF16 (bf16 storage, fp32 accumulate).
+ *  - "seed" is a device pointer to a uint64 so a captured hipGraph re-reads it on every replay.
+ *  - Token-major activations: row index t = sequence * S + position; feature index contiguous.
+ */
+#ifndef DSVG_H
+#define DSVG_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSVG_F32 0
+#define DSVG_BF16 1
+
+const char* dsvg_last_error(void);
+int dsvg_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM with fused prologue/epilogue:  C = epi( sum_k A(m,k) * B(n,k) )
+ *   epi(v) = [C +] [res +] drop( gate( act( v + bias [+ res if res_pre] ) ) )
+ * Replaces aten::addmm / aten::mm of every nn.Linear on the path:
+ *   deepsvg/model/layers/functional.py:92,249 (QKV, out-proj),
+ *   deepsvg/model/layers/improved_transformer.py:52,131,139 (FFN, linear_global),
+ *   deepsvg/model/model.py:50,183,197 (embed_fcn, VAE, bottleneck),
+ *   deepsvg/model/basic_blocks.py:18,20,36-37,60-63 (heads, ResNet),
+ * and the two backward matmuls autograd derives for each of them (deepsvg/train.py:98).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dsvg_gemm_desc {
+    int32_t dtype;            /* element type of A, B, res, gate and (unless c_f32) C             */
+    int32_t M, N, K;
+    const void* A; int64_t lda; int32_t a_kc;   /* a_kc=1: A(m,k)=A[m*lda+k]  0: A[k*lda+m]      */
+    const void* B; int64_t ldb; int32_t b_kc;   /* b_kc=1: B(n,k)=B[n*ldb+k]  0: B[k*ldb+n]      */
+    void* C; int64_t ldc; int32_t c_f32;        /* C[m*ldc+n]; c_f32=1 forces fp32 output        */
+    const float* bias;                          /* [N] fp32 or NULL                              */
+    const void* res; int64_t ldres; int32_t res_pre; /* residual (may alias C)                   */
+    int32_t act;                                /* 0 none, 1 relu                                */
+    const void* gate; int64_t ldgate; float gate_scale; /* v *= gate_scale*(gate[m,n]>0)         */
+    float drop_p; uint32_t drop_site;           /* epilogue dropout, element id = m*N+n          */
+    float a_drop_p; uint32_t a_drop_site; int64_t a_drop_ld; /* dropout replay on operand A,
+                                                   element id = storage_row*a_drop_ld+storage_col */
+    const uint64_t* seed;                       /* device pointer (may be NULL when p==0)        */
+    int32_t accumulate;                         /* C += result                                   */
+    int32_t split_k; float* workspace; int64_t workspace_bytes; /* split over K (weight grads);
+                                                   needs c_f32 output and no epilogue            */
+    int32_t impl;                               /* 0 = MFMA kernel, 1 = one-thread-per-output    */
+} dsvg_gemm_desc;
+
+int dsvg_gemm(const dsvg_gemm_desc* d, void* stream);
+/* workspace bytes dsvg_gemm needs for a given split_k (0 when split_k<=1) */
+int64_t dsvg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
+
+/* out[j] = (accumulate? out[j] : 0) + sum_{p<P} partial[p*n+j]   (fp32; deterministic order) */
+int dsvg_reduce_partials(const float* partial, int64_t P, int64_t n, float* out, int32_t accumulate,
+                         void* stream);
+
+/* out[n] (+)= sum_m drop(A[m*lda+n])  — bias gradients (autograd of the `+ b` in every nn.Linear).
+ * workspace: at least dsvg_colsum_workspace_bytes(M,N) bytes. */
+int dsvg_colsum(int32_t dtype, const void* A, int64_t lda, int64_t M, int32_t N, float* out,
+                int32_t accumulate, float drop_p, uint32_t drop_site, const uint64_t* seed,
+                float* workspace, int64_t workspace_bytes, void* stream);
+int64_t dsvg_colsum_workspace_bytes(int64_t M, int32_t N);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension (d % 4 == 0, d <= 1024), eps as given.
+ * Replaces torch.nn.LayerNorm at deepsvg/model/layers/improved_transformer.py:43,51,127,138 and
+ * deepsvg/model/layers/transformer.py:185-186,239-240.
+ * bwd: dx = [res +] LN'(dy);  dgamma/dbeta partials go to workspace then are reduced into
+ * dgamma/dbeta (fp32, overwritten unless accumulate).
+ * ------------------------------------------------------------------------------------------ */
+int dsvg_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y,
+                       float* mean, float* rstd, int64_t rows, int32_t d, float eps, void* stream);
+int dsvg_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* mean,
+                       const float* rstd, const float* gamma, const void* res, void* dx,
+                       float* dgamma, float* dbeta, int32_t accumulate, int64_t rows, int32_t d,
+                       float* workspace, int64_t workspace_bytes, void* stream);
+int64_t dsvg_layernorm_bwd_workspace_bytes(int64_t rows, int32_t d);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head self-attention core on packed QKV (after the in-projection):
+ *   qkv[t, 0:d]=q, [d:2d]=k, [2d:3d]=v ; head h uses columns h*32..h*32+31 (head_dim must be 32);
+ *   sequence b owns rows b*S..b*S+S-1 (S <= 64); key j of sequence b is visible iff bit j of
+ *   key_mask[b] is set (NULL = all S keys).  q is scaled by `scale` after the bias add.
+ *   out[t, h*32+c] = sum_j drop(softmax_j(scale*q_i.k_j))*v_j
+ * Replaces deepsvg/model/layers/functional.py:168,197-248 (scale, reshape, bmm, masked_fill,
+ * softmax, dropout, bmm, head merge).  bwd recomputes the probabilities (no S×S tensor in HBM).
+ * ------------------------------------------------------------------------------------------ */
+int dsvg_attention_fwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, void* out,
+                       int64_t n_seq, int32_t S, int32_t n_heads, float scale, float drop_p,
+                       uint32_t drop_site, const uint64_t* seed, void* stream);
+int dsvg_attention_bwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const void* dout,
+                       void* dqkv, int64_t n_seq, int32_t S, int32_t n_heads, float scale,
+                       float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Masks from the command tensor (deepsvg/model/utils.py:7-66).  commands: float32 [n_seq, S]
+ * (batch-first rows, values are command indices; EOS = eos_id).
+ *   key_mask[b]   bit j set  <=>  no EOS at positions <= j   (complement of _get_key_padding_mask)
+ *   seq_visible[b] = (#EOS in row b) < S-1                    (_get_visibility_mask)
+ * and per group-of-G rows: group_mask[n] bit g = seq_visible[n*G+g]  (_get_key_visibility_mask)
+ * ------------------------------------------------------------------------------------------ */
+int dsvg_build_masks(const float* commands, int64_t n_seq, int32_t S, int32_t G, int32_t eos_id,
+                     uint64_t* key_mask, int32_t* seq_visible, uint64_t* group_mask, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SVGEmbedding pieces (deepsvg/model/model.py:46-57):
+ *  gather:  A[t, a*E:(a+1)*E] = arg_embed[args[t,a]+1]   (fp32 table -> dtype)  and
+ *           R[t, :] = command_embed[commands[t]] (+ group_embed[groups[t]] when given)
+ *  bwd:     d_arg_embed += scatter(dA), d_command_embed += scatter(dR), d_group_embed likewise.
+ * ------------------------------------------------------------------------------------------ */
+int dsvg_embed_gather(int32_t dtype, const float* commands, const float* args,
+                      const float* command_embed, const float* arg_embed, const float* group_embed,
+                      const int32_t* groups, void* A, void* R, int64_t T, int32_t n_args, int32_t E,
+                      int32_t d, int32_t n_cmd, int32_t n_argvals, void* stream);
+int dsvg_embed_scatter(int32_t dtype, const float* commands, const float* args,
+                       const int32_t* groups, const void* dA, const void* dR, float* d_arg_embed,
+                       float* d_command_embed, float* d_group_embed, int64_t T, int32_t n_args,
+                       int32_t E, int32_t d, int32_t n_cmd, int32_t n_argvals, int32_t n_groups,
+                       float* workspace, int64_t workspace_bytes, void* stream);
+int64_t dsvg_embed_scatter_workspace_bytes(int64_t T, int32_t n_args, int32_t E, int32_t d,
+                                           int32_t n_cmd, int32_t n_argvals, int32_t n_groups);
+/* group index per token: groups[b*S+s] = #{ s' <= s : commands[b,s'] == m_id }  (utils.py:35-42) */
+int dsvg_group_index(const float* commands, int64_t n_seq, int32_t S, int32_t m_id, int32_t* groups,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * y[t,:] = drop( (x ? x[t,:] : 0) + pos_embed[t % S, :] )
+ * PositionalEncodingLUT.forward (deepsvg/model/layers/positional_encoding.py:40-43) and
+ * ConstEmbedding.forward (deepsvg/model/model.py:70-73, x == NULL).
+ * bwd: dx = dy*mask (if dx != NULL), d_pos[s,:] (+)= sum_b (dy*mask)[b*S+s,:]
+ * ------------------------------------------------------------------------------------------ */
+int dsvg_add_pos_fwd(int32_t dtype, const void* x, const float* pos, void* y, int64_t n_seq, int32_t S,
+                     int32_t d, float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream);
+int dsvg_add_pos_bwd(int32_t dtype, const void* dy, void* dx, float* d_pos, int32_t accumulate,
+                     int64_t n_seq, int32_t S, int32_t d, float drop_p, uint32_t drop_site,
+                     const uint64_t* seed, float* workspace, int64_t workspace_bytes, void* stream);
+int64_t dsvg_add_pos_bwd_workspace_bytes(int64_t n_seq, int32_t S, int32_t d);
+
+/* ------------------------------------------------------------------------------------------
+ * Masked mean over the sequence axis (deepsvg/model/model.py:137,161):
+ *   out[b,:] = sum_{s in mask[b]} x[b*S+s,:] / popcount(mask[b])
+ * ------------------------------------------------------------------------------------------ */
+int dsvg_masked_mean_fwd(int32_t dtype, const void* x, const uint64_t* mask, void* out, int64_t n_seq,
+                         int32_t S, int32_t d, void* stream);
+int dsvg_masked_mean_bwd(int32_t dtype, const void* dout, const uint64_t* mask, void* dx,
+                         int64_t n_seq, int32_t S, int32_t d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * x[t,:] += drop(g[t / S, :])      "implicit broadcast" add of linear_global(z)
+ * (deepsvg/model/layers/improved_transformer.py:131-136).
+ * bwd: dg[b,:] = sum_s (dx*mask)[b*S+s,:]
+ * ------------------------------------------------------------------------------------------ */
+int dsvg_bcast_add_fwd(int32_t dtype, void* x, const void* g, int64_t n_seq, int32_t S, int32_t d,
+                       float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream);
+int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64_t n_seq, int32_t S, int32_t d,
+                       float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SVGLoss (deepsvg/model/loss.py:19-65).
+ *  targets: from tgt_commands [n_seq,S1] / tgt_args [n_seq,S1,n_args] (float32, S1=S+1 incl. SOS)
+ *    cmd_tgt[n_seq,S], cmd_w[n_seq,S] (extended padding mask x visibility, loss.py:35-36,49),
+ *    arg_tgt[n_seq,S,n_args] (=arg+1), arg_w = CMD_ARGS_MASK[cmd] (loss.py:51), vis_tgt[n_seq]
+ *  masked CE: logical row r of the [rows, C] matrix lives at logits + (r/group)*ld + (r%group)*C
+ *    (group = n_args for args_logits, whose 11x257 slots are contiguous per token; 1 otherwise);
+ *    lse per row, sum_count = {sum_r w_r*(lse_r - logit[r,target_r]), sum_r w_r}; rows with w==0
+ *    are never read.  loss = sum/count is formed by the caller on device.
+ *  ce_bwd: dlogits = w * (softmax - onehot) * coef * (*gscale) / count  [zeros where w == 0, and
+ *    zeros in the [group*C, ld_d) row padding]
+ * ------------------------------------------------------------------------------------------ */
+int dsvg_loss_targets(const float* tgt_commands, const float* tgt_args, const float* cmd_args_mask,
+                      int64_t n_seq, int32_t S1, int32_t n_args, int32_t n_cmd, int32_t eos_id,
+                      int32_t* cmd_tgt, float* cmd_w, int32_t* arg_tgt, float* arg_w, int32_t* vis_tgt,
+                      void* stream);
+int dsvg_masked_ce_fwd(int32_t dtype, const void* logits, int64_t ld, int32_t group, const int32_t* target,
+                       const float* w, int64_t rows, int32_t C, float* lse, float* sum_count /*[2]*/,
+                       float* workspace, int64_t workspace_bytes, void* stream);
+int64_t dsvg_masked_ce_workspace_bytes(int64_t rows);
+int dsvg_masked_ce_bwd(int32_t dtype, const void* logits, int64_t ld, int32_t group, const int32_t* target,
+                       const float* w, const float* lse, const float* sum_count, const float* gscale,
+                       float coef, void* dlogits, int64_t ld_d, int64_t rows, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flat-buffer optimizer step: clip_grad_norm_ (deepsvg/train.py:100) + AdamW
+ * (deepsvg/config.py:64-65, torch.optim.AdamW defaults) on one contiguous fp32 parameter buffer.
+ * ------------------------------------------------------------------------------------------ */
+int dsvg_sumsq(const float* x, int64_t n, float* out /*[1]*/, float* workspace, int64_t workspace_bytes,
+               void* stream);
+int64_t dsvg_sumsq_workspace_bytes(int64_t n);
+int dsvg_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr,
+                    float beta1, float beta2, float eps, float weight_decay, const int64_t* step,
+                    const float* gnorm_sq, float max_norm, float grad_scale, void* stream);
+/* dst (dtype) = src (fp32), optional transposed copy: dst_t[c*rows+r] = src[r*cols+c] */
+int dsvg_cast_weights(int32_t dtype, const float* src, void* dst, void* dst_t, int64_t rows,
+                      int64_t cols, void* stream);
+/* *counter += 1 ; *seed = hash(*seed)  — per-step dropout seed advance, graph-capturable */
+int dsvg_advance_step(int64_t* counter, uint64_t* seed, void* stream);
+/* out[i] = y[i] > 0 ? dy[i]*scale : 0 — backward of ReLU (basic_blocks.py:47-57) from the saved output */
+int dsvg_gate_mul(int32_t dtype, const void* dy, const void* y, void* out, int64_t n, float scale, void* stream);
+/* test hook: raw ds_read_b64_tr_b16 on a 4 KiB LDS image img[i]=i, lane l reads at byte offset off[l] */
+int dsvg_probe_trread(const int* off, short* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSVG_H */
