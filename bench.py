@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: one full training step (deepsvg/train.py:92-106 = forward + SVGLoss + backward +
+clip_grad_norm_ + AdamW) of hierarchical_ordered (G=8, S=30, d_model=256) at 512 icons per GPU, synthetic data,
+on N MI355X (one process per GPU, RCCL gradient all-reduce).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     FFN GEMMs (linear1/linear2 forward + their dX/dW backward GEMMs, 3.2716 GFLOP per trained icon,
+               SURVEY.md §8(d)) timed live with HIP events on the launch stream in a few extra eager steps
+  cpu_baseline the CPU restatement of the reference step (oracle/, kind "port") timed on the host cores on a
+               bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FFN_FLOP_PER_ICON_TRAIN = 3.2716e9      # 2080 token-layers x 524,288 FLOP x 3
+STEP_FLOP_PER_ICON_TRAIN = 8.115e9      # whole step
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="icons per GPU")
+    ap.add_argument("--dtype", default=os.environ.get("DSVG_BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("DSVG_BENCH_GRAPH", "1")))
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, batch, steps):
+    """the reference train step restated on CPU (oracle): forward + SVGLoss + backward + clip + AdamW, fp32"""
+    from oracle import svg_transformer_oracle as O
+    from deepsvg_amd.synthetic import make_batch
+    torch.set_num_threads(os.cpu_count() or 1)
+    commands, args = make_batch(batch, seed=4242)
+    leaves = {k: v.detach().clone().requires_grad_(torch.is_floating_point(v)) for k, v in sd.items()}
+    params = [v for v in leaves.values() if v.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-3)
+
+    def one():
+        opt.zero_grad()
+        out = O.forward(leaves, cfg, commands, args, commands, args)
+        ld = O.svg_loss(cfg, out, O.DEFAULT_WEIGHTS)
+        ld["loss"].backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": batch / dt, "unit": "icons/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} train steps of batch {batch} (dropout off, fp32, oracle/svg_transformer_oracle.py), "
+                      f"{dt * 1e3:.0f} ms/step"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    import deepsvg_amd
+    from deepsvg_amd import lib, ops
+    from deepsvg_amd.synthetic import make_batch, det_state_dict
+    from deepsvg_amd.trainer import TrainStep
+    lib.load()   # no fallback: fail loudly when the HIP extension is missing
+
+    torch.manual_seed(42)                                   # deepsvg/train.py:15
+    cfg = deepsvg_amd.HierarchicalOrdered()
+    cfg.dropout = a.dropout
+    model = deepsvg_amd.SVGTransformer(cfg)
+    sd_cpu = det_state_dict(model, seed=42)                 # same weights on every rank (and for the CPU leg)
+    model.load_state_dict(sd_cpu)
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    model.to(device).set_compute_dtype(dtype)
+    model.train()
+    loss_fn = deepsvg_amd.SVGLoss(cfg).to(device)
+    commands, args = make_batch(a.batch, G=8, S=30, seed=1000 + rank)
+    commands, args = commands.to(device), args.to(device)
+
+    use_graph = bool(a.graph)
+    ts = TrainStep(model, loss_fn, lr=1e-3 * world, grad_clip=1.0, use_graph=use_graph)
+    try:
+        ts.step(commands, args)
+    except Exception as e:          # graph capture can fail (e.g. collective not capturable): fall back to eager
+        if not use_graph:
+            raise
+        if rank == 0:
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+        use_graph = False
+        model = deepsvg_amd.SVGTransformer(cfg)
+        model.load_state_dict(sd_cpu)
+        model.to(device).set_compute_dtype(dtype)
+        model.train()
+        ts = TrainStep(model, loss_fn, lr=1e-3 * world, grad_clip=1.0, use_graph=False)
+        ts.step(commands, args)
+
+    for _ in range(a.warmup):
+        ts.step(commands, args)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ld = ts.step(commands, args)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss_val = float(ld["loss"])
+    assert loss_val == loss_val and abs(loss_val) < 1e4, f"loss diverged: {loss_val}"
+    ms_per_step = elapsed / a.steps * 1e3
+    icons_per_s = a.batch * world / (elapsed / a.steps)
+
+    roofline = None
+    if rank == 0 and not a.no_roofline:
+        # FFN GEMM time: a few extra eager steps with HIP events (torch.cuda.Event records on the stream the
+        # kernels are launched on: ops launch on torch's current stream)
+        ts_prof = TrainStep(model, loss_fn, lr=0.0, grad_clip=1.0, use_graph=False) if world == 1 else None
+        if ts_prof is not None:
+            ts_prof.step(commands, args)
+            ops.PROFILE.clear()
+            ops.PROFILE_ON = True
+            n_prof = 3
+            for _ in range(n_prof):
+                ts_prof.step(commands, args)
+            torch.cuda.synchronize()
+            ops.PROFILE_ON = False
+            ffn_ms = sum(s.elapsed_time(e) for (tag, s, e) in ops.PROFILE if tag == "ffn") / n_prof
+            n_ffn = sum(1 for (tag, s, e) in ops.PROFILE if tag == "ffn") // n_prof
+            ach = a.batch * FFN_FLOP_PER_ICON_TRAIN / (ffn_ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[a.dtype]
+            roofline = {"bound": "mfma", "kernel": "FFN GEMMs (linear1/linear2 fwd + dX + dW)", "achieved": round(ach, 2),
+                        "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                        "launches_per_step": n_ffn, "ffn_ms_per_step": round(ffn_ms, 3),
+                        "whole_step_frac": round(a.batch * STEP_FLOP_PER_ICON_TRAIN / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, sd_cpu, a.cpu_batch, a.cpu_steps)
+
+    if rank == 0:
+        rec = {
+            "metric": "SVG icons/sec (train step) hierarchical_ordered d=256",
+            "value": round(icons_per_s, 1), "unit": "icons/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "hierarchical_ordered (Hierarchical, use_vae=False) G=8 S=30 d_model=256 ff=512 "
+                                   "H=8 L=4x4; full train step = forward + SVGLoss + backward + grad-clip 1.0 + AdamW; "
+                                   f"dropout {a.dropout}", "global_batch": a.batch * world, "batch_per_gpu": a.batch,
+                       "parallelism": f"dp{world}", "hip_graph": use_graph, "loss": round(loss_val, 4)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -255,7 +255,7 @@ static int launch_fwd(const void* qkv, const uint64_t* km, void* out, int64_t n_
     const size_t lds = (size_t)S * C::LD * sizeof(T);
     if (lds > 160 * 1024) { dsvg_set_error("attention_fwd: LDS image too large (%zu B)", lds); return -1; }
     auto kern = attn_fwd_kernel<T, SP, HG>;
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DSVG_ENSURE_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)n_seq, H / HG), dim3(C::NT), lds, st, (const T*)qkv, km, (T*)out, S, H,
                        scale, drop_p, site, seed);
     DSVG_LAUNCH_CHECK("attention_fwd");
@@ -268,7 +268,7 @@ static int launch_bwd(const void* qkv, const uint64_t* km, const void* dout, voi
     const size_t lds = (size_t)S * (C::LD + C::LDO) * sizeof(T) + (size_t)HG * SP * 2 * sizeof(float);
     if (lds > 160 * 1024) { dsvg_set_error("attention_bwd: LDS image too large (%zu B)", lds); return -1; }
     auto kern = attn_bwd_kernel<T, SP, HG>;
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DSVG_ENSURE_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)n_seq, H / HG), dim3(C::NT), lds, st, (const T*)qkv, km, (const T*)dout,
                        (T*)dqkv, S, H, scale, drop_p, site, seed);
     DSVG_LAUNCH_CHECK("attention_bwd");

@@ -34,6 +34,18 @@ void dsvg_set_error(const char* fmt, ...);
         }                                                                              \
     } while (0)
 
+// raise a kernel's dynamic-LDS cap above the 64 KiB default, once per high-water mark (host-side call, kept
+// out of the steady state so a captured hipGraph never sees it)
+#define DSVG_ENSURE_LDS(kern, bytes)                                                                      \
+    do {                                                                                                  \
+        static size_t _dsvg_cap = 64 * 1024;                                                              \
+        if ((size_t)(bytes) > _dsvg_cap) {                                                                \
+            (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                      (int)(bytes));                                                      \
+            _dsvg_cap = (size_t)(bytes);                                                                  \
+        }                                                                                                 \
+    } while (0)
+
 // ---------------------------------------------------------------------------------------------
 // bf16 <-> fp32
 // ---------------------------------------------------------------------------------------------

@@ -236,16 +236,16 @@ extern "C" int dsvg_embed_scatter(int32_t dtype, const float* commands, const fl
     if (dtype == DSVG_F32) {
         auto ka = embed_scatter_arg_kernel<float>;
         auto kr = embed_scatter_row_kernel<float>;
-        if (lds_a > 64 * 1024) hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-        if (lds_r > 64 * 1024) hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+        DSVG_ENSURE_LDS(ka, lds_a);
+        DSVG_ENSURE_LDS(kr, lds_r);
         hipLaunchKernelGGL(ka, dim3(nb), dim3(256), lds_a, st, args, (const float*)dA, part_arg, (long long)T_tok, n_args, E, n_argvals);
         hipLaunchKernelGGL(kr, dim3(nb), dim3(256), lds_r, st, commands, groups, (const float*)dR, part_cmd, part_grp,
                            (long long)T_tok, d, n_cmd, n_groups);
     } else if (dtype == DSVG_BF16) {
         auto ka = embed_scatter_arg_kernel<bf16_t>;
         auto kr = embed_scatter_row_kernel<bf16_t>;
-        if (lds_a > 64 * 1024) hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-        if (lds_r > 64 * 1024) hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+        DSVG_ENSURE_LDS(ka, lds_a);
+        DSVG_ENSURE_LDS(kr, lds_r);
         hipLaunchKernelGGL(ka, dim3(nb), dim3(256), lds_a, st, args, (const bf16_t*)dA, part_arg, (long long)T_tok, n_args, E, n_argvals);
         hipLaunchKernelGGL(kr, dim3(nb), dim3(256), lds_r, st, commands, groups, (const bf16_t*)dR, part_cmd, part_grp,
                            (long long)T_tok, d, n_cmd, n_groups);
@@ -347,12 +347,12 @@ extern "C" int dsvg_add_pos_bwd(int32_t dtype, const void* dy, void* dx, float* 
     dim3 grid(nb, dsvg_cdiv(d, 256));
     if (dtype == DSVG_F32) {
         auto k = add_pos_bwd_kernel<float>;
-        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DSVG_ENSURE_LDS(k, lds);
         hipLaunchKernelGGL(k, grid, dim3(256), lds, st, (const float*)dy, (float*)dx, workspace, (long long)n_seq, S, d,
                            drop_p, drop_site, seed);
     } else if (dtype == DSVG_BF16) {
         auto k = add_pos_bwd_kernel<bf16_t>;
-        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DSVG_ENSURE_LDS(k, lds);
         hipLaunchKernelGGL(k, grid, dim3(256), lds, st, (const bf16_t*)dy, (bf16_t*)dx, workspace, (long long)n_seq, S,
                            d, drop_p, drop_site, seed);
     } else { dsvg_set_error("add_pos_bwd: bad dtype"); return -1; }

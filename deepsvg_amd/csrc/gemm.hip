@@ -335,7 +335,9 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
         // the MFMA kernel needs 16-byte aligned rows
         if ((d.lda & 3) || (d.ldb & 3) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) use_naive = true;
     } else {
-        if ((d.lda & 7) || (d.ldb & 7) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15) || (d.K & 7)) use_naive = true;
+        const int Kp = (d.K + 7) / 8 * 8;
+        if ((d.lda & 7) || (d.ldb & 7) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) use_naive = true;
+        if ((d.a_kc && d.lda < Kp) || (d.b_kc && d.ldb < Kp)) use_naive = true;
         if (!d.a_kc && d.lda < ((d.M + 7) / 8) * 8) use_naive = true;
         if (!d.b_kc && d.ldb < ((d.N + 7) / 8) * 8) use_naive = true;
     }

@@ -30,6 +30,17 @@ __device__ __forceinline__ uint4 drop_chunk8(uint4 v, const DropCtx& dc, uint64_
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// keep the first `nvalid` (1..7) bf16 elements of an 8-element chunk, zero the rest (K tail)
+__device__ __forceinline__ uint4 mask_tail8(uint4 v, int nvalid) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (2 * i >= nvalid) w[i] = 0u;
+        else if (2 * i + 1 >= nvalid) w[i] &= 0x0000ffffu;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 union Frag8 {
     bf16x8 v;
     shortx4 h[2];
@@ -74,6 +85,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
                 uint4 v = zero4;
                 if (gm < p.M && gk < k_end) {
                     v = *reinterpret_cast<const uint4*>(A + (size_t)gm * p.lda + gk);
+                    if (gk + 8 > k_end) v = mask_tail8(v, k_end - gk);
                     if (adc.on) v = drop_chunk8(v, adc, (uint64_t)gm * p.a_drop_ld + gk);
                 }
                 ra[j] = v;
@@ -98,7 +110,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int gn = n0 + r + 32 * j, gk = k0 + 8 * c;
-                rb[j] = (gn < p.N && gk < k_end) ? *reinterpret_cast<const uint4*>(B + (size_t)gn * p.ldb + gk) : zero4;
+                uint4 v = zero4;
+                if (gn < p.N && gk < k_end) {
+                    v = *reinterpret_cast<const uint4*>(B + (size_t)gn * p.ldb + gk);
+                    if (gk + 8 > k_end) v = mask_tail8(v, k_end - gk);
+                }
+                rb[j] = v;
             }
         } else {
             const int c = tid & 15, r = tid >> 4;
@@ -220,8 +237,9 @@ extern "C" int dsvg_probe_trread(const int* off, short* out, void* stream) {
 }
 
 int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, float* part, hipStream_t st) {
+    const int Kp = (d.K + 7) / 8 * 8;   // k-contiguous operands are read in 8-element chunks (tail masked)
     const bool aligned = !(d.lda & 7) && !(d.ldb & 7) && !((uintptr_t)d.A & 15) && !((uintptr_t)d.B & 15) &&
-                         !(d.K & 7);
+                         (!d.a_kc || d.lda >= Kp) && (!d.b_kc || d.ldb >= Kp);
     if (!aligned) {
         dsvg_set_error("gemm(bf16): operands must be 16-byte aligned with lda/ldb/K multiples of 8 "
                        "(lda=%lld ldb=%lld K=%d)", (long long)d.lda, (long long)d.ldb, d.K);

@@ -161,6 +161,26 @@ extern "C" int dsvg_gate_mul(int32_t dtype, const void* dy, const void* y, void*
     return 0;
 }
 
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        Elem<T>::st(out + i, Elem<T>::ld(a + i) + Elem<T>::ld(b + i));
+}
+extern "C" int dsvg_add(int32_t dtype, const void* a, const void* b, void* out, int64_t n, void* stream) {
+    DSVG_CHECK_ARG(a && b && out && n > 0, "add: bad args");
+    const int nb = (int)min(4096LL, (long long)dsvg_cdiv(n, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(add_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out,
+                           (long long)n);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b,
+                           (bf16_t*)out, (long long)n);
+    else { dsvg_set_error("add: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("add");
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------------------------

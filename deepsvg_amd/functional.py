@@ -115,6 +115,29 @@ class LinearFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------------
+class ResBlockFn(torch.autograd.Function):
+    """z + relu(z W^T + b): one block of the latent ResNet (deepsvg/model/basic_blocks.py:59-65)"""
+
+    @staticmethod
+    def forward(ctx, rt, z, weight, bias):
+        r = ops.gemm(z, rt.w(weight), bias=bias.detach(), act=ops.RELU)
+        ctx.rt = rt
+        ctx.save_for_backward(z, r, weight, bias)
+        return ops.add(z, r)
+
+    @staticmethod
+    def backward(ctx, dout):
+        rt = ctx.rt
+        z, r, weight, bias = ctx.saved_tensors
+        dout = dout.contiguous()
+        dpre = ops.gate_mul(dout, r, 1.0)
+        dw = _wgrad(rt, weight, dpre, z)
+        db = _bgrad(rt, bias, dpre)
+        dz = ops.gemm(dpre, rt.w(weight), b_kc=False, res=dout)
+        return None, dz, dw, db
+
+
+# --------------------------------------------------------------------------------------------------
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rt, x, gamma, beta, eps):
@@ -232,8 +255,9 @@ class LayerFn(torch.autograd.Function):
             g2 = ops.gemm(l, rt.w(wg2), bias=bg2.detach())
             ops.bcast_add_fwd_(x1, g2, n_seq, S, p, site0 + 5, rt.seed)
         xn2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach())
-        h = ops.gemm(xn2, rt.w(w1), bias=b1.detach(), act=ops.RELU, drop_p=p, drop_site=site0 + 3, seed=rt.seed)
-        x2 = ops.gemm(h, rt.w(w2), bias=b2.detach(), res=x1, drop_p=p, drop_site=site0 + 4, seed=rt.seed)
+        with ops.tag("ffn"):
+            h = ops.gemm(xn2, rt.w(w1), bias=b1.detach(), act=ops.RELU, drop_p=p, drop_site=site0 + 3, seed=rt.seed)
+            x2 = ops.gemm(h, rt.w(w2), bias=b2.detach(), res=x1, drop_p=p, drop_site=site0 + 4, seed=rt.seed)
         ctx.rt, ctx.n_seq, ctx.S, ctx.n_heads, ctx.p, ctx.site0, ctx.scale = rt, n_seq, S, n_heads, p, site0, scale
         ctx.save_for_backward(x, key_mask, z, l, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h,
                               n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2)
@@ -247,13 +271,14 @@ class LayerFn(torch.autograd.Function):
         dx2 = dx2.contiguous()
         inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
         # ---- FFN: x2 = x1 + drop4(h W2^T + b2),  h = drop3(relu(xn2 W1^T + b1)) ----
-        dw2 = _wgrad(rt, w2, dx2, h, a_drop_p=p, a_drop_site=s0 + 4)
+        with ops.tag("ffn"):
+            dw2 = _wgrad(rt, w2, dx2, h, a_drop_p=p, a_drop_site=s0 + 4)
+            dh = ops.gemm(dx2, rt.w(w2), b_kc=False, a_drop_p=p, a_drop_site=s0 + 4, seed=rt.seed,
+                          gate=h, gate_scale=inv_keep)     # (h > 0) <=> relu passed AND kept by drop3
+            dw1 = _wgrad(rt, w1, dh, xn2)
+            dxn2 = ops.gemm(dh, rt.w(w1), b_kc=False)
         db2 = _bgrad(rt, b2, dx2, drop_p=p, drop_site=s0 + 4)
-        dh = ops.gemm(dx2, rt.w(w2), b_kc=False, a_drop_p=p, a_drop_site=s0 + 4, seed=rt.seed,
-                      gate=h, gate_scale=inv_keep)     # (h > 0) <=> relu passed AND kept by drop3
-        dw1 = _wgrad(rt, w1, dh, xn2)
         db1 = _bgrad(rt, b1, dh)
-        dxn2 = ops.gemm(dh, rt.w(w1), b_kc=False)
         dx1, dn2w, dn2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w.detach(), res=dx2,
                                             dgamma=rt.grad_out(n2w), dbeta=rt.grad_out(n2b))
         # ---- conditioning adds ----
@@ -289,10 +314,12 @@ class MaskedCEFn(torch.autograd.Function):
     """mean over rows with w != 0 of CE(logits[row], target[row]); logits2d: [n_tok, group*C] row-major view."""
 
     @staticmethod
-    def forward(ctx, logits2d, target, w, C_, group, count_override):
+    def forward(ctx, logits2d, target, w, C_, group, count_fn):
         lse, sc = ops.masked_ce_fwd(logits2d, target, w, C_, group)
-        if count_override is not None:      # data-parallel: normalise by the global count (see trainer)
-            sc = torch.stack([sc[0], count_override.to(sc.dtype).reshape(())])
+        if count_fn is not None:
+            # data-parallel: replace the local count by (global count / world) so that the rank-averaged
+            # gradient equals the gradient of the global mean (deepsvg_amd/trainer.py)
+            sc = torch.stack([sc[0], count_fn(sc[1].clone()).to(sc.dtype).reshape(())])
         ctx.C_, ctx.group = C_, group
         ctx.save_for_backward(logits2d, target, w, lse, sc)
         loss = sc[0] / sc[1]

@@ -1,0 +1,68 @@
+"""Drop-in for deepsvg.model.loss.SVGLoss (deepsvg/model/loss.py:11-65): same constructor, same
+forward(output, labels, weights) -> {"loss", "loss_cmd", "loss_args"[, "loss_visibility"][, "loss_kl"]}.
+
+The three cross-entropies run in the masked-CE HIP kernels (no boolean-mask gathers, no host syncs, static
+shapes -> hipGraph-capturable).  Mask semantics: the `extended` padding mask uses the non-aliased reading of
+deepsvg/model/utils.py:25-28 (mask | mask shifted by 3), see DESIGN.md "loss_cmd mask".
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import functional as Fn
+from .svgtensor import CMD_ARGS_MASK, EOS_ID
+
+
+class SVGLoss(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.args_dim = 2 * cfg.args_dim if cfg.rel_targets else cfg.args_dim + 1
+        self.register_buffer("cmd_args_mask", CMD_ARGS_MASK.clone())
+        self._cam_f32 = None
+        # data-parallel hook (deepsvg_amd/trainer.py): count_reducer(name, local_count) -> global_count / world
+        self.count_reducer = None
+
+    def _cam(self, device):
+        if self._cam_f32 is None or self._cam_f32.device != device:
+            self._cam_f32 = self.cmd_args_mask.to(device=device, dtype=torch.float32).contiguous()
+        return self._cam_f32
+
+    def forward(self, output, labels=None, weights=None):
+        cfg = self.cfg
+        loss = 0.0
+        res = {}
+        if cfg.use_vae:
+            # KL term (loss.py:24-30): N x dim_z elementwise math on the fp32 mu/logsigma, left to torch
+            mu, logsigma = output["mu"].float(), output["logsigma"].float()
+            loss_kl = -0.5 * torch.mean(1 + logsigma - mu.pow(2) - torch.exp(logsigma))
+            loss_kl = loss_kl.clamp(min=weights["kl_tolerance"])
+            loss = loss + weights["loss_kl_weight"] * loss_kl
+            res["loss_kl"] = loss_kl
+
+        tgt_commands, tgt_args = output["tgt_commands"], output["tgt_args"]
+        command_logits, args_logits = output["command_logits"], output["args_logits"]
+        device = command_logits.device
+        N, G, S1 = tgt_commands.shape
+        n_args = tgt_args.shape[-1]
+        S = S1 - 1
+        tc = tgt_commands.to(device=device, dtype=torch.float32).contiguous().view(N * G, S1)
+        ta = tgt_args.to(device=device, dtype=torch.float32).contiguous().view(N * G, S1, n_args)
+        cmd_tgt, cmd_w, arg_tgt, arg_w, vis_tgt = ops.loss_targets(tc, ta, self._cam(device), EOS_ID)
+
+        red = self.count_reducer
+        if cfg.decode_stages == 2:
+            vl = output["visibility_logits"].reshape(N * G, 2)
+            loss_visibility, sc_v = Fn.MaskedCEFn.apply(vl, vis_tgt, None, 2, 1, (lambda c: red("vis", c)) if red else None)
+            loss = loss + weights["loss_visibility_weight"] * loss_visibility
+            res["loss_visibility"] = loss_visibility
+
+        cl = command_logits.reshape(N * G * S, cfg.n_commands)
+        al = args_logits.reshape(N * G * S, n_args * self.args_dim)
+        loss_cmd, sc_c = Fn.MaskedCEFn.apply(cl, cmd_tgt.view(-1), cmd_w.view(-1), cfg.n_commands, 1,
+                                             (lambda c: red("cmd", c)) if red else None)
+        loss_args, sc_a = Fn.MaskedCEFn.apply(al, arg_tgt.view(-1), arg_w.view(-1), self.args_dim, n_args,
+                                              (lambda c: red("args", c)) if red else None)
+        loss = loss + weights["loss_cmd_weight"] * loss_cmd + weights["loss_args_weight"] * loss_args
+        res.update({"loss": loss, "loss_cmd": loss_cmd, "loss_args": loss_args})
+        return res

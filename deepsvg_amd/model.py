@@ -1,0 +1,480 @@
+"""MI355X-native SVGTransformer: same constructor, forward signature, result dict and state_dict layout as
+deepsvg.model.model.SVGTransformer (deepsvg/model/model.py:288-479), so cfg.make_model() can return it and the
+reference trainer (deepsvg/train.py) and checkpoints work unchanged.  The sub-modules below are parameter
+containers whose names mirror the reference's; all arithmetic runs in the gfx950 kernels behind
+deepsvg_amd.functional / deepsvg_amd.ops.
+
+Internal layout: token-major activations [n_seq * S, d] with the batch-first order of the inputs
+((n, g, s) -> row (n*G + g)*S + s), i.e. the (N, G, S, d) layout; the reference's seq-first permutes and
+g*N+n packing (deepsvg/utils/utils.py:20-49) never happen.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import functional as Fn
+from .svgtensor import CMD_ARGS_MASK, EOS_ID, M_ID, SOS_ID
+
+PE_DROPOUT = 0.1  # hard-wired in PositionalEncodingLUT (deepsvg/model/layers/positional_encoding.py:26-28)
+
+
+# ----------------------------------------------------------------------------------------------------
+# parameter containers (names == reference state_dict keys)
+# ----------------------------------------------------------------------------------------------------
+class _PosLUT(nn.Module):
+    """PositionalEncodingLUT (positional_encoding.py:24-43): `pos_embed.weight` + `position` buffer"""
+
+    def __init__(self, d_model, max_len):
+        super().__init__()
+        self.register_buffer("position", torch.arange(0, max_len, dtype=torch.long).unsqueeze(1))
+        self.pos_embed = nn.Embedding(max_len, d_model)
+        nn.init.kaiming_normal_(self.pos_embed.weight, mode="fan_in")
+
+
+class _SVGEmbedding(nn.Module):
+    """SVGEmbedding (model.py:16-44)"""
+
+    def __init__(self, cfg, seq_len, rel_args=False, use_group=True, group_len=None):
+        super().__init__()
+        self.command_embed = nn.Embedding(cfg.n_commands, cfg.d_model)
+        args_dim = 2 * cfg.args_dim if rel_args else cfg.args_dim + 1
+        self.arg_embed = nn.Embedding(args_dim, 64)
+        self.embed_fcn = nn.Linear(64 * cfg.n_args, cfg.d_model)
+        self.use_group = use_group
+        if use_group:
+            if group_len is None:
+                group_len = cfg.max_num_groups
+            self.group_embed = nn.Embedding(group_len + 2, cfg.d_model)
+        self.pos_encoding = _PosLUT(cfg.d_model, max_len=seq_len + 2)
+        nn.init.kaiming_normal_(self.command_embed.weight, mode="fan_in")
+        nn.init.kaiming_normal_(self.arg_embed.weight, mode="fan_in")
+        nn.init.kaiming_normal_(self.embed_fcn.weight, mode="fan_in")
+        if use_group:
+            nn.init.kaiming_normal_(self.group_embed.weight, mode="fan_in")
+
+
+class _ConstEmbedding(nn.Module):
+    """ConstEmbedding (model.py:60-73)"""
+
+    def __init__(self, cfg, seq_len):
+        super().__init__()
+        self.seq_len = seq_len
+        self.PE = _PosLUT(cfg.d_model, max_len=seq_len)
+
+
+class _SelfAttn(nn.Module):
+    """MultiheadAttention parameters (layers/attention.py:46-99)"""
+
+    def __init__(self, d_model):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = nn.Linear(d_model, d_model)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+
+class _Layer(nn.Module):
+    """TransformerEncoderLayerImproved / TransformerDecoderLayerGlobalImproved parameters
+    (layers/improved_transformer.py:16-34,97-119)"""
+
+    def __init__(self, d_model, dim_ff, d_global=None, d_global2=None):
+        super().__init__()
+        self.self_attn = _SelfAttn(d_model)
+        if d_global is not None:
+            self.linear_global = nn.Linear(d_global, d_model)
+        if d_global2 is not None:
+            self.linear_global2 = nn.Linear(d_global2, d_model)
+        self.linear1 = nn.Linear(d_model, dim_ff)
+        self.linear2 = nn.Linear(dim_ff, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+
+class _Stack(nn.Module):
+    """TransformerEncoder / TransformerDecoder (layers/transformer.py:146-242): `layers.{i}` + final `norm`.
+    Like the reference's _get_clones (transformer.py:383-384) all layers start from identical weights."""
+
+    def __init__(self, n_layers, d_model, dim_ff, d_global=None, d_global2=None):
+        super().__init__()
+        proto = _Layer(d_model, dim_ff, d_global, d_global2)
+        layers = [proto]
+        for _ in range(n_layers - 1):
+            clone = _Layer(d_model, dim_ff, d_global, d_global2)
+            clone.load_state_dict(proto.state_dict())
+            layers.append(clone)
+        self.layers = nn.ModuleList(layers)
+        self.norm = nn.LayerNorm(d_model)
+
+
+class _FCN(nn.Module):
+    def __init__(self, d_model, n_commands, n_args, args_dim):
+        super().__init__()
+        self.command_fcn = nn.Linear(d_model, n_commands)
+        self.args_fcn = nn.Linear(d_model, n_args * args_dim)
+
+
+class _HierarchFCN(nn.Module):
+    def __init__(self, d_model, dim_z):
+        super().__init__()
+        self.visibility_fcn = nn.Linear(d_model, 2)
+        self.z_fcn = nn.Linear(d_model, dim_z)
+
+
+class _ResNet(nn.Module):
+    def __init__(self, d_model):
+        super().__init__()
+        for i in range(1, 5):
+            setattr(self, f"linear{i}", nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU()))
+
+
+class _VAE(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.enc_mu_fcn = nn.Linear(cfg.d_model, cfg.dim_z)
+        self.enc_sigma_fcn = nn.Linear(cfg.d_model, cfg.dim_z)
+        nn.init.normal_(self.enc_mu_fcn.weight, std=0.001)
+        nn.init.constant_(self.enc_mu_fcn.bias, 0)
+        nn.init.normal_(self.enc_sigma_fcn.weight, std=0.001)
+        nn.init.constant_(self.enc_sigma_fcn.bias, 0)
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.bottleneck = nn.Linear(cfg.d_model, cfg.dim_z)
+
+
+class _LabelEmbedding(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.label_embedding = nn.Embedding(cfg.n_labels, cfg.dim_label)
+        nn.init.kaiming_normal_(self.label_embedding.weight, mode="fan_in")
+
+
+class _Encoder(nn.Module):
+    """Encoder parameters (model.py:92-119)"""
+
+    def __init__(self, cfg):
+        super().__init__()
+        seq_len = cfg.max_seq_len if cfg.encode_stages == 2 else cfg.max_total_len
+        self.use_group = cfg.encode_stages == 1
+        self.embedding = _SVGEmbedding(cfg, seq_len, use_group=self.use_group)
+        if cfg.label_condition:
+            self.label_embedding = _LabelEmbedding(cfg)
+        dim_label = cfg.dim_label if cfg.label_condition else None
+        self.encoder = _Stack(cfg.n_layers, cfg.d_model, cfg.dim_feedforward, None, dim_label)
+        if cfg.encode_stages == 2:
+            if not cfg.self_match:
+                self.hierarchical_PE = _PosLUT(cfg.d_model, max_len=cfg.max_num_groups)
+            self.hierarchical_encoder = _Stack(cfg.n_layers, cfg.d_model, cfg.dim_feedforward, None, dim_label)
+
+
+class _Decoder(nn.Module):
+    """Decoder parameters (model.py:200-236), one-shot prediction mode"""
+
+    def __init__(self, cfg, args_dim):
+        super().__init__()
+        if cfg.label_condition:
+            self.label_embedding = _LabelEmbedding(cfg)
+        dim_label = cfg.dim_label if cfg.label_condition else None
+        if cfg.decode_stages == 2:
+            self.hierarchical_embedding = _ConstEmbedding(cfg, cfg.num_groups_proposal)
+            self.hierarchical_decoder = _Stack(cfg.n_layers_decode, cfg.d_model, cfg.dim_feedforward, cfg.dim_z, dim_label)
+            self.hierarchical_fcn = _HierarchFCN(cfg.d_model, cfg.dim_z)
+        seq_len = cfg.max_seq_len + 1 if cfg.decode_stages == 2 else cfg.max_total_len + 1
+        self.embedding = _ConstEmbedding(cfg, seq_len)
+        self.decoder = _Stack(cfg.n_layers_decode, cfg.d_model, cfg.dim_feedforward, cfg.dim_z, dim_label)
+        self.fcn = _FCN(cfg.d_model, cfg.n_commands, cfg.n_args, args_dim)
+
+
+# ----------------------------------------------------------------------------------------------------
+# flat parameter / gradient storage
+# ----------------------------------------------------------------------------------------------------
+class ParamStore:
+    """Keeps every parameter of a module as a view of one contiguous fp32 buffer (8-element aligned slots),
+    plus a bf16 image of the same layout and flat gradient buffers.  One RCCL all-reduce, one grad-norm and one
+    AdamW launch then cover the whole model (deepsvg_amd/trainer.py)."""
+
+    ALIGN = 8
+
+    def __init__(self, module):
+        self.module = module
+        self.flat = None
+        self.flat_lp = None
+        self.gbuf = [None, None]
+        self.index = {}          # id(param) -> (offset, numel, shape)
+        self.params = []
+        self.total = 0
+
+    def _flatten(self, device):
+        params = [p for p in self.module.parameters()]
+        off = 0
+        index = {}
+        for p in params:
+            index[id(p)] = (off, p.numel(), tuple(p.shape))
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        total = off
+        flat = torch.zeros(total + 64, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for p in params:
+                o, n, shape = index[id(p)]
+                view = flat[o:o + n].view(shape)
+                view.copy_(p.data)
+                p.data = view
+        self.flat, self.index, self.params, self.total = flat, index, params, total
+        self.flat_lp = None
+        self.gbuf = [None, None]
+
+    def ensure(self, device, dtype):
+        params = self.params
+        stale = self.flat is None or self.flat.device != device or not params
+        if not stale:
+            first, last = params[0], params[-1]
+            base = self.flat.data_ptr()
+            stale = (first.data_ptr() != base + 4 * self.index[id(first)][0] or
+                     last.data_ptr() != base + 4 * self.index[id(last)][0])
+        if stale:
+            self._flatten(device)
+        if dtype != torch.float32:
+            if self.flat_lp is None or self.flat_lp.dtype != dtype:
+                self.flat_lp = torch.empty(self.flat.numel(), dtype=dtype, device=device)
+            ops.cast_weights(self.flat, self.flat_lp)
+
+    def lp(self, param):
+        ent = self.index.get(id(param))
+        if ent is None or self.flat_lp is None:
+            return None
+        o, n, shape = ent
+        return self.flat_lp[o:o + n].view(shape)
+
+    def grad_buffer(self, which=0):
+        if self.gbuf[which] is None:
+            self.gbuf[which] = torch.zeros(self.flat.numel(), dtype=torch.float32, device=self.flat.device)
+        return self.gbuf[which]
+
+    def grad_view(self, param):
+        ent = self.index.get(id(param))
+        if ent is None:
+            return None
+        o, n, shape = ent
+        v = self.grad_buffer(0)[o:o + n].view(shape)
+        # autograd accumulates into an existing .grad: never hand it a view that aliases that .grad
+        if param.grad is not None and param.grad.data_ptr() == v.data_ptr():
+            v = self.grad_buffer(1)[o:o + n].view(shape)
+        return v
+
+
+def _compute_dtype_default():
+    name = os.environ.get("DSVG_DTYPE", "fp32").lower()
+    return torch.bfloat16 if name in ("bf16", "bfloat16") else torch.float32
+
+
+# ----------------------------------------------------------------------------------------------------
+# the model
+# ----------------------------------------------------------------------------------------------------
+class SVGTransformer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        if cfg.model_type != "transformer":
+            raise NotImplementedError("model_type='lstm' (SketchRNN baseline) is outside the MI355X hot path")
+        if cfg.pred_mode != "one_shot":
+            raise NotImplementedError("autoregressive decoding is not built yet (SURVEY.md §8(f)-3)")
+        if cfg.self_match:
+            raise NotImplementedError("Hungarian self-matching (HierarchicalSelfMatching) is not built yet")
+        if cfg.label_condition:
+            raise NotImplementedError("label conditioning (fonts config) is not built yet")
+        if cfg.d_model // cfg.n_heads != 32 or cfg.d_model % cfg.n_heads:
+            raise NotImplementedError("the attention kernel is specialised for head_dim == 32")
+        self.args_dim = 2 * cfg.args_dim if cfg.rel_targets else cfg.args_dim + 1
+
+        if cfg.encode_stages > 0:
+            self.encoder = _Encoder(cfg)
+            if cfg.use_resnet:
+                self.resnet = _ResNet(cfg.d_model)
+            if cfg.use_vae:
+                self.vae = _VAE(cfg)
+            else:
+                self.bottleneck = _Bottleneck(cfg)
+        self.decoder = _Decoder(cfg, self.args_dim)
+        self.register_buffer("cmd_args_mask", CMD_ARGS_MASK.clone())
+
+        self.compute_dtype = _compute_dtype_default()
+        self._store = ParamStore(self)
+        self._seed = None           # int64[1] device tensor (dropout seed of the current step)
+        self._own_seed = True       # advance the seed on every training forward unless a trainer drives it
+
+    # ---- runtime plumbing ------------------------------------------------------------------------
+    def set_compute_dtype(self, dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.compute_dtype = dtype
+        return self
+
+    @property
+    def store(self):
+        return self._store
+
+    def seed_tensor(self, device):
+        if self._seed is None or self._seed.device != device:
+            self._seed = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
+        return self._seed
+
+    def _runtime(self, device):
+        self._store.ensure(device, self.compute_dtype)
+        training = self.training
+        seed = self.seed_tensor(device) if training else None
+        if training and self._own_seed:
+            ops.advance_step_(None, seed)
+        return Fn.Runtime(self.compute_dtype, seed, self._store, training)
+
+    # ---- blocks ----------------------------------------------------------------------------------
+    def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site):
+        cfg = self.cfg
+        for i, L in enumerate(stack.layers):
+            has_g = hasattr(L, "linear_global")
+            x = Fn.LayerFn.apply(
+                rt, x, key_mask, z if has_g else None, None, n_seq, S, cfg.n_heads, cfg.dropout, site + 8 * i,
+                L.norm1.weight, L.norm1.bias, L.self_attn.in_proj_weight, L.self_attn.in_proj_bias,
+                L.self_attn.out_proj.weight, L.self_attn.out_proj.bias, L.norm2.weight, L.norm2.bias,
+                L.linear1.weight, L.linear1.bias, L.linear2.weight, L.linear2.bias,
+                L.linear_global.weight if has_g else None, L.linear_global.bias if has_g else None, None, None)
+        return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps)
+
+    def _encode(self, rt, commands, args):
+        """commands (N, G, S) / args (N, G, S, n_args) float32, batch-first  ->  z [N, d_model]"""
+        cfg = self.cfg
+        enc = self.encoder
+        N, G, S = commands.shape
+        cmd = commands.to(torch.float32).contiguous().view(N * G, S)
+        arg = args.to(torch.float32).contiguous().view(N * G * S, -1)
+        two = cfg.encode_stages == 2
+        key_mask, _vis, group_mask = ops.build_masks(cmd, S, G, EOS_ID, want_group_mask=two)
+        emb = enc.embedding
+        groups = ops.group_index(cmd, S, M_ID) if enc.use_group else None
+        src = Fn.EmbedFn.apply(rt, cmd.view(-1), arg, groups, N * G, S, PE_DROPOUT, 1,
+                               emb.command_embed.weight, emb.arg_embed.weight, emb.embed_fcn.weight,
+                               emb.embed_fcn.bias, emb.pos_encoding.pos_embed.weight,
+                               emb.group_embed.weight if enc.use_group else None)
+        mem = self._run_stack(rt, enc.encoder, src, key_mask, None, N * G, S, 100)
+        z = Fn.MaskedMeanFn.apply(rt, mem, key_mask, N * G, S)          # [N*G, d]
+        if two:
+            src2 = Fn.AddPosFn.apply(rt, z, enc.hierarchical_PE.pos_embed.weight, N, G, PE_DROPOUT, 2)
+            mem2 = self._run_stack(rt, enc.hierarchical_encoder, src2, group_mask, None, N, G, 200)
+            z = Fn.MaskedMeanFn.apply(rt, mem2, group_mask, N, G)       # [N, d]
+        return z
+
+    def _bottleneck(self, rt, z):
+        cfg = self.cfg
+        mu = logsigma = None
+        if cfg.use_resnet:
+            for i in range(1, 5):
+                lin = getattr(self.resnet, f"linear{i}")[0]
+                z = Fn.ResBlockFn.apply(rt, z, lin.weight, lin.bias)
+        if cfg.use_vae:
+            mu = Fn.LinearFn.apply(rt, z, self.vae.enc_mu_fcn.weight, self.vae.enc_mu_fcn.bias, 0, None, 0.0, 0,
+                                   torch.float32)
+            logsigma = Fn.LinearFn.apply(rt, z, self.vae.enc_sigma_fcn.weight, self.vae.enc_sigma_fcn.bias, 0, None,
+                                         0.0, 0, torch.float32)
+            # reparametrisation (model.py:184-185): N x dim_z elementwise + randn, left to torch (not a hot op)
+            sigma = torch.exp(logsigma / 2.0)
+            z = (mu + sigma * torch.randn_like(sigma)).to(rt.dtype)
+        else:
+            z = Fn.LinearFn.apply(rt, z, self.bottleneck.bottleneck.weight, self.bottleneck.bottleneck.bias, 0, None,
+                                  0.0, 0, None)
+        return z, mu, logsigma
+
+    def _decode(self, rt, z):
+        """z [N, dim_z] -> command_logits (N,G,S,n_cmd), args_logits (N,G,S,n_args,args_dim)[, visibility (N,G,1,2)]"""
+        cfg = self.cfg
+        dec = self.decoder
+        N = z.shape[0]
+        vis_logits = None
+        if cfg.decode_stages == 2:
+            G = cfg.num_groups_proposal
+            src = Fn.AddPosFn.apply(rt, None, dec.hierarchical_embedding.PE.pos_embed.weight, N, G, PE_DROPOUT, 3)
+            out = self._run_stack(rt, dec.hierarchical_decoder, src, None, z, N, G, 300)
+            hf = dec.hierarchical_fcn
+            vis_logits = Fn.LinearFn.apply(rt, out, hf.visibility_fcn.weight, hf.visibility_fcn.bias, 0, None, 0.0, 0,
+                                           None)
+            z = Fn.LinearFn.apply(rt, out, hf.z_fcn.weight, hf.z_fcn.bias, 0, None, 0.0, 0, None)   # [N*G, dim_z]
+            n_seq = N * G
+        else:
+            G = 1
+            n_seq = N
+        S = dec.embedding.seq_len
+        src = Fn.AddPosFn.apply(rt, None, dec.embedding.PE.pos_embed.weight, n_seq, S, PE_DROPOUT, 4)
+        out = self._run_stack(rt, dec.decoder, src, None, z, n_seq, S, 400)
+        cmd_logits = Fn.LinearFn.apply(rt, out, dec.fcn.command_fcn.weight, dec.fcn.command_fcn.bias, 0, None, 0.0, 0,
+                                       None)
+        args_logits = Fn.LinearFn.apply(rt, out, dec.fcn.args_fcn.weight, dec.fcn.args_fcn.bias, 0, None, 0.0, 0, None)
+        cmd_logits = cmd_logits.view(N, G, S, cfg.n_commands)
+        args_logits = args_logits.view(N, G, S, cfg.n_args, self.args_dim)
+        if vis_logits is not None:
+            vis_logits = vis_logits.view(N, G, 1, 2)
+        return cmd_logits, args_logits, vis_logits
+
+    # ---- public surface (model.py:352-412) ---------------------------------------------------------
+    def forward(self, commands_enc, args_enc, commands_dec, args_dec, label=None, z=None, hierarch_logits=None,
+                return_tgt=True, params=None, encode_mode=False, return_hierarch=False):
+        cfg = self.cfg
+        if hierarch_logits is not None or return_hierarch:
+            raise NotImplementedError("hierarch_logits / return_hierarch (GUI path) is not built yet")
+        ref = commands_enc if commands_enc is not None else z
+        device = ref.device
+        ops.require_device(device)
+        rt = self._runtime(device)
+        mu = logsigma = None
+        if z is None:
+            zz = self._encode(rt, commands_enc, args_enc)
+            zz, mu, logsigma = self._bottleneck(rt, zz)
+        else:
+            # externally supplied z is batch-first (N, 1, 1, dim_z)  (model.py:369)
+            zz = z.reshape(z.shape[0], -1).to(rt.dtype).contiguous()
+        if encode_mode:
+            return zz.to(torch.float32).view(1, 1, zz.shape[0], zz.shape[1])   # seq-first, as model.py:371
+        cmd_logits, args_logits, vis_logits = self._decode(rt, zz)
+        res = {"command_logits": cmd_logits, "args_logits": args_logits}
+        if cfg.decode_stages == 2:
+            res["visibility_logits"] = vis_logits
+        if return_tgt:
+            res["tgt_commands"] = commands_dec
+            res["tgt_args"] = args_dec
+            if cfg.use_vae and mu is not None:
+                res["mu"] = mu.view(mu.shape[0], 1, 1, -1)
+                res["logsigma"] = logsigma.view(logsigma.shape[0], 1, 1, -1)
+        return res
+
+    # ---- sampling (model.py:414-459; inference-only host glue on the logits) -------------------------
+    @torch.no_grad()
+    def greedy_sample(self, commands_enc=None, args_enc=None, commands_dec=None, args_dec=None, label=None,
+                      z=None, hierarch_logits=None, concat_groups=True, temperature=0.0001):
+        res = self.forward(commands_enc, args_enc, commands_dec, args_dec, label=label, z=z,
+                           hierarch_logits=hierarch_logits, return_tgt=False)
+        cl, al = res["command_logits"].float(), res["args_logits"].float()
+        commands_y = torch.distributions.Categorical(logits=cl / temperature).sample()
+        args_y = torch.distributions.Categorical(logits=al / temperature).sample()
+        args_y -= 1   # shift due to -1 PAD_VAL
+        visibility_y = None
+        if self.cfg.decode_stages == 2:
+            scores = torch.softmax(res["visibility_logits"].float(), dim=-1)[..., 1]
+            visibility_y = (scores > 0.7).squeeze(-1)
+        commands_y, args_y = self._make_valid(commands_y, args_y, visibility_y)
+        if concat_groups:
+            N = commands_y.size(0)
+            pm = ((commands_y == EOS_ID).cumsum(dim=-1) == 0)
+            commands_y = commands_y[pm].reshape(N, -1)
+            args_y = args_y[pm].reshape(N, -1, self.cfg.n_args)
+        return commands_y, args_y
+
+    def _make_valid(self, commands_y, args_y, visibility_y=None, PAD_VAL=-1):
+        if visibility_y is not None:
+            S = commands_y.size(-1)
+            commands_y[~visibility_y] = commands_y.new_tensor([M_ID, *[EOS_ID] * (S - 1)])
+            args_y[~visibility_y] = PAD_VAL
+        mask = self.cmd_args_mask[commands_y.long()].bool()
+        args_y[~mask] = PAD_VAL
+        return commands_y, args_y

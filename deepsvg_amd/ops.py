@@ -10,6 +10,27 @@ from . import lib as _l
 F32, BF16 = _l.DSVG_F32, _l.DSVG_BF16
 RELU = 1
 
+# optional per-launch timing of tagged GEMMs (bench.py roofline leg): HIP events on the launch stream
+PROFILE_ON = False
+PROFILE = []          # (tag, start_event, end_event)
+_TAG = None
+
+
+class tag:
+    """with ops.tag("ffn"): ...  labels the GEMM launches inside for the profiler"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global _TAG
+        self.prev, _TAG = _TAG, self.name
+
+    def __exit__(self, *exc):
+        global _TAG
+        _TAG = self.prev
+        return False
+
 
 def _dt(t):
     if t.dtype == torch.float32:
@@ -25,6 +46,13 @@ def _chk(*ts):
             continue
         if not t.is_cuda:
             raise _l.DsvgError("deepsvg_amd ops need HIP device tensors (no CPU fallback)")
+
+
+def require_device(device):
+    if torch.device(device).type != "cuda":
+        raise _l.DsvgError("deepsvg_amd runs on a HIP device only (no CPU fallback): move the model and its "
+                           "inputs to 'cuda'")
+    _l.load()
 
 
 def _p(t):
@@ -93,6 +121,13 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
         nbytes = _l.load().dsvg_gemm_workspace_bytes(M, N, split_k)
         ws = _ws(nbytes, a.device)
         d.split_k, d.workspace, d.workspace_bytes = split_k, ws.data_ptr(), ws.numel() * 4
+    if PROFILE_ON and _TAG is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        _l.check(_l.load().dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
+        ev1.record()
+        PROFILE.append((_TAG, ev0, ev1))
+        return out
     _l.check(_l.load().dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
     return out
 
@@ -426,6 +461,14 @@ def gate_mul(dy, y, scale=1.0):
     out = torch.empty_like(dy)
     _l.check(_l.load().dsvg_gate_mul(_dt(dy), dy.data_ptr(), y.data_ptr(), out.data_ptr(), dy.numel(), float(scale),
                                      _stream()), "dsvg_gate_mul")
+    return out
+
+
+def add(a, b):
+    _chk(a, b)
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and a.dtype == b.dtype
+    out = torch.empty_like(a)
+    _l.check(_l.load().dsvg_add(_dt(a), a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "dsvg_add")
     return out
 
 

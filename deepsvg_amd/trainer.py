@@ -1,0 +1,114 @@
+"""Data-parallel training step for the MI355X build: the body of deepsvg/train.py:92-106
+(zero_grad, forward, SVGLoss, backward, clip_grad_norm_, AdamW.step) as one static sequence of HIP launches on
+flat buffers, one process per GPU.
+
+  * parameters, gradients and Adam moments each live in ONE contiguous fp32 buffer (ParamStore), so the
+    gradient exchange is one RCCL all-reduce (10.3 M floats = 41 MB over xGMI, replacing nn.DataParallel's
+    broadcast/scatter/gather/reduce_add of deepsvg/train.py:74), the global-norm clip is one reduction and
+    AdamW is one launch;
+  * the per-rank mean losses are re-normalised by the GLOBAL selected-element counts (three scalars), so the
+    averaged gradient equals the gradient of the global-batch mean exactly as in single-process training
+    (SURVEY.md §8(e));
+  * every scalar the kernels need (lr, step, seed, norm, counts) lives in device memory, so the whole step can
+    be captured in a hipGraph and replayed (use_graph=True) to remove the host launch overhead.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+DEFAULT_WEIGHTS = {   # configs/deepsvg/default_icons.py:65-73 at step 0
+    "kl_tolerance": 0.1, "loss_kl_weight": 0.0, "loss_hierarch_weight": 1.0, "loss_cmd_weight": 1.0,
+    "loss_args_weight": 2.0, "loss_visibility_weight": 1.0,
+}
+
+
+class TrainStep:
+    def __init__(self, model, loss_fn, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_clip=1.0,
+                 weights=None, process_group=None, use_graph=False, exact_global_mean=True):
+        self.model, self.loss_fn = model, loss_fn
+        self.betas, self.eps, self.weight_decay, self.grad_clip = betas, eps, weight_decay, grad_clip
+        self.weights = dict(weights or DEFAULT_WEIGHTS)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.use_graph = use_graph
+        self.exact_global_mean = exact_global_mean and self.world > 1
+        self._lr_value = float(lr)
+        self._ready = False
+        self._graph = None
+        self._static = None
+        model._own_seed = False          # the trainer advances the dropout seed once per step
+        if self.exact_global_mean:
+            loss_fn.count_reducer = self._reduce_count
+
+    # ---- lazily created device state -----------------------------------------------------------------
+    def _setup(self, device):
+        model = self.model
+        model.store.ensure(device, model.compute_dtype)
+        n = model.store.flat.numel()
+        self.m = torch.zeros(n, dtype=torch.float32, device=device)
+        self.v = torch.zeros(n, dtype=torch.float32, device=device)
+        self.lr = torch.full((1,), self._lr_value, dtype=torch.float32, device=device)
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=device)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=device)
+        self.seed = model.seed_tensor(device)
+        self._ready = True
+
+    def set_lr(self, lr):
+        self._lr_value = float(lr)
+        if self._ready:
+            self.lr.fill_(self._lr_value)
+
+    def _reduce_count(self, name, count):
+        dist.all_reduce(count, group=self.pg)
+        return count / self.world
+
+    # ---- one step ------------------------------------------------------------------------------------
+    def _step_body(self, commands, args):
+        model = self.model
+        ops.advance_step_(self.step_count, self.seed)
+        for p in model.store.params:
+            p.grad = None
+        out = model(commands, args, commands, args, params={})
+        ld = self.loss_fn(out, None, weights=self.weights)
+        ld["loss"].backward()
+        flat_g = model.store.grad_buffer(0)
+        if self.world > 1:
+            dist.all_reduce(flat_g, group=self.pg)
+        ops.sumsq(flat_g, out=self.gnorm_sq)
+        ops.adamw_step_(model.store.flat, flat_g, self.m, self.v, self.lr, self.step_count,
+                        beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay,
+                        gnorm_sq=self.gnorm_sq if self.grad_clip else None, max_norm=float(self.grad_clip or 0.0),
+                        grad_scale=1.0 / self.world)
+        return {k: v.detach() for k, v in ld.items()}
+
+    def step(self, commands, args):
+        if not self._ready:
+            self._setup(commands.device)
+        if not self.use_graph:
+            return self._step_body(commands, args)
+        if self._graph is None:
+            self._capture(commands, args)
+        else:
+            self._static[0].copy_(commands)
+            self._static[1].copy_(args)
+        self._graph.replay()
+        return self._static[2]
+
+    def _capture(self, commands, args):
+        sc, sa = commands.clone(), args.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                      # warm-up: allocator pools, lazy buffers, RCCL communicators
+                self._step_body(sc, sa)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            res = self._step_body(sc, sa)
+        self._graph, self._static = g, (sc, sa, res)
+
+    def grad_norm(self):
+        """global gradient L2 norm of the last step (after the all-reduce averaging)"""
+        return (self.gnorm_sq.sqrt() / self.world).item()

@@ -1,0 +1,311 @@
+"""ORACLE — test infrastructure, not product code.
+
+A plain-PyTorch (CPU, fp32 or fp64) restatement of the reference algorithm for the hot path
+`deepsvg.model.model.SVGTransformer.forward` + `deepsvg.model.loss.SVGLoss.forward` (one-shot transformer
+configs: Hierarchical / OneStageOneShot, with or without VAE).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this file; the product (deepsvg_amd/) never does.
+
+Parity pinning: the reference has no tests or golden vectors of its own, so this restatement is
+pinned against the reference module itself, imported from /root/reference in the build container:
+tests/golden/make_golden.py runs the real deepsvg.model.model.SVGTransformer + SVGLoss on seeded inputs and
+deterministic weights and commits the outputs as tests/golden/*.npz; tests/test_oracle_golden.py checks this
+file against those fixtures (and, when /root/reference is present, against the live reference).
+
+Every function cites the reference lines it restates (paths relative to /root/reference).  The arithmetic
+lives in aten (torch 2.10 here; the reference pins torch==1.4.0, requirements.txt:1); the composition below is
+the in-tree part.
+
+Written functionally on a reference-format state_dict, in the reference's own seq-first layout so that the
+restatement stays line-comparable with the original.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+EOS, SOS, M = 4, 5, 0
+
+# deepsvg/difflib/tensor.py:15-21
+CMD_ARGS_MASK = torch.tensor([[0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1],
+                              [0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1],
+                              [0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1],
+                              [1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1],
+                              [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+                              [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+                              [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]])
+
+
+# ---------------------------------------------------------------------------------------------------
+# masks — deepsvg/model/utils.py
+# ---------------------------------------------------------------------------------------------------
+def key_padding_mask(commands, seq_dim=0):
+    """utils.py:7-17 — True where a key must be ignored (at or after the first EOS)"""
+    m = (commands == EOS).cumsum(dim=seq_dim) > 0
+    return m.transpose(0, 1) if seq_dim == 0 else m
+
+
+def padding_mask(commands, seq_dim=0, extended=False):
+    """utils.py:20-32 — 1.0 on valid (pre-EOS) positions.  `extended`: the reference adds the mask shifted by 3
+    positions IN PLACE on overlapping views (utils.py:28), which is implementation-defined;
+    the canonical non-aliased value clamp(mask + shift3(mask), max=1) is used here."""
+    pm = ((commands == EOS).cumsum(dim=seq_dim) == 0).to(torch.float32)
+    if extended:
+        S = commands.size(seq_dim)
+        shifted = torch.zeros_like(pm)
+        torch.narrow(shifted, seq_dim, 3, S - 3).copy_(torch.narrow(pm, seq_dim, 0, S - 3))
+        pm = (pm + shifted).clamp(max=1)
+    return pm.unsqueeze(-1) if seq_dim == 0 else pm
+
+
+def group_mask(commands, seq_dim=0):
+    """utils.py:35-42"""
+    return (commands == M).cumsum(dim=seq_dim)
+
+
+def visibility_mask(commands, seq_dim=0):
+    """utils.py:45-56"""
+    S = commands.size(seq_dim)
+    m = (commands == EOS).sum(dim=seq_dim) < S - 1
+    return m.unsqueeze(-1) if seq_dim == 0 else m
+
+
+def key_visibility_mask(commands, seq_dim=0):
+    """utils.py:59-66"""
+    S = commands.size(seq_dim)
+    m = (commands == EOS).sum(dim=seq_dim) >= S - 1
+    return m.transpose(0, 1) if seq_dim == 0 else m
+
+
+# ---------------------------------------------------------------------------------------------------
+# layers
+# ---------------------------------------------------------------------------------------------------
+def mha(sd, pre, x, n_heads, kpm=None):
+    """layers/functional.py:8-256 for the self-attention case (q = k = v = x), eval mode.
+    x (L, B, E); kpm (B, L) bool, True = ignore key."""
+    L, B, E = x.shape
+    hd = E // n_heads
+    qkv = F.linear(x, sd[pre + "in_proj_weight"], sd[pre + "in_proj_bias"])            # :92
+    q, k, v = qkv.chunk(3, dim=-1)
+    q = q * (float(hd) ** -0.5)                                                            # :168
+    q = q.contiguous().view(L, B * n_heads, hd).transpose(0, 1)                           # :197-201
+    k = k.contiguous().view(L, B * n_heads, hd).transpose(0, 1)
+    v = v.contiguous().view(L, B * n_heads, hd).transpose(0, 1)
+    w = torch.bmm(q, k.transpose(1, 2))                                                    # :228
+    if kpm is not None:                                                                    # :234-239
+        w = w.view(B, n_heads, L, L).masked_fill(kpm.unsqueeze(1).unsqueeze(2), float("-inf")).view(B * n_heads, L, L)
+    w = F.softmax(w, dim=-1)                                                               # :242
+    o = torch.bmm(w, v)                                                                    # :246
+    o = o.transpose(0, 1).contiguous().view(L, B, E)                                       # :248
+    return F.linear(o, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])             # :249
+
+
+def ln(sd, pre, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[pre + "weight"], sd[pre + "bias"], 1e-5)
+
+
+def encoder_layer(sd, pre, x, n_heads, kpm, memory2=None):
+    """layers/improved_transformer.py:42-54 (dropout = identity)"""
+    x1 = ln(sd, pre + "norm1.", x)
+    x = x + mha(sd, pre + "self_attn.", x1, n_heads, kpm)
+    if memory2 is not None:
+        x = x + F.linear(memory2, sd[pre + "linear_global2.weight"], sd[pre + "linear_global2.bias"])
+    x1 = ln(sd, pre + "norm2.", x)
+    h = F.relu(F.linear(x1, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"]))
+    return x + F.linear(h, sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
+
+
+def decoder_layer(sd, pre, x, memory, n_heads, memory2=None):
+    """layers/improved_transformer.py:126-141 (one-shot: no masks)"""
+    x1 = ln(sd, pre + "norm1.", x)
+    x = x + mha(sd, pre + "self_attn.", x1, n_heads, None)
+    x = x + F.linear(memory, sd[pre + "linear_global.weight"], sd[pre + "linear_global.bias"])   # broadcast over seq
+    if memory2 is not None:
+        x = x + F.linear(memory2, sd[pre + "linear_global2.weight"], sd[pre + "linear_global2.bias"])
+    x1 = ln(sd, pre + "norm2.", x)
+    h = F.relu(F.linear(x1, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"]))
+    return x + F.linear(h, sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
+
+
+def encoder_stack(sd, pre, x, n_layers, n_heads, kpm):
+    """layers/transformer.py:168-188"""
+    for i in range(n_layers):
+        x = encoder_layer(sd, f"{pre}layers.{i}.", x, n_heads, kpm)
+    return ln(sd, pre + "norm.", x)
+
+
+def decoder_stack(sd, pre, x, memory, n_layers, n_heads):
+    """layers/transformer.py:214-242"""
+    for i in range(n_layers):
+        x = decoder_layer(sd, f"{pre}layers.{i}.", x, memory, n_heads)
+    return ln(sd, pre + "norm.", x)
+
+
+# ---------------------------------------------------------------------------------------------------
+# model — deepsvg/model/model.py
+# ---------------------------------------------------------------------------------------------------
+def svg_embedding(sd, pre, commands, args, groups=None):
+    """model.py:46-57 + positional_encoding.py:40-43 (eval).  commands (S, GN), args (S, GN, n_args)"""
+    S, GN = commands.shape
+    src = F.embedding(commands.long(), sd[pre + "command_embed.weight"]) + \
+        F.linear(F.embedding((args + 1).long(), sd[pre + "arg_embed.weight"]).view(S, GN, -1),
+                 sd[pre + "embed_fcn.weight"], sd[pre + "embed_fcn.bias"])
+    if groups is not None:
+        src = src + F.embedding(groups.long(), sd[pre + "group_embed.weight"])
+    return src + sd[pre + "pos_encoding.pos_embed.weight"][:S].unsqueeze(1)
+
+
+def const_embedding(sd, pre, seq_len, n, like):
+    """model.py:70-73"""
+    return sd[pre + "PE.pos_embed.weight"][:seq_len].unsqueeze(1).expand(seq_len, n, -1).to(like.dtype).contiguous()
+
+
+def pack(x):
+    """utils/utils.py:36-41  (S, G, N, ...) -> (S, G*N, ...)"""
+    return x.reshape(x.size(0), x.size(1) * x.size(2), *x.shape[3:])
+
+
+def unpack(N, x):
+    """utils/utils.py:44-49"""
+    return x.reshape(x.size(0), -1, N, *x.shape[2:])
+
+
+def seq_first(x):
+    """utils/utils.py:20-25  (N, G, S, ...) -> (S, G, N, ...)"""
+    return x.permute(2, 1, 0, *range(3, x.dim()))
+
+
+def encode(sd, cfg, commands, args):
+    """Encoder.forward model.py:121-164.  commands (S, G, N) seq-first."""
+    S, G, N = commands.shape
+    two = cfg.encode_stages == 2
+    if two:
+        vis_mask, key_vis_mask = visibility_mask(commands, 0), key_visibility_mask(commands, 0)
+    commands, args = pack(commands), pack(args)
+    pm, kpm = padding_mask(commands, 0).to(args.dtype), key_padding_mask(commands, 0)
+    groups = group_mask(commands, 0) if cfg.encode_stages == 1 else None
+    src = svg_embedding(sd, "encoder.embedding.", commands, args, groups)
+    memory = encoder_stack(sd, "encoder.encoder.", src, cfg.n_layers, cfg.n_heads, kpm)
+    z = (memory * pm).sum(dim=0, keepdim=True) / pm.sum(dim=0, keepdim=True)              # :137
+    z = unpack(N, z)
+    if two:
+        src = pack(z.transpose(0, 1))                                                       # :153-154
+        src = src + sd["encoder.hierarchical_PE.pos_embed.weight"][:src.size(0)].unsqueeze(1)
+        memory = encoder_stack(sd, "encoder.hierarchical_encoder.", src, cfg.n_layers, cfg.n_heads, key_vis_mask)
+        vm = vis_mask.to(memory.dtype)
+        z = (memory * vm).sum(dim=0, keepdim=True) / vm.sum(dim=0, keepdim=True)          # :161
+        z = unpack(N, z)
+    return z                                                                               # (1, 1, N, d)
+
+
+def resnet(sd, z):
+    """basic_blocks.py:59-65"""
+    for i in range(1, 5):
+        z = z + F.relu(F.linear(z, sd[f"resnet.linear{i}.0.weight"], sd[f"resnet.linear{i}.0.bias"]))
+    return z
+
+
+def decode(sd, cfg, z):
+    """Decoder.forward model.py:243-285 (one_shot).  z (1, 1, N, dim_z) -> seq-first logits"""
+    N = z.size(2)
+    z = pack(z)                                                                            # (1, N, dz)
+    hierarch_logits = None
+    if cfg.decode_stages == 2:
+        src = const_embedding(sd, "decoder.hierarchical_embedding.", cfg.num_groups_proposal, N, z)
+        out = decoder_stack(sd, "decoder.hierarchical_decoder.", src, z, cfg.n_layers_decode, cfg.n_heads)
+        hierarch_logits = F.linear(out, sd["decoder.hierarchical_fcn.visibility_fcn.weight"],
+                                   sd["decoder.hierarchical_fcn.visibility_fcn.bias"]).unsqueeze(0)      # basic_blocks.py:36
+        z = F.linear(out, sd["decoder.hierarchical_fcn.z_fcn.weight"],
+                     sd["decoder.hierarchical_fcn.z_fcn.bias"]).unsqueeze(0)                             # :37
+        hierarch_logits, z = pack(hierarch_logits), pack(z)                                 # (1, G*N, .)
+    seq_len = cfg.max_seq_len + 1 if cfg.decode_stages == 2 else cfg.max_total_len + 1
+    src = const_embedding(sd, "decoder.embedding.", seq_len, z.size(1), z)
+    out = decoder_stack(sd, "decoder.decoder.", src, z, cfg.n_layers_decode, cfg.n_heads)
+    S, GN, _ = out.shape
+    command_logits = F.linear(out, sd["decoder.fcn.command_fcn.weight"], sd["decoder.fcn.command_fcn.bias"])
+    args_dim = 2 * cfg.args_dim if cfg.rel_targets else cfg.args_dim + 1
+    args_logits = F.linear(out, sd["decoder.fcn.args_fcn.weight"], sd["decoder.fcn.args_fcn.bias"]) \
+        .reshape(S, GN, cfg.n_args, args_dim)                                               # basic_blocks.py:18-21
+    outs = (command_logits, args_logits) + ((hierarch_logits,) if cfg.decode_stages == 2 else ())
+    return tuple(unpack(N, o) for o in outs)
+
+
+def forward(sd, cfg, commands_enc, args_enc, commands_dec, args_dec, z=None, eps=None, encode_mode=False):
+    """SVGTransformer.forward model.py:352-412, eval semantics (dropout = identity).
+    Inputs batch-first (N, G, S) / (N, G, S, n_args).  `eps` replaces torch.randn_like in the VAE (model.py:185)."""
+    dt = sd["decoder.fcn.command_fcn.weight"].dtype
+    mu = logsigma = None
+    if z is None:
+        ce, ae = seq_first(commands_enc.to(dt)), seq_first(args_enc.to(dt))
+        z = encode(sd, cfg, ce, ae)
+        if cfg.use_resnet:
+            z = resnet(sd, z)
+        if cfg.use_vae:                                                                     # model.py:182-187
+            mu = F.linear(z, sd["vae.enc_mu_fcn.weight"], sd["vae.enc_mu_fcn.bias"])
+            logsigma = F.linear(z, sd["vae.enc_sigma_fcn.weight"], sd["vae.enc_sigma_fcn.bias"])
+            sigma = torch.exp(logsigma / 2.0)
+            z = mu + sigma * (eps.to(dt).view_as(sigma) if eps is not None else torch.randn_like(sigma))
+        else:
+            z = F.linear(z, sd["bottleneck.bottleneck.weight"], sd["bottleneck.bottleneck.bias"])   # :196-197
+    else:
+        z = seq_first(z.to(dt))
+    if encode_mode:
+        return z
+    outs = decode(sd, cfg, z)
+    outs = tuple(seq_first(o) for o in outs)                                                # _make_batch_first
+    res = {"command_logits": outs[0], "args_logits": outs[1]}
+    if cfg.decode_stages == 2:
+        res["visibility_logits"] = outs[2]
+    res["tgt_commands"], res["tgt_args"] = commands_dec, args_dec
+    if mu is not None:
+        res["mu"], res["logsigma"] = seq_first(mu), seq_first(logsigma)
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------
+# loss — deepsvg/model/loss.py:19-65
+# ---------------------------------------------------------------------------------------------------
+def svg_loss(cfg, output, weights):
+    loss = 0.0
+    res = {}
+    if cfg.use_vae:                                                                         # :24-30
+        mu, logsigma = output["mu"], output["logsigma"]
+        loss_kl = -0.5 * torch.mean(1 + logsigma - mu.pow(2) - torch.exp(logsigma))
+        loss_kl = loss_kl.clamp(min=weights["kl_tolerance"])
+        loss = loss + weights["loss_kl_weight"] * loss_kl
+        res["loss_kl"] = loss_kl
+    tgt_commands, tgt_args = output["tgt_commands"], output["tgt_args"]
+    vis = visibility_mask(tgt_commands, seq_dim=-1)                                         # :35
+    pm = padding_mask(tgt_commands, seq_dim=-1, extended=True) * vis.unsqueeze(-1)          # :36
+    command_logits, args_logits = output["command_logits"], output["args_logits"]
+    args_dim = 2 * cfg.args_dim if cfg.rel_targets else cfg.args_dim + 1
+    if cfg.decode_stages == 2:                                                              # :41-46
+        lv = F.cross_entropy(output["visibility_logits"].reshape(-1, 2), vis.reshape(-1).long())
+        loss = loss + weights["loss_visibility_weight"] * lv
+        res["loss_visibility"] = lv
+    tgt_commands, tgt_args, pm = tgt_commands[..., 1:], tgt_args[..., 1:, :], pm[..., 1:]   # :49
+    mask = CMD_ARGS_MASK.to(tgt_commands.device)[tgt_commands.long()]                       # :51
+    loss_cmd = F.cross_entropy(command_logits[pm.bool()].reshape(-1, cfg.n_commands),
+                               tgt_commands[pm.bool()].reshape(-1).long())                  # :53
+    loss_args = F.cross_entropy(args_logits[mask.bool()].reshape(-1, args_dim),
+                                tgt_args[mask.bool()].reshape(-1).long() + 1)               # :54
+    loss = loss + weights["loss_cmd_weight"] * loss_cmd + weights["loss_args_weight"] * loss_args   # :56-57
+    res.update({"loss": loss, "loss_cmd": loss_cmd, "loss_args": loss_args})
+    return res
+
+
+DEFAULT_WEIGHTS = {   # configs/deepsvg/default_icons.py:65-73 at step 0
+    "kl_tolerance": 0.1, "loss_kl_weight": 0.0, "loss_hierarch_weight": 1.0, "loss_cmd_weight": 1.0,
+    "loss_args_weight": 2.0, "loss_visibility_weight": 1.0,
+}
+
+
+def loss_and_grads(sd, cfg, commands, args, weights=None, eps=None):
+    """forward + SVGLoss + autograd backward (the body of deepsvg/train.py:94-98 with dropout p = 0).
+    Returns (output dict, loss dict, {name: grad})."""
+    weights = weights or DEFAULT_WEIGHTS
+    leaves = {k: v.detach().clone().requires_grad_(torch.is_floating_point(v)) for k, v in sd.items()}
+    out = forward(leaves, cfg, commands, args, commands, args, eps=eps)
+    ld = svg_loss(cfg, out, weights)
+    names = [k for k, v in leaves.items() if v.requires_grad]
+    grads = torch.autograd.grad(ld["loss"], [leaves[k] for k in names], allow_unused=True)
+    return out, ld, {k: g for k, g in zip(names, grads)}

@@ -1,0 +1,164 @@
+"""Generates tests/golden/*.npz by running the REAL reference (imported read-only from /root/reference) on
+seeded synthetic inputs with deterministic weights.  Run in the build container only:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is stored (small enough to commit): the inputs, the weight seed, full command/visibility logits, a strided
+sample + checksums of args_logits, the latent z, every loss term, and per-parameter gradient norms + a 16-value
+sample of each gradient.  Weights are NOT stored: deepsvg_amd.synthetic.det_state_dict(seed) regenerates them.
+
+loss_cmd: the reference's `_get_padding_mask(extended=True)` adds overlapping views in place
+(deepsvg/model/utils.py:28), whose result is implementation-defined.  Two values are
+recorded: `loss_cmd_ref_aliased` (the unmodified reference on this CPU) and `loss_cmd` / `loss` / the
+gradients with `_get_padding_mask` patched to the non-aliased semantics (clone before add).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from deepsvg.model.model import SVGTransformer as RefModel          # noqa: E402
+from deepsvg.model.loss import SVGLoss as RefLoss                    # noqa: E402
+import deepsvg.model.loss as ref_loss_mod                            # noqa: E402
+import deepsvg.model.model as ref_model_mod                          # noqa: E402
+from deepsvg.model import config as ref_cfg                          # noqa: E402
+from deepsvg.difflib.tensor import SVGTensor                         # noqa: E402
+
+from deepsvg_amd.synthetic import make_batch, make_batch_onestage, det_state_dict   # noqa: E402
+from oracle import svg_transformer_oracle as O                        # noqa: E402
+
+WEIGHTS = dict(O.DEFAULT_WEIGHTS)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _canonical_padding_mask(commands, seq_dim=0, extended=False):
+    with torch.no_grad():
+        pm = (commands == SVGTensor.COMMANDS_SIMPLIFIED.index("EOS")).cumsum(dim=seq_dim) == 0
+        pm = pm.float()
+        if extended:
+            S = commands.size(seq_dim)
+            src = torch.narrow(pm, seq_dim, 0, S - 3).clone()
+            torch.narrow(pm, seq_dim, 3, S - 3).add_(src).clamp_(max=1)
+        return pm.unsqueeze(-1) if seq_dim == 0 else pm
+
+
+def build_cfg(kind):
+    if kind == "hier":
+        cfg = ref_cfg.Hierarchical()
+        cfg.use_vae = False
+    elif kind == "hier_vae":
+        cfg = ref_cfg.Hierarchical()
+    elif kind == "onestage":
+        cfg = ref_cfg.OneStageOneShot()
+        cfg.max_total_len = 50
+        cfg.use_vae = False
+    else:
+        raise ValueError(kind)
+    return cfg
+
+
+def run_case(name, kind, n, seed, wseed):
+    torch.manual_seed(0)
+    cfg = build_cfg(kind)
+    model = RefModel(cfg)
+    sd = det_state_dict(model, seed=wseed)
+    model.load_state_dict(sd)
+    if kind == "onestage":
+        commands, args = make_batch_onestage(n, total_len=cfg.max_total_len, seed=seed)
+    else:
+        commands, args = make_batch(n, G=cfg.max_num_groups, S=cfg.max_seq_len, seed=seed)
+    eps = None
+    if cfg.use_vae:
+        g = torch.Generator().manual_seed(seed + 77)
+        eps = torch.randn(1, 1, n, cfg.dim_z, generator=g)
+        ref_model_mod.torch.randn_like = lambda t: eps.to(t.dtype)      # model.py:185
+    try:
+        # ---- eval forward: logits ----
+        model.eval()
+        with torch.no_grad():
+            out = model(commands, args, commands, args, params={})
+            z = model(commands, args, commands, args, encode_mode=True)
+        # ---- train mode, every dropout p = 0: loss + grads ----
+        model.train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
+                m.dropout = 0.0
+        loss_fn = RefLoss(cfg)
+        out_t = model(commands, args, commands, args, params={})
+        ld_alias = loss_fn(out_t, None, weights=WEIGHTS)
+        orig = ref_loss_mod._get_padding_mask
+        ref_loss_mod._get_padding_mask = _canonical_padding_mask
+        try:
+            model.zero_grad()
+            out_t = model(commands, args, commands, args, params={})
+            ld = loss_fn(out_t, None, weights=WEIGHTS)
+            ld["loss"].backward()
+        finally:
+            ref_loss_mod._get_padding_mask = orig
+    finally:
+        if cfg.use_vae:
+            ref_model_mod.torch.randn_like = torch.randn_like
+
+    # ---- the oracle restatement must agree with the live reference ----
+    o_out = O.forward(sd, cfg, commands, args, commands, args, eps=eps)
+    for k in ("command_logits", "args_logits", "visibility_logits"):
+        if k in out:
+            err = (o_out[k] - out[k]).abs().max().item()
+            assert err < 2e-5, (name, k, err)
+    _, o_ld, o_grads = O.loss_and_grads(sd, cfg, commands, args, WEIGHTS, eps=eps)
+    for k in ld:
+        assert abs(o_ld[k].item() - ld[k].item()) < 2e-5 * max(1.0, abs(ld[k].item())), (name, k, o_ld[k].item(), ld[k].item())
+    worst = 0.0
+    for pname, p in model.named_parameters():
+        g_ref, g_o = p.grad, o_grads[pname]
+        rel = (g_ref - g_o).norm().item() / max(g_ref.norm().item(), 1e-12)
+        worst = max(worst, rel)
+    assert worst < 1e-4, (name, "grad rel", worst)
+
+    al = out["args_logits"].reshape(-1)
+    stride = 997
+    rec = {
+        "kind": kind, "n": n, "seed": seed, "wseed": wseed,
+        "commands": commands.numpy().astype(np.float32), "args": args.numpy().astype(np.float32),
+        "command_logits": out["command_logits"].numpy(),
+        "args_logits_sample": al[::stride].numpy(), "args_logits_stride": stride,
+        "args_logits_sum": np.float64(al.double().sum().item()),
+        "args_logits_abssum": np.float64(al.double().abs().sum().item()),
+        "args_argmax": out["args_logits"].argmax(-1).numpy().astype(np.int16),
+        "z": z.numpy(),
+    }
+    if "visibility_logits" in out:
+        rec["visibility_logits"] = out["visibility_logits"].numpy()
+    if eps is not None:
+        rec["eps"] = eps.numpy()
+    for k, v in ld.items():
+        rec[k] = np.float64(v.item())
+    rec["loss_cmd_ref_aliased"] = np.float64(ld_alias["loss_cmd"].item())
+    names, norms, samples = [], [], []
+    for pname, p in model.named_parameters():
+        names.append(pname)
+        norms.append(p.grad.double().norm().item())
+        flat = p.grad.reshape(-1)
+        idx = torch.linspace(0, flat.numel() - 1, 16).long()
+        samples.append(flat[idx].numpy())
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = np.array(norms, dtype=np.float64)
+    rec["grad_samples"] = np.stack(samples).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: loss={ld['loss'].item():.6f} loss_cmd={ld['loss_cmd'].item():.6f} "
+          f"(aliased {ld_alias['loss_cmd'].item():.6f}) oracle-vs-ref grad rel {worst:.2e}")
+
+
+if __name__ == "__main__":
+    run_case("hier_ordered_n2", "hier", 2, 11, 1234)          # BASELINE config C1 shape
+    run_case("hier_ordered_n5", "hier", 5, 12, 4321)
+    run_case("hier_vae_n3", "hier_vae", 3, 13, 1234)
+    run_case("onestage50_n3", "onestage", 3, 14, 1234)

@@ -1,0 +1,101 @@
+"""Shared helpers for the parity tests."""
+import glob
+import os
+
+import numpy as np
+import torch
+
+from deepsvg_amd import config as C
+from deepsvg_amd.synthetic import det_state_dict
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_cases():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
+
+
+def build_cfg(kind):
+    """same three configurations as tests/golden/make_golden.py (which builds them from the reference classes)"""
+    if kind == "hier":
+        cfg = C.Hierarchical()
+        cfg.use_vae = False
+    elif kind == "hier_vae":
+        cfg = C.Hierarchical()
+    elif kind == "onestage":
+        cfg = C.OneStageOneShot()
+        cfg.max_total_len = 50
+        cfg.use_vae = False
+    else:
+        raise ValueError(kind)
+    return cfg
+
+
+def golden_setup(name):
+    """-> (golden dict, cfg, commands, args, eps)"""
+    g = load_golden(name)
+    cfg = build_cfg(str(g["kind"]))
+    commands = torch.from_numpy(g["commands"])
+    args = torch.from_numpy(g["args"])
+    eps = torch.from_numpy(g["eps"]) if "eps" in g else None
+    return g, cfg, commands, args, eps
+
+
+def weights_for(model, wseed):
+    return det_state_dict(model, seed=int(wseed))
+
+
+def rel_l2(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def check_against_golden(g, out, losses=None, grads=None, *, logit_rtol=1e-3, logit_atol=1e-5, loss_tol=2e-5,
+                         grad_norm_rtol=1e-3, grad_sample_atol=None, exact_argmax=True):
+    """out: dict of CPU float tensors; grads: {name: tensor} or None"""
+    cl = out["command_logits"].float()
+    ref_cl = torch.from_numpy(g["command_logits"])
+    assert torch.allclose(cl, ref_cl, rtol=logit_rtol, atol=logit_atol), \
+        f"command_logits max err {(cl - ref_cl).abs().max().item():.3e}"
+    if exact_argmax:
+        assert torch.equal(cl.argmax(-1), ref_cl.argmax(-1)), "command argmax differs from the reference"
+    al = out["args_logits"].float().reshape(-1)
+    stride = int(g["args_logits_stride"])
+    ref_s = torch.from_numpy(g["args_logits_sample"])
+    assert torch.allclose(al[::stride], ref_s, rtol=logit_rtol, atol=logit_atol), \
+        f"args_logits sample max err {(al[::stride] - ref_s).abs().max().item():.3e}"
+    abssum = al.double().abs().sum().item()
+    assert abs(abssum - float(g["args_logits_abssum"])) <= logit_rtol * float(g["args_logits_abssum"])
+    if exact_argmax:
+        am = out["args_logits"].float().argmax(-1).to(torch.int16)
+        ref_am = torch.from_numpy(g["args_argmax"])
+        agree = (am == ref_am).float().mean().item()
+        assert agree > 0.9999, f"args argmax agreement {agree}"
+    if "visibility_logits" in g:
+        vl = out["visibility_logits"].float()
+        ref_vl = torch.from_numpy(g["visibility_logits"])
+        assert torch.allclose(vl, ref_vl, rtol=logit_rtol, atol=logit_atol)
+    if losses is not None:
+        for k in ("loss", "loss_cmd", "loss_args", "loss_visibility", "loss_kl"):
+            if k in g:
+                v = float(losses[k])
+                assert abs(v - float(g[k])) <= loss_tol * max(1.0, abs(float(g[k]))), (k, v, float(g[k]))
+    if grads is not None:
+        names = [str(n) for n in g["grad_names"]]
+        norms = g["grad_norms"]
+        samples = g["grad_samples"]
+        for i, n in enumerate(names):
+            gr = grads[n].double().reshape(-1)
+            ref_norm = float(norms[i])
+            assert abs(gr.norm().item() - ref_norm) <= grad_norm_rtol * max(ref_norm, 1e-8), \
+                (n, gr.norm().item(), ref_norm)
+            idx = torch.linspace(0, gr.numel() - 1, 16).long()
+            s = gr[idx].float()
+            ref_sample = torch.from_numpy(samples[i])
+            rms = ref_norm / max(gr.numel(), 1) ** 0.5
+            atol = grad_sample_atol if grad_sample_atol is not None else 5e-3 * rms + 1e-6
+            assert torch.allclose(s, ref_sample, rtol=2e-3, atol=atol), (n, (s - ref_sample).abs().max().item())

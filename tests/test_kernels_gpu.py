@@ -1,0 +1,332 @@
+"""Every HIP kernel (through the C ABI / deepsvg_amd.ops) against its plain-PyTorch fp32 restatement
+(tests/torch_ops_ref.py) on the same seeded inputs.  fp32 kernels: tight tolerances (exact-fp32 MFMA);
+bf16 kernels: tolerances of bf16 storage rounding, stated per test."""
+import numpy as np
+import pytest
+import torch
+
+from deepsvg_amd import ops
+from tests import torch_ops_ref as R
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _tol(dtype, k=1):
+    """relative-to-max tolerance: fp32 accumulate error grows ~sqrt(k); bf16 adds 2^-8 storage rounding"""
+    return 2e-6 * max(1.0, k ** 0.5) if dtype == torch.float32 else 1.2e-2
+
+
+def _close(a, b, tol, what=""):
+    a, b = a.float(), b.float()
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol:.1e})"
+
+
+def _rand(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def _seed_tensor(v=0x1234567887654321):
+    return torch.tensor([v if v < (1 << 63) else v - (1 << 64)], dtype=torch.int64, device=DEV)
+
+
+# ----------------------------------------------------------------------------------------------------
+def test_library_loads_and_reports_version(gpu_device):
+    from deepsvg_amd import lib
+    assert lib.load().dsvg_version() >= 1
+
+
+def test_trread_probe_semantics(gpu_device):
+    """ds_read_b64_tr_b16: within each 16-lane group, lane i / element j receives the element that lane
+    (4*j + i//4) of the group loaded at position (i % 4).  With per-lane addresses l*8 bytes (a contiguous
+    4x16 row-major b16 matrix per group) lane i therefore gets column i: img[g*64 + j*16 + i]."""
+    off = (torch.arange(64, dtype=torch.int32) * 8).to(DEV)
+    out = ops.probe_trread(off).cpu().view(64, 4)
+    exp = torch.empty(64, 4, dtype=torch.int16)
+    for l in range(64):
+        g, i = l // 16, l % 16
+        for j in range(4):
+            exp[l, j] = g * 64 + j * 16 + i
+    print("trread probe lanes 0..19:\n", out[:20].tolist())
+    assert torch.equal(out, exp), "ds_read_b64_tr_b16 semantics differ from the assumed 4x16 transpose"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 64), (257, 768, 256), (128, 7, 512), (520, 264, 1000)])
+def test_gemm_layouts(gpu_device, dtype, impl, a_kc, b_kc, M, N, K):
+    pad = 8
+    Mp, Np, Kp = (M + pad - 1) // pad * pad, (N + pad - 1) // pad * pad, (K + pad - 1) // pad * pad
+    # operands live in padded buffers (row stride multiple of 8) like the model's internal buffers
+    a_full = _rand(M if a_kc else K, Kp if a_kc else Mp, dtype=dtype, seed=1)
+    b_full = _rand(N if b_kc else K, Kp if b_kc else Np, dtype=dtype, seed=2)
+    a = a_full[:, :K] if a_kc else a_full[:, :M]
+    b = b_full[:, :K] if b_kc else b_full[:, :N]
+    bias = _rand(N, seed=3)
+    out = ops.gemm(a, b, a_kc=a_kc, b_kc=b_kc, bias=bias, impl=impl)
+    ref = R.gemm(a, b, a_kc=a_kc, b_kc=b_kc, bias=bias, out_dtype=torch.float32)
+    _close(out, ref, _tol(dtype, K), f"gemm {M}x{N}x{K} akc={a_kc} bkc={b_kc} impl={impl}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_asymmetric_identity(gpu_device, dtype):
+    """A = I with an asymmetric B catches a transposed C write (guide rule G9)"""
+    n = 160
+    a = torch.eye(n, device=DEV, dtype=dtype)
+    b = (torch.arange(n * n, device=DEV, dtype=torch.float32).view(n, n) % 251 / 16.0).to(dtype)
+    out = ops.gemm(a, b, b_kc=False)          # C = I @ B
+    assert torch.equal(out.float(), b.float())
+    out2 = ops.gemm(a, b, b_kc=True)          # C = I @ B^T
+    assert torch.equal(out2.float(), b.float().t())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(gpu_device, dtype):
+    M, N, K = 384, 512, 256
+    a, b = _rand(M, K, dtype=dtype, seed=4), _rand(N, K, dtype=dtype, seed=5, scale=0.1)
+    bias, res = _rand(N, seed=6), _rand(M, N, dtype=dtype, seed=7)
+    gate = _rand(M, N, dtype=dtype, seed=8)
+    seed = _seed_tensor()
+    tol = _tol(dtype, K)
+    for kw in [dict(bias=bias, act=R.RELU), dict(bias=bias, res=res), dict(bias=bias, res=res, res_pre=True, act=R.RELU),
+               dict(gate=gate, gate_scale=1.25), dict(bias=bias, res=res, drop_p=0.1, drop_site=7, seed=seed),
+               dict(bias=bias, act=R.RELU, drop_p=0.3, drop_site=9, seed=seed),
+               dict(a_drop_p=0.1, a_drop_site=11, seed=seed)]:
+        out = ops.gemm(a, b, **kw)
+        ref = R.gemm(a, b, out_dtype=torch.float32, **kw)
+        _close(out, ref, tol, f"epilogue {sorted(kw)}")
+    # in-place residual (C aliases res) and accumulate
+    x = res.clone()
+    ops.gemm(a, b, bias=bias, res=x, out=x)
+    _close(x, R.gemm(a, b, bias=bias, res=res, out_dtype=torch.float32), tol, "in-place residual")
+    acc = torch.ones(M, N, device=DEV, dtype=torch.float32)
+    ops.gemm(a, b, out=acc, accumulate=True)
+    _close(acc, 1.0 + R.gemm(a, b, out_dtype=torch.float32), tol, "accumulate")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_weight_grad_splitk_with_dropout_replay(gpu_device, dtype):
+    """dW[n,k] = sum_t drop(dy)[t,n] x[t,k]: TN layout, split over tokens, dropout mask replayed on dy"""
+    T, n_out, k_in = 4100, 512, 256
+    dy, x = _rand(T, n_out, dtype=dtype, seed=9), _rand(T, k_in, dtype=dtype, seed=10)
+    seed = _seed_tensor(0xDEADBEEFCAFEF00D)
+    out = torch.empty(n_out, k_in, device=DEV, dtype=torch.float32)
+    ops.gemm(dy, x, a_kc=False, b_kc=False, out=out, a_drop_p=0.1, a_drop_site=3, seed=seed,
+             split_k=ops.split_k_for(n_out, k_in, T))
+    ref = R.gemm(dy, x, a_kc=False, b_kc=False, a_drop_p=0.1, a_drop_site=3, seed=seed, out_dtype=torch.float32)
+    _close(out, ref, _tol(dtype, T), "dW split-k")
+    bs = ops.colsum(dy, drop_p=0.1, drop_site=3, seed=seed)
+    _close(bs, R.colsum(dy, drop_p=0.1, drop_site=3, seed=seed), _tol(dtype, T), "colsum")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_args_head_shapes(gpu_device, dtype):
+    """N = 11*257 = 2827 (not a multiple of 8): forward, dX with a padded-stride dlogits, dW"""
+    T, d, N = 992, 256, 2827
+    x, w = _rand(T, d, dtype=dtype, seed=11), _rand(N, d, dtype=dtype, seed=12, scale=0.05)
+    bias = _rand(N, seed=13)
+    y = ops.gemm(x, w, bias=bias)
+    _close(y, R.gemm(x, w, bias=bias, out_dtype=torch.float32), _tol(dtype, d), "args head fwd")
+    ld = 2832
+    dbuf = torch.zeros(T, ld, device=DEV, dtype=dtype)
+    dbuf[:, :N] = _rand(T, N, dtype=dtype, seed=14)
+    dy = dbuf[:, :N]
+    dx = ops.gemm(dy, w, b_kc=False)
+    _close(dx, R.gemm(dy, w, b_kc=False, out_dtype=torch.float32), _tol(dtype, N), "args head dX")
+    dw = torch.empty(N, d, device=DEV, dtype=torch.float32)
+    ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw, split_k=4)
+    _close(dw, R.gemm(dy, x, a_kc=False, b_kc=False, out_dtype=torch.float32), _tol(dtype, T), "args head dW")
+
+
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,d", [(1000, 256), (37, 512), (5000, 64)])
+def test_layernorm(gpu_device, dtype, rows, d):
+    x = _rand(rows, d, dtype=dtype, seed=1) * 2 + 0.5
+    gamma, beta = _rand(d, seed=2) * 0.1 + 1, _rand(d, seed=3) * 0.1
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta)
+    yr, mr, rr = R.layernorm_fwd(x, gamma, beta)
+    tol = 5e-6 if dtype == torch.float32 else 1e-2
+    _close(y, yr, tol, "ln fwd")
+    _close(mean, mr, 1e-5, "ln mean")
+    _close(rstd, rr, 1e-5, "ln rstd")
+    dy, res = _rand(rows, d, dtype=dtype, seed=4), _rand(rows, d, dtype=dtype, seed=5)
+    dx, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, gamma, res=res)
+    dxr, dgr, dbr = R.layernorm_bwd(dy, x, mean, rstd, gamma, res=res)
+    _close(dx, dxr, tol, "ln dx")
+    _close(dg, dgr, 2e-5 if dtype == torch.float32 else 1e-2, "ln dgamma")
+    _close(db, dbr, 2e-5 if dtype == torch.float32 else 1e-2, "ln dbeta")
+    # in-place residual (dx aliases res)
+    r2 = res.clone()
+    ops.layernorm_bwd(dy, x, mean, rstd, gamma, res=r2, dx=r2)
+    _close(r2, dxr, tol, "ln dx in place")
+
+
+def _key_masks(n_seq, S, seed, all_valid=False):
+    if all_valid:
+        return None
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(1, S + 1, (n_seq,), generator=g)
+    return ((1 << lens.to(torch.int64)) - 1).to(DEV)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S,n_seq,masked", [(32, 40, True), (31, 33, False), (8, 100, True), (8, 64, False),
+                                             (52, 6, True), (16, 9, True), (5, 7, False)])
+def test_attention(gpu_device, dtype, S, n_seq, masked):
+    H = 8
+    qkv = _rand(n_seq * S, 3 * 32 * H, dtype=dtype, seed=S)
+    km = _key_masks(n_seq, S, seed=S + 1, all_valid=not masked)
+    if masked and S == 8:   # arbitrary (non-prefix) visibility patterns, at least one visible key
+        g = torch.Generator().manual_seed(99)
+        km = (torch.randint(1, 256, (n_seq,), generator=g)).to(torch.int64).to(DEV)
+    scale = 32 ** -0.5
+    seed = _seed_tensor(0x0123456789ABCDEF)
+    tol = 3e-6 if dtype == torch.float32 else 1.5e-2
+    for p in (0.0, 0.1):
+        o = ops.attention_fwd(qkv, km, n_seq, S, H, scale, p, 21, seed)
+        orf = R.attention_fwd(qkv.float(), km, n_seq, S, H, scale, p, 21, seed)
+        _close(o, orf, tol, f"attn fwd S={S} p={p}")
+        do = _rand(n_seq * S, 32 * H, dtype=dtype, seed=S + 2)
+        dq = ops.attention_bwd(qkv, km, do, n_seq, S, H, scale, p, 21, seed)
+        dqr = R.attention_bwd(qkv.float(), km, do.float(), n_seq, S, H, scale, p, 21, seed)
+        _close(dq, dqr, 1e-5 if dtype == torch.float32 else 2e-2, f"attn bwd S={S} p={p}")
+
+
+# ----------------------------------------------------------------------------------------------------
+def _cmd_args(n, G=8, S=30, seed=0):
+    from deepsvg_amd.synthetic import make_batch
+    c, a = make_batch(n, G, S, seed=seed)
+    return c.to(DEV), a.to(DEV)
+
+
+def test_masks_and_group_index(gpu_device):
+    c, _ = _cmd_args(37, seed=3)
+    cmd = c.view(-1, 32).contiguous()
+    km, vis, gm = ops.build_masks(cmd, 32, 8, 4, want_group_mask=True)
+    kmr, visr, gmr = R.build_masks(cmd, 32, 8, 4, want_group_mask=True)
+    assert torch.equal(km, kmr) and torch.equal(vis, visr) and torch.equal(gm, gmr)
+    gi = ops.group_index(cmd, 32, 0)
+    assert torch.equal(gi, R.group_index(cmd, 32, 0))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embedding_gather_scatter(gpu_device, dtype):
+    c, a = _cmd_args(21, seed=4)
+    T = c.numel()
+    cmd, arg = c.view(-1), a.view(T, 11)
+    ce, ae, ge = _rand(7, 256, seed=1), _rand(257, 64, seed=2), _rand(10, 256, seed=3)
+    groups = ops.group_index(c.view(-1, 32).contiguous(), 32, 0).clamp(max=9)
+    A, Rr = ops.embed_gather(cmd, arg, ce, ae, dtype, ge, groups)
+    Ar, Rrr = R.embed_gather(cmd, arg, ce, ae, torch.float32, ge, groups)
+    tol = 0.0 if dtype == torch.float32 else 8e-3
+    _close(A, Ar, tol + 1e-12, "gather A")
+    _close(Rr, Rrr, tol + 1e-7, "gather R")
+    dA, dR = _rand(T, 704, dtype=dtype, seed=5), _rand(T, 256, dtype=dtype, seed=6)
+    d_arg, d_cmd, d_grp = (torch.empty(257, 64, device=DEV), torch.empty(7, 256, device=DEV),
+                           torch.empty(10, 256, device=DEV))
+    ops.embed_scatter(cmd, arg, dA, dR, d_arg, d_cmd, groups, d_grp)
+    r_arg, r_cmd, r_grp = torch.empty_like(d_arg), torch.empty_like(d_cmd), torch.empty_like(d_grp)
+    R.embed_scatter(cmd, arg, dA, dR, r_arg, r_cmd, groups, r_grp)
+    _close(d_arg, r_arg, 2e-5, "scatter arg")
+    _close(d_cmd, r_cmd, 2e-5, "scatter cmd")
+    _close(d_grp, r_grp, 2e-5, "scatter grp")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_add_pos_mean_bcast(gpu_device, dtype):
+    n_seq, S, d = 70, 31, 256
+    seed = _seed_tensor(42)
+    pos = _rand(40, d, seed=1)
+    x = _rand(n_seq * S, d, dtype=dtype, seed=2)
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    for xx in (x, None):
+        for p in (0.0, 0.1):
+            y = ops.add_pos_fwd(xx, pos, n_seq, S, dtype, p, 5, seed)
+            _close(y, R.add_pos_fwd(xx, pos, n_seq, S, torch.float32, p, 5, seed), tol, "add_pos fwd")
+            dy = _rand(n_seq * S, d, dtype=dtype, seed=3)
+            dpos, dposr = torch.empty(S, d, device=DEV), torch.empty(S, d, device=DEV)
+            dx = ops.add_pos_bwd(dy, n_seq, S, dpos, want_dx=xx is not None, drop_p=p, drop_site=5, seed=seed)
+            dxr = R.add_pos_bwd(dy, n_seq, S, dposr, want_dx=xx is not None, drop_p=p, drop_site=5, seed=seed)
+            _close(dpos, dposr, 2e-5 if dtype == torch.float32 else 1e-2, "add_pos dpos")
+            if xx is not None:
+                _close(dx, dxr, tol, "add_pos dx")
+    km = _key_masks(n_seq, S, 7)
+    m = ops.masked_mean_fwd(x, km, n_seq, S)
+    _close(m, R.masked_mean_fwd(x.float(), km, n_seq, S), tol * 4, "masked mean")
+    dm = _rand(n_seq, d, dtype=dtype, seed=4)
+    _close(ops.masked_mean_bwd(dm, km, n_seq, S), R.masked_mean_bwd(dm.float(), km, n_seq, S), tol, "masked mean bwd")
+    g = _rand(n_seq, d, dtype=dtype, seed=5)
+    for p in (0.0, 0.1):
+        x1, x2 = x.clone(), x.clone().float()
+        ops.bcast_add_fwd_(x1, g, n_seq, S, p, 6, seed)
+        R.bcast_add_fwd_(x2, g.float(), n_seq, S, p, 6, seed)
+        _close(x1, x2, tol, "bcast add")
+        _close(ops.bcast_add_bwd(x, n_seq, S, p, 6, seed), R.bcast_add_bwd(x.float(), n_seq, S, p, 6, seed),
+               2e-5 if dtype == torch.float32 else 1e-2, "bcast add bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_loss_targets_and_masked_ce(gpu_device, dtype):
+    from deepsvg_amd.svgtensor import CMD_ARGS_MASK
+    c, a = _cmd_args(9, seed=6)
+    tc, ta = c.view(-1, 32).contiguous(), a.view(-1, 32, 11).contiguous()
+    cam = CMD_ARGS_MASK.float().to(DEV)
+    outs = ops.loss_targets(tc, ta, cam)
+    refs = R.loss_targets(tc, ta, cam)
+    for o, r, nm in zip(outs, refs, ["cmd_tgt", "cmd_w", "arg_tgt", "arg_w", "vis_tgt"]):
+        assert torch.equal(o.cpu(), r.cpu().to(o.dtype)), nm
+    cmd_tgt, cmd_w, arg_tgt, arg_w, vis_tgt = outs
+    n_tok = cmd_tgt.numel()
+    for (logits, tgt, w, C_, group) in [
+            (_rand(n_tok, 7, dtype=dtype, seed=1), cmd_tgt.view(-1), cmd_w.view(-1), 7, 1),
+            (_rand(n_tok, 11 * 257, dtype=dtype, seed=2), arg_tgt.view(-1), arg_w.view(-1), 257, 11),
+            (_rand(vis_tgt.numel(), 2, dtype=dtype, seed=3), vis_tgt, None, 2, 1)]:
+        lse, sc = ops.masked_ce_fwd(logits, tgt, w, C_, group)
+        lser, scr = R.masked_ce_fwd(logits.float(), tgt, w, C_, group)
+        _close(lse, lser, 2e-6, "lse")
+        _close(sc, scr, 1e-5, "sum/count")
+        gs = torch.tensor([0.7], device=DEV)
+        d = ops.masked_ce_bwd(logits, tgt, w, lse, sc, gs, 2.0, C_, group, pad_to=8)
+        dr = R.masked_ce_bwd(logits.float(), tgt, w, lser, scr, gs, 2.0, C_, group, pad_to=8)
+        assert d.stride(0) % 8 == 0
+        _close(d, dr, 2e-6 if dtype == torch.float32 else 1e-2, "dlogits")
+
+
+def test_optimizer_matches_torch_adamw(gpu_device):
+    n = 100003
+    p0, g = _rand(n, seed=1), _rand(n, seed=2, scale=3.0)
+    p = p0.clone()
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    lr = torch.tensor([1e-3], device=DEV)
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3)
+    for it in range(3):
+        gi = g * (it + 1)
+        ops.advance_step_(step, None)
+        nsq = ops.sumsq(gi)
+        _close(nsq, (gi.double() ** 2).sum().float().reshape(1), 1e-5, "sumsq")
+        ops.adamw_step_(p, gi, m, v, lr, step, gnorm_sq=nsq, max_norm=1.0)
+        ref.grad = gi.clone()
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        _close(p, ref.data, 2e-6, f"adamw step {it}")
+    assert step.item() == 3
+
+
+def test_cast_gate_add(gpu_device):
+    src = _rand(300, 77, seed=1)
+    dst, dst_t = torch.empty(300, 77, device=DEV, dtype=torch.bfloat16), torch.empty(77, 300, device=DEV, dtype=torch.bfloat16)
+    ops.cast_weights(src, dst, dst_t)
+    assert torch.equal(dst, src.to(torch.bfloat16)) and torch.equal(dst_t, src.t().to(torch.bfloat16))
+    for dtype in DTYPES:
+        a, b = _rand(1000, 16, dtype=dtype, seed=2), _rand(1000, 16, dtype=dtype, seed=3)
+        _close(ops.gate_mul(a, b, 1.5), R.gate_mul(a, b, 1.5), 1e-6 if dtype == torch.float32 else 8e-3, "gate_mul")
+        _close(ops.add(a, b), R.add(a, b), 1e-6 if dtype == torch.float32 else 8e-3, "add")

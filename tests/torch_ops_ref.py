@@ -1,0 +1,385 @@
+"""Plain-PyTorch restatement of every op in deepsvg_amd/ops.py (same names, same signatures).
+
+Two uses, both test-only:
+  * `-m gpu` tests compare each HIP kernel with the function of the same name here (fp32 reference);
+  * `-m "not gpu"` tests monkey-patch deepsvg_amd.ops with this module (see conftest.emulated_ops) to exercise
+    the host logic (autograd wiring, flat parameter store, trainer, gloo data-parallel path) on CPU.
+The product never imports this file.
+
+The dropout masks reproduce the counter-based hash of deepsvg_amd/csrc/dsvg_common.h bit for bit.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+RELU = 1
+M32 = 0xFFFFFFFF
+
+
+# ----------------------------------------------------------------------------------------------------
+# dropout hash (dsvg_common.h: dsvg_hash32 / drop_make / drop_mult)
+# ----------------------------------------------------------------------------------------------------
+def _hash32_int(x):
+    x &= M32
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & M32
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & M32
+    x ^= x >> 16
+    return x
+
+
+def _hash32_t(x):
+    x = x & M32
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & M32
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & M32
+    x = x ^ (x >> 16)
+    return x
+
+
+def drop_mult(p, seed, site, idx):
+    """multiplier tensor (0 or 1/(1-p)) for int64 element ids `idx`"""
+    if p <= 0 or seed is None:
+        return torch.ones(idx.shape, dtype=torch.float32, device=idx.device)
+    p32 = float(np.float32(p))
+    s = int(seed.reshape(-1)[0].item()) & 0xFFFFFFFFFFFFFFFF
+    s0 = _hash32_int((s & M32) ^ ((site * 0x9E3779B1) & M32))
+    s1 = _hash32_int(((s >> 32) + site * 0x85EBCA77 + 0x165667B1) & M32)
+    t = p32 * 4294967296.0
+    thresh = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
+    scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+    idx = idx.to(torch.int64)
+    lo, hi = idx & M32, (idx >> 32) & M32
+    h = _hash32_t(lo ^ s0)
+    h = _hash32_t((h + hi * 0x9E3779B1 + s1) & M32)
+    return torch.where(h < thresh, torch.zeros((), dtype=torch.float32, device=idx.device),
+                       torch.full((), scale, dtype=torch.float32, device=idx.device))
+
+
+def _ids(rows, cols, device, ld=None):
+    ld = cols if ld is None else ld
+    return torch.arange(rows, device=device, dtype=torch.int64).unsqueeze(1) * ld + \
+        torch.arange(cols, device=device, dtype=torch.int64).unsqueeze(0)
+
+
+def _f(t):
+    return t.to(torch.float32)
+
+
+# ----------------------------------------------------------------------------------------------------
+def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=0, gate=None, gate_scale=1.0,
+         drop_p=0.0, drop_site=0, a_drop_p=0.0, a_drop_site=0, seed=None, out=None, out_dtype=None,
+         accumulate=False, split_k=1, impl=0):
+    af = _f(a)
+    if a_drop_p > 0:
+        af = af * drop_mult(a_drop_p, seed, a_drop_site, _ids(a.shape[0], a.shape[1], a.device))
+        af = _f(af.to(a.dtype))      # the kernel re-rounds the dropped operand to the storage type
+    A = af if a_kc else af.t()
+    B = _f(b) if b_kc else _f(b).t()
+    v = A @ B.t()
+    M, N = v.shape
+    if bias is not None:
+        v = v + _f(bias)
+    if res is not None and res_pre:
+        v = v + _f(res)
+    if act == RELU:
+        v = torch.relu(v)
+    if gate is not None:
+        v = torch.where(_f(gate) > 0, v * gate_scale, torch.zeros_like(v))
+    if drop_p > 0:
+        v = v * drop_mult(drop_p, seed, drop_site, _ids(M, N, v.device))
+    if res is not None and not res_pre:
+        v = v + _f(res)
+    dt = out.dtype if out is not None else (out_dtype or a.dtype)
+    if out is None:
+        return v.to(dt)
+    if accumulate:
+        v = v + _f(out)
+    out.copy_(v.to(dt))
+    return out
+
+
+def split_k_for(M, N, K, target_blocks=768):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    s = max(1, target_blocks // tiles)
+    return min(s, max(1, K // 256))
+
+
+def colsum(a, *, out=None, accumulate=False, drop_p=0.0, drop_site=0, seed=None):
+    af = _f(a)
+    if drop_p > 0:
+        af = af * drop_mult(drop_p, seed, drop_site, _ids(a.shape[0], a.shape[1], a.device))
+    s = af.sum(0)
+    if out is None:
+        return s
+    out.copy_(s + out if accumulate else s)
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    xf = _f(x)
+    mean = xf.mean(-1)
+    var = ((xf - mean.unsqueeze(-1)) ** 2).mean(-1)
+    rstd = torch.rsqrt(var + eps)
+    y = (xf - mean.unsqueeze(-1)) * rstd.unsqueeze(-1) * gamma + beta
+    return y.to(x.dtype), mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, res=None, dgamma=None, dbeta=None, accumulate=False, dx=None):
+    dyf, xf = _f(dy), _f(x)
+    xh = (xf - mean.unsqueeze(-1)) * rstd.unsqueeze(-1)
+    gd = dyf * gamma
+    c1 = gd.mean(-1, keepdim=True)
+    c2 = (gd * xh).mean(-1, keepdim=True)
+    o = rstd.unsqueeze(-1) * (gd - c1 - xh * c2)
+    if res is not None:
+        o = o + _f(res)
+    dg, db = (dyf * xh).sum(0), dyf.sum(0)
+    if dgamma is not None:
+        dgamma.copy_(dgamma + dg if accumulate else dg)
+        dg = dgamma
+    if dbeta is not None:
+        dbeta.copy_(dbeta + db if accumulate else db)
+        db = dbeta
+    o = o.to(x.dtype)
+    if dx is not None:
+        dx.copy_(o)
+        o = dx
+    return o, dg, db
+
+
+def _mask_bits(mask, S):
+    """int64 [n] bitmask -> bool [n, S]"""
+    bits = torch.arange(S, device=mask.device, dtype=torch.int64)
+    return ((mask.unsqueeze(1) >> bits) & 1).bool()
+
+
+def _attn_probs(qkv, key_mask, n_seq, S, H, scale):
+    d = 32 * H
+    q, k, v = _f(qkv).view(n_seq, S, 3, H, 32).permute(2, 0, 3, 1, 4)      # each (n_seq, H, S, 32)
+    s = (q * scale) @ k.transpose(-1, -2)
+    if key_mask is not None:
+        valid = _mask_bits(key_mask, S)
+        s = s.masked_fill(~valid.view(n_seq, 1, 1, S), float("-inf"))
+    return q, k, v, torch.softmax(s, dim=-1)
+
+
+def _attn_drop(p, seed, site, n_seq, S, H, device):
+    idx = torch.arange(n_seq * H * S * S, device=device, dtype=torch.int64).view(n_seq, H, S, S)
+    return drop_mult(p, seed, site, idx)
+
+
+def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None):
+    H = n_heads
+    q, k, v, P = _attn_probs(qkv, key_mask, n_seq, S, H, scale)
+    Pd = P * _attn_drop(drop_p, seed, drop_site, n_seq, S, H, qkv.device)
+    o = Pd @ v                                                               # (n_seq, H, S, 32)
+    return o.permute(0, 2, 1, 3).reshape(n_seq * S, H * 32).to(qkv.dtype)
+
+
+def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None):
+    H = n_heads
+    q, k, v, P = _attn_probs(qkv, key_mask, n_seq, S, H, scale)
+    mult = _attn_drop(drop_p, seed, drop_site, n_seq, S, H, qkv.device)
+    do = _f(dout).view(n_seq, S, H, 32).permute(0, 2, 1, 3)
+    dv = (P * mult).transpose(-1, -2) @ do
+    dP = (do @ v.transpose(-1, -2)) * mult
+    D = (P * dP).sum(-1, keepdim=True)
+    dS = P * (dP - D)
+    dq = (dS @ k) * scale
+    dk = dS.transpose(-1, -2) @ (q * scale)
+    out = torch.stack([dq, dk, dv], dim=0).permute(1, 3, 0, 2, 4).reshape(n_seq * S, 3 * H * 32)
+    return out.to(qkv.dtype)
+
+
+def build_masks(commands, S, G=0, eos_id=4, want_group_mask=False):
+    cmd = commands.view(-1, S)
+    n_seq = cmd.shape[0]
+    is_eos = (cmd.long() == eos_id)
+    valid = is_eos.cumsum(1) == 0
+    w = (1 << torch.arange(S, dtype=torch.int64, device=cmd.device))
+    key_mask = (valid.long() * w).sum(1)
+    seq_visible = (is_eos.sum(1) < S - 1).to(torch.int32)
+    group_mask = None
+    if want_group_mask:
+        wg = (1 << torch.arange(G, dtype=torch.int64, device=cmd.device))
+        group_mask = (seq_visible.view(-1, G).long() * wg).sum(1)
+    return key_mask, seq_visible, group_mask
+
+
+def group_index(commands, S, m_id=0):
+    return (commands.view(-1, S).long() == m_id).cumsum(1).to(torch.int32).reshape(-1)
+
+
+def embed_gather(commands, args, command_embed, arg_embed, dtype, group_embed=None, groups=None):
+    T = commands.numel()
+    a = args.view(T, -1)
+    iv = (a.long() + 1).clamp(0, arg_embed.shape[0] - 1)
+    A = arg_embed[iv].reshape(T, -1)
+    ic = commands.view(-1).long().clamp(0, command_embed.shape[0] - 1)
+    R = command_embed[ic]
+    if group_embed is not None:
+        R = R + group_embed[groups.long()]
+    return A.to(dtype), R.to(dtype)
+
+
+def embed_scatter(commands, args, dA, dR, d_arg_embed, d_command_embed, groups=None, d_group_embed=None):
+    T = commands.numel()
+    n_argvals, E = d_arg_embed.shape
+    a = args.view(T, -1)
+    iv = (a.long() + 1).clamp(0, n_argvals - 1).reshape(-1)
+    d_arg_embed.zero_().index_add_(0, iv, _f(dA).reshape(-1, E))
+    ic = commands.view(-1).long().clamp(0, d_command_embed.shape[0] - 1)
+    d_command_embed.zero_().index_add_(0, ic, _f(dR))
+    if d_group_embed is not None:
+        d_group_embed.zero_().index_add_(0, groups.long(), _f(dR))
+
+
+def add_pos_fwd(x, pos, n_seq, S, dtype, drop_p=0.0, drop_site=0, seed=None):
+    d = pos.shape[1]
+    v = pos[:S].unsqueeze(0).expand(n_seq, S, d).reshape(n_seq * S, d)
+    if x is not None:
+        v = v + _f(x)
+    v = v * drop_mult(drop_p, seed, drop_site, _ids(n_seq * S, d, pos.device))
+    return v.to(dtype)
+
+
+def add_pos_bwd(dy, n_seq, S, d_pos, *, want_dx=True, accumulate=False, drop_p=0.0, drop_site=0, seed=None):
+    d = dy.shape[1]
+    g = _f(dy) * drop_mult(drop_p, seed, drop_site, _ids(n_seq * S, d, dy.device))
+    s = g.view(n_seq, S, d).sum(0)
+    d_pos.copy_(d_pos + s if accumulate else s)
+    return g.to(dy.dtype) if want_dx else None
+
+
+def masked_mean_fwd(x, mask, n_seq, S):
+    d = x.shape[1]
+    valid = _mask_bits(mask, S).to(torch.float32)
+    xf = _f(x).view(n_seq, S, d)
+    return ((xf * valid.unsqueeze(-1)).sum(1) / valid.sum(1, keepdim=True)).to(x.dtype)
+
+
+def masked_mean_bwd(dout, mask, n_seq, S):
+    valid = _mask_bits(mask, S).to(torch.float32)
+    g = _f(dout) / valid.sum(1, keepdim=True)
+    return (g.unsqueeze(1) * valid.unsqueeze(-1)).reshape(n_seq * S, -1).to(dout.dtype)
+
+
+def bcast_add_fwd_(x, g, n_seq, S, drop_p=0.0, drop_site=0, seed=None):
+    d = x.shape[1]
+    gv = _f(g).unsqueeze(1).expand(n_seq, S, d).reshape(n_seq * S, d)
+    x.copy_((_f(x) + gv * drop_mult(drop_p, seed, drop_site, _ids(n_seq * S, d, x.device))).to(x.dtype))
+    return x
+
+
+def bcast_add_bwd(dx, n_seq, S, drop_p=0.0, drop_site=0, seed=None):
+    d = dx.shape[1]
+    g = _f(dx) * drop_mult(drop_p, seed, drop_site, _ids(n_seq * S, d, dx.device))
+    return g.view(n_seq, S, d).sum(1).to(dx.dtype)
+
+
+def loss_targets(tgt_commands, tgt_args, cmd_args_mask, eos_id=4):
+    n_seq, S1 = tgt_commands.shape
+    c = tgt_commands.long()
+    is_eos = c == eos_id
+    pm = (is_eos.cumsum(1) == 0)
+    ext = pm.clone()
+    ext[:, 3:] |= pm[:, :S1 - 3]
+    vis = (is_eos.sum(1) < S1 - 1)
+    cmd_tgt = c[:, 1:].clamp(0, cmd_args_mask.shape[0] - 1).to(torch.int32).contiguous()
+    cmd_w = (ext[:, 1:] & vis.unsqueeze(1)).to(torch.float32).contiguous()
+    arg_tgt = (tgt_args[:, 1:].long() + 1).to(torch.int32).contiguous()
+    arg_w = cmd_args_mask[cmd_tgt.long()].to(torch.float32).contiguous()
+    return cmd_tgt, cmd_w, arg_tgt, arg_w, vis.to(torch.int32)
+
+
+def _ce_rows(logits2d, C_, group):
+    n_tok = logits2d.shape[0]
+    return _f(logits2d)[:, :group * C_].reshape(n_tok * group, C_)
+
+
+def masked_ce_fwd(logits2d, target, w, C_, group=1):
+    rows = _ce_rows(logits2d, C_, group)
+    lse = torch.logsumexp(rows, dim=-1)
+    t = target.long().clamp(0, C_ - 1)
+    nll = lse - rows.gather(1, t.unsqueeze(1)).squeeze(1)
+    ww = torch.ones_like(lse) if w is None else w
+    lse = torch.where(ww != 0, lse, torch.zeros_like(lse))
+    sc = torch.stack([(ww * torch.where(ww != 0, nll, torch.zeros_like(nll))).sum(), ww.sum()])
+    return lse, sc
+
+
+def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1, pad_to=8):
+    rows = _ce_rows(logits2d, C_, group)
+    n_tok = logits2d.shape[0]
+    ww = torch.ones(rows.shape[0], device=rows.device) if w is None else w
+    g = coef * (gscale.reshape(()) if gscale is not None else 1.0) / sum_count[1]
+    sm = torch.exp(rows - lse.unsqueeze(1))
+    onehot = F.one_hot(target.long().clamp(0, C_ - 1), C_).to(torch.float32)
+    d = (ww * g).unsqueeze(1) * (sm - onehot)
+    d = torch.where((ww != 0).unsqueeze(1), d, torch.zeros_like(d))
+    width = group * C_
+    ld = (width + pad_to - 1) // pad_to * pad_to
+    buf = torch.zeros((n_tok, ld), dtype=logits2d.dtype, device=logits2d.device)
+    buf[:, :width] = d.reshape(n_tok, width).to(logits2d.dtype)
+    return buf[:, :width]
+
+
+def sumsq(x, out=None):
+    s = (x.double() ** 2).sum().to(torch.float32).reshape(1)
+    if out is not None:
+        out.copy_(s)
+        return out
+    return s
+
+
+def adamw_step_(p, g, m, v, lr, step, *, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, gnorm_sq=None,
+                max_norm=0.0, grad_scale=1.0):
+    coef = grad_scale
+    if gnorm_sq is not None and max_norm > 0:
+        norm = torch.sqrt(gnorm_sq.reshape(())) * grad_scale
+        coef = coef * torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+    t = float(step.item())
+    lr_ = float(lr.item())
+    gi = g * coef
+    m.mul_(beta1).add_(gi, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
+    bc1 = 1 - beta1 ** t
+    bc2s = (1 - beta2 ** t) ** 0.5
+    p.mul_(1 - lr_ * weight_decay).addcdiv_(m, v.sqrt() / bc2s + eps, value=-lr_ / bc1)
+
+
+def cast_weights(src, dst=None, dst_t=None):
+    if dst is not None:
+        dst.view(-1)[:src.numel()].copy_(src.reshape(-1).to(dst.dtype))
+    if dst_t is not None:
+        dst_t.view(-1)[:src.numel()].copy_(src.t().reshape(-1).to(dst_t.dtype))
+    return dst, dst_t
+
+
+def advance_step_(counter, seed):
+    if counter is not None:
+        counter += 1
+    if seed is not None:
+        s = (int(seed.item()) + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        z = z ^ (z >> 31)
+        if z >= 1 << 63:
+            z -= 1 << 64
+        seed.fill_(z)
+
+
+def gate_mul(dy, y, scale=1.0):
+    return torch.where(_f(y) > 0, _f(dy) * scale, torch.zeros_like(_f(dy))).to(dy.dtype)
+
+
+def add(a, b):
+    return (_f(a) + _f(b)).to(a.dtype)
+
+
+def require_device(device):
+    return None
