@@ -47,7 +47,7 @@ union Frag8 {
     uint4 u;
 };
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, bool ADROP>
 __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
                                                              int k_chunk, float* part) {
     constexpr int A_ELEMS = AKC ? TBM * LDK : TBK * LDM;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
                 if (gm < p.M && gk < k_end) {
                     v = *reinterpret_cast<const uint4*>(A + (size_t)gm * p.lda + gk);
                     if (gk + 8 > k_end) v = mask_tail8(v, k_end - gk);
-                    if (adc.on) v = drop_chunk8(v, adc, (uint64_t)gm * p.a_drop_ld + gk);
+                    if (ADROP && adc.on) v = drop_chunk8(v, adc, (uint64_t)gm * p.a_drop_ld + gk);
                 }
                 ra[j] = v;
             }
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
                 uint4 v = zero4;
                 if (gk < k_end && gm < p.M) {
                     v = *reinterpret_cast<const uint4*>(A + (size_t)gk * p.lda + gm);
-                    if (adc.on) v = drop_chunk8(v, adc, (uint64_t)gk * p.a_drop_ld + gm);
+                    if (ADROP && adc.on) v = drop_chunk8(v, adc, (uint64_t)gk * p.a_drop_ld + gm);
                 }
                 ra[j] = v;
             }
@@ -252,14 +252,20 @@ int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, float* part, hip
     const int nwg = tiles_m * tiles_n;
     const int nsplit = (d.K + k_chunk - 1) / k_chunk;
     dim3 grid(nwg, nsplit);
-    if (d.a_kc && d.b_kc)
-        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<true, true>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
-    else if (d.a_kc && !d.b_kc)
-        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<true, false>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
-    else if (!d.a_kc && d.b_kc)
-        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<false, true>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
-    else
-        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<false, false>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
+    // the dropout-replay prologue is a compile-time variant so the common kernels carry no RNG code
+    const bool adrop = d.a_drop_p > 0.f;
+#define DSVG_LAUNCH_BF16(AK, BK)                                                                                   \
+    do {                                                                                                           \
+        if (adrop) hipLaunchKernelGGL((gemm_bf16_mfma_kernel<AK, BK, true>), grid, dim3(256), 0, st, d, tiles_n,   \
+                                      nwg, k_chunk, part);                                                         \
+        else hipLaunchKernelGGL((gemm_bf16_mfma_kernel<AK, BK, false>), grid, dim3(256), 0, st, d, tiles_n, nwg,   \
+                                k_chunk, part);                                                                    \
+    } while (0)
+    if (d.a_kc && d.b_kc) DSVG_LAUNCH_BF16(true, true);
+    else if (d.a_kc && !d.b_kc) DSVG_LAUNCH_BF16(true, false);
+    else if (!d.a_kc && d.b_kc) DSVG_LAUNCH_BF16(false, true);
+    else DSVG_LAUNCH_BF16(false, false);
+#undef DSVG_LAUNCH_BF16
     DSVG_LAUNCH_CHECK("gemm_bf16_mfma");
     return 0;
 }

@@ -21,7 +21,7 @@ if [[ "$WHAT" == "all" || "$WHAT" == *smoke* ]]; then
   run smoke 600 python -c "import __graft_entry__ as g; g.smoke()"
 fi
 if [[ "$WHAT" == "all" || "$WHAT" == *test* ]]; then
-  run pytest_gpu 2400 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 -rA
+  run pytest_gpu 900 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 -rA
 fi
 if [[ "$WHAT" == "all" || "$WHAT" == *bench* ]]; then
   run bench_fp32 900 python bench.py --dtype fp32 --steps 5 --warmup 2 --graph 0
