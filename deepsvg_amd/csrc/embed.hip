@@ -285,30 +285,17 @@ __global__ void add_pos_fwd_kernel(const T* __restrict__ x, const float* __restr
     }
 }
 
-// block = 256 threads owning 256 consecutive columns (blockIdx.y selects the column panel); each block
-// accumulates d_pos[s, c] over its chunk of sequences in registers-per-s via LDS columns it owns.
-constexpr int AP_SEQ_PER_BLOCK = 64;
+// dx = dy * dropmask (elementwise, 4 elements per lane)
 template <typename T>
-__global__ __launch_bounds__(256) void add_pos_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx,
-                                                          float* __restrict__ part, long long n_seq, int S, int d,
-                                                          float drop_p, uint32_t site, const uint64_t* seed) {
-    extern __shared__ float acc[];   // [S][256]
+__global__ void drop_copy_kernel(const T* __restrict__ dy, T* __restrict__ dx, long long n4, float drop_p,
+                                 uint32_t site, const uint64_t* seed) {
     const DropCtx dc = drop_make(drop_p, seed, site);
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    for (int s = 0; s < S; ++s) acc[s * 256 + threadIdx.x] = 0.f;
-    const long long b0 = (long long)blockIdx.x * AP_SEQ_PER_BLOCK;
-    const long long b1 = min(n_seq, b0 + AP_SEQ_PER_BLOCK);
-    if (c < d) {
-        for (long long b = b0; b < b1; ++b) {
-            for (int s = 0; s < S; ++s) {
-                const long long t = b * S + s;
-                const float g = Elem<T>::ld(dy + t * d + c) * drop_mult(dc, (uint64_t)t * d + c);
-                if (dx) Elem<T>::st(dx + t * d + c, g);
-                acc[s * 256 + threadIdx.x] += g;
-            }
-        }
-        float* dst = part + (size_t)blockIdx.x * S * d;
-        for (int s = 0; s < S; ++s) dst[(size_t)s * d + c] = acc[s * 256 + threadIdx.x];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float v[4];
+        Elem<T>::ld4(dy + 4 * i, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= drop_mult(dc, (uint64_t)(4 * i + e));
+        Elem<T>::st4(dx + 4 * i, v);
     }
 }
 
@@ -330,34 +317,32 @@ extern "C" int dsvg_add_pos_fwd(int32_t dtype, const void* x, const float* pos, 
     return 0;
 }
 
+// d_pos[s, c] = sum_b (dy*mask)[b*S+s, c] is the column sum of dy viewed as [n_seq, S*d] (element ids coincide:
+// b*(S*d) + s*d + c = t*d + c), so the generic column-sum kernel of gemm.hip does the reduction.
 extern "C" int64_t dsvg_add_pos_bwd_workspace_bytes(int64_t n_seq, int32_t S, int32_t d) {
-    return (int64_t)dsvg_cdiv(n_seq, AP_SEQ_PER_BLOCK) * S * d * (int64_t)sizeof(float);
+    return dsvg_colsum_workspace_bytes(n_seq, S * d);
 }
 
 extern "C" int dsvg_add_pos_bwd(int32_t dtype, const void* dy, void* dx, float* d_pos, int32_t accumulate,
                                 int64_t n_seq, int32_t S, int32_t d, float drop_p, uint32_t drop_site,
                                 const uint64_t* seed, float* workspace, int64_t workspace_bytes, void* stream) {
-    DSVG_CHECK_ARG(dy && d_pos && n_seq > 0 && S > 0 && S <= 160 && d > 0, "add_pos_bwd: bad args");
+    DSVG_CHECK_ARG(dy && d_pos && n_seq > 0 && S > 0 && d > 0 && (d % 4) == 0, "add_pos_bwd: bad args");
     DSVG_CHECK_ARG(drop_p <= 0.f || seed, "add_pos_bwd: dropout needs a seed pointer");
-    DSVG_CHECK_ARG(workspace && workspace_bytes >= dsvg_add_pos_bwd_workspace_bytes(n_seq, S, d),
-                   "add_pos_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    const int nb = dsvg_cdiv(n_seq, AP_SEQ_PER_BLOCK);
-    const size_t lds = (size_t)S * 256 * sizeof(float);
-    dim3 grid(nb, dsvg_cdiv(d, 256));
-    if (dtype == DSVG_F32) {
-        auto k = add_pos_bwd_kernel<float>;
-        DSVG_ENSURE_LDS(k, lds);
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, (const float*)dy, (float*)dx, workspace, (long long)n_seq, S, d,
-                           drop_p, drop_site, seed);
-    } else if (dtype == DSVG_BF16) {
-        auto k = add_pos_bwd_kernel<bf16_t>;
-        DSVG_ENSURE_LDS(k, lds);
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, (const bf16_t*)dy, (bf16_t*)dx, workspace, (long long)n_seq, S,
-                           d, drop_p, drop_site, seed);
-    } else { dsvg_set_error("add_pos_bwd: bad dtype"); return -1; }
-    DSVG_LAUNCH_CHECK("add_pos_bwd");
-    return dsvg_reduce_partials_strided(workspace, nb, (int64_t)S * d, (int64_t)S * d, d_pos, accumulate, st);
+    if (dx) {
+        const long long n4 = n_seq * S * (long long)d / 4;
+        const int nb = (int)min((long long)dsvg_cdiv(n4, 256), 8192LL);
+        if (dtype == DSVG_F32)
+            hipLaunchKernelGGL(drop_copy_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dy, (float*)dx, n4,
+                               drop_p, drop_site, seed);
+        else if (dtype == DSVG_BF16)
+            hipLaunchKernelGGL(drop_copy_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, n4,
+                               drop_p, drop_site, seed);
+        else { dsvg_set_error("add_pos_bwd: bad dtype"); return -1; }
+        DSVG_LAUNCH_CHECK("add_pos_bwd(dx)");
+    }
+    return dsvg_colsum(dtype, dy, (int64_t)S * d, n_seq, S * d, d_pos, accumulate, drop_p, drop_site, seed, workspace,
+                       workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -235,37 +235,129 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, in
 // ---------------------------------------------------------------------------------------------
 // deterministic reductions
 // ---------------------------------------------------------------------------------------------
-__global__ void reduce_partials_strided_kernel(const float* __restrict__ part, long long P, long long stride,
-                                               long long n, float* __restrict__ out, int accumulate) {
-    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    float s = accumulate ? out[j] : 0.f;
-    for (long long q = 0; q < P; ++q) s += part[q * stride + j];
-    out[j] = s;
+// out[j] = [out[j] +] sum_q part[q*stride + j].  Block = 64 column lanes x 4 slices of the partial index;
+// each slice keeps 4 independent accumulators (fixed summation tree -> bit-reproducible), the 4 slices are
+// combined through LDS.  VEC = 4 (float4 lanes) when stride, n and the pointers allow it.
+template <int VEC>
+__global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const float* __restrict__ part, long long P,
+                                                                      long long stride, long long n,
+                                                                      float* __restrict__ out, int accumulate) {
+    __shared__ float red[4][64][VEC];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long j = ((long long)blockIdx.x * 64 + tx) * VEC;
+    float acc[4][VEC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[u][e] = 0.f;
+    if (j < n) {
+        long long q = ty;
+        for (; q + 12 < P; q += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* p = part + (q + 4 * u) * stride + j;
+                if (VEC == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(p);
+                    acc[u][0] += v.x; acc[u][1 % VEC] += v.y; acc[u][2 % VEC] += v.z; acc[u][3 % VEC] += v.w;
+                } else {
+                    acc[u][0] += p[0];
+                }
+            }
+        }
+        for (; q < P; q += 4) {
+            const float* p = part + q * stride + j;
+            if (VEC == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(p);
+                acc[0][0] += v.x; acc[0][1 % VEC] += v.y; acc[0][2 % VEC] += v.z; acc[0][3 % VEC] += v.w;
+            } else {
+                acc[0][0] += p[0];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[ty][tx][e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+    __syncthreads();
+    if (ty == 0 && j < n) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float s = (red[0][tx][e] + red[1][tx][e]) + (red[2][tx][e] + red[3][tx][e]);
+            if (accumulate) s += out[j + e];
+            out[j + e] = s;
+        }
+    }
 }
 
 int dsvg_reduce_partials_strided(const float* part, int64_t P, int64_t stride, int64_t n, float* out,
                                  int32_t accumulate, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3(dsvg_cdiv(n, 256)), dim3(256), 0, st, part, (long long)P,
-                       (long long)stride, (long long)n, out, accumulate);
+    const bool vec = !(n & 3) && !(stride & 3) && !((uintptr_t)part & 15) && !((uintptr_t)out & 15);
+    if (vec)
+        hipLaunchKernelGGL(reduce_partials_strided_kernel<4>, dim3(dsvg_cdiv(n, 256)), dim3(256), 0, st, part,
+                           (long long)P, (long long)stride, (long long)n, out, accumulate);
+    else
+        hipLaunchKernelGGL(reduce_partials_strided_kernel<1>, dim3(dsvg_cdiv(n, 64)), dim3(256), 0, st, part,
+                           (long long)P, (long long)stride, (long long)n, out, accumulate);
     DSVG_LAUNCH_CHECK("reduce_partials");
     return 0;
 }
 
-// column sums of a [M, N] matrix (bias gradients): block handles ROWS_PER_BLOCK rows, thread owns columns
-constexpr int CS_ROWS = 256;
+// column sums of a [M, N] matrix (bias gradients).  A block owns CS_ROWS rows and a panel of up to 64 column
+// chunks (16 bytes each); its 256 threads are (256/cpb) row groups x cpb column chunks, every thread streams
+// 16-byte row segments with independent accumulators; row groups are combined through LDS; one partial row
+// per block goes to the workspace and is reduced in a fixed order.
+constexpr int CS_ROWS_MIN = 64, CS_ROWS_MAX = 1024;
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ A, long long lda, long long M, int N,
-                              float* __restrict__ part, float drop_p, uint32_t site, const uint64_t* seed) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, long long lda, long long M, int N,
+                                                     float* __restrict__ part, float drop_p, uint32_t site,
+                                                     const uint64_t* seed, int cpb, int vec_ok, int rows_per_block) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    __shared__ float red[256][VEC + 1];
     const DropCtx dc = drop_make(drop_p, seed, site);
-    const long long r0 = (long long)blockIdx.x * CS_ROWS;
-    const long long r1 = min(M, r0 + CS_ROWS);
-    for (int c = threadIdx.x; c < N; c += blockDim.x) {
-        float s = 0.f;
-        for (long long r = r0; r < r1; ++r)
-            s += Elem<T>::ld(A + r * lda + c) * drop_mult(dc, (uint64_t)r * N + c);
-        part[(long long)blockIdx.x * N + c] = s;
+    const int cl = threadIdx.x % cpb, rg = threadIdx.x / cpb, nrg = 256 / cpb;
+    const int c0 = (blockIdx.y * cpb + cl) * VEC;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(M, r0 + rows_per_block);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    if (c0 < N) {
+        if (vec_ok && c0 + VEC <= N) {
+            for (long long r = r0 + rg; r < r1; r += nrg) {
+                float v[VEC];
+                if (VEC == 4) {
+                    float t[4];
+                    Elem<T>::ld4(A + r * lda + c0, t);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e % VEC] = t[e];
+                } else {
+                    float t0[4], t1[4];
+                    Elem<T>::ld4(A + r * lda + c0, t0);
+                    Elem<T>::ld4(A + r * lda + c0 + 4, t1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[(e + 4) % VEC] = t1[e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += v[e] * drop_mult(dc, (uint64_t)r * N + c0 + e);
+            }
+        } else {
+            for (long long r = r0 + rg; r < r1; r += nrg)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (c0 + e < N) acc[e] += Elem<T>::ld(A + r * lda + c0 + e) * drop_mult(dc, (uint64_t)r * N + c0 + e);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    if (rg == 0 && c0 < N) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            if (c0 + e < N) {
+                float s = 0.f;
+                for (int g = 0; g < nrg; ++g) s += red[g * cpb + cl][e];
+                part[(long long)blockIdx.x * N + c0 + e] = s;
+            }
+        }
     }
 }
 
@@ -281,7 +373,7 @@ extern "C" int dsvg_reduce_partials(const float* partial, int64_t P, int64_t n, 
 }
 
 extern "C" int64_t dsvg_colsum_workspace_bytes(int64_t M, int32_t N) {
-    return (int64_t)dsvg_cdiv(M, CS_ROWS) * N * (int64_t)sizeof(float);
+    return (int64_t)dsvg_cdiv(M, CS_ROWS_MIN) * N * (int64_t)sizeof(float);
 }
 
 extern "C" int dsvg_colsum(int32_t dtype, const void* A, int64_t lda, int64_t M, int32_t N, float* out,
@@ -291,15 +383,25 @@ extern "C" int dsvg_colsum(int32_t dtype, const void* A, int64_t lda, int64_t M,
     DSVG_CHECK_ARG(workspace && workspace_bytes >= dsvg_colsum_workspace_bytes(M, N),
                    "colsum: workspace too small (%lld < %lld)", (long long)workspace_bytes,
                    (long long)dsvg_colsum_workspace_bytes(M, N));
-    const int nb = dsvg_cdiv(M, CS_ROWS);
     hipStream_t st = (hipStream_t)stream;
+    DSVG_CHECK_ARG(dtype == DSVG_F32 || dtype == DSVG_BF16, "colsum: bad dtype %d", dtype);
+    const int vec = dtype == DSVG_F32 ? 4 : 8;
+    const int chunks = dsvg_cdiv(N, vec);
+    int cpb = 8;
+    while (cpb < 64 && cpb < chunks) cpb *= 2;
+    const int vec_ok = !(lda % vec) && !((uintptr_t)A & 15);
+    const int col_blocks = dsvg_cdiv(chunks, cpb);
+    // enough row blocks to fill the chip (~1024 workgroups), between 64 and 1024 rows each
+    long long rpb = M / max(1, 1024 / col_blocks);
+    rpb = rpb < CS_ROWS_MIN ? CS_ROWS_MIN : (rpb > CS_ROWS_MAX ? CS_ROWS_MAX : rpb);
+    const int nb = dsvg_cdiv(M, rpb);
+    dim3 grid(nb, col_blocks);
     if (dtype == DSVG_F32)
-        hipLaunchKernelGGL(colsum_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)A, (long long)lda,
-                           (long long)M, N, workspace, drop_p, drop_site, seed);
-    else if (dtype == DSVG_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)A, (long long)lda,
-                           (long long)M, N, workspace, drop_p, drop_site, seed);
-    else { dsvg_set_error("colsum: bad dtype %d", dtype); return -1; }
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)A, (long long)lda,
+                           (long long)M, N, workspace, drop_p, drop_site, seed, cpb, vec_ok, (int)rpb);
+    else
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)A, (long long)lda,
+                           (long long)M, N, workspace, drop_p, drop_site, seed, cpb, vec_ok, (int)rpb);
     DSVG_LAUNCH_CHECK("colsum");
     return dsvg_reduce_partials(workspace, nb, N, out, accumulate, stream);
 }

@@ -201,19 +201,118 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
 
     const DropCtx dc = drop_make(p.drop_p, p.seed, p.drop_site);
     float* my_part = part ? part + (size_t)kz * p.M * p.N : nullptr;
+    if (my_part) {   // split-K partial: raw fp32 accumulators, 128-byte row segments per half wave
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+                    if (m < p.M && n < p.N) my_part[(size_t)m * p.N + n] = acc[i][j][r];
+                }
+        return;
+    }
+    // Row-per-lane-group epilogue: the MFMA C layout gives every lane ONE column (2-byte stores); instead each
+    // wave transposes its 32x64 half tile through a private fp32 LDS slab (the A/B images are dead after the
+    // last barrier) and every lane finishes 8 consecutive columns of a row: 16-byte residual/gate loads and
+    // 16-byte C stores (8 rows x 128 B per wave instruction).
+    constexpr int SLD = 68;
+    float* slab = reinterpret_cast<float*>(smem) + wave * (32 * SLD);
+    const int chunk = lane & 7, rsub = lane >> 3;
+    const int nb = n0 + wn * 64 + chunk * 8;
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = (p.bias && nb + e < p.N) ? p.bias[nb + e] : 0.f;
+    const bool vec_c = p.c_f32 ? (!(p.ldc & 3) && !((uintptr_t)p.C & 15)) : (!(p.ldc & 7) && !((uintptr_t)p.C & 15));
+    const bool vec_res = !p.res || (!(p.ldres & 7) && !((uintptr_t)p.res & 15));
+    const bool vec_gate = !p.gate || (!(p.ldgate & 7) && !((uintptr_t)p.gate & 15));
+    const bool fast = vec_c && vec_res && vec_gate && (nb + 8 <= p.N);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-                if (m < p.M && n < p.N) {
-                    if (my_part) my_part[(size_t)m * p.N + n] = acc[i][j][r];
-                    else gemm_epilogue<bf16_t>(p, dc, m, n, acc[i][j][r]);
+            for (int r = 0; r < 16; ++r)
+                slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + j * 32 + (lane & 31)] = acc[i][j][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rl = rsub + 8 * q;
+            const int m = m0 + wm * 64 + i * 32 + rl;
+            const float4 lo = *reinterpret_cast<const float4*>(&slab[rl * SLD + chunk * 8]);
+            const float4 hi = *reinterpret_cast<const float4*>(&slab[rl * SLD + chunk * 8 + 4]);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            if (m >= p.M || nb >= p.N) continue;
+            if (!fast) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (nb + e < p.N) gemm_epilogue<bf16_t>(p, dc, m, nb + e, v[e]);
+                continue;
+            }
+            float rv[8];
+            if (p.res) {
+                const uint4 t = *reinterpret_cast<const uint4*>((const bf16_t*)p.res + (size_t)m * p.ldres + nb);
+                const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rv[2 * e] = __uint_as_float(w[e] << 16);
+                    rv[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
                 }
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] += bias8[e];
+                if (p.res && p.res_pre) v[e] += rv[e];
+                if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (p.gate) {
+                const uint4 t = *reinterpret_cast<const uint4*>((const bf16_t*)p.gate + (size_t)m * p.ldgate + nb);
+                const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] = __uint_as_float(w[e] << 16) > 0.f ? v[2 * e] * p.gate_scale : 0.f;
+                    v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u) > 0.f ? v[2 * e + 1] * p.gate_scale : 0.f;
+                }
+            }
+            if (dc.on) {
+                const uint64_t eid = (uint64_t)m * p.N + nb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= drop_mult(dc, eid + e);
+            }
+            if (p.res && !p.res_pre) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            }
+            if (p.c_f32) {
+                float4* c = reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + nb);
+                if (p.accumulate) {
+                    const float4 c0 = c[0], c1 = c[1];
+                    v[0] += c0.x; v[1] += c0.y; v[2] += c0.z; v[3] += c0.w;
+                    v[4] += c1.x; v[5] += c1.y; v[6] += c1.z; v[7] += c1.w;
+                }
+                c[0] = make_float4(v[0], v[1], v[2], v[3]);
+                c[1] = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                uint4* c = reinterpret_cast<uint4*>((bf16_t*)p.C + (size_t)m * p.ldc + nb);
+                if (p.accumulate) {
+                    const uint4 t = *c;
+                    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += __uint_as_float(w[e] << 16);
+                        v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+                    }
+                }
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+                *c = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
 }
 
 template <typename T>

@@ -85,8 +85,17 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rt, x, weight, bias, act, res, drop_rate, site, out_dtype):
         p = rt.p(drop_rate)
+        # rows of the output are padded to a 16-byte multiple (e.g. the 2827-wide args logits -> 2832) so that
+        # the GEMM epilogue, the loss kernels and the backward GEMMs all use 16-byte accesses
+        dt = out_dtype or x.dtype
+        n_out = weight.shape[0]
+        mult = 4 if dt == torch.float32 else 8
+        out = None
+        if n_out % mult:
+            ld = (n_out + mult - 1) // mult * mult
+            out = torch.empty((x.shape[0], ld), dtype=dt, device=x.device)[:, :n_out]
         y = ops.gemm(x, rt.w(weight), bias=bias.detach() if bias is not None else None, act=act,
-                     res=res, drop_p=p, drop_site=site, seed=rt.seed, out_dtype=out_dtype)
+                     res=res, drop_p=p, drop_site=site, seed=rt.seed, out_dtype=out_dtype, out=out)
         ctx.rt, ctx.act, ctx.p, ctx.site = rt, act, p, site
         ctx.has_res = res is not None
         ctx.save_for_backward(x, weight, bias, y if act == ops.RELU else None)

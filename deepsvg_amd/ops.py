@@ -132,7 +132,7 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
     return out
 
 
-def split_k_for(M, N, K, target_blocks=768):
+def split_k_for(M, N, K, target_blocks=512):
     """split factor for the weight-gradient GEMMs (small M x N output, K = #tokens)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     s = max(1, target_blocks // tiles)

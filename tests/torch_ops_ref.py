@@ -101,7 +101,7 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
     return out
 
 
-def split_k_for(M, N, K, target_blocks=768):
+def split_k_for(M, N, K, target_blocks=512):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     s = max(1, target_blocks // tiles)
     return min(s, max(1, K // 256))
