@@ -50,11 +50,18 @@ void dsvg_set_error(const char* fmt, ...);
 // bf16 <-> fp32
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// fp32 -> bf16 with the hardware converter (v_cvt_pk_bf16_f32, round-to-nearest-even)
+typedef __bf16 dsvg_bf2 __attribute__((ext_vector_type(2)));
+typedef float dsvg_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                           // round to nearest even
-    return (bf16_t)(u >> 16);
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+// two values -> one packed dword (lo in bits 0..15)
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
+    const dsvg_f2 v = {lo, hi};
+    const dsvg_bf2 b = __builtin_convertvector(v, dsvg_bf2);
+    return __builtin_bit_cast(uint32_t, b);
 }
 
 template <typename T> struct Elem;
@@ -83,8 +90,8 @@ template <> struct Elem<bf16_t> {
     }
     static __device__ __forceinline__ void st4(bf16_t* p, const float (&v)[4]) {
         uint2 t;
-        t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        t.x = f2bf_pk(v[0], v[1]);
+        t.y = f2bf_pk(v[2], v[3]);
         *reinterpret_cast<uint2*>(p) = t;
     }
 };
@@ -120,16 +127,21 @@ __device__ __forceinline__ void row32_store(bf16_t* p, const float (&v)[32]) {
         uint32_t w[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            w[e] = (uint32_t)f2bf(v[8 * i + 2 * e]) | ((uint32_t)f2bf(v[8 * i + 2 * e + 1]) << 16);
+            w[e] = f2bf_pk(v[8 * i + 2 * e], v[8 * i + 2 * e + 1]);
         reinterpret_cast<uint4*>(p)[i] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Counter-based dropout RNG.  keep(seed, site, idx) is a pure function so that the backward pass
-// regenerates the forward mask instead of storing it.  `seed` lives in device memory so that a
-// captured hipGraph sees a new value on every replay.  The same hash is restated with int64 torch
-// ops in tests/torch_ops_ref.py.
+// Counter-based dropout RNG.  The mask is a pure function of (seed, site, element id) so the backward
+// pass regenerates the forward mask instead of storing it; `seed` lives in device memory so that a
+// captured hipGraph sees a new value on every replay.
+//   group g = id >> 3 :  h  = hash32(hash32(lo(g) ^ s0) + hi(g)*C + s1)           (once per 8 elements)
+//   word  i = 0..3    :  w  = hash32(h + (i+1)*0x9e3779b9)                         (two 16-bit draws each)
+//   element slot = id & 7 uses the low (even slot) / high (odd slot) half of word slot>>1 and is dropped
+//   when draw16 < round(p * 65536); survivors are scaled by 65536 / (65536 - thresh16).
+// Kernels that own an aligned run of 8 elements pay 6 hash rounds per 8 elements (drop_mult8); scalar
+// users pay 3 per element (drop_mult).  Restated bit-for-bit with int64 torch ops in tests/torch_ops_ref.py.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t dsvg_hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -137,8 +149,8 @@ __device__ __forceinline__ uint32_t dsvg_hash32(uint32_t x) {
 }
 struct DropCtx {
     uint32_t s0, s1;    // mixed seed words
-    uint32_t thresh;    // drop when hash < thresh
-    float scale;        // 1/(1-p)
+    uint32_t thresh;    // 16-bit threshold: drop when draw16 < thresh
+    float scale;        // 65536 / (65536 - thresh)
     bool on;
 };
 __device__ __forceinline__ DropCtx drop_make(float p, const uint64_t* seed_ptr, uint32_t site) {
@@ -148,21 +160,41 @@ __device__ __forceinline__ DropCtx drop_make(float p, const uint64_t* seed_ptr, 
         uint64_t seed = *seed_ptr;
         c.s0 = dsvg_hash32((uint32_t)seed ^ (site * 0x9e3779b1u));
         c.s1 = dsvg_hash32((uint32_t)(seed >> 32) + site * 0x85ebca77u + 0x165667b1u);
-        double t = (double)p * 4294967296.0;
-        c.thresh = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
-        c.scale = 1.f / (1.f - p);
+        uint32_t t = (uint32_t)(p * 65536.f + 0.5f);
+        c.thresh = t > 65535u ? 65535u : t;
+        c.scale = 65536.f / (float)(65536u - c.thresh);
     } else {
         c.s0 = c.s1 = 0; c.thresh = 0; c.scale = 1.f;
     }
     return c;
 }
-// returns the multiplier (0 or 1/(1-p)) for element idx
+__device__ __forceinline__ uint32_t drop_group(const DropCtx& c, uint64_t g) {
+    uint32_t h = dsvg_hash32((uint32_t)g ^ c.s0);
+    return dsvg_hash32(h + (uint32_t)(g >> 32) * 0x9e3779b1u + c.s1);
+}
+__device__ __forceinline__ uint32_t drop_word(uint32_t h, uint32_t i) { return dsvg_hash32(h + (i + 1u) * 0x9e3779b9u); }
+// multiplier (0 or scale) for element idx
 __device__ __forceinline__ float drop_mult(const DropCtx& c, uint64_t idx) {
     if (!c.on) return 1.f;
-    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-    uint32_t h = dsvg_hash32(lo ^ c.s0);
-    h = dsvg_hash32(h + hi * 0x9e3779b1u + c.s1);
-    return h < c.thresh ? 0.f : c.scale;
+    const uint32_t slot = (uint32_t)idx & 7u;
+    const uint32_t w = drop_word(drop_group(c, idx >> 3), slot >> 1);
+    const uint32_t draw = (slot & 1u) ? (w >> 16) : (w & 0xffffu);
+    return draw < c.thresh ? 0.f : c.scale;
+}
+// multipliers for the 8 elements idx8 .. idx8+7 (idx8 must be a multiple of 8)
+__device__ __forceinline__ void drop_mult8(const DropCtx& c, uint64_t idx8, float (&m)[8]) {
+    if (!c.on) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = 1.f;
+        return;
+    }
+    const uint32_t h = drop_group(c, idx8 >> 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t w = drop_word(h, i);
+        m[2 * i] = (w & 0xffffu) < c.thresh ? 0.f : c.scale;
+        m[2 * i + 1] = (w >> 16) < c.thresh ? 0.f : c.scale;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

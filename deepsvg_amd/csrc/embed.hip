@@ -299,6 +299,43 @@ __global__ void drop_copy_kernel(const T* __restrict__ dy, T* __restrict__ dx, l
     }
 }
 
+// y = x * dropmask, 8 elements per lane (one hash group), element id = flat index.  Materialises the masked
+// gradient once per dropout site so that the dX GEMM, the dW GEMM and the bias column-sum that all consume it
+// read plain data instead of re-hashing it per output tile.
+template <typename T>
+__global__ void drop_apply8_kernel(const T* __restrict__ x, T* __restrict__ y, long long n8, float drop_p,
+                                   uint32_t site, const uint64_t* seed) {
+    const DropCtx dc = drop_make(drop_p, seed, site);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        float a[4], b[4], m[8];
+        Elem<T>::ld4(x + 8 * i, a);
+        Elem<T>::ld4(x + 8 * i + 4, b);
+        drop_mult8(dc, (uint64_t)(8 * i), m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] *= m[e]; b[e] *= m[4 + e]; }
+        Elem<T>::st4(y + 8 * i, a);
+        Elem<T>::st4(y + 8 * i + 4, b);
+    }
+}
+extern "C" int dsvg_drop_apply(int32_t dtype, const void* x, void* y, int64_t n, float drop_p, uint32_t drop_site,
+                               const uint64_t* seed, void* stream) {
+    DSVG_CHECK_ARG(x && y && n > 0 && (n % 8) == 0, "drop_apply: n must be a positive multiple of 8");
+    DSVG_CHECK_ARG(drop_p <= 0.f || seed, "drop_apply: dropout needs a seed pointer");
+    DSVG_CHECK_ARG(!((uintptr_t)x & 15) && !((uintptr_t)y & 15), "drop_apply: buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const long long n8 = n / 8;
+    const int nb = (int)min((long long)dsvg_cdiv(n8, 256), 8192LL);
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(drop_apply8_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, (float*)y, n8, drop_p,
+                           drop_site, seed);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(drop_apply8_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n8,
+                           drop_p, drop_site, seed);
+    else { dsvg_set_error("drop_apply: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("drop_apply");
+    return 0;
+}
+
 extern "C" int dsvg_add_pos_fwd(int32_t dtype, const void* x, const float* pos, void* y, int64_t n_seq, int32_t S,
                                 int32_t d, float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream) {
     DSVG_CHECK_ARG(pos && y && n_seq > 0 && S > 0 && (d % 4) == 0, "add_pos_fwd: bad args");

@@ -71,12 +71,19 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, in
 
     // XCD-aware tile mapping (bijective): neighbouring column tiles of one row tile share an XCD's L2
     const int bid = blockIdx.x;
-    const int q = nwg_mn / 8, r8 = nwg_mn % 8;
     const int xcd = bid % 8, local = bid / 8;
-    const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+    int wgid, kz;
+    if (gridDim.y == 1 && (int)gridDim.x != nwg_mn) {
+        // split-K as a 1-D grid (nsplit % 8 == 0): the output tiles of one K slice share an XCD (and its L2)
+        wgid = local % nwg_mn;
+        kz = (local / nwg_mn) * 8 + xcd;
+    } else {
+        const int q = nwg_mn / 8, r8 = nwg_mn % 8;
+        wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+        kz = blockIdx.y;
+    }
     const int tile_m = wgid / tiles_n, tile_n = wgid % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int kz = blockIdx.y;
     const int k_begin = kz * k_chunk;
     const int k_end = min(p.K, k_begin + k_chunk);
 
@@ -336,8 +343,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, lo
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[(e + 4) % VEC] = t1[e]; }
                 }
+                if (VEC == 8 && dc.on && !(N & 7)) {
+                    float m8[8];
+                    drop_mult8(dc, (uint64_t)r * N + c0, m8);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] += v[e] * drop_mult(dc, (uint64_t)r * N + c0 + e);
+                    for (int e = 0; e < VEC; ++e) acc[e] += v[e] * m8[e % 8];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] += v[e] * drop_mult(dc, (uint64_t)r * N + c0 + e);
+                }
             }
         } else {
             for (long long r = r0 + rg; r < r1; r += nrg)
@@ -406,7 +420,7 @@ extern "C" int dsvg_colsum(int32_t dtype, const void* A, int64_t lda, int64_t M,
     return dsvg_reduce_partials(workspace, nb, N, out, accumulate, stream);
 }
 
-int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, float* part, hipStream_t st);  // gemm_bf16.hip
+int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, float* part, hipStream_t st);  // gemm_bf16.hip
 
 extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
     DSVG_CHECK_ARG(dp, "gemm: null desc");
@@ -430,7 +444,8 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
         part = d.workspace;
         k_chunk = ((d.K + split - 1) / split + 63) / 64 * 64;
     }
-    const int nsplit = (d.K + k_chunk - 1) / k_chunk;
+    int nsplit = (d.K + k_chunk - 1) / k_chunk;
+    if (split > 1 && (split % 8) == 0) nsplit = split;   // trailing slices may be empty (they write zero partials)
 
     bool use_naive = d.impl == 1;
     if (d.dtype == DSVG_F32) {
@@ -458,6 +473,7 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
         const int tiles_m = dsvg_cdiv(d.M, BM), tiles_n = dsvg_cdiv(d.N, BN);
         const int nwg = tiles_m * tiles_n;
         dim3 grid(nwg, nsplit);
+        if (nsplit > 1 && (nsplit % 8) == 0) grid = dim3(nwg * nsplit, 1);
         if (d.a_kc && d.b_kc)
             hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
         else if (d.a_kc && !d.b_kc)
@@ -468,7 +484,7 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
             hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
         DSVG_LAUNCH_CHECK("gemm_f32_mfma");
     } else {
-        int rc = dsvg_gemm_bf16_launch(d, k_chunk, part, st);
+        int rc = dsvg_gemm_bf16_launch(d, k_chunk, nsplit, part, st);
         if (rc) return rc;
     }
     if (part) return dsvg_reduce_partials(part, nsplit, (int64_t)d.M * d.N, (float*)d.C, d.accumulate, stream);

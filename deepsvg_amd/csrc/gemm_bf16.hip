@@ -7,6 +7,9 @@
 //                             transpose) fragments; 4 rows * 64 B fold onto all 64 banks
 //   so the weight-gradient GEMM (both operands token-major, reduction over tokens) needs no
 //   transposed copies in HBM.
+//   Epilogue: each wave transposes its accumulators through a private fp32 LDS slab and finishes 8
+//   consecutive columns per lane (16-byte residual/gate loads and C stores).  The epilogue kinds the model
+//   uses are compile-time variants (EPI_*), so the hot kernels carry no dead branches or RNG code.
 #include "dsvg_common.h"
 #include "../../include/dsvg.h"
 #include "gemm_common.h"
@@ -19,15 +22,39 @@ constexpr int TBM = 128, TBN = 128, TBK = 64;
 constexpr int LDK = 72;
 constexpr int LDM = 160;
 
-__device__ __forceinline__ uint4 drop_chunk8(uint4 v, const DropCtx& dc, uint64_t e) {
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+enum {
+    EPI_GENERIC = 0,        // everything decided at run time (any alignment, any option)
+    EPI_BIAS = 1,           // C = acc [+ bias]
+    EPI_BIAS_RES_DROP = 2,  // C = res + drop(acc [+ bias])
+    EPI_BIAS_RELU_DROP = 3, // C = drop(relu(acc [+ bias]))
+    EPI_GATE = 4,           // C = gate > 0 ? acc * gate_scale : 0
+};
+
+__device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float lo = __uint_as_float(w[i] << 16) * drop_mult(dc, e + 2 * i);
-        float hi = __uint_as_float(w[i] & 0xffff0000u) * drop_mult(dc, e + 2 * i + 1);
-        w[i] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __uint_as_float(w[e] << 16);
+        v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
     }
-    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    return make_uint4(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]), f2bf_pk(v[4], v[5]), f2bf_pk(v[6], v[7]));
+}
+
+// dropout replay on an 8-element chunk of operand A whose first element has id e
+__device__ __forceinline__ uint4 drop_chunk8(uint4 t, const DropCtx& dc, uint64_t e) {
+    float v[8], m[8];
+    unpack8(t, v);
+    if ((e & 7ull) == 0) {
+        drop_mult8(dc, e, m);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = drop_mult(dc, e + i);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= m[i];
+    return pack8(v);
 }
 
 // keep the first `nvalid` (1..7) bf16 elements of an 8-element chunk, zero the rest (K tail)
@@ -47,7 +74,7 @@ union Frag8 {
     uint4 u;
 };
 
-template <bool AKC, bool BKC, bool ADROP>
+template <bool AKC, bool BKC, bool ADROP, int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
                                                              int k_chunk, float* part) {
     constexpr int A_ELEMS = AKC ? TBM * LDK : TBK * LDM;
@@ -56,13 +83,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
     bf16_t* As = smem;
     bf16_t* Bs = smem + A_ELEMS;
 
+    // XCD-aware tile order (bijective): the column tiles of one row tile run on one XCD and share its L2
     const int bid = blockIdx.x;
-    const int q8 = nwg_mn / 8, r8 = nwg_mn % 8;
     const int xcd = bid % 8, local = bid / 8;
-    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+    int wgid, kz;
+    if (gridDim.y == 1 && (int)gridDim.x != nwg_mn) {
+        // split-K launch as a 1-D grid of nwg_mn * nsplit blocks (nsplit % 8 == 0): all output tiles of one K
+        // slice run back to back on ONE XCD, so each operand tile is fetched from HBM once and re-used from
+        // that XCD's L2 by the other tiles of the slice
+        wgid = local % nwg_mn;
+        kz = (local / nwg_mn) * 8 + xcd;
+    } else {
+        const int q8 = nwg_mn / 8, r8 = nwg_mn % 8;
+        wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+        kz = blockIdx.y;
+    }
     const int tile_m = wgid / tiles_n, tile_n = wgid % tiles_n;
     const int m0 = tile_m * TBM, n0 = tile_n * TBN;
-    const int kz = blockIdx.y;
     const int k_begin = kz * k_chunk;
     const int k_end = min(p.K, k_begin + k_chunk);
 
@@ -71,79 +108,69 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
     const int wm = wave >> 1, wn = wave & 1;
     const bf16_t* A = (const bf16_t*)p.A;
     const bf16_t* B = (const bf16_t*)p.B;
-    const DropCtx adc = drop_make(p.a_drop_p, p.seed, p.a_drop_site);
+    const DropCtx adc = drop_make(ADROP ? p.a_drop_p : 0.f, p.seed, p.a_drop_site);
+
+    // per-thread staging geometry, hoisted out of the K loop
+    //   k-contiguous operand : thread -> (row = r + 32 j, 8-element k chunk c)      r = tid/8,  c = tid%8
+    //   mn-contiguous operand: thread -> (k row = r + 16 j, 8-element mn chunk c)   r = tid/16, c = tid%16
+    const int ca = AKC ? (tid & 7) : (tid & 15), rwa = AKC ? (tid >> 3) : (tid >> 4);
+    const int cb = BKC ? (tid & 7) : (tid & 15), rwb = BKC ? (tid >> 3) : (tid >> 4);
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
+    bool va[4], vb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (AKC) { const int gm = m0 + rwa + 32 * j; va[j] = gm < p.M; pa[j] = A + (size_t)gm * p.lda + 8 * ca; }
+        else     { const int gm = m0 + 8 * ca;       va[j] = gm < p.M; pa[j] = A + (size_t)(rwa + 16 * j) * p.lda + gm; }
+        if (BKC) { const int gn = n0 + rwb + 32 * j; vb[j] = gn < p.N; pb[j] = B + (size_t)gn * p.ldb + 8 * cb; }
+        else     { const int gn = n0 + 8 * cb;       vb[j] = gn < p.N; pb[j] = B + (size_t)(rwb + 16 * j) * p.ldb + gn; }
+    }
 
     uint4 ra[4], rb[4];
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 
-    auto load_a = [&](int k0) {
-        if (AKC) {
-            const int c = tid & 7, r = tid >> 3;
+    auto load_tiles = [&](int k0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gm = m0 + r + 32 * j, gk = k0 + 8 * c;
-                uint4 v = zero4;
-                if (gm < p.M && gk < k_end) {
-                    v = *reinterpret_cast<const uint4*>(A + (size_t)gm * p.lda + gk);
+        for (int j = 0; j < 4; ++j) {
+            uint4 v = zero4;
+            if (AKC) {
+                const int gk = k0 + 8 * ca;
+                if (va[j] && gk < k_end) {
+                    v = *reinterpret_cast<const uint4*>(pa[j] + k0);
                     if (gk + 8 > k_end) v = mask_tail8(v, k_end - gk);
-                    if (ADROP && adc.on) v = drop_chunk8(v, adc, (uint64_t)gm * p.a_drop_ld + gk);
+                    if (ADROP) v = drop_chunk8(v, adc, (uint64_t)(m0 + rwa + 32 * j) * p.a_drop_ld + gk);
                 }
-                ra[j] = v;
-            }
-        } else {
-            const int c = tid & 15, r = tid >> 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gk = k0 + r + 16 * j, gm = m0 + 8 * c;
-                uint4 v = zero4;
-                if (gk < k_end && gm < p.M) {
-                    v = *reinterpret_cast<const uint4*>(A + (size_t)gk * p.lda + gm);
-                    if (ADROP && adc.on) v = drop_chunk8(v, adc, (uint64_t)gk * p.a_drop_ld + gm);
+            } else {
+                const int gk = k0 + rwa + 16 * j;
+                if (va[j] && gk < k_end) {
+                    v = *reinterpret_cast<const uint4*>(pa[j] + (size_t)k0 * p.lda);
+                    if (ADROP) v = drop_chunk8(v, adc, (uint64_t)gk * p.a_drop_ld + m0 + 8 * ca);
                 }
-                ra[j] = v;
             }
+            ra[j] = v;
         }
-    };
-    auto load_b = [&](int k0) {
-        if (BKC) {
-            const int c = tid & 7, r = tid >> 3;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gn = n0 + r + 32 * j, gk = k0 + 8 * c;
-                uint4 v = zero4;
-                if (gn < p.N && gk < k_end) {
-                    v = *reinterpret_cast<const uint4*>(B + (size_t)gn * p.ldb + gk);
+        for (int j = 0; j < 4; ++j) {
+            uint4 v = zero4;
+            if (BKC) {
+                const int gk = k0 + 8 * cb;
+                if (vb[j] && gk < k_end) {
+                    v = *reinterpret_cast<const uint4*>(pb[j] + k0);
                     if (gk + 8 > k_end) v = mask_tail8(v, k_end - gk);
                 }
-                rb[j] = v;
+            } else {
+                if (vb[j] && k0 + rwb + 16 * j < k_end) v = *reinterpret_cast<const uint4*>(pb[j] + (size_t)k0 * p.ldb);
             }
-        } else {
-            const int c = tid & 15, r = tid >> 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gk = k0 + r + 16 * j, gn = n0 + 8 * c;
-                rb[j] = (gk < k_end && gn < p.N) ? *reinterpret_cast<const uint4*>(B + (size_t)gk * p.ldb + gn) : zero4;
-            }
+            rb[j] = v;
         }
     };
     auto store_lds = [&]() {
-        if (AKC) {
-            const int c = tid & 7, r = tid >> 3;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(&As[(r + 32 * j) * LDK + 8 * c]) = ra[j];
-        } else {
-            const int c = tid & 15, r = tid >> 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(&As[(r + 16 * j) * LDM + 8 * c]) = ra[j];
-        }
-        if (BKC) {
-            const int c = tid & 7, r = tid >> 3;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(&Bs[(r + 32 * j) * LDK + 8 * c]) = rb[j];
-        } else {
-            const int c = tid & 15, r = tid >> 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(&Bs[(r + 16 * j) * LDM + 8 * c]) = rb[j];
+        for (int j = 0; j < 4; ++j) {
+            if (AKC) *reinterpret_cast<uint4*>(&As[(rwa + 32 * j) * LDK + 8 * ca]) = ra[j];
+            else     *reinterpret_cast<uint4*>(&As[(rwa + 16 * j) * LDM + 8 * ca]) = ra[j];
+            if (BKC) *reinterpret_cast<uint4*>(&Bs[(rwb + 32 * j) * LDK + 8 * cb]) = rb[j];
+            else     *reinterpret_cast<uint4*>(&Bs[(rwb + 16 * j) * LDM + 8 * cb]) = rb[j];
         }
     };
 
@@ -173,17 +200,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (k_begin < k_end) {
-        load_a(k_begin);
-        load_b(k_begin);
-    }
+    if (k_begin < k_end) load_tiles(k_begin);
     for (int k0 = k_begin; k0 < k_end; k0 += TBK) {
         store_lds();
         __syncthreads();
-        if (k0 + TBK < k_end) {
-            load_a(k0 + TBK);
-            load_b(k0 + TBK);
-        }
+        if (k0 + TBK < k_end) load_tiles(k0 + TBK);   // register prefetch overlaps the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < TBK / 16; ++kk) {
             bf16x8 a0, a1, b0, b1;
@@ -199,9 +220,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
         __syncthreads();
     }
 
-    const DropCtx dc = drop_make(p.drop_p, p.seed, p.drop_site);
-    float* my_part = part ? part + (size_t)kz * p.M * p.N : nullptr;
-    if (my_part) {   // split-K partial: raw fp32 accumulators, 128-byte row segments per half wave
+    if (part) {   // split-K partial: raw fp32 accumulators, 128-byte row segments per half wave
+        float* my_part = part + (size_t)kz * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -214,21 +234,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
                 }
         return;
     }
-    // Row-per-lane-group epilogue: the MFMA C layout gives every lane ONE column (2-byte stores); instead each
-    // wave transposes its 32x64 half tile through a private fp32 LDS slab (the A/B images are dead after the
-    // last barrier) and every lane finishes 8 consecutive columns of a row: 16-byte residual/gate loads and
-    // 16-byte C stores (8 rows x 128 B per wave instruction).
+
+    // ---- epilogue through a per-wave LDS slab (the A/B images are dead after the last barrier) --------------
+    constexpr bool GEN = EPI == EPI_GENERIC;
+    const bool has_res = GEN ? (p.res != nullptr) : (EPI == EPI_BIAS_RES_DROP);
+    const bool has_gate = GEN ? (p.gate != nullptr) : (EPI == EPI_GATE);
+    const bool relu = GEN ? (p.act == 1) : (EPI == EPI_BIAS_RELU_DROP);
+    const bool res_pre = GEN ? (p.res_pre != 0) : false;
+    const bool may_drop = GEN || EPI == EPI_BIAS_RES_DROP || EPI == EPI_BIAS_RELU_DROP;
+    const DropCtx dc = drop_make(may_drop ? p.drop_p : 0.f, p.seed, p.drop_site);
+
     constexpr int SLD = 68;
     float* slab = reinterpret_cast<float*>(smem) + wave * (32 * SLD);
     const int chunk = lane & 7, rsub = lane >> 3;
     const int nb = n0 + wn * 64 + chunk * 8;
     float bias8[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = (p.bias && nb + e < p.N) ? p.bias[nb + e] : 0.f;
-    const bool vec_c = p.c_f32 ? (!(p.ldc & 3) && !((uintptr_t)p.C & 15)) : (!(p.ldc & 7) && !((uintptr_t)p.C & 15));
-    const bool vec_res = !p.res || (!(p.ldres & 7) && !((uintptr_t)p.res & 15));
-    const bool vec_gate = !p.gate || (!(p.ldgate & 7) && !((uintptr_t)p.gate & 15));
-    const bool fast = vec_c && vec_res && vec_gate && (nb + 8 <= p.N);
+    for (int e = 0; e < 8; ++e) bias8[e] = (EPI != EPI_GATE && p.bias && nb + e < p.N) ? p.bias[nb + e] : 0.f;
+    bool fast = true;
+    if (GEN) {
+        const bool vec_c = p.c_f32 ? (!(p.ldc & 3) && !((uintptr_t)p.C & 15)) : (!(p.ldc & 7) && !((uintptr_t)p.C & 15));
+        const bool vec_res = !p.res || (!(p.ldres & 7) && !((uintptr_t)p.res & 15));
+        const bool vec_gate = !p.gate || (!(p.ldgate & 7) && !((uintptr_t)p.gate & 15));
+        fast = vec_c && vec_res && vec_gate && (nb + 8 <= p.N);
+    }
+    const bool drop_aligned = !(p.N & 7);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         __builtin_amdgcn_wave_barrier();
@@ -246,47 +276,43 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
             const float4 hi = *reinterpret_cast<const float4*>(&slab[rl * SLD + chunk * 8 + 4]);
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             if (m >= p.M || nb >= p.N) continue;
-            if (!fast) {
+            if (GEN && !fast) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (nb + e < p.N) gemm_epilogue<bf16_t>(p, dc, m, nb + e, v[e]);
                 continue;
             }
             float rv[8];
-            if (p.res) {
-                const uint4 t = *reinterpret_cast<const uint4*>((const bf16_t*)p.res + (size_t)m * p.ldres + nb);
-                const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    rv[2 * e] = __uint_as_float(w[e] << 16);
-                    rv[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
-                }
-            }
+            if (has_res) unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)p.res + (size_t)m * p.ldres + nb), rv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 v[e] += bias8[e];
-                if (p.res && p.res_pre) v[e] += rv[e];
-                if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
+                if (has_res && res_pre) v[e] += rv[e];
+                if (relu) v[e] = fmaxf(v[e], 0.f);
             }
-            if (p.gate) {
-                const uint4 t = *reinterpret_cast<const uint4*>((const bf16_t*)p.gate + (size_t)m * p.ldgate + nb);
-                const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+            if (has_gate) {
+                float gv[8];
+                unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)p.gate + (size_t)m * p.ldgate + nb), gv);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[2 * e] = __uint_as_float(w[e] << 16) > 0.f ? v[2 * e] * p.gate_scale : 0.f;
-                    v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u) > 0.f ? v[2 * e + 1] * p.gate_scale : 0.f;
-                }
+                for (int e = 0; e < 8; ++e) v[e] = gv[e] > 0.f ? v[e] * p.gate_scale : 0.f;
             }
-            if (dc.on) {
+            if (may_drop && dc.on) {
                 const uint64_t eid = (uint64_t)m * p.N + nb;
+                float dm[8];
+                if (drop_aligned) {
+                    drop_mult8(dc, eid, dm);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= drop_mult(dc, eid + e);
+                    for (int e = 0; e < 8; ++e) dm[e] = drop_mult(dc, eid + e);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dm[e];
             }
-            if (p.res && !p.res_pre) {
+            if (has_res && !res_pre) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += rv[e];
             }
-            if (p.c_f32) {
+            if (GEN && p.c_f32) {
                 float4* c = reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + nb);
                 if (p.accumulate) {
                     const float4 c0 = c[0], c1 = c[1];
@@ -297,26 +323,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
                 c[1] = make_float4(v[4], v[5], v[6], v[7]);
             } else {
                 uint4* c = reinterpret_cast<uint4*>((bf16_t*)p.C + (size_t)m * p.ldc + nb);
-                if (p.accumulate) {
-                    const uint4 t = *c;
-                    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+                if (GEN && p.accumulate) {
+                    float cv[8];
+                    unpack8(*c, cv);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += __uint_as_float(w[e] << 16);
-                        v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
-                    }
+                    for (int e = 0; e < 8; ++e) v[e] += cv[e];
                 }
-                uint32_t o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
-                *c = make_uint4(o[0], o[1], o[2], o[3]);
+                *c = pack8(v);
             }
         }
     }
 }
-
-template <typename T>
-__global__ void gemm_naive_kernel(dsvg_gemm_desc p, int k_begin, int k_end, float* part);  // gemm.hip
 
 // raw ds_read_b64_tr_b16 probe: lane l reads from byte offset off[l] of a 4 KiB LDS image filled with
 // img[i] = i (16-bit).  Used by the test-suite to pin the hardware transpose semantics.
@@ -335,12 +352,18 @@ extern "C" int dsvg_probe_trread(const int* off, short* out, void* stream) {
     return 0;
 }
 
-int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, float* part, hipStream_t st) {
+template <bool AKC, bool BKC, bool ADROP, int EPI>
+static void launch_variant(const dsvg_gemm_desc& d, dim3 grid, int tiles_n, int nwg, int k_chunk, float* part,
+                           hipStream_t st) {
+    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<AKC, BKC, ADROP, EPI>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
+}
+
+int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, float* part, hipStream_t st) {
     const int Kp = (d.K + 7) / 8 * 8;   // k-contiguous operands are read in 8-element chunks (tail masked)
     const bool aligned = !(d.lda & 7) && !(d.ldb & 7) && !((uintptr_t)d.A & 15) && !((uintptr_t)d.B & 15) &&
                          (!d.a_kc || d.lda >= Kp) && (!d.b_kc || d.ldb >= Kp);
     if (!aligned) {
-        dsvg_set_error("gemm(bf16): operands must be 16-byte aligned with lda/ldb/K multiples of 8 "
+        dsvg_set_error("gemm(bf16): operands must be 16-byte aligned with lda/ldb multiples of 8 "
                        "(lda=%lld ldb=%lld K=%d)", (long long)d.lda, (long long)d.ldb, d.K);
         return -1;
     }
@@ -349,22 +372,46 @@ int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, float* part, hip
     if (!d.b_kc && d.ldb < ((d.N + 7) / 8) * 8) { dsvg_set_error("gemm(bf16): ldb too small for NN operand"); return -1; }
     const int tiles_m = dsvg_cdiv(d.M, TBM), tiles_n = dsvg_cdiv(d.N, TBN);
     const int nwg = tiles_m * tiles_n;
-    const int nsplit = (d.K + k_chunk - 1) / k_chunk;
     dim3 grid(nwg, nsplit);
-    // the dropout-replay prologue is a compile-time variant so the common kernels carry no RNG code
+    if (nsplit > 1 && (nsplit % 8) == 0) grid = dim3(nwg * nsplit, 1);   // XCD-grouped K slices (see kernel)
     const bool adrop = d.a_drop_p > 0.f;
-#define DSVG_LAUNCH_BF16(AK, BK)                                                                                   \
-    do {                                                                                                           \
-        if (adrop) hipLaunchKernelGGL((gemm_bf16_mfma_kernel<AK, BK, true>), grid, dim3(256), 0, st, d, tiles_n,   \
-                                      nwg, k_chunk, part);                                                         \
-        else hipLaunchKernelGGL((gemm_bf16_mfma_kernel<AK, BK, false>), grid, dim3(256), 0, st, d, tiles_n, nwg,   \
-                                k_chunk, part);                                                                    \
-    } while (0)
-    if (d.a_kc && d.b_kc) DSVG_LAUNCH_BF16(true, true);
-    else if (d.a_kc && !d.b_kc) DSVG_LAUNCH_BF16(true, false);
-    else if (!d.a_kc && d.b_kc) DSVG_LAUNCH_BF16(false, true);
-    else DSVG_LAUNCH_BF16(false, false);
-#undef DSVG_LAUNCH_BF16
+
+    // pick the compile-time epilogue variant when the call matches one exactly and everything is 16-byte aligned
+    int epi = EPI_GENERIC;
+    const bool vec_ok = !part && !d.c_f32 && !d.accumulate && !d.res_pre && !(d.N & 7) && !(d.ldc & 7) &&
+                        !((uintptr_t)d.C & 15) && (!d.res || (!(d.ldres & 7) && !((uintptr_t)d.res & 15))) &&
+                        (!d.gate || (!(d.ldgate & 7) && !((uintptr_t)d.gate & 15)));
+    if (vec_ok) {
+        if (!d.res && !d.gate && d.act == 0 && d.drop_p <= 0.f) epi = EPI_BIAS;
+        else if (d.res && !d.gate && d.act == 0) epi = EPI_BIAS_RES_DROP;
+        else if (!d.res && !d.gate && d.act == 1) epi = EPI_BIAS_RELU_DROP;
+        else if (d.gate && !d.res && !d.bias && d.act == 0 && d.drop_p <= 0.f) epi = EPI_GATE;
+    }
+#define DSVG_V(AK, BK, AD, EP) launch_variant<AK, BK, AD, EP>(d, grid, tiles_n, nwg, k_chunk, part, st)
+    if (d.a_kc && d.b_kc) {                 // forward layers
+        if (adrop) DSVG_V(true, true, true, EPI_GENERIC);
+        else if (epi == EPI_BIAS) DSVG_V(true, true, false, EPI_BIAS);
+        else if (epi == EPI_BIAS_RES_DROP) DSVG_V(true, true, false, EPI_BIAS_RES_DROP);
+        else if (epi == EPI_BIAS_RELU_DROP) DSVG_V(true, true, false, EPI_BIAS_RELU_DROP);
+        else DSVG_V(true, true, false, EPI_GENERIC);
+    } else if (d.a_kc && !d.b_kc) {         // input gradients (B = weight read [k][n])
+        if (adrop) {
+            if (epi == EPI_GATE) DSVG_V(true, false, true, EPI_GATE);
+            else if (epi == EPI_BIAS) DSVG_V(true, false, true, EPI_BIAS);
+            else DSVG_V(true, false, true, EPI_GENERIC);
+        } else {
+            if (epi == EPI_GATE) DSVG_V(true, false, false, EPI_GATE);
+            else if (epi == EPI_BIAS) DSVG_V(true, false, false, EPI_BIAS);
+            else DSVG_V(true, false, false, EPI_GENERIC);
+        }
+    } else if (!d.a_kc && !d.b_kc) {        // weight gradients (both operands token-major)
+        if (adrop) DSVG_V(false, false, true, EPI_GENERIC);
+        else DSVG_V(false, false, false, EPI_GENERIC);
+    } else {
+        if (adrop) DSVG_V(false, true, true, EPI_GENERIC);
+        else DSVG_V(false, true, false, EPI_GENERIC);
+    }
+#undef DSVG_V
     DSVG_LAUNCH_CHECK("gemm_bf16_mfma");
     return 0;
 }

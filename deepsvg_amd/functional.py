@@ -280,14 +280,16 @@ class LayerFn(torch.autograd.Function):
         dx2 = dx2.contiguous()
         inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
         # ---- FFN: x2 = x1 + drop4(h W2^T + b2),  h = drop3(relu(xn2 W1^T + b1)) ----
+        # the mask of the residual dropout is replayed ONCE into dx2m; the three consumers read plain data
+        dx2m = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
         with ops.tag("ffn"):
-            dw2 = _wgrad(rt, w2, dx2, h, a_drop_p=p, a_drop_site=s0 + 4)
-            dh = ops.gemm(dx2, rt.w(w2), b_kc=False, a_drop_p=p, a_drop_site=s0 + 4, seed=rt.seed,
-                          gate=h, gate_scale=inv_keep)     # (h > 0) <=> relu passed AND kept by drop3
+            dw2 = _wgrad(rt, w2, dx2m, h)
+            dh = ops.gemm(dx2m, rt.w(w2), b_kc=False, gate=h, gate_scale=inv_keep)   # (h > 0) <=> relu passed AND kept
             dw1 = _wgrad(rt, w1, dh, xn2)
             dxn2 = ops.gemm(dh, rt.w(w1), b_kc=False)
-        db2 = _bgrad(rt, b2, dx2, drop_p=p, drop_site=s0 + 4)
+        db2 = _bgrad(rt, b2, dx2m)
         db1 = _bgrad(rt, b1, dh)
+        del dx2m
         dx1, dn2w, dn2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w.detach(), res=dx2,
                                             dgamma=rt.grad_out(n2w), dbeta=rt.grad_out(n2b))
         # ---- conditioning adds ----
@@ -305,9 +307,11 @@ class LayerFn(torch.autograd.Function):
             if ctx.needs_input_grad[3]:
                 dz = ops.gemm(dg, rt.w(wg), b_kc=False)
         # ---- attention: x1 = x + drop1(ao Wo^T + bo) ----
-        dwo = _wgrad(rt, wo, dx1, ao, a_drop_p=p, a_drop_site=s0 + 1)
-        dbo = _bgrad(rt, bo, dx1, drop_p=p, drop_site=s0 + 1)
-        dao = ops.gemm(dx1, rt.w(wo), b_kc=False, a_drop_p=p, a_drop_site=s0 + 1, seed=rt.seed)
+        dx1m = ops.drop_apply(dx1, p, s0 + 1, rt.seed)
+        dwo = _wgrad(rt, wo, dx1m, ao)
+        dbo = _bgrad(rt, bo, dx1m)
+        dao = ops.gemm(dx1m, rt.w(wo), b_kc=False)
+        del dx1m
         dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed)
         dwin = _wgrad(rt, win, dqkv, xn1)
         dbin = _bgrad(rt, bin_, dqkv)

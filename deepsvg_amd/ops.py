@@ -132,11 +132,14 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
     return out
 
 
-def split_k_for(M, N, K, target_blocks=512):
-    """split factor for the weight-gradient GEMMs (small M x N output, K = #tokens)."""
+def split_k_for(M, N, K, target_blocks=1024):
+    """split factor for the weight-gradient GEMMs (small M x N output, K = #tokens): a multiple of 8 so that the
+    K slices are grouped per XCD (see gemm_bf16.hip), about `target_blocks` workgroups in total."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     s = max(1, target_blocks // tiles)
-    s = min(s, max(1, K // 256))
+    s = min(s, max(1, K // 128))
+    if s >= 8:
+        s = s // 8 * 8
     return s
 
 
@@ -462,6 +465,18 @@ def gate_mul(dy, y, scale=1.0):
     _l.check(_l.load().dsvg_gate_mul(_dt(dy), dy.data_ptr(), y.data_ptr(), out.data_ptr(), dy.numel(), float(scale),
                                      _stream()), "dsvg_gate_mul")
     return out
+
+
+def drop_apply(x, drop_p, drop_site, seed):
+    """y = x * dropmask(seed, site, flat index); returns x itself when drop_p == 0"""
+    if drop_p <= 0:
+        return x
+    _chk(x, seed)
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    _l.check(_l.load().dsvg_drop_apply(_dt(x), x.data_ptr(), y.data_ptr(), x.numel(), float(drop_p), int(drop_site),
+                                       seed.data_ptr(), _stream()), "dsvg_drop_apply")
+    return y
 
 
 def add(a, b):

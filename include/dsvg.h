@@ -211,6 +211,9 @@ int dsvg_cast_weights(int32_t dtype, const float* src, void* dst, void* dst_t, i
 int dsvg_advance_step(int64_t* counter, uint64_t* seed, void* stream);
 /* out[i] = y[i] > 0 ? dy[i]*scale : 0 — backward of ReLU (basic_blocks.py:47-57) from the saved output */
 int dsvg_gate_mul(int32_t dtype, const void* dy, const void* y, void* out, int64_t n, float scale, void* stream);
+/* y[i] = x[i] * dropmask(seed, site, i): replay of an nn.Dropout mask on a gradient (n % 8 == 0) */
+int dsvg_drop_apply(int32_t dtype, const void* x, void* y, int64_t n, float drop_p, uint32_t drop_site,
+                    const uint64_t* seed, void* stream);
 /* out[i] = a[i] + b[i] — the residual add of the latent ResNet (basic_blocks.py:59-65) */
 int dsvg_add(int32_t dtype, const void* a, const void* b, void* out, int64_t n, void* stream);
 /* test hook: raw ds_read_b64_tr_b16 on a 4 KiB LDS image img[i]=i, lane l reads at byte offset off[l] */

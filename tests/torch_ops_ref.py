@@ -40,21 +40,23 @@ def _hash32_t(x):
 
 
 def drop_mult(p, seed, site, idx):
-    """multiplier tensor (0 or 1/(1-p)) for int64 element ids `idx`"""
+    """multiplier tensor (0 or 65536/(65536-thresh16)) for int64 element ids `idx` (dsvg_common.h drop_mult)"""
     if p <= 0 or seed is None:
         return torch.ones(idx.shape, dtype=torch.float32, device=idx.device)
-    p32 = float(np.float32(p))
     s = int(seed.reshape(-1)[0].item()) & 0xFFFFFFFFFFFFFFFF
     s0 = _hash32_int((s & M32) ^ ((site * 0x9E3779B1) & M32))
     s1 = _hash32_int(((s >> 32) + site * 0x85EBCA77 + 0x165667B1) & M32)
-    t = p32 * 4294967296.0
-    thresh = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
-    scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+    thresh = min(65535, int(np.float32(np.float32(p) * np.float32(65536.0) + np.float32(0.5))))
+    scale = float(np.float32(65536.0) / np.float32(65536 - thresh))
     idx = idx.to(torch.int64)
-    lo, hi = idx & M32, (idx >> 32) & M32
+    g = idx >> 3
+    slot = idx & 7
+    lo, hi = g & M32, (g >> 32) & M32
     h = _hash32_t(lo ^ s0)
     h = _hash32_t((h + hi * 0x9E3779B1 + s1) & M32)
-    return torch.where(h < thresh, torch.zeros((), dtype=torch.float32, device=idx.device),
+    w = _hash32_t((h + ((slot >> 1) + 1) * 0x9E3779B9) & M32)
+    draw = torch.where((slot & 1) == 1, w >> 16, w & 0xFFFF)
+    return torch.where(draw < thresh, torch.zeros((), dtype=torch.float32, device=idx.device),
                        torch.full((), scale, dtype=torch.float32, device=idx.device))
 
 
@@ -101,10 +103,8 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
     return out
 
 
-def split_k_for(M, N, K, target_blocks=512):
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    s = max(1, target_blocks // tiles)
-    return min(s, max(1, K // 256))
+def split_k_for(M, N, K, target_blocks=1024):
+    return 1
 
 
 def colsum(a, *, out=None, accumulate=False, drop_p=0.0, drop_site=0, seed=None):
@@ -375,6 +375,13 @@ def advance_step_(counter, seed):
 
 def gate_mul(dy, y, scale=1.0):
     return torch.where(_f(y) > 0, _f(dy) * scale, torch.zeros_like(_f(dy))).to(dy.dtype)
+
+
+def drop_apply(x, drop_p, drop_site, seed):
+    if drop_p <= 0:
+        return x
+    idx = torch.arange(x.numel(), device=x.device, dtype=torch.int64).view(x.shape)
+    return (_f(x) * drop_mult(drop_p, seed, drop_site, idx)).to(x.dtype)
 
 
 def add(a, b):
