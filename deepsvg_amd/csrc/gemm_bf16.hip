@@ -28,6 +28,7 @@ enum {
     EPI_BIAS_RES_DROP = 2,  // C = res + drop(acc [+ bias])
     EPI_BIAS_RELU_DROP = 3, // C = drop(relu(acc [+ bias]))
     EPI_GATE = 4,           // C = gate > 0 ? acc * gate_scale : 0
+    EPI_PARTIAL = 5,        // split-K slice: raw fp32 accumulators to the workspace, nothing else
 };
 
 __device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
         __syncthreads();
     }
 
-    if (part) {   // split-K partial: raw fp32 accumulators, 128-byte row segments per half wave
+    if (EPI == EPI_PARTIAL || (EPI == EPI_GENERIC && part)) {   // split-K partial: raw fp32 accumulators
         float* my_part = part + (size_t)kz * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -259,14 +260,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
         fast = vec_c && vec_res && vec_gate && (nb + 8 <= p.N);
     }
     const bool drop_aligned = !(p.N & 7);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    // NB: the two 32-row halves are handled by one lambda invoked with acc[0][*] and acc[1][*] explicitly: a loop
+    // over i whose (large) body the compiler declines to unroll would index `acc` dynamically and push the
+    // accumulators to scratch memory for the whole kernel (guide rule 20; measured 4x slowdown).
+    auto half_tile = [&](const floatx16& c0, const floatx16& c1, const int i) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + j * 32 + (lane & 31)] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            slab[row * SLD + (lane & 31)] = c0[r];
+            slab[row * SLD + 32 + (lane & 31)] = c1[r];
+        }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -332,7 +336,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
                 *c = pack8(v);
             }
         }
-    }
+    };
+    half_tile(acc[0][0], acc[0][1], 0);
+    half_tile(acc[1][0], acc[1][1], 1);
 }
 
 // raw ds_read_b64_tr_b16 probe: lane l reads from byte offset off[l] of a 4 KiB LDS image filled with
@@ -373,8 +379,18 @@ int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, floa
     const int tiles_m = dsvg_cdiv(d.M, TBM), tiles_n = dsvg_cdiv(d.N, TBN);
     const int nwg = tiles_m * tiles_n;
     dim3 grid(nwg, nsplit);
-    if (nsplit > 1 && (nsplit % 8) == 0) grid = dim3(nwg * nsplit, 1);   // XCD-grouped K slices (see kernel)
+    static const bool force_2d = getenv("DSVG_SPLITK_2D") != nullptr;     // debugging knob
+    if (nsplit > 1 && (nsplit % 8) == 0 && !force_2d) grid = dim3(nwg * nsplit, 1);   // XCD-grouped K slices (see kernel)
     const bool adrop = d.a_drop_p > 0.f;
+#define DSVG_V(AK, BK, AD, EP) launch_variant<AK, BK, AD, EP>(d, grid, tiles_n, nwg, k_chunk, part, st)
+    if (part) {     // split-K slices: dedicated variants that contain no epilogue code at all
+        if (d.a_kc && d.b_kc) { if (adrop) DSVG_V(true, true, true, EPI_PARTIAL); else DSVG_V(true, true, false, EPI_PARTIAL); }
+        else if (d.a_kc && !d.b_kc) { if (adrop) DSVG_V(true, false, true, EPI_PARTIAL); else DSVG_V(true, false, false, EPI_PARTIAL); }
+        else if (!d.a_kc && d.b_kc) { if (adrop) DSVG_V(false, true, true, EPI_PARTIAL); else DSVG_V(false, true, false, EPI_PARTIAL); }
+        else { if (adrop) DSVG_V(false, false, true, EPI_PARTIAL); else DSVG_V(false, false, false, EPI_PARTIAL); }
+        DSVG_LAUNCH_CHECK("gemm_bf16_mfma(split-k)");
+        return 0;
+    }
 
     // pick the compile-time epilogue variant when the call matches one exactly and everything is 16-byte aligned
     int epi = EPI_GENERIC;
@@ -387,7 +403,6 @@ int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, floa
         else if (!d.res && !d.gate && d.act == 1) epi = EPI_BIAS_RELU_DROP;
         else if (d.gate && !d.res && !d.bias && d.act == 0 && d.drop_p <= 0.f) epi = EPI_GATE;
     }
-#define DSVG_V(AK, BK, AD, EP) launch_variant<AK, BK, AD, EP>(d, grid, tiles_n, nwg, k_chunk, part, st)
     if (d.a_kc && d.b_kc) {                 // forward layers
         if (adrop) DSVG_V(true, true, true, EPI_GENERIC);
         else if (epi == EPI_BIAS) DSVG_V(true, true, false, EPI_BIAS);

@@ -59,6 +59,11 @@ def main():
         ("bwd dW1   TN  512x256 xT", lambda: ops.gemm(x512, x256, a_kc=False, b_kc=False, out_dtype=torch.float32, split_k=ops.split_k_for(512, 256, T)), 512, 256, T),
         ("bwd dW2   TN+adrop 256x512 xT", lambda: ops.gemm(x256, x512, a_kc=False, b_kc=False, out_dtype=torch.float32, a_drop_p=0.1, a_drop_site=3, seed=seed, split_k=ops.split_k_for(256, 512, T)), 256, 512, T),
         ("bwd dWin  TN  768x256 xT", lambda: ops.gemm(x768, x256, a_kc=False, b_kc=False, out_dtype=torch.float32, split_k=ops.split_k_for(768, 256, T)), 768, 256, T),
+    ] + [
+        (f"bwd dW1   TN split={s:4d}", (lambda s=s: ops.gemm(x512, x256, a_kc=False, b_kc=False, out_dtype=torch.float32, split_k=s)), 512, 256, T)
+        for s in (32, 64, 128, 256, 512)
+    ] + [
+        ("drop_apply T x256", lambda: ops.drop_apply(x256, 0.1, 5, seed), T, 256, 0),
         ("colsum T x512", lambda: ops.colsum(x512), T, 512, 0),
         ("colsum+drop T x256", lambda: ops.colsum(x256, drop_p=0.1, drop_site=3, seed=seed), T, 256, 0),
     ]

@@ -321,6 +321,24 @@ def test_optimizer_matches_torch_adamw(gpu_device):
     assert step.item() == 3
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_drop_apply_matches_gemm_epilogue_mask(gpu_device, dtype):
+    """the mask replayed by drop_apply must be the mask the GEMM epilogue applied (same element ids)"""
+    T, N, K = 520, 256, 64
+    seed = _seed_tensor(0x1122334455667788)
+    x, w = _rand(T, K, dtype=dtype, seed=1), _rand(N, K, dtype=dtype, seed=2)
+    y0 = ops.gemm(x, w)
+    y1 = ops.gemm(x, w, drop_p=0.25, drop_site=17, seed=seed)
+    keep_gemm = (y1.float() != 0) | (y0.float() == 0)
+    ones = torch.ones(T, N, device=DEV, dtype=dtype)
+    m = ops.drop_apply(ones, 0.25, 17, seed)
+    mr = R.drop_apply(ones, 0.25, 17, seed)
+    assert torch.equal(m, mr)
+    assert torch.equal(m.float() != 0, keep_gemm)
+    frac = (m.float() == 0).float().mean().item()
+    assert abs(frac - 0.25) < 0.01, frac
+
+
 def test_cast_gate_add(gpu_device):
     src = _rand(300, 77, seed=1)
     dst, dst_t = torch.empty(300, 77, device=DEV, dtype=torch.bfloat16), torch.empty(77, 300, device=DEV, dtype=torch.bfloat16)
