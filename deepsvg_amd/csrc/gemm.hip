@@ -13,14 +13,14 @@
 // reference kernel: one thread per output element (debug / odd-stride fallback)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void gemm_naive_kernel(dsvg_gemm_desc p, int k_begin, int k_end, float* part) {
+__global__ void gemm_naive_kernel(dsvg_gemm_desc p, int k_begin, int k_end, float* part, float* rs) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)p.M * p.N) return;
     int m = (int)(idx / p.N), n = (int)(idx % p.N);
     const T* A = (const T*)p.A;
     const T* B = (const T*)p.B;
     DropCtx adc = drop_make(p.a_drop_p, p.seed, p.a_drop_site);
-    float acc = 0.f;
+    float acc = 0.f, asum = 0.f;
     for (int k = k_begin; k < k_end; ++k) {
         float a, b;
         if (p.a_kc) {
@@ -32,7 +32,9 @@ __global__ void gemm_naive_kernel(dsvg_gemm_desc p, int k_begin, int k_end, floa
         }
         b = p.b_kc ? Elem<T>::ld(B + (size_t)n * p.ldb + k) : Elem<T>::ld(B + (size_t)k * p.ldb + n);
         acc = fmaf(a, b, acc);
+        asum += a;
     }
+    if (rs && n == 0) rs[m] = asum;
     if (part) {
         part[(size_t)m * p.N + n] = acc;
     } else {
@@ -63,7 +65,7 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid) {
 
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
-                                                            int k_chunk, float* part) {
+                                                            int k_chunk, float* part, float* rs_part) {
     constexpr int LDA_S = AKC ? 129 : 132;
     constexpr int LDB_S = BKC ? 129 : 132;
     __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
@@ -195,6 +197,13 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const bool do_rs = part != nullptr && rs_part != nullptr && tile_n == 0 && wn == 0;
+    floatx16 accb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+
     if (k_begin < k_end) {
         load_a(k_begin);
         load_b(k_begin);
@@ -218,10 +227,23 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, in
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if (do_rs) {   // row sums of A (bias gradient): MFMA against an all-ones B fragment
+                accb[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, 1.0f, accb[0], 0, 0, 0);
+                accb[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, 1.0f, accb[1], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
 
+    if (do_rs && (lane & 31) == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) rs_part[(size_t)kz * p.M + m] = accb[i][r];
+            }
+    }
     const DropCtx dc = drop_make(p.drop_p, p.seed, p.drop_site);
     float* my_part = part ? part + (size_t)kz * p.M * p.N : nullptr;
 #pragma unroll
@@ -245,13 +267,14 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, in
 // out[j] = [out[j] +] sum_q part[q*stride + j].  Block = 64 column lanes x 4 slices of the partial index;
 // each slice keeps 4 independent accumulators (fixed summation tree -> bit-reproducible), the 4 slices are
 // combined through LDS.  VEC = 4 (float4 lanes) when stride, n and the pointers allow it.
-template <int VEC>
+template <int VEC, int TX>
 __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const float* __restrict__ part, long long P,
                                                                       long long stride, long long n,
                                                                       float* __restrict__ out, int accumulate) {
-    __shared__ float red[4][64][VEC];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const long long j = ((long long)blockIdx.x * 64 + tx) * VEC;
+    constexpr int TY = 256 / TX;           // slices over the partial index
+    __shared__ float red[TY][TX][VEC];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const long long j = ((long long)blockIdx.x * TX + tx) * VEC;
     float acc[4][VEC];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -259,10 +282,10 @@ __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const floa
         for (int e = 0; e < VEC; ++e) acc[u][e] = 0.f;
     if (j < n) {
         long long q = ty;
-        for (; q + 12 < P; q += 16) {
+        for (; q + 3 * TY < P; q += 4 * TY) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float* p = part + (q + 4 * u) * stride + j;
+                const float* p = part + (q + TY * u) * stride + j;
                 if (VEC == 4) {
                     const float4 v = *reinterpret_cast<const float4*>(p);
                     acc[u][0] += v.x; acc[u][1 % VEC] += v.y; acc[u][2 % VEC] += v.z; acc[u][3 % VEC] += v.w;
@@ -271,7 +294,7 @@ __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const floa
                 }
             }
         }
-        for (; q < P; q += 4) {
+        for (; q < P; q += TY) {
             const float* p = part + q * stride + j;
             if (VEC == 4) {
                 const float4 v = *reinterpret_cast<const float4*>(p);
@@ -287,7 +310,9 @@ __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const floa
     if (ty == 0 && j < n) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            float s = (red[0][tx][e] + red[1][tx][e]) + (red[2][tx][e] + red[3][tx][e]);
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < TY; ++t) s += red[t][tx][e];
             if (accumulate) s += out[j + e];
             out[j + e] = s;
         }
@@ -298,12 +323,15 @@ int dsvg_reduce_partials_strided(const float* part, int64_t P, int64_t stride, i
                                  int32_t accumulate, hipStream_t st) {
     if (n <= 0) return 0;
     const bool vec = !(n & 3) && !(stride & 3) && !((uintptr_t)part & 15) && !((uintptr_t)out & 15);
-    if (vec)
-        hipLaunchKernelGGL(reduce_partials_strided_kernel<4>, dim3(dsvg_cdiv(n, 256)), dim3(256), 0, st, part,
-                           (long long)P, (long long)stride, (long long)n, out, accumulate);
-    else
-        hipLaunchKernelGGL(reduce_partials_strided_kernel<1>, dim3(dsvg_cdiv(n, 64)), dim3(256), 0, st, part,
-                           (long long)P, (long long)stride, (long long)n, out, accumulate);
+    const long long cols = vec ? n / 4 : n;
+    // few columns + many partial rows (bias / LayerNorm gradients): 16 slices over the partial index per block;
+    // many columns (weight gradients): 64 column lanes x 4 slices
+    const bool wide = cols >= 64 * 128 || P <= 16;
+#define DSVG_RP(V, X) hipLaunchKernelGGL((reduce_partials_strided_kernel<V, X>), dim3(dsvg_cdiv(cols, X)), dim3(256), 0,   \
+                                         st, part, (long long)P, (long long)stride, (long long)n, out, accumulate)
+    if (vec) { if (wide) DSVG_RP(4, 64); else DSVG_RP(4, 16); }
+    else     { if (wide) DSVG_RP(1, 64); else DSVG_RP(1, 16); }
+#undef DSVG_RP
     DSVG_LAUNCH_CHECK("reduce_partials");
     return 0;
 }
@@ -377,7 +405,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, lo
 
 extern "C" int64_t dsvg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
     if (split_k <= 1) return 0;
-    return (int64_t)split_k * M * N * (int64_t)sizeof(float);
+    return (int64_t)split_k * ((int64_t)M * N + M) * (int64_t)sizeof(float);   // [split][M*N] + [split][M] row sums
 }
 
 extern "C" int dsvg_reduce_partials(const float* partial, int64_t P, int64_t n, float* out,
@@ -420,7 +448,8 @@ extern "C" int dsvg_colsum(int32_t dtype, const void* A, int64_t lda, int64_t M,
     return dsvg_reduce_partials(workspace, nb, N, out, accumulate, stream);
 }
 
-int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, float* part, hipStream_t st);  // gemm_bf16.hip
+int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, float* part, float* rs_part,
+                          hipStream_t st);  // gemm_bf16.hip
 
 extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
     DSVG_CHECK_ARG(dp, "gemm: null desc");
@@ -446,6 +475,8 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
     }
     int nsplit = (d.K + k_chunk - 1) / k_chunk;
     if (split > 1 && (split % 8) == 0) nsplit = split;   // trailing slices may be empty (they write zero partials)
+    DSVG_CHECK_ARG(!d.rowsum || part, "gemm: rowsum needs split_k > 1");
+    float* rs_part = d.rowsum ? part + (size_t)nsplit * d.M * d.N : nullptr;
 
     bool use_naive = d.impl == 1;
     if (d.dtype == DSVG_F32) {
@@ -463,10 +494,11 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
         for (int z = 0; z < nsplit; ++z) {
             const int kb = z * k_chunk, ke = min(d.K, kb + k_chunk);
             float* pz = part ? part + (size_t)z * d.M * d.N : nullptr;
+            float* rz = rs_part ? rs_part + (size_t)z * d.M : nullptr;
             if (d.dtype == DSVG_F32)
-                hipLaunchKernelGGL(gemm_naive_kernel<float>, dim3(dsvg_cdiv(total, 256)), dim3(256), 0, st, d, kb, ke, pz);
+                hipLaunchKernelGGL(gemm_naive_kernel<float>, dim3(dsvg_cdiv(total, 256)), dim3(256), 0, st, d, kb, ke, pz, rz);
             else
-                hipLaunchKernelGGL(gemm_naive_kernel<bf16_t>, dim3(dsvg_cdiv(total, 256)), dim3(256), 0, st, d, kb, ke, pz);
+                hipLaunchKernelGGL(gemm_naive_kernel<bf16_t>, dim3(dsvg_cdiv(total, 256)), dim3(256), 0, st, d, kb, ke, pz, rz);
         }
         DSVG_LAUNCH_CHECK("gemm_naive");
     } else if (d.dtype == DSVG_F32) {
@@ -475,18 +507,22 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
         dim3 grid(nwg, nsplit);
         if (nsplit > 1 && (nsplit % 8) == 0) grid = dim3(nwg * nsplit, 1);
         if (d.a_kc && d.b_kc)
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part, rs_part);
         else if (d.a_kc && !d.b_kc)
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, false>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, false>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part, rs_part);
         else if (!d.a_kc && d.b_kc)
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part, rs_part);
         else
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part, rs_part);
         DSVG_LAUNCH_CHECK("gemm_f32_mfma");
     } else {
-        int rc = dsvg_gemm_bf16_launch(d, k_chunk, nsplit, part, st);
+        int rc = dsvg_gemm_bf16_launch(d, k_chunk, nsplit, part, rs_part, st);
         if (rc) return rc;
     }
-    if (part) return dsvg_reduce_partials(part, nsplit, (int64_t)d.M * d.N, (float*)d.C, d.accumulate, stream);
+    if (part) {
+        int rc = dsvg_reduce_partials(part, nsplit, (int64_t)d.M * d.N, (float*)d.C, d.accumulate, stream);
+        if (rc) return rc;
+        if (rs_part) return dsvg_reduce_partials(rs_part, nsplit, d.M, d.rowsum, d.accumulate, stream);
+    }
     return 0;
 }

@@ -77,7 +77,7 @@ union Frag8 {
 
 template <bool AKC, bool BKC, bool ADROP, int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
-                                                             int k_chunk, float* part) {
+                                                             int k_chunk, float* part, float* rs_part) {
     constexpr int A_ELEMS = AKC ? TBM * LDK : TBK * LDM;
     constexpr int B_ELEMS = BKC ? TBN * LDK : TBK * LDM;
     __shared__ __attribute__((aligned(16))) bf16_t smem[A_ELEMS + B_ELEMS];
@@ -201,6 +201,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // optional row sums of A (bias gradient inside the weight-gradient GEMM): one extra MFMA against an all-ones
+    // B fragment per A fragment, only in the column-tile-0 workgroups and only in the waves with wn == 0
+    const bool do_rs = (EPI == EPI_PARTIAL) && rs_part != nullptr && tile_n == 0 && wn == 0;
+    floatx16 accb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+    Frag8 ones;
+    ones.u = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+
     if (k_begin < k_end) load_tiles(k_begin);
     for (int k0 = k_begin; k0 < k_end; k0 += TBK) {
         store_lds();
@@ -217,6 +228,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            if (EPI == EPI_PARTIAL && do_rs) {
+                accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, ones.v, accb[0], 0, 0, 0);
+                accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ones.v, accb[1], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -233,6 +248,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
                     const int n = n0 + wn * 64 + j * 32 + (lane & 31);
                     if (m < p.M && n < p.N) my_part[(size_t)m * p.N + n] = acc[i][j][r];
                 }
+        if (EPI == EPI_PARTIAL && do_rs && (lane & 31) == 0) {   // every column of accb holds the same row sums
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < p.M) rs_part[(size_t)kz * p.M + m] = accb[i][r];
+                }
+        }
         return;
     }
 
@@ -360,11 +384,13 @@ extern "C" int dsvg_probe_trread(const int* off, short* out, void* stream) {
 
 template <bool AKC, bool BKC, bool ADROP, int EPI>
 static void launch_variant(const dsvg_gemm_desc& d, dim3 grid, int tiles_n, int nwg, int k_chunk, float* part,
-                           hipStream_t st) {
-    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<AKC, BKC, ADROP, EPI>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part);
+                           float* rs_part, hipStream_t st) {
+    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<AKC, BKC, ADROP, EPI>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk,
+                       part, rs_part);
 }
 
-int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, float* part, hipStream_t st) {
+int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, float* part, float* rs_part,
+                          hipStream_t st) {
     const int Kp = (d.K + 7) / 8 * 8;   // k-contiguous operands are read in 8-element chunks (tail masked)
     const bool aligned = !(d.lda & 7) && !(d.ldb & 7) && !((uintptr_t)d.A & 15) && !((uintptr_t)d.B & 15) &&
                          (!d.a_kc || d.lda >= Kp) && (!d.b_kc || d.ldb >= Kp);
@@ -382,7 +408,7 @@ int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, floa
     static const bool force_2d = getenv("DSVG_SPLITK_2D") != nullptr;     // debugging knob
     if (nsplit > 1 && (nsplit % 8) == 0 && !force_2d) grid = dim3(nwg * nsplit, 1);   // XCD-grouped K slices (see kernel)
     const bool adrop = d.a_drop_p > 0.f;
-#define DSVG_V(AK, BK, AD, EP) launch_variant<AK, BK, AD, EP>(d, grid, tiles_n, nwg, k_chunk, part, st)
+#define DSVG_V(AK, BK, AD, EP) launch_variant<AK, BK, AD, EP>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, st)
     if (part) {     // split-K slices: dedicated variants that contain no epilogue code at all
         if (d.a_kc && d.b_kc) { if (adrop) DSVG_V(true, true, true, EPI_PARTIAL); else DSVG_V(true, true, false, EPI_PARTIAL); }
         else if (d.a_kc && !d.b_kc) { if (adrop) DSVG_V(true, false, true, EPI_PARTIAL); else DSVG_V(true, false, false, EPI_PARTIAL); }

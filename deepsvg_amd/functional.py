@@ -61,6 +61,22 @@ def _wgrad(rt, param, dy, x, *, a_drop_p=0.0, a_drop_site=0):
     return out
 
 
+def _wbgrad(rt, weight, bias, dy, x):
+    """(dW, db) of y = x W^T + b from dy: db[n] = sum_t dy[t, n] is the row sum of the GEMM's A operand, so it
+    rides on the weight-gradient GEMM (an extra MFMA against ones in a few workgroups) whenever that GEMM is
+    split over tokens; otherwise a separate column-sum launch."""
+    n_out, k_in = weight.shape
+    split = ops.split_k_for(n_out, k_in, dy.shape[0])
+    dw = rt.grad_out(weight)
+    db = rt.grad_out(bias)
+    if split > 1:
+        ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in), split_k=split, rowsum=db)
+    else:
+        ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in))
+        ops.colsum(dy, out=db)
+    return dw, db
+
+
 def _bgrad(rt, param, dy, *, drop_p=0.0, drop_site=0):
     out = rt.grad_out(param)
     ops.colsum(dy, out=out, drop_p=drop_p, drop_site=drop_site, seed=rt.seed)
@@ -118,8 +134,11 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[1]:
             dx = ops.gemm(dy_eff, rt.w(weight), b_kc=False, a_drop_p=a_drop_p_eff, a_drop_site=a_site, seed=rt.seed)
-        dw = _wgrad(rt, weight, dy_eff, x, a_drop_p=a_drop_p_eff, a_drop_site=a_site)
-        db = _bgrad(rt, bias, dy_eff, drop_p=a_drop_p_eff, drop_site=a_site) if bias is not None else None
+        if a_drop_p_eff == 0.0 and bias is not None:
+            dw, db = _wbgrad(rt, weight, bias, dy_eff, x)
+        else:
+            dw = _wgrad(rt, weight, dy_eff, x, a_drop_p=a_drop_p_eff, a_drop_site=a_site)
+            db = _bgrad(rt, bias, dy_eff, drop_p=a_drop_p_eff, drop_site=a_site) if bias is not None else None
         return None, dx, dw, db, None, dres, None, None, None
 
 
@@ -140,8 +159,7 @@ class ResBlockFn(torch.autograd.Function):
         z, r, weight, bias = ctx.saved_tensors
         dout = dout.contiguous()
         dpre = ops.gate_mul(dout, r, 1.0)
-        dw = _wgrad(rt, weight, dpre, z)
-        db = _bgrad(rt, bias, dpre)
+        dw, db = _wbgrad(rt, weight, bias, dpre, z)
         dz = ops.gemm(dpre, rt.w(weight), b_kc=False, res=dout)
         return None, dz, dw, db
 
@@ -228,8 +246,7 @@ class EmbedFn(torch.autograd.Function):
             dpos[ctx.S:].zero_()
         dpre = ops.add_pos_bwd(dsrc.contiguous(), ctx.n_seq, ctx.S, dpos[:ctx.S], want_dx=True, drop_p=ctx.p,
                                drop_site=ctx.site, seed=rt.seed)
-        dw = _wgrad(rt, fcn_w, dpre, A)
-        db = _bgrad(rt, fcn_b, dpre)
+        dw, db = _wbgrad(rt, fcn_w, fcn_b, dpre, A)
         dA = ops.gemm(dpre, rt.w(fcn_w), b_kc=False)
         d_arg = rt.grad_out(arg_embed)
         d_cmd = rt.grad_out(command_embed)
@@ -283,12 +300,10 @@ class LayerFn(torch.autograd.Function):
         # the mask of the residual dropout is replayed ONCE into dx2m; the three consumers read plain data
         dx2m = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
         with ops.tag("ffn"):
-            dw2 = _wgrad(rt, w2, dx2m, h)
+            dw2, db2 = _wbgrad(rt, w2, b2, dx2m, h)
             dh = ops.gemm(dx2m, rt.w(w2), b_kc=False, gate=h, gate_scale=inv_keep)   # (h > 0) <=> relu passed AND kept
-            dw1 = _wgrad(rt, w1, dh, xn2)
+            dw1, db1 = _wbgrad(rt, w1, b1, dh, xn2)
             dxn2 = ops.gemm(dh, rt.w(w1), b_kc=False)
-        db2 = _bgrad(rt, b2, dx2m)
-        db1 = _bgrad(rt, b1, dh)
         del dx2m
         dx1, dn2w, dn2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w.detach(), res=dx2,
                                             dgamma=rt.grad_out(n2w), dbeta=rt.grad_out(n2b))
@@ -296,25 +311,21 @@ class LayerFn(torch.autograd.Function):
         dz = dl = dwg = dbg = dwg2 = dbg2 = None
         if l is not None:
             dg2 = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 5, rt.seed)
-            dwg2 = _wgrad(rt, wg2, dg2, l)
-            dbg2 = _bgrad(rt, bg2, dg2)
+            dwg2, dbg2 = _wbgrad(rt, wg2, bg2, dg2, l)
             if ctx.needs_input_grad[4]:
                 dl = ops.gemm(dg2, rt.w(wg2), b_kc=False)
         if z is not None:
             dg = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed)
-            dwg = _wgrad(rt, wg, dg, z)
-            dbg = _bgrad(rt, bg, dg)
+            dwg, dbg = _wbgrad(rt, wg, bg, dg, z)
             if ctx.needs_input_grad[3]:
                 dz = ops.gemm(dg, rt.w(wg), b_kc=False)
         # ---- attention: x1 = x + drop1(ao Wo^T + bo) ----
         dx1m = ops.drop_apply(dx1, p, s0 + 1, rt.seed)
-        dwo = _wgrad(rt, wo, dx1m, ao)
-        dbo = _bgrad(rt, bo, dx1m)
+        dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao)
         dao = ops.gemm(dx1m, rt.w(wo), b_kc=False)
         del dx1m
         dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed)
-        dwin = _wgrad(rt, win, dqkv, xn1)
-        dbin = _bgrad(rt, bin_, dqkv)
+        dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1)
         dxn1 = ops.gemm(dqkv, rt.w(win), b_kc=False)
         dx, dn1w, dn1b = ops.layernorm_bwd(dxn1, x, mean1, rstd1, n1w.detach(), res=dx1,
                                            dgamma=rt.grad_out(n1w), dbeta=rt.grad_out(n1b))

@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("seed", vp),
         ("accumulate", c_i32),
         ("split_k", c_i32), ("workspace", vp), ("workspace_bytes", c_i64),
+        ("rowsum", vp),
         ("impl", c_i32),
     ]
 

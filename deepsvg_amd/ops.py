@@ -77,8 +77,9 @@ def _rowmajor(t):
 # ------------------------------------------------------------------------------------------------
 def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=0, gate=None, gate_scale=1.0,
          drop_p=0.0, drop_site=0, a_drop_p=0.0, a_drop_site=0, seed=None, out=None, out_dtype=None,
-         accumulate=False, split_k=1, impl=0):
-    """C[M,N] = epi(sum_k A(m,k) B(n,k)).  a: [M,K] if a_kc else [K,M]; b: [N,K] if b_kc else [K,N]."""
+         accumulate=False, split_k=1, impl=0, rowsum=None):
+    """C[M,N] = epi(sum_k A(m,k) B(n,k)).  a: [M,K] if a_kc else [K,M]; b: [N,K] if b_kc else [K,N].
+    rowsum (fp32 [M], only with split_k > 1): also rowsum[m] = sum_k A(m,k) (bias gradient of a weight-grad GEMM)."""
     _chk(a, b, bias, res, gate, seed, out)
     _rowmajor(a), _rowmajor(b)
     assert a.dtype == b.dtype
@@ -121,6 +122,11 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
         nbytes = _l.load().dsvg_gemm_workspace_bytes(M, N, split_k)
         ws = _ws(nbytes, a.device)
         d.split_k, d.workspace, d.workspace_bytes = split_k, ws.data_ptr(), ws.numel() * 4
+        if rowsum is not None:
+            assert rowsum.dtype == torch.float32 and rowsum.is_contiguous() and rowsum.numel() == M
+            d.rowsum = rowsum.data_ptr()
+    else:
+        assert rowsum is None, "rowsum needs split_k > 1"
     if PROFILE_ON and _TAG is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -132,7 +138,7 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
     return out
 
 
-def split_k_for(M, N, K, target_blocks=1024):
+def split_k_for(M, N, K, target_blocks=512):
     """split factor for the weight-gradient GEMMs (small M x N output, K = #tokens): a multiple of 8 so that the
     K slices are grouped per XCD (see gemm_bf16.hip), about `target_blocks` workgroups in total."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)

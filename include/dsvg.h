@@ -58,6 +58,9 @@ typedef struct dsvg_gemm_desc {
     int32_t accumulate;                         /* C += result                                   */
     int32_t split_k; float* workspace; int64_t workspace_bytes; /* split over K (weight grads);
                                                    needs c_f32 output and no epilogue            */
+    float* rowsum;                              /* optional fp32 [M]: rowsum[m] = sum_k A(m,k), i.e.
+                                                   the bias gradient for free inside the weight-
+                                                   gradient GEMM (only with split_k > 1)         */
     int32_t impl;                               /* 0 = MFMA kernel, 1 = one-thread-per-output    */
 } dsvg_gemm_desc;
 

@@ -126,6 +126,21 @@ def test_gemm_weight_grad_splitk_with_dropout_replay(gpu_device, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,n_out,k_in,split", [(4100, 512, 256, 16), (992, 2827, 256, 4), (3000, 7, 256, 8), (640, 256, 704, 3)])
+def test_gemm_weight_grad_with_fused_bias_rowsum(gpu_device, dtype, T, n_out, k_in, split):
+    """dW and db from ONE split-K GEMM: rowsum[m] = sum_t dy[t, m] via an MFMA against ones"""
+    ld = (n_out + 7) // 8 * 8
+    buf = torch.zeros(T, ld, device=DEV, dtype=dtype)
+    buf[:, :n_out] = _rand(T, n_out, dtype=dtype, seed=21)
+    dy, x = buf[:, :n_out], _rand(T, k_in, dtype=dtype, seed=22)
+    dw = torch.empty(n_out, k_in, device=DEV, dtype=torch.float32)
+    db = torch.empty(n_out, device=DEV, dtype=torch.float32)
+    ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw, split_k=split, rowsum=db)
+    _close(dw, R.gemm(dy, x, a_kc=False, b_kc=False, out_dtype=torch.float32), _tol(dtype, T), "dW")
+    _close(db, dy.float().sum(0), 1e-5 * T ** 0.5 if dtype == torch.float32 else 1e-2, "fused bias grad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_args_head_shapes(gpu_device, dtype):
     """N = 11*257 = 2827 (not a multiple of 8): forward, dX with a padded-stride dlogits, dW"""
     T, d, N = 992, 256, 2827

@@ -73,7 +73,7 @@ def _f(t):
 # ----------------------------------------------------------------------------------------------------
 def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=0, gate=None, gate_scale=1.0,
          drop_p=0.0, drop_site=0, a_drop_p=0.0, a_drop_site=0, seed=None, out=None, out_dtype=None,
-         accumulate=False, split_k=1, impl=0):
+         accumulate=False, split_k=1, impl=0, rowsum=None):
     af = _f(a)
     if a_drop_p > 0:
         af = af * drop_mult(a_drop_p, seed, a_drop_site, _ids(a.shape[0], a.shape[1], a.device))
@@ -81,6 +81,8 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
     A = af if a_kc else af.t()
     B = _f(b) if b_kc else _f(b).t()
     v = A @ B.t()
+    if rowsum is not None:
+        rowsum.copy_(rowsum + A.sum(1) if accumulate else A.sum(1))
     M, N = v.shape
     if bias is not None:
         v = v + _f(bias)
@@ -103,8 +105,15 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
     return out
 
 
-def split_k_for(M, N, K, target_blocks=1024):
-    return 1
+def split_k_for(M, N, K, target_blocks=512):
+    """same policy as deepsvg_amd.ops.split_k_for (the emulated gemm ignores the value, but the host logic that
+    decides whether the bias gradient can ride on the weight-gradient GEMM depends on it)"""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    s = max(1, target_blocks // tiles)
+    s = min(s, max(1, K // 128))
+    if s >= 8:
+        s = s // 8 * 8
+    return s
 
 
 def colsum(a, *, out=None, accumulate=False, drop_p=0.0, drop_site=0, seed=None):
