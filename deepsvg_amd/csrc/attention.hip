@@ -11,6 +11,15 @@
 #include "dsvg_common.h"
 #include "../../include/dsvg.h"
 
+// bf16 MFMA variant for 17..32-token sequences (attention_mfma.hip)
+bool dsvg_attention_mfma_ok(int32_t dtype, int32_t S, int32_t n_heads);
+int dsvg_attention_fwd_mfma(const void* qkv, const uint64_t* key_mask, void* out, int64_t n_seq, int32_t S,
+                            int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
+                            hipStream_t st);
+int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const void* dout, void* dqkv, int64_t n_seq,
+                            int32_t S, int32_t n_heads, float scale, float drop_p, uint32_t drop_site,
+                            const uint64_t* seed, hipStream_t st);
+
 template <typename T, int SP, int HG>
 struct AttnCfg {
     static constexpr int HPW = 64 / SP;          // heads per wave
@@ -292,6 +301,8 @@ extern "C" int dsvg_attention_fwd(int32_t dtype, const void* qkv, const uint64_t
     DSVG_CHECK_ARG(qkv && out && n_seq > 0 && S > 0 && S <= 64 && n_heads > 0, "attention_fwd: bad args (S=%d)", S);
     DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_fwd: dropout needs a seed pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (dsvg_attention_mfma_ok(dtype, S, n_heads))
+        return dsvg_attention_fwd_mfma(qkv, key_mask, out, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
     if (dtype == DSVG_F32) {
         DSVG_ATTN_DISPATCH(launch_fwd, float, qkv, key_mask, out, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
     } else if (dtype == DSVG_BF16) {
@@ -307,6 +318,8 @@ extern "C" int dsvg_attention_bwd(int32_t dtype, const void* qkv, const uint64_t
     DSVG_CHECK_ARG(qkv && dout && dqkv && n_seq > 0 && S > 0 && S <= 64 && n_heads > 0, "attention_bwd: bad args");
     DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_bwd: dropout needs a seed pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (dsvg_attention_mfma_ok(dtype, S, n_heads))
+        return dsvg_attention_bwd_mfma(qkv, key_mask, dout, dqkv, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
     if (dtype == DSVG_F32) {
         DSVG_ATTN_DISPATCH(launch_bwd, float, qkv, key_mask, dout, dqkv, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
     } else if (dtype == DSVG_BF16) {

@@ -1,0 +1,297 @@
+// MFMA attention core for the bf16 path, sequences of 17..32 tokens, head_dim 32 (the two big stacks of the
+// hierarchical model: S = 32 encoder, S = 31 decoder).  One 512-thread workgroup per sequence, one wave per head;
+// the q|k|v slabs of the 8 heads are staged once in LDS (rows >= S zero-filled: 0 * garbage would be NaN in an
+// MFMA), every matrix product of the head is 2 x v_mfma_f32_32x32x16_bf16:
+//
+//   forward   St = K Q^T   (A = K rows, B = Q rows)  -> lane (q = l&31, h2 = l>>5) holds S[q][key(r,h2)], r<16
+//             softmax over keys = 16 local registers + one exchange with lane^32
+//             O^T = V^T P^T (A = V^T by ds_read_b64_tr_b16, B = the lane's own P registers, key order permuted
+//                            identically on both operands)  -> lane holds O[q][d(r,h2)]
+//   backward  pass A (same orientation):  P, dP = V dO^T, D_q = sum_k P dP, dS;  dQ^T = K^T dS^T
+//             pass B (operands swapped):  S2 = Q K^T, dP2 = dO V^T -> lane (key, h2) holds [q(r,h2)][key];
+//                                          dK^T = Q^T dS2, dV^T = dO^T P~2      (lse_q, D_q through LDS)
+//   with key(r,h2) = q(r,h2) = d(r,h2) = (r&3) + 8*(r>>2) + 4*h2  (the 32x32 MFMA C layout).
+//
+// ~20 MFMAs and a few hundred VALU ops per head instead of ~7000 FMAs per lane in the VALU kernel
+// (attention.hip, kept for fp32 and for the 8-token group stages); the kernel is HBM-bound.
+// Replaces deepsvg/model/layers/functional.py:168,197-248 and its autograd backward.
+#include "dsvg_common.h"
+#include "../../include/dsvg.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short shortx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int HG = 8;            // heads (= waves) per workgroup
+constexpr int W = HG * 32;       // columns of one q/k/v slab
+constexpr int LD = 3 * W + 8;    // row stride of the qkv image (elements); 388 dwords == 4 (mod 64)
+constexpr int LDO = W + 8;       // row stride of the dO image
+
+union F8 {
+    bf16x8 v;
+    shortx4 h[2];
+    uint4 u;
+};
+
+__device__ __forceinline__ int rowmap(int r, int h2) { return (r & 3) + 8 * (r >> 2) + 4 * h2; }
+
+__device__ __forceinline__ bf16x8 row_frag(const bf16_t* img, int ld, int row, int col0, int step, int h2) {
+    F8 f;
+    f.u = *reinterpret_cast<const uint4*>(&img[row * ld + col0 + 16 * step + 8 * h2]);
+    return f.v;
+}
+// A[i = column c (lane&31)][k-slot e] = img[row(8*ks + e, h2)][col0 + c]: two hardware-transposed 4x16 reads
+__device__ __forceinline__ bf16x8 col_frag(const bf16_t* img, int ld, int col0, int ks, int lane) {
+    const int g = lane >> 4, q16 = lane & 15;
+    const int row = 16 * ks + 4 * (g >> 1) + (q16 >> 2);
+    const int col = col0 + 16 * (g & 1) + 4 * (q16 & 3);
+    F8 f;
+    f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(&img[row * ld + col]));
+    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(&img[(row + 8) * ld + col]));
+    return f.v;
+}
+__device__ __forceinline__ bf16x8 pack_regs(const float (&p)[16], int ks) {
+    F8 f;
+    f.u = make_uint4(f2bf_pk(p[8 * ks + 0], p[8 * ks + 1]), f2bf_pk(p[8 * ks + 2], p[8 * ks + 3]),
+                     f2bf_pk(p[8 * ks + 4], p[8 * ks + 5]), f2bf_pk(p[8 * ks + 6], p[8 * ks + 7]));
+    return f.v;
+}
+// lane holds out[row = lane&31][d = rowmap(r, h2)]: four 8-byte pieces per lane into the staging image
+__device__ __forceinline__ void stage_rows(bf16_t* img, int ld, int row, int col0, int h2, const floatx16& v) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint2 t;
+        t.x = f2bf_pk(v[4 * c + 0], v[4 * c + 1]);
+        t.y = f2bf_pk(v[4 * c + 2], v[4 * c + 3]);
+        *reinterpret_cast<uint2*>(&img[row * ld + col0 + 8 * c + 4 * h2]) = t;
+    }
+}
+
+// rows [0,S) of `cols` columns, 16-byte pieces; rows [S,32) are zero-filled
+__device__ __forceinline__ void load_slab(bf16_t* dst, int ld_dst, const bf16_t* src, long long ld_src, int S, int cols) {
+    const int cpr = cols / 8;
+    for (int idx = threadIdx.x; idx < 32 * cpr; idx += 512) {
+        const int r = idx / cpr, c = idx % cpr;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r < S) v = *reinterpret_cast<const uint4*>(src + r * ld_src + 8 * c);
+        *reinterpret_cast<uint4*>(dst + r * ld_dst + 8 * c) = v;
+    }
+}
+__device__ __forceinline__ void store_slab(bf16_t* dst, long long ld_dst, const bf16_t* src, int ld_src, int S, int cols) {
+    const int cpr = cols / 8;
+    for (int idx = threadIdx.x; idx < S * cpr; idx += 512) {
+        const int r = idx / cpr, c = idx % cpr;
+        *reinterpret_cast<uint4*>(dst + r * ld_dst + 8 * c) = *reinterpret_cast<const uint4*>(src + r * ld_src + 8 * c);
+    }
+}
+
+__global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv,
+                                                            const uint64_t* __restrict__ key_mask,
+                                                            bf16_t* __restrict__ out, int S, int H, float scale,
+                                                            float drop_p, uint32_t drop_site, const uint64_t* seed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);   // [32][LD]
+    const int b = blockIdx.x, hg = blockIdx.y, d = H * 32;
+    const int lane = threadIdx.x & 63, hh = threadIdx.x >> 6;
+    const int li = lane & 31, h2 = lane >> 5;
+    const int h = hg * HG + hh;
+    const bf16_t* src = qkv + (size_t)b * S * 3 * d + (size_t)hg * W;
+    load_slab(tile, LD, src, 3LL * d, S, W);
+    load_slab(tile + W, LD, src + d, 3LL * d, S, W);
+    load_slab(tile + 2 * W, LD, src + 2 * d, 3LL * d, S, W);
+    __syncthreads();
+
+    const uint64_t km = (key_mask ? key_mask[b] : ~0ull) & ((S >= 64) ? ~0ull : ((1ull << S) - 1ull));
+    const DropCtx dc = drop_make(drop_p, seed, drop_site);
+    const int qc = hh * 32, kc = W + hh * 32, vc = 2 * W + hh * 32;
+
+    floatx16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int step = 0; step < 2; ++step)
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tile, LD, li, kc, step, h2),
+                                                     row_frag(tile, LD, li, qc, step, h2), st, 0, 0, 0);
+    // st[r] = q_li . k_key(r,h2)
+    float p[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = rowmap(r, h2);
+        p[r] = ((km >> key) & 1ull) ? st[r] * scale : -INFINITY;
+        m = fmaxf(m, p[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        p[r] = (p[r] == -INFINITY) ? 0.f : __expf(p[r] - m);
+        l += p[r];
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    const uint64_t ebase = (((uint64_t)b * H + h) * S + li) * S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = p[r] * inv * drop_mult(dc, ebase + rowmap(r, h2));
+    if (li >= S) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = 0.f;     // padded query row: keep NaNs of an all-masked row out of the MFMA
+    }
+    floatx16 ot;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(tile, LD, vc, ks, lane), pack_regs(p, ks), ot, 0, 0, 0);
+    // ot[r] = O[q = li][d = rowmap(r,h2)]; the head's q slab is dead: reuse it as the output staging slab
+    stage_rows(tile, LD, li, qc, h2, ot);
+    __syncthreads();
+    store_slab(out + (size_t)b * S * d + (size_t)hg * W, (long long)d, tile, LD, S, W);
+}
+
+__global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv,
+                                                            const uint64_t* __restrict__ key_mask,
+                                                            const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
+                                                            int S, int H, float scale, float drop_p, uint32_t drop_site,
+                                                            const uint64_t* seed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);          // [32][LD]   q|k|v
+    bf16_t* dtile = tile + 32 * LD;                              // [32][LDO]  dO
+    float* stat = reinterpret_cast<float*>(dtile + 32 * LDO);    // [HG][32][2] lse, D
+    const int b = blockIdx.x, hg = blockIdx.y, d = H * 32;
+    const int lane = threadIdx.x & 63, hh = threadIdx.x >> 6;
+    const int li = lane & 31, h2 = lane >> 5;
+    const int h = hg * HG + hh;
+    const bf16_t* src = qkv + (size_t)b * S * 3 * d + (size_t)hg * W;
+    load_slab(tile, LD, src, 3LL * d, S, W);
+    load_slab(tile + W, LD, src + d, 3LL * d, S, W);
+    load_slab(tile + 2 * W, LD, src + 2 * d, 3LL * d, S, W);
+    load_slab(dtile, LDO, dout + (size_t)b * S * d + (size_t)hg * W, (long long)d, S, W);
+    __syncthreads();
+
+    const uint64_t km = (key_mask ? key_mask[b] : ~0ull) & ((S >= 64) ? ~0ull : ((1ull << S) - 1ull));
+    const DropCtx dc = drop_make(drop_p, seed, drop_site);
+    const int qc = hh * 32, kc = W + hh * 32, vc = 2 * W + hh * 32, oc = hh * 32;
+    const uint64_t hbase = ((uint64_t)b * H + h) * S;            // id(q, key) = (hbase + q) * S + key
+    float* my_stat = stat + hh * 64;
+
+    floatx16 acc, acc2;
+    float p[16], g[16];
+    // ---------------- pass A: lane = (query li, half h2), registers over keys -----------------------------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tile, LD, li, kc, step, h2),
+                                                      row_frag(tile, LD, li, qc, step, h2), acc, 0, 0, 0);      // K Q^T
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tile, LD, li, vc, step, h2),
+                                                       row_frag(dtile, LDO, li, oc, step, h2), acc2, 0, 0, 0);  // V dO^T
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        p[r] = ((km >> rowmap(r, h2)) & 1ull) ? acc[r] * scale : -INFINITY;
+        m = fmaxf(m, p[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        p[r] = (p[r] == -INFINITY) ? 0.f : __expf(p[r] - m);
+        l += p[r];
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    const float lse = m + __logf(l);
+    float D = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        p[r] *= inv;                                                               // P[q][key]
+        g[r] = acc2[r] * drop_mult(dc, (hbase + li) * S + rowmap(r, h2));          // dP[q][key]
+        D = fmaf(p[r], g[r], D);
+    }
+    D += __shfl_xor(D, 32, 64);
+    const bool qvalid = li < S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = qvalid ? p[r] * (g[r] - D) * scale : 0.f;  // scale * dS[q][key]
+    if (h2 == 0) { my_stat[li * 2 + 0] = lse; my_stat[li * 2 + 1] = D; }
+    floatx16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(tile, LD, kc, ks, lane), pack_regs(g, ks), dq, 0, 0, 0);
+    // dq[r] = dQ[q = li][d = rowmap(r,h2)]
+    __builtin_amdgcn_wave_barrier();
+
+    // ---------------- pass B: lane = (key li, half h2), registers over queries -----------------------------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tile, LD, li, qc, step, h2),
+                                                      row_frag(tile, LD, li, kc, step, h2), acc, 0, 0, 0);      // Q K^T
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dtile, LDO, li, oc, step, h2),
+                                                       row_frag(tile, LD, li, vc, step, h2), acc2, 0, 0, 0);    // dO V^T
+    }
+    const bool kvalid = (km >> li) & 1ull;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = rowmap(r, h2);
+        const float lse_q = my_stat[q * 2 + 0], D_q = my_stat[q * 2 + 1];
+        const bool ok = kvalid && q < S;
+        const float pr = ok ? __expf(acc[r] * scale - lse_q) : 0.f;               // P[q][key = li]
+        const float mult = drop_mult(dc, (hbase + q) * S + li);
+        p[r] = pr * mult;                                                          // P~ (as used by O = P~ V)
+        g[r] = ok ? pr * (acc2[r] * mult - D_q) * scale : 0.f;                     // scale * dS[q][key]
+    }
+    floatx16 dk, dv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(tile, LD, qc, ks, lane), pack_regs(g, ks), dk, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(dtile, LDO, oc, ks, lane), pack_regs(p, ks), dv, 0, 0, 0);
+    }
+    // every operand read of this head's slabs is done (same wave, in-order LDS): stage dq|dk|dv over q|k|v
+    __builtin_amdgcn_wave_barrier();
+    stage_rows(tile, LD, li, qc, h2, dq);
+    stage_rows(tile, LD, li, kc, h2, dk);
+    stage_rows(tile, LD, li, vc, h2, dv);
+    __syncthreads();
+    bf16_t* dst = dqkv + (size_t)b * S * 3 * d + (size_t)hg * W;
+    store_slab(dst, 3LL * d, tile, LD, S, W);
+    store_slab(dst + d, 3LL * d, tile + W, LD, S, W);
+    store_slab(dst + 2 * d, 3LL * d, tile + 2 * W, LD, S, W);
+}
+
+}  // namespace
+
+bool dsvg_attention_mfma_ok(int32_t dtype, int32_t S, int32_t n_heads) {
+    static const bool off = getenv("DSVG_ATTN_VALU") != nullptr;
+    return !off && dtype == DSVG_BF16 && S > 16 && S <= 32 && (n_heads % HG) == 0;
+}
+
+int dsvg_attention_fwd_mfma(const void* qkv, const uint64_t* key_mask, void* out, int64_t n_seq, int32_t S,
+                            int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
+                            hipStream_t st) {
+    const size_t lds = (size_t)32 * LD * sizeof(bf16_t);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)n_seq, n_heads / HG), dim3(512), lds, st, (const bf16_t*)qkv,
+                       key_mask, (bf16_t*)out, S, n_heads, scale, drop_p, drop_site, seed);
+    DSVG_LAUNCH_CHECK("attention_fwd_mfma");
+    return 0;
+}
+
+int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const void* dout, void* dqkv, int64_t n_seq,
+                            int32_t S, int32_t n_heads, float scale, float drop_p, uint32_t drop_site,
+                            const uint64_t* seed, hipStream_t st) {
+    const size_t lds = (size_t)32 * (LD + LDO) * sizeof(bf16_t) + (size_t)HG * 64 * sizeof(float);
+    auto kern = attn_bwd_mfma_kernel;
+    DSVG_ENSURE_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq, n_heads / HG), dim3(512), lds, st, (const bf16_t*)qkv, key_mask,
+                       (const bf16_t*)dout, (bf16_t*)dqkv, S, n_heads, scale, drop_p, drop_site, seed);
+    DSVG_LAUNCH_CHECK("attention_bwd_mfma");
+    return 0;
+}
