@@ -110,6 +110,7 @@ def main():
     model = deepsvg_amd.SVGTransformer(cfg)
     sd_cpu = det_state_dict(model, seed=42)                 # same weights on every rank (and for the CPU leg)
     model.load_state_dict(sd_cpu)
+    torch.manual_seed(42 + rank)                            # per-rank dropout streams (weights are already fixed)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     model.to(device).set_compute_dtype(dtype)
     model.train()
@@ -118,7 +119,9 @@ def main():
     commands, args = commands.to(device), args.to(device)
 
     log(f"model on {device}, dtype={a.dtype}, batch={a.batch}, world={world}")
-    use_graph = bool(a.graph)
+    # hipGraph replay of the whole step is verified on one GPU; with RCCL collectives inside the captured region it
+    # is opt-in (DSVG_BENCH_GRAPH_DDP=1) because it cannot be exercised on the single-GPU development boxes
+    use_graph = bool(a.graph) and (world == 1 or os.environ.get("DSVG_BENCH_GRAPH_DDP") == "1")
     ts = TrainStep(model, loss_fn, lr=1e-3 * world, grad_clip=1.0, use_graph=use_graph)
     try:
         ts.step(commands, args)

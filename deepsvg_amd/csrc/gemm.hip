@@ -241,11 +241,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) rs_part[(size_t)kz * p.M + m] = accb[i][r];
+                if (m < p.M) rs_part[(size_t)kz * ((size_t)p.M * p.N + p.M) + m] = accb[i][r];
             }
     }
     const DropCtx dc = drop_make(p.drop_p, p.seed, p.drop_site);
-    float* my_part = part ? part + (size_t)kz * p.M * p.N : nullptr;
+    // K-slice z of the workspace = [M*N partial | M row sums (only when requested)]
+    float* my_part = part ? part + (size_t)kz * ((size_t)p.M * p.N + (rs_part ? p.M : 0)) : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -476,7 +477,8 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
     int nsplit = (d.K + k_chunk - 1) / k_chunk;
     if (split > 1 && (split % 8) == 0) nsplit = split;   // trailing slices may be empty (they write zero partials)
     DSVG_CHECK_ARG(!d.rowsum || part, "gemm: rowsum needs split_k > 1");
-    float* rs_part = d.rowsum ? part + (size_t)nsplit * d.M * d.N : nullptr;
+    float* rs_part = d.rowsum ? part + (size_t)d.M * d.N : nullptr;   // row sums of slice 0 (slices are interleaved)
+    const size_t slice = (size_t)d.M * d.N + (d.rowsum ? d.M : 0);
 
     bool use_naive = d.impl == 1;
     if (d.dtype == DSVG_F32) {
@@ -493,8 +495,8 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
         const long long total = (long long)d.M * d.N;
         for (int z = 0; z < nsplit; ++z) {
             const int kb = z * k_chunk, ke = min(d.K, kb + k_chunk);
-            float* pz = part ? part + (size_t)z * d.M * d.N : nullptr;
-            float* rz = rs_part ? rs_part + (size_t)z * d.M : nullptr;
+            float* pz = part ? part + (size_t)z * slice : nullptr;
+            float* rz = rs_part ? rs_part + (size_t)z * slice : nullptr;
             if (d.dtype == DSVG_F32)
                 hipLaunchKernelGGL(gemm_naive_kernel<float>, dim3(dsvg_cdiv(total, 256)), dim3(256), 0, st, d, kb, ke, pz, rz);
             else
@@ -520,9 +522,13 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
         if (rc) return rc;
     }
     if (part) {
-        int rc = dsvg_reduce_partials(part, nsplit, (int64_t)d.M * d.N, (float*)d.C, d.accumulate, stream);
+        const int64_t mn = (int64_t)d.M * d.N;
+        // dW and db are adjacent in the flat gradient buffer (bias follows weight): one reduction covers both
+        if (rs_part && d.rowsum == (float*)d.C + mn)
+            return dsvg_reduce_partials_strided(part, nsplit, (int64_t)slice, mn + d.M, (float*)d.C, d.accumulate, st);
+        int rc = dsvg_reduce_partials_strided(part, nsplit, (int64_t)slice, mn, (float*)d.C, d.accumulate, st);
         if (rc) return rc;
-        if (rs_part) return dsvg_reduce_partials(rs_part, nsplit, d.M, d.rowsum, d.accumulate, stream);
+        if (rs_part) return dsvg_reduce_partials_strided(rs_part, nsplit, (int64_t)slice, d.M, d.rowsum, d.accumulate, st);
     }
     return 0;
 }

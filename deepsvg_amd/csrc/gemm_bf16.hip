@@ -77,28 +77,35 @@ union Frag8 {
 
 template <bool AKC, bool BKC, bool ADROP, int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
-                                                             int k_chunk, float* part, float* rs_part) {
+                                                             int k_chunk, float* part, float* rs_part, int mode) {
     constexpr int A_ELEMS = AKC ? TBM * LDK : TBK * LDM;
     constexpr int B_ELEMS = BKC ? TBN * LDK : TBK * LDM;
     __shared__ __attribute__((aligned(16))) bf16_t smem[A_ELEMS + B_ELEMS];
     bf16_t* As = smem;
     bf16_t* Bs = smem + A_ELEMS;
 
-    // XCD-aware tile order (bijective): the column tiles of one row tile run on one XCD and share its L2
+    // Tile schedule (XCD-aware, bijective; workgroup b runs on XCD b % 8):
+    //   mode 0  one tile per workgroup, 2-D grid: x = tile (each XCD owns a contiguous chunk of the tile list, so
+    //           the column tiles of one row tile share that XCD's L2), y = K slice
+    //   mode 1  split-K as a 1-D grid of nwg_mn * nsplit workgroups (nsplit % 8 == 0): all output tiles of one K
+    //           slice run back to back on ONE XCD: each operand tile is fetched from HBM once, re-used from L2
+    //   mode 2  persistent: gridDim.x (<= 4 per CU) resident workgroups walk their XCD's chunk of the tile list,
+    //           which removes the launch/drain gaps of 10 us workgroups (the K loop is only 4-8 steps long)
     const int bid = blockIdx.x;
     const int xcd = bid % 8, local = bid / 8;
-    int wgid, kz;
-    if (gridDim.y == 1 && (int)gridDim.x != nwg_mn) {
-        // split-K launch as a 1-D grid of nwg_mn * nsplit blocks (nsplit % 8 == 0): all output tiles of one K
-        // slice run back to back on ONE XCD, so each operand tile is fetched from HBM once and re-used from
-        // that XCD's L2 by the other tiles of the slice
-        wgid = local % nwg_mn;
+    int wg_base, wl_first, wl_end, wl_stride, kz;
+    if (mode == 1) {
+        wg_base = 0; wl_first = local % nwg_mn; wl_end = wl_first + 1; wl_stride = 1;
         kz = (local / nwg_mn) * 8 + xcd;
     } else {
         const int q8 = nwg_mn / 8, r8 = nwg_mn % 8;
-        wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+        wg_base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+        wl_first = local; wl_end = q8 + (xcd < r8 ? 1 : 0);
+        wl_stride = mode == 2 ? ((int)gridDim.x + 7) / 8 : (wl_end > 0 ? wl_end : 1);
         kz = blockIdx.y;
     }
+    for (int wl = wl_first; wl < wl_end; wl += wl_stride) {
+    const int wgid = wg_base + wl;
     const int tile_m = wgid / tiles_n, tile_n = wgid % tiles_n;
     const int m0 = tile_m * TBM, n0 = tile_n * TBN;
     const int k_begin = kz * k_chunk;
@@ -237,7 +244,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
     }
 
     if (EPI == EPI_PARTIAL || (EPI == EPI_GENERIC && part)) {   // split-K partial: raw fp32 accumulators
-        float* my_part = part + (size_t)kz * p.M * p.N;
+        const size_t slice = (size_t)p.M * p.N + (rs_part ? p.M : 0);   // [M*N partial | M row sums] per K slice
+        float* my_part = part + (size_t)kz * slice;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (m < p.M) rs_part[(size_t)kz * p.M + m] = accb[i][r];
+                    if (m < p.M) rs_part[(size_t)kz * slice + m] = accb[i][r];
                 }
         }
         return;
@@ -363,6 +371,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
     };
     half_tile(acc[0][0], acc[0][1], 0);
     half_tile(acc[1][0], acc[1][1], 1);
+    if (wl + wl_stride < wl_end) __syncthreads();   // the slab aliases the next tile's A/B images
+    }   // persistent tile loop
 }
 
 // raw ds_read_b64_tr_b16 probe: lane l reads from byte offset off[l] of a 4 KiB LDS image filled with
@@ -384,9 +394,9 @@ extern "C" int dsvg_probe_trread(const int* off, short* out, void* stream) {
 
 template <bool AKC, bool BKC, bool ADROP, int EPI>
 static void launch_variant(const dsvg_gemm_desc& d, dim3 grid, int tiles_n, int nwg, int k_chunk, float* part,
-                           float* rs_part, hipStream_t st) {
+                           float* rs_part, int mode, hipStream_t st) {
     hipLaunchKernelGGL((gemm_bf16_mfma_kernel<AKC, BKC, ADROP, EPI>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk,
-                       part, rs_part);
+                       part, rs_part, mode);
 }
 
 int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, float* part, float* rs_part,
@@ -404,11 +414,21 @@ int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, floa
     if (!d.b_kc && d.ldb < ((d.N + 7) / 8) * 8) { dsvg_set_error("gemm(bf16): ldb too small for NN operand"); return -1; }
     const int tiles_m = dsvg_cdiv(d.M, TBM), tiles_n = dsvg_cdiv(d.N, TBN);
     const int nwg = tiles_m * tiles_n;
+    // schedule (see the kernel): split-K -> mode 1 (or 0), everything else -> persistent (mode 2, <= 4 blocks per CU)
+    static const bool force_2d = getenv("DSVG_SPLITK_2D") != nullptr;     // debugging knobs
+    // persistent scheduling measured 5-12 % SLOWER than one tile per workgroup on the T x {256..768} x {256,512}
+    // shapes (the 4-8 step K loop is issue-bound, not launch-bound), so it is opt-in
+    static const bool no_persist = getenv("DSVG_GEMM_PERSIST") == nullptr;
     dim3 grid(nwg, nsplit);
-    static const bool force_2d = getenv("DSVG_SPLITK_2D") != nullptr;     // debugging knob
-    if (nsplit > 1 && (nsplit % 8) == 0 && !force_2d) grid = dim3(nwg * nsplit, 1);   // XCD-grouped K slices (see kernel)
+    int mode = 0;
+    if (nsplit > 1) {
+        if ((nsplit % 8) == 0 && !force_2d) { grid = dim3(nwg * nsplit, 1); mode = 1; }
+    } else if (!no_persist && nwg > 1024) {
+        grid = dim3(1024, 1);
+        mode = 2;
+    }
     const bool adrop = d.a_drop_p > 0.f;
-#define DSVG_V(AK, BK, AD, EP) launch_variant<AK, BK, AD, EP>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, st)
+#define DSVG_V(AK, BK, AD, EP) launch_variant<AK, BK, AD, EP>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, st)
     if (part) {     // split-K slices: dedicated variants that contain no epilogue code at all
         if (d.a_kc && d.b_kc) { if (adrop) DSVG_V(true, true, true, EPI_PARTIAL); else DSVG_V(true, true, false, EPI_PARTIAL); }
         else if (d.a_kc && !d.b_kc) { if (adrop) DSVG_V(true, false, true, EPI_PARTIAL); else DSVG_V(true, false, false, EPI_PARTIAL); }

@@ -194,7 +194,10 @@ extern "C" int dsvg_layernorm_bwd(int32_t dtype, const void* dy, const void* x, 
                            rstd, gamma, (const bf16_t*)res, (bf16_t*)dx, workspace, (long long)rows, d);
     else { dsvg_set_error("layernorm_bwd: bad dtype %d", dtype); return -1; }
     DSVG_LAUNCH_CHECK("layernorm_bwd");
-    // workspace rows are [dgamma(d) | dbeta(d)]: two strided deterministic reductions
+    // workspace rows are [dgamma(d) | dbeta(d)]; in the flat gradient buffer norm.bias follows norm.weight, so the
+    // usual case is ONE deterministic reduction of 2d columns, otherwise two strided ones
+    if (dbeta == dgamma + d)
+        return dsvg_reduce_partials_strided(workspace, nb, 2 * (int64_t)d, 2 * (int64_t)d, dgamma, accumulate, st);
     int rc = 0;
     rc = dsvg_reduce_partials_strided(workspace, nb, 2 * (int64_t)d, d, dgamma, accumulate, st);
     if (rc) return rc;
