@@ -63,7 +63,7 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid) {
     return r;
 }
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, bool RS>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
                                                             int k_chunk, float* part, float* rs_part) {
     constexpr int LDA_S = AKC ? 129 : 132;
@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const bool do_rs = part != nullptr && rs_part != nullptr && tile_n == 0 && wn == 0;
+    // RS is a compile-time variant: the two extra accumulators cost 32 VGPRs, which the plain kernels must not pay
+    const bool do_rs = RS && part != nullptr && rs_part != nullptr && tile_n == 0 && wn == 0;
     floatx16 accb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, in
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            if (do_rs) {   // row sums of A (bias gradient): MFMA against an all-ones B fragment
+            if (RS && do_rs) {   // row sums of A (bias gradient): MFMA against an all-ones B fragment
                 accb[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, 1.0f, accb[0], 0, 0, 0);
                 accb[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, 1.0f, accb[1], 0, 0, 0);
             }
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, in
         __syncthreads();
     }
 
-    if (do_rs && (lane & 31) == 0) {
+    if (RS && do_rs && (lane & 31) == 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -508,14 +509,18 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
         const int nwg = tiles_m * tiles_n;
         dim3 grid(nwg, nsplit);
         if (nsplit > 1 && (nsplit % 8) == 0) grid = dim3(nwg * nsplit, 1);
-        if (d.a_kc && d.b_kc)
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part, rs_part);
-        else if (d.a_kc && !d.b_kc)
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, false>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part, rs_part);
-        else if (!d.a_kc && d.b_kc)
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part, rs_part);
-        else
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk, part, rs_part);
+#define DSVG_F32V(AK, BK)                                                                                              \
+    do {                                                                                                               \
+        if (rs_part) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BK, true>), grid, dim3(256), 0, st, d, tiles_n, nwg, \
+                                        k_chunk, part, rs_part);                                                       \
+        else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BK, false>), grid, dim3(256), 0, st, d, tiles_n, nwg,        \
+                                k_chunk, part, rs_part);                                                               \
+    } while (0)
+        if (d.a_kc && d.b_kc) DSVG_F32V(true, true);
+        else if (d.a_kc && !d.b_kc) DSVG_F32V(true, false);
+        else if (!d.a_kc && d.b_kc) DSVG_F32V(false, true);
+        else DSVG_F32V(false, false);
+#undef DSVG_F32V
         DSVG_LAUNCH_CHECK("gemm_f32_mfma");
     } else {
         int rc = dsvg_gemm_bf16_launch(d, k_chunk, nsplit, part, rs_part, st);
