@@ -1,0 +1,18 @@
+// Shared declarations of the two bf16 GEMM kernels (gemm_bf16.hip: register-staged, any shape;
+// gemm_bf16_glds.hip: LDS-DMA staged, aligned shapes).
+#pragma once
+#include "dsvg_common.h"
+#include "../../include/dsvg.h"
+
+enum {
+    EPI_GENERIC = 0,        // everything decided at run time (any alignment, any option)
+    EPI_BIAS = 1,           // C = acc [+ bias]
+    EPI_BIAS_RES_DROP = 2,  // C = res + drop(acc [+ bias])
+    EPI_BIAS_RELU_DROP = 3, // C = drop(relu(acc [+ bias]))
+    EPI_GATE = 4,           // C = gate > 0 ? acc * gate_scale : 0
+    EPI_PARTIAL = 5,        // split-K slice: raw fp32 accumulators to the workspace, nothing else
+};
+
+// Launches the LDS-DMA kernel when the call is eligible (see gemm_bf16_glds.hip); returns false otherwise.
+bool dsvg_gemm_bf16_glds_try(const dsvg_gemm_desc& d, int epi, dim3 grid, int tiles_n, int nwg, int k_chunk,
+                             float* part, float* rs_part, int mode, hipStream_t st);

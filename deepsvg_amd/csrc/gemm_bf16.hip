@@ -10,8 +10,7 @@
 //   Epilogue: each wave transposes its accumulators through a private fp32 LDS slab and finishes 8
 //   consecutive columns per lane (16-byte residual/gate loads and C stores).  The epilogue kinds the model
 //   uses are compile-time variants (EPI_*), so the hot kernels carry no dead branches or RNG code.
-#include "dsvg_common.h"
-#include "../../include/dsvg.h"
+#include "gemm_bf16.h"
 #include "gemm_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -21,15 +20,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int TBM = 128, TBN = 128, TBK = 64;
 constexpr int LDK = 72;
 constexpr int LDM = 160;
-
-enum {
-    EPI_GENERIC = 0,        // everything decided at run time (any alignment, any option)
-    EPI_BIAS = 1,           // C = acc [+ bias]
-    EPI_BIAS_RES_DROP = 2,  // C = res + drop(acc [+ bias])
-    EPI_BIAS_RELU_DROP = 3, // C = drop(relu(acc [+ bias]))
-    EPI_GATE = 4,           // C = gate > 0 ? acc * gate_scale : 0
-    EPI_PARTIAL = 5,        // split-K slice: raw fp32 accumulators to the workspace, nothing else
-};
 
 __device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
@@ -430,6 +420,10 @@ int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, floa
     const bool adrop = d.a_drop_p > 0.f;
 #define DSVG_V(AK, BK, AD, EP) launch_variant<AK, BK, AD, EP>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, st)
     if (part) {     // split-K slices: dedicated variants that contain no epilogue code at all
+        if (dsvg_gemm_bf16_glds_try(d, EPI_PARTIAL, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, st)) {
+            DSVG_LAUNCH_CHECK("gemm_bf16_glds(split-k)");
+            return 0;
+        }
         if (d.a_kc && d.b_kc) { if (adrop) DSVG_V(true, true, true, EPI_PARTIAL); else DSVG_V(true, true, false, EPI_PARTIAL); }
         else if (d.a_kc && !d.b_kc) { if (adrop) DSVG_V(true, false, true, EPI_PARTIAL); else DSVG_V(true, false, false, EPI_PARTIAL); }
         else if (!d.a_kc && d.b_kc) { if (adrop) DSVG_V(false, true, true, EPI_PARTIAL); else DSVG_V(false, true, false, EPI_PARTIAL); }
@@ -448,6 +442,10 @@ int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, floa
         else if (d.res && !d.gate && d.act == 0) epi = EPI_BIAS_RES_DROP;
         else if (!d.res && !d.gate && d.act == 1) epi = EPI_BIAS_RELU_DROP;
         else if (d.gate && !d.res && !d.bias && d.act == 0 && d.drop_p <= 0.f) epi = EPI_GATE;
+    }
+    if (epi != EPI_GENERIC && dsvg_gemm_bf16_glds_try(d, epi, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, st)) {
+        DSVG_LAUNCH_CHECK("gemm_bf16_glds");
+        return 0;
     }
     if (d.a_kc && d.b_kc) {                 // forward layers
         if (adrop) DSVG_V(true, true, true, EPI_GENERIC);

@@ -1,0 +1,328 @@
+// bf16 GEMM (fp32 accumulate) for the aligned shapes of the hot path: tokens x {256..768} x {256,512} forward /
+// input-gradient GEMMs and the split-K weight-gradient GEMM.  Same math and options as gemm_bf16.hip, built around
+// what bounds these short-K GEMMs on gfx950 (memory latency per workgroup and LDS cycles, not MFMA issue):
+//   * operand tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass, so the
+//     kernel fits 4 workgroups per CU and the whole K step of a tile is in flight at once.  The DMA writes lane-linear
+//     (wave-uniform base + 16 B x lane), so the bank swizzle is applied to the per-lane SOURCE address:
+//        k-contiguous operand  image [128 mn][64 k] (128 B rows): 16-byte chunk c of row r lives at c ^ ((r>>1)&7)
+//        mn-contiguous operand image [64 k][128 mn] (256 B rows): chunk c of k-row k lives at c ^ ((k&3)<<2)
+//     both conflict-free for ds_read_b128 / ds_read_b64_tr_b16 fragment reads (lane groups of MI355X_MICROARCH §LDS).
+//   * the MFMA is issued with the operands swapped (D = W_frag x X_frag, i.e. the transposed tile): a lane then owns
+//     one token row and 4 consecutive output columns per accumulator quad; one v_permlane32_swap per register makes
+//     that 8 consecutive columns, so bias / ReLU / dropout / residual / gate and the 16-byte stores run from
+//     registers - the epilogue uses no LDS at all (the register-staged kernel spends ~1/3 of its LDS cycles there).
+//   * out-of-range rows are clamped on the load side (their results are never stored): no exec-mask branches.
+// Eligibility is decided on the host (dsvg_gemm_bf16_glds_try); everything else runs on gemm_bf16.hip.
+#include "gemm_bf16.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short shortx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int GBM = 128, GBN = 128, GBK = 64;
+constexpr int IMG = 128 * 64;          // elements per operand image (16 KiB)
+
+#define DSVG_LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
+#define DSVG_GLB_PTR(p) ((const void __attribute__((address_space(1)))*)(p))
+
+union Frag8 {
+    bf16x8 v;
+    shortx4 h[2];
+    uint4 u;
+};
+
+__device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __uint_as_float(w[e] << 16);
+        v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    return make_uint4(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]), f2bf_pk(v[4], v[5]), f2bf_pk(v[6], v[7]));
+}
+
+template <bool AKC, bool BKC, int EPI, int NST>
+__global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void gemm_bf16_glds_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
+                                                                              int k_chunk, float* part, float* rs_part,
+                                                                              int mode) {
+    __shared__ __attribute__((aligned(1024))) bf16_t smem[NST * 2 * IMG];
+
+    // tile schedule: identical to gemm_bf16.hip modes 0 and 1 (workgroup b runs on XCD b % 8)
+    const int bid = blockIdx.x;
+    const int xcd = bid % 8, local = bid / 8;
+    int wgid, kz;
+    if (mode == 1) {
+        wgid = local % nwg_mn;
+        kz = (local / nwg_mn) * 8 + xcd;
+    } else {
+        const int q8 = nwg_mn / 8, r8 = nwg_mn % 8;
+        wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+        kz = blockIdx.y;
+    }
+    const int tile_m = wgid / tiles_n, tile_n = wgid % tiles_n;
+    const int m0 = tile_m * GBM, n0 = tile_n * GBN;
+    const int k_begin = kz * k_chunk;
+    const int k_end = min(p.K, k_begin + k_chunk);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5;
+
+    // ---- LDS-DMA source offsets (bytes, relative to the operand's address at the current k0) -----------------
+    uint32_t offa[4], offb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i;                 // 1 KiB piece of the 16 KiB image this instruction fills
+        if (AKC) {
+            const int r = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            offa[i] = (uint32_t)(((size_t)min(m0 + r, p.M - 1) * p.lda + 8 * c) * 2);
+        } else {
+            const int kr = piece * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ ((lane >> 4) << 2);
+            offa[i] = (uint32_t)(((size_t)kr * p.lda + min(m0 + 8 * c, p.M - 8)) * 2);
+        }
+        if (BKC) {
+            const int r = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            offb[i] = (uint32_t)(((size_t)min(n0 + r, p.N - 1) * p.ldb + 8 * c) * 2);
+        } else {
+            const int kr = piece * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ ((lane >> 4) << 2);
+            offb[i] = (uint32_t)(((size_t)kr * p.ldb + min(n0 + 8 * c, p.N - 8)) * 2);
+        }
+    }
+    auto stage = [&](int k0, int buf) {
+        const char* ab = (const char*)p.A + (AKC ? (size_t)k0 * 2 : (size_t)k0 * p.lda * 2);
+        const char* bb = (const char*)p.B + (BKC ? (size_t)k0 * 2 : (size_t)k0 * p.ldb * 2);
+        bf16_t* da = smem + buf * 2 * IMG + wave * 2048;
+        bf16_t* db = da + IMG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(DSVG_GLB_PTR(ab + offa[i]), DSVG_LDS_PTR(da + i * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(DSVG_GLB_PTR(bb + offb[i]), DSVG_LDS_PTR(db + i * 512), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside one operand image) ------------------------------------------------
+    // k-contiguous image: row r = base + (lane & 31), chunk 2 kk + h, swizzle (r >> 1) & 7 = (lane >> 1) & 7
+    uint32_t fk[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fk[kk] = (uint32_t)(((lane & 31) * 64 + 8 * ((2 * kk + h) ^ ((lane >> 1) & 7))) * 2);
+    // mn-contiguous image (hardware-transpose read): logical (k row, column) of gemm_bf16.hip's frag_tr, physical
+    // chunk = (column >> 3) ^ ((k row & 3) << 2)
+    const int g = lane >> 4, q = lane & 15;
+    auto tr_off = [&](int w, int it) -> uint32_t {
+        const int krow = 8 * (g >> 1) + (q >> 2);
+        const int chunk = (8 * w + 4 * it + 2 * (g & 1) + ((q & 3) >> 1)) ^ (((q >> 2) & 3) << 2);
+        return (uint32_t)((krow * 128 + 8 * chunk + 4 * (q & 1)) * 2);
+    };
+    const uint32_t ta0 = tr_off(wm, 0), ta1 = tr_off(wm, 1), tb0 = tr_off(wn, 0), tb1 = tr_off(wn, 1);
+
+    auto frag_kc = [&](const char* img, int w, int it, int kk) -> bf16x8 {
+        Frag8 f;
+        f.u = *reinterpret_cast<const uint4*>(img + (w * 64 + it * 32) * 128 + fk[kk]);
+        return f.v;
+    };
+    auto frag_tr = [&](const char* img, uint32_t off, int kk) -> bf16x8 {
+        Frag8 f;
+        f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(img + off + kk * 4096));
+        f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (shortx4 __attribute__((address_space(3)))*)(img + off + kk * 4096 + 1024));
+        return f.v;
+    };
+
+    // acc[jn][im]: transposed 32x32 tiles, D[i = output column][j = token row]
+    floatx16 acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+    // row sums of the token-side operand (bias gradient inside the weight-gradient GEMM): the lane's 8 k values of
+    // token row (lane & 31) are summed with v_dot2c_f32_bf16 against packed ones - 2 VGPRs instead of the 32 an
+    // all-ones MFMA would need; only the waves with wn == 0 of the column-tile-0 workgroups do it
+    const bool do_rs = (EPI == EPI_PARTIAL) && rs_part != nullptr && tile_n == 0 && wn == 0;
+    float rs0 = 0.f, rs1 = 0.f;
+    auto rowsum8 = [](const bf16x8& f, float s) -> float {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        Frag8 t;
+        t.v = f;
+        const uint32_t w[4] = {t.u.x, t.u.y, t.u.z, t.u.w};
+        const bf16x2 one = __builtin_bit_cast(bf16x2, 0x3f803f80u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w[e]), one, s, false);
+        return s;
+    };
+
+    auto compute = [&](int buf) {
+        const char* ia = (const char*)(smem + buf * 2 * IMG);
+        const char* ib = ia + IMG * 2;
+#pragma unroll
+        for (int kk = 0; kk < GBK / 16; ++kk) {
+            bf16x8 a0, a1, b0, b1;
+            if (AKC) { a0 = frag_kc(ia, wm, 0, kk); a1 = frag_kc(ia, wm, 1, kk); }
+            else     { a0 = frag_tr(ia, ta0, kk);   a1 = frag_tr(ia, ta1, kk); }
+            if (BKC) { b0 = frag_kc(ib, wn, 0, kk); b1 = frag_kc(ib, wn, 1, kk); }
+            else     { b0 = frag_tr(ib, tb0, kk);   b1 = frag_tr(ib, tb1, kk); }
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc11, 0, 0, 0);
+            if (EPI == EPI_PARTIAL && do_rs) { rs0 = rowsum8(a0, rs0); rs1 = rowsum8(a1, rs1); }
+        }
+    };
+
+    if (NST == 1) {
+        for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
+            stage(k0, 0);
+            __syncthreads();            // every wave drains its DMA (vmcnt 0) before the barrier
+            compute(0);
+            __syncthreads();            // all fragment reads done before the image is overwritten
+        }
+    } else {
+        if (k_begin < k_end) stage(k_begin, 0);
+        int buf = 0;
+        for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
+            __syncthreads();            // tile k0 landed everywhere; everybody is done reading the other buffer
+            if (k0 + GBK < k_end) stage(k0 + GBK, buf ^ 1);
+            compute(buf);
+            buf ^= 1;
+        }
+    }
+
+    const int mrow = m0 + wm * 64 + (lane & 31);        // + 32 im
+    const int ncol = n0 + wn * 64;                       // + 32 jn + ...
+
+    if (EPI == EPI_PARTIAL) {       // split-K slice: raw fp32 accumulators, 16-byte stores (4 consecutive columns)
+        const size_t slice = (size_t)p.M * p.N + (rs_part ? p.M : 0);
+        float* my_part = part + (size_t)kz * slice;
+        auto put = [&](const floatx16& c, int jn, int im) {
+            const int m = mrow + 32 * im;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = ncol + 32 * jn + 8 * gq + 4 * h;
+                if (m < p.M && n < p.N)
+                    *reinterpret_cast<float4*>(my_part + (size_t)m * p.N + n) =
+                        make_float4(c[4 * gq], c[4 * gq + 1], c[4 * gq + 2], c[4 * gq + 3]);
+            }
+        };
+        put(acc00, 0, 0); put(acc01, 0, 1); put(acc10, 1, 0); put(acc11, 1, 1);
+        if (do_rs) {                // lanes l and l+32 hold the two k halves of token row (lane & 31)
+            rs0 += __shfl_xor(rs0, 32, 64);
+            rs1 += __shfl_xor(rs1, 32, 64);
+            if (h == 0 && mrow < p.M) rs_part[(size_t)kz * slice + mrow] = rs0;
+            if (h == 0 && mrow + 32 < p.M) rs_part[(size_t)kz * slice + mrow + 32] = rs1;
+        }
+        return;
+    }
+
+    // ---- register epilogue ------------------------------------------------------------------------------------
+    constexpr bool has_res = EPI == EPI_BIAS_RES_DROP;
+    constexpr bool has_gate = EPI == EPI_GATE;
+    constexpr bool relu = EPI == EPI_BIAS_RELU_DROP;
+    constexpr bool may_drop = EPI == EPI_BIAS_RES_DROP || EPI == EPI_BIAS_RELU_DROP;
+    const DropCtx dc = drop_make(may_drop ? p.drop_p : 0.f, p.seed, p.drop_site);
+    const bool has_bias = !has_gate && p.bias != nullptr;
+
+    auto tile = [&](const floatx16& c, int jn, int im) {
+        const int m = mrow + 32 * im;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            // lanes l and l+32 exchange accumulator quads: afterwards each lane owns 8 consecutive columns
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[8 * cb + e]),
+                                                                 __float_as_uint(c[8 * cb + 4 + e]), false, false);
+                v[e] = __uint_as_float(sw[0]);
+                v[4 + e] = __uint_as_float(sw[1]);
+            }
+            const int nb = ncol + 32 * jn + 16 * cb + 8 * h;
+            if (m >= p.M || nb >= p.N) continue;
+            if (has_bias) {
+                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + nb);
+                const float4 b1 = *reinterpret_cast<const float4*>(p.bias + nb + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (has_gate) {
+                float gv[8];
+                unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)p.gate + (size_t)m * p.ldgate + nb), gv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gv[e] > 0.f ? v[e] * p.gate_scale : 0.f;
+            }
+            if (may_drop && dc.on) {
+                float dm[8];
+                drop_mult8(dc, (uint64_t)m * p.N + nb, dm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dm[e];
+            }
+            if (has_res) {
+                float rv[8];
+                unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)p.res + (size_t)m * p.ldres + nb), rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            }
+            *reinterpret_cast<uint4*>((bf16_t*)p.C + (size_t)m * p.ldc + nb) = pack8(v);
+        }
+    };
+    tile(acc00, 0, 0); tile(acc01, 0, 1); tile(acc10, 1, 0); tile(acc11, 1, 1);
+}
+
+template <bool AKC, bool BKC, int EPI>
+void launch(const dsvg_gemm_desc& d, dim3 grid, int tiles_n, int nwg, int k_chunk, float* part, float* rs_part, int mode,
+            int nst, hipStream_t st) {
+    if (nst == 2)
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AKC, BKC, EPI, 2>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk,
+                           part, rs_part, mode);
+    else
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AKC, BKC, EPI, 1>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk,
+                           part, rs_part, mode);
+}
+
+}  // namespace
+
+bool dsvg_gemm_bf16_glds_try(const dsvg_gemm_desc& d, int epi, dim3 grid, int tiles_n, int nwg, int k_chunk, float* part,
+                             float* rs_part, int mode, hipStream_t st) {
+    static const bool disabled = getenv("DSVG_GEMM_NOGLDS") != nullptr;         // A/B knob
+    static const int nst_env = getenv("DSVG_GEMM_STAGES") ? atoi(getenv("DSVG_GEMM_STAGES")) : 1;
+    if (disabled || d.impl == 2 || mode == 2 || d.a_drop_p > 0.f) return false;
+    const int nst = d.impl == 3 ? 2 : (d.impl == 4 ? 1 : nst_env);
+    if ((d.K % GBK) || (part && (k_chunk % GBK))) return false;
+    if ((d.lda & 7) || (d.ldb & 7) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) return false;
+    if (!d.a_kc && ((d.M & 7) || d.M < 8)) return false;
+    if ((d.N & 7) || d.N < 8 || d.M < 1) return false;
+    // per-lane source offsets are 32-bit byte offsets
+    const size_t span_a = d.a_kc ? (size_t)d.M * d.lda : (size_t)GBK * d.lda + d.M;
+    const size_t span_b = d.b_kc ? (size_t)d.N * d.ldb : (size_t)GBK * d.ldb + d.N;
+    if (span_a * 2 >= (1ull << 32) || span_b * 2 >= (1ull << 32)) return false;
+    if (part) {
+        const size_t slice = (size_t)d.M * d.N + (rs_part ? d.M : 0);
+        if ((slice & 3) || ((uintptr_t)part & 15)) return false;
+        if (!d.a_kc && !d.b_kc) { launch<false, false, EPI_PARTIAL>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, nst, st); return true; }
+        return false;
+    }
+    if (d.bias && ((uintptr_t)d.bias & 15)) return false;
+    if (d.a_kc && d.b_kc) {
+        if (epi == EPI_BIAS) launch<true, true, EPI_BIAS>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, nst, st);
+        else if (epi == EPI_BIAS_RES_DROP) launch<true, true, EPI_BIAS_RES_DROP>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, nst, st);
+        else if (epi == EPI_BIAS_RELU_DROP) launch<true, true, EPI_BIAS_RELU_DROP>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, nst, st);
+        else return false;
+        return true;
+    }
+    if (d.a_kc && !d.b_kc) {
+        if (epi == EPI_BIAS) launch<true, false, EPI_BIAS>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, nst, st);
+        else if (epi == EPI_GATE) launch<true, false, EPI_GATE>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, nst, st);
+        else return false;
+        return true;
+    }
+    return false;
+}

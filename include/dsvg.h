@@ -61,7 +61,9 @@ typedef struct dsvg_gemm_desc {
     float* rowsum;                              /* optional fp32 [M]: rowsum[m] = sum_k A(m,k), i.e.
                                                    the bias gradient for free inside the weight-
                                                    gradient GEMM (only with split_k > 1)         */
-    int32_t impl;                               /* 0 = MFMA kernel, 1 = one-thread-per-output    */
+    int32_t impl;                               /* 0 = best MFMA kernel, 1 = one-thread-per-output,
+                                                   2 = register-staged MFMA kernel only, 3 / 4 = LDS-DMA
+                                                   kernel with 2 / 1 LDS stages when eligible (test knobs) */
 } dsvg_gemm_desc;
 
 int dsvg_gemm(const dsvg_gemm_desc* d, void* stream);

@@ -140,6 +140,49 @@ def test_gemm_weight_grad_with_fused_bias_rowsum(gpu_device, dtype, T, n_out, k_
     _close(db, dy.float().sum(0), 1e-5 * T ** 0.5 if dtype == torch.float32 else 1e-2, "fused bias grad")
 
 
+@pytest.mark.parametrize("stages", [4, 3])
+@pytest.mark.parametrize("M,N,K", [(384, 512, 256), (1000, 264, 512), (129, 8, 64), (4096, 768, 256)])
+def test_gemm_lds_dma_kernel_equals_register_staged_kernel(gpu_device, stages, M, N, K):
+    """The LDS-DMA bf16 kernel (impl 3/4: swizzled DMA images, swapped MFMA, register epilogue) must reproduce the
+    register-staged kernel (impl 2) BIT FOR BIT on every epilogue it implements: same k order, same epilogue order."""
+    dtype = torch.bfloat16
+    a, w = _rand(M, K, dtype=dtype, seed=31), _rand(N, K, dtype=dtype, seed=32, scale=0.1)
+    wt = _rand(K, N, dtype=dtype, seed=33, scale=0.1)          # [k][n] weight view for the input-gradient layout
+    bias, res, gate = _rand(N, seed=34), _rand(M, N, dtype=dtype, seed=35), _rand(M, N, dtype=dtype, seed=36)
+    seed = _seed_tensor(0x0123456789ABCDEF)
+    cases = [(w, dict(bias=bias)), (w, dict()), (w, dict(bias=bias, res=res, drop_p=0.1, drop_site=5, seed=seed)),
+             (w, dict(bias=bias, res=res)), (w, dict(bias=bias, act=R.RELU, drop_p=0.2, drop_site=6, seed=seed)),
+             (wt, dict(b_kc=False)), (wt, dict(b_kc=False, gate=gate, gate_scale=1.0 / 0.9))]
+    for b, kw in cases:
+        new = ops.gemm(a, b, impl=stages, **kw)
+        old = ops.gemm(a, b, impl=2, **kw)
+        assert torch.equal(new, old), f"LDS-DMA kernel differs from the register-staged kernel: {sorted(kw)} {M}x{N}x{K}"
+        _close(new, R.gemm(a, b, out_dtype=torch.float32, **kw), _tol(dtype, K), f"glds {sorted(kw)}")
+
+
+@pytest.mark.parametrize("stages", [4, 3])
+@pytest.mark.parametrize("T,n_out,k_in,split", [(4096, 512, 256, 16), (1920, 256, 512, 8), (640, 264, 704, 3),
+                                                (8192, 768, 256, 64)])
+def test_gemm_lds_dma_weight_grad(gpu_device, stages, T, n_out, k_in, split):
+    """split-K weight gradient + fused bias row sums through the LDS-DMA kernel (both operands token-major, hardware
+    transpose reads from the swizzled image): partial sums identical to the register-staged kernel"""
+    dtype = torch.bfloat16
+    dy, x = _rand(T, n_out, dtype=dtype, seed=41), _rand(T, k_in, dtype=dtype, seed=42)
+    outs = {}
+    for impl in (stages, 2):
+        dw = torch.empty(n_out, k_in, device=DEV, dtype=torch.float32)
+        db = torch.empty(n_out, device=DEV, dtype=torch.float32)
+        ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw, split_k=split, rowsum=db, impl=impl)
+        dw2 = torch.empty(n_out, k_in, device=DEV, dtype=torch.float32)
+        ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw2, split_k=split, impl=impl)
+        assert torch.equal(dw, dw2)
+        outs[impl] = (dw, db)
+    assert torch.equal(outs[stages][0], outs[2][0]), "dW differs between the two bf16 kernels"
+    _close(outs[stages][0], R.gemm(dy, x, a_kc=False, b_kc=False, out_dtype=torch.float32), _tol(dtype, T), "dW")
+    _close(outs[stages][1], dy.float().sum(0), 1e-2, "fused bias grad (v_dot2c row sums)")
+    _close(outs[stages][1], outs[2][1], 1e-5, "row sums: dot2 vs MFMA-against-ones")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_args_head_shapes(gpu_device, dtype):
     """N = 11*257 = 2827 (not a multiple of 8): forward, dX with a padded-stride dlogits, dW"""
