@@ -8,8 +8,10 @@ on N MI355X (one process per GPU, RCCL gradient all-reduce).
         bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     FFN GEMMs (linear1/linear2 forward + their dX/dW backward GEMMs, 3.2716 GFLOP per trained icon,
-               SURVEY.md §8(d)) timed live with HIP events on the launch stream in a few extra eager steps
+  roofline     FFN GEMMs (linear1/linear2 forward + their dX/dW backward GEMMs; 3.2716 GFLOP per trained icon on
+               the padded layout) timed live with HIP events on the launch stream in a few extra
+               eager steps.  `achieved` counts the FLOPs the launches EXECUTED (padding that is skipped is not
+               counted as achieved work; the skipped fraction is reported beside it)
   cpu_baseline the CPU restatement of the reference step (oracle/, kind "port") timed on the host cores on a
                bounded sample
 """
@@ -38,7 +40,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="icons per GPU")
     ap.add_argument("--dtype", default=os.environ.get("DSVG_BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("DSVG_BENCH_GRAPH", "1")))
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("DSVG_BENCH_GRAPH", "0")),
+                    help="1: replay the step as a hipGraph (padded encoder layout: the packed layout needs the token "
+                         "count on the host)")
+    ap.add_argument("--pack-encoder", type=int, default=int(os.environ.get("DSVG_PACK_ENCODER", "1")),
+                    help="1: first encoder stage on the valid tokens only (exact, SURVEY.md 7.3-12); 0: padded layout")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -113,6 +119,7 @@ def main():
     torch.manual_seed(42 + rank)                            # per-rank dropout streams (weights are already fixed)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     model.to(device).set_compute_dtype(dtype)
+    model.pack_encoder = bool(a.pack_encoder)
     model.train()
     loss_fn = deepsvg_amd.SVGLoss(cfg).to(device)
     commands, args = make_batch(a.batch, G=8, S=30, seed=1000 + rank)
@@ -134,6 +141,7 @@ def main():
         model = deepsvg_amd.SVGTransformer(cfg)
         model.load_state_dict(sd_cpu)
         model.to(device).set_compute_dtype(dtype)
+        model.pack_encoder = bool(a.pack_encoder)
         model.train()
         ts = TrainStep(model, loss_fn, lr=1e-3 * world, grad_clip=1.0, use_graph=False)
         ts.step(commands, args)
@@ -177,14 +185,23 @@ def main():
                 ts_prof.step(commands, args)
             torch.cuda.synchronize()
             ops.PROFILE_ON = False
-            ffn_ms = sum(s.elapsed_time(e) for (tag, s, e) in ops.PROFILE if tag == "ffn") / n_prof
-            n_ffn = sum(1 for (tag, s, e) in ops.PROFILE if tag == "ffn") // n_prof
-            ach = a.batch * FFN_FLOP_PER_ICON_TRAIN / (ffn_ms * 1e-3) / 1e12
+            ffn = [r for r in ops.PROFILE if r[0] == "ffn"]
+            ffn_ms = sum(r[1].elapsed_time(r[2]) for r in ffn) / n_prof
+            n_ffn = len(ffn) // n_prof
+            flop_exec = sum(r[3] for r in ffn) / n_prof             # what the launches executed
+            bytes_exec = sum(r[4] for r in ffn) / n_prof            # operands + outputs of those launches, once each
+            flop_padded = a.batch * FFN_FLOP_PER_ICON_TRAIN         # the reference's padded layout
+            ach = flop_exec / (ffn_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[a.dtype]
             roofline = {"bound": "mfma", "kernel": "FFN GEMMs (linear1/linear2 fwd + dX + dW)", "achieved": round(ach, 2),
                         "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                         "launches_per_step": n_ffn, "ffn_ms_per_step": round(ffn_ms, 3),
-                        "whole_step_frac": round(a.batch * STEP_FLOP_PER_ICON_TRAIN / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
+                        "executed_gflop_per_step": round(flop_exec / 1e9, 1),
+                        "padded_layout_gflop_per_step": round(flop_padded / 1e9, 1),
+                        "padding_skipped_frac": round(1.0 - flop_exec / flop_padded, 4),
+                        "hbm_view": {"algorithmic_GB_per_step": round(bytes_exec / 1e9, 3),
+                                     "achieved_TBps": round(bytes_exec / (ffn_ms * 1e-3) / 1e12, 3), "peak_TBps": 8.0,
+                                     "frac": round(bytes_exec / (ffn_ms * 1e-3) / 8e12, 4)}}
 
     log(f"roofline leg done: {roofline}")
     cpu = None
@@ -201,7 +218,10 @@ def main():
             "config": {"workload": "hierarchical_ordered (Hierarchical, use_vae=False) G=8 S=30 d_model=256 ff=512 "
                                    "H=8 L=4x4; full train step = forward + SVGLoss + backward + grad-clip 1.0 + AdamW; "
                                    f"dropout {a.dropout}", "global_batch": a.batch * world, "batch_per_gpu": a.batch,
-                       "parallelism": f"dp{world}", "hip_graph": use_graph, "loss": round(loss_val, 4)},
+                       "parallelism": f"dp{world}", "hip_graph": use_graph, "loss": round(loss_val, 4),
+                       "encoder_layout": ("packed (valid tokens only, exact)" if model.last_packing else "padded"),
+                       "encoder_valid_token_frac": (round(model.last_packing[0] / model.last_packing[1], 4)
+                                                    if model.last_packing else 1.0)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(rec), flush=True)

@@ -13,12 +13,12 @@
 
 // bf16 MFMA variant for 17..32-token sequences (attention_mfma.hip)
 bool dsvg_attention_mfma_ok(int32_t dtype, int32_t S, int32_t n_heads);
-int dsvg_attention_fwd_mfma(const void* qkv, const uint64_t* key_mask, void* out, int64_t n_seq, int32_t S,
-                            int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
-                            hipStream_t st);
-int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const void* dout, void* dqkv, int64_t n_seq,
-                            int32_t S, int32_t n_heads, float scale, float drop_p, uint32_t drop_site,
-                            const uint64_t* seed, hipStream_t st);
+int dsvg_attention_fwd_mfma(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
+                            void* out, int64_t n_seq, int32_t S, int32_t n_heads, float scale, float drop_p,
+                            uint32_t drop_site, const uint64_t* seed, hipStream_t st);
+int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
+                            const void* dout, void* dqkv, int64_t n_seq, int32_t S, int32_t n_heads, float scale,
+                            float drop_p, uint32_t drop_site, const uint64_t* seed, hipStream_t st);
 
 template <typename T, int SP, int HG>
 struct AttnCfg {
@@ -50,10 +50,27 @@ __device__ __forceinline__ void tile_copy_out(T* dst, long long ld_dst, const T*
     }
 }
 
+// packed (variable-length) layout: sequence b owns rows [seq_off[b], seq_off[b+1]) of the token-major buffers and all
+// of its keys are valid; the workgroup with blockIdx.x == n_seq zero-fills the pad rows [seq_off[n_seq], total_rows)
+// of its column slab so that later reductions over rows (weight gradients) see finite values / exact zeros.
+template <typename T, int NT>
+__device__ __forceinline__ void zero_rows(T* dst, long long ld, long long row_begin, long long row_end, int cols) {
+    typedef typename Elem<T>::raw4 raw4;
+    const int cpr = cols / 4;
+    raw4 z;
+    memset(&z, 0, sizeof(z));
+    for (long long idx = threadIdx.x; idx < (row_end - row_begin) * cpr; idx += NT) {
+        const long long r = row_begin + idx / cpr;
+        const int c = (int)(idx % cpr);
+        *reinterpret_cast<raw4*>(dst + r * ld + 4 * c) = z;
+    }
+}
+
 template <typename T, int SP, int HG>
 __global__ __launch_bounds__(HG * SP) void attn_fwd_kernel(
-    const T* __restrict__ qkv, const uint64_t* __restrict__ key_mask, T* __restrict__ out, int S, int H, float scale,
-    float drop_p, uint32_t drop_site, const uint64_t* seed) {
+    const T* __restrict__ qkv, const uint64_t* __restrict__ key_mask, const int32_t* __restrict__ seq_off,
+    long long total_rows, T* __restrict__ out, int Smax, int H, float scale, float drop_p, uint32_t drop_site,
+    const uint64_t* seed) {
     typedef AttnCfg<T, SP, HG> C;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* tile = reinterpret_cast<T*>(smem_raw);
@@ -63,7 +80,17 @@ __global__ __launch_bounds__(HG * SP) void attn_fwd_kernel(
     const int hl = lane / SP, i = lane % SP;
     const int hh = wave * C::HPW + hl;      // head inside the group
     const int h = hg * HG + hh;             // global head
-    const T* src = qkv + (size_t)b * S * 3 * d + (size_t)hg * C::W;
+    long long row0 = (long long)b * Smax;
+    int S = Smax;                           // this sequence's length (dropout ids keep the Smax-based numbering)
+    if (seq_off) {
+        if (b == (int)gridDim.x - 1) {
+            zero_rows<T, C::NT>(out + (size_t)hg * C::W, (long long)d, seq_off[b], total_rows, C::W);
+            return;
+        }
+        row0 = seq_off[b];
+        S = seq_off[b + 1] - seq_off[b];
+    }
+    const T* src = qkv + (size_t)row0 * 3 * d + (size_t)hg * C::W;
 
     tile_copy_in<T, C::NT>(tile, C::LD, src, 3LL * d, S, C::W);                          // q slab
     tile_copy_in<T, C::NT>(tile + C::W, C::LD, src + d, 3LL * d, S, C::W);               // k slab
@@ -104,7 +131,7 @@ __global__ __launch_bounds__(HG * SP) void attn_fwd_kernel(
             l += s[j];
         }
         const float inv = 1.f / l;
-        const uint64_t ebase = (((uint64_t)b * H + h) * S + i) * S;
+        const uint64_t ebase = (((uint64_t)b * H + h) * Smax + i) * Smax;
 #pragma unroll
         for (int j = 0; j < SP; ++j) {
             if (j < S) {
@@ -119,36 +146,50 @@ __global__ __launch_bounds__(HG * SP) void attn_fwd_kernel(
         row32_store(tile + i * C::LD + hh * 32, o);
     }
     __syncthreads();
-    tile_copy_out<T, C::NT>(out + (size_t)b * S * d + (size_t)hg * C::W, (long long)d, tile, C::LD, S, C::W);
+    tile_copy_out<T, C::NT>(out + (size_t)row0 * d + (size_t)hg * C::W, (long long)d, tile, C::LD, S, C::W);
 }
 
 template <typename T, int SP, int HG>
 __global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
-    const T* __restrict__ qkv, const uint64_t* __restrict__ key_mask, const T* __restrict__ dout, T* __restrict__ dqkv,
-    int S, int H, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed) {
+    const T* __restrict__ qkv, const uint64_t* __restrict__ key_mask, const int32_t* __restrict__ seq_off,
+    long long total_rows, const T* __restrict__ dout, T* __restrict__ dqkv, int Smax, int H, float scale, float drop_p,
+    uint32_t drop_site, const uint64_t* seed) {
     typedef AttnCfg<T, SP, HG> C;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* tile = reinterpret_cast<T*>(smem_raw);                         // [S][LD]   q|k|v
-    T* dtile = tile + S * C::LD;                                      // [S][LDO]  dO
-    float* stat = reinterpret_cast<float*>(dtile + S * C::LDO);       // [HG][SP][2]  lse, D
+    T* tile = reinterpret_cast<T*>(smem_raw);                         // [Smax][LD]   q|k|v
+    T* dtile = tile + Smax * C::LD;                                   // [Smax][LDO]  dO
+    float* stat = reinterpret_cast<float*>(dtile + Smax * C::LDO);    // [HG][SP][2]  lse, D
     const int b = blockIdx.x, hg = blockIdx.y;
     const int d = H * 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hl = lane / SP, i = lane % SP;
     const int hh = wave * C::HPW + hl;
     const int h = hg * HG + hh;
-    const T* src = qkv + (size_t)b * S * 3 * d + (size_t)hg * C::W;
+    long long row0 = (long long)b * Smax;
+    int S = Smax;
+    if (seq_off) {
+        if (b == (int)gridDim.x - 1) {
+            T* z = dqkv + (size_t)hg * C::W;
+            zero_rows<T, C::NT>(z, 3LL * d, seq_off[b], total_rows, C::W);
+            zero_rows<T, C::NT>(z + d, 3LL * d, seq_off[b], total_rows, C::W);
+            zero_rows<T, C::NT>(z + 2 * d, 3LL * d, seq_off[b], total_rows, C::W);
+            return;
+        }
+        row0 = seq_off[b];
+        S = seq_off[b + 1] - seq_off[b];
+    }
+    const T* src = qkv + (size_t)row0 * 3 * d + (size_t)hg * C::W;
 
     tile_copy_in<T, C::NT>(tile, C::LD, src, 3LL * d, S, C::W);
     tile_copy_in<T, C::NT>(tile + C::W, C::LD, src + d, 3LL * d, S, C::W);
     tile_copy_in<T, C::NT>(tile + 2 * C::W, C::LD, src + 2 * d, 3LL * d, S, C::W);
-    tile_copy_in<T, C::NT>(dtile, C::LDO, dout + (size_t)b * S * d + (size_t)hg * C::W, (long long)d, S, C::W);
+    tile_copy_in<T, C::NT>(dtile, C::LDO, dout + (size_t)row0 * d + (size_t)hg * C::W, (long long)d, S, C::W);
     __syncthreads();
 
     const uint64_t km = key_mask ? key_mask[b] : ~0ull;
     const DropCtx dc = drop_make(drop_p, seed, drop_site);
     const bool active = i < S;
-    const uint64_t hbase = ((uint64_t)b * H + h) * S;   // element id of (i, j) = (hbase + i) * S + j
+    const uint64_t hbase = ((uint64_t)b * H + h) * Smax;   // element id of (i, j) = (hbase + i) * Smax + j
 
     float dq[32];
 #pragma unroll
@@ -196,7 +237,7 @@ __global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
 #pragma unroll
                 for (int c = 0; c < 32; ++c) acc = fmaf(go[c], vr[c], acc);
                 s[j] *= inv;                                                  // P_ij
-                dp[j] = acc * drop_mult(dc, (hbase + i) * S + j);            // dP_ij
+                dp[j] = acc * drop_mult(dc, (hbase + i) * Smax + j);            // dP_ij
                 D = fmaf(s[j], dp[j], D);
             }
         }
@@ -235,7 +276,7 @@ __global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
                 for (int c = 0; c < 32; ++c) { sacc = fmaf(q[c], kr[c], sacc); dacc = fmaf(go[c], vr[c], dacc); }
                 const float lse = stat[(hh * SP + r) * 2 + 0];
                 const float D = stat[(hh * SP + r) * 2 + 1];
-                const float mult = drop_mult(dc, (hbase + r) * S + j);
+                const float mult = drop_mult(dc, (hbase + r) * Smax + j);
                 const float p = __expf(sacc * scale - lse);
                 const float pd = p * mult;                                   // dropped probability used in O = P~ V
                 const float ds = p * (dacc * mult - D) * scale;             // dS_rj * scale (q unscaled below)
@@ -251,35 +292,37 @@ __global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
         row32_store(tile + i * C::LD + 2 * C::W + hh * 32, dv);
     }
     __syncthreads();
-    T* dst = dqkv + (size_t)b * S * 3 * d + (size_t)hg * C::W;
+    T* dst = dqkv + (size_t)row0 * 3 * d + (size_t)hg * C::W;
     tile_copy_out<T, C::NT>(dst, 3LL * d, tile, C::LD, S, C::W);
     tile_copy_out<T, C::NT>(dst + d, 3LL * d, tile + C::W, C::LD, S, C::W);
     tile_copy_out<T, C::NT>(dst + 2 * d, 3LL * d, tile + 2 * C::W, C::LD, S, C::W);
 }
 
 template <typename T, int SP, int HG>
-static int launch_fwd(const void* qkv, const uint64_t* km, void* out, int64_t n_seq, int S, int H, float scale,
-                      float drop_p, uint32_t site, const uint64_t* seed, hipStream_t st) {
+static int launch_fwd(const void* qkv, const uint64_t* km, const int32_t* seq_off, int64_t total_rows, void* out,
+                      int64_t n_seq, int S, int H, float scale, float drop_p, uint32_t site, const uint64_t* seed,
+                      hipStream_t st) {
     typedef AttnCfg<T, SP, HG> C;
     const size_t lds = (size_t)S * C::LD * sizeof(T);
     if (lds > 160 * 1024) { dsvg_set_error("attention_fwd: LDS image too large (%zu B)", lds); return -1; }
     auto kern = attn_fwd_kernel<T, SP, HG>;
     DSVG_ENSURE_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq, H / HG), dim3(C::NT), lds, st, (const T*)qkv, km, (T*)out, S, H,
-                       scale, drop_p, site, seed);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (seq_off ? 1u : 0u), H / HG), dim3(C::NT), lds, st, (const T*)qkv, km,
+                       seq_off, (long long)total_rows, (T*)out, S, H, scale, drop_p, site, seed);
     DSVG_LAUNCH_CHECK("attention_fwd");
     return 0;
 }
 template <typename T, int SP, int HG>
-static int launch_bwd(const void* qkv, const uint64_t* km, const void* dout, void* dqkv, int64_t n_seq, int S, int H,
-                      float scale, float drop_p, uint32_t site, const uint64_t* seed, hipStream_t st) {
+static int launch_bwd(const void* qkv, const uint64_t* km, const int32_t* seq_off, int64_t total_rows, const void* dout,
+                      void* dqkv, int64_t n_seq, int S, int H, float scale, float drop_p, uint32_t site,
+                      const uint64_t* seed, hipStream_t st) {
     typedef AttnCfg<T, SP, HG> C;
     const size_t lds = (size_t)S * (C::LD + C::LDO) * sizeof(T) + (size_t)HG * SP * 2 * sizeof(float);
     if (lds > 160 * 1024) { dsvg_set_error("attention_bwd: LDS image too large (%zu B)", lds); return -1; }
     auto kern = attn_bwd_kernel<T, SP, HG>;
     DSVG_ENSURE_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq, H / HG), dim3(C::NT), lds, st, (const T*)qkv, km, (const T*)dout,
-                       (T*)dqkv, S, H, scale, drop_p, site, seed);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (seq_off ? 1u : 0u), H / HG), dim3(C::NT), lds, st, (const T*)qkv, km,
+                       seq_off, (long long)total_rows, (const T*)dout, (T*)dqkv, S, H, scale, drop_p, site, seed);
     DSVG_LAUNCH_CHECK("attention_bwd");
     return 0;
 }
@@ -295,35 +338,44 @@ static int launch_bwd(const void* qkv, const uint64_t* km, const void* dout, voi
         if (S <= 64) return FN<T, 64, 1>(__VA_ARGS__);                              \
     } while (0)
 
-extern "C" int dsvg_attention_fwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, void* out, int64_t n_seq,
-                                  int32_t S, int32_t n_heads, float scale, float drop_p, uint32_t drop_site,
-                                  const uint64_t* seed, void* stream) {
+extern "C" int dsvg_attention_fwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const int32_t* seq_off,
+                                  int64_t total_rows, void* out, int64_t n_seq, int32_t S, int32_t n_heads, float scale,
+                                  float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream) {
     DSVG_CHECK_ARG(qkv && out && n_seq > 0 && S > 0 && S <= 64 && n_heads > 0, "attention_fwd: bad args (S=%d)", S);
     DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_fwd: dropout needs a seed pointer");
+    DSVG_CHECK_ARG(!seq_off || (!key_mask && total_rows > 0), "attention_fwd: packed layout takes no key mask");
     hipStream_t st = (hipStream_t)stream;
     if (dsvg_attention_mfma_ok(dtype, S, n_heads))
-        return dsvg_attention_fwd_mfma(qkv, key_mask, out, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
+        return dsvg_attention_fwd_mfma(qkv, key_mask, seq_off, total_rows, out, n_seq, S, n_heads, scale, drop_p, drop_site,
+                                       seed, st);
     if (dtype == DSVG_F32) {
-        DSVG_ATTN_DISPATCH(launch_fwd, float, qkv, key_mask, out, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
+        DSVG_ATTN_DISPATCH(launch_fwd, float, qkv, key_mask, seq_off, total_rows, out, n_seq, S, n_heads, scale, drop_p,
+                           drop_site, seed, st);
     } else if (dtype == DSVG_BF16) {
-        DSVG_ATTN_DISPATCH(launch_fwd, bf16_t, qkv, key_mask, out, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
+        DSVG_ATTN_DISPATCH(launch_fwd, bf16_t, qkv, key_mask, seq_off, total_rows, out, n_seq, S, n_heads, scale, drop_p,
+                           drop_site, seed, st);
     }
     dsvg_set_error("attention_fwd: unsupported dtype/shape (dtype=%d S=%d H=%d)", dtype, S, n_heads);
     return -1;
 }
 
-extern "C" int dsvg_attention_bwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const void* dout,
-                                  void* dqkv, int64_t n_seq, int32_t S, int32_t n_heads, float scale, float drop_p,
-                                  uint32_t drop_site, const uint64_t* seed, void* stream) {
+extern "C" int dsvg_attention_bwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const int32_t* seq_off,
+                                  int64_t total_rows, const void* dout, void* dqkv, int64_t n_seq, int32_t S,
+                                  int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
+                                  void* stream) {
     DSVG_CHECK_ARG(qkv && dout && dqkv && n_seq > 0 && S > 0 && S <= 64 && n_heads > 0, "attention_bwd: bad args");
     DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_bwd: dropout needs a seed pointer");
+    DSVG_CHECK_ARG(!seq_off || (!key_mask && total_rows > 0), "attention_bwd: packed layout takes no key mask");
     hipStream_t st = (hipStream_t)stream;
     if (dsvg_attention_mfma_ok(dtype, S, n_heads))
-        return dsvg_attention_bwd_mfma(qkv, key_mask, dout, dqkv, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
+        return dsvg_attention_bwd_mfma(qkv, key_mask, seq_off, total_rows, dout, dqkv, n_seq, S, n_heads, scale, drop_p,
+                                       drop_site, seed, st);
     if (dtype == DSVG_F32) {
-        DSVG_ATTN_DISPATCH(launch_bwd, float, qkv, key_mask, dout, dqkv, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
+        DSVG_ATTN_DISPATCH(launch_bwd, float, qkv, key_mask, seq_off, total_rows, dout, dqkv, n_seq, S, n_heads, scale,
+                           drop_p, drop_site, seed, st);
     } else if (dtype == DSVG_BF16) {
-        DSVG_ATTN_DISPATCH(launch_bwd, bf16_t, qkv, key_mask, dout, dqkv, n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
+        DSVG_ATTN_DISPATCH(launch_bwd, bf16_t, qkv, key_mask, seq_off, total_rows, dout, dqkv, n_seq, S, n_heads, scale,
+                           drop_p, drop_site, seed, st);
     }
     dsvg_set_error("attention_bwd: unsupported dtype/shape (dtype=%d S=%d H=%d)", dtype, S, n_heads);
     return -1;

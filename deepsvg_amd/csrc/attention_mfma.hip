@@ -87,9 +87,19 @@ __device__ __forceinline__ void store_slab(bf16_t* dst, long long ld_dst, const 
     }
 }
 
+// pad rows [row_begin, row_end) of one column slab <- 0 (packed layout, see attention.hip)
+__device__ __forceinline__ void zero_slab_rows(bf16_t* dst, long long ld, long long row_begin, long long row_end, int cols) {
+    const int cpr = cols / 8;
+    for (long long idx = threadIdx.x; idx < (row_end - row_begin) * cpr; idx += 512) {
+        const long long r = row_begin + idx / cpr;
+        *reinterpret_cast<uint4*>(dst + r * ld + 8 * (int)(idx % cpr)) = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                             const uint64_t* __restrict__ key_mask,
-                                                            bf16_t* __restrict__ out, int S, int H, float scale,
+                                                            const int32_t* __restrict__ seq_off, long long total_rows,
+                                                            bf16_t* __restrict__ out, int Smax, int H, float scale,
                                                             float drop_p, uint32_t drop_site, const uint64_t* seed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);   // [32][LD]
@@ -97,7 +107,17 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
     const int lane = threadIdx.x & 63, hh = threadIdx.x >> 6;
     const int li = lane & 31, h2 = lane >> 5;
     const int h = hg * HG + hh;
-    const bf16_t* src = qkv + (size_t)b * S * 3 * d + (size_t)hg * W;
+    long long row0 = (long long)b * Smax;
+    int S = Smax;                   // this sequence's length; dropout ids keep the Smax-based numbering
+    if (seq_off) {
+        if (b == (int)gridDim.x - 1) {
+            zero_slab_rows(out + (size_t)hg * W, (long long)d, seq_off[b], total_rows, W);
+            return;
+        }
+        row0 = seq_off[b];
+        S = seq_off[b + 1] - seq_off[b];
+    }
+    const bf16_t* src = qkv + (size_t)row0 * 3 * d + (size_t)hg * W;
     load_slab(tile, LD, src, 3LL * d, S, W);
     load_slab(tile + W, LD, src + d, 3LL * d, S, W);
     load_slab(tile + 2 * W, LD, src + 2 * d, 3LL * d, S, W);
@@ -132,7 +152,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.f / l;
-    const uint64_t ebase = (((uint64_t)b * H + h) * S + li) * S;
+    const uint64_t ebase = (((uint64_t)b * H + h) * Smax + li) * Smax;
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = p[r] * inv * drop_mult(dc, ebase + rowmap(r, h2));
     if (li >= S) {
@@ -148,14 +168,15 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
     // ot[r] = O[q = li][d = rowmap(r,h2)]; the head's q slab is dead: reuse it as the output staging slab
     stage_rows(tile, LD, li, qc, h2, ot);
     __syncthreads();
-    store_slab(out + (size_t)b * S * d + (size_t)hg * W, (long long)d, tile, LD, S, W);
+    store_slab(out + (size_t)row0 * d + (size_t)hg * W, (long long)d, tile, LD, S, W);
 }
 
 __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                             const uint64_t* __restrict__ key_mask,
+                                                            const int32_t* __restrict__ seq_off, long long total_rows,
                                                             const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
-                                                            int S, int H, float scale, float drop_p, uint32_t drop_site,
-                                                            const uint64_t* seed) {
+                                                            int Smax, int H, float scale, float drop_p,
+                                                            uint32_t drop_site, const uint64_t* seed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);          // [32][LD]   q|k|v
     bf16_t* dtile = tile + 32 * LD;                              // [32][LDO]  dO
@@ -164,17 +185,30 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
     const int lane = threadIdx.x & 63, hh = threadIdx.x >> 6;
     const int li = lane & 31, h2 = lane >> 5;
     const int h = hg * HG + hh;
-    const bf16_t* src = qkv + (size_t)b * S * 3 * d + (size_t)hg * W;
+    long long row0 = (long long)b * Smax;
+    int S = Smax;
+    if (seq_off) {
+        if (b == (int)gridDim.x - 1) {
+            bf16_t* z = dqkv + (size_t)hg * W;
+            zero_slab_rows(z, 3LL * d, seq_off[b], total_rows, W);
+            zero_slab_rows(z + d, 3LL * d, seq_off[b], total_rows, W);
+            zero_slab_rows(z + 2 * d, 3LL * d, seq_off[b], total_rows, W);
+            return;
+        }
+        row0 = seq_off[b];
+        S = seq_off[b + 1] - seq_off[b];
+    }
+    const bf16_t* src = qkv + (size_t)row0 * 3 * d + (size_t)hg * W;
     load_slab(tile, LD, src, 3LL * d, S, W);
     load_slab(tile + W, LD, src + d, 3LL * d, S, W);
     load_slab(tile + 2 * W, LD, src + 2 * d, 3LL * d, S, W);
-    load_slab(dtile, LDO, dout + (size_t)b * S * d + (size_t)hg * W, (long long)d, S, W);
+    load_slab(dtile, LDO, dout + (size_t)row0 * d + (size_t)hg * W, (long long)d, S, W);
     __syncthreads();
 
     const uint64_t km = (key_mask ? key_mask[b] : ~0ull) & ((S >= 64) ? ~0ull : ((1ull << S) - 1ull));
     const DropCtx dc = drop_make(drop_p, seed, drop_site);
     const int qc = hh * 32, kc = W + hh * 32, vc = 2 * W + hh * 32, oc = hh * 32;
-    const uint64_t hbase = ((uint64_t)b * H + h) * S;            // id(q, key) = (hbase + q) * S + key
+    const uint64_t hbase = ((uint64_t)b * H + h) * Smax;         // id(q, key) = (hbase + q) * Smax + key
     float* my_stat = stat + hh * 64;
 
     floatx16 acc, acc2;
@@ -209,7 +243,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         p[r] *= inv;                                                               // P[q][key]
-        g[r] = acc2[r] * drop_mult(dc, (hbase + li) * S + rowmap(r, h2));          // dP[q][key]
+        g[r] = acc2[r] * drop_mult(dc, (hbase + li) * Smax + rowmap(r, h2));          // dP[q][key]
         D = fmaf(p[r], g[r], D);
     }
     D += __shfl_xor(D, 32, 64);
@@ -243,7 +277,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
         const float lse_q = my_stat[q * 2 + 0], D_q = my_stat[q * 2 + 1];
         const bool ok = kvalid && q < S;
         const float pr = ok ? __expf(acc[r] * scale - lse_q) : 0.f;               // P[q][key = li]
-        const float mult = drop_mult(dc, (hbase + q) * S + li);
+        const float mult = drop_mult(dc, (hbase + q) * Smax + li);
         p[r] = pr * mult;                                                          // P~ (as used by O = P~ V)
         g[r] = ok ? pr * (acc2[r] * mult - D_q) * scale : 0.f;                     // scale * dS[q][key]
     }
@@ -261,7 +295,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
     stage_rows(tile, LD, li, kc, h2, dk);
     stage_rows(tile, LD, li, vc, h2, dv);
     __syncthreads();
-    bf16_t* dst = dqkv + (size_t)b * S * 3 * d + (size_t)hg * W;
+    bf16_t* dst = dqkv + (size_t)row0 * 3 * d + (size_t)hg * W;
     store_slab(dst, 3LL * d, tile, LD, S, W);
     store_slab(dst + d, 3LL * d, tile + W, LD, S, W);
     store_slab(dst + 2 * d, 3LL * d, tile + 2 * W, LD, S, W);
@@ -274,24 +308,26 @@ bool dsvg_attention_mfma_ok(int32_t dtype, int32_t S, int32_t n_heads) {
     return !off && dtype == DSVG_BF16 && S > 16 && S <= 32 && (n_heads % HG) == 0;
 }
 
-int dsvg_attention_fwd_mfma(const void* qkv, const uint64_t* key_mask, void* out, int64_t n_seq, int32_t S,
-                            int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
-                            hipStream_t st) {
+int dsvg_attention_fwd_mfma(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
+                            void* out, int64_t n_seq, int32_t S, int32_t n_heads, float scale, float drop_p,
+                            uint32_t drop_site, const uint64_t* seed, hipStream_t st) {
     const size_t lds = (size_t)32 * LD * sizeof(bf16_t);
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)n_seq, n_heads / HG), dim3(512), lds, st, (const bf16_t*)qkv,
-                       key_mask, (bf16_t*)out, S, n_heads, scale, drop_p, drop_site, seed);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)n_seq + (seq_off ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
+                       (const bf16_t*)qkv, key_mask, seq_off, (long long)total_rows, (bf16_t*)out, S, n_heads, scale,
+                       drop_p, drop_site, seed);
     DSVG_LAUNCH_CHECK("attention_fwd_mfma");
     return 0;
 }
 
-int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const void* dout, void* dqkv, int64_t n_seq,
-                            int32_t S, int32_t n_heads, float scale, float drop_p, uint32_t drop_site,
-                            const uint64_t* seed, hipStream_t st) {
+int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
+                            const void* dout, void* dqkv, int64_t n_seq, int32_t S, int32_t n_heads, float scale,
+                            float drop_p, uint32_t drop_site, const uint64_t* seed, hipStream_t st) {
     const size_t lds = (size_t)32 * (LD + LDO) * sizeof(bf16_t) + (size_t)HG * 64 * sizeof(float);
     auto kern = attn_bwd_mfma_kernel;
     DSVG_ENSURE_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq, n_heads / HG), dim3(512), lds, st, (const bf16_t*)qkv, key_mask,
-                       (const bf16_t*)dout, (bf16_t*)dqkv, S, n_heads, scale, drop_p, drop_site, seed);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (seq_off ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
+                       (const bf16_t*)qkv, key_mask, seq_off, (long long)total_rows, (const bf16_t*)dout, (bf16_t*)dqkv, S,
+                       n_heads, scale, drop_p, drop_site, seed);
     DSVG_LAUNCH_CHECK("attention_bwd_mfma");
     return 0;
 }

@@ -73,6 +73,73 @@ extern "C" int dsvg_group_index(const float* commands, int64_t n_seq, int32_t S,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Packed (variable-length) token layout for the first encoder stage.  Only keys are masked there
+// (layers/functional.py:234-239) and padded query rows are dropped by the masked mean-pool (model.py:137), so rows
+// past a sequence's first EOS influence neither an output nor a gradient: the encoder runs on the valid tokens only.
+//   seq_off[b]  = number of valid tokens in sequences < b (exclusive scan of popcount(key_mask)), seq_off[n_seq] = total
+//   row t of the packed buffers = token (b, s) with t = seq_off[b] + s, s < len_b
+//   rows >= total (up to the capacity n_seq * S) replicate token 0: finite inputs, their gradients are exact zeros
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void seq_offsets_kernel(const uint64_t* __restrict__ key_mask, long long n_seq,
+                                                           int32_t* __restrict__ seq_off) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (long long base = 0; base < n_seq; base += 1024) {
+        const long long b = base + threadIdx.x;
+        const int len = b < n_seq ? __popcll(key_mask[b]) : 0;
+        part[threadIdx.x] = len;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {            // Hillis-Steele inclusive scan
+            const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (b < n_seq) seq_off[b] = carry + part[threadIdx.x] - len;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) seq_off[n_seq] = carry;
+}
+__global__ void pack_tokens_kernel(const float* __restrict__ commands, const float* __restrict__ args,
+                                   const int32_t* __restrict__ seq_off, long long n_seq, int S, int n_args,
+                                   float* __restrict__ pcmd, float* __restrict__ pargs, int32_t* __restrict__ ppos) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // dense token index
+    if (t >= n_seq * S) return;
+    const long long b = t / S;
+    const int s = (int)(t % S);
+    const int total = seq_off[n_seq];
+    if (s < seq_off[b + 1] - seq_off[b]) {
+        const long long r = seq_off[b] + s;
+        pcmd[r] = commands[t];
+        ppos[r] = s;
+        for (int a = 0; a < n_args; ++a) pargs[r * n_args + a] = args[t * n_args + a];
+    }
+    if (t >= total) {                       // pad rows of the packed buffers
+        pcmd[t] = commands[0];
+        ppos[t] = 0;
+        for (int a = 0; a < n_args; ++a) pargs[t * n_args + a] = args[a];
+    }
+}
+extern "C" int dsvg_pack_tokens(const float* commands, const float* args, const uint64_t* key_mask, int64_t n_seq,
+                                int32_t S, int32_t n_args, int32_t* seq_off, float* packed_commands, float* packed_args,
+                                int32_t* packed_pos, void* stream) {
+    DSVG_CHECK_ARG(commands && args && key_mask && seq_off && packed_commands && packed_args && packed_pos,
+                   "pack_tokens: null pointer");
+    DSVG_CHECK_ARG(n_seq > 0 && S > 0 && S <= 64 && n_args > 0 && n_seq * S < (1ll << 31), "pack_tokens: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(1024), 0, st, key_mask, (long long)n_seq, seq_off);
+    DSVG_LAUNCH_CHECK("seq_offsets");
+    hipLaunchKernelGGL(pack_tokens_kernel, dim3(dsvg_cdiv(n_seq * S, 256)), dim3(256), 0, st, commands, args, seq_off,
+                       (long long)n_seq, S, n_args, packed_commands, packed_args, packed_pos);
+    DSVG_LAUNCH_CHECK("pack_tokens");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // embedding gather (deepsvg/model/model.py:49-53)
 //   A[t, a*E + e] = arg_embed[args[t,a] + 1, e];   R[t, c] = command_embed[cmd[t], c] (+ group_embed[grp[t], c])
 // one thread per 4 output elements
@@ -385,54 +452,81 @@ extern "C" int dsvg_add_pos_bwd(int32_t dtype, const void* dy, void* dx, float* 
 // ---------------------------------------------------------------------------------------------
 // masked mean over the sequence axis (deepsvg/model/model.py:137,161); one block per sequence
 // ---------------------------------------------------------------------------------------------
+// packed layout (seq_off != null): sequence b owns rows [seq_off[b], seq_off[b+1]), all valid; the backward
+// workgroup with blockIdx.x == n_seq zero-fills the pad rows [seq_off[n_seq], total_rows)
 template <typename T>
-__global__ void masked_mean_fwd_kernel(const T* __restrict__ x, const uint64_t* __restrict__ mask, T* __restrict__ out,
-                                       int S, int d) {
+__global__ void masked_mean_fwd_kernel(const T* __restrict__ x, const uint64_t* __restrict__ mask,
+                                       const int32_t* __restrict__ seq_off, T* __restrict__ out, int S, int d) {
     const long long b = blockIdx.x;
-    const uint64_t m = mask[b];
+    long long row0 = b * S;
+    uint64_t m;
+    if (seq_off) {
+        row0 = seq_off[b];
+        const int len = seq_off[b + 1] - seq_off[b];
+        m = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+        S = len;
+    } else {
+        m = mask[b];
+    }
     const float inv = 1.f / (float)__popcll(m);
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
         float s = 0.f;
         for (int i = 0; i < S; ++i)
-            if ((m >> i) & 1ull) s += Elem<T>::ld(x + (b * S + i) * d + c);
+            if ((m >> i) & 1ull) s += Elem<T>::ld(x + (row0 + i) * d + c);
         Elem<T>::st(out + b * d + c, s * inv);
     }
 }
 template <typename T>
 __global__ void masked_mean_bwd_kernel(const T* __restrict__ dout, const uint64_t* __restrict__ mask,
-                                       T* __restrict__ dx, int S, int d) {
+                                       const int32_t* __restrict__ seq_off, long long total_rows, T* __restrict__ dx,
+                                       int S, int d) {
     const long long b = blockIdx.x;
-    const uint64_t m = mask[b];
+    long long row0 = b * S;
+    uint64_t m;
+    if (seq_off) {
+        if (b == (long long)gridDim.x - 1) {
+            for (long long r = seq_off[b]; r < total_rows; ++r)
+                for (int c = threadIdx.x; c < d; c += blockDim.x) Elem<T>::st(dx + r * d + c, 0.f);
+            return;
+        }
+        row0 = seq_off[b];
+        const int len = seq_off[b + 1] - seq_off[b];
+        m = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+        S = len;
+    } else {
+        m = mask[b];
+    }
     const float inv = 1.f / (float)__popcll(m);
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
         const float g = Elem<T>::ld(dout + b * d + c) * inv;
-        for (int i = 0; i < S; ++i) Elem<T>::st(dx + (b * S + i) * d + c, ((m >> i) & 1ull) ? g : 0.f);
+        for (int i = 0; i < S; ++i) Elem<T>::st(dx + (row0 + i) * d + c, ((m >> i) & 1ull) ? g : 0.f);
     }
 }
-extern "C" int dsvg_masked_mean_fwd(int32_t dtype, const void* x, const uint64_t* mask, void* out, int64_t n_seq,
-                                    int32_t S, int32_t d, void* stream) {
-    DSVG_CHECK_ARG(x && mask && out && n_seq > 0 && S > 0 && S <= 64 && d > 0, "masked_mean_fwd: bad args");
+extern "C" int dsvg_masked_mean_fwd(int32_t dtype, const void* x, const uint64_t* mask, const int32_t* seq_off, void* out,
+                                    int64_t n_seq, int32_t S, int32_t d, void* stream) {
+    DSVG_CHECK_ARG(x && (mask || seq_off) && out && n_seq > 0 && S > 0 && S <= 64 && d > 0, "masked_mean_fwd: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DSVG_F32)
         hipLaunchKernelGGL(masked_mean_fwd_kernel<float>, dim3((unsigned)n_seq), dim3(256), 0, st, (const float*)x, mask,
-                           (float*)out, S, d);
+                           seq_off, (float*)out, S, d);
     else if (dtype == DSVG_BF16)
         hipLaunchKernelGGL(masked_mean_fwd_kernel<bf16_t>, dim3((unsigned)n_seq), dim3(256), 0, st, (const bf16_t*)x,
-                           mask, (bf16_t*)out, S, d);
+                           mask, seq_off, (bf16_t*)out, S, d);
     else { dsvg_set_error("masked_mean_fwd: bad dtype"); return -1; }
     DSVG_LAUNCH_CHECK("masked_mean_fwd");
     return 0;
 }
-extern "C" int dsvg_masked_mean_bwd(int32_t dtype, const void* dout, const uint64_t* mask, void* dx, int64_t n_seq,
-                                    int32_t S, int32_t d, void* stream) {
-    DSVG_CHECK_ARG(dout && mask && dx && n_seq > 0 && S > 0 && S <= 64 && d > 0, "masked_mean_bwd: bad args");
+extern "C" int dsvg_masked_mean_bwd(int32_t dtype, const void* dout, const uint64_t* mask, const int32_t* seq_off,
+                                    int64_t total_rows, void* dx, int64_t n_seq, int32_t S, int32_t d, void* stream) {
+    DSVG_CHECK_ARG(dout && (mask || seq_off) && dx && n_seq > 0 && S > 0 && S <= 64 && d > 0, "masked_mean_bwd: bad args");
     hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = (unsigned)n_seq + (seq_off ? 1u : 0u);
     if (dtype == DSVG_F32)
-        hipLaunchKernelGGL(masked_mean_bwd_kernel<float>, dim3((unsigned)n_seq), dim3(256), 0, st, (const float*)dout,
-                           mask, (float*)dx, S, d);
+        hipLaunchKernelGGL(masked_mean_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, mask, seq_off,
+                           (long long)total_rows, (float*)dx, S, d);
     else if (dtype == DSVG_BF16)
-        hipLaunchKernelGGL(masked_mean_bwd_kernel<bf16_t>, dim3((unsigned)n_seq), dim3(256), 0, st, (const bf16_t*)dout,
-                           mask, (bf16_t*)dx, S, d);
+        hipLaunchKernelGGL(masked_mean_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, mask, seq_off,
+                           (long long)total_rows, (bf16_t*)dx, S, d);
     else { dsvg_set_error("masked_mean_bwd: bad dtype"); return -1; }
     DSVG_LAUNCH_CHECK("masked_mean_bwd");
     return 0;

@@ -208,16 +208,19 @@ class AddPosFn(torch.autograd.Function):
 
 
 class MaskedMeanFn(torch.autograd.Function):
+    """mask: 64-bit key bitmasks (dense layout) or None with seq_off (packed layout: every row of a sequence counts)"""
+
     @staticmethod
-    def forward(ctx, rt, x, mask, n_seq, S):
-        ctx.n_seq, ctx.S = n_seq, S
-        ctx.save_for_backward(mask)
-        return ops.masked_mean_fwd(x, mask, n_seq, S)
+    def forward(ctx, rt, x, mask, n_seq, S, seq_off=None):
+        ctx.n_seq, ctx.S, ctx.rows = n_seq, S, x.shape[0]
+        ctx.save_for_backward(mask, seq_off)
+        return ops.masked_mean_fwd(x, mask, n_seq, S, seq_off=seq_off)
 
     @staticmethod
     def backward(ctx, dout):
-        mask, = ctx.saved_tensors
-        return None, ops.masked_mean_bwd(dout.contiguous(), mask, ctx.n_seq, ctx.S), None, None, None
+        mask, seq_off = ctx.saved_tensors
+        dx = ops.masked_mean_bwd(dout.contiguous(), mask, ctx.n_seq, ctx.S, seq_off=seq_off, total_rows=ctx.rows)
+        return None, dx, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------------
@@ -255,6 +258,38 @@ class EmbedFn(torch.autograd.Function):
         return (None, None, None, None, None, None, None, None, d_cmd, d_arg, dw, db, dpos, d_grp)
 
 
+class PackedEmbedFn(torch.autograd.Function):
+    """SVGEmbedding on the packed token layout of the first encoder stage (ops.pack_tokens):
+         src[r] = drop( embed_fcn(arg_embed[args_r + 1]) + command_embed[cmd_r] + pos[pos_r] )
+    The positional table rides in the gather/scatter kernels' per-token index slot (free here: the two-stage encoder
+    has no group embedding, deepsvg/model/model.py:105,119-122) and the dropout runs in the GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, rt, commands, args, pos_idx, S, drop_rate, site, command_embed, arg_embed, fcn_w, fcn_b, pos_weight):
+        pos_tab = pos_weight.detach()[:S].contiguous()
+        A, R = ops.embed_gather(commands, args, command_embed.detach(), arg_embed.detach(), rt.dtype, pos_tab, pos_idx)
+        p = rt.p(drop_rate)
+        src = ops.gemm(A, rt.w(fcn_w), bias=fcn_b.detach(), res=R, res_pre=True, drop_p=p, drop_site=site, seed=rt.seed)
+        ctx.rt, ctx.S, ctx.p, ctx.site = rt, S, p, site
+        ctx.save_for_backward(commands, args, pos_idx, A, command_embed, arg_embed, fcn_w, fcn_b, pos_weight)
+        return src
+
+    @staticmethod
+    def backward(ctx, dsrc):
+        rt = ctx.rt
+        commands, args, pos_idx, A, command_embed, arg_embed, fcn_w, fcn_b, pos_weight = ctx.saved_tensors
+        dpre = ops.drop_apply(dsrc.contiguous(), ctx.p, ctx.site, rt.seed)
+        dw, db = _wbgrad(rt, fcn_w, fcn_b, dpre, A)
+        dA = ops.gemm(dpre, rt.w(fcn_w), b_kc=False)
+        d_arg = rt.grad_out(arg_embed)
+        d_cmd = rt.grad_out(command_embed)
+        dpos = rt.grad_out(pos_weight)
+        if pos_weight.shape[0] > ctx.S:
+            dpos[ctx.S:].zero_()
+        ops.embed_scatter(commands, args, dA, dpre, d_arg, d_cmd, pos_idx, dpos[:ctx.S])
+        return (None, None, None, None, None, None, None, d_cmd, d_arg, dw, db, dpos)
+
+
 # --------------------------------------------------------------------------------------------------
 class LayerFn(torch.autograd.Function):
     """One pre-LN transformer block.  With z: the 'global' decoder block (x += linear_global(z) broadcast over
@@ -266,13 +301,13 @@ class LayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rt, x, key_mask, z, l, n_seq, S, n_heads, drop_rate, site0,
-                n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2):
+                n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off=None):
         p = rt.p(drop_rate)
         d = x.shape[1]
         scale = float(d // n_heads) ** -0.5
         xn1, mean1, rstd1 = ops.layernorm_fwd(x, n1w.detach(), n1b.detach())
         qkv = ops.gemm(xn1, rt.w(win), bias=bin_.detach())
-        ao = ops.attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, p, site0, rt.seed)
+        ao = ops.attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, p, site0, rt.seed, seq_off=seq_off)
         x1 = ops.gemm(ao, rt.w(wo), bias=bo.detach(), res=x, drop_p=p, drop_site=site0 + 1, seed=rt.seed)
         if z is not None:
             g = ops.gemm(z, rt.w(wg), bias=bg.detach())
@@ -285,15 +320,16 @@ class LayerFn(torch.autograd.Function):
             h = ops.gemm(xn2, rt.w(w1), bias=b1.detach(), act=ops.RELU, drop_p=p, drop_site=site0 + 3, seed=rt.seed)
             x2 = ops.gemm(h, rt.w(w2), bias=b2.detach(), res=x1, drop_p=p, drop_site=site0 + 4, seed=rt.seed)
         ctx.rt, ctx.n_seq, ctx.S, ctx.n_heads, ctx.p, ctx.site0, ctx.scale = rt, n_seq, S, n_heads, p, site0, scale
+        assert seq_off is None or (z is None and l is None), "packed layout: no per-sequence conditioning adds"
         ctx.save_for_backward(x, key_mask, z, l, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h,
-                              n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2)
+                              n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off)
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
         rt, n_seq, S, H, p, s0 = ctx.rt, ctx.n_seq, ctx.S, ctx.n_heads, ctx.p, ctx.site0
         (x, key_mask, z, l, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h,
-         n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2) = ctx.saved_tensors
+         n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off) = ctx.saved_tensors
         dx2 = dx2.contiguous()
         inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
         # ---- FFN: x2 = x1 + drop4(h W2^T + b2),  h = drop3(relu(xn2 W1^T + b1)) ----
@@ -324,13 +360,13 @@ class LayerFn(torch.autograd.Function):
         dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao)
         dao = ops.gemm(dx1m, rt.w(wo), b_kc=False)
         del dx1m
-        dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed)
+        dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed, seq_off=seq_off)
         dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1)
         dxn1 = ops.gemm(dqkv, rt.w(win), b_kc=False)
         dx, dn1w, dn1b = ops.layernorm_bwd(dxn1, x, mean1, rstd1, n1w.detach(), res=dx1,
                                            dgamma=rt.grad_out(n1w), dbeta=rt.grad_out(n1b))
         return (None, dx, None, dz, dl, None, None, None, None, None,
-                dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, dwg2, dbg2)
+                dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, dwg2, dbg2, None)
 
 
 # --------------------------------------------------------------------------------------------------

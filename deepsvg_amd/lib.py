@@ -50,8 +50,9 @@ SIGNATURES = {
     "dsvg_layernorm_fwd": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_f32, vp]),
     "dsvg_layernorm_bwd": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i32, c_i64, c_i32, vp, c_i64, vp]),
     "dsvg_layernorm_bwd_workspace_bytes": (c_i64, [c_i64, c_i32]),
-    "dsvg_attention_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
-    "dsvg_attention_bwd": (c_i32, [c_i32, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
+    "dsvg_attention_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
+    "dsvg_attention_bwd": (c_i32, [c_i32, vp, vp, vp, c_i64, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
+    "dsvg_pack_tokens": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, vp]),
     "dsvg_build_masks": (c_i32, [vp, c_i64, c_i32, c_i32, c_i32, vp, vp, vp, vp]),
     "dsvg_embed_gather": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, vp]),
     "dsvg_embed_scatter": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32,
@@ -61,8 +62,8 @@ SIGNATURES = {
     "dsvg_add_pos_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_u32, vp, vp]),
     "dsvg_add_pos_bwd": (c_i32, [c_i32, vp, vp, vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_u32, vp, vp, c_i64, vp]),
     "dsvg_add_pos_bwd_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32]),
-    "dsvg_masked_mean_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, vp]),
-    "dsvg_masked_mean_bwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, vp]),
+    "dsvg_masked_mean_fwd": (c_i32, [c_i32, vp, vp, vp, vp, c_i64, c_i32, c_i32, vp]),
+    "dsvg_masked_mean_bwd": (c_i32, [c_i32, vp, vp, vp, c_i64, vp, c_i64, c_i32, c_i32, vp]),
     "dsvg_bcast_add_fwd": (c_i32, [c_i32, vp, vp, c_i64, c_i32, c_i32, c_f32, c_u32, vp, vp]),
     "dsvg_bcast_add_bwd": (c_i32, [c_i32, vp, vp, c_i64, c_i32, c_i32, c_f32, c_u32, vp, vp]),
     "dsvg_loss_targets": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, vp]),

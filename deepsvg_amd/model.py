@@ -307,6 +307,9 @@ class SVGTransformer(nn.Module):
         self._store = ParamStore(self)
         self._seed = None           # int64[1] device tensor (dropout seed of the current step)
         self._own_seed = True       # advance the seed on every training forward unless a trainer drives it
+        # first encoder stage on the valid tokens only (exact); DSVG_PACK_ENCODER=0 -> padded layout
+        self.pack_encoder = os.environ.get("DSVG_PACK_ENCODER", "1") != "0"
+        self.last_packing = None
 
     # ---- runtime plumbing ------------------------------------------------------------------------
     def set_compute_dtype(self, dtype):
@@ -332,7 +335,7 @@ class SVGTransformer(nn.Module):
         return Fn.Runtime(self.compute_dtype, seed, self._store, training)
 
     # ---- blocks ----------------------------------------------------------------------------------
-    def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site):
+    def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site, seq_off=None):
         cfg = self.cfg
         for i, L in enumerate(stack.layers):
             has_g = hasattr(L, "linear_global")
@@ -341,8 +344,27 @@ class SVGTransformer(nn.Module):
                 L.norm1.weight, L.norm1.bias, L.self_attn.in_proj_weight, L.self_attn.in_proj_bias,
                 L.self_attn.out_proj.weight, L.self_attn.out_proj.bias, L.norm2.weight, L.norm2.bias,
                 L.linear1.weight, L.linear1.bias, L.linear2.weight, L.linear2.bias,
-                L.linear_global.weight if has_g else None, L.linear_global.bias if has_g else None, None, None)
+                L.linear_global.weight if has_g else None, L.linear_global.bias if has_g else None, None, None,
+                seq_off)
         return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps)
+
+    def _encode_stage1_packed(self, rt, cmd, arg, key_mask, n_seq, S):
+        """First encoder stage on the valid tokens only: rows past a sequence's first EOS are
+        masked as keys (layers/functional.py:234-239) and dropped by the mean-pool (model.py:137), so they reach
+        neither an output nor a gradient.  Tokens are packed back to back; the row count is rounded up to a
+        multiple of 128 with inert rows (finite activations, exactly-zero gradients).  One device->host read of
+        the token count per forward (the reference's own loss syncs the same way, loss.py:53-54)."""
+        enc = self.encoder
+        emb = enc.embedding
+        seq_off, pcmd, parg, ppos = ops.pack_tokens(cmd.view(-1), arg, key_mask, n_seq, S)
+        total = int(seq_off[-1].item())
+        rows = min((total + 127) // 128 * 128, n_seq * S)
+        self.last_packing = (total, n_seq * S)      # valid tokens, dense tokens (reported by bench.py)
+        src = Fn.PackedEmbedFn.apply(rt, pcmd[:rows], parg[:rows], ppos[:rows], S, PE_DROPOUT, 1,
+                                     emb.command_embed.weight, emb.arg_embed.weight, emb.embed_fcn.weight,
+                                     emb.embed_fcn.bias, emb.pos_encoding.pos_embed.weight)
+        mem = self._run_stack(rt, enc.encoder, src, None, None, n_seq, S, 100, seq_off=seq_off)
+        return Fn.MaskedMeanFn.apply(rt, mem, None, n_seq, S, seq_off)
 
     def _encode(self, rt, commands, args):
         """commands (N, G, S) / args (N, G, S, n_args) float32, batch-first  ->  z [N, d_model]"""
@@ -354,13 +376,18 @@ class SVGTransformer(nn.Module):
         two = cfg.encode_stages == 2
         key_mask, _vis, group_mask = ops.build_masks(cmd, S, G, EOS_ID, want_group_mask=two)
         emb = enc.embedding
-        groups = ops.group_index(cmd, S, M_ID) if enc.use_group else None
-        src = Fn.EmbedFn.apply(rt, cmd.view(-1), arg, groups, N * G, S, PE_DROPOUT, 1,
-                               emb.command_embed.weight, emb.arg_embed.weight, emb.embed_fcn.weight,
-                               emb.embed_fcn.bias, emb.pos_encoding.pos_embed.weight,
-                               emb.group_embed.weight if enc.use_group else None)
-        mem = self._run_stack(rt, enc.encoder, src, key_mask, None, N * G, S, 100)
-        z = Fn.MaskedMeanFn.apply(rt, mem, key_mask, N * G, S)          # [N*G, d]
+        capturing = cmd.is_cuda and torch.cuda.is_current_stream_capturing()
+        if self.pack_encoder and not enc.use_group and not capturing:
+            z = self._encode_stage1_packed(rt, cmd, arg, key_mask, N * G, S)
+        else:
+            self.last_packing = None
+            groups = ops.group_index(cmd, S, M_ID) if enc.use_group else None
+            src = Fn.EmbedFn.apply(rt, cmd.view(-1), arg, groups, N * G, S, PE_DROPOUT, 1,
+                                   emb.command_embed.weight, emb.arg_embed.weight, emb.embed_fcn.weight,
+                                   emb.embed_fcn.bias, emb.pos_encoding.pos_embed.weight,
+                                   emb.group_embed.weight if enc.use_group else None)
+            mem = self._run_stack(rt, enc.encoder, src, key_mask, None, N * G, S, 100)
+            z = Fn.MaskedMeanFn.apply(rt, mem, key_mask, N * G, S)          # [N*G, d]
         if two:
             src2 = Fn.AddPosFn.apply(rt, z, enc.hierarchical_PE.pos_embed.weight, N, G, PE_DROPOUT, 2)
             mem2 = self._run_stack(rt, enc.hierarchical_encoder, src2, group_mask, None, N, G, 200)

@@ -12,7 +12,7 @@ RELU = 1
 
 # optional per-launch timing of tagged GEMMs (bench.py roofline leg): HIP events on the launch stream
 PROFILE_ON = False
-PROFILE = []          # (tag, start_event, end_event)
+PROFILE = []          # (tag, start_event, end_event, flops of the launch, algorithmic bytes of the launch)
 _TAG = None
 
 
@@ -132,7 +132,9 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
         ev0.record()
         _l.check(_l.load().dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
         ev1.record()
-        PROFILE.append((_TAG, ev0, ev1))
+        esz = 2 if a.dtype == torch.bfloat16 else 4
+        PROFILE.append((_TAG, ev0, ev1, 2.0 * d.M * d.N * d.K,
+                        float(esz * (d.M * d.K + d.N * d.K) + out.element_size() * d.M * d.N)))
         return out
     _l.check(_l.load().dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
     return out
@@ -206,24 +208,29 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, res=None, dgamma=None, dbeta=None
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
-def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None):
-    _chk(qkv, key_mask, seed)
-    assert qkv.is_contiguous() and qkv.shape[0] == n_seq * S and qkv.shape[1] == 3 * 32 * n_heads, \
-        "attention needs head_dim == 32"
-    out = torch.empty((n_seq * S, 32 * n_heads), dtype=qkv.dtype, device=qkv.device)
-    _l.check(_l.load().dsvg_attention_fwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), out.data_ptr(), n_seq, S, n_heads,
-                                          float(scale), float(drop_p), int(drop_site),
+def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None):
+    """seq_off (int32 [n_seq+1], device): packed layout, sequence b = rows seq_off[b]..seq_off[b+1]-1 (<= S rows, all
+    keys visible, key_mask must be None); rows past seq_off[n_seq] are zero-filled."""
+    _chk(qkv, key_mask, seed, seq_off)
+    rows = qkv.shape[0]
+    assert qkv.is_contiguous() and qkv.shape[1] == 3 * 32 * n_heads, "attention needs head_dim == 32"
+    assert (rows == n_seq * S) if seq_off is None else (key_mask is None and seq_off.numel() == n_seq + 1)
+    out = torch.empty((rows, 32 * n_heads), dtype=qkv.dtype, device=qkv.device)
+    _l.check(_l.load().dsvg_attention_fwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), _p(seq_off), rows, out.data_ptr(),
+                                          n_seq, S, n_heads, float(scale), float(drop_p), int(drop_site),
                                           _p(seed) if drop_p > 0 else None, _stream()), "dsvg_attention_fwd")
     return out
 
 
-def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None):
-    _chk(qkv, key_mask, dout, seed)
+def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None):
+    _chk(qkv, key_mask, dout, seed, seq_off)
     assert qkv.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype
+    assert seq_off is None or (key_mask is None and seq_off.numel() == n_seq + 1)
     dqkv = torch.empty_like(qkv)
-    _l.check(_l.load().dsvg_attention_bwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), dout.data_ptr(), dqkv.data_ptr(),
-                                          n_seq, S, n_heads, float(scale), float(drop_p), int(drop_site),
-                                          _p(seed) if drop_p > 0 else None, _stream()), "dsvg_attention_bwd")
+    _l.check(_l.load().dsvg_attention_bwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), _p(seq_off), qkv.shape[0],
+                                          dout.data_ptr(), dqkv.data_ptr(), n_seq, S, n_heads, float(scale),
+                                          float(drop_p), int(drop_site), _p(seed) if drop_p > 0 else None, _stream()),
+             "dsvg_attention_bwd")
     return dqkv
 
 
@@ -317,24 +324,43 @@ def add_pos_bwd(dy, n_seq, S, d_pos, *, want_dx=True, accumulate=False, drop_p=0
     return dx
 
 
-def masked_mean_fwd(x, mask, n_seq, S):
-    _chk(x, mask)
-    assert x.is_contiguous()
+def masked_mean_fwd(x, mask, n_seq, S, seq_off=None):
+    _chk(x, mask, seq_off)
+    assert x.is_contiguous() and (mask is not None or seq_off is not None)
     d = x.shape[1]
     out = torch.empty((n_seq, d), dtype=x.dtype, device=x.device)
-    _l.check(_l.load().dsvg_masked_mean_fwd(_dt(x), x.data_ptr(), mask.data_ptr(), out.data_ptr(), n_seq, S, d,
+    _l.check(_l.load().dsvg_masked_mean_fwd(_dt(x), x.data_ptr(), _p(mask), _p(seq_off), out.data_ptr(), n_seq, S, d,
                                             _stream()), "dsvg_masked_mean_fwd")
     return out
 
 
-def masked_mean_bwd(dout, mask, n_seq, S):
-    _chk(dout, mask)
-    assert dout.is_contiguous()
+def masked_mean_bwd(dout, mask, n_seq, S, seq_off=None, total_rows=None):
+    _chk(dout, mask, seq_off)
+    assert dout.is_contiguous() and (mask is not None or seq_off is not None)
     d = dout.shape[1]
-    dx = torch.empty((n_seq * S, d), dtype=dout.dtype, device=dout.device)
-    _l.check(_l.load().dsvg_masked_mean_bwd(_dt(dout), dout.data_ptr(), mask.data_ptr(), dx.data_ptr(), n_seq, S, d,
-                                            _stream()), "dsvg_masked_mean_bwd")
+    rows = n_seq * S if seq_off is None else int(total_rows)
+    dx = torch.empty((rows, d), dtype=dout.dtype, device=dout.device)
+    _l.check(_l.load().dsvg_masked_mean_bwd(_dt(dout), dout.data_ptr(), _p(mask), _p(seq_off), rows, dx.data_ptr(),
+                                            n_seq, S, d, _stream()), "dsvg_masked_mean_bwd")
     return dx
+
+
+def pack_tokens(commands, args, key_mask, n_seq, S):
+    """packed token layout of the first encoder stage (include/dsvg.h): returns seq_off int32 [n_seq+1] and the packed
+    commands [n_seq*S], args [n_seq*S, n_args], positions int32 [n_seq*S] (rows past seq_off[-1] replicate token 0)"""
+    _chk(commands, args, key_mask)
+    assert commands.dtype == torch.float32 and args.dtype == torch.float32 and commands.is_contiguous() and \
+        args.is_contiguous() and commands.numel() == n_seq * S
+    n_args = args.numel() // (n_seq * S)
+    dev = commands.device
+    seq_off = torch.empty(n_seq + 1, dtype=torch.int32, device=dev)
+    pcmd = torch.empty(n_seq * S, dtype=torch.float32, device=dev)
+    parg = torch.empty((n_seq * S, n_args), dtype=torch.float32, device=dev)
+    ppos = torch.empty(n_seq * S, dtype=torch.int32, device=dev)
+    _l.check(_l.load().dsvg_pack_tokens(commands.data_ptr(), args.data_ptr(), key_mask.data_ptr(), n_seq, S, n_args,
+                                        seq_off.data_ptr(), pcmd.data_ptr(), parg.data_ptr(), ppos.data_ptr(),
+                                        _stream()), "dsvg_pack_tokens")
+    return seq_off, pcmd, parg, ppos
 
 
 def bcast_add_fwd_(x, g, n_seq, S, drop_p=0.0, drop_site=0, seed=None):

@@ -104,13 +104,16 @@ int64_t dsvg_layernorm_bwd_workspace_bytes(int64_t rows, int32_t d);
  *   out[t, h*32+c] = sum_j drop(softmax_j(scale*q_i.k_j))*v_j
  * Replaces deepsvg/model/layers/functional.py:168,197-248 (scale, reshape, bmm, masked_fill,
  * softmax, dropout, bmm, head merge).  bwd recomputes the probabilities (no S×S tensor in HBM).
+ * Packed layout (seq_off != NULL, key_mask == NULL): sequence b owns rows seq_off[b]..seq_off[b+1]-1
+ * (at most S of them, all visible); rows seq_off[n_seq]..total_rows-1 of out / dqkv are zero-filled.
  * ------------------------------------------------------------------------------------------ */
-int dsvg_attention_fwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, void* out,
-                       int64_t n_seq, int32_t S, int32_t n_heads, float scale, float drop_p,
-                       uint32_t drop_site, const uint64_t* seed, void* stream);
-int dsvg_attention_bwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const void* dout,
-                       void* dqkv, int64_t n_seq, int32_t S, int32_t n_heads, float scale,
-                       float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream);
+int dsvg_attention_fwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const int32_t* seq_off,
+                       int64_t total_rows, void* out, int64_t n_seq, int32_t S, int32_t n_heads,
+                       float scale, float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream);
+int dsvg_attention_bwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const int32_t* seq_off,
+                       int64_t total_rows, const void* dout, void* dqkv, int64_t n_seq, int32_t S,
+                       int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Masks from the command tensor (deepsvg/model/utils.py:7-66).  commands: float32 [n_seq, S]
@@ -142,6 +145,14 @@ int64_t dsvg_embed_scatter_workspace_bytes(int64_t T, int32_t n_args, int32_t E,
 /* group index per token: groups[b*S+s] = #{ s' <= s : commands[b,s'] == m_id }  (utils.py:35-42) */
 int dsvg_group_index(const float* commands, int64_t n_seq, int32_t S, int32_t m_id, int32_t* groups,
                      void* stream);
+/* Packed token layout of the first encoder stage: only keys are masked there (layers/functional.py:234-239)
+ * and padded query rows are dropped by the mean-pool (model/model.py:137), so the encoder can run on the
+ * valid tokens only, bit-for-bit safe.  seq_off[b] = exclusive scan of popcount(key_mask) (n_seq+1 entries,
+ * seq_off[n_seq] = number of valid tokens); packed row seq_off[b]+s = token (b, s); rows past the total, up
+ * to the capacity n_seq*S, replicate token 0.  packed_pos[row] = s (position index). */
+int dsvg_pack_tokens(const float* commands, const float* args, const uint64_t* key_mask, int64_t n_seq,
+                     int32_t S, int32_t n_args, int32_t* seq_off, float* packed_commands,
+                     float* packed_args, int32_t* packed_pos, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * y[t,:] = drop( (x ? x[t,:] : 0) + pos_embed[t % S, :] )
@@ -159,11 +170,13 @@ int64_t dsvg_add_pos_bwd_workspace_bytes(int64_t n_seq, int32_t S, int32_t d);
 /* ------------------------------------------------------------------------------------------
  * Masked mean over the sequence axis (deepsvg/model/model.py:137,161):
  *   out[b,:] = sum_{s in mask[b]} x[b*S+s,:] / popcount(mask[b])
+ * Packed layout (seq_off != NULL): mean over rows seq_off[b]..seq_off[b+1]-1; bwd zero-fills the rows
+ * seq_off[n_seq]..total_rows-1.
  * ------------------------------------------------------------------------------------------ */
-int dsvg_masked_mean_fwd(int32_t dtype, const void* x, const uint64_t* mask, void* out, int64_t n_seq,
-                         int32_t S, int32_t d, void* stream);
-int dsvg_masked_mean_bwd(int32_t dtype, const void* dout, const uint64_t* mask, void* dx,
-                         int64_t n_seq, int32_t S, int32_t d, void* stream);
+int dsvg_masked_mean_fwd(int32_t dtype, const void* x, const uint64_t* mask, const int32_t* seq_off,
+                         void* out, int64_t n_seq, int32_t S, int32_t d, void* stream);
+int dsvg_masked_mean_bwd(int32_t dtype, const void* dout, const uint64_t* mask, const int32_t* seq_off,
+                         int64_t total_rows, void* dx, int64_t n_seq, int32_t S, int32_t d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * x[t,:] += drop(g[t / S, :])      "implicit broadcast" add of linear_global(z)

@@ -49,6 +49,30 @@ def test_model_matches_golden_with_emulated_ops(name, emulated_ops):
         assert torch.allclose(z, torch.from_numpy(g["z"]), rtol=1e-4, atol=1e-5)
 
 
+def test_packed_encoder_equals_padded_encoder(emulated_ops):
+    """the first encoder stage on the valid tokens only (default) vs on the reference's padded layout: same logits,
+    losses and gradients (padded rows reach neither)"""
+    g, cfg, commands, args, eps = H.golden_setup("hier_ordered_n5")
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), g["wseed"])
+    res = {}
+    for packed in (True, False):
+        model = deepsvg_amd.SVGTransformer(cfg)
+        model.load_state_dict(sd)
+        model.pack_encoder = packed
+        model.eval()
+        out = model(commands, args, commands, args, params={})
+        ld = deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
+        ld["loss"].backward()
+        res[packed] = (out, ld, {n: p.grad.clone() for n, p in model.named_parameters()}, model.last_packing)
+    total, dense = res[True][3]
+    assert res[False][3] is None and 0 < total < dense
+    for k in ("command_logits", "args_logits", "visibility_logits"):
+        assert torch.allclose(res[True][0][k], res[False][0][k], rtol=1e-4, atol=2e-5), k
+    assert abs(res[True][1]["loss"].item() - res[False][1]["loss"].item()) < 1e-5
+    for n in res[True][2]:
+        assert H.rel_l2(res[True][2][n], res[False][2][n]) < 1e-4, n
+
+
 def test_state_dict_layout_matches_reference_names(emulated_ops):
     g = H.load_golden("hier_ordered_n2")
     cfg = H.build_cfg("hier")

@@ -258,6 +258,63 @@ def test_attention(gpu_device, dtype, S, n_seq, masked):
 
 
 # ----------------------------------------------------------------------------------------------------
+def _packed_case(n_seq, S, seed):
+    """random valid-prefix lengths in 1..S -> (key_mask int64 [n_seq], seq_off int32 [n_seq+1], total)"""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(1, S + 1, (n_seq,), generator=g)
+    lens[0], lens[-1] = S, 1
+    km = ((torch.ones_like(lens) << lens) - 1).to(torch.int64).to(DEV)
+    off = torch.zeros(n_seq + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    return km, off.to(DEV), int(off[-1])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S,n_seq", [(32, 70), (31, 40), (8, 50)])
+def test_attention_packed_layout(gpu_device, dtype, S, n_seq):
+    """variable-length sequences packed back to back (first encoder stage): forward and backward against the padded
+    reference, pad rows zero-filled; S = 32 / 31 bf16 runs the MFMA kernel, the rest the VALU kernel"""
+    H_, d = 8, 256
+    km, off, total = _packed_case(n_seq, S, 5)
+    rows = (total + 127) // 128 * 128
+    qkv = _rand(rows, 3 * d, dtype=dtype, seed=50)
+    do = _rand(rows, d, dtype=dtype, seed=51)
+    seed = _seed_tensor(0x1111222233334444)
+    for p in (0.0, 0.2):
+        out = ops.attention_fwd(qkv, None, n_seq, S, H_, 32 ** -0.5, p, 17, seed, seq_off=off)
+        ref = R.attention_fwd(qkv, None, n_seq, S, H_, 32 ** -0.5, p, 17, seed, seq_off=off)
+        _close(out, ref, 2e-5 if dtype == torch.float32 else 2e-2, f"packed attention fwd p={p}")
+        assert torch.count_nonzero(out[total:]) == 0
+        dq = ops.attention_bwd(qkv, None, do, n_seq, S, H_, 32 ** -0.5, p, 17, seed, seq_off=off)
+        dref = R.attention_bwd(qkv, None, do, n_seq, S, H_, 32 ** -0.5, p, 17, seed, seq_off=off)
+        _close(dq, dref, 5e-5 if dtype == torch.float32 else 3e-2, f"packed attention bwd p={p}")
+        assert torch.count_nonzero(dq[total:]) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_tokens_and_packed_mean(gpu_device, dtype):
+    n, G, S = 6, 8, 32
+    cmd, arg = _cmd_args(n, G, S - 2, seed=3)
+    cmd2 = cmd.view(n * G, S).contiguous()
+    arg2 = arg.view(n * G * S, -1).contiguous()
+    km, _, _ = ops.build_masks(cmd2, S, G, 4, want_group_mask=True)
+    got = ops.pack_tokens(cmd2.view(-1), arg2, km, n * G, S)
+    exp = R.pack_tokens(cmd2.view(-1), arg2, km, n * G, S)
+    for a, b, what in zip(got, exp, ("seq_off", "commands", "args", "pos")):
+        assert torch.equal(a, b), f"pack_tokens {what}"
+    off = got[0]
+    total = int(off[-1])
+    rows = (total + 127) // 128 * 128
+    x = _rand(rows, 256, dtype=dtype, seed=60)
+    m = ops.masked_mean_fwd(x, None, n * G, S, seq_off=off)
+    _close(m, R.masked_mean_fwd(x, None, n * G, S, seq_off=off), 1e-6 if dtype == torch.float32 else 1e-2, "packed mean")
+    dm = _rand(n * G, 256, dtype=dtype, seed=61)
+    dx = ops.masked_mean_bwd(dm, None, n * G, S, seq_off=off, total_rows=rows)
+    _close(dx, R.masked_mean_bwd(dm, None, n * G, S, seq_off=off, total_rows=rows),
+           1e-6 if dtype == torch.float32 else 1e-2, "packed mean bwd")
+    assert torch.count_nonzero(dx[total:]) == 0
+
+
 def _cmd_args(n, G=8, S=30, seed=0):
     from deepsvg_amd.synthetic import make_batch
     c, a = make_batch(n, G, S, seed=seed)

@@ -42,10 +42,13 @@ def _fwd_bwd(model, cfg, commands, args, eps=None):
     return out, {k: float(v) for k, v in ld.items()}, grads
 
 
+@pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("name", H.golden_cases())
-def test_fp32_model_matches_reference_golden(gpu_device, name):
+def test_fp32_model_matches_reference_golden(gpu_device, name, packed):
+    """packed: first encoder stage on the valid tokens only (default) / on the reference's padded layout"""
     g, cfg, commands, args, eps = H.golden_setup(name)
     model = _hip_model(cfg, H.weights_for(deepsvg_amd.SVGTransformer(cfg), g["wseed"]))
+    model.pack_encoder = packed
     model.eval()
     out, ld, grads = _fwd_bwd(model, cfg, commands, args, eps)
     H.check_against_golden(g, out, ld, grads, logit_rtol=1e-3, logit_atol=1e-5, loss_tol=1e-4, grad_norm_rtol=1e-3)
@@ -70,6 +73,30 @@ def test_fp32_model_matches_oracle_on_fresh_batch(gpu_device):
         assert abs(ld[k] - o_ld[k].item()) <= 1e-4 * max(1.0, abs(o_ld[k].item())), (k, ld[k], o_ld[k].item())
     worst = max(H.rel_l2(grads[n], o_grads[n]) for n in o_grads)
     assert worst < 1e-3, f"worst per-tensor gradient relative L2 error {worst:.2e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_packed_encoder_equals_padded_encoder(gpu_device, dtype):
+    """exact padding skip: identical logits / loss / gradients with and without it (to rounding), and the packing
+    actually drops rows on the synthetic distribution"""
+    cfg = H.build_cfg("hier")
+    commands, args = make_batch(40, seed=99)
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 321)
+    res = {}
+    for packed in (True, False):
+        model = _hip_model(cfg, sd, dtype).eval()
+        model.pack_encoder = packed
+        res[packed] = _fwd_bwd(model, cfg, commands, args) + (model.last_packing,)
+    total, dense = res[True][3]
+    print(f"packed encoder: {total} of {dense} tokens ({100.0 * total / dense:.1f} %)")
+    assert res[False][3] is None and 0 < total < 0.6 * dense
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    for k in ("command_logits", "args_logits", "visibility_logits"):
+        a, b = res[True][0][k], res[False][0][k]
+        assert (a - b).abs().max().item() <= tol * (1.0 + b.abs().max().item()), k
+    assert abs(res[True][1]["loss"] - res[False][1]["loss"]) <= tol * abs(res[False][1]["loss"])
+    worst = max(H.rel_l2(res[True][2][n], res[False][2][n]) for n in res[True][2])
+    assert worst < (1e-4 if dtype == torch.float32 else 6e-2), f"worst gradient rel L2 {worst:.2e}"
 
 
 def test_bf16_model_tracks_fp32_reference(gpu_device):

@@ -180,7 +180,35 @@ def _attn_drop(p, seed, site, n_seq, S, H, device):
     return drop_mult(p, seed, site, idx)
 
 
-def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None):
+# packed layout helpers: seq_off int32 [n_seq+1]; sequence b = rows seq_off[b]..seq_off[b+1]-1
+def _unpack_rows(x, seq_off, n_seq, S):
+    """packed [rows, w] -> dense zero-padded [n_seq * S, w] plus the dense row index of every packed row"""
+    off = seq_off.long()
+    lens = off[1:] - off[:-1]
+    total = int(off[-1])
+    seq = torch.repeat_interleave(torch.arange(n_seq, device=x.device), lens)
+    pos = torch.arange(total, device=x.device) - off[:-1][seq]
+    idx = seq * S + pos
+    dense = torch.zeros((n_seq * S, x.shape[1]), dtype=x.dtype, device=x.device)
+    dense[idx] = x[:total]
+    return dense, idx, lens
+
+
+def _len_mask(lens):
+    return ((torch.ones_like(lens) << lens) - 1).to(torch.int64)
+
+
+def _repack_rows(dense, idx, rows):
+    out = torch.zeros((rows, dense.shape[1]), dtype=dense.dtype, device=dense.device)
+    out[:idx.numel()] = dense[idx]
+    return out
+
+
+def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None):
+    if seq_off is not None:
+        dense, idx, lens = _unpack_rows(qkv, seq_off, n_seq, S)
+        o = attention_fwd(dense, _len_mask(lens), n_seq, S, n_heads, scale, drop_p, drop_site, seed)
+        return _repack_rows(o, idx, qkv.shape[0])
     H = n_heads
     q, k, v, P = _attn_probs(qkv, key_mask, n_seq, S, H, scale)
     Pd = P * _attn_drop(drop_p, seed, drop_site, n_seq, S, H, qkv.device)
@@ -188,7 +216,12 @@ def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site
     return o.permute(0, 2, 1, 3).reshape(n_seq * S, H * 32).to(qkv.dtype)
 
 
-def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None):
+def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None):
+    if seq_off is not None:
+        dense, idx, lens = _unpack_rows(qkv, seq_off, n_seq, S)
+        ddense, _, _ = _unpack_rows(dout, seq_off, n_seq, S)
+        g = attention_bwd(dense, _len_mask(lens), ddense, n_seq, S, n_heads, scale, drop_p, drop_site, seed)
+        return _repack_rows(g, idx, qkv.shape[0])
     H = n_heads
     q, k, v, P = _attn_probs(qkv, key_mask, n_seq, S, H, scale)
     mult = _attn_drop(drop_p, seed, drop_site, n_seq, S, H, qkv.device)
@@ -220,6 +253,24 @@ def build_masks(commands, S, G=0, eos_id=4, want_group_mask=False):
 
 def group_index(commands, S, m_id=0):
     return (commands.view(-1, S).long() == m_id).cumsum(1).to(torch.int32).reshape(-1)
+
+
+def pack_tokens(commands, args, key_mask, n_seq, S):
+    valid = _mask_bits(key_mask, S)                                      # [n_seq, S], a prefix per row
+    lens = valid.sum(1)
+    seq_off = torch.zeros(n_seq + 1, dtype=torch.int32, device=commands.device)
+    seq_off[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    total = int(seq_off[-1])
+    cap = n_seq * S
+    a = args.reshape(cap, -1)
+    sel = valid.reshape(-1).nonzero().squeeze(1)
+    pcmd = commands.reshape(-1)[0].repeat(cap).clone()
+    parg = a[0:1].repeat(cap, 1).clone()
+    ppos = torch.zeros(cap, dtype=torch.int32, device=commands.device)
+    pcmd[:total] = commands.reshape(-1)[sel]
+    parg[:total] = a[sel]
+    ppos[:total] = (sel % S).to(torch.int32)
+    return seq_off, pcmd, parg, ppos
 
 
 def embed_gather(commands, args, command_embed, arg_embed, dtype, group_embed=None, groups=None):
@@ -263,14 +314,21 @@ def add_pos_bwd(dy, n_seq, S, d_pos, *, want_dx=True, accumulate=False, drop_p=0
     return g.to(dy.dtype) if want_dx else None
 
 
-def masked_mean_fwd(x, mask, n_seq, S):
+def masked_mean_fwd(x, mask, n_seq, S, seq_off=None):
+    if seq_off is not None:
+        dense, _, lens = _unpack_rows(x, seq_off, n_seq, S)
+        return masked_mean_fwd(dense, _len_mask(lens), n_seq, S)
     d = x.shape[1]
     valid = _mask_bits(mask, S).to(torch.float32)
     xf = _f(x).view(n_seq, S, d)
     return ((xf * valid.unsqueeze(-1)).sum(1) / valid.sum(1, keepdim=True)).to(x.dtype)
 
 
-def masked_mean_bwd(dout, mask, n_seq, S):
+def masked_mean_bwd(dout, mask, n_seq, S, seq_off=None, total_rows=None):
+    if seq_off is not None:
+        probe = torch.zeros((int(total_rows), 1), dtype=dout.dtype, device=dout.device)
+        _, idx, lens = _unpack_rows(probe, seq_off, n_seq, S)
+        return _repack_rows(masked_mean_bwd(dout, _len_mask(lens), n_seq, S), idx, int(total_rows))
     valid = _mask_bits(mask, S).to(torch.float32)
     g = _f(dout) / valid.sum(1, keepdim=True)
     return (g.unsqueeze(1) * valid.unsqueeze(-1)).reshape(n_seq * S, -1).to(dout.dtype)
