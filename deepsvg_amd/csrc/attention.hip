@@ -82,11 +82,11 @@ __global__ __launch_bounds__(HG * SP) void attn_fwd_kernel(
     const int h = hg * HG + hh;             // global head
     long long row0 = (long long)b * Smax;
     int S = Smax;                           // this sequence's length (dropout ids keep the Smax-based numbering)
+    if (total_rows > 0 && b == (int)gridDim.x - 1) {     // tail workgroup: rows past the last sequence <- 0
+        zero_rows<T, C::NT>(out + (size_t)hg * C::W, (long long)d, seq_off ? (long long)seq_off[b] : row0, total_rows, C::W);
+        return;
+    }
     if (seq_off) {
-        if (b == (int)gridDim.x - 1) {
-            zero_rows<T, C::NT>(out + (size_t)hg * C::W, (long long)d, seq_off[b], total_rows, C::W);
-            return;
-        }
         row0 = seq_off[b];
         S = seq_off[b + 1] - seq_off[b];
     }
@@ -167,14 +167,15 @@ __global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
     const int h = hg * HG + hh;
     long long row0 = (long long)b * Smax;
     int S = Smax;
+    if (total_rows > 0 && b == (int)gridDim.x - 1) {     // tail workgroup: rows past the last sequence <- 0
+        const long long first = seq_off ? (long long)seq_off[b] : row0;
+        T* z = dqkv + (size_t)hg * C::W;
+        zero_rows<T, C::NT>(z, 3LL * d, first, total_rows, C::W);
+        zero_rows<T, C::NT>(z + d, 3LL * d, first, total_rows, C::W);
+        zero_rows<T, C::NT>(z + 2 * d, 3LL * d, first, total_rows, C::W);
+        return;
+    }
     if (seq_off) {
-        if (b == (int)gridDim.x - 1) {
-            T* z = dqkv + (size_t)hg * C::W;
-            zero_rows<T, C::NT>(z, 3LL * d, seq_off[b], total_rows, C::W);
-            zero_rows<T, C::NT>(z + d, 3LL * d, seq_off[b], total_rows, C::W);
-            zero_rows<T, C::NT>(z + 2 * d, 3LL * d, seq_off[b], total_rows, C::W);
-            return;
-        }
         row0 = seq_off[b];
         S = seq_off[b + 1] - seq_off[b];
     }
@@ -307,8 +308,8 @@ static int launch_fwd(const void* qkv, const uint64_t* km, const int32_t* seq_of
     if (lds > 160 * 1024) { dsvg_set_error("attention_fwd: LDS image too large (%zu B)", lds); return -1; }
     auto kern = attn_fwd_kernel<T, SP, HG>;
     DSVG_ENSURE_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (seq_off ? 1u : 0u), H / HG), dim3(C::NT), lds, st, (const T*)qkv, km,
-                       seq_off, (long long)total_rows, (T*)out, S, H, scale, drop_p, site, seed);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (total_rows > 0 ? 1u : 0u), H / HG), dim3(C::NT), lds, st, (const T*)qkv,
+                       km, seq_off, (long long)total_rows, (T*)out, S, H, scale, drop_p, site, seed);
     DSVG_LAUNCH_CHECK("attention_fwd");
     return 0;
 }
@@ -321,8 +322,8 @@ static int launch_bwd(const void* qkv, const uint64_t* km, const int32_t* seq_of
     if (lds > 160 * 1024) { dsvg_set_error("attention_bwd: LDS image too large (%zu B)", lds); return -1; }
     auto kern = attn_bwd_kernel<T, SP, HG>;
     DSVG_ENSURE_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (seq_off ? 1u : 0u), H / HG), dim3(C::NT), lds, st, (const T*)qkv, km,
-                       seq_off, (long long)total_rows, (const T*)dout, (T*)dqkv, S, H, scale, drop_p, site, seed);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (total_rows > 0 ? 1u : 0u), H / HG), dim3(C::NT), lds, st, (const T*)qkv,
+                       km, seq_off, (long long)total_rows, (const T*)dout, (T*)dqkv, S, H, scale, drop_p, site, seed);
     DSVG_LAUNCH_CHECK("attention_bwd");
     return 0;
 }
@@ -344,6 +345,8 @@ extern "C" int dsvg_attention_fwd(int32_t dtype, const void* qkv, const uint64_t
     DSVG_CHECK_ARG(qkv && out && n_seq > 0 && S > 0 && S <= 64 && n_heads > 0, "attention_fwd: bad args (S=%d)", S);
     DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_fwd: dropout needs a seed pointer");
     DSVG_CHECK_ARG(!seq_off || (!key_mask && total_rows > 0), "attention_fwd: packed layout takes no key mask");
+    DSVG_CHECK_ARG(seq_off || total_rows == 0 || total_rows >= n_seq * S, "attention_fwd: total_rows < n_seq * S");
+    if (!seq_off && total_rows <= n_seq * S) total_rows = 0;       // dense layout without a tail
     hipStream_t st = (hipStream_t)stream;
     if (dsvg_attention_mfma_ok(dtype, S, n_heads))
         return dsvg_attention_fwd_mfma(qkv, key_mask, seq_off, total_rows, out, n_seq, S, n_heads, scale, drop_p, drop_site,
@@ -366,6 +369,8 @@ extern "C" int dsvg_attention_bwd(int32_t dtype, const void* qkv, const uint64_t
     DSVG_CHECK_ARG(qkv && dout && dqkv && n_seq > 0 && S > 0 && S <= 64 && n_heads > 0, "attention_bwd: bad args");
     DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_bwd: dropout needs a seed pointer");
     DSVG_CHECK_ARG(!seq_off || (!key_mask && total_rows > 0), "attention_bwd: packed layout takes no key mask");
+    DSVG_CHECK_ARG(seq_off || total_rows == 0 || total_rows >= n_seq * S, "attention_bwd: total_rows < n_seq * S");
+    if (!seq_off && total_rows <= n_seq * S) total_rows = 0;       // dense layout without a tail
     hipStream_t st = (hipStream_t)stream;
     if (dsvg_attention_mfma_ok(dtype, S, n_heads))
         return dsvg_attention_bwd_mfma(qkv, key_mask, seq_off, total_rows, dout, dqkv, n_seq, S, n_heads, scale, drop_p,

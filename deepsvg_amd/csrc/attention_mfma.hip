@@ -109,11 +109,11 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
     const int h = hg * HG + hh;
     long long row0 = (long long)b * Smax;
     int S = Smax;                   // this sequence's length; dropout ids keep the Smax-based numbering
+    if (total_rows > 0 && b == (int)gridDim.x - 1) {     // tail workgroup: rows past the last sequence <- 0
+        zero_slab_rows(out + (size_t)hg * W, (long long)d, seq_off ? (long long)seq_off[b] : row0, total_rows, W);
+        return;
+    }
     if (seq_off) {
-        if (b == (int)gridDim.x - 1) {
-            zero_slab_rows(out + (size_t)hg * W, (long long)d, seq_off[b], total_rows, W);
-            return;
-        }
         row0 = seq_off[b];
         S = seq_off[b + 1] - seq_off[b];
     }
@@ -187,14 +187,15 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
     const int h = hg * HG + hh;
     long long row0 = (long long)b * Smax;
     int S = Smax;
+    if (total_rows > 0 && b == (int)gridDim.x - 1) {     // tail workgroup: rows past the last sequence <- 0
+        const long long first = seq_off ? (long long)seq_off[b] : row0;
+        bf16_t* z = dqkv + (size_t)hg * W;
+        zero_slab_rows(z, 3LL * d, first, total_rows, W);
+        zero_slab_rows(z + d, 3LL * d, first, total_rows, W);
+        zero_slab_rows(z + 2 * d, 3LL * d, first, total_rows, W);
+        return;
+    }
     if (seq_off) {
-        if (b == (int)gridDim.x - 1) {
-            bf16_t* z = dqkv + (size_t)hg * W;
-            zero_slab_rows(z, 3LL * d, seq_off[b], total_rows, W);
-            zero_slab_rows(z + d, 3LL * d, seq_off[b], total_rows, W);
-            zero_slab_rows(z + 2 * d, 3LL * d, seq_off[b], total_rows, W);
-            return;
-        }
         row0 = seq_off[b];
         S = seq_off[b + 1] - seq_off[b];
     }
@@ -312,7 +313,7 @@ int dsvg_attention_fwd_mfma(const void* qkv, const uint64_t* key_mask, const int
                             void* out, int64_t n_seq, int32_t S, int32_t n_heads, float scale, float drop_p,
                             uint32_t drop_site, const uint64_t* seed, hipStream_t st) {
     const size_t lds = (size_t)32 * LD * sizeof(bf16_t);
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)n_seq + (seq_off ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)n_seq + (total_rows > 0 ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
                        (const bf16_t*)qkv, key_mask, seq_off, (long long)total_rows, (bf16_t*)out, S, n_heads, scale,
                        drop_p, drop_site, seed);
     DSVG_LAUNCH_CHECK("attention_fwd_mfma");
@@ -325,7 +326,7 @@ int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const int
     const size_t lds = (size_t)32 * (LD + LDO) * sizeof(bf16_t) + (size_t)HG * 64 * sizeof(float);
     auto kern = attn_bwd_mfma_kernel;
     DSVG_ENSURE_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (seq_off ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (total_rows > 0 ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
                        (const bf16_t*)qkv, key_mask, seq_off, (long long)total_rows, (const bf16_t*)dout, (bf16_t*)dqkv, S,
                        n_heads, scale, drop_p, drop_site, seed);
     DSVG_LAUNCH_CHECK("attention_bwd_mfma");

@@ -73,6 +73,93 @@ extern "C" int dsvg_group_index(const float* commands, int64_t n_seq, int32_t S,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Visible-first ordering of the second decoder stage.  The sequences of that stage are independent (one per group,
+// model.py:250-262) and the loss excludes every position of an invisible target group (loss.py:36,51-54), so the
+// backward pass of an invisible group's sequence is identically zero: with the visible sequences first, backward runs
+// on a row prefix only.  new_of_old[b] = position of sequence b in the new order (stable partition), old_of_new = its
+// inverse, *n_visible = number of visible sequences.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void visible_first_kernel(const int32_t* __restrict__ visible, long long n,
+                                                             int32_t* __restrict__ new_of_old,
+                                                             int32_t* __restrict__ old_of_new,
+                                                             int32_t* __restrict__ n_visible) {
+    __shared__ int part[1024];
+    __shared__ int carry, total;
+    // pass 0 counts the visible sequences, pass 1 assigns positions
+    for (int pass = 0; pass < 2; ++pass) {
+        if (threadIdx.x == 0) carry = 0;
+        __syncthreads();
+        for (long long base = 0; base < n; base += 1024) {
+            const long long b = base + threadIdx.x;
+            const int v = (b < n && visible[b]) ? 1 : 0;
+            part[threadIdx.x] = v;
+            __syncthreads();
+            for (int o = 1; o < 1024; o <<= 1) {
+                const int t = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+                __syncthreads();
+                part[threadIdx.x] += t;
+                __syncthreads();
+            }
+            if (pass == 1 && b < n) {
+                const int vis_before = carry + part[threadIdx.x] - v;
+                const int pos = v ? vis_before : total + (int)(b - vis_before);
+                new_of_old[b] = pos;
+                old_of_new[pos] = (int)b;
+            }
+            __syncthreads();
+            if (threadIdx.x == 1023) carry += part[1023];
+            __syncthreads();
+        }
+        if (pass == 0) {
+            if (threadIdx.x == 0) { total = carry; *n_visible = carry; }
+            __syncthreads();
+        }
+    }
+}
+extern "C" int dsvg_visible_first(const int32_t* visible, int64_t n, int32_t* new_of_old, int32_t* old_of_new,
+                                  int32_t* n_visible, void* stream) {
+    DSVG_CHECK_ARG(visible && new_of_old && old_of_new && n_visible && n > 0, "visible_first: bad args");
+    hipLaunchKernelGGL(visible_first_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, visible, (long long)n,
+                       new_of_old, old_of_new, n_visible);
+    DSVG_LAUNCH_CHECK("visible_first");
+    return 0;
+}
+
+// dst[g * S + s, :] = src[idx[g] * S + s, :] for g < n_groups  (whole-sequence row gather; 16-byte pieces)
+template <typename T>
+__global__ void gather_groups_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx, T* __restrict__ dst,
+                                     long long n_groups, int S, int width) {
+    typedef typename Elem<T>::raw4 raw4;
+    const int cpr = width / 4;
+    const long long total = n_groups * S * cpr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / cpr;
+        const int c = (int)(i - row * cpr);
+        const long long g = row / S;
+        const int sidx = (int)(row - g * S);
+        reinterpret_cast<raw4*>(dst + row * width)[c] =
+            reinterpret_cast<const raw4*>(src + ((long long)idx[g] * S + sidx) * width)[c];
+    }
+}
+extern "C" int dsvg_gather_groups(int32_t dtype, const void* src, const int32_t* idx, void* dst, int64_t n_groups,
+                                  int32_t S, int32_t width, void* stream) {
+    DSVG_CHECK_ARG(src && idx && dst && n_groups > 0 && S > 0 && width > 0 && (width % 4) == 0, "gather_groups: bad args");
+    const long long total = n_groups * S * (long long)(width / 4);
+    const int nb = (int)min((long long)dsvg_cdiv(total, 256), 8192LL);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(gather_groups_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)src, idx, (float*)dst,
+                           (long long)n_groups, S, width);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(gather_groups_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)src, idx,
+                           (bf16_t*)dst, (long long)n_groups, S, width);
+    else { dsvg_set_error("gather_groups: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("gather_groups");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Packed (variable-length) token layout for the first encoder stage.  Only keys are masked there
 // (layers/functional.py:234-239) and padded query rows are dropped by the masked mean-pool (model.py:137), so rows
 // past a sequence's first EOS influence neither an output nor a gradient: the encoder runs on the valid tokens only.
@@ -211,8 +298,10 @@ extern "C" int dsvg_embed_gather(int32_t dtype, const float* commands, const flo
 // global atomics.  (LDS float atomics make the sum order inside one workgroup schedule-dependent, i.e.
 // reproducible to ~1e-7 relative, not bitwise.)
 // ---------------------------------------------------------------------------------------------
-constexpr int ES_TOK_PER_BLOCK = 256;
+constexpr int ES_TOK_PER_BLOCK = 64;
 
+// token-outer / column-inner loops: no 64-bit divisions in the hot loop; 64 tokens per workgroup so that even the
+// packed encoder (~40k tokens at 512 icons) fills the chip
 template <typename T>
 __global__ __launch_bounds__(256) void embed_scatter_arg_kernel(const float* __restrict__ args, const T* __restrict__ dA,
                                                                 float* __restrict__ part, long long T_tok, int n_args,
@@ -224,17 +313,17 @@ __global__ __launch_bounds__(256) void embed_scatter_arg_kernel(const float* __r
     const long long t0 = (long long)blockIdx.x * ES_TOK_PER_BLOCK;
     const long long t1 = min(T_tok, t0 + ES_TOK_PER_BLOCK);
     const int width = n_args * E;
-    const long long i0 = t0 * width, i1 = t1 * width;
-#pragma unroll 4
-    for (long long idx = i0 + threadIdx.x; idx < i1; idx += 256) {
-        const float g = Elem<T>::ld(dA + idx);
-        if (g != 0.f) {
-            const long long t = idx / width;
-            const int c = (int)(idx - t * width);
-            const int a = c / E, e = c - a * E;
-            int iv = (int)args[t * n_args + a] + 1;
-            iv = min(max(iv, 0), n_argvals - 1);
-            atomicAdd(&acc[iv * E + e], g);
+    for (long long t = t0; t < t1; ++t) {
+        const T* row = dA + t * width;
+        const float* arow = args + t * n_args;
+        for (int c = threadIdx.x; c < width; c += 256) {
+            const float g = Elem<T>::ld(row + c);
+            if (g != 0.f) {
+                const int a = c / E, e = c - a * E;
+                int iv = (int)arow[a] + 1;
+                iv = min(max(iv, 0), n_argvals - 1);
+                atomicAdd(&acc[iv * E + e], g);
+            }
         }
     }
     __syncthreads();
@@ -255,17 +344,16 @@ __global__ __launch_bounds__(256) void embed_scatter_row_kernel(const float* __r
     __syncthreads();
     const long long t0 = (long long)blockIdx.x * ES_TOK_PER_BLOCK;
     const long long t1 = min(T_tok, t0 + ES_TOK_PER_BLOCK);
-    const long long i0 = t0 * d, i1 = t1 * d;
-#pragma unroll 4
-    for (long long idx = i0 + threadIdx.x; idx < i1; idx += 256) {
-        const float g = Elem<T>::ld(dR + idx);
-        if (g != 0.f) {
-            const long long t = idx / d;
-            const int c = (int)(idx - t * d);
-            int ic = (int)commands[t];
-            ic = min(max(ic, 0), n_cmd - 1);
-            atomicAdd(&acc_c[ic * d + c], g);
-            if (part_grp) atomicAdd(&acc_g[groups[t] * d + c], g);
+    for (long long t = t0; t < t1; ++t) {
+        int ic = (int)commands[t];
+        ic = min(max(ic, 0), n_cmd - 1);
+        const int ig = part_grp ? groups[t] : 0;
+        for (int c = threadIdx.x; c < d; c += 256) {
+            const float g = Elem<T>::ld(dR + t * d + c);
+            if (g != 0.f) {     // column c of every table row belongs to this thread alone: plain read-modify-write
+                acc_c[ic * d + c] += g;
+                if (part_grp) acc_g[ig * d + c] += g;
+            }
         }
     }
     __syncthreads();

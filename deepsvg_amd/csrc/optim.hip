@@ -105,11 +105,30 @@ __global__ void cast_weights_kernel(const float* __restrict__ src, T* __restrict
     }
 }
 
+// flat fp32 -> bf16 image of the whole parameter buffer: 8 elements per thread, 16-byte stores
+__global__ __launch_bounds__(256) void cast_flat_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             long long n8) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * i];
+        const float4 b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        reinterpret_cast<uint4*>(dst)[i] =
+            make_uint4(f2bf_pk(a.x, a.y), f2bf_pk(a.z, a.w), f2bf_pk(b.x, b.y), f2bf_pk(b.z, b.w));
+    }
+}
+
 extern "C" int dsvg_cast_weights(int32_t dtype, const float* src, void* dst, void* dst_t, int64_t rows, int64_t cols,
                                  void* stream) {
     DSVG_CHECK_ARG(src && (dst || dst_t) && rows > 0 && cols > 0, "cast_weights: bad args");
-    dim3 grid(dsvg_cdiv(cols, 32), dsvg_cdiv(rows, 32));
     hipStream_t st = (hipStream_t)stream;
+    const long long n = rows * cols;
+    if (dtype == DSVG_BF16 && !dst_t && !(n & 7) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15)) {
+        const long long n8 = n / 8;
+        const int nb = (int)min((long long)dsvg_cdiv(n8, 256), 2048LL);
+        hipLaunchKernelGGL(cast_flat_bf16_kernel, dim3(nb), dim3(256), 0, st, src, (bf16_t*)dst, n8);
+        DSVG_LAUNCH_CHECK("cast_weights(flat)");
+        return 0;
+    }
+    dim3 grid(dsvg_cdiv(cols, 32), dsvg_cdiv(rows, 32));
     if (dtype == DSVG_F32)
         hipLaunchKernelGGL(cast_weights_kernel<float>, grid, dim3(256), 0, st, src, (float*)dst, (float*)dst_t,
                            (long long)rows, (long long)cols);

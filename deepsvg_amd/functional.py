@@ -165,11 +165,19 @@ class ResBlockFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------------
+def _live_rows(live, full_rows):
+    """`live` = (n_live_sequences, n_live_rows) or None: backward only has to cover that row prefix (the rest of every
+    incoming gradient is known to be zero and the rest of every returned gradient is never read)."""
+    if live is None or live[1] >= full_rows:
+        return None
+    return live
+
+
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rt, x, gamma, beta, eps):
+    def forward(ctx, rt, x, gamma, beta, eps, live=None):
         y, mean, rstd = ops.layernorm_fwd(x, gamma.detach(), beta.detach(), eps)
-        ctx.rt = rt
+        ctx.rt, ctx.live = rt, _live_rows(live, x.shape[0])
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         return y
 
@@ -177,9 +185,16 @@ class LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         rt = ctx.rt
         x, mean, rstd, gamma, beta = ctx.saved_tensors
-        dx, dg, db = ops.layernorm_bwd(dy.contiguous(), x, mean, rstd, gamma.detach(),
-                                       dgamma=rt.grad_out(gamma), dbeta=rt.grad_out(beta))
-        return None, dx, dg, db, None
+        dy = dy.contiguous()
+        if ctx.live is None:
+            dx, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, gamma.detach(),
+                                           dgamma=rt.grad_out(gamma), dbeta=rt.grad_out(beta))
+        else:
+            R = ctx.live[1]
+            dx = torch.empty_like(x)
+            _, dg, db = ops.layernorm_bwd(dy[:R], x[:R], mean[:R], rstd[:R], gamma.detach(), dx=dx[:R],
+                                          dgamma=rt.grad_out(gamma), dbeta=rt.grad_out(beta))
+        return None, dx, dg, db, None, None
 
 
 # --------------------------------------------------------------------------------------------------
@@ -187,11 +202,14 @@ class AddPosFn(torch.autograd.Function):
     """y = drop(x + pos[:S]) with x optional (ConstEmbedding feeds zeros)."""
 
     @staticmethod
-    def forward(ctx, rt, x, pos_weight, n_seq, S, drop_rate, site):
+    def forward(ctx, rt, x, pos_weight, n_seq, S, drop_rate, site, live=None):
         p = rt.p(drop_rate)
         y = ops.add_pos_fwd(x, pos_weight.detach(), n_seq, S, rt.dtype, p, site, rt.seed)
         ctx.rt, ctx.n_seq, ctx.S, ctx.p, ctx.site = rt, n_seq, S, p, site
         ctx.has_x = x is not None
+        if _live_rows(live, n_seq * S) is not None:
+            assert x is None, "live-prefix backward is only wired for the constant embedding"
+            ctx.n_seq = live[0]
         ctx.save_for_backward(pos_weight)
         return y
 
@@ -202,9 +220,10 @@ class AddPosFn(torch.autograd.Function):
         dpos = rt.grad_out(pos_weight)
         if pos_weight.shape[0] > ctx.S:
             dpos[ctx.S:].zero_()
-        dx = ops.add_pos_bwd(dy.contiguous(), ctx.n_seq, ctx.S, dpos[:ctx.S], want_dx=ctx.has_x, drop_p=ctx.p,
+        dy = dy.contiguous()[:ctx.n_seq * ctx.S]
+        dx = ops.add_pos_bwd(dy, ctx.n_seq, ctx.S, dpos[:ctx.S], want_dx=ctx.has_x, drop_p=ctx.p,
                              drop_site=ctx.site, seed=rt.seed)
-        return None, dx, dpos, None, None, None, None
+        return None, dx, dpos, None, None, None, None, None
 
 
 class MaskedMeanFn(torch.autograd.Function):
@@ -258,6 +277,29 @@ class EmbedFn(torch.autograd.Function):
         return (None, None, None, None, None, None, None, None, d_cmd, d_arg, dw, db, dpos, d_grp)
 
 
+class GatherGroupsFn(torch.autograd.Function):
+    """y[g*S + s] = x[idx[g]*S + s] (whole sequences); inv = inverse permutation.  With `live` = (n_live, rows): the
+    upstream gradient of the sequences inv[g >= n_live] is known to be zero, so backward gathers only the sequences
+    that cover the first `rows` rows (the exact zeros included) and leaves the rest of dx unwritten (never read)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, inv, n_groups, S, live=None):
+        ctx.n_groups, ctx.S, ctx.live = n_groups, S, _live_rows(live, n_groups * S)
+        ctx.save_for_backward(inv)
+        return ops.gather_groups(x.contiguous(), idx, n_groups, S)
+
+    @staticmethod
+    def backward(ctx, dy):
+        inv, = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.live is None:
+            return ops.gather_groups(dy, inv, ctx.n_groups, ctx.S), None, None, None, None, None
+        n_cover = min(ctx.n_groups, -(-ctx.live[1] // ctx.S))
+        dx = torch.empty_like(dy)
+        ops.gather_groups(dy, inv, n_cover, ctx.S, out=dx)
+        return dx, None, None, None, None, None
+
+
 class PackedEmbedFn(torch.autograd.Function):
     """SVGEmbedding on the packed token layout of the first encoder stage (ops.pack_tokens):
          src[r] = drop( embed_fcn(arg_embed[args_r + 1]) + command_embed[cmd_r] + pos[pos_r] )
@@ -301,7 +343,7 @@ class LayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rt, x, key_mask, z, l, n_seq, S, n_heads, drop_rate, site0,
-                n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off=None):
+                n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off=None, live=None):
         p = rt.p(drop_rate)
         d = x.shape[1]
         scale = float(d // n_heads) ** -0.5
@@ -321,6 +363,8 @@ class LayerFn(torch.autograd.Function):
             x2 = ops.gemm(h, rt.w(w2), bias=b2.detach(), res=x1, drop_p=p, drop_site=site0 + 4, seed=rt.seed)
         ctx.rt, ctx.n_seq, ctx.S, ctx.n_heads, ctx.p, ctx.site0, ctx.scale = rt, n_seq, S, n_heads, p, site0, scale
         assert seq_off is None or (z is None and l is None), "packed layout: no per-sequence conditioning adds"
+        ctx.live = _live_rows(live, x.shape[0])
+        assert ctx.live is None or (seq_off is None and key_mask is None and l is None)
         ctx.save_for_backward(x, key_mask, z, l, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h,
                               n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off)
         return x2
@@ -331,6 +375,11 @@ class LayerFn(torch.autograd.Function):
         (x, key_mask, z, l, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h,
          n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off) = ctx.saved_tensors
         dx2 = dx2.contiguous()
+        full_rows, n_seq_full = x.shape[0], n_seq
+        if ctx.live is not None:        # backward over the live row prefix only (visible-first decoder order)
+            n_seq, R = ctx.live
+            (dx2, x, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h) = (
+                t[:R] for t in (dx2, x, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h))
         inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
         # ---- FFN: x2 = x1 + drop4(h W2^T + b2),  h = drop3(relu(xn2 W1^T + b1)) ----
         # the mask of the residual dropout is replayed ONCE into dx2m; the three consumers read plain data
@@ -351,7 +400,9 @@ class LayerFn(torch.autograd.Function):
             if ctx.needs_input_grad[4]:
                 dl = ops.gemm(dg2, rt.w(wg2), b_kc=False)
         if z is not None:
-            dg = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed)
+            dg = ops.bcast_add_bwd(dx1[:n_seq * S], n_seq, S, p, s0 + 2, rt.seed)
+            if n_seq < n_seq_full:      # sequences past the live prefix: zero gradient
+                dg = torch.cat([dg, dg.new_zeros((n_seq_full - n_seq, dg.shape[1]))])
             dwg, dbg = _wbgrad(rt, wg, bg, dg, z)
             if ctx.needs_input_grad[3]:
                 dz = ops.gemm(dg, rt.w(wg), b_kc=False)
@@ -363,10 +414,16 @@ class LayerFn(torch.autograd.Function):
         dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed, seq_off=seq_off)
         dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1)
         dxn1 = ops.gemm(dqkv, rt.w(win), b_kc=False)
-        dx, dn1w, dn1b = ops.layernorm_bwd(dxn1, x, mean1, rstd1, n1w.detach(), res=dx1,
+        dx_out = None
+        if ctx.live is not None:
+            dx_full = torch.empty((full_rows, x.shape[1]), dtype=x.dtype, device=x.device)
+            dx_out = dx_full[:x.shape[0]]
+        dx, dn1w, dn1b = ops.layernorm_bwd(dxn1, x, mean1, rstd1, n1w.detach(), res=dx1, dx=dx_out,
                                            dgamma=rt.grad_out(n1w), dbeta=rt.grad_out(n1b))
+        if ctx.live is not None:
+            dx = dx_full
         return (None, dx, None, dz, dl, None, None, None, None, None,
-                dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, dwg2, dbg2, None)
+                dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, dwg2, dbg2, None, None)
 
 
 # --------------------------------------------------------------------------------------------------

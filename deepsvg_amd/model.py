@@ -310,6 +310,9 @@ class SVGTransformer(nn.Module):
         # first encoder stage on the valid tokens only (exact); DSVG_PACK_ENCODER=0 -> padded layout
         self.pack_encoder = os.environ.get("DSVG_PACK_ENCODER", "1") != "0"
         self.last_packing = None
+        # backward of the second decoder stage only over the sequences of visible target groups (exact under SVGLoss)
+        self.skip_invisible_backward = os.environ.get("DSVG_SKIP_INVISIBLE", "1") != "0"
+        self.last_live = None
 
     # ---- runtime plumbing ------------------------------------------------------------------------
     def set_compute_dtype(self, dtype):
@@ -335,7 +338,7 @@ class SVGTransformer(nn.Module):
         return Fn.Runtime(self.compute_dtype, seed, self._store, training)
 
     # ---- blocks ----------------------------------------------------------------------------------
-    def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site, seq_off=None):
+    def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site, seq_off=None, live=None):
         cfg = self.cfg
         for i, L in enumerate(stack.layers):
             has_g = hasattr(L, "linear_global")
@@ -345,19 +348,58 @@ class SVGTransformer(nn.Module):
                 L.self_attn.out_proj.weight, L.self_attn.out_proj.bias, L.norm2.weight, L.norm2.bias,
                 L.linear1.weight, L.linear1.bias, L.linear2.weight, L.linear2.bias,
                 L.linear_global.weight if has_g else None, L.linear_global.bias if has_g else None, None, None,
-                seq_off)
-        return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps)
+                seq_off, live)
+        return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps, live)
 
-    def _encode_stage1_packed(self, rt, cmd, arg, key_mask, n_seq, S):
+    def _plan(self, commands_enc, args_enc, commands_dec, want_grad):
+        """Data-dependent layout decisions of one forward, made up front with ONE device->host read:
+          * packed first encoder stage (valid tokens only), see _encode_stage1_packed;
+          * visible-first order of the second decoder stage: SVGLoss excludes every position of an invisible target
+            group (loss.py:36,51-54) and the stage-2 sequences are independent, so the backward pass of those
+            sequences is identically zero and only a row prefix has to be processed.  Only used
+            when the targets are known (training call with commands_dec) - gradients are those of SVGLoss.
+        Both are disabled while a hipGraph is being captured (shapes must be static there)."""
+        cfg = self.cfg
+        plan = {"enc": None, "dec": None}
+        ref = commands_enc if commands_enc is not None else commands_dec
+        if ref is None or (ref.is_cuda and torch.cuda.is_current_stream_capturing()):
+            return plan
+        counts = []
+        if (commands_enc is not None and self.pack_encoder and cfg.encode_stages > 0
+                and not self.encoder.use_group):
+            N, G, S = commands_enc.shape
+            cmd = commands_enc.to(torch.float32).contiguous().view(N * G, S)
+            arg = args_enc.to(torch.float32).contiguous().view(N * G * S, -1)
+            key_mask, _vis, group_mask = ops.build_masks(cmd, S, G, EOS_ID, want_group_mask=cfg.encode_stages == 2)
+            seq_off, pcmd, parg, ppos = ops.pack_tokens(cmd.view(-1), arg, key_mask, N * G, S)
+            plan["enc"] = dict(key_mask=key_mask, group_mask=group_mask, seq_off=seq_off, pcmd=pcmd, parg=parg, ppos=ppos)
+            counts.append(seq_off[-1:])
+        if (commands_dec is not None and want_grad and self.skip_invisible_backward and cfg.decode_stages == 2
+                and commands_dec.shape[1] == cfg.num_groups_proposal):
+            N, G, St = commands_dec.shape
+            cmd_t = commands_dec.to(torch.float32).contiguous().view(N * G, St)
+            _km, vis, _gm = ops.build_masks(cmd_t, St, G, EOS_ID)
+            new_of_old, old_of_new, nvis = ops.visible_first(vis)
+            plan["dec"] = dict(new_of_old=new_of_old, old_of_new=old_of_new)
+            counts.append(nvis)
+        if counts:
+            vals = (torch.cat(counts) if len(counts) > 1 else counts[0]).tolist()      # the one host read
+            if plan["enc"] is not None:
+                plan["enc"]["total"] = int(vals.pop(0))
+            if plan["dec"] is not None:
+                plan["dec"]["n_visible"] = int(vals.pop(0))
+        return plan
+
+
+    def _encode_stage1_packed(self, rt, pe, n_seq, S):
         """First encoder stage on the valid tokens only: rows past a sequence's first EOS are
         masked as keys (layers/functional.py:234-239) and dropped by the mean-pool (model.py:137), so they reach
         neither an output nor a gradient.  Tokens are packed back to back; the row count is rounded up to a
-        multiple of 128 with inert rows (finite activations, exactly-zero gradients).  One device->host read of
-        the token count per forward (the reference's own loss syncs the same way, loss.py:53-54)."""
+        multiple of 128 with inert rows (finite activations, exactly-zero gradients).  The token count comes from
+        the forward's single device->host read (_plan; the reference's own loss syncs too, loss.py:53-54)."""
         enc = self.encoder
         emb = enc.embedding
-        seq_off, pcmd, parg, ppos = ops.pack_tokens(cmd.view(-1), arg, key_mask, n_seq, S)
-        total = int(seq_off[-1].item())
+        seq_off, pcmd, parg, ppos, total = pe["seq_off"], pe["pcmd"], pe["parg"], pe["ppos"], pe["total"]
         rows = min((total + 127) // 128 * 128, n_seq * S)
         self.last_packing = (total, n_seq * S)      # valid tokens, dense tokens (reported by bench.py)
         src = Fn.PackedEmbedFn.apply(rt, pcmd[:rows], parg[:rows], ppos[:rows], S, PE_DROPOUT, 1,
@@ -366,20 +408,21 @@ class SVGTransformer(nn.Module):
         mem = self._run_stack(rt, enc.encoder, src, None, None, n_seq, S, 100, seq_off=seq_off)
         return Fn.MaskedMeanFn.apply(rt, mem, None, n_seq, S, seq_off)
 
-    def _encode(self, rt, commands, args):
+    def _encode(self, rt, commands, args, plan=None):
         """commands (N, G, S) / args (N, G, S, n_args) float32, batch-first  ->  z [N, d_model]"""
         cfg = self.cfg
         enc = self.encoder
         N, G, S = commands.shape
-        cmd = commands.to(torch.float32).contiguous().view(N * G, S)
-        arg = args.to(torch.float32).contiguous().view(N * G * S, -1)
         two = cfg.encode_stages == 2
-        key_mask, _vis, group_mask = ops.build_masks(cmd, S, G, EOS_ID, want_group_mask=two)
         emb = enc.embedding
-        capturing = cmd.is_cuda and torch.cuda.is_current_stream_capturing()
-        if self.pack_encoder and not enc.use_group and not capturing:
-            z = self._encode_stage1_packed(rt, cmd, arg, key_mask, N * G, S)
+        pe = plan["enc"] if plan is not None else None
+        if pe is not None:
+            group_mask = pe["group_mask"]
+            z = self._encode_stage1_packed(rt, pe, N * G, S)
         else:
+            cmd = commands.to(torch.float32).contiguous().view(N * G, S)
+            arg = args.to(torch.float32).contiguous().view(N * G * S, -1)
+            key_mask, _vis, group_mask = ops.build_masks(cmd, S, G, EOS_ID, want_group_mask=two)
             self.last_packing = None
             groups = ops.group_index(cmd, S, M_ID) if enc.use_group else None
             src = Fn.EmbedFn.apply(rt, cmd.view(-1), arg, groups, N * G, S, PE_DROPOUT, 1,
@@ -414,7 +457,7 @@ class SVGTransformer(nn.Module):
                                   0.0, 0, None)
         return z, mu, logsigma
 
-    def _decode(self, rt, z):
+    def _decode(self, rt, z, plan=None):
         """z [N, dim_z] -> command_logits (N,G,S,n_cmd), args_logits (N,G,S,n_args,args_dim)[, visibility (N,G,1,2)]"""
         cfg = self.cfg
         dec = self.decoder
@@ -433,8 +476,18 @@ class SVGTransformer(nn.Module):
             G = 1
             n_seq = N
         S = dec.embedding.seq_len
-        src = Fn.AddPosFn.apply(rt, None, dec.embedding.PE.pos_embed.weight, n_seq, S, PE_DROPOUT, 4)
-        out = self._run_stack(rt, dec.decoder, src, None, z, n_seq, S, 400)
+        pd = plan["dec"] if (plan is not None and cfg.decode_stages == 2) else None
+        live = None
+        if pd is not None and pd["n_visible"] < n_seq:
+            # visible-first order: sequence `new` of the stage is group old_of_new[new]; backward covers the prefix
+            nv = pd["n_visible"]
+            live = (nv, min((nv * S + 127) // 128 * 128, n_seq * S))
+            z = Fn.GatherGroupsFn.apply(z, pd["old_of_new"], pd["new_of_old"], n_seq, 1, None)
+        self.last_live = (live[0], n_seq) if live is not None else None
+        src = Fn.AddPosFn.apply(rt, None, dec.embedding.PE.pos_embed.weight, n_seq, S, PE_DROPOUT, 4, live)
+        out = self._run_stack(rt, dec.decoder, src, None, z, n_seq, S, 400, live=live)
+        if live is not None:        # back to the caller's group order before the heads
+            out = Fn.GatherGroupsFn.apply(out, pd["new_of_old"], pd["old_of_new"], n_seq, S, live)
         cmd_logits = Fn.LinearFn.apply(rt, out, dec.fcn.command_fcn.weight, dec.fcn.command_fcn.bias, 0, None, 0.0, 0,
                                        None)
         args_logits = Fn.LinearFn.apply(rt, out, dec.fcn.args_fcn.weight, dec.fcn.args_fcn.bias, 0, None, 0.0, 0, None)
@@ -455,15 +508,17 @@ class SVGTransformer(nn.Module):
         ops.require_device(device)
         rt = self._runtime(device)
         mu = logsigma = None
+        plan = self._plan(commands_enc if z is None else None, args_enc, commands_dec if return_tgt else None,
+                          torch.is_grad_enabled() and not encode_mode)
         if z is None:
-            zz = self._encode(rt, commands_enc, args_enc)
+            zz = self._encode(rt, commands_enc, args_enc, plan)
             zz, mu, logsigma = self._bottleneck(rt, zz)
         else:
             # externally supplied z is batch-first (N, 1, 1, dim_z)  (model.py:369)
             zz = z.reshape(z.shape[0], -1).to(rt.dtype).contiguous()
         if encode_mode:
             return zz.to(torch.float32).view(1, 1, zz.shape[0], zz.shape[1])   # seq-first, as model.py:371
-        cmd_logits, args_logits, vis_logits = self._decode(rt, zz)
+        cmd_logits, args_logits, vis_logits = self._decode(rt, zz, plan)
         res = {"command_logits": cmd_logits, "args_logits": args_logits}
         if cfg.decode_stages == 2:
             res["visibility_logits"] = vis_logits

@@ -214,7 +214,7 @@ def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site
     _chk(qkv, key_mask, seed, seq_off)
     rows = qkv.shape[0]
     assert qkv.is_contiguous() and qkv.shape[1] == 3 * 32 * n_heads, "attention needs head_dim == 32"
-    assert (rows == n_seq * S) if seq_off is None else (key_mask is None and seq_off.numel() == n_seq + 1)
+    assert (rows >= n_seq * S) if seq_off is None else (key_mask is None and seq_off.numel() == n_seq + 1)
     out = torch.empty((rows, 32 * n_heads), dtype=qkv.dtype, device=qkv.device)
     _l.check(_l.load().dsvg_attention_fwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), _p(seq_off), rows, out.data_ptr(),
                                           n_seq, S, n_heads, float(scale), float(drop_p), int(drop_site),
@@ -343,6 +343,31 @@ def masked_mean_bwd(dout, mask, n_seq, S, seq_off=None, total_rows=None):
     _l.check(_l.load().dsvg_masked_mean_bwd(_dt(dout), dout.data_ptr(), _p(mask), _p(seq_off), rows, dx.data_ptr(),
                                             n_seq, S, d, _stream()), "dsvg_masked_mean_bwd")
     return dx
+
+
+def visible_first(visible):
+    """visible int32 [n] -> (new_of_old int32 [n], old_of_new int32 [n], n_visible int32 [1]); include/dsvg.h"""
+    _chk(visible)
+    assert visible.dtype == torch.int32 and visible.is_contiguous()
+    n = visible.numel()
+    new_of_old = torch.empty(n, dtype=torch.int32, device=visible.device)
+    old_of_new = torch.empty(n, dtype=torch.int32, device=visible.device)
+    nvis = torch.empty(1, dtype=torch.int32, device=visible.device)
+    _l.check(_l.load().dsvg_visible_first(visible.data_ptr(), n, new_of_old.data_ptr(), old_of_new.data_ptr(),
+                                          nvis.data_ptr(), _stream()), "dsvg_visible_first")
+    return new_of_old, old_of_new, nvis
+
+
+def gather_groups(src, idx, n_groups, S, out=None):
+    """out[g*S + s] = src[idx[g]*S + s] for g < n_groups (rows past n_groups*S of `out` are left untouched)"""
+    _chk(src, idx, out)
+    assert src.is_contiguous() and idx.dtype == torch.int32 and src.dim() == 2
+    if out is None:
+        out = torch.empty((n_groups * S, src.shape[1]), dtype=src.dtype, device=src.device)
+    assert out.is_contiguous() and out.shape[0] >= n_groups * S and out.shape[1] == src.shape[1] and out.dtype == src.dtype
+    _l.check(_l.load().dsvg_gather_groups(_dt(src), src.data_ptr(), idx.data_ptr(), out.data_ptr(), n_groups, S,
+                                          src.shape[1], _stream()), "dsvg_gather_groups")
+    return out
 
 
 def pack_tokens(commands, args, key_mask, n_seq, S):

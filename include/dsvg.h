@@ -106,6 +106,8 @@ int64_t dsvg_layernorm_bwd_workspace_bytes(int64_t rows, int32_t d);
  * softmax, dropout, bmm, head merge).  bwd recomputes the probabilities (no S×S tensor in HBM).
  * Packed layout (seq_off != NULL, key_mask == NULL): sequence b owns rows seq_off[b]..seq_off[b+1]-1
  * (at most S of them, all visible); rows seq_off[n_seq]..total_rows-1 of out / dqkv are zero-filled.
+ * Dense layout with total_rows > n_seq*S: rows n_seq*S..total_rows-1 of out / dqkv are zero-filled
+ * (backward over a row prefix, see dsvg_visible_first); total_rows == 0: no tail.
  * ------------------------------------------------------------------------------------------ */
 int dsvg_attention_fwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const int32_t* seq_off,
                        int64_t total_rows, void* out, int64_t n_seq, int32_t S, int32_t n_heads,
@@ -145,6 +147,15 @@ int64_t dsvg_embed_scatter_workspace_bytes(int64_t T, int32_t n_args, int32_t E,
 /* group index per token: groups[b*S+s] = #{ s' <= s : commands[b,s'] == m_id }  (utils.py:35-42) */
 int dsvg_group_index(const float* commands, int64_t n_seq, int32_t S, int32_t m_id, int32_t* groups,
                      void* stream);
+/* Visible-first order of the second decoder stage: its sequences are independent (one per group,
+ * model/model.py:250-262) and SVGLoss excludes every position of an invisible target group (loss.py:36,51-54),
+ * so those sequences have an identically zero backward pass; with the visible sequences first the backward
+ * kernels run on a row prefix.  new_of_old / old_of_new: stable partition and its inverse. */
+int dsvg_visible_first(const int32_t* visible, int64_t n, int32_t* new_of_old, int32_t* old_of_new,
+                       int32_t* n_visible, void* stream);
+/* dst[g*S + s, :] = src[idx[g]*S + s, :], g < n_groups: whole-sequence row gather (width % 4 == 0) */
+int dsvg_gather_groups(int32_t dtype, const void* src, const int32_t* idx, void* dst, int64_t n_groups,
+                       int32_t S, int32_t width, void* stream);
 /* Packed token layout of the first encoder stage: only keys are masked there (layers/functional.py:234-239)
  * and padded query rows are dropped by the mean-pool (model/model.py:137), so the encoder can run on the
  * valid tokens only, bit-for-bit safe.  seq_off[b] = exclusive scan of popcount(key_mask) (n_seq+1 entries,

@@ -292,6 +292,35 @@ def test_attention_packed_layout(gpu_device, dtype, S, n_seq):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_backward_over_a_sequence_prefix(gpu_device, dtype):
+    """dense layout, n_seq sequences followed by rows that must come back as zeros (visible-first decoder order)"""
+    H_, d, S, n_seq, rows = 8, 256, 31, 37, 1280
+    qkv, do = _rand(rows, 3 * d, dtype=dtype, seed=70), _rand(rows, d, dtype=dtype, seed=71)
+    dq = ops.attention_bwd(qkv, None, do, n_seq, S, H_, 32 ** -0.5)
+    ref = R.attention_bwd(qkv, None, do, n_seq, S, H_, 32 ** -0.5)
+    _close(dq, ref, 5e-5 if dtype == torch.float32 else 3e-2, "prefix attention bwd")
+    assert torch.count_nonzero(dq[n_seq * S:]) == 0
+    out = ops.attention_fwd(qkv, None, n_seq, S, H_, 32 ** -0.5)
+    _close(out, R.attention_fwd(qkv, None, n_seq, S, H_, 32 ** -0.5), 2e-5 if dtype == torch.float32 else 2e-2, "fwd")
+    assert torch.count_nonzero(out[n_seq * S:]) == 0
+
+
+def test_visible_first_and_gather_groups(gpu_device):
+    g = torch.Generator().manual_seed(9)
+    for n in (5, 1024, 4099):
+        vis = (torch.rand(n, generator=g) < 0.56).to(torch.int32).to(DEV)
+        got = ops.visible_first(vis)
+        exp = R.visible_first(vis)
+        for a, b, what in zip(got, exp, ("new_of_old", "old_of_new", "n_visible")):
+            assert torch.equal(a, b), f"visible_first {what} n={n}"
+        for dtype in DTYPES:
+            x = _rand(n * 3, 64, dtype=dtype, seed=n)
+            y = ops.gather_groups(x, got[1], n, 3)
+            assert torch.equal(y, R.gather_groups(x, got[1], n, 3))
+            assert torch.equal(ops.gather_groups(y, got[0], n, 3), x)       # the inverse permutation restores x
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_pack_tokens_and_packed_mean(gpu_device, dtype):
     n, G, S = 6, 8, 32
     cmd, arg = _cmd_args(n, G, S - 2, seed=3)

@@ -209,6 +209,9 @@ def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site
         dense, idx, lens = _unpack_rows(qkv, seq_off, n_seq, S)
         o = attention_fwd(dense, _len_mask(lens), n_seq, S, n_heads, scale, drop_p, drop_site, seed)
         return _repack_rows(o, idx, qkv.shape[0])
+    if qkv.shape[0] > n_seq * S:        # dense layout, rows past the last sequence are zero-filled
+        o = attention_fwd(qkv[:n_seq * S], key_mask, n_seq, S, n_heads, scale, drop_p, drop_site, seed)
+        return torch.cat([o, torch.zeros((qkv.shape[0] - n_seq * S, o.shape[1]), dtype=o.dtype, device=o.device)])
     H = n_heads
     q, k, v, P = _attn_probs(qkv, key_mask, n_seq, S, H, scale)
     Pd = P * _attn_drop(drop_p, seed, drop_site, n_seq, S, H, qkv.device)
@@ -222,6 +225,9 @@ def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, dro
         ddense, _, _ = _unpack_rows(dout, seq_off, n_seq, S)
         g = attention_bwd(dense, _len_mask(lens), ddense, n_seq, S, n_heads, scale, drop_p, drop_site, seed)
         return _repack_rows(g, idx, qkv.shape[0])
+    if qkv.shape[0] > n_seq * S:
+        g = attention_bwd(qkv[:n_seq * S], key_mask, dout[:n_seq * S], n_seq, S, n_heads, scale, drop_p, drop_site, seed)
+        return torch.cat([g, torch.zeros((qkv.shape[0] - n_seq * S, g.shape[1]), dtype=g.dtype, device=g.device)])
     H = n_heads
     q, k, v, P = _attn_probs(qkv, key_mask, n_seq, S, H, scale)
     mult = _attn_drop(drop_p, seed, drop_site, n_seq, S, H, qkv.device)
@@ -253,6 +259,24 @@ def build_masks(commands, S, G=0, eos_id=4, want_group_mask=False):
 
 def group_index(commands, S, m_id=0):
     return (commands.view(-1, S).long() == m_id).cumsum(1).to(torch.int32).reshape(-1)
+
+
+def visible_first(visible):
+    v = visible.bool()
+    n = v.numel()
+    idx = torch.arange(n, device=visible.device)
+    old_of_new = torch.cat([idx[v], idx[~v]]).to(torch.int32)
+    new_of_old = torch.empty(n, dtype=torch.int32, device=visible.device)
+    new_of_old[old_of_new.long()] = idx.to(torch.int32)
+    return new_of_old, old_of_new, v.sum().to(torch.int32).reshape(1)
+
+
+def gather_groups(src, idx, n_groups, S, out=None):
+    rows = (idx[:n_groups].long().unsqueeze(1) * S + torch.arange(S, device=src.device)).reshape(-1)
+    if out is None:
+        return src[rows].clone()
+    out[:n_groups * S] = src[rows]
+    return out
 
 
 def pack_tokens(commands, args, key_mask, n_seq, S):
