@@ -300,8 +300,10 @@ extern "C" int dsvg_embed_gather(int32_t dtype, const float* commands, const flo
 // ---------------------------------------------------------------------------------------------
 constexpr int ES_TOK_PER_BLOCK = 64;
 
-// token-outer / column-inner loops: no 64-bit divisions in the hot loop; 64 tokens per workgroup so that even the
-// packed encoder (~40k tokens at 512 icons) fills the chip
+// Each thread owns up to 4 columns (c = tid + 256 k) of the [n_args * E] gradient row, i.e. fixed (arg slot, e) pairs;
+// tokens are processed 4 at a time with all of their loads issued before the first LDS atomic (the loop is otherwise a
+// chain of dependent ~2 us loads), no integer divisions inside the loop.  64 tokens per workgroup so that even the
+// packed encoder (~40k tokens at 512 icons) fills the chip.
 template <typename T>
 __global__ __launch_bounds__(256) void embed_scatter_arg_kernel(const float* __restrict__ args, const T* __restrict__ dA,
                                                                 float* __restrict__ part, long long T_tok, int n_args,
@@ -313,18 +315,40 @@ __global__ __launch_bounds__(256) void embed_scatter_arg_kernel(const float* __r
     const long long t0 = (long long)blockIdx.x * ES_TOK_PER_BLOCK;
     const long long t1 = min(T_tok, t0 + ES_TOK_PER_BLOCK);
     const int width = n_args * E;
-    for (long long t = t0; t < t1; ++t) {
-        const T* row = dA + t * width;
-        const float* arow = args + t * n_args;
-        for (int c = threadIdx.x; c < width; c += 256) {
-            const float g = Elem<T>::ld(row + c);
-            if (g != 0.f) {
-                const int a = c / E, e = c - a * E;
-                int iv = (int)arow[a] + 1;
-                iv = min(max(iv, 0), n_argvals - 1);
-                atomicAdd(&acc[iv * E + e], g);
+    constexpr int KC = 4, TU = 4;
+    int a_of[KC], e_of[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        a_of[k] = c < width ? c / E : -1;
+        e_of[k] = c < width ? c % E : 0;
+    }
+    for (int c = threadIdx.x + 256 * KC; c < width; c += 256) {      // rows wider than 1024 columns: plain path
+        for (long long t = t0; t < t1; ++t) {
+            const float g = Elem<T>::ld(dA + t * width + c);
+            int iv = (int)args[t * n_args + c / E] + 1;
+            iv = min(max(iv, 0), n_argvals - 1);
+            if (g != 0.f) atomicAdd(&acc[iv * E + c % E], g);
+        }
+    }
+    for (long long tb = t0; tb < t1; tb += TU) {
+        float g[TU][KC];
+        int iv[TU][KC];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const long long t = tb + u;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const bool ok = t < t1 && a_of[k] >= 0;
+                g[u][k] = ok ? Elem<T>::ld(dA + t * width + threadIdx.x + 256 * k) : 0.f;
+                iv[u][k] = ok ? (int)args[t * n_args + a_of[k]] + 1 : 0;
             }
         }
+#pragma unroll
+        for (int u = 0; u < TU; ++u)
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                if (g[u][k] != 0.f) atomicAdd(&acc[min(max(iv[u][k], 0), n_argvals - 1) * E + e_of[k]], g[u][k]);
     }
     __syncthreads();
     float* dst = part + (size_t)blockIdx.x * tab;

@@ -7,7 +7,7 @@
 #include "../../include/dsvg.h"
 
 constexpr int LN_MAXV = 4;            // 4 x (64 lanes x 4 elements) = 1024 features max
-constexpr int LN_MAX_BLOCKS = 1024;
+constexpr int LN_MAX_BLOCKS = 2048;   // backward: 8 resident workgroups per CU (32 waves), one partial row each
 
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
@@ -71,7 +71,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* __res
                                                      const float* __restrict__ gamma, const T* res,
                                                      T* dx, float* __restrict__ part,
                                                      long long rows, int d) {
-    __shared__ float red[4][2][1024 / 4 + 1][4];  // [wave][dg/db][vec][elem]  (padded)
+    // [wave][dg/db][d/4 + 1 vectors][4]: sized by d at launch (8 KiB at d = 256) so that LDS does not cap the number of
+    // resident workgroups - the kernel hides HBM latency with waves, each wave walks its rows one after the other
+    extern __shared__ float red_raw[];
+    const int nvec = d / 4 + 1;
+    auto red = [&](int w, int k, int vec, int e) -> float& { return red_raw[((w * 2 + k) * nvec + vec) * 4 + e]; };
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nv = d / 256 + ((d % 256) ? 1 : 0);
@@ -133,8 +137,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* __res
         if (i < nv) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                red[wave][0][i * 64 + lane][e] = ag[i][e];
-                red[wave][1][i * 64 + lane][e] = ab[i][e];
+                if (i * 256 + lane * 4 < d) {
+                    red(wave, 0, i * 64 + lane, e) = ag[i][e];
+                    red(wave, 1, i * 64 + lane, e) = ab[i][e];
+                }
             }
         }
     }
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* __res
         const int vec = c >> 2, e = c & 3;
         float sg = 0.f, sb = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { sg += red[w][0][vec][e]; sb += red[w][1][vec][e]; }
+        for (int w = 0; w < 4; ++w) { sg += red(w, 0, vec, e); sb += red(w, 1, vec, e); }
         pg[c] = sg;
         pg[d + c] = sb;
     }
@@ -154,6 +160,12 @@ static int ln_grid(long long rows) {
     long long nb = (rows + 3) / 4;
     return (int)(nb < LN_MAX_BLOCKS ? nb : LN_MAX_BLOCKS);
 }
+// forward: no per-block partials, so one wave per row with every row's load in flight at once (a wave that walks 30
+// rows one after the other is a chain of dependent ~2 us loads: measured 58 us for 134 MB of traffic)
+static int ln_grid_fwd(long long rows) {
+    long long nb = (rows + 3) / 4;
+    return (int)(nb < 65536 ? nb : 65536);
+}
 
 extern "C" int dsvg_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y,
                                   float* mean, float* rstd, int64_t rows, int32_t d, float eps, void* stream) {
@@ -162,10 +174,10 @@ extern "C" int dsvg_layernorm_fwd(int32_t dtype, const void* x, const float* gam
                    (long long)rows, d);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DSVG_F32)
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(ln_grid(rows)), dim3(256), 0, st, (const float*)x, gamma, beta,
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(ln_grid_fwd(rows)), dim3(256), 0, st, (const float*)x, gamma, beta,
                            (float*)y, mean, rstd, (long long)rows, d, eps);
     else if (dtype == DSVG_BF16)
-        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(ln_grid(rows)), dim3(256), 0, st, (const bf16_t*)x, gamma, beta,
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(ln_grid_fwd(rows)), dim3(256), 0, st, (const bf16_t*)x, gamma, beta,
                            (bf16_t*)y, mean, rstd, (long long)rows, d, eps);
     else { dsvg_set_error("layernorm_fwd: bad dtype %d", dtype); return -1; }
     DSVG_LAUNCH_CHECK("layernorm_fwd");
@@ -186,11 +198,12 @@ extern "C" int dsvg_layernorm_bwd(int32_t dtype, const void* dy, const void* x, 
                    "layernorm_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int nb = ln_grid(rows);
+    const size_t lds = (size_t)4 * 2 * (d / 4 + 1) * 4 * sizeof(float);
     if (dtype == DSVG_F32)
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dy, (const float*)x, mean,
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), lds, st, (const float*)dy, (const float*)x, mean,
                            rstd, gamma, (const float*)res, (float*)dx, workspace, (long long)rows, d);
     else if (dtype == DSVG_BF16)
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean,
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, mean,
                            rstd, gamma, (const bf16_t*)res, (bf16_t*)dx, workspace, (long long)rows, d);
     else { dsvg_set_error("layernorm_bwd: bad dtype %d", dtype); return -1; }
     DSVG_LAUNCH_CHECK("layernorm_bwd");

@@ -10,6 +10,6 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$NAM
 cd $GRAFT_REPO_ROOT
 DB=$(find gpurun_out/$NAME -name "*.db" | head -1)
 python scripts/rocpd_stats.py "$DB" gpurun_out/${NAME}_kernel_stats.csv > /dev/null
-head -45 gpurun_out/${NAME}_kernel_stats.csv | cut -c1-200
+head -45 gpurun_out/${NAME}_kernel_stats.csv | cut -c1-200; grep HIST gpurun_out/${NAME}_kernel_stats.csv
 tail -1 gpurun_out/$NAME.log | cut -c1-400
 rm -rf gpurun_out/$NAME

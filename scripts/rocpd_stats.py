@@ -22,6 +22,12 @@ def main(db_path, out_csv=None, skip_calls=0):
         lines.append(f"{name},{r[1]},{r[2] / 1e6:.3f},{r[3] / 1e3:.1f},{r[4] / 1e3:.1f},{r[5] / 1e3:.1f},"
                      f"{100 * r[2] / tot:.1f},{r[6]},{r[7]},{r[8]}")
     lines.append(f"TOTAL,,{tot / 1e6:.3f},,,,100.0,,,")
+    # where the time goes by launch duration (launch-latency-bound tail vs bandwidth-bound body)
+    edges = [0, 5, 10, 20, 50, 100, 200, 1e9]
+    durs = [r[0] / 1e3 for r in c.execute(f"select end-start from {kd}")]
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        sel = [d for d in durs if lo <= d < hi]
+        lines.append(f"HIST {lo:g}-{hi:g} us,{len(sel)},{sum(sel) / 1e3:.3f},,,,{100 * sum(sel) * 1e3 / tot:.1f},,,")
     txt = "\n".join(lines) + "\n"
     if out_csv:
         open(out_csv, "w").write(txt)
