@@ -213,6 +213,12 @@ __device__ __forceinline__ float wave_max(float v) {
 
 static inline int dsvg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// split-K workspace: K slice z = [M*N partial | M row sums (only when requested)], slices `dsvg_splitk_slice` floats
+// apart (rounded up to 4 floats so that every slice starts 16-byte aligned)
+__host__ __device__ inline size_t dsvg_splitk_slice(size_t M, size_t N, bool rowsums) {
+    return (M * N + (rowsums ? M : 0) + 3) & ~(size_t)3;
+}
+
 // out[j] = (accumulate ? out[j] : 0) + sum_{q<P} part[q*stride + j], j < n   (deterministic order; gemm.hip)
 int dsvg_reduce_partials_strided(const float* part, int64_t P, int64_t stride, int64_t n, float* out,
                                  int32_t accumulate, hipStream_t st);

@@ -242,12 +242,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) rs_part[(size_t)kz * ((size_t)p.M * p.N + p.M) + m] = accb[i][r];
+                if (m < p.M) rs_part[(size_t)kz * dsvg_splitk_slice(p.M, p.N, true) + m] = accb[i][r];
             }
     }
     const DropCtx dc = drop_make(p.drop_p, p.seed, p.drop_site);
     // K-slice z of the workspace = [M*N partial | M row sums (only when requested)]
-    float* my_part = part ? part + (size_t)kz * ((size_t)p.M * p.N + (rs_part ? p.M : 0)) : nullptr;
+    float* my_part = part ? part + (size_t)kz * dsvg_splitk_slice(p.M, p.N, rs_part != nullptr) : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, lo
 
 extern "C" int64_t dsvg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
     if (split_k <= 1) return 0;
-    return (int64_t)split_k * ((int64_t)M * N + M) * (int64_t)sizeof(float);   // [split][M*N] + [split][M] row sums
+    return (int64_t)split_k * (int64_t)dsvg_splitk_slice(M, N, true) * (int64_t)sizeof(float);   // [split][M*N | M row sums]
 }
 
 extern "C" int dsvg_reduce_partials(const float* partial, int64_t P, int64_t n, float* out,
@@ -479,7 +479,7 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
     if (split > 1 && (split % 8) == 0) nsplit = split;   // trailing slices may be empty (they write zero partials)
     DSVG_CHECK_ARG(!d.rowsum || part, "gemm: rowsum needs split_k > 1");
     float* rs_part = d.rowsum ? part + (size_t)d.M * d.N : nullptr;   // row sums of slice 0 (slices are interleaved)
-    const size_t slice = (size_t)d.M * d.N + (d.rowsum ? d.M : 0);
+    const size_t slice = dsvg_splitk_slice(d.M, d.N, d.rowsum != nullptr);
 
     bool use_naive = d.impl == 1;
     if (d.dtype == DSVG_F32) {

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(dsvg_gemm_desc p, i
     }
 
     if (EPI == EPI_PARTIAL || (EPI == EPI_GENERIC && part)) {   // split-K partial: raw fp32 accumulators
-        const size_t slice = (size_t)p.M * p.N + (rs_part ? p.M : 0);   // [M*N partial | M row sums] per K slice
+        const size_t slice = dsvg_splitk_slice(p.M, p.N, rs_part != nullptr);   // [M*N partial | M row sums] per K slice
         float* my_part = part + (size_t)kz * slice;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -433,17 +433,21 @@ int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, floa
     }
 
     // pick the compile-time epilogue variant when the call matches one exactly and everything is 16-byte aligned
-    int epi = EPI_GENERIC;
-    const bool vec_ok = !part && !d.c_f32 && !d.accumulate && !d.res_pre && !(d.N & 7) && !(d.ldc & 7) &&
-                        !((uintptr_t)d.C & 15) && (!d.res || (!(d.ldres & 7) && !((uintptr_t)d.res & 15))) &&
-                        (!d.gate || (!(d.ldgate & 7) && !((uintptr_t)d.gate & 15)));
-    if (vec_ok) {
-        if (!d.res && !d.gate && d.act == 0 && d.drop_p <= 0.f) epi = EPI_BIAS;
-        else if (d.res && !d.gate && d.act == 0) epi = EPI_BIAS_RES_DROP;
-        else if (!d.res && !d.gate && d.act == 1) epi = EPI_BIAS_RELU_DROP;
-        else if (d.gate && !d.res && !d.bias && d.act == 0 && d.drop_p <= 0.f) epi = EPI_GATE;
-    }
-    if (epi != EPI_GENERIC && dsvg_gemm_bf16_glds_try(d, epi, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, st)) {
+    // (the LDS-DMA kernel also takes N % 8 != 0: it finishes the last partial 8-column chunk element-wise)
+    auto classify = [&](bool ok) -> int {
+        if (!ok) return EPI_GENERIC;
+        if (!d.res && !d.gate && d.act == 0 && d.drop_p <= 0.f) return EPI_BIAS;
+        if (d.res && !d.gate && d.act == 0) return EPI_BIAS_RES_DROP;
+        if (!d.res && !d.gate && d.act == 1) return EPI_BIAS_RELU_DROP;
+        if (d.gate && !d.res && !d.bias && d.act == 0 && d.drop_p <= 0.f) return EPI_GATE;
+        return EPI_GENERIC;
+    };
+    const bool vec_base = !part && !d.c_f32 && !d.accumulate && !d.res_pre && !(d.ldc & 7) &&
+                          !((uintptr_t)d.C & 15) && (!d.res || (!(d.ldres & 7) && !((uintptr_t)d.res & 15))) &&
+                          (!d.gate || (!(d.ldgate & 7) && !((uintptr_t)d.gate & 15)));
+    const int epi_dma = classify(vec_base);
+    const int epi = classify(vec_base && !(d.N & 7));
+    if (epi_dma != EPI_GENERIC && dsvg_gemm_bf16_glds_try(d, epi_dma, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, st)) {
         DSVG_LAUNCH_CHECK("gemm_bf16_glds");
         return 0;
     }

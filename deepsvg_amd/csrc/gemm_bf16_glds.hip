@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void gemm_bf16_glds_kernel(d
         } else {
             const int kr = piece * 4 + (lane >> 4);
             const int c = (lane & 15) ^ ((lane >> 4) << 2);
-            offa[i] = (uint32_t)(((size_t)kr * p.lda + min(m0 + 8 * c, p.M - 8)) * 2);
+            offa[i] = (uint32_t)(((size_t)kr * p.lda + min(m0 + 8 * c, ((p.M + 7) & ~7) - 8)) * 2);
         }
         if (BKC) {
             const int r = piece * 8 + (lane >> 3);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void gemm_bf16_glds_kernel(d
     const int ncol = n0 + wn * 64;                       // + 32 jn + ...
 
     if (EPI == EPI_PARTIAL) {       // split-K slice: raw fp32 accumulators, 16-byte stores (4 consecutive columns)
-        const size_t slice = (size_t)p.M * p.N + (rs_part ? p.M : 0);
+        const size_t slice = dsvg_splitk_slice(p.M, p.N, rs_part != nullptr);
         float* my_part = part + (size_t)kz * slice;
         auto put = [&](const floatx16& c, int jn, int im) {
             const int m = mrow + 32 * im;
@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void gemm_bf16_glds_kernel(d
     constexpr bool may_drop = EPI == EPI_BIAS_RES_DROP || EPI == EPI_BIAS_RELU_DROP;
     const DropCtx dc = drop_make(may_drop ? p.drop_p : 0.f, p.seed, p.drop_site);
     const bool has_bias = !has_gate && p.bias != nullptr;
+    const bool n_aligned = !(p.N & 7);     // else: the last chunk of a row is partial and dropout ids are unaligned
 
     auto tile = [&](const floatx16& c, int jn, int im) {
         const int m = mrow + 32 * im;
@@ -243,11 +244,17 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void gemm_bf16_glds_kernel(d
             }
             const int nb = ncol + 32 * jn + 16 * cb + 8 * h;
             if (m >= p.M || nb >= p.N) continue;
+            const int nv = min(8, p.N - nb);        // valid columns of this chunk (8 except at a ragged row end)
             if (has_bias) {
-                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + nb);
-                const float4 b1 = *reinterpret_cast<const float4*>(p.bias + nb + 4);
-                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                if (nv == 8) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + nb);
+                    const float4 b1 = *reinterpret_cast<const float4*>(p.bias + nb + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += e < nv ? p.bias[nb + e] : 0.f;
+                }
             }
             if (relu) {
 #pragma unroll
@@ -255,23 +262,44 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void gemm_bf16_glds_kernel(d
             }
             if (has_gate) {
                 float gv[8];
-                unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)p.gate + (size_t)m * p.ldgate + nb), gv);
+                const bf16_t* gp = (const bf16_t*)p.gate + (size_t)m * p.ldgate + nb;
+                if (nv == 8) unpack8(*reinterpret_cast<const uint4*>(gp), gv);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gv[e] = e < nv ? bf2f(gp[e]) : 0.f;
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = gv[e] > 0.f ? v[e] * p.gate_scale : 0.f;
             }
             if (may_drop && dc.on) {
                 float dm[8];
-                drop_mult8(dc, (uint64_t)m * p.N + nb, dm);
+                if (n_aligned) {
+                    drop_mult8(dc, (uint64_t)m * p.N + nb, dm);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dm[e] = drop_mult(dc, (uint64_t)m * p.N + nb + e);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= dm[e];
             }
             if (has_res) {
                 float rv[8];
-                unpack8(*reinterpret_cast<const uint4*>((const bf16_t*)p.res + (size_t)m * p.ldres + nb), rv);
+                const bf16_t* rp = (const bf16_t*)p.res + (size_t)m * p.ldres + nb;
+                if (nv == 8) unpack8(*reinterpret_cast<const uint4*>(rp), rv);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rv[e] = e < nv ? bf2f(rp[e]) : 0.f;
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += rv[e];
             }
-            *reinterpret_cast<uint4*>((bf16_t*)p.C + (size_t)m * p.ldc + nb) = pack8(v);
+            bf16_t* cp = (bf16_t*)p.C + (size_t)m * p.ldc + nb;
+            if (nv == 8) *reinterpret_cast<uint4*>(cp) = pack8(v);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e < nv) cp[e] = f2bf(v[e]);
+            }
         }
     };
     tile(acc00, 0, 0); tile(acc01, 0, 1); tile(acc10, 1, 0); tile(acc11, 1, 1);
@@ -298,15 +326,17 @@ bool dsvg_gemm_bf16_glds_try(const dsvg_gemm_desc& d, int epi, dim3 grid, int ti
     const int nst = d.impl == 3 ? 2 : (d.impl == 4 ? 1 : nst_env);
     if ((d.K % GBK) || (part && (k_chunk % GBK))) return false;
     if ((d.lda & 7) || (d.ldb & 7) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) return false;
-    if (!d.a_kc && ((d.M & 7) || d.M < 8)) return false;
-    if ((d.N & 7) || d.N < 8 || d.M < 1) return false;
+    // token-major (mn-contiguous) operands are read in 8-element chunks: the row must be padded to a multiple of 8
+    // elements (checked by the caller) - a ragged M is fine, a ragged N only for the k-contiguous B of the forward GEMMs
+    if (!d.a_kc && d.M < 8) return false;
+    if (!d.b_kc && ((d.N & 7) || d.N < 8)) return false;
+    if (d.M < 1 || d.N < 1) return false;
     // per-lane source offsets are 32-bit byte offsets
     const size_t span_a = d.a_kc ? (size_t)d.M * d.lda : (size_t)GBK * d.lda + d.M;
     const size_t span_b = d.b_kc ? (size_t)d.N * d.ldb : (size_t)GBK * d.ldb + d.N;
     if (span_a * 2 >= (1ull << 32) || span_b * 2 >= (1ull << 32)) return false;
     if (part) {
-        const size_t slice = (size_t)d.M * d.N + (rs_part ? d.M : 0);
-        if ((slice & 3) || ((uintptr_t)part & 15)) return false;
+        if (((uintptr_t)part & 15) || (d.N & 3)) return false;
         if (!d.a_kc && !d.b_kc) { launch<false, false, EPI_PARTIAL>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, nst, st); return true; }
         return false;
     }

@@ -161,6 +161,36 @@ def test_gemm_lds_dma_kernel_equals_register_staged_kernel(gpu_device, stages, M
 
 
 @pytest.mark.parametrize("stages", [4, 3])
+def test_gemm_lds_dma_ragged_head_shapes(gpu_device, stages):
+    """N = 523 (like the 2827-wide argument head: not a multiple of 8) in a row-padded buffer: forward through the
+    LDS-DMA kernel (last 8-column chunk finished element-wise) and the weight gradient with a ragged M, both
+    bit-identical to the register-staged kernel"""
+    dtype = torch.bfloat16
+    T, N, K, ld = 1920, 523, 256, 528
+    x, w, bias = _rand(T, K, dtype=dtype, seed=81), _rand(N, K, dtype=dtype, seed=82, scale=0.1), _rand(N, seed=83)
+    outs = []
+    for impl in (stages, 2):
+        buf = torch.full((T, ld), 7.0, device=DEV, dtype=dtype)
+        ops.gemm(x, w, bias=bias, out=buf[:, :N], impl=impl)
+        assert torch.all(buf[:, N:] == 7.0), "wrote into the row padding"
+        outs.append(buf[:, :N].clone())
+    assert torch.equal(outs[0], outs[1])
+    _close(outs[0], R.gemm(x, w, bias=bias, out_dtype=torch.float32), _tol(dtype, K), "ragged-N forward")
+    dbuf = torch.zeros(T, ld, device=DEV, dtype=dtype)
+    dbuf[:, :N] = _rand(T, N, dtype=dtype, seed=84)
+    dy = dbuf[:, :N]
+    res = []
+    for impl in (stages, 2):
+        flat = torch.empty(N * K + N, device=DEV, dtype=torch.float32)
+        dw, db = flat[:N * K].view(N, K), flat[N * K:]
+        ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw, split_k=8, rowsum=db, impl=impl)
+        res.append((dw.clone(), db.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    _close(res[0][0], R.gemm(dy, x, a_kc=False, b_kc=False, out_dtype=torch.float32), _tol(dtype, T), "ragged-M dW")
+    _close(res[0][1], dy.float().sum(0), 1e-2, "ragged-M bias grad")
+
+
+@pytest.mark.parametrize("stages", [4, 3])
 @pytest.mark.parametrize("T,n_out,k_in,split", [(4096, 512, 256, 16), (1920, 256, 512, 8), (640, 264, 704, 3),
                                                 (8192, 768, 256, 64)])
 def test_gemm_lds_dma_weight_grad(gpu_device, stages, T, n_out, k_in, split):
