@@ -8,9 +8,10 @@
 //        mn-contiguous operand image [64 k][128 mn] (256 B rows): chunk c of k-row k lives at c ^ ((k&3)<<2)
 //     both conflict-free for ds_read_b128 / ds_read_b64_tr_b16 fragment reads (lane groups of MI355X_MICROARCH §LDS).
 //   * the MFMA is issued with the operands swapped (D = W_frag x X_frag, i.e. the transposed tile): a lane then owns
-//     one token row and 4 consecutive output columns per accumulator quad; one v_permlane32_swap per register makes
-//     that 8 consecutive columns, so bias / ReLU / dropout / residual / gate and the 16-byte stores run from
-//     registers - the epilogue uses no LDS at all (the register-staged kernel spends ~1/3 of its LDS cycles there).
+//     one token row and 4 consecutive output columns per accumulator quad; two v_permlane32_swap rounds turn that
+//     into 16 consecutive columns, so bias / ReLU / dropout / residual / gate and the stores (32 contiguous bytes
+//     per lane, 64 per lane pair, a row's four pieces issued back to back) run from registers - the epilogue uses
+//     no LDS at all (the register-staged kernel spends ~1/3 of its LDS cycles there).
 //   * out-of-range rows are clamped on the load side (their results are never stored): no exec-mask branches.
 // Eligibility is decided on the host (dsvg_gemm_bf16_glds_try); everything else runs on gemm_bf16.hip.
 #include "gemm_bf16.h"
@@ -229,22 +230,40 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void gemm_bf16_glds_kernel(d
     const bool has_bias = !has_gate && p.bias != nullptr;
     const bool n_aligned = !(p.N & 7);     // else: the last chunk of a row is partial and dropout ids are unaligned
 
-    auto tile = [&](const floatx16& c, int jn, int im) {
+    // One 32x32 accumulator tile -> 16 consecutive output columns of token row m per lane (two permlane32 exchange
+    // rounds: quads 8 g + 4 h + e  ->  octets  ->  16-column runs n = 32 jn + 16 h + i), epilogue math on two aligned
+    // 8-column chunks, results left packed in `pk` so that the caller can issue all stores of a 128-byte output line
+    // back to back (PMC: stores interleaved with the dropout hash reach HBM as partial lines, WRITE_SIZE +38 %; 16-byte
+    // accesses covering only 32 contiguous bytes per row also doubled the gate / residual FETCH_SIZE).
+    auto tile16 = [&](const floatx16& c, int jn, int im, uint4 (&pk)[2], int (&nvalid)[2]) {
         const int m = mrow + 32 * im;
+        uint32_t x[4][4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[gq][e] = __float_as_uint(c[4 * gq + e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {       // round 1: (x0, x1) and (x2, x3) -> 8 consecutive columns each
+            auto s01 = __builtin_amdgcn_permlane32_swap(x[0][e], x[1][e], false, false);
+            auto s23 = __builtin_amdgcn_permlane32_swap(x[2][e], x[3][e], false, false);
+            x[0][e] = s01[0]; x[1][e] = s01[1]; x[2][e] = s23[0]; x[3][e] = s23[1];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {       // round 2: low lanes keep columns 0..15, high lanes 16..31
+            auto s02 = __builtin_amdgcn_permlane32_swap(x[0][e], x[2][e], false, false);
+            auto s13 = __builtin_amdgcn_permlane32_swap(x[1][e], x[3][e], false, false);
+            x[0][e] = s02[0]; x[2][e] = s02[1]; x[1][e] = s13[0]; x[3][e] = s13[1];
+        }
+        const int n16 = ncol + 32 * jn + 16 * h;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            // lanes l and l+32 exchange accumulator quads: afterwards each lane owns 8 consecutive columns
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[8 * cb + e]),
-                                                                 __float_as_uint(c[8 * cb + 4 + e]), false, false);
-                v[e] = __uint_as_float(sw[0]);
-                v[4 + e] = __uint_as_float(sw[1]);
-            }
-            const int nb = ncol + 32 * jn + 16 * cb + 8 * h;
-            if (m >= p.M || nb >= p.N) continue;
-            const int nv = min(8, p.N - nb);        // valid columns of this chunk (8 except at a ragged row end)
+            for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(x[2 * cb][e]); v[4 + e] = __uint_as_float(x[2 * cb + 1][e]); }
+            const int nb = n16 + 8 * cb;
+            const int nv = (m < p.M && nb < p.N) ? min(8, p.N - nb) : 0;   // valid columns of this chunk
+            nvalid[cb] = nv;
+            if (nv == 0) { pk[cb] = make_uint4(0u, 0u, 0u, 0u); continue; }
             if (has_bias) {
                 if (nv == 8) {
                     const float4 b0 = *reinterpret_cast<const float4*>(p.bias + nb);
@@ -293,16 +312,30 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void gemm_bf16_glds_kernel(d
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += rv[e];
             }
-            bf16_t* cp = (bf16_t*)p.C + (size_t)m * p.ldc + nb;
-            if (nv == 8) *reinterpret_cast<uint4*>(cp) = pack8(v);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (e < nv) cp[e] = f2bf(v[e]);
-            }
+            pk[cb] = pack8(v);
         }
     };
-    tile(acc00, 0, 0); tile(acc01, 0, 1); tile(acc10, 1, 0); tile(acc11, 1, 1);
+    auto put8 = [&](bf16_t* cp, const uint4& v, int nv) {
+        if (nv == 8) { *reinterpret_cast<uint4*>(cp) = v; return; }
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < nv) cp[e] = (bf16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+    };
+    // the 64 columns of the wave's sub-tile = one 128-byte line per token row: four 32-byte pieces (2 lanes x 2 tiles)
+    auto row_block = [&](const floatx16& c0, const floatx16& c1, int im) {
+        uint4 pk0[2], pk1[2];
+        int nv0[2], nv1[2];
+        tile16(c0, 0, im, pk0, nv0);
+        tile16(c1, 1, im, pk1, nv1);
+        bf16_t* cp = (bf16_t*)p.C + (size_t)(mrow + 32 * im) * p.ldc + ncol + 16 * h;
+        put8(cp, pk0[0], nv0[0]);
+        put8(cp + 8, pk0[1], nv0[1]);
+        put8(cp + 32, pk1[0], nv1[0]);
+        put8(cp + 40, pk1[1], nv1[1]);
+    };
+    row_block(acc00, acc10, 0);
+    row_block(acc01, acc11, 1);
 }
 
 template <bool AKC, bool BKC, int EPI>

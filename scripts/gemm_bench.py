@@ -84,7 +84,7 @@ def main():
     ]
     print(f"dtype={a.dtype} T={T} impls={impls}")
     for name, fn, M, N, K in cases:
-        if a.only and a.only not in name:
+        if a.only and not any(o in name for o in a.only.split(",")):
             continue
         if K:
             flop = 2.0 * M * N * K
