@@ -40,9 +40,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="icons per GPU")
     ap.add_argument("--dtype", default=os.environ.get("DSVG_BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("DSVG_BENCH_GRAPH", "0")),
-                    help="1: replay the step as a hipGraph (padded encoder layout: the packed layout needs the token "
-                         "count on the host)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("DSVG_BENCH_GRAPH", "1")),
+                    help="1: replay the step as a hipGraph (one graph per layout bucket, the layout plan runs eagerly "
+                         "before each replay; single-GPU default), 0: eager launches")
     ap.add_argument("--pack-encoder", type=int, default=int(os.environ.get("DSVG_PACK_ENCODER", "1")),
                     help="1: first encoder stage on the valid tokens only (exact, SURVEY.md 7.3-12); 0: padded layout")
     ap.add_argument("--dropout", type=float, default=0.1)

@@ -313,6 +313,7 @@ class SVGTransformer(nn.Module):
         # backward of the second decoder stage only over the sequences of visible target groups (exact under SVGLoss)
         self.skip_invisible_backward = os.environ.get("DSVG_SKIP_INVISIBLE", "1") != "0"
         self.last_live = None
+        self._forced_plan = None
 
     # ---- runtime plumbing ------------------------------------------------------------------------
     def set_compute_dtype(self, dtype):
@@ -351,6 +352,14 @@ class SVGTransformer(nn.Module):
                 seq_off, live)
         return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps, live)
 
+    def make_plan(self, commands_enc, args_enc, commands_dec, want_grad=True):
+        """the data-dependent layout plan of one forward (see _plan), for callers that replay captured hipGraphs"""
+        forced, self._forced_plan = self._forced_plan, None
+        try:
+            return self._plan(commands_enc, args_enc, commands_dec, want_grad)
+        finally:
+            self._forced_plan = forced
+
     def _plan(self, commands_enc, args_enc, commands_dec, want_grad):
         """Data-dependent layout decisions of one forward, made up front with ONE device->host read:
           * packed first encoder stage (valid tokens only), see _encode_stage1_packed;
@@ -360,6 +369,8 @@ class SVGTransformer(nn.Module):
             when the targets are known (training call with commands_dec) - gradients are those of SVGLoss.
         Both are disabled while a hipGraph is being captured (shapes must be static there)."""
         cfg = self.cfg
+        if self._forced_plan is not None:       # a trainer replaying bucketed hipGraphs supplies the plan (make_plan)
+            return self._forced_plan
         plan = {"enc": None, "dec": None}
         ref = commands_enc if commands_enc is not None else commands_dec
         if ref is None or (ref.is_cuda and torch.cuda.is_current_stream_capturing()):
@@ -401,6 +412,7 @@ class SVGTransformer(nn.Module):
         emb = enc.embedding
         seq_off, pcmd, parg, ppos, total = pe["seq_off"], pe["pcmd"], pe["parg"], pe["ppos"], pe["total"]
         rows = min((total + 127) // 128 * 128, n_seq * S)
+        rows = max(rows, min(int(pe.get("rows", 0)), n_seq * S))     # a graph bucket may ask for more (inert) rows
         self.last_packing = (total, n_seq * S)      # valid tokens, dense tokens (reported by bench.py)
         src = Fn.PackedEmbedFn.apply(rt, pcmd[:rows], parg[:rows], ppos[:rows], S, PE_DROPOUT, 1,
                                      emb.command_embed.weight, emb.arg_embed.weight, emb.embed_fcn.weight,
@@ -478,9 +490,10 @@ class SVGTransformer(nn.Module):
         S = dec.embedding.seq_len
         pd = plan["dec"] if (plan is not None and cfg.decode_stages == 2) else None
         live = None
-        if pd is not None and pd["n_visible"] < n_seq:
+        if pd is not None and max(pd["n_visible"], pd.get("n_live", 0)) < n_seq:
             # visible-first order: sequence `new` of the stage is group old_of_new[new]; backward covers the prefix
-            nv = pd["n_visible"]
+            # (any prefix that contains every visible sequence is exact; a graph bucket rounds it up)
+            nv = max(pd["n_visible"], pd.get("n_live", 0))
             live = (nv, min((nv * S + 127) // 128 * 128, n_seq * S))
             z = Fn.GatherGroupsFn.apply(z, pd["old_of_new"], pd["new_of_old"], n_seq, 1, None)
         self.last_live = (live[0], n_seq) if live is not None else None

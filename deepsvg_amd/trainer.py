@@ -10,7 +10,11 @@ flat buffers, one process per GPU.
     averaged gradient equals the gradient of the global-batch mean exactly as in single-process training
     (SURVEY.md §8(e));
   * every scalar the kernels need (lr, step, seed, norm, counts) lives in device memory, so the whole step can
-    be captured in a hipGraph and replayed (use_graph=True) to remove the host launch overhead.
+    be captured in a hipGraph and replayed (use_graph=True) to remove the host launch overhead (~12 ms of Python
+    dispatch per step, as long as the GPU work itself).  The two data-dependent layouts of the model (packed
+    encoder rows, visible-first decoder prefix) are made static per graph by rounding them up to buckets - extra
+    rows / sequences are inert by construction - and one graph is captured per bucket pair on first use; the layout
+    plan (a few tiny kernels + one host read) runs eagerly before each replay and is copied into the graph's buffers.
 """
 import torch
 import torch.distributed as dist
@@ -35,8 +39,9 @@ class TrainStep:
         self.exact_global_mean = exact_global_mean and self.world > 1
         self._lr_value = float(lr)
         self._ready = False
-        self._graph = None
-        self._static = None
+        self._graphs = {}               # bucket key -> (graph, static inputs, static plan, static results)
+        self._pool = None
+        self.row_bucket, self.seq_bucket = 1024, 64
         model._own_seed = False          # the trainer advances the dropout seed once per step
         if self.exact_global_mean:
             loss_fn.count_reducer = self._reduce_count
@@ -87,27 +92,76 @@ class TrainStep:
             self._setup(commands.device)
         if not self.use_graph:
             return self._step_body(commands, args)
-        if self._graph is None:
-            self._capture(commands, args)
+        model = self.model
+        plan = model.make_plan(commands, args, commands, True)
+        key, plan = self._bucketed(plan, commands)
+        entry = self._graphs.get(key)
+        if entry is None:
+            entry = self._capture(key, commands, args, plan)
         else:
-            self._static[0].copy_(commands)
-            self._static[1].copy_(args)
-        self._graph.replay()
-        return self._static[2]
+            graph, (sc, sa), splan, res = entry
+            sc.copy_(commands)
+            sa.copy_(args)
+            for part in ("enc", "dec"):
+                if splan[part] is not None:
+                    for k, v in splan[part].items():
+                        if torch.is_tensor(v):
+                            v.copy_(plan[part][k])
+        self._note_layout(plan, commands)
+        entry[0].replay()
+        return entry[3]
 
-    def _capture(self, commands, args):
+    def _bucketed(self, plan, commands):
+        """round the plan's two data-dependent sizes up to buckets -> (graph cache key, plan with the rounded sizes)"""
+        n_seq = commands.shape[0] * commands.shape[1]
+        key = []
+        if plan["enc"] is not None:
+            rb = self.row_bucket
+            rows = min((plan["enc"]["total"] + rb - 1) // rb * rb, n_seq * commands.shape[2])
+            plan["enc"]["rows"] = rows
+            key.append(rows)
+        else:
+            key.append(-1)
+        if plan["dec"] is not None:
+            sb = self.seq_bucket
+            n_live = min((plan["dec"]["n_visible"] + sb - 1) // sb * sb, n_seq)
+            plan["dec"]["n_live"] = n_live
+            key.append(n_live)
+        else:
+            key.append(-1)
+        return tuple(key), plan
+
+    def _note_layout(self, plan, commands):
+        n_seq = commands.shape[0] * commands.shape[1]
+        m = self.model
+        m.last_packing = (plan["enc"]["total"], n_seq * commands.shape[2]) if plan["enc"] is not None else None
+        m.last_live = (plan["dec"]["n_visible"], n_seq) if plan["dec"] is not None else None
+
+    def _capture(self, key, commands, args, plan):
+        model = self.model
         sc, sa = commands.clone(), args.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):                      # warm-up: allocator pools, lazy buffers, RCCL communicators
-                self._step_body(sc, sa)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            res = self._step_body(sc, sa)
-        self._graph, self._static = g, (sc, sa, res)
+        splan = {part: (None if plan[part] is None else
+                        {k: (v.clone() if torch.is_tensor(v) else v) for k, v in plan[part].items()})
+                 for part in ("enc", "dec")}
+        model._forced_plan = splan
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):                  # warm-up: allocator pools, lazy buffers, RCCL communicators
+                    self._step_body(sc, sa)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()     # graphs replay one at a time: one shared pool
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._pool):
+                res = self._step_body(sc, sa)
+        finally:
+            model._forced_plan = None
+        entry = (g, (sc, sa), splan, res)
+        self._graphs[key] = entry
+        return entry
 
     def grad_norm(self):
         """global gradient L2 norm of the last step (after the all-reduce averaging)"""

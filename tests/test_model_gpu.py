@@ -137,6 +137,35 @@ def test_train_mode_dropout_step(gpu_device, dtype):
     assert abs(ld1["loss"] - ld_eval["loss"]) < 1.5 and abs(ld1["loss"] - ld_eval["loss"]) > 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_graph_replay_matches_eager_training(gpu_device, dtype):
+    """TrainStep(use_graph=True): one hipGraph per (packed-row bucket, live-sequence bucket), the layout plan computed
+    eagerly before each replay.  Three steps on three different batches (same bucket or not) must track the eager
+    trainer: same losses, same parameters up to the summation-order differences of the rounded-up row counts."""
+    from deepsvg_amd.trainer import TrainStep
+    cfg = H.build_cfg("hier")
+    cfg.dropout = 0.1
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 555)
+    batches = [make_batch(48, seed=s) for s in (11, 12, 11)]
+    runs = {}
+    for use_graph in (False, True):
+        torch.manual_seed(1234)
+        model = _hip_model(cfg, sd, dtype).train()
+        ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=1e-3, use_graph=use_graph)
+        losses = []
+        for c, a in batches:
+            ld = ts.step(c.to(DEV), a.to(DEV))
+            losses.append(float(ld["loss"]))
+        torch.cuda.synchronize()
+        runs[use_graph] = (losses, model.store.flat.detach().clone(), len(ts._graphs), model.last_packing)
+    assert runs[True][2] >= 1 and runs[True][3] is not None
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    for a, b in zip(runs[True][0], runs[False][0]):
+        assert abs(a - b) <= tol * abs(b), (runs[True][0], runs[False][0])
+    diff = (runs[True][1] - runs[False][1]).abs().max().item()
+    assert diff <= (2e-4 if dtype == torch.float32 else 5e-3), f"parameters diverged by {diff:.2e} after 3 steps"
+
+
 def test_reference_extended_mask_aliasing_on_this_device(gpu_device):
     """Evidence for DESIGN.md: what does the reference's in-place overlapping add (model/utils.py:28) yield on
     torch-ROCm?  (the canonical mask is mask | mask<<3)"""
