@@ -144,12 +144,17 @@ class TrainStep:
                         {k: (v.clone() if torch.is_tensor(v) else v) for k, v in plan[part].items()})
                  for part in ("enc", "dec")}
         model._forced_plan = splan
+        # the warm-up steps (allocator pools, lazy buffers, RCCL communicators) must not train the model
+        state = [model.store.flat, self.m, self.v, self.step_count, self.seed]
+        saved = [t.clone() for t in state]
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(2):                  # warm-up: allocator pools, lazy buffers, RCCL communicators
+                for _ in range(2):
                     self._step_body(sc, sa)
+                for t, s0 in zip(state, saved):
+                    t.copy_(s0)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             if self._pool is None:

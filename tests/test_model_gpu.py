@@ -162,8 +162,11 @@ def test_graph_replay_matches_eager_training(gpu_device, dtype):
     tol = 2e-4 if dtype == torch.float32 else 2e-2
     for a, b in zip(runs[True][0], runs[False][0]):
         assert abs(a - b) <= tol * abs(b), (runs[True][0], runs[False][0])
-    diff = (runs[True][1] - runs[False][1]).abs().max().item()
-    assert diff <= (2e-4 if dtype == torch.float32 else 5e-3), f"parameters diverged by {diff:.2e} after 3 steps"
+    # Adam moves every weight by ~lr per step whatever the gradient's size, so a rounding-level gradient difference can
+    # show up as a fraction of a step on a few weights: bound the worst weight by 1.5 steps and the mean tightly
+    d = (runs[True][1] - runs[False][1]).abs()
+    assert d.max().item() <= 1.5e-3, f"parameters diverged by {d.max().item():.2e} after 3 steps"
+    assert d.mean().item() <= (2e-6 if dtype == torch.float32 else 1e-4), f"mean divergence {d.mean().item():.2e}"
 
 
 def test_reference_extended_mask_aliasing_on_this_device(gpu_device):
