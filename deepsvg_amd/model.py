@@ -209,6 +209,8 @@ class ParamStore:
         self.index = {}          # id(param) -> (offset, numel, shape)
         self.params = []
         self.total = 0
+        self._lp_views = {}      # id(param) -> view of the bf16 image (views are re-used: ~2000 lookups per step)
+        self._grad_views = [{}, {}]
 
     def _flatten(self, device):
         params = [p for p in self.module.parameters()]
@@ -228,6 +230,8 @@ class ParamStore:
         self.flat, self.index, self.params, self.total = flat, index, params, total
         self.flat_lp = None
         self.gbuf = [None, None]
+        self._lp_views = {}
+        self._grad_views = [{}, {}]
 
     def ensure(self, device, dtype):
         params = self.params
@@ -242,29 +246,42 @@ class ParamStore:
         if dtype != torch.float32:
             if self.flat_lp is None or self.flat_lp.dtype != dtype:
                 self.flat_lp = torch.empty(self.flat.numel(), dtype=dtype, device=device)
+                self._lp_views = {}
             ops.cast_weights(self.flat, self.flat_lp)
 
     def lp(self, param):
+        v = self._lp_views.get(id(param))
+        if v is not None:
+            return v
         ent = self.index.get(id(param))
         if ent is None or self.flat_lp is None:
             return None
         o, n, shape = ent
-        return self.flat_lp[o:o + n].view(shape)
+        v = self._lp_views[id(param)] = self.flat_lp[o:o + n].view(shape)
+        return v
 
     def grad_buffer(self, which=0):
         if self.gbuf[which] is None:
             self.gbuf[which] = torch.zeros(self.flat.numel(), dtype=torch.float32, device=self.flat.device)
+            self._grad_views[which] = {}
         return self.gbuf[which]
 
+    def _grad_view(self, param, which):
+        v = self._grad_views[which].get(id(param))
+        if v is None:
+            ent = self.index.get(id(param))
+            if ent is None:
+                return None
+            o, n, shape = ent
+            buf = self.grad_buffer(which)
+            v = self._grad_views[which][id(param)] = buf[o:o + n].view(shape)
+        return v
+
     def grad_view(self, param):
-        ent = self.index.get(id(param))
-        if ent is None:
-            return None
-        o, n, shape = ent
-        v = self.grad_buffer(0)[o:o + n].view(shape)
+        v = self._grad_view(param, 0)
         # autograd accumulates into an existing .grad: never hand it a view that aliases that .grad
-        if param.grad is not None and param.grad.data_ptr() == v.data_ptr():
-            v = self.grad_buffer(1)[o:o + n].view(shape)
+        if v is not None and param.grad is not None and param.grad.data_ptr() == v.data_ptr():
+            v = self._grad_view(param, 1)
         return v
 
 

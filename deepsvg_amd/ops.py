@@ -75,68 +75,103 @@ def _rowmajor(t):
 # ------------------------------------------------------------------------------------------------
 # GEMM
 # ------------------------------------------------------------------------------------------------
-def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=0, gate=None, gate_scale=1.0,
-         drop_p=0.0, drop_site=0, a_drop_p=0.0, a_drop_site=0, seed=None, out=None, out_dtype=None,
-         accumulate=False, split_k=1, impl=0, rowsum=None):
-    """C[M,N] = epi(sum_k A(m,k) B(n,k)).  a: [M,K] if a_kc else [K,M]; b: [N,K] if b_kc else [K,N].
-    rowsum (fp32 [M], only with split_k > 1): also rowsum[m] = sum_k A(m,k) (bias gradient of a weight-grad GEMM)."""
-    _chk(a, b, bias, res, gate, seed, out)
+_GEMM_CACHE = {}        # call signature (everything but the pointers) -> (validated descriptor, M, N, out dtype, ws bytes)
+
+
+def _gemm_build(a, b, a_kc, b_kc, bias, res, res_pre, act, gate, gate_scale, drop_p, drop_site, a_drop_p, a_drop_site,
+                seed, out, out_dtype, accumulate, split_k, impl, rowsum):
+    """full validation + a descriptor with every non-pointer field filled (cached per call signature by gemm)"""
     _rowmajor(a), _rowmajor(b)
     assert a.dtype == b.dtype
     M, K = (a.shape if a_kc else (a.shape[1], a.shape[0]))
     N, Kb = (b.shape if b_kc else (b.shape[1], b.shape[0]))
     assert K == Kb, f"gemm: inner dims differ ({K} vs {Kb})"
-    if out is None:
-        out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)
-    _rowmajor(out)
-    assert tuple(out.shape) == (M, N)
-    assert out.dtype in (a.dtype, torch.float32)
+    odt = out.dtype if out is not None else (out_dtype or a.dtype)
+    assert odt in (a.dtype, torch.float32)
     d = _l.GemmDesc()
     d.dtype = _dt(a)
     d.M, d.N, d.K = M, N, K
-    d.A, d.lda, d.a_kc = a.data_ptr(), a.stride(0), int(a_kc)
-    d.B, d.ldb, d.b_kc = b.data_ptr(), b.stride(0), int(b_kc)
-    d.C, d.ldc, d.c_f32 = out.data_ptr(), out.stride(0), int(out.dtype == torch.float32)
+    d.lda, d.a_kc = a.stride(0), int(a_kc)
+    d.ldb, d.b_kc = b.stride(0), int(b_kc)
+    d.c_f32 = int(odt == torch.float32)
+    if out is not None:
+        _rowmajor(out)
+        assert tuple(out.shape) == (M, N)
+        d.ldc = out.stride(0)
+    else:
+        d.ldc = N
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
-        d.bias = bias.data_ptr()
     if res is not None:
         _rowmajor(res)
         assert res.dtype == a.dtype and tuple(res.shape) == (M, N)
-        d.res, d.ldres, d.res_pre = res.data_ptr(), res.stride(0), int(res_pre)
+        d.ldres, d.res_pre = res.stride(0), int(res_pre)
     d.act = act
     if gate is not None:
         _rowmajor(gate)
         assert gate.dtype == a.dtype and tuple(gate.shape) == (M, N)
-        d.gate, d.ldgate, d.gate_scale = gate.data_ptr(), gate.stride(0), float(gate_scale)
+        d.ldgate, d.gate_scale = gate.stride(0), float(gate_scale)
     d.drop_p, d.drop_site = float(drop_p), int(drop_site)
     d.a_drop_p, d.a_drop_site, d.a_drop_ld = float(a_drop_p), int(a_drop_site), a.shape[1]
     if drop_p > 0 or a_drop_p > 0:
         assert seed is not None and seed.dtype == torch.int64
-        d.seed = seed.data_ptr()
     d.accumulate = int(accumulate)
     d.impl = impl
-    ws = None
+    ws_bytes = 0
     if split_k > 1:
-        assert out.dtype == torch.float32 and out.is_contiguous()
-        nbytes = _l.load().dsvg_gemm_workspace_bytes(M, N, split_k)
-        ws = _ws(nbytes, a.device)
-        d.split_k, d.workspace, d.workspace_bytes = split_k, ws.data_ptr(), ws.numel() * 4
+        assert odt == torch.float32 and (out is None or out.is_contiguous())
+        ws_bytes = _l.load().dsvg_gemm_workspace_bytes(M, N, split_k)
+        d.split_k = split_k
         if rowsum is not None:
             assert rowsum.dtype == torch.float32 and rowsum.is_contiguous() and rowsum.numel() == M
-            d.rowsum = rowsum.data_ptr()
     else:
         assert rowsum is None, "rowsum needs split_k > 1"
+    return d, M, N, odt, ws_bytes
+
+
+def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=0, gate=None, gate_scale=1.0,
+         drop_p=0.0, drop_site=0, a_drop_p=0.0, a_drop_site=0, seed=None, out=None, out_dtype=None,
+         accumulate=False, split_k=1, impl=0, rowsum=None):
+    """C[M,N] = epi(sum_k A(m,k) B(n,k)).  a: [M,K] if a_kc else [K,M]; b: [N,K] if b_kc else [K,N].
+    rowsum (fp32 [M], only with split_k > 1): also rowsum[m] = sum_k A(m,k) (bias gradient of a weight-grad GEMM).
+    The descriptor of a call signature (shapes, strides, options - everything but the pointers) is validated and
+    built once and re-used: the Python dispatch of the ~250 GEMMs of a train step is otherwise as long as the step."""
+    _chk(a, b, bias, res, gate, seed, out)
+    key = (a.dtype, a.shape, a.stride(0), b.shape, b.stride(0), a_kc, b_kc, bias is not None,
+           None if res is None else (res.shape, res.stride(0)), res_pre, act,
+           None if gate is None else (gate.shape, gate.stride(0)), gate_scale, drop_p, drop_site, a_drop_p,
+           a_drop_site, out_dtype if out is None else (out.dtype, out.shape, out.stride(0), out.stride(1)),
+           accumulate, split_k, impl, rowsum is not None)
+    ent = _GEMM_CACHE.get(key)
+    if ent is None:
+        ent = _gemm_build(a, b, a_kc, b_kc, bias, res, res_pre, act, gate, gate_scale, drop_p, drop_site, a_drop_p,
+                          a_drop_site, seed, out, out_dtype, accumulate, split_k, impl, rowsum)
+        if len(_GEMM_CACHE) < 4096:
+            _GEMM_CACHE[key] = ent
+    d, M, N, odt, ws_bytes = ent
+    if out is None:
+        out = torch.empty((M, N), dtype=odt, device=a.device)
+    d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.res = res.data_ptr() if res is not None else None
+    d.gate = gate.data_ptr() if gate is not None else None
+    d.seed = seed.data_ptr() if (seed is not None and (drop_p > 0 or a_drop_p > 0)) else None
+    d.rowsum = rowsum.data_ptr() if rowsum is not None else None
+    ws = None
+    if ws_bytes:
+        ws = _ws(ws_bytes, a.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    L = _l.load()
     if PROFILE_ON and _TAG is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        _l.check(_l.load().dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
+        _l.check(L.dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
         ev1.record()
         esz = 2 if a.dtype == torch.bfloat16 else 4
         PROFILE.append((_TAG, ev0, ev1, 2.0 * d.M * d.N * d.K,
                         float(esz * (d.M * d.K + d.N * d.K) + out.element_size() * d.M * d.N)))
         return out
-    _l.check(_l.load().dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
+    _l.check(L.dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
     return out
 
 
