@@ -282,7 +282,9 @@ class ParamStore:
         # autograd accumulates into an existing .grad: never hand it a view that aliases that .grad
         if v is not None and param.grad is not None and param.grad.data_ptr() == v.data_ptr():
             v = self._grad_view(param, 1)
-        return v
+        # a fresh tensor object per call: AccumulateGrad only adopts ("steals") a gradient nobody else references,
+        # otherwise it deep-copies it - the cached view itself would cost one copy launch per parameter per step
+        return v.detach() if v is not None else None
 
 
 def _compute_dtype_default():

@@ -108,6 +108,8 @@ def test_param_store_flat_views_and_grad_aliasing(emulated_ops):
     for p in model.parameters():
         off = store.index[id(p)][0]
         assert p.data_ptr() == base + 4 * off and off % 8 == 0
+        # autograd adopted the view of the flat gradient buffer (a deep copy would cost one launch per parameter)
+        assert p.grad.data_ptr() == store.grad_buffer(0).data_ptr() + 4 * off, "p.grad is not a view of the flat buffer"
     g1 = {n: p.grad.clone() for n, p in model.named_parameters()}
     # second backward WITHOUT zeroing: autograd must accumulate (2x), not alias-and-double (4x) or overwrite (1x)
     step()
