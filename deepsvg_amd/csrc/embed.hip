@@ -125,7 +125,8 @@ extern "C" int dsvg_visible_first(const int32_t* visible, int64_t n, int32_t* ne
     return 0;
 }
 
-// dst[g * S + s, :] = src[idx[g] * S + s, :] for g < n_groups  (whole-sequence row gather; 16-byte pieces)
+// dst[g * S + s, :] = src[max(idx[g], 0) * S + s, :] for g < n_groups  (whole-sequence row gather; 16-byte pieces;
+// a negative index marks list padding and reads group 0)
 template <typename T>
 __global__ void gather_groups_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx, T* __restrict__ dst,
                                      long long n_groups, int S, int width) {
@@ -139,7 +140,7 @@ __global__ void gather_groups_kernel(const T* __restrict__ src, const int32_t* _
         const long long g = row / S;
         const int sidx = (int)(row - g * S);
         reinterpret_cast<raw4*>(dst + row * width)[c] =
-            reinterpret_cast<const raw4*>(src + ((long long)idx[g] * S + sidx) * width)[c];
+            reinterpret_cast<const raw4*>(src + ((long long)max(idx[g], 0) * S + sidx) * width)[c];
     }
 }
 extern "C" int dsvg_gather_groups(int32_t dtype, const void* src, const int32_t* idx, void* dst, int64_t n_groups,

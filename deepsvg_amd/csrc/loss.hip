@@ -107,14 +107,18 @@ __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ sum_count,
                                                             const float* __restrict__ gscale, float coef,
                                                             T* __restrict__ dlogits, long long ld_d, long long rows,
-                                                            int C) {
+                                                            int C, const int32_t* __restrict__ tok_idx) {
+    // tok_idx != null: output token i is source token tok_idx[i] (a compact list of the tokens that carry loss;
+    // negative = padding of the list -> a zero row); `rows` counts OUTPUT rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float g = coef * (gscale ? *gscale : 1.f) / sum_count[1];
-    for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
-        const float wr = w ? w[r] : 1.f;
-        const long long tok = r / group;
-        const int slot = (int)(r % group);
-        T* q = dlogits + tok * ld_d + slot * (long long)C;
+    for (long long ro = (long long)blockIdx.x * 4 + wave; ro < rows; ro += (long long)gridDim.x * 4) {
+        const long long tok_o = ro / group;
+        const int slot = (int)(ro % group);
+        const long long tok = tok_idx ? (long long)tok_idx[tok_o] : tok_o;
+        const long long r = tok * group + slot;                 // source row
+        const float wr = tok < 0 ? 0.f : (w ? w[r] : 1.f);
+        T* q = dlogits + tok_o * ld_d + slot * (long long)C;
         if (wr == 0.f) {
             for (int c = lane; c < C; c += 64) Elem<T>::st(q + c, 0.f);
         } else {
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const T* __restrict_
             }
         }
         if (slot == group - 1) {   // zero the row padding so padded-K GEMMs read zeros
-            for (long long c = (long long)group * C + lane; c < ld_d; c += 64) Elem<T>::st(dlogits + tok * ld_d + c, 0.f);
+            for (long long c = (long long)group * C + lane; c < ld_d; c += 64) Elem<T>::st(dlogits + tok_o * ld_d + c, 0.f);
         }
     }
 }
@@ -160,7 +164,8 @@ extern "C" int dsvg_masked_ce_fwd(int32_t dtype, const void* logits, int64_t ld,
 
 extern "C" int dsvg_masked_ce_bwd(int32_t dtype, const void* logits, int64_t ld, int32_t group, const int32_t* target,
                                   const float* w, const float* lse, const float* sum_count, const float* gscale,
-                                  float coef, void* dlogits, int64_t ld_d, int64_t rows, int32_t C, void* stream) {
+                                  float coef, void* dlogits, int64_t ld_d, int64_t rows, int32_t C,
+                                  const int32_t* tok_idx, void* stream) {
     DSVG_CHECK_ARG(logits && target && lse && sum_count && dlogits && rows > 0 && C > 0 && group > 0,
                    "masked_ce_bwd: bad args");
     DSVG_CHECK_ARG(ld_d >= (int64_t)group * C, "masked_ce_bwd: ld_d too small");
@@ -169,12 +174,86 @@ extern "C" int dsvg_masked_ce_bwd(int32_t dtype, const void* logits, int64_t ld,
     if (dtype == DSVG_F32)
         hipLaunchKernelGGL(masked_ce_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)logits, (long long)ld,
                            group, target, w, lse, sum_count, gscale, coef, (float*)dlogits, (long long)ld_d,
-                           (long long)rows, C);
+                           (long long)rows, C, tok_idx);
     else if (dtype == DSVG_BF16)
         hipLaunchKernelGGL(masked_ce_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)logits,
                            (long long)ld, group, target, w, lse, sum_count, gscale, coef, (bf16_t*)dlogits,
-                           (long long)ld_d, (long long)rows, C);
+                           (long long)ld_d, (long long)rows, C, tok_idx);
     else { dsvg_set_error("masked_ce_bwd: bad dtype"); return -1; }
     DSVG_LAUNCH_CHECK("masked_ce_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tokens that carry argument loss: live[i] = index of the i-th token t with any w[t*group + a] != 0 (ascending),
+// entries past the count = -1 (capacity n_tok), *count = number of such tokens.  The backward pass of the
+// 2827-wide argument head then runs on that compact list (about 30 % of the decoder tokens): rows of dlogits that
+// the loss masks out are exact zeros (loss.py:51-54) and contribute neither to dX nor to dW.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void live_rows_kernel(const float* __restrict__ w, long long n_tok, int group,
+                                                         int32_t* __restrict__ live, int32_t* __restrict__ count) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (long long base = 0; base < n_tok; base += 1024) {
+        const long long t = base + threadIdx.x;
+        int v = 0;
+        if (t < n_tok)
+            for (int a = 0; a < group; ++a) v |= (w[t * group + a] != 0.f) ? 1 : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int u = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+            __syncthreads();
+            part[threadIdx.x] += u;
+            __syncthreads();
+        }
+        if (v) live[carry + part[threadIdx.x] - 1] = (int32_t)t;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    for (long long i = carry + threadIdx.x; i < n_tok; i += 1024) live[i] = -1;
+    if (threadIdx.x == 0) *count = carry;
+}
+extern "C" int dsvg_live_rows(const float* w, int64_t n_tok, int32_t group, int32_t* live, int32_t* count,
+                              void* stream) {
+    DSVG_CHECK_ARG(w && live && count && n_tok > 0 && group > 0 && n_tok < (1ll << 31), "live_rows: bad args");
+    hipLaunchKernelGGL(live_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)n_tok, group, live,
+                       count);
+    DSVG_LAUNCH_CHECK("live_rows");
+    return 0;
+}
+
+// dst[idx[i], :] = src[i, :] for idx[i] >= 0 (rows of dst not named by idx keep their content)
+template <typename T>
+__global__ void scatter_rows_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx, T* __restrict__ dst,
+                                    long long n_rows, int width) {
+    typedef typename Elem<T>::raw4 raw4;
+    const int cpr = width / 4;
+    const long long total = n_rows * cpr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / cpr;
+        const int c = (int)(i - row * cpr);
+        const int t = idx[row];
+        if (t >= 0) reinterpret_cast<raw4*>(dst + (long long)t * width)[c] = reinterpret_cast<const raw4*>(src + row * width)[c];
+    }
+}
+extern "C" int dsvg_scatter_rows(int32_t dtype, const void* src, const int32_t* idx, void* dst, int64_t n_rows,
+                                 int32_t width, void* stream) {
+    DSVG_CHECK_ARG(src && idx && dst && n_rows > 0 && width > 0 && (width % 4) == 0, "scatter_rows: bad args");
+    const long long total = n_rows * (long long)(width / 4);
+    const int nb = (int)min((long long)dsvg_cdiv(total, 256), 8192LL);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_F32)
+        hipLaunchKernelGGL(scatter_rows_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)src, idx, (float*)dst,
+                           (long long)n_rows, width);
+    else if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(scatter_rows_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)src, idx,
+                           (bf16_t*)dst, (long long)n_rows, width);
+    else { dsvg_set_error("scatter_rows: bad dtype"); return -1; }
+    DSVG_LAUNCH_CHECK("scatter_rows");
     return 0;
 }

@@ -449,3 +449,37 @@ class MaskedCEFn(torch.autograd.Function):
         mult = 4 if logits2d.dtype == torch.float32 else 8
         dlogits = ops.masked_ce_bwd(logits2d, target, w, lse, sc, g, 1.0, ctx.C_, ctx.group, pad_to=mult)
         return dlogits, None, None, None, None, None
+
+
+class ArgsHeadLossFn(torch.autograd.Function):
+    """loss_args = masked CE over the argument logits, with the backward pass of the argument head (args_fcn,
+    deepsvg/model/model.py:228-246) folded in: logits = x W^T + b were already computed by the model (they are part
+    of its output); here only the tokens that carry argument loss are differentiated.  dlogits rows of every other
+    token are exact zeros (loss.py:51-54), so dX / dW / db come from a compact [n_live, 2827] gradient instead of the
+    dense [T, 2827] one (about 30 % of the decoder tokens on the synthetic distribution).
+    `live` = (token list int32 padded with -1, number of rows to process >= number of listed tokens)."""
+
+    @staticmethod
+    def forward(ctx, rt, x, weight, bias, logits2d, target, w, C_, group, count_fn, live):
+        lse, sc = ops.masked_ce_fwd(logits2d, target, w, C_, group)
+        if count_fn is not None:
+            sc = torch.stack([sc[0], count_fn(sc[1].clone()).to(sc.dtype).reshape(())])
+        ctx.rt, ctx.C_, ctx.group, ctx.n_rows = rt, C_, group, int(live[1])
+        ctx.save_for_backward(x, weight, bias, logits2d, target, w, lse, sc, live[0])
+        return sc[0] / sc[1], sc
+
+    @staticmethod
+    def backward(ctx, dloss, _dsc):
+        rt = ctx.rt
+        x, weight, bias, logits2d, target, w, lse, sc, live_idx = ctx.saved_tensors
+        g = dloss.reshape(1).to(torch.float32).contiguous()
+        R = min(ctx.n_rows, x.shape[0])
+        idx = live_idx[:R]
+        mult = 4 if logits2d.dtype == torch.float32 else 8
+        dl = ops.masked_ce_bwd(logits2d, target, w, lse, sc, g, 1.0, ctx.C_, ctx.group, pad_to=mult, tok_idx=idx)
+        xc = ops.gather_groups(x, idx, R, 1)
+        dw, db = _wbgrad(rt, weight, bias, dl, xc)
+        dxc = ops.gemm(dl, rt.w(weight), b_kc=False)
+        dx = torch.zeros_like(x)
+        ops.scatter_rows(dxc, idx, dx)
+        return None, dx, dw, db, None, None, None, None, None, None, None

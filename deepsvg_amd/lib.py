@@ -71,7 +71,9 @@ SIGNATURES = {
     "dsvg_loss_targets": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, vp]),
     "dsvg_masked_ce_fwd": (c_i32, [c_i32, vp, c_i64, c_i32, vp, vp, c_i64, c_i32, vp, vp, vp, c_i64, vp]),
     "dsvg_masked_ce_workspace_bytes": (c_i64, [c_i64]),
-    "dsvg_masked_ce_bwd": (c_i32, [c_i32, vp, c_i64, c_i32, vp, vp, vp, vp, vp, c_f32, vp, c_i64, c_i64, c_i32, vp]),
+    "dsvg_masked_ce_bwd": (c_i32, [c_i32, vp, c_i64, c_i32, vp, vp, vp, vp, vp, c_f32, vp, c_i64, c_i64, c_i32, vp, vp]),
+    "dsvg_live_rows": (c_i32, [vp, c_i64, c_i32, vp, vp, vp]),
+    "dsvg_scatter_rows": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, vp]),
     "dsvg_sumsq": (c_i32, [vp, c_i64, vp, vp, c_i64, vp]),
     "dsvg_sumsq_workspace_bytes": (c_i64, [c_i64]),
     "dsvg_adamw_step": (c_i32, [vp, vp, vp, vp, c_i64, vp, c_f32, c_f32, c_f32, c_f32, vp, vp, c_f32, c_f32, vp]),

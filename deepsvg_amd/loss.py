@@ -46,9 +46,18 @@ class SVGLoss(nn.Module):
         N, G, S1 = tgt_commands.shape
         n_args = tgt_args.shape[-1]
         S = S1 - 1
-        tc = tgt_commands.to(device=device, dtype=torch.float32).contiguous().view(N * G, S1)
-        ta = tgt_args.to(device=device, dtype=torch.float32).contiguous().view(N * G, S1, n_args)
-        cmd_tgt, cmd_w, arg_tgt, arg_w, vis_tgt = ops.loss_targets(tc, ta, self._cam(device), EOS_ID)
+        # the model's forward may have prepared the targets and the list of tokens that carry argument loss
+        # (SVGTransformer._plan): the argument head's backward then runs on those tokens only
+        head = output.get("_dsvg_head")
+        if head is not None and not (head["tgt_commands"] is tgt_commands and head["tgt_args"] is tgt_args
+                                     and torch.is_grad_enabled()):
+            head = None
+        if head is not None:
+            cmd_tgt, cmd_w, arg_tgt, arg_w, vis_tgt = head["targets"]
+        else:
+            tc = tgt_commands.to(device=device, dtype=torch.float32).contiguous().view(N * G, S1)
+            ta = tgt_args.to(device=device, dtype=torch.float32).contiguous().view(N * G, S1, n_args)
+            cmd_tgt, cmd_w, arg_tgt, arg_w, vis_tgt = ops.loss_targets(tc, ta, self._cam(device), EOS_ID)
 
         red = self.count_reducer
         if cfg.decode_stages == 2:
@@ -61,8 +70,13 @@ class SVGLoss(nn.Module):
         al = args_logits.reshape(N * G * S, n_args * self.args_dim)
         loss_cmd, sc_c = Fn.MaskedCEFn.apply(cl, cmd_tgt.view(-1), cmd_w.view(-1), cfg.n_commands, 1,
                                              (lambda c: red("cmd", c)) if red else None)
-        loss_args, sc_a = Fn.MaskedCEFn.apply(al, arg_tgt.view(-1), arg_w.view(-1), self.args_dim, n_args,
-                                              (lambda c: red("args", c)) if red else None)
+        if head is not None:
+            loss_args, sc_a = Fn.ArgsHeadLossFn.apply(head["rt"], head["x"], head["weight"], head["bias"], al.detach(),
+                                                      arg_tgt.view(-1), arg_w.view(-1), self.args_dim, n_args,
+                                                      (lambda c: red("args", c)) if red else None, head["live"])
+        else:
+            loss_args, sc_a = Fn.MaskedCEFn.apply(al, arg_tgt.view(-1), arg_w.view(-1), self.args_dim, n_args,
+                                                  (lambda c: red("args", c)) if red else None)
         loss = loss + weights["loss_cmd_weight"] * loss_cmd + weights["loss_args_weight"] * loss_args
         res.update({"loss": loss, "loss_cmd": loss_cmd, "loss_args": loss_args})
         return res

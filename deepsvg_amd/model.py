@@ -332,6 +332,9 @@ class SVGTransformer(nn.Module):
         # backward of the second decoder stage only over the sequences of visible target groups (exact under SVGLoss)
         self.skip_invisible_backward = os.environ.get("DSVG_SKIP_INVISIBLE", "1") != "0"
         self.last_live = None
+        # backward of the argument head only over the tokens that carry argument loss (exact under SVGLoss)
+        self.compact_head_backward = os.environ.get("DSVG_COMPACT_HEAD", "1") != "0"
+        self.last_head_rows = None
         self._forced_plan = None
 
     # ---- runtime plumbing ------------------------------------------------------------------------
@@ -371,15 +374,15 @@ class SVGTransformer(nn.Module):
                 seq_off, live)
         return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps, live)
 
-    def make_plan(self, commands_enc, args_enc, commands_dec, want_grad=True):
+    def make_plan(self, commands_enc, args_enc, commands_dec, want_grad=True, args_dec=None):
         """the data-dependent layout plan of one forward (see _plan), for callers that replay captured hipGraphs"""
         forced, self._forced_plan = self._forced_plan, None
         try:
-            return self._plan(commands_enc, args_enc, commands_dec, want_grad)
+            return self._plan(commands_enc, args_enc, commands_dec, want_grad, args_dec)
         finally:
             self._forced_plan = forced
 
-    def _plan(self, commands_enc, args_enc, commands_dec, want_grad):
+    def _plan(self, commands_enc, args_enc, commands_dec, want_grad, args_dec=None):
         """Data-dependent layout decisions of one forward, made up front with ONE device->host read:
           * packed first encoder stage (valid tokens only), see _encode_stage1_packed;
           * visible-first order of the second decoder stage: SVGLoss excludes every position of an invisible target
@@ -390,7 +393,7 @@ class SVGTransformer(nn.Module):
         cfg = self.cfg
         if self._forced_plan is not None:       # a trainer replaying bucketed hipGraphs supplies the plan (make_plan)
             return self._forced_plan
-        plan = {"enc": None, "dec": None}
+        plan = {"enc": None, "dec": None, "loss": None}
         ref = commands_enc if commands_enc is not None else commands_dec
         if ref is None or (ref.is_cuda and torch.cuda.is_current_stream_capturing()):
             return plan
@@ -412,12 +415,25 @@ class SVGTransformer(nn.Module):
             new_of_old, old_of_new, nvis = ops.visible_first(vis)
             plan["dec"] = dict(new_of_old=new_of_old, old_of_new=old_of_new)
             counts.append(nvis)
+        if commands_dec is not None and want_grad and self.compact_head_backward and args_dec is not None:
+            # targets / weights of SVGLoss (loss.py:33-54) and the tokens that carry argument loss: the backward of
+            # the 2827-wide argument head then runs on those tokens only (functional.ArgsHeadLossFn)
+            N, G, S1 = commands_dec.shape
+            tc = commands_dec.to(torch.float32).contiguous().view(N * G, S1)
+            ta = args_dec.to(torch.float32).contiguous().view(N * G, S1, -1)
+            cam = self.cmd_args_mask.to(device=tc.device, dtype=torch.float32).contiguous()
+            targets = ops.loss_targets(tc, ta, cam, EOS_ID)
+            live, n_live = ops.live_rows(targets[3].view(-1), ta.shape[-1])
+            plan["loss"] = dict(targets=targets, live=live)
+            counts.append(n_live)
         if counts:
             vals = (torch.cat(counts) if len(counts) > 1 else counts[0]).tolist()      # the one host read
             if plan["enc"] is not None:
                 plan["enc"]["total"] = int(vals.pop(0))
             if plan["dec"] is not None:
                 plan["dec"]["n_visible"] = int(vals.pop(0))
+            if plan["loss"] is not None:
+                plan["loss"]["n_live"] = int(vals.pop(0))
         return plan
 
 
@@ -523,6 +539,7 @@ class SVGTransformer(nn.Module):
         cmd_logits = Fn.LinearFn.apply(rt, out, dec.fcn.command_fcn.weight, dec.fcn.command_fcn.bias, 0, None, 0.0, 0,
                                        None)
         args_logits = Fn.LinearFn.apply(rt, out, dec.fcn.args_fcn.weight, dec.fcn.args_fcn.bias, 0, None, 0.0, 0, None)
+        self._head_in = out         # input of the heads (for the loss-side backward of the argument head)
         cmd_logits = cmd_logits.view(N, G, S, cfg.n_commands)
         args_logits = args_logits.view(N, G, S, cfg.n_args, self.args_dim)
         if vis_logits is not None:
@@ -541,7 +558,7 @@ class SVGTransformer(nn.Module):
         rt = self._runtime(device)
         mu = logsigma = None
         plan = self._plan(commands_enc if z is None else None, args_enc, commands_dec if return_tgt else None,
-                          torch.is_grad_enabled() and not encode_mode)
+                          torch.is_grad_enabled() and not encode_mode, args_dec)
         if z is None:
             zz = self._encode(rt, commands_enc, args_enc, plan)
             zz, mu, logsigma = self._bottleneck(rt, zz)
@@ -557,9 +574,21 @@ class SVGTransformer(nn.Module):
         if return_tgt:
             res["tgt_commands"] = commands_dec
             res["tgt_args"] = args_dec
+            pl = plan["loss"] if plan is not None else None
+            self.last_head_rows = None
+            if pl is not None:
+                # hand SVGLoss what it needs to differentiate the argument head on the loss-carrying tokens only
+                T_dec = self._head_in.shape[0]
+                n_rows = min(max((pl["n_live"] + 127) // 128 * 128, int(pl.get("rows", 0))), T_dec)
+                fcn = self.decoder.fcn.args_fcn
+                res["_dsvg_head"] = dict(rt=rt, x=self._head_in, weight=fcn.weight, bias=fcn.bias,
+                                         targets=pl["targets"], live=(pl["live"], n_rows),
+                                         tgt_commands=commands_dec, tgt_args=args_dec)
+                self.last_head_rows = (pl["n_live"], T_dec)
             if cfg.use_vae and mu is not None:
                 res["mu"] = mu.view(mu.shape[0], 1, 1, -1)
                 res["logsigma"] = logsigma.view(logsigma.shape[0], 1, 1, -1)
+        self._head_in = None
         return res
 
     # ---- sampling (model.py:414-459; inference-only host glue on the logits) -------------------------

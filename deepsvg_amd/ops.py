@@ -491,10 +491,12 @@ def masked_ce_fwd(logits2d, target, w, C_, group=1):
     return lse, sc
 
 
-def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1, pad_to=8):
-    """returns dlogits as a [n_tok, group*C] view of a buffer whose token stride is padded to `pad_to` elements."""
-    _chk(logits2d, target, w, lse, sum_count, gscale)
-    n_tok = logits2d.shape[0]
+def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1, pad_to=8, tok_idx=None):
+    """returns dlogits as a [n_tok, group*C] view of a buffer whose token stride is padded to `pad_to` elements.
+    tok_idx (int32 [n_out]): compact backward - output token i is source token tok_idx[i], negative -> zero row."""
+    _chk(logits2d, target, w, lse, sum_count, gscale, tok_idx)
+    n_tok = logits2d.shape[0] if tok_idx is None else tok_idx.numel()
+    assert tok_idx is None or (tok_idx.dtype == torch.int32 and tok_idx.is_contiguous())
     rows = n_tok * group
     width = group * C_
     ld_d = (width + pad_to - 1) // pad_to * pad_to
@@ -502,9 +504,32 @@ def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1
     assert gscale is None or (gscale.dtype == torch.float32 and gscale.numel() == 1)
     _l.check(_l.load().dsvg_masked_ce_bwd(_dt(logits2d), logits2d.data_ptr(), logits2d.stride(0), group,
                                           target.data_ptr(), _p(w), lse.data_ptr(), sum_count.data_ptr(), _p(gscale),
-                                          float(coef), buf.data_ptr(), ld_d, rows, C_, _stream()),
+                                          float(coef), buf.data_ptr(), ld_d, rows, C_, _p(tok_idx), _stream()),
              "dsvg_masked_ce_bwd")
     return buf[:, :width]
+
+
+def live_rows(w, group):
+    """w float32 [n_tok * group] -> (live int32 [n_tok]: ascending tokens with any non-zero weight, -1 padded;
+    count int32 [1])"""
+    _chk(w)
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() % group == 0
+    n_tok = w.numel() // group
+    live = torch.empty(n_tok, dtype=torch.int32, device=w.device)
+    count = torch.empty(1, dtype=torch.int32, device=w.device)
+    _l.check(_l.load().dsvg_live_rows(w.data_ptr(), n_tok, group, live.data_ptr(), count.data_ptr(), _stream()),
+             "dsvg_live_rows")
+    return live, count
+
+
+def scatter_rows(src, idx, dst):
+    """dst[idx[i]] = src[i] for idx[i] >= 0"""
+    _chk(src, idx, dst)
+    assert src.is_contiguous() and dst.is_contiguous() and idx.dtype == torch.int32 and src.dtype == dst.dtype
+    assert src.shape[1] == dst.shape[1] and idx.numel() >= src.shape[0]
+    _l.check(_l.load().dsvg_scatter_rows(_dt(src), src.data_ptr(), idx.data_ptr(), dst.data_ptr(), src.shape[0],
+                                         src.shape[1], _stream()), "dsvg_scatter_rows")
+    return dst
 
 
 # ------------------------------------------------------------------------------------------------

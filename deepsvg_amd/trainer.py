@@ -93,7 +93,7 @@ class TrainStep:
         if not self.use_graph:
             return self._step_body(commands, args)
         model = self.model
-        plan = model.make_plan(commands, args, commands, True)
+        plan = model.make_plan(commands, args, commands, True, args)
         key, plan = self._bucketed(plan, commands)
         entry = self._graphs.get(key)
         if entry is None:
@@ -102,11 +102,14 @@ class TrainStep:
             graph, (sc, sa), splan, res = entry
             sc.copy_(commands)
             sa.copy_(args)
-            for part in ("enc", "dec"):
+            for part in ("enc", "dec", "loss"):
                 if splan[part] is not None:
                     for k, v in splan[part].items():
                         if torch.is_tensor(v):
                             v.copy_(plan[part][k])
+                        elif isinstance(v, tuple):
+                            for dst, src in zip(v, plan[part][k]):
+                                dst.copy_(src)
         self._note_layout(plan, commands)
         entry[0].replay()
         return entry[3]
@@ -129,6 +132,13 @@ class TrainStep:
             key.append(n_live)
         else:
             key.append(-1)
+        if plan["loss"] is not None:
+            rb = self.row_bucket
+            rows = min((plan["loss"]["n_live"] + rb - 1) // rb * rb, n_seq * (commands.shape[2] - 1))
+            plan["loss"]["rows"] = rows
+            key.append(rows)
+        else:
+            key.append(-1)
         return tuple(key), plan
 
     def _note_layout(self, plan, commands):
@@ -136,13 +146,20 @@ class TrainStep:
         m = self.model
         m.last_packing = (plan["enc"]["total"], n_seq * commands.shape[2]) if plan["enc"] is not None else None
         m.last_live = (plan["dec"]["n_visible"], n_seq) if plan["dec"] is not None else None
+        m.last_head_rows = ((plan["loss"]["n_live"], n_seq * (commands.shape[2] - 1))
+                            if plan["loss"] is not None else None)
 
     def _capture(self, key, commands, args, plan):
         model = self.model
         sc, sa = commands.clone(), args.clone()
-        splan = {part: (None if plan[part] is None else
-                        {k: (v.clone() if torch.is_tensor(v) else v) for k, v in plan[part].items()})
-                 for part in ("enc", "dec")}
+        def _static(v):
+            if torch.is_tensor(v):
+                return v.clone()
+            if isinstance(v, tuple):
+                return tuple(t.clone() for t in v)
+            return v
+        splan = {part: (None if plan[part] is None else {k: _static(v) for k, v in plan[part].items()})
+                 for part in ("enc", "dec", "loss")}
         model._forced_plan = splan
         # the warm-up steps (allocator pools, lazy buffers, RCCL communicators) must not train the model
         state = [model.store.flat, self.m, self.v, self.step_count, self.seed]

@@ -221,7 +221,16 @@ int dsvg_masked_ce_fwd(int32_t dtype, const void* logits, int64_t ld, int32_t gr
 int64_t dsvg_masked_ce_workspace_bytes(int64_t rows);
 int dsvg_masked_ce_bwd(int32_t dtype, const void* logits, int64_t ld, int32_t group, const int32_t* target,
                        const float* w, const float* lse, const float* sum_count, const float* gscale,
-                       float coef, void* dlogits, int64_t ld_d, int64_t rows, int32_t C, void* stream);
+                       float coef, void* dlogits, int64_t ld_d, int64_t rows, int32_t C,
+                       const int32_t* tok_idx, void* stream);
+/* tok_idx (optional): compact backward, output token i = source token tok_idx[i] (negative -> zero row), `rows`
+ * = output tokens * group.  dsvg_live_rows builds that list: the tokens with any non-zero weight among their
+ * `group` rows, ascending, padded with -1 up to n_tok entries; *count = their number.  Rows the loss masks out
+ * have exactly zero dlogits (deepsvg/model/loss.py:51-54), so the argument head's dX / dW need only those tokens. */
+int dsvg_live_rows(const float* w, int64_t n_tok, int32_t group, int32_t* live, int32_t* count, void* stream);
+/* dst[idx[i], :] = src[i, :] for idx[i] >= 0 (width % 4 == 0); other rows of dst are left untouched */
+int dsvg_scatter_rows(int32_t dtype, const void* src, const int32_t* idx, void* dst, int64_t n_rows,
+                      int32_t width, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Flat-buffer optimizer step: clip_grad_norm_ (deepsvg/train.py:100) + AdamW

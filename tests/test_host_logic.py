@@ -60,14 +60,16 @@ def test_packed_encoder_equals_padded_encoder(emulated_ops):
         model.load_state_dict(sd)
         model.pack_encoder = packed
         model.skip_invisible_backward = packed      # second exact skip: decoder stage-2 backward of invisible groups
+        model.compact_head_backward = packed        # third: argument-head backward on the loss-carrying tokens only
         model.eval()
         out = model(commands, args, commands, args, params={})
         ld = deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
         ld["loss"].backward()
         res[packed] = (out, ld, {n: p.grad.clone() for n, p in model.named_parameters()}, model.last_packing)
-        assert (model.last_live is not None) == packed
+        assert (model.last_live is not None) == packed and (model.last_head_rows is not None) == packed
         if packed:
             assert 0 < model.last_live[0] < model.last_live[1]
+            assert 0 < model.last_head_rows[0] < model.last_head_rows[1]
     total, dense = res[True][3]
     assert res[False][3] is None and 0 < total < dense
     for k in ("command_logits", "args_logits", "visibility_logits"):

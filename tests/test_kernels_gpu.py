@@ -473,6 +473,42 @@ def test_loss_targets_and_masked_ce(gpu_device, dtype):
         _close(d, dr, 2e-6 if dtype == torch.float32 else 1e-2, "dlogits")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_compact_ce_backward_live_rows_scatter(gpu_device, dtype):
+    """argument-head backward on the loss-carrying tokens only: token list, compact dlogits, row scatter"""
+    n_tok, group, C_ = 700, 11, 257
+    g = torch.Generator().manual_seed(4)
+    w = (torch.rand(n_tok, group, generator=g) < 0.15).float()
+    w[torch.rand(n_tok, generator=g) < 0.6] = 0.0            # most tokens carry no loss at all
+    w = w.to(DEV).view(-1).contiguous()
+    live, count = ops.live_rows(w, group)
+    elive, ecount = R.live_rows(w, group)
+    assert torch.equal(live, elive) and torch.equal(count, ecount)
+    n_live = int(count)
+    assert 0 < n_live < n_tok
+    ld = 2832
+    buf = _rand(n_tok, ld, dtype=dtype, seed=90)
+    logits = buf[:, :group * C_]
+    target = torch.randint(0, C_, (n_tok * group,), generator=g).to(torch.int32).to(DEV)
+    lse, sc = ops.masked_ce_fwd(logits, target, w, C_, group)
+    gs = torch.tensor([0.7], device=DEV)
+    rows = (n_live + 127) // 128 * 128
+    idx = live[:rows].contiguous()
+    dl = ops.masked_ce_bwd(logits, target, w, lse, sc, gs, 1.0, C_, group, pad_to=8, tok_idx=idx)
+    ref = R.masked_ce_bwd(logits, target, w, lse, sc, gs, 1.0, C_, group, pad_to=8, tok_idx=idx)
+    _close(dl, ref, 1e-6 if dtype == torch.float32 else 1e-2, "compact CE bwd")
+    assert torch.count_nonzero(dl[n_live:]) == 0
+    dense = ops.masked_ce_bwd(logits, target, w, lse, sc, gs, 1.0, C_, group, pad_to=8)
+    assert torch.equal(dl[:n_live], dense[live[:n_live].long()])
+    src = _rand(rows, 256, dtype=dtype, seed=91)
+    dst = torch.zeros(n_tok, 256, device=DEV, dtype=dtype)
+    ops.scatter_rows(src, idx, dst)
+    exp = R.scatter_rows(src, idx, torch.zeros_like(dst))
+    assert torch.equal(dst, exp)
+    back = ops.gather_groups(dst, idx, rows, 1)
+    assert torch.equal(back[:n_live], src[:n_live])
+
+
 def test_optimizer_matches_torch_adamw(gpu_device):
     n = 100003
     p0, g = _rand(n, seed=1), _rand(n, seed=2, scale=3.0)

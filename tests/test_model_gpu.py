@@ -48,7 +48,7 @@ def test_fp32_model_matches_reference_golden(gpu_device, name, packed):
     """packed: first encoder stage on the valid tokens only (default) / on the reference's padded layout"""
     g, cfg, commands, args, eps = H.golden_setup(name)
     model = _hip_model(cfg, H.weights_for(deepsvg_amd.SVGTransformer(cfg), g["wseed"]))
-    model.pack_encoder = model.skip_invisible_backward = packed
+    model.pack_encoder = model.skip_invisible_backward = model.compact_head_backward = packed
     model.eval()
     out, ld, grads = _fwd_bwd(model, cfg, commands, args, eps)
     H.check_against_golden(g, out, ld, grads, logit_rtol=1e-3, logit_atol=1e-5, loss_tol=1e-4, grad_norm_rtol=1e-3)
@@ -85,11 +85,12 @@ def test_packed_encoder_equals_padded_encoder(gpu_device, dtype):
     res = {}
     for packed in (True, False):
         model = _hip_model(cfg, sd, dtype).eval()
-        model.pack_encoder = model.skip_invisible_backward = packed
+        model.pack_encoder = model.skip_invisible_backward = model.compact_head_backward = packed
         res[packed] = _fwd_bwd(model, cfg, commands, args) + (model.last_packing,)
-        assert (model.last_live is not None) == packed
+        assert (model.last_live is not None) == packed and (model.last_head_rows is not None) == packed
         if packed:
             print(f"decoder stage 2 backward: {model.last_live[0]} of {model.last_live[1]} sequences")
+            print(f"argument head backward: {model.last_head_rows[0]} of {model.last_head_rows[1]} tokens")
     total, dense = res[True][3]
     print(f"packed encoder: {total} of {dense} tokens ({100.0 * total / dense:.1f} %)")
     assert res[False][3] is None and 0 < total < 0.6 * dense

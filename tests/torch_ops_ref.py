@@ -272,7 +272,7 @@ def visible_first(visible):
 
 
 def gather_groups(src, idx, n_groups, S, out=None):
-    rows = (idx[:n_groups].long().unsqueeze(1) * S + torch.arange(S, device=src.device)).reshape(-1)
+    rows = (idx[:n_groups].long().clamp(min=0).unsqueeze(1) * S + torch.arange(S, device=src.device)).reshape(-1)
     if out is None:
         return src[rows].clone()
     out[:n_groups * S] = src[rows]
@@ -402,7 +402,32 @@ def masked_ce_fwd(logits2d, target, w, C_, group=1):
     return lse, sc
 
 
-def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1, pad_to=8):
+def live_rows(w, group):
+    live_tok = (w.reshape(-1, group) != 0).any(1)
+    idx = live_tok.nonzero().squeeze(1).to(torch.int32)
+    live = torch.full((live_tok.numel(),), -1, dtype=torch.int32, device=w.device)
+    live[:idx.numel()] = idx
+    return live, torch.tensor([idx.numel()], dtype=torch.int32, device=w.device)
+
+
+def scatter_rows(src, idx, dst):
+    sel = idx[:src.shape[0]].long()
+    ok = sel >= 0
+    dst[sel[ok]] = src[ok]
+    return dst
+
+
+def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1, pad_to=8, tok_idx=None):
+    if tok_idx is not None:     # compact backward: dense result, then pick the listed tokens (negative -> zero row)
+        dense = masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group, pad_to)
+        sel = tok_idx.long()
+        out = dense[sel.clamp(min=0)].clone()
+        out[sel < 0] = 0
+        width = group * C_
+        ld = (width + pad_to - 1) // pad_to * pad_to
+        buf = torch.zeros((sel.numel(), ld), dtype=logits2d.dtype, device=logits2d.device)
+        buf[:, :width] = out
+        return buf[:, :width]
     rows = _ce_rows(logits2d, C_, group)
     n_tok = logits2d.shape[0]
     ww = torch.ones(rows.shape[0], device=rows.device) if w is None else w
