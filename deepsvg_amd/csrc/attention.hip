@@ -14,11 +14,12 @@
 // bf16 MFMA variant for 17..32-token sequences (attention_mfma.hip)
 bool dsvg_attention_mfma_ok(int32_t dtype, int32_t S, int32_t n_heads);
 int dsvg_attention_fwd_mfma(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
-                            void* out, int64_t n_seq, int32_t S, int32_t n_heads, float scale, float drop_p,
-                            uint32_t drop_site, const uint64_t* seed, hipStream_t st);
+                            const int32_t* tile_first, void* out, int64_t n_seq, int32_t S, int32_t n_heads,
+                            float scale, float drop_p, uint32_t drop_site, const uint64_t* seed, hipStream_t st);
 int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
-                            const void* dout, void* dqkv, int64_t n_seq, int32_t S, int32_t n_heads, float scale,
-                            float drop_p, uint32_t drop_site, const uint64_t* seed, hipStream_t st);
+                            const int32_t* tile_first, const void* dout, void* dqkv, int64_t n_seq, int32_t S,
+                            int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
+                            hipStream_t st);
 
 template <typename T, int SP, int HG>
 struct AttnCfg {
@@ -339,9 +340,51 @@ static int launch_bwd(const void* qkv, const uint64_t* km, const int32_t* seq_of
         if (S <= 64) return FN<T, 64, 1>(__VA_ARGS__);                              \
     } while (0)
 
+// Greedy grouping of the packed sequences into attention tiles of at most 32 rows (the MFMA kernel's score tile):
+// tile j = sequences tile_first[j] .. tile_first[j+1]-1; tile_first[n_tiles] = n_seq; tile_first[n_seq + 1] = n_tiles.
+// The average packed encoder sequence has ~10 valid tokens, so a tile carries ~3 of them.  One workgroup: the offsets
+// are staged in LDS in chunks, thread 0 walks them.
+__global__ __launch_bounds__(1024) void attention_tiles_kernel(const int32_t* __restrict__ seq_off, int n_seq,
+                                                               int max_rows, int32_t* __restrict__ tile_first) {
+    __shared__ int off[1025];
+    __shared__ int n_tiles, tile_start_row;
+    if (threadIdx.x == 0) { n_tiles = 0; tile_start_row = -1; }
+    __syncthreads();
+    for (int base = 0; base < n_seq; base += 1024) {
+        const int cnt = min(1024, n_seq - base);
+        for (int i = threadIdx.x; i <= cnt; i += 1024) off[i] = seq_off[base + i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int nt = n_tiles, start = tile_start_row;
+            for (int i = 0; i < cnt; ++i) {
+                if (start < 0 || off[i + 1] - start > max_rows) {      // sequence base+i opens a new tile
+                    tile_first[nt++] = base + i;
+                    start = off[i];
+                }
+            }
+            n_tiles = nt;
+            tile_start_row = start;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tile_first[n_tiles] = n_seq;
+        tile_first[n_seq + 1] = n_tiles;
+    }
+}
+extern "C" int dsvg_attention_tiles(const int32_t* seq_off, int64_t n_seq, int32_t max_rows, int32_t* tile_first,
+                                    void* stream) {
+    DSVG_CHECK_ARG(seq_off && tile_first && n_seq > 0 && n_seq < (1 << 30) && max_rows > 0, "attention_tiles: bad args");
+    hipLaunchKernelGGL(attention_tiles_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, seq_off, (int)n_seq, max_rows,
+                       tile_first);
+    DSVG_LAUNCH_CHECK("attention_tiles");
+    return 0;
+}
+
 extern "C" int dsvg_attention_fwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const int32_t* seq_off,
-                                  int64_t total_rows, void* out, int64_t n_seq, int32_t S, int32_t n_heads, float scale,
-                                  float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream) {
+                                  int64_t total_rows, const int32_t* tile_first, void* out, int64_t n_seq, int32_t S,
+                                  int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
+                                  void* stream) {
     DSVG_CHECK_ARG(qkv && out && n_seq > 0 && S > 0 && S <= 64 && n_heads > 0, "attention_fwd: bad args (S=%d)", S);
     DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_fwd: dropout needs a seed pointer");
     DSVG_CHECK_ARG(!seq_off || (!key_mask && total_rows > 0), "attention_fwd: packed layout takes no key mask");
@@ -349,8 +392,8 @@ extern "C" int dsvg_attention_fwd(int32_t dtype, const void* qkv, const uint64_t
     if (!seq_off && total_rows <= n_seq * S) total_rows = 0;       // dense layout without a tail
     hipStream_t st = (hipStream_t)stream;
     if (dsvg_attention_mfma_ok(dtype, S, n_heads))
-        return dsvg_attention_fwd_mfma(qkv, key_mask, seq_off, total_rows, out, n_seq, S, n_heads, scale, drop_p, drop_site,
-                                       seed, st);
+        return dsvg_attention_fwd_mfma(qkv, key_mask, seq_off, total_rows, seq_off ? tile_first : nullptr, out, n_seq, S,
+                                       n_heads, scale, drop_p, drop_site, seed, st);
     if (dtype == DSVG_F32) {
         DSVG_ATTN_DISPATCH(launch_fwd, float, qkv, key_mask, seq_off, total_rows, out, n_seq, S, n_heads, scale, drop_p,
                            drop_site, seed, st);
@@ -363,9 +406,9 @@ extern "C" int dsvg_attention_fwd(int32_t dtype, const void* qkv, const uint64_t
 }
 
 extern "C" int dsvg_attention_bwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const int32_t* seq_off,
-                                  int64_t total_rows, const void* dout, void* dqkv, int64_t n_seq, int32_t S,
-                                  int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
-                                  void* stream) {
+                                  int64_t total_rows, const int32_t* tile_first, const void* dout, void* dqkv,
+                                  int64_t n_seq, int32_t S, int32_t n_heads, float scale, float drop_p,
+                                  uint32_t drop_site, const uint64_t* seed, void* stream) {
     DSVG_CHECK_ARG(qkv && dout && dqkv && n_seq > 0 && S > 0 && S <= 64 && n_heads > 0, "attention_bwd: bad args");
     DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_bwd: dropout needs a seed pointer");
     DSVG_CHECK_ARG(!seq_off || (!key_mask && total_rows > 0), "attention_bwd: packed layout takes no key mask");
@@ -373,8 +416,8 @@ extern "C" int dsvg_attention_bwd(int32_t dtype, const void* qkv, const uint64_t
     if (!seq_off && total_rows <= n_seq * S) total_rows = 0;       // dense layout without a tail
     hipStream_t st = (hipStream_t)stream;
     if (dsvg_attention_mfma_ok(dtype, S, n_heads))
-        return dsvg_attention_bwd_mfma(qkv, key_mask, seq_off, total_rows, dout, dqkv, n_seq, S, n_heads, scale, drop_p,
-                                       drop_site, seed, st);
+        return dsvg_attention_bwd_mfma(qkv, key_mask, seq_off, total_rows, seq_off ? tile_first : nullptr, dout, dqkv,
+                                       n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
     if (dtype == DSVG_F32) {
         DSVG_ATTN_DISPATCH(launch_bwd, float, qkv, key_mask, seq_off, total_rows, dout, dqkv, n_seq, S, n_heads, scale,
                            drop_p, drop_site, seed, st);

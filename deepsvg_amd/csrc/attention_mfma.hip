@@ -99,6 +99,7 @@ __device__ __forceinline__ void zero_slab_rows(bf16_t* dst, long long ld, long l
 __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                             const uint64_t* __restrict__ key_mask,
                                                             const int32_t* __restrict__ seq_off, long long total_rows,
+                                                            const int32_t* __restrict__ tile_first, int n_seq,
                                                             bf16_t* __restrict__ out, int Smax, int H, float scale,
                                                             float drop_p, uint32_t drop_site, const uint64_t* seed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -108,14 +109,31 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
     const int li = lane & 31, h2 = lane >> 5;
     const int h = hg * HG + hh;
     long long row0 = (long long)b * Smax;
-    int S = Smax;                   // this sequence's length; dropout ids keep the Smax-based numbering
+    int S = Smax;                   // rows of this workgroup's tile; dropout ids keep the Smax-based numbering
     if (total_rows > 0 && b == (int)gridDim.x - 1) {     // tail workgroup: rows past the last sequence <- 0
-        zero_slab_rows(out + (size_t)hg * W, (long long)d, seq_off ? (long long)seq_off[b] : row0, total_rows, W);
+        zero_slab_rows(out + (size_t)hg * W, (long long)d, seq_off ? (long long)seq_off[n_seq] : row0, total_rows, W);
         return;
     }
+    // packed layout with tiles (dsvg_attention_tiles): the workgroup owns the sequences tile_first[b]..tile_first[b+1]-1,
+    // at most 32 rows in total, block-diagonal attention inside the 32x32 score tile
+    int s_first = b, s_last = b + 1;
+    if (tile_first) {
+        if (b >= tile_first[n_seq + 1]) return;
+        s_first = tile_first[b];
+        s_last = tile_first[b + 1];
+    }
     if (seq_off) {
-        row0 = seq_off[b];
-        S = seq_off[b + 1] - seq_off[b];
+        row0 = seq_off[s_first];
+        S = seq_off[s_last] - seq_off[s_first];
+    }
+    // this lane's row (query in pass A, key in pass B): its sequence, first row of that sequence in the tile, length
+    int my_seq = b, my_start = 0, my_len = S;
+    if (tile_first) {
+        my_seq = s_first;
+        for (int q = s_first; q < s_last; ++q)
+            if (row0 + li >= seq_off[q]) my_seq = q;
+        my_start = (int)(seq_off[my_seq] - row0);
+        my_len = seq_off[my_seq + 1] - seq_off[my_seq];
     }
     const bf16_t* src = qkv + (size_t)row0 * 3 * d + (size_t)hg * W;
     load_slab(tile, LD, src, 3LL * d, S, W);
@@ -123,7 +141,9 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
     load_slab(tile + 2 * W, LD, src + 2 * d, 3LL * d, S, W);
     __syncthreads();
 
-    const uint64_t km = (key_mask ? key_mask[b] : ~0ull) & ((S >= 64) ? ~0ull : ((1ull << S) - 1ull));
+    // keys visible to this lane's query: the rows of its own sequence
+    const uint64_t km = tile_first ? (((1ull << my_len) - 1ull) << my_start)
+                                   : ((key_mask ? key_mask[b] : ~0ull) & ((S >= 64) ? ~0ull : ((1ull << S) - 1ull)));
     const DropCtx dc = drop_make(drop_p, seed, drop_site);
     const int qc = hh * 32, kc = W + hh * 32, vc = 2 * W + hh * 32;
 
@@ -152,7 +172,8 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.f / l;
-    const uint64_t ebase = (((uint64_t)b * H + h) * Smax + li) * Smax;
+    // element id of (query i, key j) of sequence s: ((s H + h) Smax + i) Smax + j with i, j counted inside the sequence
+    const uint64_t ebase = (((uint64_t)my_seq * H + h) * Smax + (li - my_start)) * Smax - my_start;
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = p[r] * inv * drop_mult(dc, ebase + rowmap(r, h2));
     if (li >= S) {
@@ -174,6 +195,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
 __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                             const uint64_t* __restrict__ key_mask,
                                                             const int32_t* __restrict__ seq_off, long long total_rows,
+                                                            const int32_t* __restrict__ tile_first, int n_seq,
                                                             const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                             int Smax, int H, float scale, float drop_p,
                                                             uint32_t drop_site, const uint64_t* seed) {
@@ -188,16 +210,30 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
     long long row0 = (long long)b * Smax;
     int S = Smax;
     if (total_rows > 0 && b == (int)gridDim.x - 1) {     // tail workgroup: rows past the last sequence <- 0
-        const long long first = seq_off ? (long long)seq_off[b] : row0;
+        const long long first = seq_off ? (long long)seq_off[n_seq] : row0;
         bf16_t* z = dqkv + (size_t)hg * W;
         zero_slab_rows(z, 3LL * d, first, total_rows, W);
         zero_slab_rows(z + d, 3LL * d, first, total_rows, W);
         zero_slab_rows(z + 2 * d, 3LL * d, first, total_rows, W);
         return;
     }
+    int s_first = b, s_last = b + 1;        // tile mode: see the forward kernel
+    if (tile_first) {
+        if (b >= tile_first[n_seq + 1]) return;
+        s_first = tile_first[b];
+        s_last = tile_first[b + 1];
+    }
     if (seq_off) {
-        row0 = seq_off[b];
-        S = seq_off[b + 1] - seq_off[b];
+        row0 = seq_off[s_first];
+        S = seq_off[s_last] - seq_off[s_first];
+    }
+    int my_seq = b, my_start = 0, my_len = S;
+    if (tile_first) {
+        my_seq = s_first;
+        for (int q = s_first; q < s_last; ++q)
+            if (row0 + li >= seq_off[q]) my_seq = q;
+        my_start = (int)(seq_off[my_seq] - row0);
+        my_len = seq_off[my_seq + 1] - seq_off[my_seq];
     }
     const bf16_t* src = qkv + (size_t)row0 * 3 * d + (size_t)hg * W;
     load_slab(tile, LD, src, 3LL * d, S, W);
@@ -206,10 +242,13 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
     load_slab(dtile, LDO, dout + (size_t)row0 * d + (size_t)hg * W, (long long)d, S, W);
     __syncthreads();
 
-    const uint64_t km = (key_mask ? key_mask[b] : ~0ull) & ((S >= 64) ? ~0ull : ((1ull << S) - 1ull));
+    // rows of this lane's sequence: the keys its query sees (pass A) = the queries that see its key (pass B)
+    const uint64_t km = tile_first ? (((1ull << my_len) - 1ull) << my_start)
+                                   : ((key_mask ? key_mask[b] : ~0ull) & ((S >= 64) ? ~0ull : ((1ull << S) - 1ull)));
     const DropCtx dc = drop_make(drop_p, seed, drop_site);
     const int qc = hh * 32, kc = W + hh * 32, vc = 2 * W + hh * 32, oc = hh * 32;
-    const uint64_t hbase = ((uint64_t)b * H + h) * Smax;         // id(q, key) = (hbase + q) * Smax + key
+    // id(q, key) = ((seq H + h) Smax + q_local) Smax + key_local; q and key are tile rows of the lane's own sequence
+    const uint64_t hbase = ((uint64_t)my_seq * H + h) * Smax - my_start;
     float* my_stat = stat + hh * 64;
 
     floatx16 acc, acc2;
@@ -244,7 +283,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         p[r] *= inv;                                                               // P[q][key]
-        g[r] = acc2[r] * drop_mult(dc, (hbase + li) * Smax + rowmap(r, h2));          // dP[q][key]
+        g[r] = acc2[r] * drop_mult(dc, (hbase + li) * Smax + rowmap(r, h2) - my_start);   // dP[q][key]
         D = fmaf(p[r], g[r], D);
     }
     D += __shfl_xor(D, 32, 64);
@@ -271,14 +310,14 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dtile, LDO, li, oc, step, h2),
                                                        row_frag(tile, LD, li, vc, step, h2), acc2, 0, 0, 0);    // dO V^T
     }
-    const bool kvalid = (km >> li) & 1ull;
+    const bool kvalid = tile_first ? (li < S) : (bool)((km >> li) & 1ull);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int q = rowmap(r, h2);
         const float lse_q = my_stat[q * 2 + 0], D_q = my_stat[q * 2 + 1];
-        const bool ok = kvalid && q < S;
+        const bool ok = kvalid && q < S && (!tile_first || ((km >> q) & 1ull));
         const float pr = ok ? __expf(acc[r] * scale - lse_q) : 0.f;               // P[q][key = li]
-        const float mult = drop_mult(dc, (hbase + q) * Smax + li);
+        const float mult = drop_mult(dc, (hbase + q) * Smax + li - my_start);
         p[r] = pr * mult;                                                          // P~ (as used by O = P~ V)
         g[r] = ok ? pr * (acc2[r] * mult - D_q) * scale : 0.f;                     // scale * dS[q][key]
     }
@@ -310,25 +349,26 @@ bool dsvg_attention_mfma_ok(int32_t dtype, int32_t S, int32_t n_heads) {
 }
 
 int dsvg_attention_fwd_mfma(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
-                            void* out, int64_t n_seq, int32_t S, int32_t n_heads, float scale, float drop_p,
-                            uint32_t drop_site, const uint64_t* seed, hipStream_t st) {
+                            const int32_t* tile_first, void* out, int64_t n_seq, int32_t S, int32_t n_heads,
+                            float scale, float drop_p, uint32_t drop_site, const uint64_t* seed, hipStream_t st) {
     const size_t lds = (size_t)32 * LD * sizeof(bf16_t);
     hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)n_seq + (total_rows > 0 ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
-                       (const bf16_t*)qkv, key_mask, seq_off, (long long)total_rows, (bf16_t*)out, S, n_heads, scale,
-                       drop_p, drop_site, seed);
+                       (const bf16_t*)qkv, key_mask, seq_off, (long long)total_rows, tile_first, (int)n_seq, (bf16_t*)out,
+                       S, n_heads, scale, drop_p, drop_site, seed);
     DSVG_LAUNCH_CHECK("attention_fwd_mfma");
     return 0;
 }
 
 int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
-                            const void* dout, void* dqkv, int64_t n_seq, int32_t S, int32_t n_heads, float scale,
-                            float drop_p, uint32_t drop_site, const uint64_t* seed, hipStream_t st) {
+                            const int32_t* tile_first, const void* dout, void* dqkv, int64_t n_seq, int32_t S,
+                            int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
+                            hipStream_t st) {
     const size_t lds = (size_t)32 * (LD + LDO) * sizeof(bf16_t) + (size_t)HG * 64 * sizeof(float);
     auto kern = attn_bwd_mfma_kernel;
     DSVG_ENSURE_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (total_rows > 0 ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
-                       (const bf16_t*)qkv, key_mask, seq_off, (long long)total_rows, (const bf16_t*)dout, (bf16_t*)dqkv, S,
-                       n_heads, scale, drop_p, drop_site, seed);
+                       (const bf16_t*)qkv, key_mask, seq_off, (long long)total_rows, tile_first, (int)n_seq,
+                       (const bf16_t*)dout, (bf16_t*)dqkv, S, n_heads, scale, drop_p, drop_site, seed);
     DSVG_LAUNCH_CHECK("attention_bwd_mfma");
     return 0;
 }

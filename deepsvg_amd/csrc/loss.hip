@@ -190,17 +190,34 @@ extern "C" int dsvg_masked_ce_bwd(int32_t dtype, const void* logits, int64_t ld,
 // 2827-wide argument head then runs on that compact list (about 30 % of the decoder tokens): rows of dlogits that
 // the loss masks out are exact zeros (loss.py:51-54) and contribute neither to dX nor to dW.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void live_rows_kernel(const float* __restrict__ w, long long n_tok, int group,
-                                                         int32_t* __restrict__ live, int32_t* __restrict__ count) {
+// three small launches: per-block (1024 tokens) flags + local ranks, scan of the block totals, scatter of the list
+__global__ __launch_bounds__(1024) void live_rows_rank_kernel(const float* __restrict__ w, long long n_tok, int group,
+                                                              int32_t* __restrict__ rank, int32_t* __restrict__ block_sum) {
+    __shared__ int part[1024];
+    const long long t = (long long)blockIdx.x * 1024 + threadIdx.x;
+    int v = 0;
+    if (t < n_tok)
+        for (int a = 0; a < group; ++a) v |= (w[t * group + a] != 0.f) ? 1 : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int u = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += u;
+        __syncthreads();
+    }
+    if (t < n_tok) rank[t] = v ? part[threadIdx.x] - 1 : -1;       // rank inside the block, -1 = not listed
+    if (threadIdx.x == 1023) block_sum[blockIdx.x] = part[1023];
+}
+__global__ __launch_bounds__(1024) void live_rows_scan_kernel(int32_t* __restrict__ block_sum, int nb,
+                                                              int32_t* __restrict__ count) {
     __shared__ int part[1024];
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (long long base = 0; base < n_tok; base += 1024) {
-        const long long t = base + threadIdx.x;
-        int v = 0;
-        if (t < n_tok)
-            for (int a = 0; a < group; ++a) v |= (w[t * group + a] != 0.f) ? 1 : 0;
+    for (int base = 0; base < nb; base += 1024) {
+        const int b = base + threadIdx.x;
+        const int v = b < nb ? block_sum[b] : 0;
         part[threadIdx.x] = v;
         __syncthreads();
         for (int o = 1; o < 1024; o <<= 1) {
@@ -209,19 +226,37 @@ __global__ __launch_bounds__(1024) void live_rows_kernel(const float* __restrict
             part[threadIdx.x] += u;
             __syncthreads();
         }
-        if (v) live[carry + part[threadIdx.x] - 1] = (int32_t)t;
+        if (b < nb) block_sum[b] = carry + part[threadIdx.x] - v;      // exclusive offset of the block
         __syncthreads();
         if (threadIdx.x == 1023) carry += part[1023];
         __syncthreads();
     }
-    for (long long i = carry + threadIdx.x; i < n_tok; i += 1024) live[i] = -1;
     if (threadIdx.x == 0) *count = carry;
 }
+__global__ __launch_bounds__(1024) void live_rows_fill_kernel(const int32_t* __restrict__ rank,
+                                                              const int32_t* __restrict__ block_off,
+                                                              const int32_t* __restrict__ count, long long n_tok,
+                                                              int32_t* __restrict__ live) {
+    const long long t = (long long)blockIdx.x * 1024 + threadIdx.x;
+    if (t >= n_tok) return;
+    if (t >= *count) live[t] = -1;                 // tail padding (positions < count are written by their owners)
+    const int r = rank[t];
+    if (r >= 0) live[block_off[blockIdx.x] + r] = (int32_t)t;
+}
+extern "C" int64_t dsvg_live_rows_workspace_bytes(int64_t n_tok) {
+    return (n_tok + (n_tok + 1023) / 1024) * (int64_t)sizeof(int32_t);
+}
 extern "C" int dsvg_live_rows(const float* w, int64_t n_tok, int32_t group, int32_t* live, int32_t* count,
-                              void* stream) {
+                              int32_t* workspace, int64_t workspace_bytes, void* stream) {
     DSVG_CHECK_ARG(w && live && count && n_tok > 0 && group > 0 && n_tok < (1ll << 31), "live_rows: bad args");
-    hipLaunchKernelGGL(live_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)n_tok, group, live,
-                       count);
+    DSVG_CHECK_ARG(workspace && workspace_bytes >= dsvg_live_rows_workspace_bytes(n_tok), "live_rows: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)((n_tok + 1023) / 1024);
+    int32_t* rank = workspace;
+    int32_t* block_sum = workspace + n_tok;
+    hipLaunchKernelGGL(live_rows_rank_kernel, dim3(nb), dim3(1024), 0, st, w, (long long)n_tok, group, rank, block_sum);
+    hipLaunchKernelGGL(live_rows_scan_kernel, dim3(1), dim3(1024), 0, st, block_sum, nb, count);
+    hipLaunchKernelGGL(live_rows_fill_kernel, dim3(nb), dim3(1024), 0, st, rank, block_sum, count, (long long)n_tok, live);
     DSVG_LAUNCH_CHECK("live_rows");
     return 0;
 }

@@ -50,8 +50,9 @@ SIGNATURES = {
     "dsvg_layernorm_fwd": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_f32, vp]),
     "dsvg_layernorm_bwd": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i32, c_i64, c_i32, vp, c_i64, vp]),
     "dsvg_layernorm_bwd_workspace_bytes": (c_i64, [c_i64, c_i32]),
-    "dsvg_attention_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
-    "dsvg_attention_bwd": (c_i32, [c_i32, vp, vp, vp, c_i64, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
+    "dsvg_attention_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
+    "dsvg_attention_bwd": (c_i32, [c_i32, vp, vp, vp, c_i64, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
+    "dsvg_attention_tiles": (c_i32, [vp, c_i64, c_i32, vp, vp]),
     "dsvg_pack_tokens": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, vp]),
     "dsvg_visible_first": (c_i32, [vp, c_i64, vp, vp, vp, vp]),
     "dsvg_gather_groups": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, vp]),
@@ -72,7 +73,8 @@ SIGNATURES = {
     "dsvg_masked_ce_fwd": (c_i32, [c_i32, vp, c_i64, c_i32, vp, vp, c_i64, c_i32, vp, vp, vp, c_i64, vp]),
     "dsvg_masked_ce_workspace_bytes": (c_i64, [c_i64]),
     "dsvg_masked_ce_bwd": (c_i32, [c_i32, vp, c_i64, c_i32, vp, vp, vp, vp, vp, c_f32, vp, c_i64, c_i64, c_i32, vp, vp]),
-    "dsvg_live_rows": (c_i32, [vp, c_i64, c_i32, vp, vp, vp]),
+    "dsvg_live_rows": (c_i32, [vp, c_i64, c_i32, vp, vp, vp, c_i64, vp]),
+    "dsvg_live_rows_workspace_bytes": (c_i64, [c_i64]),
     "dsvg_scatter_rows": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, vp]),
     "dsvg_sumsq": (c_i32, [vp, c_i64, vp, vp, c_i64, vp]),
     "dsvg_sumsq_workspace_bytes": (c_i64, [c_i64]),

@@ -361,7 +361,7 @@ class SVGTransformer(nn.Module):
         return Fn.Runtime(self.compute_dtype, seed, self._store, training)
 
     # ---- blocks ----------------------------------------------------------------------------------
-    def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site, seq_off=None, live=None):
+    def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site, seq_off=None, live=None, tiles=None):
         cfg = self.cfg
         for i, L in enumerate(stack.layers):
             has_g = hasattr(L, "linear_global")
@@ -371,7 +371,7 @@ class SVGTransformer(nn.Module):
                 L.self_attn.out_proj.weight, L.self_attn.out_proj.bias, L.norm2.weight, L.norm2.bias,
                 L.linear1.weight, L.linear1.bias, L.linear2.weight, L.linear2.bias,
                 L.linear_global.weight if has_g else None, L.linear_global.bias if has_g else None, None, None,
-                seq_off, live)
+                seq_off, live, tiles)
         return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps, live)
 
     def make_plan(self, commands_enc, args_enc, commands_dec, want_grad=True, args_dec=None):
@@ -405,7 +405,9 @@ class SVGTransformer(nn.Module):
             arg = args_enc.to(torch.float32).contiguous().view(N * G * S, -1)
             key_mask, _vis, group_mask = ops.build_masks(cmd, S, G, EOS_ID, want_group_mask=cfg.encode_stages == 2)
             seq_off, pcmd, parg, ppos = ops.pack_tokens(cmd.view(-1), arg, key_mask, N * G, S)
-            plan["enc"] = dict(key_mask=key_mask, group_mask=group_mask, seq_off=seq_off, pcmd=pcmd, parg=parg, ppos=ppos)
+            tiles = ops.attention_tiles(seq_off, N * G, 32) if S <= 32 else None
+            plan["enc"] = dict(key_mask=key_mask, group_mask=group_mask, seq_off=seq_off, pcmd=pcmd, parg=parg, ppos=ppos,
+                               tiles=tiles)
             counts.append(seq_off[-1:])
         if (commands_dec is not None and want_grad and self.skip_invisible_backward and cfg.decode_stages == 2
                 and commands_dec.shape[1] == cfg.num_groups_proposal):
@@ -452,7 +454,7 @@ class SVGTransformer(nn.Module):
         src = Fn.PackedEmbedFn.apply(rt, pcmd[:rows], parg[:rows], ppos[:rows], S, PE_DROPOUT, 1,
                                      emb.command_embed.weight, emb.arg_embed.weight, emb.embed_fcn.weight,
                                      emb.embed_fcn.bias, emb.pos_encoding.pos_embed.weight)
-        mem = self._run_stack(rt, enc.encoder, src, None, None, n_seq, S, 100, seq_off=seq_off)
+        mem = self._run_stack(rt, enc.encoder, src, None, None, n_seq, S, 100, seq_off=seq_off, tiles=pe.get("tiles"))
         return Fn.MaskedMeanFn.apply(rt, mem, None, n_seq, S, seq_off)
 
     def _encode(self, rt, commands, args, plan=None):

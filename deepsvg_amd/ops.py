@@ -243,7 +243,18 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, res=None, dgamma=None, dbeta=None
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
-def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None):
+def attention_tiles(seq_off, n_seq, max_rows=32):
+    """groups of consecutive packed sequences with <= max_rows rows in total (include/dsvg.h): int32 [n_seq + 2]"""
+    _chk(seq_off)
+    assert seq_off.dtype == torch.int32 and seq_off.numel() == n_seq + 1
+    tiles = torch.empty(n_seq + 2, dtype=torch.int32, device=seq_off.device)
+    _l.check(_l.load().dsvg_attention_tiles(seq_off.data_ptr(), n_seq, max_rows, tiles.data_ptr(), _stream()),
+             "dsvg_attention_tiles")
+    return tiles
+
+
+def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None,
+                  tiles=None):
     """seq_off (int32 [n_seq+1], device): packed layout, sequence b = rows seq_off[b]..seq_off[b+1]-1 (<= S rows, all
     keys visible, key_mask must be None); rows past seq_off[n_seq] are zero-filled."""
     _chk(qkv, key_mask, seed, seq_off)
@@ -251,19 +262,20 @@ def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site
     assert qkv.is_contiguous() and qkv.shape[1] == 3 * 32 * n_heads, "attention needs head_dim == 32"
     assert (rows >= n_seq * S) if seq_off is None else (key_mask is None and seq_off.numel() == n_seq + 1)
     out = torch.empty((rows, 32 * n_heads), dtype=qkv.dtype, device=qkv.device)
-    _l.check(_l.load().dsvg_attention_fwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), _p(seq_off), rows, out.data_ptr(),
-                                          n_seq, S, n_heads, float(scale), float(drop_p), int(drop_site),
+    _l.check(_l.load().dsvg_attention_fwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), _p(seq_off), rows, _p(tiles),
+                                          out.data_ptr(), n_seq, S, n_heads, float(scale), float(drop_p), int(drop_site),
                                           _p(seed) if drop_p > 0 else None, _stream()), "dsvg_attention_fwd")
     return out
 
 
-def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None):
+def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None,
+                  tiles=None):
     _chk(qkv, key_mask, dout, seed, seq_off)
     assert qkv.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype
     assert seq_off is None or (key_mask is None and seq_off.numel() == n_seq + 1)
     dqkv = torch.empty_like(qkv)
     _l.check(_l.load().dsvg_attention_bwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), _p(seq_off), qkv.shape[0],
-                                          dout.data_ptr(), dqkv.data_ptr(), n_seq, S, n_heads, float(scale),
+                                          _p(tiles), dout.data_ptr(), dqkv.data_ptr(), n_seq, S, n_heads, float(scale),
                                           float(drop_p), int(drop_site), _p(seed) if drop_p > 0 else None, _stream()),
              "dsvg_attention_bwd")
     return dqkv
@@ -517,8 +529,10 @@ def live_rows(w, group):
     n_tok = w.numel() // group
     live = torch.empty(n_tok, dtype=torch.int32, device=w.device)
     count = torch.empty(1, dtype=torch.int32, device=w.device)
-    _l.check(_l.load().dsvg_live_rows(w.data_ptr(), n_tok, group, live.data_ptr(), count.data_ptr(), _stream()),
-             "dsvg_live_rows")
+    L = _l.load()
+    ws = _ws(L.dsvg_live_rows_workspace_bytes(n_tok), w.device)
+    _l.check(L.dsvg_live_rows(w.data_ptr(), n_tok, group, live.data_ptr(), count.data_ptr(), ws.data_ptr(),
+                              ws.numel() * 4, _stream()), "dsvg_live_rows")
     return live, count
 
 

@@ -204,7 +204,22 @@ def _repack_rows(dense, idx, rows):
     return out
 
 
-def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None):
+def attention_tiles(seq_off, n_seq, max_rows=32):
+    off = seq_off.tolist()
+    first, start = [], None
+    for i in range(n_seq):
+        if start is None or off[i + 1] - start > max_rows:
+            first.append(i)
+            start = off[i]
+    t = torch.zeros(n_seq + 2, dtype=torch.int32, device=seq_off.device)
+    t[:len(first)] = torch.tensor(first, dtype=torch.int32)
+    t[len(first)] = n_seq
+    t[n_seq + 1] = len(first)
+    return t
+
+
+def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None,
+                  tiles=None):
     if seq_off is not None:
         dense, idx, lens = _unpack_rows(qkv, seq_off, n_seq, S)
         o = attention_fwd(dense, _len_mask(lens), n_seq, S, n_heads, scale, drop_p, drop_site, seed)
@@ -219,7 +234,8 @@ def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site
     return o.permute(0, 2, 1, 3).reshape(n_seq * S, H * 32).to(qkv.dtype)
 
 
-def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None):
+def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None,
+                  tiles=None):
     if seq_off is not None:
         dense, idx, lens = _unpack_rows(qkv, seq_off, n_seq, S)
         ddense, _, _ = _unpack_rows(dout, seq_off, n_seq, S)
