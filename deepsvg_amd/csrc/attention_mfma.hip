@@ -96,6 +96,7 @@ __device__ __forceinline__ void zero_slab_rows(bf16_t* dst, long long ld, long l
     }
 }
 
+template <bool TILED>
 __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                             const uint64_t* __restrict__ key_mask,
                                                             const int32_t* __restrict__ seq_off, long long total_rows,
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
                                                             float drop_p, uint32_t drop_site, const uint64_t* seed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);   // [32][LD]
+    int* soff = reinterpret_cast<int*>(tile + 32 * LD);   // [34] sequence offsets of the tile (TILED)
     const int b = blockIdx.x, hg = blockIdx.y, d = H * 32;
     const int lane = threadIdx.x & 63, hh = threadIdx.x >> 6;
     const int li = lane & 31, h2 = lane >> 5;
@@ -117,33 +119,35 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
     // packed layout with tiles (dsvg_attention_tiles): the workgroup owns the sequences tile_first[b]..tile_first[b+1]-1,
     // at most 32 rows in total, block-diagonal attention inside the 32x32 score tile
     int s_first = b, s_last = b + 1;
-    if (tile_first) {
+    if (TILED) {
         if (b >= tile_first[n_seq + 1]) return;
         s_first = tile_first[b];
         s_last = tile_first[b + 1];
+        if ((int)threadIdx.x <= s_last - s_first) soff[threadIdx.x] = seq_off[s_first + threadIdx.x];   // <= 33 entries
     }
     if (seq_off) {
         row0 = seq_off[s_first];
         S = seq_off[s_last] - seq_off[s_first];
-    }
-    // this lane's row (query in pass A, key in pass B): its sequence, first row of that sequence in the tile, length
-    int my_seq = b, my_start = 0, my_len = S;
-    if (tile_first) {
-        my_seq = s_first;
-        for (int q = s_first; q < s_last; ++q)
-            if (row0 + li >= seq_off[q]) my_seq = q;
-        my_start = (int)(seq_off[my_seq] - row0);
-        my_len = seq_off[my_seq + 1] - seq_off[my_seq];
     }
     const bf16_t* src = qkv + (size_t)row0 * 3 * d + (size_t)hg * W;
     load_slab(tile, LD, src, 3LL * d, S, W);
     load_slab(tile + W, LD, src + d, 3LL * d, S, W);
     load_slab(tile + 2 * W, LD, src + 2 * d, 3LL * d, S, W);
     __syncthreads();
+    // this lane's row (query in pass A, key in pass B): its sequence, first row of that sequence in the tile, length
+    int my_seq = b, my_start = 0, my_len = S;
+    if (TILED) {
+        int qi = 0;
+        for (int q = 1; q < s_last - s_first; ++q)
+            if (row0 + li >= soff[q]) qi = q;
+        my_seq = s_first + qi;
+        my_start = soff[qi] - (int)row0;
+        my_len = soff[qi + 1] - soff[qi];
+    }
 
     // keys visible to this lane's query: the rows of its own sequence
-    const uint64_t km = tile_first ? (((1ull << my_len) - 1ull) << my_start)
-                                   : ((key_mask ? key_mask[b] : ~0ull) & ((S >= 64) ? ~0ull : ((1ull << S) - 1ull)));
+    const uint32_t km = TILED ? (uint32_t)(((1ull << my_len) - 1ull) << my_start)
+                                   : ((key_mask ? (uint32_t)key_mask[b] : ~0u) & (uint32_t)((1ull << S) - 1ull));
     const DropCtx dc = drop_make(drop_p, seed, drop_site);
     const int qc = hh * 32, kc = W + hh * 32, vc = 2 * W + hh * 32;
 
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int key = rowmap(r, h2);
-        p[r] = ((km >> key) & 1ull) ? st[r] * scale : -INFINITY;
+        p[r] = ((km >> key) & 1u) ? st[r] * scale : -INFINITY;
         m = fmaxf(m, p[r]);
     }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
     store_slab(out + (size_t)row0 * d + (size_t)hg * W, (long long)d, tile, LD, S, W);
 }
 
+template <bool TILED>
 __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                             const uint64_t* __restrict__ key_mask,
                                                             const int32_t* __restrict__ seq_off, long long total_rows,
@@ -203,6 +208,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
     bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);          // [32][LD]   q|k|v
     bf16_t* dtile = tile + 32 * LD;                              // [32][LDO]  dO
     float* stat = reinterpret_cast<float*>(dtile + 32 * LDO);    // [HG][32][2] lse, D
+    int* soff = reinterpret_cast<int*>(stat + HG * 64);          // [34] sequence offsets of the tile (TILED)
     const int b = blockIdx.x, hg = blockIdx.y, d = H * 32;
     const int lane = threadIdx.x & 63, hh = threadIdx.x >> 6;
     const int li = lane & 31, h2 = lane >> 5;
@@ -218,33 +224,37 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
         return;
     }
     int s_first = b, s_last = b + 1;        // tile mode: see the forward kernel
-    if (tile_first) {
+    if (TILED) {
         if (b >= tile_first[n_seq + 1]) return;
         s_first = tile_first[b];
         s_last = tile_first[b + 1];
+        if ((int)threadIdx.x <= s_last - s_first) soff[threadIdx.x] = seq_off[s_first + threadIdx.x];   // <= 33 entries
     }
     if (seq_off) {
         row0 = seq_off[s_first];
         S = seq_off[s_last] - seq_off[s_first];
     }
-    int my_seq = b, my_start = 0, my_len = S;
-    if (tile_first) {
-        my_seq = s_first;
-        for (int q = s_first; q < s_last; ++q)
-            if (row0 + li >= seq_off[q]) my_seq = q;
-        my_start = (int)(seq_off[my_seq] - row0);
-        my_len = seq_off[my_seq + 1] - seq_off[my_seq];
-    }
+
     const bf16_t* src = qkv + (size_t)row0 * 3 * d + (size_t)hg * W;
     load_slab(tile, LD, src, 3LL * d, S, W);
     load_slab(tile + W, LD, src + d, 3LL * d, S, W);
     load_slab(tile + 2 * W, LD, src + 2 * d, 3LL * d, S, W);
     load_slab(dtile, LDO, dout + (size_t)row0 * d + (size_t)hg * W, (long long)d, S, W);
     __syncthreads();
+    // this lane's row (query in pass A, key in pass B): its sequence, first row of that sequence in the tile, length
+    int my_seq = b, my_start = 0, my_len = S;
+    if (TILED) {
+        int qi = 0;
+        for (int q = 1; q < s_last - s_first; ++q)
+            if (row0 + li >= soff[q]) qi = q;
+        my_seq = s_first + qi;
+        my_start = soff[qi] - (int)row0;
+        my_len = soff[qi + 1] - soff[qi];
+    }
 
     // rows of this lane's sequence: the keys its query sees (pass A) = the queries that see its key (pass B)
-    const uint64_t km = tile_first ? (((1ull << my_len) - 1ull) << my_start)
-                                   : ((key_mask ? key_mask[b] : ~0ull) & ((S >= 64) ? ~0ull : ((1ull << S) - 1ull)));
+    const uint32_t km = TILED ? (uint32_t)(((1ull << my_len) - 1ull) << my_start)
+                                   : ((key_mask ? (uint32_t)key_mask[b] : ~0u) & (uint32_t)((1ull << S) - 1ull));
     const DropCtx dc = drop_make(drop_p, seed, drop_site);
     const int qc = hh * 32, kc = W + hh * 32, vc = 2 * W + hh * 32, oc = hh * 32;
     // id(q, key) = ((seq H + h) Smax + q_local) Smax + key_local; q and key are tile rows of the lane's own sequence
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
     float m = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        p[r] = ((km >> rowmap(r, h2)) & 1ull) ? acc[r] * scale : -INFINITY;
+        p[r] = ((km >> rowmap(r, h2)) & 1u) ? acc[r] * scale : -INFINITY;
         m = fmaxf(m, p[r]);
     }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -297,8 +307,14 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
         dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(tile, LD, kc, ks, lane), pack_regs(g, ks), dq, 0, 0, 0);
-    // dq[r] = dQ[q = li][d = rowmap(r,h2)]
+    // dq[r] = dQ[q = li][d = rowmap(r,h2)]: packed to bf16 right away (8 instead of 16 live registers through pass B)
+    uint32_t dq_pk[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dq_pk[c] = f2bf_pk(dq[2 * c], dq[2 * c + 1]);
     __builtin_amdgcn_wave_barrier();
+    // pass B reads the same q / k / v / dO fragments as pass A in swapped roles: make the compiler re-read them from LDS
+    // instead of keeping 32 fragment registers alive across the softmax code (that was 24 spilled dwords per lane)
+    asm volatile("" ::: "memory");
 
     // ---------------- pass B: lane = (key li, half h2), registers over queries -----------------------------------
 #pragma unroll
@@ -310,28 +326,42 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dtile, LDO, li, oc, step, h2),
                                                        row_frag(tile, LD, li, vc, step, h2), acc2, 0, 0, 0);    // dO V^T
     }
-    const bool kvalid = tile_first ? (li < S) : (bool)((km >> li) & 1ull);
+    const bool kvalid = TILED ? (li < S) : (bool)((km >> li) & 1u);
+    // P~ and dS go straight to packed bf16 pairs (they are only MFMA operands from here on): 16 registers instead of 32
+    uint32_t pp[8], gp[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q = rowmap(r, h2);
-        const float lse_q = my_stat[q * 2 + 0], D_q = my_stat[q * 2 + 1];
-        const bool ok = kvalid && q < S && (!tile_first || ((km >> q) & 1ull));
-        const float pr = ok ? __expf(acc[r] * scale - lse_q) : 0.f;               // P[q][key = li]
-        const float mult = drop_mult(dc, (hbase + q) * Smax + li - my_start);
-        p[r] = pr * mult;                                                          // P~ (as used by O = P~ V)
-        g[r] = ok ? pr * (acc2[r] * mult - D_q) * scale : 0.f;                     // scale * dS[q][key]
+    for (int c = 0; c < 8; ++c) {
+        float pv[2], gv[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = 2 * c + e;
+            const int q = rowmap(r, h2);
+            const float lse_q = my_stat[q * 2 + 0], D_q = my_stat[q * 2 + 1];
+            const bool ok = kvalid && q < S && (!TILED || ((km >> q) & 1u));
+            const float pr = ok ? __expf(acc[r] * scale - lse_q) : 0.f;               // P[q][key = li]
+            const float mult = drop_mult(dc, (hbase + q) * Smax + li - my_start);
+            pv[e] = pr * mult;                                                        // P~ (as used by O = P~ V)
+            gv[e] = ok ? pr * (acc2[r] * mult - D_q) * scale : 0.f;                   // scale * dS[q][key]
+        }
+        pp[c] = f2bf_pk(pv[0], pv[1]);
+        gp[c] = f2bf_pk(gv[0], gv[1]);
     }
     floatx16 dk, dv;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(tile, LD, qc, ks, lane), pack_regs(g, ks), dk, 0, 0, 0);
-        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(dtile, LDO, oc, ks, lane), pack_regs(p, ks), dv, 0, 0, 0);
+        F8 fg, fp;
+        fg.u = make_uint4(gp[4 * ks], gp[4 * ks + 1], gp[4 * ks + 2], gp[4 * ks + 3]);
+        fp.u = make_uint4(pp[4 * ks], pp[4 * ks + 1], pp[4 * ks + 2], pp[4 * ks + 3]);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(tile, LD, qc, ks, lane), fg.v, dk, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(dtile, LDO, oc, ks, lane), fp.v, dv, 0, 0, 0);
     }
     // every operand read of this head's slabs is done (same wave, in-order LDS): stage dq|dk|dv over q|k|v
     __builtin_amdgcn_wave_barrier();
-    stage_rows(tile, LD, li, qc, h2, dq);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<uint2*>(&tile[li * LD + qc + 8 * c + 4 * h2]) = make_uint2(dq_pk[2 * c], dq_pk[2 * c + 1]);
     stage_rows(tile, LD, li, kc, h2, dk);
     stage_rows(tile, LD, li, vc, h2, dv);
     __syncthreads();
@@ -351,8 +381,9 @@ bool dsvg_attention_mfma_ok(int32_t dtype, int32_t S, int32_t n_heads) {
 int dsvg_attention_fwd_mfma(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
                             const int32_t* tile_first, void* out, int64_t n_seq, int32_t S, int32_t n_heads,
                             float scale, float drop_p, uint32_t drop_site, const uint64_t* seed, hipStream_t st) {
-    const size_t lds = (size_t)32 * LD * sizeof(bf16_t);
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)n_seq + (total_rows > 0 ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
+    const size_t lds = (size_t)32 * LD * sizeof(bf16_t) + 34 * sizeof(int);
+    auto kern = tile_first ? attn_fwd_mfma_kernel<true> : attn_fwd_mfma_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (total_rows > 0 ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
                        (const bf16_t*)qkv, key_mask, seq_off, (long long)total_rows, tile_first, (int)n_seq, (bf16_t*)out,
                        S, n_heads, scale, drop_p, drop_site, seed);
     DSVG_LAUNCH_CHECK("attention_fwd_mfma");
@@ -363,9 +394,10 @@ int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const int
                             const int32_t* tile_first, const void* dout, void* dqkv, int64_t n_seq, int32_t S,
                             int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
                             hipStream_t st) {
-    const size_t lds = (size_t)32 * (LD + LDO) * sizeof(bf16_t) + (size_t)HG * 64 * sizeof(float);
-    auto kern = attn_bwd_mfma_kernel;
-    DSVG_ENSURE_LDS(kern, lds);
+    const size_t lds = (size_t)32 * (LD + LDO) * sizeof(bf16_t) + (size_t)HG * 64 * sizeof(float) + 34 * sizeof(int);
+    auto kern = tile_first ? attn_bwd_mfma_kernel<true> : attn_bwd_mfma_kernel<false>;
+    DSVG_ENSURE_LDS(attn_bwd_mfma_kernel<true>, lds);
+    DSVG_ENSURE_LDS(attn_bwd_mfma_kernel<false>, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (total_rows > 0 ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
                        (const bf16_t*)qkv, key_mask, seq_off, (long long)total_rows, tile_first, (int)n_seq,
                        (const bf16_t*)dout, (bf16_t*)dqkv, S, n_heads, scale, drop_p, drop_site, seed);

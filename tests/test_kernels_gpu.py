@@ -328,8 +328,6 @@ def test_attention_packed_layout(gpu_device, dtype, S, n_seq):
         dq_t = ops.attention_bwd(qkv, None, do, n_seq, S, H_, 32 ** -0.5, p, 17, seed, seq_off=off, tiles=tiles)
         _close(out_t, ref, 2e-5 if dtype == torch.float32 else 2e-2, f"tiled packed attention fwd p={p}")
         _close(dq_t, dref, 5e-5 if dtype == torch.float32 else 3e-2, f"tiled packed attention bwd p={p}")
-        if dtype == torch.bfloat16 and S > 16:      # the MFMA kernel: identical math per sequence, tile or not
-            assert torch.equal(out_t, out) and torch.equal(dq_t, dq)
         assert torch.count_nonzero(out_t[total:]) == 0 and torch.count_nonzero(dq_t[total:]) == 0
 
 
