@@ -346,25 +346,34 @@ static int launch_bwd(const void* qkv, const uint64_t* km, const int32_t* seq_of
 // are staged in LDS in chunks, thread 0 walks them.
 __global__ __launch_bounds__(1024) void attention_tiles_kernel(const int32_t* __restrict__ seq_off, int n_seq,
                                                                int max_rows, int32_t* __restrict__ tile_first) {
+    // chunks of 1024 sequences: offsets staged in LDS, thread 0 runs the (inherently sequential) greedy walk over LDS
+    // with the loads unrolled ahead of the compare/select chain and collects the tile starts in LDS; all threads then
+    // copy the chunk's starts to global memory
     __shared__ int off[1025];
-    __shared__ int n_tiles, tile_start_row;
-    if (threadIdx.x == 0) { n_tiles = 0; tile_start_row = -1; }
+    __shared__ int starts[1024];
+    __shared__ int n_tiles, n_chunk, tile_start_row;
+    if (threadIdx.x == 0) { n_tiles = 0; tile_start_row = -(1 << 30); }
     __syncthreads();
     for (int base = 0; base < n_seq; base += 1024) {
         const int cnt = min(1024, n_seq - base);
         for (int i = threadIdx.x; i <= cnt; i += 1024) off[i] = seq_off[base + i];
         __syncthreads();
         if (threadIdx.x == 0) {
-            int nt = n_tiles, start = tile_start_row;
+            int nc = 0, start = tile_start_row;
+#pragma unroll 8
             for (int i = 0; i < cnt; ++i) {
-                if (start < 0 || off[i + 1] - start > max_rows) {      // sequence base+i opens a new tile
-                    tile_first[nt++] = base + i;
-                    start = off[i];
-                }
+                const bool open = off[i + 1] - start > max_rows;      // sequence base+i does not fit: opens a new tile
+                if (open) starts[nc] = base + i;
+                nc += open ? 1 : 0;
+                start = open ? off[i] : start;
             }
-            n_tiles = nt;
+            n_chunk = nc;
             tile_start_row = start;
         }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_chunk; i += 1024) tile_first[n_tiles + i] = starts[i];
+        __syncthreads();
+        if (threadIdx.x == 0) n_tiles += n_chunk;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
