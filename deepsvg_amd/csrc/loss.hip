@@ -65,6 +65,77 @@ extern "C" int dsvg_loss_targets(const float* tgt_commands, const float* tgt_arg
 // ---------------------------------------------------------------------------------------------
 constexpr int CE_MAX_BLOCKS = 2048;
 
+// Forward.  A wave takes RC (16 or 64) consecutive rows at a time: one coalesced load of their weights and a ballot
+// pick the rows that carry loss (88 % of the 1.4 M argument rows do not; per-row weight loads were a chain of
+// dependent global loads); each quarter-wave (16 lanes) then handles one of those rows with the row's logits held in
+// registers (one pass over memory, C <= 272), i.e. 4 rows in flight per wave.  The generic kernel below covers C > 272.
+constexpr int CE_NV = 17;           // register-resident row: 16 lanes x 17 elements
+template <typename T>
+__global__ __launch_bounds__(256) void masked_ce_fwd16_kernel(const T* __restrict__ logits, long long ld, int group,
+                                                              const int* __restrict__ target,
+                                                              const float* __restrict__ w, long long rows, int C,
+                                                              float* __restrict__ lse, float* __restrict__ part, int RC) {
+    __shared__ float red[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4, sl = lane & 15;
+    float acc_l = 0.f, acc_w = 0.f;
+    for (long long r0 = ((long long)blockIdx.x * 4 + wave) * RC; r0 < rows; r0 += (long long)gridDim.x * 4 * RC) {
+        const long long rl = r0 + lane;
+        const bool mine = lane < RC && rl < rows;
+        const float wl = mine ? (w ? w[rl] : 1.f) : 0.f;
+        if (mine && wl == 0.f) lse[rl] = 0.f;
+        const unsigned long long live = __ballot(wl != 0.f);
+        const int n_live = __popcll(live);
+        const int rank = __popcll(live & ((1ull << lane) - 1ull));       // rank of this lane's row among the live ones
+        for (int k = 0; k < n_live; k += 4) {
+            // quarter-wave `sub` takes the live row of rank k + sub
+            int j = -1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned long long hit = __ballot(wl != 0.f && rank == k + q);
+                if (q == sub && hit) j = __builtin_ctzll(hit);
+            }
+            const float wr = __shfl(wl, j < 0 ? 0 : j, 64);
+            if (j >= 0) {
+                const long long r = r0 + j;
+                const T* p = logits + (r / group) * ld + (r % group) * (long long)C;
+                float v[CE_NV];
+                float m = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < CE_NV; ++i) {
+                    const int c = sl + 16 * i;
+                    v[i] = c < C ? Elem<T>::ld(p + c) : -INFINITY;
+                    m = fmaxf(m, v[i]);
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+                float sacc = 0.f;
+#pragma unroll
+                for (int i = 0; i < CE_NV; ++i) sacc += (sl + 16 * i < C) ? __expf(v[i] - m) : 0.f;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 16);
+                const float l = m + __logf(sacc);
+                if (sl == 0) {
+                    lse[r] = l;
+                    int t = target[r];
+                    t = min(max(t, 0), C - 1);
+                    acc_l += wr * (l - Elem<T>::ld(p + t));
+                    acc_w += wr;
+                }
+            }
+        }
+    }
+    // lanes 0, 16, 32, 48 hold the quarter-wave sums: fixed-order combine
+    acc_l = acc_l + __shfl(acc_l, 16, 64) + (__shfl(acc_l, 32, 64) + __shfl(acc_l, 48, 64));
+    acc_w = acc_w + __shfl(acc_w, 16, 64) + (__shfl(acc_w, 32, 64) + __shfl(acc_w, 48, 64));
+    if (lane == 0) { red[wave][0] = acc_l; red[wave][1] = acc_w; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2 + 0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        part[blockIdx.x * 2 + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void masked_ce_fwd_kernel(const T* __restrict__ logits, long long ld, int group,
                                                             const int* __restrict__ target, const float* __restrict__ w,
@@ -73,34 +144,23 @@ __global__ __launch_bounds__(256) void masked_ce_fwd_kernel(const T* __restrict_
     __shared__ float red[4][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc_l = 0.f, acc_w = 0.f;
-    // a wave takes 64 consecutive rows at a time: one coalesced load of their weights, a ballot, then only the rows
-    // that carry loss are visited (88 % of the argument rows do not: a per-row weight load was a chain of dependent
-    // global loads, 228 us for the 1.4 M argument rows)
-    for (long long r0 = ((long long)blockIdx.x * 4 + wave) * 64; r0 < rows; r0 += (long long)gridDim.x * 4 * 64) {
-        const long long rl = r0 + lane;
-        const float wl = rl < rows ? (w ? w[rl] : 1.f) : 0.f;
-        if (rl < rows && wl == 0.f) lse[rl] = 0.f;
-        unsigned long long live = __ballot(wl != 0.f);
-        while (live) {
-            const int j = __builtin_ctzll(live);
-            live &= live - 1;
-            const long long r = r0 + j;
-            const float wr = __shfl(wl, j, 64);
-            const T* p = logits + (r / group) * ld + (r % group) * (long long)C;
-            float m = -INFINITY;
-            for (int c = lane; c < C; c += 64) m = fmaxf(m, Elem<T>::ld(p + c));
-            m = wave_max(m);
-            float s = 0.f;
-            for (int c = lane; c < C; c += 64) s += __expf(Elem<T>::ld(p + c) - m);
-            s = wave_sum(s);
-            const float l = m + __logf(s);
-            if (lane == 0) {
-                lse[r] = l;
-                int t = target[r];
-                t = min(max(t, 0), C - 1);
-                acc_l += wr * (l - Elem<T>::ld(p + t));
-                acc_w += wr;
-            }
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
+        const float wr = w ? w[r] : 1.f;
+        if (wr == 0.f) { if (lane == 0) lse[r] = 0.f; continue; }
+        const T* p = logits + (r / group) * ld + (r % group) * (long long)C;
+        float m = -INFINITY;
+        for (int c = lane; c < C; c += 64) m = fmaxf(m, Elem<T>::ld(p + c));
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += __expf(Elem<T>::ld(p + c) - m);
+        s = wave_sum(s);
+        const float l = m + __logf(s);
+        if (lane == 0) {
+            lse[r] = l;
+            int t = target[r];
+            t = min(max(t, 0), C - 1);
+            acc_l += wr * (l - Elem<T>::ld(p + t));
+            acc_w += wr;
         }
     }
     if (lane == 0) { red[wave][0] = acc_l; red[wave][1] = acc_w; }
@@ -149,8 +209,7 @@ __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const T* __restrict_
 }
 
 static int ce_grid(long long rows) {
-    long long nb = (rows + 255) / 256;      // 4 waves x 64 rows per sweep of the forward kernel
-    if (nb < 1) nb = 1;
+    long long nb = (rows + 3) / 4;
     return (int)(nb < CE_MAX_BLOCKS ? nb : CE_MAX_BLOCKS);
 }
 
@@ -162,8 +221,20 @@ extern "C" int dsvg_masked_ce_fwd(int32_t dtype, const void* logits, int64_t ld,
     DSVG_CHECK_ARG(logits && target && lse && sum_count && rows > 0 && C > 0 && group > 0, "masked_ce_fwd: bad args");
     DSVG_CHECK_ARG(workspace && workspace_bytes >= dsvg_masked_ce_workspace_bytes(rows), "masked_ce_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    const int nb = ce_grid(rows);
-    if (dtype == DSVG_F32)
+    const int nb = ce_grid(rows);       // the workspace holds at least this many partial rows
+    int nparts = nb;
+    if (C <= 16 * CE_NV) {
+        const int RC = rows >= 64LL * 4 * CE_MAX_BLOCKS ? 64 : 16;    // rows per wave sweep
+        const int nbq = (int)min((long long)nb, (rows + 4LL * RC - 1) / (4LL * RC));
+        nparts = nbq;
+        if (dtype == DSVG_F32)
+            hipLaunchKernelGGL(masked_ce_fwd16_kernel<float>, dim3(nbq), dim3(256), 0, st, (const float*)logits,
+                               (long long)ld, group, target, w, (long long)rows, C, lse, workspace, RC);
+        else if (dtype == DSVG_BF16)
+            hipLaunchKernelGGL(masked_ce_fwd16_kernel<bf16_t>, dim3(nbq), dim3(256), 0, st, (const bf16_t*)logits,
+                               (long long)ld, group, target, w, (long long)rows, C, lse, workspace, RC);
+        else { dsvg_set_error("masked_ce_fwd: bad dtype"); return -1; }
+    } else if (dtype == DSVG_F32)
         hipLaunchKernelGGL(masked_ce_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)logits, (long long)ld,
                            group, target, w, (long long)rows, C, lse, workspace);
     else if (dtype == DSVG_BF16)
@@ -171,7 +242,7 @@ extern "C" int dsvg_masked_ce_fwd(int32_t dtype, const void* logits, int64_t ld,
                            (long long)ld, group, target, w, (long long)rows, C, lse, workspace);
     else { dsvg_set_error("masked_ce_fwd: bad dtype"); return -1; }
     DSVG_LAUNCH_CHECK("masked_ce_fwd");
-    return dsvg_reduce_partials_strided(workspace, nb, 2, 2, sum_count, 0, st);
+    return dsvg_reduce_partials_strided(workspace, nparts, 2, 2, sum_count, 0, st);
 }
 
 extern "C" int dsvg_masked_ce_bwd(int32_t dtype, const void* logits, int64_t ld, int32_t group, const int32_t* target,
