@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=40)
     return ap.parse_args()
 
 
@@ -78,7 +78,7 @@ def cpu_baseline(cfg, sd, batch, steps):
     one()                                   # warm-up (also the fallback sample when the host is very slow)
     first = time.perf_counter() - t0
     done, t0 = 0, time.perf_counter()
-    while done < steps and (time.perf_counter() - t0) + first < 40.0:
+    while done < steps and (time.perf_counter() - t0) + first < 25.0:
         one()
         done += 1
     dt = (time.perf_counter() - t0) / done if done else first

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64) void attention_tiles_kernel(const int32_t* __re
                 const int j = __builtin_ctzll(cand);            // first sequence that does not fit: it opens a tile
                 if (lane == j) tile_first[nt] = sbase + base + j;
                 ++nt;
-                start = __shfl(o0, j, 64);
+                start = __builtin_amdgcn_readlane(o0, j);       // j is wave-uniform: a scalar read, not a permute
                 pos = j + 1;
             }
         }
