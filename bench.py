@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--ffn-replay", type=int, default=0,
+                    help="N > 0: after the roofline leg replay ONLY the step's FFN GEMM launches N times on random "
+                         "operands of the recorded shapes (for a rocprofv3 --pmc pass, scripts/gpu_ffn_traffic.sh)")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=40)
     return ap.parse_args()
@@ -86,6 +89,43 @@ def cpu_baseline(cfg, sd, batch, steps):
             "host_cores": ncores, "kind": "port",
             "sample": f"{max(done, 1)} train step(s) of batch {batch} (fwd+SVGLoss+bwd+clip+AdamW, dropout off, fp32, "
                       f"oracle/svg_transformer_oracle.py), {dt * 1e3:.0f} ms/step"}
+
+
+def replay_ffn(specs, n, device):
+    """the FFN GEMM launches of one step, again, on random operands of the recorded shapes (PMC pass only)"""
+    from deepsvg_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(0)
+    seed = torch.tensor([1234], dtype=torch.int64, device=device)
+    calls = []
+    for sp in specs:
+        dt = torch.bfloat16 if "bfloat16" in sp["dtype"] else torch.float32
+        A = (torch.randn(sp["a"], generator=g) * 0.5).to(device).to(dt)
+        B = (torch.randn(sp["b"], generator=g) * 0.1).to(device).to(dt)
+        M = sp["a"][0] if sp["a_kc"] else sp["a"][1]
+        N = sp["b"][0] if sp["b_kc"] else sp["b"][1]
+        kw = dict(a_kc=sp["a_kc"], b_kc=sp["b_kc"], act=sp["act"], drop_p=sp["drop_p"], drop_site=3, seed=seed,
+                  split_k=sp["split_k"])
+        if sp["bias"]:
+            kw["bias"] = torch.randn(N, device=device)
+        if sp["res"]:
+            kw["res"] = (torch.randn(M, N, generator=g) * 0.5).to(device).to(dt)
+        if sp["gate"]:
+            kw["gate"] = (torch.randn(M, N, generator=g)).to(device).to(dt)
+            kw["gate_scale"] = sp["gate_scale"]
+        if sp["split_k"] > 1:
+            flat = torch.empty(M * N + M, device=device, dtype=torch.float32)
+            kw["out"] = flat[:M * N].view(M, N)
+            if sp["rowsum"]:
+                kw["rowsum"] = flat[M * N:]
+        elif sp["out_f32"]:
+            kw["out_dtype"] = torch.float32
+        calls.append((A, B, kw))
+    torch.cuda.synchronize()
+    for _ in range(n):
+        for A, B, kw in calls:
+            ops.gemm(A, B, **kw)
+    torch.cuda.synchronize()
+    log(f"replayed {len(calls)} FFN launches x {n}")
 
 
 def log(msg):
@@ -202,6 +242,21 @@ def main():
                         "hbm_view": {"algorithmic_GB_per_step": round(bytes_exec / 1e9, 3),
                                      "achieved_TBps": round(bytes_exec / (ffn_ms * 1e-3) / 1e12, 3), "peak_TBps": 8.0,
                                      "frac": round(bytes_exec / (ffn_ms * 1e-3) / 8e12, 4)}}
+
+            # HBM traffic of exactly these launches, measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the
+            # --ffn-replay mode of this script (scripts/gpu_ffn_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md
+            # prescribes for 16-byte streaming reads on gfx950); committed under profiles/, keyed by the executed FLOPs
+            tj = os.path.join(ROOT, "profiles", "ffn_traffic.json")
+            if os.path.exists(tj):
+                t = json.load(open(tj))
+                if abs(t.get("executed_gflop_per_step", 0) - flop_exec / 1e9) < 0.02 * flop_exec / 1e9 \
+                        and t.get("dtype") == a.dtype:
+                    roofline["traffic"] = t["hbm_GB_per_step"]
+                    roofline["traffic_unit"] = "GB per step (all FFN launches; rocprofv3 --pmc, " + t["source"] + ")"
+                    roofline["traffic_over_algorithmic"] = round(t["hbm_GB_per_step"] / (bytes_exec / 1e9), 3)
+            if a.ffn_replay > 0:
+                specs = [r[5] for r in ffn[:n_ffn]]
+                replay_ffn(specs, a.ffn_replay, device)
 
     log(f"roofline leg done: {roofline}")
     cpu = None

@@ -168,8 +168,12 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
         _l.check(L.dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
         ev1.record()
         esz = 2 if a.dtype == torch.bfloat16 else 4
+        extra = (esz * d.M * d.N if (res is not None or gate is not None) else 0)    # residual / gate operand
+        spec = dict(a=tuple(a.shape), b=tuple(b.shape), a_kc=a_kc, b_kc=b_kc, bias=bias is not None, res=res is not None,
+                    act=act, gate=gate is not None, gate_scale=gate_scale, drop_p=drop_p, split_k=split_k,
+                    rowsum=rowsum is not None, out_f32=out.dtype == torch.float32, dtype=str(a.dtype))
         PROFILE.append((_TAG, ev0, ev1, 2.0 * d.M * d.N * d.K,
-                        float(esz * (d.M * d.K + d.N * d.K) + out.element_size() * d.M * d.N)))
+                        float(esz * (d.M * d.K + d.N * d.K) + out.element_size() * d.M * d.N + extra), spec))
         return out
     _l.check(L.dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
     return out
