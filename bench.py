@@ -231,18 +231,28 @@ def main():
             flop_exec = sum(r[3] for r in ffn) / n_prof             # what the launches executed
             bytes_exec = sum(r[4] for r in ffn) / n_prof            # operands + outputs of those launches, once each
             flop_padded = a.batch * FFN_FLOP_PER_ICON_TRAIN         # the reference's padded layout
-            ach = flop_exec / (ffn_ms * 1e-3) / 1e12
-            peak = PEAK_TFLOPS[a.dtype]
-            roofline = {"bound": "mfma", "kernel": "FFN GEMMs (linear1/linear2 fwd + dX + dW)", "achieved": round(ach, 2),
-                        "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            tf = flop_exec / (ffn_ms * 1e-3) / 1e12
+            peak_tf = PEAK_TFLOPS[a.dtype]
+            gbs = bytes_exec / (ffn_ms * 1e-3) / 1e9
+            # Which roofline bounds these kernels: an unfused d_model = 256 GEMM has ~170 FLOP per algorithmic byte,
+            # below the ~310 FLOP/B ridge of 2.5 PFLOP/s over 8 TB/s -> HBM-bound in bf16 (PMC: measured traffic =
+            # algorithmic bytes); the exact-fp32 MFMA path (157 TFLOP/s peak) is compute-bound.  Both views are given.
+            hbm_bound = a.dtype == "bf16"
+            mfma_view = {"achieved_TFLOPs": round(tf, 2), "peak_TFLOPs": peak_tf, "frac": round(tf / peak_tf, 4),
+                         "executed_gflop_per_step": round(flop_exec / 1e9, 1),
+                         "padded_layout_gflop_per_step": round(flop_padded / 1e9, 1),
+                         "padding_skipped_frac": round(1.0 - flop_exec / flop_padded, 4)}
+            hbm_view = {"achieved_GBps": round(gbs, 1), "peak_GBps": 8000.0, "frac": round(gbs / 8000.0, 4),
+                        "algorithmic_GB_per_step": round(bytes_exec / 1e9, 3)}
+            roofline = {"bound": "hbm" if hbm_bound else "mfma",
+                        "kernel": "FFN GEMMs (linear1/linear2 fwd + dX + dW), %d launches per step" % n_ffn,
+                        "achieved": hbm_view["achieved_GBps"] if hbm_bound else mfma_view["achieved_TFLOPs"],
+                        "peak": 8000.0 if hbm_bound else peak_tf, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                        "frac": hbm_view["frac"] if hbm_bound else mfma_view["frac"], "traffic": None,
                         "launches_per_step": n_ffn, "ffn_ms_per_step": round(ffn_ms, 3),
-                        "executed_gflop_per_step": round(flop_exec / 1e9, 1),
-                        "padded_layout_gflop_per_step": round(flop_padded / 1e9, 1),
-                        "padding_skipped_frac": round(1.0 - flop_exec / flop_padded, 4),
-                        "hbm_view": {"algorithmic_GB_per_step": round(bytes_exec / 1e9, 3),
-                                     "achieved_TBps": round(bytes_exec / (ffn_ms * 1e-3) / 1e12, 3), "peak_TBps": 8.0,
-                                     "frac": round(bytes_exec / (ffn_ms * 1e-3) / 8e12, 4)}}
-
+                        "avg_launch_us": round(ffn_ms * 1e3 / n_ffn, 2),
+                        "algorithmic_MB_per_launch": round(bytes_exec / n_ffn / 1e6, 2),
+                        "hbm_view": hbm_view, "mfma_view": mfma_view}
             # HBM traffic of exactly these launches, measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the
             # --ffn-replay mode of this script (scripts/gpu_ffn_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md
             # prescribes for 16-byte streaming reads on gfx950); committed under profiles/, keyed by the executed FLOPs
@@ -251,8 +261,9 @@ def main():
                 t = json.load(open(tj))
                 if abs(t.get("executed_gflop_per_step", 0) - flop_exec / 1e9) < 0.02 * flop_exec / 1e9 \
                         and t.get("dtype") == a.dtype:
-                    roofline["traffic"] = t["hbm_GB_per_step"]
-                    roofline["traffic_unit"] = "GB per step (all FFN launches; rocprofv3 --pmc, " + t["source"] + ")"
+                    roofline["traffic"] = round(t["hbm_GB_per_step"] * 1e3 / n_ffn, 2)
+                    roofline["traffic_unit"] = "MB per launch (mean over the FFN launches; rocprofv3 --pmc, " + \
+                                               t["source"] + ")"
                     roofline["traffic_over_algorithmic"] = round(t["hbm_GB_per_step"] / (bytes_exec / 1e9), 3)
             if a.ffn_replay > 0:
                 specs = [r[5] for r in ffn[:n_ffn]]
