@@ -69,15 +69,38 @@ __device__ __forceinline__ void stage_rows(bf16_t* img, int ld, int row, int col
     }
 }
 
-// rows [0,S) of `cols` columns, 16-byte pieces; rows [S,32) are zero-filled
-__device__ __forceinline__ void load_slab(bf16_t* dst, int ld_dst, const bf16_t* src, long long ld_src, int S, int cols) {
-    const int cpr = cols / 8;
-    for (int idx = threadIdx.x; idx < 32 * cpr; idx += 512) {
-        const int r = idx / cpr, c = idx % cpr;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (r < S) v = *reinterpret_cast<const uint4*>(src + r * ld_src + 8 * c);
-        *reinterpret_cast<uint4*>(dst + r * ld_dst + 8 * c) = v;
-    }
+// 32 rows x W columns of up to four slabs -> LDS, 16-byte pieces, rows [S,32) zero-filled.  W = 256: 1024 pieces per
+// slab = 2 per thread.  All loads are issued before the first use, from row-clamped addresses with the zero selected
+// afterwards: a load under `if (r < S)` is compiled as a branch + s_waitcnt vmcnt(0) per piece, i.e. 6-8 dependent
+// HBM round trips at the start of every workgroup.
+struct SlabSrc {
+    const bf16_t* src;
+    long long ld;
+    bf16_t* dst;
+    int ld_dst;
+};
+template <int NS>
+__device__ __forceinline__ void load_slabs(const SlabSrc (&sl)[NS], int S) {
+    constexpr int CPR = W / 8;                 // 16-byte pieces per row
+    constexpr int PER = 32 * CPR / 512;        // pieces per thread and slab
+    uint4 v[NS][PER];
+    const int rmax = S > 0 ? S - 1 : 0;
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int idx = threadIdx.x + 512 * k;
+            const int r = idx / CPR, c = idx % CPR;
+            v[n][k] = *reinterpret_cast<const uint4*>(sl[n].src + (long long)min(r, rmax) * sl[n].ld + 8 * c);
+        }
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int idx = threadIdx.x + 512 * k;
+            const int r = idx / CPR, c = idx % CPR;
+            *reinterpret_cast<uint4*>(sl[n].dst + r * sl[n].ld_dst + 8 * c) = r < S ? v[n][k] : make_uint4(0u, 0u, 0u, 0u);
+        }
 }
 __device__ __forceinline__ void store_slab(bf16_t* dst, long long ld_dst, const bf16_t* src, int ld_src, int S, int cols) {
     const int cpr = cols / 8;
@@ -130,9 +153,10 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
         S = seq_off[s_last] - seq_off[s_first];
     }
     const bf16_t* src = qkv + (size_t)row0 * 3 * d + (size_t)hg * W;
-    load_slab(tile, LD, src, 3LL * d, S, W);
-    load_slab(tile + W, LD, src + d, 3LL * d, S, W);
-    load_slab(tile + 2 * W, LD, src + 2 * d, 3LL * d, S, W);
+    {
+        const SlabSrc sl[3] = {{src, 3LL * d, tile, LD}, {src + d, 3LL * d, tile + W, LD}, {src + 2 * d, 3LL * d, tile + 2 * W, LD}};
+        load_slabs<3>(sl, S);
+    }
     __syncthreads();
     // this lane's row (query in pass A, key in pass B): its sequence, first row of that sequence in the tile, length
     int my_seq = b, my_start = 0, my_len = S;
@@ -236,10 +260,11 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
     }
 
     const bf16_t* src = qkv + (size_t)row0 * 3 * d + (size_t)hg * W;
-    load_slab(tile, LD, src, 3LL * d, S, W);
-    load_slab(tile + W, LD, src + d, 3LL * d, S, W);
-    load_slab(tile + 2 * W, LD, src + 2 * d, 3LL * d, S, W);
-    load_slab(dtile, LDO, dout + (size_t)row0 * d + (size_t)hg * W, (long long)d, S, W);
+    {
+        const SlabSrc sl[4] = {{src, 3LL * d, tile, LD}, {src + d, 3LL * d, tile + W, LD}, {src + 2 * d, 3LL * d, tile + 2 * W, LD},
+                               {dout + (size_t)row0 * d + (size_t)hg * W, (long long)d, dtile, LDO}};
+        load_slabs<4>(sl, S);
+    }
     __syncthreads();
     // this lane's row (query in pass A, key in pass B): its sequence, first row of that sequence in the tile, length
     int my_seq = b, my_start = 0, my_len = S;

@@ -299,7 +299,7 @@ extern "C" int dsvg_embed_gather(int32_t dtype, const float* commands, const flo
 // global atomics.  (LDS float atomics make the sum order inside one workgroup schedule-dependent, i.e.
 // reproducible to ~1e-7 relative, not bitwise.)
 // ---------------------------------------------------------------------------------------------
-constexpr int ES_TOK_PER_BLOCK = 64;
+constexpr int ES_TOK_PER_BLOCK = 128;
 
 // Each thread owns up to 4 columns (c = tid + 256 k) of the [n_args * E] gradient row, i.e. fixed (arg slot, e) pairs;
 // tokens are processed 4 at a time with all of their loads issued before the first LDS atomic (the loop is otherwise a
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void embed_scatter_arg_kernel(const float* __r
     const long long t0 = (long long)blockIdx.x * ES_TOK_PER_BLOCK;
     const long long t1 = min(T_tok, t0 + ES_TOK_PER_BLOCK);
     const int width = n_args * E;
-    constexpr int KC = 4, TU = 4;
+    constexpr int KC = 4, TU = 8;
     int a_of[KC], e_of[KC];
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
@@ -340,9 +340,14 @@ __global__ __launch_bounds__(256) void embed_scatter_arg_kernel(const float* __r
             const long long t = tb + u;
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
+                // unconditional loads from clamped addresses, select afterwards (a guarded load is compiled as a branch
+                // plus s_waitcnt vmcnt(0) per element: the loads would not overlap)
                 const bool ok = t < t1 && a_of[k] >= 0;
-                g[u][k] = ok ? Elem<T>::ld(dA + t * width + threadIdx.x + 256 * k) : 0.f;
-                iv[u][k] = ok ? (int)args[t * n_args + a_of[k]] + 1 : 0;
+                const long long tt = min(t, t1 - 1);
+                const float gv = Elem<T>::ld(dA + tt * width + (a_of[k] >= 0 ? threadIdx.x + 256 * k : 0));
+                const int av = (int)args[tt * n_args + max(a_of[k], 0)] + 1;
+                g[u][k] = ok ? gv : 0.f;
+                iv[u][k] = ok ? av : 0;
             }
         }
 #pragma unroll

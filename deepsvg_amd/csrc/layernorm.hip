@@ -6,10 +6,10 @@
 #include "dsvg_common.h"
 #include "../../include/dsvg.h"
 
-constexpr int LN_MAXV = 4;            // 4 x (64 lanes x 4 elements) = 1024 features max
+constexpr int LN_MAXV_MAX = 4;        // 4 x (64 lanes x 4 elements) = 1024 features max; kernels are built for 1, 2, 4
 constexpr int LN_MAX_BLOCKS = 2048;   // backward: 8 resident workgroups per CU (32 waves), one partial row each
 
-template <typename T>
+template <typename T, int LN_MAXV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
@@ -17,6 +17,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nv = d / 256 + ((d % 256) ? 1 : 0);
+    // row-invariant scale / shift: loaded once, up front and unconditionally (clamped column) so that they are in
+    // flight together with the row itself instead of costing a dependent round trip after the reductions
+    float4 g4[LN_MAXV], b4[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = min(i * 256 + lane * 4, d - 4);
+        g4[i] = *reinterpret_cast<const float4*>(gamma + c);
+        b4[i] = *reinterpret_cast<const float4*>(beta + c);
+    }
     for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
         const T* xr = x + row * d;
         float v[LN_MAXV][4];
@@ -49,8 +58,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = i * 256 + lane * 4;
             if (i < nv && c < d) {
-                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-                const float4 b = *reinterpret_cast<const float4*>(beta + c);
+                const float4 g = g4[i];
+                const float4 b = b4[i];
                 float o[4];
                 o[0] = (v[i][0] - mu) * rs * g.x + b.x;
                 o[1] = (v[i][1] - mu) * rs * g.y + b.y;
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // dx = [res +] rstd * (g*dy - mean_d(g*dy) - xhat * mean_d(g*dy*xhat))
 // dgamma/dbeta: per-wave register accumulation over the wave's rows, combined per block in LDS, one
 // partial row per block -> workspace [gridDim.x][2][d]; reduced by dsvg_reduce_partials.
-template <typename T>
+template <typename T, int LN_MAXV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const T* res,
@@ -85,9 +94,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; }
 
+    float4 g4[LN_MAXV];             // row-invariant, loaded once (clamped column)
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) g4[i] = *reinterpret_cast<const float4*>(gamma + min(i * 256 + lane * 4, d - 4));
     for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
-        float xh[LN_MAXV][4], gd[LN_MAXV][4];
+        float xh[LN_MAXV][4], gd[LN_MAXV][4], rv[LN_MAXV][4];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
@@ -96,7 +108,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* __res
                 float xv[4], dv[4];
                 Elem<T>::ld4(x + row * d + c, xv);
                 Elem<T>::ld4(dy + row * d + c, dv);
-                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+                // the residual gradient is fetched with x and dy (one HBM round trip per row instead of two)
+                if (res) Elem<T>::ld4(res + row * d + c, rv[i]);
+                const float4 g = g4[i];
                 const float gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -122,10 +136,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* __res
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (gd[i][e] - c1 - xh[i][e] * c2);
                 if (res) {
-                    float rv[4];
-                    Elem<T>::ld4(res + row * d + c, rv);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += rv[e];
+                    for (int e = 0; e < 4; ++e) o[e] += rv[i][e];
                 }
                 Elem<T>::st4(dx + row * d + c, o);
             }
@@ -173,13 +185,12 @@ extern "C" int dsvg_layernorm_fwd(int32_t dtype, const void* x, const float* gam
     DSVG_CHECK_ARG(rows > 0 && d > 0 && (d % 4) == 0 && d <= 1024, "layernorm_fwd: bad shape rows=%lld d=%d",
                    (long long)rows, d);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DSVG_F32)
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(ln_grid_fwd(rows)), dim3(256), 0, st, (const float*)x, gamma, beta,
-                           (float*)y, mean, rstd, (long long)rows, d, eps);
-    else if (dtype == DSVG_BF16)
-        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(ln_grid_fwd(rows)), dim3(256), 0, st, (const bf16_t*)x, gamma, beta,
-                           (bf16_t*)y, mean, rstd, (long long)rows, d, eps);
+#define DSVG_LNF(TT, NV) hipLaunchKernelGGL((ln_fwd_kernel<TT, NV>), dim3(ln_grid_fwd(rows)), dim3(256), 0, st, \
+                                            (const TT*)x, gamma, beta, (TT*)y, mean, rstd, (long long)rows, d, eps)
+    if (dtype == DSVG_F32) { if (d <= 256) DSVG_LNF(float, 1); else if (d <= 512) DSVG_LNF(float, 2); else DSVG_LNF(float, 4); }
+    else if (dtype == DSVG_BF16) { if (d <= 256) DSVG_LNF(bf16_t, 1); else if (d <= 512) DSVG_LNF(bf16_t, 2); else DSVG_LNF(bf16_t, 4); }
     else { dsvg_set_error("layernorm_fwd: bad dtype %d", dtype); return -1; }
+#undef DSVG_LNF
     DSVG_LAUNCH_CHECK("layernorm_fwd");
     return 0;
 }
@@ -199,13 +210,13 @@ extern "C" int dsvg_layernorm_bwd(int32_t dtype, const void* dy, const void* x, 
     hipStream_t st = (hipStream_t)stream;
     const int nb = ln_grid(rows);
     const size_t lds = (size_t)4 * 2 * (d / 4 + 1) * 4 * sizeof(float);
-    if (dtype == DSVG_F32)
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), lds, st, (const float*)dy, (const float*)x, mean,
-                           rstd, gamma, (const float*)res, (float*)dx, workspace, (long long)rows, d);
-    else if (dtype == DSVG_BF16)
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, mean,
-                           rstd, gamma, (const bf16_t*)res, (bf16_t*)dx, workspace, (long long)rows, d);
+#define DSVG_LNB(TT, NV) hipLaunchKernelGGL((ln_bwd_kernel<TT, NV>), dim3(nb), dim3(256), lds, st, (const TT*)dy, \
+                                            (const TT*)x, mean, rstd, gamma, (const TT*)res, (TT*)dx, workspace,  \
+                                            (long long)rows, d)
+    if (dtype == DSVG_F32) { if (d <= 256) DSVG_LNB(float, 1); else if (d <= 512) DSVG_LNB(float, 2); else DSVG_LNB(float, 4); }
+    else if (dtype == DSVG_BF16) { if (d <= 256) DSVG_LNB(bf16_t, 1); else if (d <= 512) DSVG_LNB(bf16_t, 2); else DSVG_LNB(bf16_t, 4); }
     else { dsvg_set_error("layernorm_bwd: bad dtype %d", dtype); return -1; }
+#undef DSVG_LNB
     DSVG_LAUNCH_CHECK("layernorm_bwd");
     // workspace rows are [dgamma(d) | dbeta(d)]; in the flat gradient buffer norm.bias follows norm.weight, so the
     // usual case is ONE deterministic reduction of 2d columns, otherwise two strided ones

@@ -103,8 +103,11 @@ __global__ __launch_bounds__(256) void masked_ce_fwd16_kernel(const T* __restric
                 float m = -INFINITY;
 #pragma unroll
                 for (int i = 0; i < CE_NV; ++i) {
+                    // unconditional load from a clamped column, select afterwards: a guarded load makes hipcc branch
+                    // around every load and wait vmcnt(0) after each (17 dependent round trips per row)
                     const int c = sl + 16 * i;
-                    v[i] = c < C ? Elem<T>::ld(p + c) : -INFINITY;
+                    const float x = Elem<T>::ld(p + min(c, C - 1));
+                    v[i] = c < C ? x : -INFINITY;
                     m = fmaxf(m, v[i]);
                 }
 #pragma unroll
@@ -197,9 +200,20 @@ __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const T* __restrict_
             const float l = lse[r];
             int t = target[r];
             t = min(max(t, 0), C - 1);
-            for (int c = lane; c < C; c += 64) {
-                const float sm = __expf(Elem<T>::ld(p + c) - l);
-                Elem<T>::st(q + c, wr * g * (sm - (c == t ? 1.f : 0.f)));
+            if (C <= 320) {     // all loads of the row in flight at once (clamped column, see masked_ce_fwd16_kernel)
+                float xv[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) xv[i] = Elem<T>::ld(p + min(lane + 64 * i, C - 1));
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < C) Elem<T>::st(q + c, wr * g * (__expf(xv[i] - l) - (c == t ? 1.f : 0.f)));
+                }
+            } else {
+                for (int c = lane; c < C; c += 64) {
+                    const float sm = __expf(Elem<T>::ld(p + c) - l);
+                    Elem<T>::st(q + c, wr * g * (sm - (c == t ? 1.f : 0.f)));
+                }
             }
         }
         if (slot == group - 1) {   // zero the row padding so padded-K GEMMs read zeros

@@ -3,6 +3,8 @@ only: every op takes/returns torch tensors that live on a HIP device and enqueue
 kernels on the current stream.  No op has a CPU or aten fallback.
 """
 import ctypes as C
+import os
+
 import torch
 
 from . import lib as _l
@@ -179,9 +181,13 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
     return out
 
 
-def split_k_for(M, N, K, target_blocks=512):
+_SPLITK_BLOCKS = int(os.environ.get("DSVG_SPLITK_BLOCKS", "512"))     # tuning knob
+
+
+def split_k_for(M, N, K, target_blocks=None):
     """split factor for the weight-gradient GEMMs (small M x N output, K = #tokens): a multiple of 8 so that the
     K slices are grouped per XCD (see gemm_bf16.hip), about `target_blocks` workgroups in total."""
+    target_blocks = target_blocks or _SPLITK_BLOCKS
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     s = max(1, target_blocks // tiles)
     s = min(s, max(1, K // 128))
