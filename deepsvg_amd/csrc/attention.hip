@@ -340,52 +340,77 @@ static int launch_bwd(const void* qkv, const uint64_t* km, const int32_t* seq_of
         if (S <= 64) return FN<T, 64, 1>(__VA_ARGS__);                              \
     } while (0)
 
-// Greedy grouping of the packed sequences into attention tiles of at most 32 rows (the MFMA kernel's score tile):
+// Grouping of the packed sequences into attention tiles of at most 32 rows (the MFMA kernel's score tile):
 // tile j = sequences tile_first[j] .. tile_first[j+1]-1; tile_first[n_tiles] = n_seq; tile_first[n_seq + 1] = n_tiles.
-// The average packed encoder sequence has ~10 valid tokens, so a tile carries ~3 of them.  One workgroup: the offsets
-// are staged in LDS in chunks, thread 0 walks them.
-__global__ __launch_bounds__(64) void attention_tiles_kernel(const int32_t* __restrict__ seq_off, int n_seq,
-                                                             int max_rows, int32_t* __restrict__ tile_first) {
-    // ONE wave.  The greedy walk is sequential in the tiles, not in the sequences: the offsets of 64 sequences sit in
-    // the 64 lanes, a ballot finds the first sequence that no longer fits the open tile, a shuffle fetches the row it
-    // starts at - a handful of wave instructions per TILE (about 1400 tiles for 4096 packed sequences).
-    constexpr int STAGE = 8192;
-    __shared__ int off[STAGE + 1];
-    const int lane = threadIdx.x;
-    int nt = 0;
-    int start = -(1 << 30);
-    for (int sbase = 0; sbase < n_seq; sbase += STAGE) {
-        const int cnt = min(STAGE, n_seq - sbase);
-        for (int i = lane; i <= cnt; i += 64) off[i] = seq_off[sbase + i];       // independent, coalesced loads
+// The average packed encoder sequence has ~10 valid tokens, so a tile carries ~3 of them.  Greedy inside segments of 64
+// consecutive sequences (a tile never crosses a segment boundary: ~5 % more tiles than the global greedy walk, which is
+// inherently sequential): one wave per segment, the 64 offsets in the 64 lanes, a ballot finds the first sequence that
+// no longer fits the open tile and a scalar lane read fetches the row it starts at; the per-segment lists are then
+// compacted with a workgroup scan.
+__global__ __launch_bounds__(1024) void attention_tiles_kernel(const int32_t* __restrict__ seq_off, int n_seq,
+                                                               int max_rows, int32_t* __restrict__ tile_first,
+                                                               int32_t* __restrict__ scratch) {
+    __shared__ int cnt[1024];
+    __shared__ int carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_segs = (n_seq + 63) / 64;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int seg0 = 0; seg0 < n_segs; seg0 += 1024) {
+        const int seg1 = min(n_segs, seg0 + 1024);
+        cnt[threadIdx.x] = 0;
         __syncthreads();
-        for (int base = 0; base < cnt; base += 64) {
-            const int i = base + lane;
-            const bool valid = i < cnt;
-            const int o0 = valid ? off[i] : 0;
-            const int o1 = valid ? off[i + 1] : 0;
-            int pos = 0;
+        for (int sg = seg0 + wave; sg < seg1; sg += 16) {
+            const int i = sg * 64 + lane;
+            const bool valid = i < n_seq;
+            const int o0 = valid ? seq_off[i] : 0;
+            const int o1 = valid ? seq_off[i + 1] : 0;
+            int start = -(1 << 30), pos = 0, c = 0;
             while (true) {
                 const unsigned long long cand = __ballot(valid && lane >= pos && (o1 - start > max_rows));
                 if (!cand) break;
                 const int j = __builtin_ctzll(cand);            // first sequence that does not fit: it opens a tile
-                if (lane == j) tile_first[nt] = sbase + base + j;
-                ++nt;
+                if (lane == j) scratch[sg * 64 + c] = i;
+                ++c;
                 start = __builtin_amdgcn_readlane(o0, j);       // j is wave-uniform: a scalar read, not a permute
                 pos = j + 1;
             }
+            if (lane == 0) cnt[sg - seg0] = c;
         }
         __syncthreads();
+        const int mine = cnt[threadIdx.x];
+        for (int o = 1; o < 1024; o <<= 1) {                    // inclusive scan of the segment counts
+            const int v = threadIdx.x >= o ? cnt[threadIdx.x - o] : 0;
+            __syncthreads();
+            cnt[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const int total = cnt[1023];
+        const int excl = cnt[threadIdx.x] - mine;
+        __syncthreads();
+        cnt[threadIdx.x] = excl;
+        __syncthreads();
+        __threadfence_block();
+        for (int sg = seg0 + wave; sg < seg1; sg += 16) {
+            const int first = carry + cnt[sg - seg0];
+            const int c = (sg - seg0 + 1 < 1024 ? cnt[sg - seg0 + 1] : total) - cnt[sg - seg0];
+            for (int q = lane; q < c; q += 64) tile_first[first + q] = scratch[sg * 64 + q];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry += total;
+        __syncthreads();
     }
-    if (lane == 0) {
-        tile_first[nt] = n_seq;
-        tile_first[n_seq + 1] = nt;
+    if (threadIdx.x == 0) {
+        tile_first[carry] = n_seq;
+        tile_first[n_seq + 1] = carry;
     }
 }
 extern "C" int dsvg_attention_tiles(const int32_t* seq_off, int64_t n_seq, int32_t max_rows, int32_t* tile_first,
-                                    void* stream) {
-    DSVG_CHECK_ARG(seq_off && tile_first && n_seq > 0 && n_seq < (1 << 30) && max_rows > 0, "attention_tiles: bad args");
-    hipLaunchKernelGGL(attention_tiles_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seq_off, (int)n_seq, max_rows,
-                       tile_first);
+                                    int32_t* scratch, void* stream) {
+    DSVG_CHECK_ARG(seq_off && tile_first && scratch && n_seq > 0 && n_seq < (1 << 30) && max_rows > 0,
+                   "attention_tiles: bad args");
+    hipLaunchKernelGGL(attention_tiles_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, seq_off, (int)n_seq, max_rows,
+                       tile_first, scratch);
     DSVG_LAUNCH_CHECK("attention_tiles");
     return 0;
 }

@@ -318,6 +318,7 @@ __global__ __launch_bounds__(256) void embed_scatter_arg_kernel(const float* __r
     const int width = n_args * E;
     constexpr int KC = 4, TU = 8;
     int a_of[KC], e_of[KC];
+    float acc0[KC] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
         const int c = threadIdx.x + 256 * k;
@@ -353,9 +354,18 @@ __global__ __launch_bounds__(256) void embed_scatter_arg_kernel(const float* __r
 #pragma unroll
         for (int u = 0; u < TU; ++u)
 #pragma unroll
-            for (int k = 0; k < KC; ++k)
-                if (g[u][k] != 0.f) atomicAdd(&acc[min(max(iv[u][k], 0), n_argvals - 1) * E + e_of[k]], g[u][k]);
+            for (int k = 0; k < KC; ++k) {
+                const int row = min(max(iv[u][k], 0), n_argvals - 1);
+                // table row 0 (argument value -1 = "unused slot") receives ~60 % of all contributions: those are summed
+                // in a register of the thread that owns the column (LDS float atomics run at a fraction of a lane per
+                // clock) and added once at the end
+                if (row == 0) acc0[k] += g[u][k];
+                else if (g[u][k] != 0.f) atomicAdd(&acc[row * E + e_of[k]], g[u][k]);
+            }
     }
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+        if (a_of[k] >= 0 && acc0[k] != 0.f) atomicAdd(&acc[e_of[k]], acc0[k]);
     __syncthreads();
     float* dst = part + (size_t)blockIdx.x * tab;
     for (int i = threadIdx.x; i < tab; i += 256) dst[i] = acc[i];

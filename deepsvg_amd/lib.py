@@ -52,7 +52,7 @@ SIGNATURES = {
     "dsvg_layernorm_bwd_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "dsvg_attention_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
     "dsvg_attention_bwd": (c_i32, [c_i32, vp, vp, vp, c_i64, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
-    "dsvg_attention_tiles": (c_i32, [vp, c_i64, c_i32, vp, vp]),
+    "dsvg_attention_tiles": (c_i32, [vp, c_i64, c_i32, vp, vp, vp]),
     "dsvg_pack_tokens": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, vp]),
     "dsvg_visible_first": (c_i32, [vp, c_i64, vp, vp, vp, vp]),
     "dsvg_gather_groups": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, vp]),

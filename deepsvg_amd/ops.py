@@ -258,8 +258,9 @@ def attention_tiles(seq_off, n_seq, max_rows=32):
     _chk(seq_off)
     assert seq_off.dtype == torch.int32 and seq_off.numel() == n_seq + 1
     tiles = torch.empty(n_seq + 2, dtype=torch.int32, device=seq_off.device)
-    _l.check(_l.load().dsvg_attention_tiles(seq_off.data_ptr(), n_seq, max_rows, tiles.data_ptr(), _stream()),
-             "dsvg_attention_tiles")
+    scratch = torch.empty((n_seq + 63) // 64 * 64, dtype=torch.int32, device=seq_off.device)
+    _l.check(_l.load().dsvg_attention_tiles(seq_off.data_ptr(), n_seq, max_rows, tiles.data_ptr(), scratch.data_ptr(),
+                                            _stream()), "dsvg_attention_tiles")
     return tiles
 
 

@@ -121,9 +121,10 @@ int dsvg_attention_bwd(int32_t dtype, const void* qkv, const uint64_t* key_mask,
                        int32_t S, int32_t n_heads, float scale, float drop_p, uint32_t drop_site,
                        const uint64_t* seed, void* stream);
 /* tile_first: int32 [n_seq + 2]; tile j = sequences tile_first[j]..tile_first[j+1]-1 (sum of their lengths
- * <= max_rows), tile_first[n_tiles] = n_seq, tile_first[n_seq + 1] = n_tiles */
+ * <= max_rows; greedy inside segments of 64 consecutive sequences), tile_first[n_tiles] = n_seq,
+ * tile_first[n_seq + 1] = n_tiles; scratch: int32 [ceil(n_seq / 64) * 64] */
 int dsvg_attention_tiles(const int32_t* seq_off, int64_t n_seq, int32_t max_rows, int32_t* tile_first,
-                         void* stream);
+                         int32_t* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Masks from the command tensor (deepsvg/model/utils.py:7-66).  commands: float32 [n_seq, S]

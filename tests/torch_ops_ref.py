@@ -208,6 +208,8 @@ def attention_tiles(seq_off, n_seq, max_rows=32):
     off = seq_off.tolist()
     first, start = [], None
     for i in range(n_seq):
+        if i % 64 == 0:                 # tiles never cross a segment of 64 sequences (device kernel: a wave per segment)
+            start = None
         if start is None or off[i + 1] - start > max_rows:
             first.append(i)
             start = off[i]
