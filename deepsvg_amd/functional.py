@@ -14,6 +14,8 @@ All arithmetic happens in the HIP kernels; `ops` may be monkey-patched by the CP
 plain-torch restatements in tests/torch_ops_ref.py to exercise this host logic without a GPU.
 """
 import math
+import contextlib
+
 import torch
 
 from . import ops
@@ -22,11 +24,31 @@ from . import ops
 class Runtime:
     """Per-forward execution context shared by the Functions."""
 
-    def __init__(self, dtype=torch.float32, seed=None, store=None, training=False):
+    def __init__(self, dtype=torch.float32, seed=None, store=None, training=False, side_stream=None):
         self.dtype = dtype
         self.seed = seed          # int64[1] device tensor holding the dropout seed of this step
         self.store = store        # ParamStore or None
         self.training = training
+        # optional second stream for the weight-gradient GEMMs (+ their split-K reductions): they are off the critical
+        # path of the backward pass, and a third of the step is launch-latency-bound small kernels they can overlap
+        # with.  Only a trainer that joins the stream before it touches the gradients may set it (TrainStep).
+        self.side_stream = side_stream
+        self._keep = []           # operands of side-stream work, kept alive until join()
+
+    def on_side(self, *operands):
+        """context manager: run the enclosed launches on the side stream, ordered after everything enqueued so far"""
+        side = self.side_stream
+        if side is None:
+            return contextlib.nullcontext()
+        side.wait_stream(torch.cuda.current_stream())
+        self._keep.extend(operands)
+        return torch.cuda.stream(side)
+
+    def join(self):
+        """make the current stream wait for the side stream; only then may the kept operands be released"""
+        if self.side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
+        self._keep.clear()
 
     def p(self, rate):
         """effective dropout probability"""
@@ -56,8 +78,9 @@ def _wgrad(rt, param, dy, x, *, a_drop_p=0.0, a_drop_site=0):
     out = rt.grad_out(param)
     n_out, k_in = param.shape
     T = dy.shape[0]
-    ops.gemm(dy, x, a_kc=False, b_kc=False, out=out.view(n_out, k_in), a_drop_p=a_drop_p, a_drop_site=a_drop_site,
-             seed=rt.seed, split_k=ops.split_k_for(n_out, k_in, T))
+    with rt.on_side(dy, x):
+        ops.gemm(dy, x, a_kc=False, b_kc=False, out=out.view(n_out, k_in), a_drop_p=a_drop_p, a_drop_site=a_drop_site,
+                 seed=rt.seed, split_k=ops.split_k_for(n_out, k_in, T))
     return out
 
 
@@ -69,11 +92,12 @@ def _wbgrad(rt, weight, bias, dy, x):
     split = ops.split_k_for(n_out, k_in, dy.shape[0])
     dw = rt.grad_out(weight)
     db = rt.grad_out(bias)
-    if split > 1:
-        ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in), split_k=split, rowsum=db)
-    else:
-        ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in))
-        ops.colsum(dy, out=db)
+    with rt.on_side(dy, x):
+        if split > 1:
+            ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in), split_k=split, rowsum=db)
+        else:
+            ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in))
+            ops.colsum(dy, out=db)
     return dw, db
 
 

@@ -336,12 +336,19 @@ class SVGTransformer(nn.Module):
         self.compact_head_backward = os.environ.get("DSVG_COMPACT_HEAD", "1") != "0"
         self.last_head_rows = None
         self._forced_plan = None
+        self._side_stream = None    # set by a trainer that calls join_side_stream() after backward (TrainStep)
+        self._rt = None
 
     # ---- runtime plumbing ------------------------------------------------------------------------
     def set_compute_dtype(self, dtype):
         assert dtype in (torch.float32, torch.bfloat16)
         self.compute_dtype = dtype
         return self
+
+    def join_side_stream(self):
+        """after backward: wait for the weight-gradient work on the side stream (no-op without one)"""
+        if self._rt is not None:
+            self._rt.join()
 
     @property
     def store(self):
@@ -358,7 +365,8 @@ class SVGTransformer(nn.Module):
         seed = self.seed_tensor(device) if training else None
         if training and self._own_seed:
             ops.advance_step_(None, seed)
-        return Fn.Runtime(self.compute_dtype, seed, self._store, training)
+        self._rt = Fn.Runtime(self.compute_dtype, seed, self._store, training, side_stream=self._side_stream)
+        return self._rt
 
     # ---- blocks ----------------------------------------------------------------------------------
     def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site, seq_off=None, live=None, tiles=None):

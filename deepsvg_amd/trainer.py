@@ -16,6 +16,8 @@ flat buffers, one process per GPU.
     rows / sequences are inert by construction - and one graph is captured per bucket pair on first use; the layout
     plan (a few tiny kernels + one host read) runs eagerly before each replay and is copied into the graph's buffers.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -42,6 +44,7 @@ class TrainStep:
         self._graphs = {}               # bucket key -> (graph, static inputs, static plan, static results)
         self._pool = None
         self.row_bucket, self.seq_bucket = 1024, 64
+        self.side_stream = os.environ.get("DSVG_SIDE_STREAM", "1") != "0"
         model._own_seed = False          # the trainer advances the dropout seed once per step
         if self.exact_global_mean:
             loss_fn.count_reducer = self._reduce_count
@@ -57,6 +60,8 @@ class TrainStep:
         self.step_count = torch.zeros(1, dtype=torch.int64, device=device)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=device)
         self.seed = model.seed_tensor(device)
+        if self.side_stream and device.type == "cuda":
+            model._side_stream = torch.cuda.Stream(device=device)
         self._ready = True
 
     def set_lr(self, lr):
@@ -77,6 +82,7 @@ class TrainStep:
         out = model(commands, args, commands, args, params={})
         ld = self.loss_fn(out, None, weights=self.weights)
         ld["loss"].backward()
+        model.join_side_stream()        # weight gradients are computed on a second stream (functional.Runtime)
         flat_g = model.store.grad_buffer(0)
         if self.world > 1:
             dist.all_reduce(flat_g, group=self.pg)
