@@ -44,7 +44,9 @@ class TrainStep:
         self._graphs = {}               # bucket key -> (graph, static inputs, static plan, static results)
         self._pool = None
         self.row_bucket, self.seq_bucket = 1024, 64
-        self.side_stream = os.environ.get("DSVG_SIDE_STREAM", "1") != "0"
+        # weight-gradient GEMMs on a second stream: measured 2-4 % SLOWER on one MI355X (event fork/join per GEMM costs
+        # more than the overlap with the small kernels of the group stages returns), so it is opt-in
+        self.side_stream = os.environ.get("DSVG_SIDE_STREAM", "0") != "0"
         model._own_seed = False          # the trainer advances the dropout seed once per step
         if self.exact_global_mean:
             loss_fn.count_reducer = self._reduce_count
