@@ -97,8 +97,29 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, in
     const DropCtx adc = drop_make(p.a_drop_p, p.seed, p.a_drop_site);
 
     float4 ra[4], rb[4];
+    // Fast staging path (uniform per launch): every 4-element piece is either entirely inside the matrix or entirely
+    // outside, so the 8 loads of a K step are issued unconditionally from clamped addresses and zeroed afterwards.
+    // (Loads under `if (inside)` are compiled as a branch + s_waitcnt vmcnt(0) each: 8 dependent round trips per step.)
+    const bool fast_a = !adc.on && !(p.K & 3) && !(k_chunk & 3) && (AKC || !(p.M & 3)) && p.M >= 4 && p.K >= 4;
+    const bool fast_b = !(p.K & 3) && !(k_chunk & 3) && (BKC || !(p.N & 3)) && p.N >= 4 && p.K >= 4;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto load_a = [&](int k0) {
+        if (fast_a) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (AKC) {
+                    const int gm = m0 + (tid >> 3) + 32 * j, gk = k0 + 4 * (tid & 7);
+                    const float4 v = *reinterpret_cast<const float4*>(A + (size_t)min(gm, p.M - 1) * p.lda + min(gk, p.K - 4));
+                    ra[j] = (gm < p.M && gk < k_end) ? v : zero4;
+                } else {
+                    const int gk = k0 + (tid >> 5) + 8 * j, gm = m0 + 4 * (tid & 31);
+                    const float4 v = *reinterpret_cast<const float4*>(A + (size_t)min(gk, p.K - 1) * p.lda + min(gm, p.M - 4));
+                    ra[j] = (gk < k_end && gm < p.M) ? v : zero4;
+                }
+            }
+            return;
+        }
         if (AKC) {
             const int c = tid & 7, r = tid >> 3;
 #pragma unroll
@@ -134,6 +155,21 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, in
         }
     };
     auto load_b = [&](int k0) {
+        if (fast_b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (BKC) {
+                    const int gn = n0 + (tid >> 3) + 32 * j, gk = k0 + 4 * (tid & 7);
+                    const float4 v = *reinterpret_cast<const float4*>(B + (size_t)min(gn, p.N - 1) * p.ldb + min(gk, p.K - 4));
+                    rb[j] = (gn < p.N && gk < k_end) ? v : zero4;
+                } else {
+                    const int gk = k0 + (tid >> 5) + 8 * j, gn = n0 + 4 * (tid & 31);
+                    const float4 v = *reinterpret_cast<const float4*>(B + (size_t)min(gk, p.K - 1) * p.ldb + min(gn, p.N - 4));
+                    rb[j] = (gk < k_end && gn < p.N) ? v : zero4;
+                }
+            }
+            return;
+        }
         if (BKC) {
             const int c = tid & 7, r = tid >> 3;
 #pragma unroll
