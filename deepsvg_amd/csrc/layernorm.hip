@@ -7,7 +7,7 @@
 #include "../../include/dsvg.h"
 
 constexpr int LN_MAXV_MAX = 4;        // 4 x (64 lanes x 4 elements) = 1024 features max; kernels are built for 1, 2, 4
-constexpr int LN_MAX_BLOCKS = 2048;   // backward: 8 resident workgroups per CU (32 waves), one partial row each
+constexpr int LN_MAX_BLOCKS = 1024;   // backward: one partial row of the parameter gradients per workgroup (512..4096 measured equal)
 
 template <typename T, int LN_MAXV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
@@ -169,8 +169,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* __res
 }
 
 static int ln_grid(long long rows) {
+    static const int cap = getenv("DSVG_LN_BLOCKS") ? atoi(getenv("DSVG_LN_BLOCKS")) : LN_MAX_BLOCKS;   // tuning knob
     long long nb = (rows + 3) / 4;
-    return (int)(nb < LN_MAX_BLOCKS ? nb : LN_MAX_BLOCKS);
+    return (int)(nb < cap ? nb : cap);
 }
 // forward: no per-block partials, so one wave per row with every row's load in flight at once (a wave that walks 30
 // rows one after the other is a chain of dependent ~2 us loads: measured 58 us for 134 MB of traffic)
