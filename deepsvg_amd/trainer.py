@@ -42,6 +42,8 @@ class TrainStep:
         self._lr_value = float(lr)
         self._ready = False
         self._graphs = {}               # bucket key -> (graph, static inputs, static plan, static results)
+        self._plan_stream = None
+        self.inputs_resident = False    # see step(): set by callers whose input tensors are complete well before step()
         self._pool = None
         self.row_bucket, self.seq_bucket = 1024, 64
         # weight-gradient GEMMs on a second stream: measured 2-4 % SLOWER on one MI355X (event fork/join per GEMM costs
@@ -101,7 +103,24 @@ class TrainStep:
         if not self.use_graph:
             return self._step_body(commands, args)
         model = self.model
-        plan = model.make_plan(commands, args, commands, True, args)
+        main = torch.cuda.current_stream()
+        # The layout plan (a few tiny kernels + ONE host read) runs on its own stream so that the host read does not
+        # wait for the previous step's graph: the GPU keeps executing step k while the host plans and enqueues k+1.
+        # Safe by default (the plan stream first waits for everything enqueued so far, i.e. for the inputs);
+        # `inputs_resident = True` (inputs were complete before the previous step was enqueued) skips that wait.
+        if self._plan_stream is None:
+            self._plan_stream = torch.cuda.Stream(device=commands.device)
+        ps = self._plan_stream
+        if not self.inputs_resident:
+            ps.wait_stream(main)
+        with torch.cuda.stream(ps):
+            plan = model.make_plan(commands, args, commands, True, args)
+        main.wait_stream(ps)
+        for part in ("enc", "dec", "loss"):        # allocated on the plan stream, read by launches on the main stream
+            for v in (plan[part] or {}).values():
+                for t in (v if isinstance(v, tuple) else (v,)):
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
         key, plan = self._bucketed(plan, commands)
         entry = self._graphs.get(key)
         if entry is None:
