@@ -100,12 +100,12 @@ class TrainStep:
     def step(self, commands, args):
         if not self._ready:
             self._setup(commands.device)
-        if not self.use_graph:
+        if not commands.is_cuda:                    # CPU emulation (tests): no streams
             return self._step_body(commands, args)
         model = self.model
         main = torch.cuda.current_stream()
         # The layout plan (a few tiny kernels + ONE host read) runs on its own stream so that the host read does not
-        # wait for the previous step's graph: the GPU keeps executing step k while the host plans and enqueues k+1.
+        # wait for the previous step's work: the GPU keeps executing step k while the host plans and enqueues k+1.
         # Safe by default (the plan stream first waits for everything enqueued so far, i.e. for the inputs);
         # `inputs_resident = True` (inputs were complete before the previous step was enqueued) skips that wait.
         if self._plan_stream is None:
@@ -121,6 +121,14 @@ class TrainStep:
                 for t in (v if isinstance(v, tuple) else (v,)):
                     if torch.is_tensor(t):
                         t.record_stream(main)
+        if not self.use_graph:
+            model._forced_plan = plan
+            try:
+                res = self._step_body(commands, args)
+            finally:
+                model._forced_plan = None
+            self._note_layout(plan, commands)
+            return res
         key, plan = self._bucketed(plan, commands)
         entry = self._graphs.get(key)
         if entry is None:
