@@ -40,9 +40,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="icons per GPU")
     ap.add_argument("--dtype", default=os.environ.get("DSVG_BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("DSVG_BENCH_GRAPH", "1")),
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("DSVG_BENCH_GRAPH", "-1")),
                     help="1: replay the step as a hipGraph (one graph per layout bucket, the layout plan runs eagerly "
-                         "before each replay; single-GPU default), 0: eager launches")
+                         "before each replay), 0: eager launches, -1 (default): time both during the warm-up and keep "
+                         "the faster (eager wins when the host dispatches ~650 launches faster than the GPU runs them)")
     ap.add_argument("--pack-encoder", type=int, default=int(os.environ.get("DSVG_PACK_ENCODER", "1")),
                     help="1: first encoder stage on the valid tokens only (exact, SURVEY.md 7.3-12); 0: padded layout")
     ap.add_argument("--dropout", type=float, default=0.1)
@@ -168,7 +169,8 @@ def main():
     log(f"model on {device}, dtype={a.dtype}, batch={a.batch}, world={world}")
     # hipGraph replay of the whole step is verified on one GPU; with RCCL collectives inside the captured region it
     # is opt-in (DSVG_BENCH_GRAPH_DDP=1) because it cannot be exercised on the single-GPU development boxes
-    use_graph = bool(a.graph) and (world == 1 or os.environ.get("DSVG_BENCH_GRAPH_DDP") == "1")
+    graph_ok = world == 1 or os.environ.get("DSVG_BENCH_GRAPH_DDP") == "1"
+    use_graph = a.graph != 0 and graph_ok
     ts = TrainStep(model, loss_fn, lr=1e-3 * world, grad_clip=1.0, use_graph=use_graph)
     ts.inputs_resident = True       # the synthetic batch sits in HBM before the timed region (bench contract)
     try:
@@ -189,6 +191,21 @@ def main():
 
     torch.cuda.synchronize()
     log(f"first step done (graph={use_graph}); warmup {a.warmup}")
+    if a.graph < 0 and use_graph:
+        # launch-mode calibration inside the (untimed) warm-up: same TrainStep, same state, both launch paths
+        t_mode = {}
+        for mode in (True, False):
+            ts.use_graph = mode
+            ts.step(commands, args)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(max(a.warmup, 3)):
+                ts.step(commands, args)
+            torch.cuda.synchronize()
+            t_mode[mode] = (time.perf_counter() - t1) / max(a.warmup, 3)
+        use_graph = t_mode[True] <= t_mode[False]
+        ts.use_graph = use_graph
+        log(f"calibration: graph {t_mode[True] * 1e3:.3f} ms/step, eager {t_mode[False] * 1e3:.3f} ms/step")
     for _ in range(a.warmup):
         ts.step(commands, args)
     if world > 1:
