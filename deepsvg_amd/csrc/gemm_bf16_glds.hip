@@ -46,8 +46,11 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
     return make_uint4(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]), f2bf_pk(v[4], v[5]), f2bf_pk(v[6], v[7]));
 }
 
-template <bool AKC, bool BKC, int EPI, int NST>
-__global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void gemm_bf16_glds_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
+// NST: LDS stages (1: 32 KiB, 2: 64 KiB); OCC: waves per SIMD the register allocation is held to (4 -> 128 VGPRs, no
+// spills; 5 -> 96 VGPRs, a few epilogue values spill, but all five 32-KiB workgroups a CU's LDS can hold are resident:
+// the packed / live-prefix GEMMs launch ~1.25 x 1024 workgroups, which then run as one wave of workgroups, not two)
+template <bool AKC, bool BKC, int EPI, int NST, int OCC>
+__global__ __launch_bounds__(256, NST == 1 ? OCC : 2) void gemm_bf16_glds_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
                                                                               int k_chunk, float* part, float* rs_part,
                                                                               int mode) {
     __shared__ __attribute__((aligned(1024))) bf16_t smem[NST * 2 * IMG];
@@ -341,11 +344,15 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : 2) void gemm_bf16_glds_kernel(d
 template <bool AKC, bool BKC, int EPI>
 void launch(const dsvg_gemm_desc& d, dim3 grid, int tiles_n, int nwg, int k_chunk, float* part, float* rs_part, int mode,
             int nst, hipStream_t st) {
+    static const int occ = getenv("DSVG_GEMM_OCC") ? atoi(getenv("DSVG_GEMM_OCC")) : 4;
     if (nst == 2)
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AKC, BKC, EPI, 2>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk,
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AKC, BKC, EPI, 2, 4>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk,
+                           part, rs_part, mode);
+    else if (occ == 5)
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AKC, BKC, EPI, 1, 5>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk,
                            part, rs_part, mode);
     else
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AKC, BKC, EPI, 1>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk,
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AKC, BKC, EPI, 1, 4>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk,
                            part, rs_part, mode);
 }
 
