@@ -336,6 +336,7 @@ class SVGTransformer(nn.Module):
         self.compact_head_backward = os.environ.get("DSVG_COMPACT_HEAD", "1") != "0"
         self.last_head_rows = None
         self._forced_plan = None
+        self._decoder_grads_ready = None    # callback of a data-parallel trainer (TrainStep), see forward()
         self._side_stream = None    # set by a trainer that calls join_side_stream() after backward (TrainStep)
         self._rt = None
 
@@ -344,6 +345,15 @@ class SVGTransformer(nn.Module):
         assert dtype in (torch.float32, torch.bfloat16)
         self.compute_dtype = dtype
         return self
+
+    def decoder_param_range(self):
+        """[lo, hi) of the decoder's parameters inside the flat parameter / gradient buffers (they come last)"""
+        st = self._store
+        dec = [st.index[id(p)] for p in self.decoder.parameters()]
+        lo = min(e[0] for e in dec)
+        assert all(st.index[id(p)][0] < lo for n, p in self.named_parameters() if not n.startswith("decoder.")), \
+            "decoder parameters are expected at the end of the flat buffer"
+        return lo, st.flat.numel()
 
     def join_side_stream(self):
         """after backward: wait for the weight-gradient work on the side stream (no-op without one)"""
@@ -572,6 +582,12 @@ class SVGTransformer(nn.Module):
         if z is None:
             zz = self._encode(rt, commands_enc, args_enc, plan)
             zz, mu, logsigma = self._bottleneck(rt, zz)
+            if self._decoder_grads_ready is not None and zz.requires_grad:
+                # data-parallel trainer: the gradient of the bottleneck output is final exactly when every decoder
+                # parameter gradient is (the decoder is the only consumer of zz) -> its bucket can be all-reduced
+                # while the encoder's backward still runs
+                cb = self._decoder_grads_ready
+                zz.register_hook(lambda g: (cb(), None)[1])
         else:
             # externally supplied z is batch-first (N, 1, 1, dim_z)  (model.py:369)
             zz = z.reshape(z.shape[0], -1).to(rt.dtype).contiguous()

@@ -44,6 +44,9 @@ class TrainStep:
         self._graphs = {}               # bucket key -> (graph, static inputs, static plan, static results)
         self._plan_stream = None
         self.inputs_resident = False    # see step(): set by callers whose input tensors are complete well before step()
+        # gradient all-reduce in two buckets, the decoder's overlapped with the encoder's backward (eager launches only)
+        self.overlap_allreduce = os.environ.get("DSVG_DDP_OVERLAP", "1") != "0" and not use_graph
+        self._pending = None
         self._pool = None
         self.row_bucket, self.seq_bucket = 1024, 64
         # weight-gradient GEMMs on a second stream: measured 2-4 % SLOWER on one MI355X (event fork/join per GEMM costs
@@ -73,6 +76,13 @@ class TrainStep:
         if self._ready:
             self.lr.fill_(self._lr_value)
 
+    def _launch_decoder_bucket(self):
+        """called from the backward pass when every decoder gradient is final (model.forward registers the hook)"""
+        lo, hi = self.model.decoder_param_range()
+        self.model.join_side_stream()       # (opt-in) weight-gradient stream: its decoder work must be complete too
+        flat_g = self.model.store.grad_buffer(0)
+        self._pending = (lo, dist.all_reduce(flat_g[lo:hi], group=self.pg, async_op=True))
+
     def _reduce_count(self, name, count):
         dist.all_reduce(count, group=self.pg)
         return count / self.world
@@ -85,11 +95,23 @@ class TrainStep:
             p.grad = None
         out = model(commands, args, commands, args, params={})
         ld = self.loss_fn(out, None, weights=self.weights)
-        ld["loss"].backward()
+        self._pending = None
+        if self.world > 1 and self.overlap_allreduce:
+            model._decoder_grads_ready = self._launch_decoder_bucket
+        try:
+            ld["loss"].backward()
+        finally:
+            model._decoder_grads_ready = None
         model.join_side_stream()        # weight gradients are computed on a second stream (functional.Runtime)
         flat_g = model.store.grad_buffer(0)
         if self.world > 1:
-            dist.all_reduce(flat_g, group=self.pg)
+            if self._pending is not None:
+                # two buckets: the decoder half went out while the encoder's backward was running
+                lo, work = self._pending
+                dist.all_reduce(flat_g[:lo], group=self.pg)
+                work.wait()
+            else:
+                dist.all_reduce(flat_g, group=self.pg)
         ops.sumsq(flat_g, out=self.gnorm_sq)
         ops.adamw_step_(model.store.flat, flat_g, self.m, self.v, self.lr, self.step_count,
                         beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay,

@@ -45,7 +45,10 @@ def _worker(rank, world, port, ret):
         per = commands.shape[0] // world
         c, a = commands[rank * per:(rank + 1) * per], args[rank * per:(rank + 1) * per]
         ts = TrainStep(model, loss_fn, lr=1e-2)
+        assert ts.overlap_allreduce
         ld = ts.step(c, a)
+        # the decoder bucket went out from inside the backward pass (hook on the bottleneck output's gradient)
+        assert ts._pending is not None and 0 < ts._pending[0] < model.store.flat.numel()
         ret[rank] = (model.store.flat.clone(), ts.grad_norm(), {k: v.item() for k, v in ld.items()},
                      model.store.grad_buffer(0).clone() / world)
     finally:
