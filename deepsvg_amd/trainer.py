@@ -93,12 +93,12 @@ class TrainStep:
         ops.advance_step_(self.step_count, self.seed)
         for p in model.store.params:
             p.grad = None
-        out = model(commands, args, commands, args, params={})
-        ld = self.loss_fn(out, None, weights=self.weights)
         self._pending = None
         if self.world > 1 and self.overlap_allreduce:
-            model._decoder_grads_ready = self._launch_decoder_bucket
+            model._decoder_grads_ready = self._launch_decoder_bucket    # hooked onto the bottleneck output in forward
         try:
+            out = model(commands, args, commands, args, params={})
+            ld = self.loss_fn(out, None, weights=self.weights)
             ld["loss"].backward()
         finally:
             model._decoder_grads_ready = None
