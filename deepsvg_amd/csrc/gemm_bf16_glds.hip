@@ -148,8 +148,9 @@ __global__ __launch_bounds__(256, NST == 1 ? OCC : 2) void gemm_bf16_glds_kernel
     for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
     // row sums of the token-side operand (bias gradient inside the weight-gradient GEMM): the lane's 8 k values of
     // token row (lane & 31) are summed with v_dot2c_f32_bf16 against packed ones - 2 VGPRs instead of the 32 an
-    // all-ones MFMA would need; only the waves with wn == 0 of the column-tile-0 workgroups do it
-    const bool do_rs = (EPI == EPI_PARTIAL) && rs_part != nullptr && tile_n == 0 && wn == 0;
+    // all-ones MFMA would need; only the column-tile-0 workgroups do it, and the two waves that hold the same token
+    // rows (wn = 0, 1) split the K step between them (the extra VALU work sits on those waves' critical path)
+    const bool do_rs = (EPI == EPI_PARTIAL) && rs_part != nullptr && tile_n == 0;
     float rs0 = 0.f, rs1 = 0.f;
     auto rowsum8 = [](const bf16x8& f, float s) -> float {
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256, NST == 1 ? OCC : 2) void gemm_bf16_glds_kernel
             acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc01, 0, 0, 0);
             acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc10, 0, 0, 0);
             acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc11, 0, 0, 0);
-            if (EPI == EPI_PARTIAL && do_rs) { rs0 = rowsum8(a0, rs0); rs1 = rowsum8(a1, rs1); }
+            if (EPI == EPI_PARTIAL && do_rs && (kk >> 1) == wn) { rs0 = rowsum8(a0, rs0); rs1 = rowsum8(a1, rs1); }
         }
     };
 
@@ -218,8 +219,18 @@ __global__ __launch_bounds__(256, NST == 1 ? OCC : 2) void gemm_bf16_glds_kernel
         if (do_rs) {                // lanes l and l+32 hold the two k halves of token row (lane & 31)
             rs0 += __shfl_xor(rs0, 32, 64);
             rs1 += __shfl_xor(rs1, 32, 64);
-            if (h == 0 && mrow < p.M) rs_part[(size_t)kz * slice + mrow] = rs0;
-            if (h == 0 && mrow + 32 < p.M) rs_part[(size_t)kz * slice + mrow + 32] = rs1;
+            // the wn = 1 wave hands its half of every K step over through LDS (the operand images are dead by now;
+            // do_rs is uniform over the workgroup, so the barrier is legal); fixed order: wn 0 + wn 1
+            float* rsx = reinterpret_cast<float*>(smem);
+            __syncthreads();        // every wave is done reading the operand images (2-stage loop has no trailing barrier)
+            if (wn == 1 && h == 0) { rsx[wm * 64 + (lane & 31)] = rs0; rsx[wm * 64 + 32 + (lane & 31)] = rs1; }
+            __syncthreads();
+            if (wn == 0 && h == 0) {
+                rs0 += rsx[wm * 64 + (lane & 31)];
+                rs1 += rsx[wm * 64 + 32 + (lane & 31)];
+                if (mrow < p.M) rs_part[(size_t)kz * slice + mrow] = rs0;
+                if (mrow + 32 < p.M) rs_part[(size_t)kz * slice + mrow + 32] = rs1;
+            }
         }
         return;
     }
