@@ -198,11 +198,21 @@ def test_full_size_properties_512_icons(gpu_device):
         ld["loss"].backward()
         torch.cuda.synchronize()
         g = model.store.grad_buffer(0).detach().clone()
+        run.named = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
         return float(ld["loss"]), g, out["command_logits"].detach().float()
 
     l1, g1, c1 = run(True, True)
+    n1 = run.named
     l2, g2, c2 = run(True, True)
-    assert l1 == l2 and torch.equal(g1, g2) and torch.equal(c1, c2), "train step is not bit-reproducible"
+    n2 = run.named
+    assert l1 == l2 and torch.equal(c1, c2), "train step is not bit-reproducible"
+    for n in n1:
+        if n.endswith("arg_embed.weight"):
+            # the one schedule-dependent sum of the path: LDS float atomics inside a workgroup of the argument-embedding
+            # scatter (DESIGN.md "Determinism"); everything else reduces in a fixed order
+            assert H.rel_l2(n1[n], n2[n]) < 1e-6, n
+        else:
+            assert torch.equal(n1[n], n2[n]), f"gradient of {n} is not bit-reproducible"
     le, ge, ce = run(False, True)
     lp, gp, cp = run(False, False)
     assert abs(le - lp) <= 2e-3 * abs(lp), (le, lp)
