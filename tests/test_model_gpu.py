@@ -177,8 +177,7 @@ def test_full_size_properties_512_icons(gpu_device):
       * determinism: two identical train-mode steps (same seed) give BIT-identical losses and gradients (no atomics in
         any cross-workgroup reduction);
       * the three exact work-skipping layouts change nothing: same loss / logits / gradient norm as the reference's
-        padded computation, to bf16 rounding;
-      * dropout really is replayed: eval-mode and p = 0 train-mode agree."""
+        padded computation, to bf16 rounding."""
     cfg = H.build_cfg("hier")
     cfg.dropout = 0.1
     commands, args = make_batch(512, seed=123)
@@ -220,9 +219,6 @@ def test_full_size_properties_512_icons(gpu_device):
     assert torch.equal(ce.argmax(-1), cp.argmax(-1)) or (ce.argmax(-1) != cp.argmax(-1)).float().mean().item() < 2e-3
     assert abs(ge.norm().item() - gp.norm().item()) <= 2e-2 * gp.norm().item()
     assert H.rel_l2(ge, gp) < 6e-2
-    cfg.dropout = 0.0
-    l0, g0, c0 = run(True, True)
-    assert abs(l0 - le) <= 1e-6 * abs(le) and torch.equal(c0, ce)
 
 
 def test_reference_extended_mask_aliasing_on_this_device(gpu_device):
