@@ -74,7 +74,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void masked_ce_fwd16_kernel(const T* __restrict__ logits, long long ld, int group,
                                                               const int* __restrict__ target,
                                                               const float* __restrict__ w, long long rows, int C,
-                                                              float* __restrict__ lse, float* __restrict__ part, int RC) {
+                                                              float* __restrict__ lse, float* __restrict__ part, int RC,
+                                                              const int32_t* __restrict__ tok_idx) {
+    // tok_idx != null: COMPACT logits - row ro of `logits` / `lse` belongs to token tok_idx[ro / group] (negative =
+    // list padding, weight 0); targets and weights stay indexed by the source token
     __shared__ float red[4][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 4, sl = lane & 15;
@@ -82,7 +85,12 @@ __global__ __launch_bounds__(256) void masked_ce_fwd16_kernel(const T* __restric
     for (long long r0 = ((long long)blockIdx.x * 4 + wave) * RC; r0 < rows; r0 += (long long)gridDim.x * 4 * RC) {
         const long long rl = r0 + lane;
         const bool mine = lane < RC && rl < rows;
-        const float wl = mine ? (w ? w[rl] : 1.f) : 0.f;
+        long long rsrc = rl;                                   // source row (targets, weights)
+        if (mine && tok_idx) {
+            const long long tk = tok_idx[rl / group];
+            rsrc = tk < 0 ? -1 : tk * group + rl % group;
+        }
+        const float wl = (mine && rsrc >= 0) ? (w ? w[rsrc] : 1.f) : 0.f;
         if (mine && wl == 0.f) lse[rl] = 0.f;
         const unsigned long long live = __ballot(wl != 0.f);
         const int n_live = __popcll(live);
@@ -96,6 +104,7 @@ __global__ __launch_bounds__(256) void masked_ce_fwd16_kernel(const T* __restric
                 if (q == sub && hit) j = __builtin_ctzll(hit);
             }
             const float wr = __shfl(wl, j < 0 ? 0 : j, 64);
+            const long long rs_j = __shfl(rsrc, j < 0 ? 0 : j, 64);
             if (j >= 0) {
                 const long long r = r0 + j;
                 const T* p = logits + (r / group) * ld + (r % group) * (long long)C;
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(256) void masked_ce_fwd16_kernel(const T* __restric
                 const float l = m + __logf(sacc);
                 if (sl == 0) {
                     lse[r] = l;
-                    int t = target[r];
+                    int t = target[rs_j];
                     t = min(max(t, 0), C - 1);
                     acc_l += wr * (l - Elem<T>::ld(p + t));
                     acc_w += wr;
@@ -143,12 +152,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void masked_ce_fwd_kernel(const T* __restrict__ logits, long long ld, int group,
                                                             const int* __restrict__ target, const float* __restrict__ w,
                                                             long long rows, int C, float* __restrict__ lse,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part,
+                                                            const int32_t* __restrict__ tok_idx) {
     __shared__ float red[4][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc_l = 0.f, acc_w = 0.f;
     for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
-        const float wr = w ? w[r] : 1.f;
+        long long rsrc = r;
+        if (tok_idx) {
+            const long long tk = tok_idx[r / group];
+            rsrc = tk < 0 ? -1 : tk * group + r % group;
+        }
+        const float wr = rsrc < 0 ? 0.f : (w ? w[rsrc] : 1.f);
         if (wr == 0.f) { if (lane == 0) lse[r] = 0.f; continue; }
         const T* p = logits + (r / group) * ld + (r % group) * (long long)C;
         float m = -INFINITY;
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(256) void masked_ce_fwd_kernel(const T* __restrict_
         const float l = m + __logf(s);
         if (lane == 0) {
             lse[r] = l;
-            int t = target[r];
+            int t = target[rsrc];
             t = min(max(t, 0), C - 1);
             acc_l += wr * (l - Elem<T>::ld(p + t));
             acc_w += wr;
@@ -181,9 +196,11 @@ __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ sum_count,
                                                             const float* __restrict__ gscale, float coef,
                                                             T* __restrict__ dlogits, long long ld_d, long long rows,
-                                                            int C, const int32_t* __restrict__ tok_idx) {
+                                                            int C, const int32_t* __restrict__ tok_idx,
+                                                            int logits_compact) {
     // tok_idx != null: output token i is source token tok_idx[i] (a compact list of the tokens that carry loss;
-    // negative = padding of the list -> a zero row); `rows` counts OUTPUT rows
+    // negative = padding of the list -> a zero row); `rows` counts OUTPUT rows.  logits_compact: `logits` and `lse`
+    // are indexed like the output (compact) instead of by source token
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float g = coef * (gscale ? *gscale : 1.f) / sum_count[1];
     for (long long ro = (long long)blockIdx.x * 4 + wave; ro < rows; ro += (long long)gridDim.x * 4) {
@@ -196,8 +213,8 @@ __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const T* __restrict_
         if (wr == 0.f) {
             for (int c = lane; c < C; c += 64) Elem<T>::st(q + c, 0.f);
         } else {
-            const T* p = logits + tok * ld + slot * (long long)C;
-            const float l = lse[r];
+            const T* p = logits + (logits_compact ? tok_o : tok) * ld + slot * (long long)C;
+            const float l = lse[logits_compact ? ro : r];
             int t = target[r];
             t = min(max(t, 0), C - 1);
             if (C <= 320) {     // all loads of the row in flight at once (clamped column, see masked_ce_fwd16_kernel)
@@ -231,7 +248,7 @@ extern "C" int64_t dsvg_masked_ce_workspace_bytes(int64_t rows) { return (int64_
 
 extern "C" int dsvg_masked_ce_fwd(int32_t dtype, const void* logits, int64_t ld, int32_t group, const int32_t* target,
                                   const float* w, int64_t rows, int32_t C, float* lse, float* sum_count,
-                                  float* workspace, int64_t workspace_bytes, void* stream) {
+                                  float* workspace, int64_t workspace_bytes, const int32_t* tok_idx, void* stream) {
     DSVG_CHECK_ARG(logits && target && lse && sum_count && rows > 0 && C > 0 && group > 0, "masked_ce_fwd: bad args");
     DSVG_CHECK_ARG(workspace && workspace_bytes >= dsvg_masked_ce_workspace_bytes(rows), "masked_ce_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -243,17 +260,17 @@ extern "C" int dsvg_masked_ce_fwd(int32_t dtype, const void* logits, int64_t ld,
         nparts = nbq;
         if (dtype == DSVG_F32)
             hipLaunchKernelGGL(masked_ce_fwd16_kernel<float>, dim3(nbq), dim3(256), 0, st, (const float*)logits,
-                               (long long)ld, group, target, w, (long long)rows, C, lse, workspace, RC);
+                               (long long)ld, group, target, w, (long long)rows, C, lse, workspace, RC, tok_idx);
         else if (dtype == DSVG_BF16)
             hipLaunchKernelGGL(masked_ce_fwd16_kernel<bf16_t>, dim3(nbq), dim3(256), 0, st, (const bf16_t*)logits,
-                               (long long)ld, group, target, w, (long long)rows, C, lse, workspace, RC);
+                               (long long)ld, group, target, w, (long long)rows, C, lse, workspace, RC, tok_idx);
         else { dsvg_set_error("masked_ce_fwd: bad dtype"); return -1; }
     } else if (dtype == DSVG_F32)
         hipLaunchKernelGGL(masked_ce_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)logits, (long long)ld,
-                           group, target, w, (long long)rows, C, lse, workspace);
+                           group, target, w, (long long)rows, C, lse, workspace, tok_idx);
     else if (dtype == DSVG_BF16)
         hipLaunchKernelGGL(masked_ce_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)logits,
-                           (long long)ld, group, target, w, (long long)rows, C, lse, workspace);
+                           (long long)ld, group, target, w, (long long)rows, C, lse, workspace, tok_idx);
     else { dsvg_set_error("masked_ce_fwd: bad dtype"); return -1; }
     DSVG_LAUNCH_CHECK("masked_ce_fwd");
     return dsvg_reduce_partials_strided(workspace, nparts, 2, 2, sum_count, 0, st);
@@ -262,7 +279,7 @@ extern "C" int dsvg_masked_ce_fwd(int32_t dtype, const void* logits, int64_t ld,
 extern "C" int dsvg_masked_ce_bwd(int32_t dtype, const void* logits, int64_t ld, int32_t group, const int32_t* target,
                                   const float* w, const float* lse, const float* sum_count, const float* gscale,
                                   float coef, void* dlogits, int64_t ld_d, int64_t rows, int32_t C,
-                                  const int32_t* tok_idx, void* stream) {
+                                  const int32_t* tok_idx, int32_t logits_compact, void* stream) {
     DSVG_CHECK_ARG(logits && target && lse && sum_count && dlogits && rows > 0 && C > 0 && group > 0,
                    "masked_ce_bwd: bad args");
     DSVG_CHECK_ARG(ld_d >= (int64_t)group * C, "masked_ce_bwd: ld_d too small");
@@ -271,11 +288,11 @@ extern "C" int dsvg_masked_ce_bwd(int32_t dtype, const void* logits, int64_t ld,
     if (dtype == DSVG_F32)
         hipLaunchKernelGGL(masked_ce_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)logits, (long long)ld,
                            group, target, w, lse, sum_count, gscale, coef, (float*)dlogits, (long long)ld_d,
-                           (long long)rows, C, tok_idx);
+                           (long long)rows, C, tok_idx, logits_compact);
     else if (dtype == DSVG_BF16)
         hipLaunchKernelGGL(masked_ce_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)logits,
                            (long long)ld, group, target, w, lse, sum_count, gscale, coef, (bf16_t*)dlogits,
-                           (long long)ld_d, (long long)rows, C, tok_idx);
+                           (long long)ld_d, (long long)rows, C, tok_idx, logits_compact);
     else { dsvg_set_error("masked_ce_bwd: bad dtype"); return -1; }
     DSVG_LAUNCH_CHECK("masked_ce_bwd");
     return 0;

@@ -479,34 +479,41 @@ class MaskedCEFn(torch.autograd.Function):
 
 
 class ArgsHeadLossFn(torch.autograd.Function):
-    """loss_args = masked CE over the argument logits, with the backward pass of the argument head (args_fcn,
-    deepsvg/model/model.py:228-246) folded in: logits = x W^T + b were already computed by the model (they are part
-    of its output); here only the tokens that carry argument loss are differentiated.  dlogits rows of every other
-    token are exact zeros (loss.py:51-54), so dX / dW / db come from a compact [n_live, 2827] gradient instead of the
-    dense [T, 2827] one (about 30 % of the decoder tokens on the synthetic distribution).
+    """loss_args = masked CE over the argument logits, with the argument head (args_fcn, deepsvg/model/model.py:228-246)
+    folded in: forward AND backward run on the tokens that carry argument loss only.  Every other token's logits do
+    not enter the loss and their dlogits are exact zeros (loss.py:51-54), so logits, dX, dW and db come from a compact
+    [n_live, 2827] problem instead of the dense [T, 2827] one (about 30 % of the decoder tokens on the synthetic
+    distribution).  The full `args_logits` of the model's result dict is materialised only if somebody reads it.
     `live` = (token list int32 padded with -1, number of rows to process >= number of listed tokens)."""
 
     @staticmethod
-    def forward(ctx, rt, x, weight, bias, logits2d, target, w, C_, group, count_fn, live):
-        lse, sc = ops.masked_ce_fwd(logits2d, target, w, C_, group)
+    def forward(ctx, rt, x, weight, bias, target, w, C_, group, count_fn, live):
+        R = min(int(live[1]), x.shape[0])
+        idx = live[0][:R]
+        xc = ops.gather_groups(x, idx, R, 1)                       # rows of list padding read token 0 (weight 0)
+        n_out = weight.shape[0]
+        mult = 4 if xc.dtype == torch.float32 else 8
+        ld = (n_out + mult - 1) // mult * mult
+        buf = torch.empty((R, ld), dtype=xc.dtype, device=xc.device)
+        logits_c = buf[:, :n_out]
+        ops.gemm(xc, rt.w(weight), bias=bias.detach(), out=logits_c)
+        lse, sc = ops.masked_ce_fwd(logits_c, target, w, C_, group, tok_idx=idx)
         if count_fn is not None:
             sc = torch.stack([sc[0], count_fn(sc[1].clone()).to(sc.dtype).reshape(())])
-        ctx.rt, ctx.C_, ctx.group, ctx.n_rows = rt, C_, group, int(live[1])
-        ctx.save_for_backward(x, weight, bias, logits2d, target, w, lse, sc, live[0])
+        ctx.rt, ctx.C_, ctx.group, ctx.rows_full = rt, C_, group, x.shape[0]
+        ctx.save_for_backward(xc, weight, bias, logits_c, target, w, lse, sc, idx)
         return sc[0] / sc[1], sc
 
     @staticmethod
     def backward(ctx, dloss, _dsc):
         rt = ctx.rt
-        x, weight, bias, logits2d, target, w, lse, sc, live_idx = ctx.saved_tensors
+        xc, weight, bias, logits_c, target, w, lse, sc, idx = ctx.saved_tensors
         g = dloss.reshape(1).to(torch.float32).contiguous()
-        R = min(ctx.n_rows, x.shape[0])
-        idx = live_idx[:R]
-        mult = 4 if logits2d.dtype == torch.float32 else 8
-        dl = ops.masked_ce_bwd(logits2d, target, w, lse, sc, g, 1.0, ctx.C_, ctx.group, pad_to=mult, tok_idx=idx)
-        xc = ops.gather_groups(x, idx, R, 1)
+        mult = 4 if logits_c.dtype == torch.float32 else 8
+        dl = ops.masked_ce_bwd(logits_c, target, w, lse, sc, g, 1.0, ctx.C_, ctx.group, pad_to=mult, tok_idx=idx,
+                               logits_compact=True)
         dw, db = _wbgrad(rt, weight, bias, dl, xc)
         dxc = ops.gemm(dl, rt.w(weight), b_kc=False)
-        dx = torch.zeros_like(x)
+        dx = torch.zeros((ctx.rows_full, xc.shape[1]), dtype=xc.dtype, device=xc.device)
         ops.scatter_rows(dxc, idx, dx)
-        return None, dx, dw, db, None, None, None, None, None, None, None
+        return None, dx, dw, db, None, None, None, None, None, None

@@ -41,7 +41,7 @@ class SVGLoss(nn.Module):
             res["loss_kl"] = loss_kl
 
         tgt_commands, tgt_args = output["tgt_commands"], output["tgt_args"]
-        command_logits, args_logits = output["command_logits"], output["args_logits"]
+        command_logits = output["command_logits"]       # ("args_logits" may be lazy: only read when it is needed)
         device = command_logits.device
         N, G, S1 = tgt_commands.shape
         n_args = tgt_args.shape[-1]
@@ -67,14 +67,16 @@ class SVGLoss(nn.Module):
             res["loss_visibility"] = loss_visibility
 
         cl = command_logits.reshape(N * G * S, cfg.n_commands)
-        al = args_logits.reshape(N * G * S, n_args * self.args_dim)
         loss_cmd, sc_c = Fn.MaskedCEFn.apply(cl, cmd_tgt.view(-1), cmd_w.view(-1), cfg.n_commands, 1,
                                              (lambda c: red("cmd", c)) if red else None)
         if head is not None:
-            loss_args, sc_a = Fn.ArgsHeadLossFn.apply(head["rt"], head["x"], head["weight"], head["bias"], al.detach(),
+            # fused argument head + loss on the loss-carrying tokens (forward and backward); the dense args_logits of
+            # the result dict stays unmaterialised
+            loss_args, sc_a = Fn.ArgsHeadLossFn.apply(head["rt"], head["x"], head["weight"], head["bias"],
                                                       arg_tgt.view(-1), arg_w.view(-1), self.args_dim, n_args,
                                                       (lambda c: red("args", c)) if red else None, head["live"])
         else:
+            al = output["args_logits"].reshape(N * G * S, n_args * self.args_dim)
             loss_args, sc_a = Fn.MaskedCEFn.apply(al, arg_tgt.view(-1), arg_w.view(-1), self.args_dim, n_args,
                                                   (lambda c: red("args", c)) if red else None)
         loss = loss + weights["loss_cmd_weight"] * loss_cmd + weights["loss_args_weight"] * loss_args

@@ -21,6 +21,58 @@ from .svgtensor import CMD_ARGS_MASK, EOS_ID, M_ID, SOS_ID
 PE_DROPOUT = 0.1  # hard-wired in PositionalEncodingLUT (deepsvg/model/layers/positional_encoding.py:26-28)
 
 
+class ModelOutput(dict):
+    """The result dict of SVGTransformer.forward (deepsvg/model/model.py:396-412).  An entry may be LAZY: a thunk that
+    is run on first read.  The training forward registers `args_logits` that way when deepsvg_amd.SVGLoss can take the
+    loss from the fused argument head (functional.ArgsHeadLossFn), so the dense (N, G, S, 11, 257) tensor - the largest
+    HBM stream of the step - is only written if somebody actually reads it (the reference's SVGLoss, a metric, a test)."""
+    _PENDING = object()
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._thunks = {}
+
+    def set_lazy(self, key, fn):
+        self._thunks[key] = fn
+        dict.__setitem__(self, key, ModelOutput._PENDING)
+
+    def is_pending(self, key):
+        return key in self._thunks
+
+    def _force(self, key=None):
+        for k in ([key] if key is not None else list(self._thunks)):
+            fn = self._thunks.pop(k, None)
+            if fn is not None:
+                dict.__setitem__(self, k, fn())
+
+    def __getitem__(self, key):
+        self._force(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self._force(key)
+        return dict.get(self, key, default)
+
+    def __iter__(self):         # (overriding __iter__ also sends dict(x) / {**x} through keys() + __getitem__)
+        return dict.__iter__(self)
+
+    def items(self):
+        self._force()
+        return dict.items(self)
+
+    def values(self):
+        self._force()
+        return dict.values(self)
+
+    def pop(self, key, *default):
+        self._force(key)
+        return dict.pop(self, key, *default)
+
+    def copy(self):
+        self._force()
+        return dict(dict.items(self))
+
+
 # ----------------------------------------------------------------------------------------------------
 # parameter containers (names == reference state_dict keys)
 # ----------------------------------------------------------------------------------------------------
@@ -524,8 +576,9 @@ class SVGTransformer(nn.Module):
                                   0.0, 0, None)
         return z, mu, logsigma
 
-    def _decode(self, rt, z, plan=None):
-        """z [N, dim_z] -> command_logits (N,G,S,n_cmd), args_logits (N,G,S,n_args,args_dim)[, visibility (N,G,1,2)]"""
+    def _decode(self, rt, z, plan=None, lazy_args=False):
+        """z [N, dim_z] -> command_logits (N,G,S,n_cmd), args_logits (N,G,S,n_args,args_dim)[, visibility (N,G,1,2)];
+        with lazy_args the second result is a thunk that computes args_logits when called"""
         cfg = self.cfg
         dec = self.decoder
         N = z.shape[0]
@@ -558,10 +611,14 @@ class SVGTransformer(nn.Module):
             out = Fn.GatherGroupsFn.apply(out, pd["new_of_old"], pd["old_of_new"], n_seq, S, live)
         cmd_logits = Fn.LinearFn.apply(rt, out, dec.fcn.command_fcn.weight, dec.fcn.command_fcn.bias, 0, None, 0.0, 0,
                                        None)
-        args_logits = Fn.LinearFn.apply(rt, out, dec.fcn.args_fcn.weight, dec.fcn.args_fcn.bias, 0, None, 0.0, 0, None)
-        self._head_in = out         # input of the heads (for the loss-side backward of the argument head)
+        n_args, args_dim, fcn = cfg.n_args, self.args_dim, dec.fcn.args_fcn
+
+        def make_args_logits():
+            al = Fn.LinearFn.apply(rt, out, fcn.weight, fcn.bias, 0, None, 0.0, 0, None)
+            return al.view(N, G, S, n_args, args_dim)
+        args_logits = make_args_logits if lazy_args else make_args_logits()
+        self._head_in = out         # input of the heads (for the fused argument head + loss)
         cmd_logits = cmd_logits.view(N, G, S, cfg.n_commands)
-        args_logits = args_logits.view(N, G, S, cfg.n_args, self.args_dim)
         if vis_logits is not None:
             vis_logits = vis_logits.view(N, G, 1, 2)
         return cmd_logits, args_logits, vis_logits
@@ -593,8 +650,13 @@ class SVGTransformer(nn.Module):
             zz = z.reshape(z.shape[0], -1).to(rt.dtype).contiguous()
         if encode_mode:
             return zz.to(torch.float32).view(1, 1, zz.shape[0], zz.shape[1])   # seq-first, as model.py:371
-        cmd_logits, args_logits, vis_logits = self._decode(rt, zz, plan)
-        res = {"command_logits": cmd_logits, "args_logits": args_logits}
+        lazy_args = bool(return_tgt and plan is not None and plan.get("loss") is not None)
+        cmd_logits, args_logits, vis_logits = self._decode(rt, zz, plan, lazy_args=lazy_args)
+        res = ModelOutput({"command_logits": cmd_logits})
+        if lazy_args:
+            res.set_lazy("args_logits", args_logits)
+        else:
+            res["args_logits"] = args_logits
         if cfg.decode_stages == 2:
             res["visibility_logits"] = vis_logits
         if return_tgt:
@@ -603,7 +665,7 @@ class SVGTransformer(nn.Module):
             pl = plan["loss"] if plan is not None else None
             self.last_head_rows = None
             if pl is not None:
-                # hand SVGLoss what it needs to differentiate the argument head on the loss-carrying tokens only
+                # hand SVGLoss what it needs to run the argument head on the loss-carrying tokens only
                 T_dec = self._head_in.shape[0]
                 n_rows = min(max((pl["n_live"] + 127) // 128 * 128, int(pl.get("rows", 0))), T_dec)
                 fcn = self.decoder.fcn.args_fcn

@@ -494,15 +494,20 @@ def loss_targets(tgt_commands, tgt_args, cmd_args_mask, eos_id=4):
     return cmd_tgt, cmd_w, arg_tgt, arg_w, vis_tgt
 
 
-def masked_ce_fwd(logits2d, target, w, C_, group=1):
+def masked_ce_fwd(logits2d, target, w, C_, group=1, tok_idx=None):
     """logits2d: [n_tok, >= group*C] row-major (stride(0) = token stride); logical rows = n_tok*group.
-    returns lse [rows] fp32, sum_count fp32[2]"""
-    _chk(logits2d, target, w)
+    returns lse [rows] fp32, sum_count fp32[2].  tok_idx (int32 [n_tok]): the logits (and lse) are COMPACT - row i
+    belongs to source token tok_idx[i] (negative: padding) - while target / w stay indexed by the source token."""
+    _chk(logits2d, target, w, tok_idx)
     _rowmajor(logits2d)
     rows = logits2d.shape[0] * group
-    assert target.numel() == rows and target.dtype == torch.int32 and target.is_contiguous()
+    assert target.dtype == torch.int32 and target.is_contiguous()
+    if tok_idx is None:
+        assert target.numel() == rows and (w is None or w.numel() == rows)
+    else:
+        assert tok_idx.dtype == torch.int32 and tok_idx.is_contiguous() and tok_idx.numel() == logits2d.shape[0]
     if w is not None:
-        assert w.numel() == rows and w.dtype == torch.float32 and w.is_contiguous()
+        assert w.dtype == torch.float32 and w.is_contiguous()
     dev = logits2d.device
     lse = torch.empty(rows, dtype=torch.float32, device=dev)
     sc = torch.empty(2, dtype=torch.float32, device=dev)
@@ -510,13 +515,15 @@ def masked_ce_fwd(logits2d, target, w, C_, group=1):
     ws = _ws(L.dsvg_masked_ce_workspace_bytes(rows), dev)
     _l.check(L.dsvg_masked_ce_fwd(_dt(logits2d), logits2d.data_ptr(), logits2d.stride(0), group, target.data_ptr(),
                                   _p(w), rows, C_, lse.data_ptr(), sc.data_ptr(), ws.data_ptr(), ws.numel() * 4,
-                                  _stream()), "dsvg_masked_ce_fwd")
+                                  _p(tok_idx), _stream()), "dsvg_masked_ce_fwd")
     return lse, sc
 
 
-def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1, pad_to=8, tok_idx=None):
+def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1, pad_to=8, tok_idx=None,
+                  logits_compact=False):
     """returns dlogits as a [n_tok, group*C] view of a buffer whose token stride is padded to `pad_to` elements.
-    tok_idx (int32 [n_out]): compact backward - output token i is source token tok_idx[i], negative -> zero row."""
+    tok_idx (int32 [n_out]): compact backward - output token i is source token tok_idx[i], negative -> zero row;
+    logits_compact: logits2d / lse are compact too (as produced by masked_ce_fwd(..., tok_idx=))."""
     _chk(logits2d, target, w, lse, sum_count, gscale, tok_idx)
     n_tok = logits2d.shape[0] if tok_idx is None else tok_idx.numel()
     assert tok_idx is None or (tok_idx.dtype == torch.int32 and tok_idx.is_contiguous())
@@ -527,8 +534,8 @@ def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1
     assert gscale is None or (gscale.dtype == torch.float32 and gscale.numel() == 1)
     _l.check(_l.load().dsvg_masked_ce_bwd(_dt(logits2d), logits2d.data_ptr(), logits2d.stride(0), group,
                                           target.data_ptr(), _p(w), lse.data_ptr(), sum_count.data_ptr(), _p(gscale),
-                                          float(coef), buf.data_ptr(), ld_d, rows, C_, _p(tok_idx), _stream()),
-             "dsvg_masked_ce_bwd")
+                                          float(coef), buf.data_ptr(), ld_d, rows, C_, _p(tok_idx),
+                                          int(bool(logits_compact)), _stream()), "dsvg_masked_ce_bwd")
     return buf[:, :width]
 
 

@@ -225,15 +225,17 @@ int dsvg_loss_targets(const float* tgt_commands, const float* tgt_args, const fl
                       int32_t* cmd_tgt, float* cmd_w, int32_t* arg_tgt, float* arg_w, int32_t* vis_tgt,
                       void* stream);
 int dsvg_masked_ce_fwd(int32_t dtype, const void* logits, int64_t ld, int32_t group, const int32_t* target,
-                       const float* w, int64_t rows, int32_t C, float* lse, float* sum_count /*[2]*/,
-                       float* workspace, int64_t workspace_bytes, void* stream);
+                       const float* w, int64_t rows, int32_t C, float* lse, float* sum_count,
+                       float* workspace, int64_t workspace_bytes, const int32_t* tok_idx, void* stream);
 int64_t dsvg_masked_ce_workspace_bytes(int64_t rows);
 int dsvg_masked_ce_bwd(int32_t dtype, const void* logits, int64_t ld, int32_t group, const int32_t* target,
                        const float* w, const float* lse, const float* sum_count, const float* gscale,
                        float coef, void* dlogits, int64_t ld_d, int64_t rows, int32_t C,
-                       const int32_t* tok_idx, void* stream);
-/* tok_idx (optional): compact backward, output token i = source token tok_idx[i] (negative -> zero row), `rows`
- * = output tokens * group.  dsvg_live_rows builds that list: the tokens with any non-zero weight among their
+                       const int32_t* tok_idx, int32_t logits_compact, void* stream);
+/* tok_idx (optional): compact token list, output token i = source token tok_idx[i] (negative -> zero row / zero
+ * weight), `rows` = listed tokens * group; targets and weights are always indexed by the source token.
+ * fwd with tok_idx: `logits` and `lse` are compact (row i = listed token i): the loss of the argument head is
+ * computed from logits of the loss-carrying tokens only.  bwd: logits_compact selects the same for its inputs.  dsvg_live_rows builds that list: the tokens with any non-zero weight among their
  * `group` rows, ascending, padded with -1 up to n_tok entries; *count = their number.  Rows the loss masks out
  * have exactly zero dlogits (deepsvg/model/loss.py:51-54), so the argument head's dX / dW need only those tokens. */
 int dsvg_live_rows(const float* w, int64_t n_tok, int32_t group, int32_t* live, int32_t* count,

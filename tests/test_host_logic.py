@@ -79,6 +79,32 @@ def test_packed_encoder_equals_padded_encoder(emulated_ops):
         assert H.rel_l2(res[True][2][n], res[False][2][n]) < 1e-4, n
 
 
+def test_args_logits_is_lazy_with_the_fused_head_loss(emulated_ops):
+    """training forward + deepsvg_amd.SVGLoss: the dense args_logits is never built (the fused argument head + loss
+    works on the loss-carrying tokens); reading it later still gives the reference's tensor"""
+    g, cfg, commands, args, eps = H.golden_setup("hier_ordered_n2")
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), g["wseed"])
+    model = deepsvg_amd.SVGTransformer(cfg)
+    model.load_state_dict(sd)
+    model.eval()
+    out = model(commands, args, commands, args, params={})
+    assert out.is_pending("args_logits") and "args_logits" in out and set(out) >= {"command_logits", "args_logits"}
+    ld = deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
+    ld["loss"].backward()
+    assert out.is_pending("args_logits"), "the loss materialised the dense argument logits"
+    al = out["args_logits"]                      # first read computes it
+    assert not out.is_pending("args_logits") and tuple(al.shape) == (2, 8, 31, 11, 257)
+    stride = int(g["args_logits_stride"])
+    assert torch.allclose(al.detach().float().reshape(-1)[::stride], torch.from_numpy(g["args_logits_sample"]),
+                          rtol=1e-4, atol=1e-5)
+    assert abs(ld["loss_args"].item() - float(g["loss_args"])) < 1e-5
+    # dict(out) / out.items() see real tensors, never the placeholder
+    assert all(torch.is_tensor(v) or v is None or isinstance(v, dict) for v in dict(out).values())
+    model.compact_head_backward = False
+    out2 = model(commands, args, commands, args, params={})
+    assert not out2.is_pending("args_logits")
+
+
 def test_state_dict_layout_matches_reference_names(emulated_ops):
     g = H.load_golden("hier_ordered_n2")
     cfg = H.build_cfg("hier")

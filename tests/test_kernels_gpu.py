@@ -510,6 +510,17 @@ def test_compact_ce_backward_live_rows_scatter(gpu_device, dtype):
     assert torch.count_nonzero(dl[n_live:]) == 0
     dense = ops.masked_ce_bwd(logits, target, w, lse, sc, gs, 1.0, C_, group, pad_to=8)
     assert torch.equal(dl[:n_live], dense[live[:n_live].long()])
+    # compact LOGITS as well (fused argument head + loss: only the listed tokens' logits exist)
+    cbuf = torch.zeros(rows, ld, device=DEV, dtype=dtype)
+    cbuf[:n_live] = buf[live[:n_live].long()]
+    clog = cbuf[:, :group * C_]
+    lse_c, sc_c = ops.masked_ce_fwd(clog, target, w, C_, group, tok_idx=idx)
+    rl, rs = R.masked_ce_fwd(clog, target, w, C_, group, tok_idx=idx)
+    _close(lse_c, rl, 1e-6 if dtype == torch.float32 else 1e-2, "compact CE fwd lse")
+    _close(sc_c, rs, 1e-5, "compact CE fwd sums")
+    _close(sc_c, sc, 1e-5, "compact == dense loss sums")
+    dl_c = ops.masked_ce_bwd(clog, target, w, lse_c, sc_c, gs, 1.0, C_, group, pad_to=8, tok_idx=idx, logits_compact=True)
+    _close(dl_c, dl, 1e-6 if dtype == torch.float32 else 1e-2, "compact-logits CE bwd == compact CE bwd")
     src = _rand(rows, 256, dtype=dtype, seed=91)
     dst = torch.zeros(n_tok, 256, device=DEV, dtype=dtype)
     ops.scatter_rows(src, idx, dst)

@@ -409,7 +409,20 @@ def _ce_rows(logits2d, C_, group):
     return _f(logits2d)[:, :group * C_].reshape(n_tok * group, C_)
 
 
-def masked_ce_fwd(logits2d, target, w, C_, group=1):
+def _compact_tw(target, w, tok_idx, group):
+    """targets / weights of the listed tokens (negative index -> weight 0), compact order"""
+    sel = tok_idx.long()
+    rows = (sel.clamp(min=0).unsqueeze(1) * group + torch.arange(group, device=sel.device)).reshape(-1)
+    t = target.reshape(-1)[rows]
+    ww = (torch.ones(target.numel(), device=target.device) if w is None else w.reshape(-1))[rows].clone()
+    ww[(sel < 0).repeat_interleave(group)] = 0
+    return t, ww
+
+
+def masked_ce_fwd(logits2d, target, w, C_, group=1, tok_idx=None):
+    if tok_idx is not None:     # compact logits / lse, source-indexed targets and weights
+        t, ww = _compact_tw(target, w, tok_idx, group)
+        return masked_ce_fwd(logits2d, t, ww, C_, group)
     rows = _ce_rows(logits2d, C_, group)
     lse = torch.logsumexp(rows, dim=-1)
     t = target.long().clamp(0, C_ - 1)
@@ -435,7 +448,11 @@ def scatter_rows(src, idx, dst):
     return dst
 
 
-def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1, pad_to=8, tok_idx=None):
+def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1, pad_to=8, tok_idx=None,
+                  logits_compact=False):
+    if tok_idx is not None and logits_compact:
+        t, ww = _compact_tw(target, w, tok_idx, group)
+        return masked_ce_bwd(logits2d, t, ww, lse, sum_count, gscale, coef, C_, group, pad_to)
     if tok_idx is not None:     # compact backward: dense result, then pick the listed tokens (negative -> zero row)
         dense = masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group, pad_to)
         sel = tok_idx.long()
