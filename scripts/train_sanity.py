@@ -21,11 +21,13 @@ for dtype, graph in ((torch.bfloat16, True), (torch.bfloat16, False), (torch.flo
     model.load_state_dict(det_state_dict(model, seed=5))
     model.to(dev).set_compute_dtype(dtype).train()
     ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(dev), lr=3e-4, use_graph=graph)
-    hist = []
-    for it in range(60):
+    every = []
+    for it in range(80):
         ld = ts.step(*batches[it % 4])
-        if it % 10 == 0 or it == 59:
-            hist.append(round(float(ld["loss"]), 3))
-    print(f"dtype={dtype} graph={graph} loss every 10 steps: {hist}  graphs captured: {len(ts._graphs)}")
-    assert hist[-1] < 0.8 * hist[0], "loss did not go down"
+        every.append(float(ld["loss"]))
+    first, last = sum(every[:4]) / 4, sum(every[-8:]) / 8
+    hist = [round(v, 3) for v in every[::10]]
+    print(f"dtype={dtype} graph={graph} loss every 10 steps: {hist}  mean first 4 = {first:.3f}, mean last 8 = {last:.3f}"
+          f"  graphs captured: {len(ts._graphs)}")
+    assert last < 0.85 * first, "loss did not go down"
 print("train sanity ok")
