@@ -84,6 +84,8 @@ SIGNATURES = {
     "dsvg_gate_mul": (c_i32, [c_i32, vp, vp, vp, c_i64, c_f32, vp]),
     "dsvg_add": (c_i32, [c_i32, vp, vp, vp, c_i64, vp]),
     "dsvg_drop_apply": (c_i32, [c_i32, vp, vp, c_i64, c_f32, c_u32, vp, vp]),
+    "dsvg_assemble_batch": (c_i32, [vp, c_i64, vp, c_i64, vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_i32, vp, vp, vp,
+                                    vp]),
     "dsvg_probe_trread": (c_i32, [vp, vp, vp]),
 }
 

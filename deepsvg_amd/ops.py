@@ -565,6 +565,31 @@ def scatter_rows(src, idx, dst):
 
 
 # ------------------------------------------------------------------------------------------------
+# device-side batch assembly (svgtensor_dataset.py:164-205)
+# ------------------------------------------------------------------------------------------------
+def assemble_batch(rows, slot_off, variant, G, L, grouped, want_args=True, want_rel=False, pad_val=-1.0,
+                   args_dim=256):
+    """rows int16 [R, 12], slot_off int32 [n_variants*G + 1], variant int32 [N]  ->
+    commands f32 [N, G or 1, L], args / args_rel f32 [N, G or 1, L, 11] (None when not wanted)"""
+    _chk(rows, slot_off, variant)
+    assert rows.dtype == torch.int16 and rows.dim() == 2 and rows.shape[1] == 12 and rows.is_contiguous()
+    assert slot_off.dtype == torch.int32 and variant.dtype == torch.int32
+    assert slot_off.is_contiguous() and variant.is_contiguous()
+    N = variant.numel()
+    Gs = 1 if grouped else G
+    dev = rows.device
+    commands = torch.empty(N, Gs, L, dtype=torch.float32, device=dev)
+    args = torch.empty(N, Gs, L, 11, dtype=torch.float32, device=dev) if want_args else None
+    rel = torch.empty(N, Gs, L, 11, dtype=torch.float32, device=dev) if want_rel else None
+    _l.check(_l.load().dsvg_assemble_batch(rows.data_ptr(), rows.shape[0], slot_off.data_ptr(), slot_off.numel() - 1,
+                                           variant.data_ptr(), N, G, 1 if grouped else 0, L,
+                                           float(pad_val), int(args_dim), commands.data_ptr(),
+                                           args.data_ptr() if want_args else None,
+                                           rel.data_ptr() if want_rel else None, _stream()), "dsvg_assemble_batch")
+    return commands, args, rel
+
+
+# ------------------------------------------------------------------------------------------------
 # optimizer / housekeeping
 # ------------------------------------------------------------------------------------------------
 def sumsq(x, out=None):

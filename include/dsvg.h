@@ -267,6 +267,24 @@ int dsvg_drop_apply(int32_t dtype, const void* x, void* y, int64_t n, float drop
                     const uint64_t* seed, void* stream);
 /* out[i] = a[i] + b[i] — the residual add of the latent ResNet (basic_blocks.py:59-65) */
 int dsvg_add(int32_t dtype, const void* a, const void* b, void* out, int64_t n, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Device-side batch assembly.  Replaces, for a whole batch, the per-item chain of
+ * SVGTensorDataset.get_data (deepsvg/svgtensor_dataset.py:164-205): SVGTensor.from_data(...).add_eos().add_sos()
+ * .pad(seq_len) (deepsvg/difflib/tensor.py:85-88,108-116,125-143), .cmds()/.args()/.get_relative_args()
+ * (tensor.py:155-162,172-189) and the DataLoader's default collate (deepsvg/train.py:27-28).
+ *   rows     int16 [n_rows, 12]: (command, 11 arguments in SVGTensor.arg_keys order) per stored drawing command
+ *   slot_off int32 [n_slots+1]:  row range of slot variant*G + group; a variant is one stored (icon, augmentation)
+ *                                pair (the list entries of the .pkl "tensors", svgtensor_dataset.py:106-109,155-156)
+ *   variant  int32 [n_items]:    which stored variant each batch item takes
+ * grouped == 0: sequences (item, group), commands [n_items, G, L], args / args_rel [n_items, G, L, 11], L = S+2;
+ * grouped != 0: one sequence per item over all its groups, commands [n_items, 1, L], L = max_total_len+2.
+ * Each sequence is SOS, the stored rows, EOS, then EOS padding; argument slots of SOS/EOS/pad rows are pad_val.
+ * args and args_rel are optional (NULL = not wanted); args_rel follows get_relative_args with ARGS_DIM=args_dim.
+ * Sequences longer than L-2 are cut (the host refuses to build such a store). */
+int dsvg_assemble_batch(const int16_t* rows, int64_t n_rows, const int32_t* slot_off, int64_t n_slots,
+                        const int32_t* variant, int64_t n_items, int32_t G, int32_t grouped, int32_t L,
+                        float pad_val, int32_t args_dim, float* commands, float* args, float* args_rel,
+                        void* stream);
 /* test hook: raw ds_read_b64_tr_b16 on a 4 KiB LDS image img[i]=i, lane l reads at byte offset off[l] */
 int dsvg_probe_trread(const int* off, short* out, void* stream);
 

@@ -12,7 +12,32 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_cases():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """the model / loss fixtures (tests/golden/make_golden.py); batch_assembly.npz belongs to the data path"""
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return [n for n in names if not n.startswith("batch_")]
+
+
+BATCH_KEYS = ["commands", "args", "args_rel", "commands_grouped", "args_grouped", "args_rel_grouped", "filling"]
+
+
+def golden_batch(tag):
+    """tests/golden/batch_assembly.npz (make_golden_batch.py: outputs of the reference's SVGTensorDataset.get_data)
+    -> (icons, fillings, (G, S, T), expected): icons[i] = list of group arrays [len, 14] float32 (the rows a
+    .pkl file would hold, START_POS columns included); expected[key] = stacked reference outputs"""
+    z = np.load(os.path.join(GOLDEN_DIR, "batch_assembly.npz"))
+    G, S, T = (int(v) for v in z[f"{tag}/cfg"])
+    rows, lens, n_groups, fills = (z[f"{tag}/{k}"] for k in ("rows", "lens", "n_groups", "fills"))
+    icons, fillings, r, gi = [], [], 0, 0
+    for n in n_groups:
+        groups = []
+        for j in range(n):
+            groups.append(rows[r:r + lens[gi + j]].astype(np.float32))
+            r += int(lens[gi + j])
+        icons.append(groups)
+        fillings.append([int(f) for f in fills[gi:gi + n]])
+        gi += int(n)
+    expected = {k: z[f"{tag}/{k}"].astype(np.int64 if k == "filling" else np.float32) for k in BATCH_KEYS}
+    return icons, fillings, (G, S, T), expected
 
 
 def load_golden(name):
