@@ -324,6 +324,27 @@ class GatherGroupsFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+class LabelEmbedFn(torch.autograd.Function):
+    """LabelEmbedding.forward (deepsvg/model/model.py:87-89): one row of the (n_labels, dim_label) table per icon.
+    An N x dim_label lookup and its scatter-add are left to torch (not a hot op); the table's gradient is written
+    into the flat gradient buffer like every other parameter gradient.  Apply once per table and forward pass."""
+
+    @staticmethod
+    def forward(ctx, rt, label, weight):
+        idx = label.reshape(-1).long()
+        ctx.rt = rt
+        ctx.save_for_backward(idx, weight)
+        return rt.w(weight).index_select(0, idx).contiguous()
+
+    @staticmethod
+    def backward(ctx, dl):
+        idx, weight = ctx.saved_tensors
+        out = ctx.rt.grad_out(weight)
+        out.zero_()
+        out.index_add_(0, idx, dl.to(torch.float32))
+        return None, None, out
+
+
 class PackedEmbedFn(torch.autograd.Function):
     """SVGEmbedding on the packed token layout of the first encoder stage (ops.pack_tokens):
          src[r] = drop( embed_fcn(arg_embed[args_r + 1]) + command_embed[cmd_r] + pos[pos_r] )

@@ -357,8 +357,6 @@ class SVGTransformer(nn.Module):
             raise NotImplementedError("autoregressive decoding is not built yet (SURVEY.md §8(f)-3)")
         if cfg.self_match:
             raise NotImplementedError("Hungarian self-matching (HierarchicalSelfMatching) is not built yet")
-        if cfg.label_condition:
-            raise NotImplementedError("label conditioning (fonts config) is not built yet")
         if cfg.d_model // cfg.n_heads != 32 or cfg.d_model % cfg.n_heads:
             raise NotImplementedError("the attention kernel is specialised for head_dim == 32")
         self.args_dim = 2 * cfg.args_dim if cfg.rel_targets else cfg.args_dim + 1
@@ -431,16 +429,21 @@ class SVGTransformer(nn.Module):
         return self._rt
 
     # ---- blocks ----------------------------------------------------------------------------------
-    def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site, seq_off=None, live=None, tiles=None):
+    def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site, seq_off=None, live=None, tiles=None, l=None):
+        """l: label embedding rows [n_seq, dim_label] of a label-conditioned config (memory2 of the reference layers,
+        layers/improved_transformer.py:47-49,134-136)"""
         cfg = self.cfg
         for i, L in enumerate(stack.layers):
             has_g = hasattr(L, "linear_global")
+            has_l = l is not None and hasattr(L, "linear_global2")
             x = Fn.LayerFn.apply(
-                rt, x, key_mask, z if has_g else None, None, n_seq, S, cfg.n_heads, cfg.dropout, site + 8 * i,
+                rt, x, key_mask, z if has_g else None, l if has_l else None, n_seq, S, cfg.n_heads, cfg.dropout,
+                site + 8 * i,
                 L.norm1.weight, L.norm1.bias, L.self_attn.in_proj_weight, L.self_attn.in_proj_bias,
                 L.self_attn.out_proj.weight, L.self_attn.out_proj.bias, L.norm2.weight, L.norm2.bias,
                 L.linear1.weight, L.linear1.bias, L.linear2.weight, L.linear2.bias,
-                L.linear_global.weight if has_g else None, L.linear_global.bias if has_g else None, None, None,
+                L.linear_global.weight if has_g else None, L.linear_global.bias if has_g else None,
+                L.linear_global2.weight if has_l else None, L.linear_global2.bias if has_l else None,
                 seq_off, live, tiles)
         return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps, live)
 
@@ -468,8 +471,9 @@ class SVGTransformer(nn.Module):
         if ref is None or (ref.is_cuda and torch.cuda.is_current_stream_capturing()):
             return plan
         counts = []
+        # (label-conditioned configs add a per-sequence term in every layer: they keep the padded / dense layouts)
         if (commands_enc is not None and self.pack_encoder and cfg.encode_stages > 0
-                and not self.encoder.use_group):
+                and not self.encoder.use_group and not cfg.label_condition):
             N, G, S = commands_enc.shape
             cmd = commands_enc.to(torch.float32).contiguous().view(N * G, S)
             arg = args_enc.to(torch.float32).contiguous().view(N * G * S, -1)
@@ -480,7 +484,7 @@ class SVGTransformer(nn.Module):
                                tiles=tiles)
             counts.append(seq_off[-1:])
         if (commands_dec is not None and want_grad and self.skip_invisible_backward and cfg.decode_stages == 2
-                and commands_dec.shape[1] == cfg.num_groups_proposal):
+                and commands_dec.shape[1] == cfg.num_groups_proposal and not cfg.label_condition):
             N, G, St = commands_dec.shape
             cmd_t = commands_dec.to(torch.float32).contiguous().view(N * G, St)
             _km, vis, _gm = ops.build_masks(cmd_t, St, G, EOS_ID)
@@ -527,7 +531,16 @@ class SVGTransformer(nn.Module):
         mem = self._run_stack(rt, enc.encoder, src, None, None, n_seq, S, 100, seq_off=seq_off, tiles=pe.get("tiles"))
         return Fn.MaskedMeanFn.apply(rt, mem, None, n_seq, S, seq_off)
 
-    def _encode(self, rt, commands, args, plan=None):
+    def _label_rows(self, rt, part, label, N):
+        """rows of `part`'s own label table, one per icon (model.py:123,155,245)"""
+        if label is None:
+            raise ValueError("label_condition=True: forward needs `label`")
+        label = label.reshape(-1)
+        if label.numel() != N:
+            raise ValueError(f"label has {label.numel()} entries for {N} icons")
+        return Fn.LabelEmbedFn.apply(rt, label, part.label_embedding.label_embedding.weight)
+
+    def _encode(self, rt, commands, args, plan=None, label=None):
         """commands (N, G, S) / args (N, G, S, n_args) float32, batch-first  ->  z [N, d_model]"""
         cfg = self.cfg
         enc = self.encoder
@@ -535,6 +548,10 @@ class SVGTransformer(nn.Module):
         two = cfg.encode_stages == 2
         emb = enc.embedding
         pe = plan["enc"] if plan is not None else None
+        l = l_seq = None
+        if cfg.label_condition:
+            l = self._label_rows(rt, enc, label, N)
+            l_seq = l.repeat_interleave(G, dim=0) if G > 1 else l         # sequence (n, g) carries icon n's label
         if pe is not None:
             group_mask = pe["group_mask"]
             z = self._encode_stage1_packed(rt, pe, N * G, S)
@@ -548,11 +565,11 @@ class SVGTransformer(nn.Module):
                                    emb.command_embed.weight, emb.arg_embed.weight, emb.embed_fcn.weight,
                                    emb.embed_fcn.bias, emb.pos_encoding.pos_embed.weight,
                                    emb.group_embed.weight if enc.use_group else None)
-            mem = self._run_stack(rt, enc.encoder, src, key_mask, None, N * G, S, 100)
+            mem = self._run_stack(rt, enc.encoder, src, key_mask, None, N * G, S, 100, l=l_seq)
             z = Fn.MaskedMeanFn.apply(rt, mem, key_mask, N * G, S)          # [N*G, d]
         if two:
             src2 = Fn.AddPosFn.apply(rt, z, enc.hierarchical_PE.pos_embed.weight, N, G, PE_DROPOUT, 2)
-            mem2 = self._run_stack(rt, enc.hierarchical_encoder, src2, group_mask, None, N, G, 200)
+            mem2 = self._run_stack(rt, enc.hierarchical_encoder, src2, group_mask, None, N, G, 200, l=l)
             z = Fn.MaskedMeanFn.apply(rt, mem2, group_mask, N, G)       # [N, d]
         return z
 
@@ -576,25 +593,40 @@ class SVGTransformer(nn.Module):
                                   0.0, 0, None)
         return z, mu, logsigma
 
-    def _decode(self, rt, z, plan=None, lazy_args=False):
+    def _decode(self, rt, z, plan=None, lazy_args=False, label=None, hierarch_logits=None, return_hierarch=False):
         """z [N, dim_z] -> command_logits (N,G,S,n_cmd), args_logits (N,G,S,n_args,args_dim)[, visibility (N,G,1,2)];
-        with lazy_args the second result is a thunk that computes args_logits when called"""
+        with lazy_args the second result is a thunk that computes args_logits when called.
+        hierarch_logits [N*G, 2] given: z is the per-group latent [N*G, dim_z] and the first decoder stage is skipped
+        (model.py:249-253); return_hierarch: stop after the first stage and return (visibility logits, per-group z),
+        both [N*G, .] (model.py:260-261)."""
         cfg = self.cfg
         dec = self.decoder
-        N = z.shape[0]
         vis_logits = None
+        l = l_seq = None
         if cfg.decode_stages == 2:
             G = cfg.num_groups_proposal
-            src = Fn.AddPosFn.apply(rt, None, dec.hierarchical_embedding.PE.pos_embed.weight, N, G, PE_DROPOUT, 3)
-            out = self._run_stack(rt, dec.hierarchical_decoder, src, None, z, N, G, 300)
-            hf = dec.hierarchical_fcn
-            vis_logits = Fn.LinearFn.apply(rt, out, hf.visibility_fcn.weight, hf.visibility_fcn.bias, 0, None, 0.0, 0,
-                                           None)
-            z = Fn.LinearFn.apply(rt, out, hf.z_fcn.weight, hf.z_fcn.bias, 0, None, 0.0, 0, None)   # [N*G, dim_z]
+            N = z.shape[0] if hierarch_logits is None else z.shape[0] // G
+            if cfg.label_condition:
+                l = self._label_rows(rt, dec, label, N)
+                l_seq = l.repeat_interleave(G, dim=0)
+            if hierarch_logits is None:
+                src = Fn.AddPosFn.apply(rt, None, dec.hierarchical_embedding.PE.pos_embed.weight, N, G, PE_DROPOUT, 3)
+                out = self._run_stack(rt, dec.hierarchical_decoder, src, None, z, N, G, 300, l=l)
+                hf = dec.hierarchical_fcn
+                vis_logits = Fn.LinearFn.apply(rt, out, hf.visibility_fcn.weight, hf.visibility_fcn.bias, 0, None, 0.0,
+                                               0, None)
+                z = Fn.LinearFn.apply(rt, out, hf.z_fcn.weight, hf.z_fcn.bias, 0, None, 0.0, 0, None)  # [N*G, dim_z]
+            else:
+                vis_logits = hierarch_logits
+            if return_hierarch:
+                return vis_logits, z
             n_seq = N * G
         else:
+            N = z.shape[0]
             G = 1
             n_seq = N
+            if cfg.label_condition:
+                l_seq = self._label_rows(rt, dec, label, N)
         S = dec.embedding.seq_len
         pd = plan["dec"] if (plan is not None and cfg.decode_stages == 2) else None
         live = None
@@ -606,7 +638,7 @@ class SVGTransformer(nn.Module):
             z = Fn.GatherGroupsFn.apply(z, pd["old_of_new"], pd["new_of_old"], n_seq, 1, None)
         self.last_live = (live[0], n_seq) if live is not None else None
         src = Fn.AddPosFn.apply(rt, None, dec.embedding.PE.pos_embed.weight, n_seq, S, PE_DROPOUT, 4, live)
-        out = self._run_stack(rt, dec.decoder, src, None, z, n_seq, S, 400, live=live)
+        out = self._run_stack(rt, dec.decoder, src, None, z, n_seq, S, 400, live=live, l=l_seq)
         if live is not None:        # back to the caller's group order before the heads
             out = Fn.GatherGroupsFn.apply(out, pd["new_of_old"], pd["old_of_new"], n_seq, S, live)
         cmd_logits = Fn.LinearFn.apply(rt, out, dec.fcn.command_fcn.weight, dec.fcn.command_fcn.bias, 0, None, 0.0, 0,
@@ -627,8 +659,8 @@ class SVGTransformer(nn.Module):
     def forward(self, commands_enc, args_enc, commands_dec, args_dec, label=None, z=None, hierarch_logits=None,
                 return_tgt=True, params=None, encode_mode=False, return_hierarch=False):
         cfg = self.cfg
-        if hierarch_logits is not None or return_hierarch:
-            raise NotImplementedError("hierarch_logits / return_hierarch (GUI path) is not built yet")
+        if (hierarch_logits is not None or return_hierarch) and cfg.decode_stages != 2:
+            raise ValueError("hierarch_logits / return_hierarch need a two-stage decoder")
         ref = commands_enc if commands_enc is not None else z
         device = ref.device
         ops.require_device(device)
@@ -637,7 +669,7 @@ class SVGTransformer(nn.Module):
         plan = self._plan(commands_enc if z is None else None, args_enc, commands_dec if return_tgt else None,
                           torch.is_grad_enabled() and not encode_mode, args_dec)
         if z is None:
-            zz = self._encode(rt, commands_enc, args_enc, plan)
+            zz = self._encode(rt, commands_enc, args_enc, plan, label)
             zz, mu, logsigma = self._bottleneck(rt, zz)
             if self._decoder_grads_ready is not None and zz.requires_grad:
                 # data-parallel trainer: the gradient of the bottleneck output is final exactly when every decoder
@@ -646,12 +678,29 @@ class SVGTransformer(nn.Module):
                 cb = self._decoder_grads_ready
                 zz.register_hook(lambda g: (cb(), None)[1])
         else:
-            # externally supplied z is batch-first (N, 1, 1, dim_z)  (model.py:369)
-            zz = z.reshape(z.shape[0], -1).to(rt.dtype).contiguous()
+            # externally supplied z is batch-first (N, 1, 1, dim_z), or (N, G, 1, dim_z) per-group latents together
+            # with hierarch_logits  (model.py:369, 249-253)
+            zz = z.reshape(-1, z.shape[-1]).to(rt.dtype).contiguous()
         if encode_mode:
             return zz.to(torch.float32).view(1, 1, zz.shape[0], zz.shape[1])   # seq-first, as model.py:371
+        hl = None
+        if hierarch_logits is not None:
+            # seq-first (1, G, N, 2), exactly what return_hierarch hands out (the reference does not permute it,
+            # model.py:379-380) -> rows n*G + g
+            hl = hierarch_logits.reshape(hierarch_logits.shape[-3], hierarch_logits.shape[-2], 2).permute(1, 0, 2) \
+                .reshape(-1, 2).to(rt.dtype).contiguous()
+            if hl.shape[0] != zz.shape[0]:
+                raise ValueError("hierarch_logits (1, G, N, 2) needs the per-group latents z (N, G, 1, dim_z)")
+        if return_hierarch:
+            vis, zg = self._decode(rt, zz, None, label=label, hierarch_logits=hl, return_hierarch=True)
+            G = cfg.num_groups_proposal
+            N = vis.shape[0] // G
+            # seq-first (1, G, N, .), as the reference returns them (model.py:260-261,382-383)
+            return (vis.to(torch.float32).view(N, G, 2).permute(1, 0, 2).unsqueeze(0),
+                    zg.to(torch.float32).view(N, G, -1).permute(1, 0, 2).unsqueeze(0))
         lazy_args = bool(return_tgt and plan is not None and plan.get("loss") is not None)
-        cmd_logits, args_logits, vis_logits = self._decode(rt, zz, plan, lazy_args=lazy_args)
+        cmd_logits, args_logits, vis_logits = self._decode(rt, zz, plan, lazy_args=lazy_args, label=label,
+                                                           hierarch_logits=hl)
         res = ModelOutput({"command_logits": cmd_logits})
         if lazy_args:
             res.set_lazy("args_logits", args_logits)

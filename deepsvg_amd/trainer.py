@@ -88,7 +88,7 @@ class TrainStep:
         return count / self.world
 
     # ---- one step ------------------------------------------------------------------------------------
-    def _step_body(self, commands, args):
+    def _step_body(self, commands, args, label=None):
         model = self.model
         ops.advance_step_(self.step_count, self.seed)
         for p in model.store.params:
@@ -97,8 +97,8 @@ class TrainStep:
         if self.world > 1 and self.overlap_allreduce:
             model._decoder_grads_ready = self._launch_decoder_bucket    # hooked onto the bottleneck output in forward
         try:
-            out = model(commands, args, commands, args, params={})
-            ld = self.loss_fn(out, None, weights=self.weights)
+            out = model(commands, args, commands, args, label=label, params={})
+            ld = self.loss_fn(out, label, weights=self.weights)
             ld["loss"].backward()
         finally:
             model._decoder_grads_ready = None
@@ -119,11 +119,12 @@ class TrainStep:
                         grad_scale=1.0 / self.world)
         return {k: v.detach() for k, v in ld.items()}
 
-    def step(self, commands, args):
+    def step(self, commands, args, label=None):
+        """one training step on a batch; `label` (N,) for label-conditioned configs (deepsvg/train.py:94-96)"""
         if not self._ready:
             self._setup(commands.device)
         if not commands.is_cuda:                    # CPU emulation (tests): no streams
-            return self._step_body(commands, args)
+            return self._step_body(commands, args, label)
         model = self.model
         main = torch.cuda.current_stream()
         # The layout plan (a few tiny kernels + ONE host read) runs on its own stream so that the host read does not
@@ -146,19 +147,22 @@ class TrainStep:
         if not self.use_graph:
             model._forced_plan = plan
             try:
-                res = self._step_body(commands, args)
+                res = self._step_body(commands, args, label)
             finally:
                 model._forced_plan = None
             self._note_layout(plan, commands)
             return res
         key, plan = self._bucketed(plan, commands)
+        key = key + (label is not None,)
         entry = self._graphs.get(key)
         if entry is None:
-            entry = self._capture(key, commands, args, plan)
+            entry = self._capture(key, commands, args, plan, label)
         else:
-            graph, (sc, sa), splan, res = entry
+            graph, (sc, sa, sl), splan, res = entry
             sc.copy_(commands)
             sa.copy_(args)
+            if sl is not None:
+                sl.copy_(label)
             for part in ("enc", "dec", "loss"):
                 if splan[part] is not None:
                     for k, v in splan[part].items():
@@ -206,9 +210,10 @@ class TrainStep:
         m.last_head_rows = ((plan["loss"]["n_live"], n_seq * (commands.shape[2] - 1))
                             if plan["loss"] is not None else None)
 
-    def _capture(self, key, commands, args, plan):
+    def _capture(self, key, commands, args, plan, label=None):
         model = self.model
         sc, sa = commands.clone(), args.clone()
+        sl = label.clone() if label is not None else None
         def _static(v):
             if torch.is_tensor(v):
                 return v.clone()
@@ -226,7 +231,7 @@ class TrainStep:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    self._step_body(sc, sa)
+                    self._step_body(sc, sa, sl)
                 for t, s0 in zip(state, saved):
                     t.copy_(s0)
             torch.cuda.current_stream().wait_stream(side)
@@ -235,10 +240,10 @@ class TrainStep:
                 self._pool = torch.cuda.graph_pool_handle()     # graphs replay one at a time: one shared pool
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self._pool):
-                res = self._step_body(sc, sa)
+                res = self._step_body(sc, sa, sl)
         finally:
             model._forced_plan = None
-        entry = (g, (sc, sa), splan, res)
+        entry = (g, (sc, sa, sl), splan, res)
         self._graphs[key] = entry
         return entry
 

@@ -126,17 +126,17 @@ def decoder_layer(sd, pre, x, memory, n_heads, memory2=None):
     return x + F.linear(h, sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
 
 
-def encoder_stack(sd, pre, x, n_layers, n_heads, kpm):
+def encoder_stack(sd, pre, x, n_layers, n_heads, kpm, memory2=None):
     """layers/transformer.py:168-188"""
     for i in range(n_layers):
-        x = encoder_layer(sd, f"{pre}layers.{i}.", x, n_heads, kpm)
+        x = encoder_layer(sd, f"{pre}layers.{i}.", x, n_heads, kpm, memory2)
     return ln(sd, pre + "norm.", x)
 
 
-def decoder_stack(sd, pre, x, memory, n_layers, n_heads):
+def decoder_stack(sd, pre, x, memory, n_layers, n_heads, memory2=None):
     """layers/transformer.py:214-242"""
     for i in range(n_layers):
-        x = decoder_layer(sd, f"{pre}layers.{i}.", x, memory, n_heads)
+        x = decoder_layer(sd, f"{pre}layers.{i}.", x, memory, n_heads, memory2)
     return ln(sd, pre + "norm.", x)
 
 
@@ -174,23 +174,32 @@ def seq_first(x):
     return x.permute(2, 1, 0, *range(3, x.dim()))
 
 
-def encode(sd, cfg, commands, args):
+def label_embedding(sd, pre, label):
+    """LabelEmbedding.forward model.py:87-89"""
+    return F.embedding(label.long(), sd[pre + "label_embedding.label_embedding.weight"])
+
+
+def encode(sd, cfg, commands, args, label=None):
     """Encoder.forward model.py:121-164.  commands (S, G, N) seq-first."""
     S, G, N = commands.shape
     two = cfg.encode_stages == 2
+    l = None
+    if cfg.label_condition:                                                                 # :123
+        l = pack(label_embedding(sd, "encoder.", label).unsqueeze(0).unsqueeze(0).repeat(1, G, 1, 1))
     if two:
         vis_mask, key_vis_mask = visibility_mask(commands, 0), key_visibility_mask(commands, 0)
     commands, args = pack(commands), pack(args)
     pm, kpm = padding_mask(commands, 0).to(args.dtype), key_padding_mask(commands, 0)
     groups = group_mask(commands, 0) if cfg.encode_stages == 1 else None
     src = svg_embedding(sd, "encoder.embedding.", commands, args, groups)
-    memory = encoder_stack(sd, "encoder.encoder.", src, cfg.n_layers, cfg.n_heads, kpm)
+    memory = encoder_stack(sd, "encoder.encoder.", src, cfg.n_layers, cfg.n_heads, kpm, l)
     z = (memory * pm).sum(dim=0, keepdim=True) / pm.sum(dim=0, keepdim=True)              # :137
     z = unpack(N, z)
     if two:
         src = pack(z.transpose(0, 1))                                                       # :153-154
         src = src + sd["encoder.hierarchical_PE.pos_embed.weight"][:src.size(0)].unsqueeze(1)
-        memory = encoder_stack(sd, "encoder.hierarchical_encoder.", src, cfg.n_layers, cfg.n_heads, key_vis_mask)
+        l = label_embedding(sd, "encoder.", label).unsqueeze(0) if cfg.label_condition else None   # :155
+        memory = encoder_stack(sd, "encoder.hierarchical_encoder.", src, cfg.n_layers, cfg.n_heads, key_vis_mask, l)
         vm = vis_mask.to(memory.dtype)
         z = (memory * vm).sum(dim=0, keepdim=True) / vm.sum(dim=0, keepdim=True)          # :161
         z = unpack(N, z)
@@ -204,22 +213,29 @@ def resnet(sd, z):
     return z
 
 
-def decode(sd, cfg, z):
-    """Decoder.forward model.py:243-285 (one_shot).  z (1, 1, N, dim_z) -> seq-first logits"""
+def decode(sd, cfg, z, label=None, hierarch_logits=None, return_hierarch=False):
+    """Decoder.forward model.py:243-285 (one_shot).  z (1, 1, N, dim_z) -> seq-first logits; with hierarch_logits
+    (1, G, N, 2) the first stage is skipped and z is the per-group latent (1, G, N, dim_z) (:246-254)"""
     N = z.size(2)
-    z = pack(z)                                                                            # (1, N, dz)
-    hierarch_logits = None
+    l = label_embedding(sd, "decoder.", label).unsqueeze(0) if cfg.label_condition else None   # :245
+    if hierarch_logits is None:
+        z = pack(z)                                                                        # (1, N, dz)
     if cfg.decode_stages == 2:
-        src = const_embedding(sd, "decoder.hierarchical_embedding.", cfg.num_groups_proposal, N, z)
-        out = decoder_stack(sd, "decoder.hierarchical_decoder.", src, z, cfg.n_layers_decode, cfg.n_heads)
-        hierarch_logits = F.linear(out, sd["decoder.hierarchical_fcn.visibility_fcn.weight"],
-                                   sd["decoder.hierarchical_fcn.visibility_fcn.bias"]).unsqueeze(0)      # basic_blocks.py:36
-        z = F.linear(out, sd["decoder.hierarchical_fcn.z_fcn.weight"],
-                     sd["decoder.hierarchical_fcn.z_fcn.bias"]).unsqueeze(0)                             # :37
+        if hierarch_logits is None:
+            src = const_embedding(sd, "decoder.hierarchical_embedding.", cfg.num_groups_proposal, N, z)
+            out = decoder_stack(sd, "decoder.hierarchical_decoder.", src, z, cfg.n_layers_decode, cfg.n_heads, l)
+            hierarch_logits = F.linear(out, sd["decoder.hierarchical_fcn.visibility_fcn.weight"],
+                                       sd["decoder.hierarchical_fcn.visibility_fcn.bias"]).unsqueeze(0)  # basic_blocks.py:36
+            z = F.linear(out, sd["decoder.hierarchical_fcn.z_fcn.weight"],
+                         sd["decoder.hierarchical_fcn.z_fcn.bias"]).unsqueeze(0)                         # :37
+        if cfg.label_condition:
+            l = pack(l.unsqueeze(0).repeat(1, z.size(1), 1, 1))                             # :256
         hierarch_logits, z = pack(hierarch_logits), pack(z)                                 # (1, G*N, .)
+        if return_hierarch:
+            return unpack(N, hierarch_logits), unpack(N, z)                                 # :260-261
     seq_len = cfg.max_seq_len + 1 if cfg.decode_stages == 2 else cfg.max_total_len + 1
     src = const_embedding(sd, "decoder.embedding.", seq_len, z.size(1), z)
-    out = decoder_stack(sd, "decoder.decoder.", src, z, cfg.n_layers_decode, cfg.n_heads)
+    out = decoder_stack(sd, "decoder.decoder.", src, z, cfg.n_layers_decode, cfg.n_heads, l)
     S, GN, _ = out.shape
     command_logits = F.linear(out, sd["decoder.fcn.command_fcn.weight"], sd["decoder.fcn.command_fcn.bias"])
     args_dim = 2 * cfg.args_dim if cfg.rel_targets else cfg.args_dim + 1
@@ -229,14 +245,15 @@ def decode(sd, cfg, z):
     return tuple(unpack(N, o) for o in outs)
 
 
-def forward(sd, cfg, commands_enc, args_enc, commands_dec, args_dec, z=None, eps=None, encode_mode=False):
+def forward(sd, cfg, commands_enc, args_enc, commands_dec, args_dec, z=None, eps=None, encode_mode=False, label=None,
+            hierarch_logits=None, return_hierarch=False):
     """SVGTransformer.forward model.py:352-412, eval semantics (dropout = identity).
     Inputs batch-first (N, G, S) / (N, G, S, n_args).  `eps` replaces torch.randn_like in the VAE (model.py:185)."""
     dt = sd["decoder.fcn.command_fcn.weight"].dtype
     mu = logsigma = None
     if z is None:
         ce, ae = seq_first(commands_enc.to(dt)), seq_first(args_enc.to(dt))
-        z = encode(sd, cfg, ce, ae)
+        z = encode(sd, cfg, ce, ae, label)
         if cfg.use_resnet:
             z = resnet(sd, z)
         if cfg.use_vae:                                                                     # model.py:182-187
@@ -250,7 +267,9 @@ def forward(sd, cfg, commands_enc, args_enc, commands_dec, args_dec, z=None, eps
         z = seq_first(z.to(dt))
     if encode_mode:
         return z
-    outs = decode(sd, cfg, z)
+    outs = decode(sd, cfg, z, label, hierarch_logits, return_hierarch)
+    if return_hierarch:
+        return outs                                                                         # :382-383, seq-first
     outs = tuple(seq_first(o) for o in outs)                                                # _make_batch_first
     res = {"command_logits": outs[0], "args_logits": outs[1]}
     if cfg.decode_stages == 2:
@@ -299,12 +318,12 @@ DEFAULT_WEIGHTS = {   # configs/deepsvg/default_icons.py:65-73 at step 0
 }
 
 
-def loss_and_grads(sd, cfg, commands, args, weights=None, eps=None):
+def loss_and_grads(sd, cfg, commands, args, weights=None, eps=None, label=None):
     """forward + SVGLoss + autograd backward (the body of deepsvg/train.py:94-98 with dropout p = 0).
     Returns (output dict, loss dict, {name: grad})."""
     weights = weights or DEFAULT_WEIGHTS
     leaves = {k: v.detach().clone().requires_grad_(torch.is_floating_point(v)) for k, v in sd.items()}
-    out = forward(leaves, cfg, commands, args, commands, args, eps=eps)
+    out = forward(leaves, cfg, commands, args, commands, args, eps=eps, label=label)
     ld = svg_loss(cfg, out, weights)
     names = [k for k, v in leaves.items() if v.requires_grad]
     grads = torch.autograd.grad(ld["loss"], [leaves[k] for k in names], allow_unused=True)

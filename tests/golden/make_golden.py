@@ -58,6 +58,10 @@ def build_cfg(kind):
         cfg = ref_cfg.OneStageOneShot()
         cfg.max_total_len = 50
         cfg.use_vae = False
+    elif kind == "fonts":           # ModelConfig of configs/deepsvg/hierarchical_ordered_fonts.py:4-9
+        cfg = ref_cfg.Hierarchical()
+        cfg.label_condition = True
+        cfg.dim_z = 128
     else:
         raise ValueError(kind)
     return cfg
@@ -73,6 +77,9 @@ def run_case(name, kind, n, seed, wseed):
         commands, args = make_batch_onestage(n, total_len=cfg.max_total_len, seed=seed)
     else:
         commands, args = make_batch(n, G=cfg.max_num_groups, S=cfg.max_seq_len, seed=seed)
+    label = None
+    if cfg.label_condition:
+        label = torch.randint(0, cfg.n_labels, (n,), generator=torch.Generator().manual_seed(seed + 5))
     eps = None
     if cfg.use_vae:
         g = torch.Generator().manual_seed(seed + 77)
@@ -82,8 +89,18 @@ def run_case(name, kind, n, seed, wseed):
         # ---- eval forward: logits ----
         model.eval()
         with torch.no_grad():
-            out = model(commands, args, commands, args, params={})
-            z = model(commands, args, commands, args, encode_mode=True)
+            out = model(commands, args, commands, args, label=label, params={})
+            z = model(commands, args, commands, args, label=label, encode_mode=True)
+            hier = None
+            if cfg.decode_stages == 2:
+                # GUI path (model.py:246-261,382-383): per-group latents out, then back in with hierarch_logits
+                hier = model(commands, args, commands, args, label=label, return_hierarch=True)
+                z_groups = hier[1].permute(2, 1, 0, 3).contiguous()     # batch-first for `z=` (model.py:369)
+                out2 = model(None, None, commands, args, label=label, z=z_groups, hierarch_logits=hier[0],
+                             return_tgt=False)       # (with a VAE, return_tgt=True needs mu: model.py:408-410)
+                for k in out:
+                    if k.endswith("logits"):
+                        assert torch.allclose(out[k], out2[k], atol=1e-6), k
         # ---- train mode, every dropout p = 0: loss + grads ----
         model.train()
         for m in model.modules():
@@ -92,13 +109,13 @@ def run_case(name, kind, n, seed, wseed):
             if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
                 m.dropout = 0.0
         loss_fn = RefLoss(cfg)
-        out_t = model(commands, args, commands, args, params={})
+        out_t = model(commands, args, commands, args, label=label, params={})
         ld_alias = loss_fn(out_t, None, weights=WEIGHTS)
         orig = ref_loss_mod._get_padding_mask
         ref_loss_mod._get_padding_mask = _canonical_padding_mask
         try:
             model.zero_grad()
-            out_t = model(commands, args, commands, args, params={})
+            out_t = model(commands, args, commands, args, label=label, params={})
             ld = loss_fn(out_t, None, weights=WEIGHTS)
             ld["loss"].backward()
         finally:
@@ -108,12 +125,18 @@ def run_case(name, kind, n, seed, wseed):
             ref_model_mod.torch.randn_like = torch.randn_like
 
     # ---- the oracle restatement must agree with the live reference ----
-    o_out = O.forward(sd, cfg, commands, args, commands, args, eps=eps)
+    o_out = O.forward(sd, cfg, commands, args, commands, args, eps=eps, label=label)
+    if hier is not None:
+        o_hier = O.forward(sd, cfg, commands, args, commands, args, eps=eps, label=label, return_hierarch=True)
+        assert (o_hier[0] - hier[0]).abs().max().item() < 2e-5 and (o_hier[1] - hier[1]).abs().max().item() < 2e-5
+        o_out2 = O.forward(sd, cfg, None, None, commands, args, z=o_hier[1].permute(2, 1, 0, 3), label=label,
+                           hierarch_logits=o_hier[0])
+        assert (o_out2["args_logits"] - out["args_logits"]).abs().max().item() < 2e-5
     for k in ("command_logits", "args_logits", "visibility_logits"):
         if k in out:
             err = (o_out[k] - out[k]).abs().max().item()
             assert err < 2e-5, (name, k, err)
-    _, o_ld, o_grads = O.loss_and_grads(sd, cfg, commands, args, WEIGHTS, eps=eps)
+    _, o_ld, o_grads = O.loss_and_grads(sd, cfg, commands, args, WEIGHTS, eps=eps, label=label)
     for k in ld:
         assert abs(o_ld[k].item() - ld[k].item()) < 2e-5 * max(1.0, abs(ld[k].item())), (name, k, o_ld[k].item(), ld[k].item())
     worst = 0.0
@@ -139,6 +162,11 @@ def run_case(name, kind, n, seed, wseed):
         rec["visibility_logits"] = out["visibility_logits"].numpy()
     if eps is not None:
         rec["eps"] = eps.numpy()
+    if label is not None:
+        rec["label"] = label.numpy()
+    if hier is not None:
+        rec["hier_logits"] = hier[0].numpy()        # seq-first (1, G, N, 2)
+        rec["hier_z"] = hier[1].numpy()             # seq-first (1, G, N, dim_z)
     for k, v in ld.items():
         rec[k] = np.float64(v.item())
     rec["loss_cmd_ref_aliased"] = np.float64(ld_alias["loss_cmd"].item())
@@ -162,3 +190,4 @@ if __name__ == "__main__":
     run_case("hier_ordered_n5", "hier", 5, 12, 4321)
     run_case("hier_vae_n3", "hier_vae", 3, 13, 1234)
     run_case("onestage50_n3", "onestage", 3, 14, 1234)
+    run_case("fonts_label_n4", "fonts", 4, 15, 1234)

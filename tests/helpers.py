@@ -55,9 +55,18 @@ def build_cfg(kind):
         cfg = C.OneStageOneShot()
         cfg.max_total_len = 50
         cfg.use_vae = False
+    elif kind == "fonts":           # ModelConfig of configs/deepsvg/hierarchical_ordered_fonts.py:4-9
+        cfg = C.Hierarchical()
+        cfg.label_condition = True
+        cfg.dim_z = 128
     else:
         raise ValueError(kind)
     return cfg
+
+
+def golden_label(g):
+    """class labels of a label-conditioned fixture (None otherwise)"""
+    return torch.from_numpy(g["label"]) if "label" in g else None
 
 
 def golden_setup(name):

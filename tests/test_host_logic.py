@@ -11,7 +11,7 @@ from oracle import svg_transformer_oracle as O
 from tests import helpers as H
 
 
-def _run_model(cfg, sd, commands, args, eps=None, dtype=torch.float32):
+def _run_model(cfg, sd, commands, args, eps=None, dtype=torch.float32, label=None):
     model = deepsvg_amd.SVGTransformer(cfg)
     model.load_state_dict(sd)
     model.set_compute_dtype(dtype)
@@ -25,7 +25,7 @@ def _run_model(cfg, sd, commands, args, eps=None, dtype=torch.float32):
         orig = torch.randn_like
         M.torch.randn_like = lambda t: eps.reshape(t.shape).to(t.dtype)
     try:
-        out = model(commands, args, commands, args, params={})
+        out = model(commands, args, commands, args, label=label, params={})
         ld = loss_fn(out, None, weights=O.DEFAULT_WEIGHTS)
         ld["loss"].backward()
     finally:
@@ -40,13 +40,43 @@ def test_model_matches_golden_with_emulated_ops(name, emulated_ops):
     g, cfg, commands, args, eps = H.golden_setup(name)
     ref_model = deepsvg_amd.SVGTransformer(cfg)
     sd = H.weights_for(ref_model, g["wseed"])
-    model, out, ld, grads = _run_model(cfg, sd, commands, args, eps)
+    label = H.golden_label(g)
+    model, out, ld, grads = _run_model(cfg, sd, commands, args, eps, label=label)
     H.check_against_golden(g, out, {k: v.item() for k, v in ld.items()}, grads, logit_rtol=1e-4, logit_atol=1e-5,
                            loss_tol=1e-5, grad_norm_rtol=2e-4)
-    z = model(commands, args, commands, args, encode_mode=True) if eps is None else None
+    z = model(commands, args, commands, args, label=label, encode_mode=True) if eps is None else None
     if z is not None:
         assert z.shape == tuple(g["z"].shape)
         assert torch.allclose(z, torch.from_numpy(g["z"]), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["hier_ordered_n5", "fonts_label_n4"])
+def test_hierarch_path_with_emulated_ops(name, emulated_ops):
+    """return_hierarch hands out the first decoder stage's (visibility logits, per-group latents), seq-first; fed
+    back as hierarch_logits + z they reproduce the full forward (deepsvg/model/model.py:246-261,379-383)"""
+    g, cfg, commands, args, eps = H.golden_setup(name)
+    label = H.golden_label(g)
+    model = deepsvg_amd.SVGTransformer(cfg)
+    model.load_state_dict(H.weights_for(model, g["wseed"]))
+    model.eval()
+    import deepsvg_amd.model as M
+    orig = torch.randn_like
+    if eps is not None:
+        M.torch.randn_like = lambda t: eps.reshape(t.shape).to(t.dtype)
+    try:
+        with torch.no_grad():
+            hl, zg = model(commands, args, commands, args, label=label, return_hierarch=True)
+            full = model(commands, args, commands, args, label=label)
+    finally:
+        M.torch.randn_like = orig
+    assert hl.shape == tuple(g["hier_logits"].shape) and zg.shape == tuple(g["hier_z"].shape)
+    assert torch.allclose(hl, torch.from_numpy(g["hier_logits"]), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(zg, torch.from_numpy(g["hier_z"]), rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        again = model(None, None, None, None, label=label, z=zg.permute(2, 1, 0, 3).contiguous(), hierarch_logits=hl,
+                      return_tgt=False)
+    for k in ("command_logits", "args_logits", "visibility_logits"):
+        assert torch.allclose(again[k], full[k], rtol=1e-5, atol=1e-6), k
 
 
 def test_packed_encoder_equals_padded_encoder(emulated_ops):
@@ -117,17 +147,20 @@ def test_state_dict_layout_matches_reference_names(emulated_ops):
                            "decoder.hierarchical_embedding.PE.position", "decoder.embedding.PE.position"])
 
 
-def test_param_store_flat_views_and_grad_aliasing(emulated_ops):
-    cfg = H.build_cfg("hier")
+@pytest.mark.parametrize("kind", ["hier", "fonts"])
+def test_param_store_flat_views_and_grad_aliasing(emulated_ops, kind):
+    cfg = H.build_cfg(kind)
     cfg.n_layers = cfg.n_layers_decode = 1
+    cfg.use_vae = False                                     # (a sampled latent would differ between the steps below)
     model = deepsvg_amd.SVGTransformer(cfg)
     from deepsvg_amd.synthetic import make_batch
     commands, args = make_batch(2, seed=3)
+    label = torch.tensor([7, 7]) if cfg.label_condition else None       # a repeated label: scatter-ADD of its rows
     loss_fn = deepsvg_amd.SVGLoss(cfg)
     model.eval()
 
     def step():
-        out = model(commands, args, commands, args)
+        out = model(commands, args, commands, args, label=label)
         loss_fn(out, None, weights=O.DEFAULT_WEIGHTS)["loss"].backward()
 
     step()

@@ -23,7 +23,7 @@ def _hip_model(cfg, sd, dtype=torch.float32):
     return model
 
 
-def _fwd_bwd(model, cfg, commands, args, eps=None):
+def _fwd_bwd(model, cfg, commands, args, eps=None, label=None):
     loss_fn = deepsvg_amd.SVGLoss(cfg).to(DEV)
     model.zero_grad()
     import deepsvg_amd.model as M
@@ -31,7 +31,8 @@ def _fwd_bwd(model, cfg, commands, args, eps=None):
     if eps is not None:
         M.torch.randn_like = lambda t: eps.reshape(t.shape).to(device=t.device, dtype=t.dtype)
     try:
-        out = model(commands.to(DEV), args.to(DEV), commands.to(DEV), args.to(DEV), params={})
+        out = model(commands.to(DEV), args.to(DEV), commands.to(DEV), args.to(DEV),
+                    label=label.to(DEV) if label is not None else None, params={})
         ld = loss_fn(out, None, weights=O.DEFAULT_WEIGHTS)
         ld["loss"].backward()
     finally:
@@ -50,11 +51,62 @@ def test_fp32_model_matches_reference_golden(gpu_device, name, packed):
     model = _hip_model(cfg, H.weights_for(deepsvg_amd.SVGTransformer(cfg), g["wseed"]))
     model.pack_encoder = model.skip_invisible_backward = model.compact_head_backward = packed
     model.eval()
-    out, ld, grads = _fwd_bwd(model, cfg, commands, args, eps)
+    label = H.golden_label(g)
+    out, ld, grads = _fwd_bwd(model, cfg, commands, args, eps, label)
     H.check_against_golden(g, out, ld, grads, logit_rtol=1e-3, logit_atol=1e-5, loss_tol=1e-4, grad_norm_rtol=1e-3)
     if eps is None:
         z = model(commands.to(DEV), args.to(DEV), None, None, encode_mode=True).cpu()
         assert torch.allclose(z, torch.from_numpy(g["z"]), rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["hier_ordered_n5", "fonts_label_n4"])
+def test_hierarch_path_matches_reference_golden(gpu_device, name):
+    """return_hierarch / hierarch_logits (deepsvg/model/model.py:246-261,379-383): first decoder stage alone against
+    the reference's outputs, then fed back into the second stage"""
+    g, cfg, commands, args, eps = H.golden_setup(name)
+    label = H.golden_label(g)
+    label = label.to(DEV) if label is not None else None
+    model = _hip_model(cfg, H.weights_for(deepsvg_amd.SVGTransformer(cfg), g["wseed"])).eval()
+    import deepsvg_amd.model as M
+    orig = torch.randn_like
+    if eps is not None:
+        M.torch.randn_like = lambda t: eps.reshape(t.shape).to(device=t.device, dtype=t.dtype)
+    try:
+        with torch.no_grad():
+            c, a = commands.to(DEV), args.to(DEV)
+            hl, zg = model(c, a, c, a, label=label, return_hierarch=True)
+            full = model(c, a, c, a, label=label)
+    finally:
+        M.torch.randn_like = orig
+    assert torch.allclose(hl.cpu(), torch.from_numpy(g["hier_logits"]), rtol=1e-3, atol=1e-5)
+    assert torch.allclose(zg.cpu(), torch.from_numpy(g["hier_z"]), rtol=1e-3, atol=1e-5)
+    with torch.no_grad():
+        again = model(None, None, None, None, label=label, z=zg.permute(2, 1, 0, 3).contiguous(), hierarch_logits=hl,
+                      return_tgt=False)
+    for k in ("command_logits", "args_logits", "visibility_logits"):
+        assert torch.allclose(again[k], full[k], rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_label_conditioned_training_step(gpu_device, dtype):
+    """fonts-style config (label_condition, dim_z=128) through TrainStep with dropout on: finite, and the label tables
+    and linear_global2 weights move"""
+    from deepsvg_amd.trainer import TrainStep
+    cfg = H.build_cfg("fonts")
+    model = _hip_model(cfg, H.weights_for(deepsvg_amd.SVGTransformer(cfg), 3), dtype).train()
+    commands, args = make_batch(16, seed=5)
+    label = torch.randint(0, cfg.n_labels, (16,), generator=torch.Generator().manual_seed(1)).to(DEV)
+    names = ["encoder.label_embedding.label_embedding.weight", "decoder.label_embedding.label_embedding.weight",
+             "encoder.encoder.layers.0.linear_global2.weight", "decoder.decoder.layers.3.linear_global2.weight"]
+    before = {n: p.detach().clone() for n, p in model.named_parameters() if n in names}
+    assert len(before) == len(names)
+    step = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=1e-3, use_graph=False)
+    commands, args = commands.to(DEV), args.to(DEV)
+    losses = [float(step.step(commands, args, label=label)["loss"]) for _ in range(3)]
+    assert all(l == l and abs(l) < 1e3 for l in losses), losses
+    after = dict(model.named_parameters())
+    for n in names:
+        assert not torch.equal(before[n], after[n].detach()), n
 
 
 def test_fp32_model_matches_oracle_on_fresh_batch(gpu_device):
