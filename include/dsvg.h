@@ -63,7 +63,8 @@ typedef struct dsvg_gemm_desc {
                                                    gradient GEMM (only with split_k > 1)         */
     int32_t impl;                               /* 0 = best MFMA kernel, 1 = one-thread-per-output,
                                                    2 = register-staged MFMA kernel only, 3 / 4 = LDS-DMA
-                                                   kernel with 2 / 1 LDS stages when eligible (test knobs) */
+                                                   kernel with 2 / 1 LDS stages when eligible, 5 = weight-
+                                                   stationary kernel when eligible (test knobs)     */
 } dsvg_gemm_desc;
 
 int dsvg_gemm(const dsvg_gemm_desc* d, void* stream);

@@ -160,6 +160,42 @@ def test_gemm_lds_dma_kernel_equals_register_staged_kernel(gpu_device, stages, M
         _close(new, R.gemm(a, b, out_dtype=torch.float32, **kw), _tol(dtype, K), f"glds {sorted(kw)}")
 
 
+@pytest.mark.parametrize("M,N,K", [(384, 512, 256), (1000, 264, 512), (4096, 768, 256), (33, 256, 256),
+                                   (20000, 256, 512), (9000, 128, 256), (5000, 1032, 256)])
+def test_gemm_weight_stationary_kernel_equals_register_staged_kernel(gpu_device, M, N, K):
+    """The weight-stationary bf16 kernel (impl 5: weight slice resident in LDS, token fragments straight from global
+    memory, register epilogue) must reproduce the register-staged kernel (impl 2) BIT FOR BIT on every epilogue it
+    implements (same k order, same epilogue order), for every slice count / ragged strip count."""
+    dtype = torch.bfloat16
+    a, w = _rand(M, K, dtype=dtype, seed=31), _rand(N, K, dtype=dtype, seed=32, scale=0.1)
+    wt = _rand(K, N, dtype=dtype, seed=33, scale=0.1)          # [k][n] weight view for the input-gradient layout
+    bias, res, gate = _rand(N, seed=34), _rand(M, N, dtype=dtype, seed=35), _rand(M, N, dtype=dtype, seed=36)
+    seed = _seed_tensor(0x0123456789ABCDEF)
+    cases = [(w, dict(bias=bias)), (w, dict()), (w, dict(bias=bias, res=res, drop_p=0.1, drop_site=5, seed=seed)),
+             (w, dict(bias=bias, res=res)), (w, dict(bias=bias, act=R.RELU, drop_p=0.2, drop_site=6, seed=seed)),
+             (wt, dict(b_kc=False)), (wt, dict(b_kc=False, gate=gate, gate_scale=1.0 / 0.9))]
+    for b, kw in cases:
+        new = ops.gemm(a, b, impl=5, **kw)
+        old = ops.gemm(a, b, impl=2, **kw)
+        assert torch.equal(new, old), f"weight-stationary kernel differs from the register-staged one: {sorted(kw)} {M}x{N}x{K}"
+        _close(new, R.gemm(a, b, out_dtype=torch.float32, **kw), _tol(dtype, K), f"ws {sorted(kw)}")
+
+
+def test_gemm_weight_stationary_ragged_head(gpu_device):
+    """N = 2827 (the argument head; not a multiple of 8) in a row-padded buffer, 12 weight slices of 256 columns"""
+    dtype = torch.bfloat16
+    T, N, K, ld = 3000, 2827, 256, 2832
+    x, w, bias = _rand(T, K, dtype=dtype, seed=81), _rand(N, K, dtype=dtype, seed=82, scale=0.1), _rand(N, seed=83)
+    outs = []
+    for impl in (5, 2):
+        buf = torch.full((T, ld), 7.0, device=DEV, dtype=dtype)
+        ops.gemm(x, w, bias=bias, out=buf[:, :N], impl=impl)
+        assert torch.all(buf[:, N:] == 7.0), "wrote into the row padding"
+        outs.append(buf[:, :N].clone())
+    assert torch.equal(outs[0], outs[1])
+    _close(outs[0], R.gemm(x, w, bias=bias, out_dtype=torch.float32), _tol(dtype, K), "ragged-N forward (ws)")
+
+
 @pytest.mark.parametrize("stages", [4, 3])
 def test_gemm_lds_dma_ragged_head_shapes(gpu_device, stages):
     """N = 523 (like the 2827-wide argument head: not a multiple of 8) in a row-padded buffer: forward through the
