@@ -77,6 +77,16 @@ class Hierarchical(_DefaultConfig):
         self.decode_stages = 2
 
 
+class HierarchicalSelfMatching(_DefaultConfig):
+    """Transformer - one-shot - two-stage - Hungarian assignment (deepsvg/model/config.py:101-108)"""
+
+    def __init__(self):
+        super().__init__()
+        self.encode_stages = 2
+        self.decode_stages = 2
+        self.self_match = True
+
+
 class HierarchicalOrdered(Hierarchical):
     """The model config of configs/deepsvg/hierarchical_ordered.py:4-9 (the north-star config)."""
 

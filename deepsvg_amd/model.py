@@ -355,8 +355,6 @@ class SVGTransformer(nn.Module):
             raise NotImplementedError("model_type='lstm' (SketchRNN baseline) is outside the MI355X hot path")
         if cfg.pred_mode != "one_shot":
             raise NotImplementedError("autoregressive decoding is not built yet (SURVEY.md §8(f)-3)")
-        if cfg.self_match:
-            raise NotImplementedError("Hungarian self-matching (HierarchicalSelfMatching) is not built yet")
         if cfg.d_model // cfg.n_heads != 32 or cfg.d_model % cfg.n_heads:
             raise NotImplementedError("the attention kernel is specialised for head_dim == 32")
         self.args_dim = 2 * cfg.args_dim if cfg.rel_targets else cfg.args_dim + 1
@@ -385,6 +383,7 @@ class SVGTransformer(nn.Module):
         # backward of the argument head only over the tokens that carry argument loss (exact under SVGLoss)
         self.compact_head_backward = os.environ.get("DSVG_COMPACT_HEAD", "1") != "0"
         self.last_head_rows = None
+        self.last_assignment = None  # self-matching configs: (N, Gp) int32 assignment of the last training forward
         self._forced_plan = None
         self._decoder_grads_ready = None    # callback of a data-parallel trainer (TrainStep), see forward()
         self._side_stream = None    # set by a trainer that calls join_side_stream() after backward (TrainStep)
@@ -484,7 +483,8 @@ class SVGTransformer(nn.Module):
                                tiles=tiles)
             counts.append(seq_off[-1:])
         if (commands_dec is not None and want_grad and self.skip_invisible_backward and cfg.decode_stages == 2
-                and commands_dec.shape[1] == cfg.num_groups_proposal and not cfg.label_condition):
+                and commands_dec.shape[1] == cfg.num_groups_proposal and not cfg.label_condition
+                and not cfg.self_match):        # (self-matching pairs predictions with targets only after the forward)
             N, G, St = commands_dec.shape
             cmd_t = commands_dec.to(torch.float32).contiguous().view(N * G, St)
             _km, vis, _gm = ops.build_masks(cmd_t, St, G, EOS_ID)
@@ -568,7 +568,9 @@ class SVGTransformer(nn.Module):
             mem = self._run_stack(rt, enc.encoder, src, key_mask, None, N * G, S, 100, l=l_seq)
             z = Fn.MaskedMeanFn.apply(rt, mem, key_mask, N * G, S)          # [N*G, d]
         if two:
-            src2 = Fn.AddPosFn.apply(rt, z, enc.hierarchical_PE.pos_embed.weight, N, G, PE_DROPOUT, 2)
+            # the self-matching variant has no group positional encoding (model.py:114-115,157-158)
+            src2 = z if cfg.self_match else \
+                Fn.AddPosFn.apply(rt, z, enc.hierarchical_PE.pos_embed.weight, N, G, PE_DROPOUT, 2)
             mem2 = self._run_stack(rt, enc.hierarchical_encoder, src2, group_mask, None, N, G, 200, l=l)
             z = Fn.MaskedMeanFn.apply(rt, mem2, group_mask, N, G)       # [N, d]
         return z
@@ -593,7 +595,8 @@ class SVGTransformer(nn.Module):
                                   0.0, 0, None)
         return z, mu, logsigma
 
-    def _decode(self, rt, z, plan=None, lazy_args=False, label=None, hierarch_logits=None, return_hierarch=False):
+    def _decode(self, rt, z, plan=None, lazy_args=False, label=None, hierarch_logits=None, return_hierarch=False,
+                match=None):
         """z [N, dim_z] -> command_logits (N,G,S,n_cmd), args_logits (N,G,S,n_args,args_dim)[, visibility (N,G,1,2)];
         with lazy_args the second result is a thunk that computes args_logits when called.
         hierarch_logits [N*G, 2] given: z is the per-group latent [N*G, dim_z] and the first decoder stage is skipped
@@ -641,6 +644,24 @@ class SVGTransformer(nn.Module):
         out = self._run_stack(rt, dec.decoder, src, None, z, n_seq, S, 400, live=live, l=l_seq)
         if live is not None:        # back to the caller's group order before the heads
             out = Fn.GatherGroupsFn.apply(out, pd["new_of_old"], pd["old_of_new"], n_seq, S, live)
+        if match is not None:
+            # Hungarian self-matching (model.py:384-395): cost of every (target group, predicted group) pair from the
+            # dense logits (no gradient), exact assignment, then output slot j takes predicted group assign[j].  The
+            # heads are per-token linears, so the rows of their INPUT are permuted instead of the three logit tensors.
+            tgt_c, tgt_a = match
+            fcn = dec.fcn
+            with torch.no_grad():
+                cl = Fn.LinearFn.apply(rt, out, fcn.command_fcn.weight, fcn.command_fcn.bias, 0, None, 0.0, 0, None)
+                al = Fn.LinearFn.apply(rt, out, fcn.args_fcn.weight, fcn.args_fcn.bias, 0, None, 0.0, 0, None)
+                cam = self.cmd_args_mask.to(device=out.device, dtype=torch.float32).contiguous()
+                cost, vis = ops.match_costs(cl, al, vis_logits.detach(),
+                                            tgt_c.to(torch.float32).contiguous(), tgt_a.to(torch.float32).contiguous(),
+                                            cam, N, tgt_c.shape[1], G, cfg.n_args, self.args_dim, cfg.n_commands, EOS_ID)
+                assign, idx, inv = ops.match_assign(cost, vis)
+                del cl, al
+            self.last_assignment = assign
+            out = Fn.GatherGroupsFn.apply(out, idx, inv, n_seq, S, None)
+            vis_logits = vis_logits.index_select(0, idx.long())         # (N*G, 2): a tiny gather, left to torch
         cmd_logits = Fn.LinearFn.apply(rt, out, dec.fcn.command_fcn.weight, dec.fcn.command_fcn.bias, 0, None, 0.0, 0,
                                        None)
         n_args, args_dim, fcn = cfg.n_args, self.args_dim, dec.fcn.args_fcn
@@ -699,8 +720,13 @@ class SVGTransformer(nn.Module):
             return (vis.to(torch.float32).view(N, G, 2).permute(1, 0, 2).unsqueeze(0),
                     zg.to(torch.float32).view(N, G, -1).permute(1, 0, 2).unsqueeze(0))
         lazy_args = bool(return_tgt and plan is not None and plan.get("loss") is not None)
+        match = None
+        if cfg.self_match and return_tgt and commands_dec is not None:      # train-mode call (model.py:384)
+            if cfg.decode_stages != 2:
+                raise ValueError("self-matching expects a two-stage decoder (model.py:385)")
+            match = (commands_dec, args_dec)
         cmd_logits, args_logits, vis_logits = self._decode(rt, zz, plan, lazy_args=lazy_args, label=label,
-                                                           hierarch_logits=hl)
+                                                           hierarch_logits=hl, match=match)
         res = ModelOutput({"command_logits": cmd_logits})
         if lazy_args:
             res.set_lazy("args_logits", args_logits)

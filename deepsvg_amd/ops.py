@@ -565,6 +565,45 @@ def scatter_rows(src, idx, dst):
 
 
 # ------------------------------------------------------------------------------------------------
+# Hungarian self-matching (model.py:311-350)
+# ------------------------------------------------------------------------------------------------
+def match_costs(cmd_logits, args_logits, vis_logits, tgt_commands, tgt_args, cam, N, G, Gp, n_args, args_dim, n_cmd,
+                eos_id, weights=(2.0, 1.0, 1.0)):
+    """cmd_logits [N*Gp*S, n_cmd] / args_logits [N*Gp*S, n_args*args_dim] / vis_logits [N*Gp, 2] (row-strided 2-D views),
+    tgt_commands [N, G, S+1] / tgt_args [N, G, S+1, n_args] float32  ->  cost f32 [N, G, Gp], visible int32 [N, G]"""
+    _chk(cmd_logits, args_logits, vis_logits, tgt_commands, tgt_args, cam)
+    assert cmd_logits.dtype == args_logits.dtype == vis_logits.dtype
+    for t in (cmd_logits, args_logits, vis_logits):
+        assert t.dim() == 2 and t.stride(1) == 1
+    assert tgt_commands.dtype == torch.float32 and tgt_args.dtype == torch.float32 and cam.dtype == torch.float32
+    assert tgt_commands.is_contiguous() and tgt_args.is_contiguous() and cam.is_contiguous()
+    S1 = tgt_commands.shape[-1]
+    assert cmd_logits.shape[0] == N * Gp * (S1 - 1) and vis_logits.shape[0] == N * Gp
+    cost = torch.empty(N, G, Gp, dtype=torch.float32, device=cmd_logits.device)
+    vis = torch.empty(N, G, dtype=torch.int32, device=cmd_logits.device)
+    _l.check(_l.load().dsvg_match_costs(_dt(cmd_logits), cmd_logits.data_ptr(), cmd_logits.stride(0),
+                                        args_logits.data_ptr(), args_logits.stride(0), vis_logits.data_ptr(),
+                                        vis_logits.stride(0), tgt_commands.data_ptr(), tgt_args.data_ptr(),
+                                        cam.data_ptr(), N, G, Gp, S1, n_args, args_dim, n_cmd, eos_id,
+                                        float(weights[0]), float(weights[1]), float(weights[2]), cost.data_ptr(),
+                                        vis.data_ptr(), _stream()), "dsvg_match_costs")
+    return cost, vis
+
+
+def match_assign(cost, vis):
+    """cost f32 [N, G, Gp], visible int32 [N, G] -> assign [N, Gp], idx [N*Gp], inv [N*Gp] (all int32)"""
+    _chk(cost, vis)
+    assert cost.dtype == torch.float32 and cost.is_contiguous() and vis.dtype == torch.int32 and vis.is_contiguous()
+    N, G, Gp = cost.shape
+    assign = torch.empty(N, Gp, dtype=torch.int32, device=cost.device)
+    idx = torch.empty(N * Gp, dtype=torch.int32, device=cost.device)
+    inv = torch.empty(N * Gp, dtype=torch.int32, device=cost.device)
+    _l.check(_l.load().dsvg_match_assign(cost.data_ptr(), vis.data_ptr(), N, G, Gp, assign.data_ptr(), idx.data_ptr(),
+                                         inv.data_ptr(), _stream()), "dsvg_match_assign")
+    return assign, idx, inv
+
+
+# ------------------------------------------------------------------------------------------------
 # device-side batch assembly (svgtensor_dataset.py:164-205)
 # ------------------------------------------------------------------------------------------------
 def assemble_batch(rows, slot_off, variant, G, L, grouped, want_args=True, want_rel=False, pad_val=-1.0,

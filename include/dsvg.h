@@ -269,6 +269,28 @@ int dsvg_drop_apply(int32_t dtype, const void* x, void* y, int64_t n, float drop
 /* out[i] = a[i] + b[i] — the residual add of the latent ResNet (basic_blocks.py:59-65) */
 int dsvg_add(int32_t dtype, const void* a, const void* b, void* out, int64_t n, void* stream);
 /* ------------------------------------------------------------------------------------------
+ * Hungarian self-matching (HierarchicalSelfMatching, deepsvg/model/config.py:101-108):
+ * SVGTransformer.perfect_matching, deepsvg/model/model.py:311-350.
+ *  match_costs: cost[n, g, p] = w_args * mean_{masked (s,a)} CE(args_logits[n,p,s,a,:], tgt_args[n,g,s+1,a] + 1)
+ *                             + w_cmd  * mean_{extended valid s} CE(command_logits[n,p,s,:], tgt_commands[n,g,s+1])
+ *                             + w_vis  * CE(visibility_logits[n,p,:], visible[n,g])            (:329-339; 2, 1, 1)
+ *    logits: rows (n*Gp + p)*S + s (S = S1 - 1) with row strides ld_* (elements); targets are the float32
+ *    tgt_commands [N,G,S1] / tgt_args [N,G,S1,n_args] including their SOS column; the masks are taken on the
+ *    sequence without it, as the reference does (:388, :314-315); visible[n,g] is returned for match_assign.
+ *    Groups without argument slots get 0/0 like the reference; they are invisible and never assigned.
+ *  match_assign: scipy.optimize.linear_sum_assignment(cost[n][visible rows]) (:344) as an exhaustive search
+ *    (G, Gp <= 8): assign[n, j] = prediction matched to the j-th visible target, then the unmatched predictions in
+ *    ascending order (:345-347); idx[n*Gp + j] = n*Gp + assign[n, j] and its inverse `inv` are the whole-sequence
+ *    gather lists for dsvg_gather_groups (:390-393). */
+int dsvg_match_costs(int32_t dtype, const void* cmd_logits, int64_t ld_c, const void* args_logits, int64_t ld_a,
+                     const void* vis_logits, int64_t ld_v, const float* tgt_commands, const float* tgt_args,
+                     const float* cmd_args_mask, int64_t N, int32_t G, int32_t Gp, int32_t S1, int32_t n_args,
+                     int32_t args_dim, int32_t n_cmd, int32_t eos_id, float w_args, float w_cmd, float w_vis,
+                     float* cost, int32_t* visible, void* stream);
+int dsvg_match_assign(const float* cost, const int32_t* visible, int64_t N, int32_t G, int32_t Gp,
+                      int32_t* assign, int32_t* idx, int32_t* inv, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Device-side batch assembly.  Replaces, for a whole batch, the per-item chain of
  * SVGTensorDataset.get_data (deepsvg/svgtensor_dataset.py:164-205): SVGTensor.from_data(...).add_eos().add_sos()
  * .pad(seq_len) (deepsvg/difflib/tensor.py:85-88,108-116,125-143), .cmds()/.args()/.get_relative_args()

@@ -197,7 +197,8 @@ def encode(sd, cfg, commands, args, label=None):
     z = unpack(N, z)
     if two:
         src = pack(z.transpose(0, 1))                                                       # :153-154
-        src = src + sd["encoder.hierarchical_PE.pos_embed.weight"][:src.size(0)].unsqueeze(1)
+        if not cfg.self_match:                                                              # :157-158
+            src = src + sd["encoder.hierarchical_PE.pos_embed.weight"][:src.size(0)].unsqueeze(1)
         l = label_embedding(sd, "encoder.", label).unsqueeze(0) if cfg.label_condition else None   # :155
         memory = encoder_stack(sd, "encoder.hierarchical_encoder.", src, cfg.n_layers, cfg.n_heads, key_vis_mask, l)
         vm = vis_mask.to(memory.dtype)
@@ -245,6 +246,44 @@ def decode(sd, cfg, z, label=None, hierarch_logits=None, return_hierarch=False):
     return tuple(unpack(N, o) for o in outs)
 
 
+def perfect_matching(cfg, command_logits, args_logits, hierarch_logits, tgt_commands, tgt_args):
+    """SVGTransformer.perfect_matching model.py:311-350 (Hungarian assignment of predicted groups to target groups).
+    Batch-first logits (N, Gp, S, .), targets WITHOUT the SOS column (N, G, S[, n_args]).  Returns (N, Gp) int64:
+    output slot j takes predicted group assignment[n, j].  The cost of pairing target g with prediction p is
+    2 * mean arg CE + mean command CE + visibility CE, each against prediction p's logits (:333-338)."""
+    from scipy.optimize import linear_sum_assignment
+    with torch.no_grad():
+        N, G, S, n_args = tgt_args.shape
+        Gp = cfg.num_groups_proposal
+        args_dim = 2 * cfg.args_dim if cfg.rel_targets else cfg.args_dim + 1
+        vis = visibility_mask(tgt_commands, seq_dim=-1)                                     # :314 (N, G)
+        pm = padding_mask(tgt_commands, seq_dim=-1, extended=True) * vis.unsqueeze(-1)      # :315 (N, G, S)
+        mask = CMD_ARGS_MASK.to(tgt_commands.device)[tgt_commands.long()].to(args_logits.dtype)   # (N, G, S, n_args)
+        lp_args = F.log_softmax(args_logits, dim=-1)                                        # (N, Gp, S, n_args, C)
+        lp_cmd = F.log_softmax(command_logits, dim=-1)                                      # (N, Gp, S, n_cmd)
+        lp_vis = F.log_softmax(hierarch_logits.squeeze(-2), dim=-1)                         # (N, Gp, 2)
+        ta = (tgt_args.long() + 1).clamp(0, args_dim - 1)
+        # CE of target g under prediction p, for every (g, p) pair
+        idx_a = ta.unsqueeze(2).expand(N, G, Gp, S, n_args).unsqueeze(-1)
+        ce_a = -lp_args.unsqueeze(1).expand(N, G, Gp, S, n_args, args_dim).gather(-1, idx_a).squeeze(-1)
+        idx_c = tgt_commands.long().unsqueeze(2).expand(N, G, Gp, S).unsqueeze(-1)
+        ce_c = -lp_cmd.unsqueeze(1).expand(N, G, Gp, S, cfg.n_commands).gather(-1, idx_c).squeeze(-1)
+        idx_v = vis.long().unsqueeze(2).expand(N, G, Gp).unsqueeze(-1)
+        ce_v = -lp_vis.unsqueeze(1).expand(N, G, Gp, 2).gather(-1, idx_v).squeeze(-1)
+        m5 = mask.unsqueeze(2)
+        loss_args = (ce_a * m5).sum(dim=[-1, -2]) / m5.sum(dim=[-1, -2])                   # :336 (0/0 on empty groups)
+        p4 = pm.unsqueeze(2)
+        loss_cmd = (ce_c * p4).sum(dim=-1) / p4.sum(dim=-1)                                 # :337
+        loss = 2.0 * loss_args + 1.0 * loss_cmd + 1.0 * ce_v                                # :339
+    out = []
+    full = set(range(Gp))
+    for i in range(N):                                                                      # :342-348
+        _, assign = linear_sum_assignment(loss[i][vis[i]].cpu())
+        assign = assign.tolist()
+        out.append(assign + list(full - set(assign)))
+    return torch.tensor(out, device=command_logits.device), loss
+
+
 def forward(sd, cfg, commands_enc, args_enc, commands_dec, args_dec, z=None, eps=None, encode_mode=False, label=None,
             hierarch_logits=None, return_hierarch=False):
     """SVGTransformer.forward model.py:352-412, eval semantics (dropout = identity).
@@ -271,7 +310,16 @@ def forward(sd, cfg, commands_enc, args_enc, commands_dec, args_dec, z=None, eps
     if return_hierarch:
         return outs                                                                         # :382-383, seq-first
     outs = tuple(seq_first(o) for o in outs)                                                # _make_batch_first
+    assignment = None
+    if cfg.self_match and commands_dec is not None:                                         # :384-395 (train mode)
+        cl, al, hl = outs
+        assignment, _ = perfect_matching(cfg, cl, al, hl, commands_dec[..., 1:], args_dec[..., 1:, :])
+        ix = assignment.unsqueeze(-1).unsqueeze(-1)
+        outs = (torch.gather(cl, 1, ix.expand_as(cl)), torch.gather(al, 1, ix.unsqueeze(-1).expand_as(al)),
+                torch.gather(hl, 1, ix.expand_as(hl)))
     res = {"command_logits": outs[0], "args_logits": outs[1]}
+    if assignment is not None:
+        res["_assignment"] = assignment
     if cfg.decode_stages == 2:
         res["visibility_logits"] = outs[2]
     res["tgt_commands"], res["tgt_args"] = commands_dec, args_dec

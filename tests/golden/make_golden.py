@@ -58,6 +58,9 @@ def build_cfg(kind):
         cfg = ref_cfg.OneStageOneShot()
         cfg.max_total_len = 50
         cfg.use_vae = False
+    elif kind == "selfmatch":       # deepsvg/model/config.py:101-108
+        cfg = ref_cfg.HierarchicalSelfMatching()
+        cfg.use_vae = False
     elif kind == "fonts":           # ModelConfig of configs/deepsvg/hierarchical_ordered_fonts.py:4-9
         cfg = ref_cfg.Hierarchical()
         cfg.label_condition = True
@@ -85,6 +88,18 @@ def run_case(name, kind, n, seed, wseed):
         g = torch.Generator().manual_seed(seed + 77)
         eps = torch.randn(1, 1, n, cfg.dim_z, generator=g)
         ref_model_mod.torch.randn_like = lambda t: eps.to(t.dtype)      # model.py:185
+    captured = {}
+    if cfg.self_match:
+        # perfect_matching builds its command mask with the aliasing in-place add too (model.py:315 -> utils.py:28):
+        # canonical semantics for the whole case; the assignment it returns is recorded
+        ref_model_mod._get_padding_mask = _canonical_padding_mask
+        orig_pm = model.perfect_matching
+
+        def _pm(*a, **k):
+            r = orig_pm(*a, **k)
+            captured["assignment"] = r.squeeze(-1).squeeze(-1).clone()
+            return r
+        model.perfect_matching = _pm
     try:
         # ---- eval forward: logits ----
         model.eval()
@@ -98,9 +113,10 @@ def run_case(name, kind, n, seed, wseed):
                 z_groups = hier[1].permute(2, 1, 0, 3).contiguous()     # batch-first for `z=` (model.py:369)
                 out2 = model(None, None, commands, args, label=label, z=z_groups, hierarch_logits=hier[0],
                              return_tgt=False)       # (with a VAE, return_tgt=True needs mu: model.py:408-410)
-                for k in out:
+                plain = model(commands, args, commands, args, label=label, return_tgt=False) if cfg.self_match else out
+                for k in plain:
                     if k.endswith("logits"):
-                        assert torch.allclose(out[k], out2[k], atol=1e-6), k
+                        assert torch.allclose(plain[k], out2[k], atol=1e-6), k
         # ---- train mode, every dropout p = 0: loss + grads ----
         model.train()
         for m in model.modules():
@@ -123,6 +139,9 @@ def run_case(name, kind, n, seed, wseed):
     finally:
         if cfg.use_vae:
             ref_model_mod.torch.randn_like = torch.randn_like
+        if cfg.self_match:
+            from deepsvg.model import utils as _ref_utils
+            ref_model_mod._get_padding_mask = _ref_utils._get_padding_mask
 
     # ---- the oracle restatement must agree with the live reference ----
     o_out = O.forward(sd, cfg, commands, args, commands, args, eps=eps, label=label)
@@ -131,7 +150,8 @@ def run_case(name, kind, n, seed, wseed):
         assert (o_hier[0] - hier[0]).abs().max().item() < 2e-5 and (o_hier[1] - hier[1]).abs().max().item() < 2e-5
         o_out2 = O.forward(sd, cfg, None, None, commands, args, z=o_hier[1].permute(2, 1, 0, 3), label=label,
                            hierarch_logits=o_hier[0])
-        assert (o_out2["args_logits"] - out["args_logits"]).abs().max().item() < 2e-5
+        if not cfg.self_match:
+            assert (o_out2["args_logits"] - out["args_logits"]).abs().max().item() < 2e-5
     for k in ("command_logits", "args_logits", "visibility_logits"):
         if k in out:
             err = (o_out[k] - out[k]).abs().max().item()
@@ -164,6 +184,9 @@ def run_case(name, kind, n, seed, wseed):
         rec["eps"] = eps.numpy()
     if label is not None:
         rec["label"] = label.numpy()
+    if "assignment" in captured:
+        rec["assignment"] = captured["assignment"].numpy().astype(np.int64)     # (N, Gp), of the last (train) pass
+        assert torch.equal(o_out["_assignment"], captured["assignment"])
     if hier is not None:
         rec["hier_logits"] = hier[0].numpy()        # seq-first (1, G, N, 2)
         rec["hier_z"] = hier[1].numpy()             # seq-first (1, G, N, dim_z)
@@ -186,8 +209,16 @@ def run_case(name, kind, n, seed, wseed):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:           # regenerate selected cases only: make_golden.py <name> ...
+        ALL = {"hier_ordered_n2": ("hier", 2, 11, 1234), "hier_ordered_n5": ("hier", 5, 12, 4321),
+               "hier_vae_n3": ("hier_vae", 3, 13, 1234), "onestage50_n3": ("onestage", 3, 14, 1234),
+               "fonts_label_n4": ("fonts", 4, 15, 1234), "selfmatch_n6": ("selfmatch", 6, 16, 1234)}
+        for nm in sys.argv[1:]:
+            run_case(nm, *ALL[nm])
+        sys.exit(0)
     run_case("hier_ordered_n2", "hier", 2, 11, 1234)          # BASELINE config C1 shape
     run_case("hier_ordered_n5", "hier", 5, 12, 4321)
     run_case("hier_vae_n3", "hier_vae", 3, 13, 1234)
     run_case("onestage50_n3", "onestage", 3, 14, 1234)
     run_case("fonts_label_n4", "fonts", 4, 15, 1234)
+    run_case("selfmatch_n6", "selfmatch", 6, 16, 1234)

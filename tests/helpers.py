@@ -55,6 +55,9 @@ def build_cfg(kind):
         cfg = C.OneStageOneShot()
         cfg.max_total_len = 50
         cfg.use_vae = False
+    elif kind == "selfmatch":       # deepsvg/model/config.py:101-108
+        cfg = C.HierarchicalSelfMatching()
+        cfg.use_vae = False
     elif kind == "fonts":           # ModelConfig of configs/deepsvg/hierarchical_ordered_fonts.py:4-9
         cfg = C.Hierarchical()
         cfg.label_condition = True

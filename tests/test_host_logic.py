@@ -44,6 +44,8 @@ def test_model_matches_golden_with_emulated_ops(name, emulated_ops):
     model, out, ld, grads = _run_model(cfg, sd, commands, args, eps, label=label)
     H.check_against_golden(g, out, {k: v.item() for k, v in ld.items()}, grads, logit_rtol=1e-4, logit_atol=1e-5,
                            loss_tol=1e-5, grad_norm_rtol=2e-4)
+    if "assignment" in g:       # Hungarian self-matching: the assignment the reference's perfect_matching returned
+        assert torch.equal(model.last_assignment.long(), torch.from_numpy(g["assignment"]))
     z = model(commands, args, commands, args, label=label, encode_mode=True) if eps is None else None
     if z is not None:
         assert z.shape == tuple(g["z"].shape)

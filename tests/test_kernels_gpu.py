@@ -615,3 +615,44 @@ def test_cast_gate_add(gpu_device):
         a, b = _rand(1000, 16, dtype=dtype, seed=2), _rand(1000, 16, dtype=dtype, seed=3)
         _close(ops.gate_mul(a, b, 1.5), R.gate_mul(a, b, 1.5), 1e-6 if dtype == torch.float32 else 8e-3, "gate_mul")
         _close(ops.add(a, b), R.add(a, b), 1e-6 if dtype == torch.float32 else 8e-3, "add")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Hungarian self-matching (deepsvg/model/model.py:311-350)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_match_costs_and_assignment(gpu_device, dtype):
+    from deepsvg_amd.synthetic import make_batch
+    from deepsvg_amd.svgtensor import CMD_ARGS_MASK
+    N, G, S, A, C, n_cmd = 24, 8, 30, 11, 257, 7
+    commands, args = make_batch(N, G=G, S=S, seed=77)                    # (N, G, S+2)
+    commands[0, :, 1:] = 4                                               # an icon without any visible group
+    commands[1, 3, 1:] = 4                                               # an invisible group between visible ones
+    S1 = S + 2
+    Sd = S1 - 1
+    gen = torch.Generator().manual_seed(5)
+    ld_a = (A * C + 7) // 8 * 8
+    abuf = torch.randn(N * G * Sd, ld_a, generator=gen) * 2
+    cbuf = torch.randn(N * G * Sd, 8, generator=gen)
+    vbuf = torch.randn(N * G, 8, generator=gen)
+    al, cl, vl = (t.to(dtype) for t in (abuf, cbuf, vbuf))
+    cam = CMD_ARGS_MASK.float()
+    want_cost, want_vis = R.match_costs(cl[:, :n_cmd].float(), al[:, :A * C].float(), vl[:, :2].float(), commands, args,
+                                        cam, N, G, G, A, C, n_cmd, 4)
+    cost, vis = ops.match_costs(cl.to(DEV)[:, :n_cmd], al.to(DEV)[:, :A * C], vl.to(DEV)[:, :2], commands.to(DEV),
+                                args.to(DEV), cam.to(DEV), N, G, G, A, C, n_cmd, 4)
+    assert torch.equal(vis.cpu(), want_vis)
+    m = want_vis.bool()
+    _close(cost.cpu()[m], want_cost[m], 2e-4 if dtype == torch.float32 else 2e-3, "match costs (visible rows)")
+    assign, idx, inv = ops.match_assign(cost, vis)
+    ref_assign, ref_idx, ref_inv = R.match_assign(cost.cpu(), vis.cpu())
+    assert torch.equal(assign.cpu(), ref_assign), "exhaustive search differs from scipy's Hungarian solver"
+    assert torch.equal(idx.cpu(), ref_idx) and torch.equal(inv.cpu(), ref_inv)
+    assert assign[0].tolist() == list(range(G))                          # nothing visible: identity
+    # random cost matrices, every visibility pattern
+    gen = torch.Generator().manual_seed(6)
+    cost2 = torch.rand(256, G, G, generator=gen)
+    vis2 = (torch.arange(256).unsqueeze(1) >> torch.arange(G).unsqueeze(0)) & 1
+    a2, i2, v2 = ops.match_assign(cost2.to(DEV), vis2.to(torch.int32).to(DEV))
+    r2, ri2, rv2 = R.match_assign(cost2, vis2.to(torch.int32))
+    assert torch.equal(a2.cpu(), r2) and torch.equal(i2.cpu(), ri2) and torch.equal(v2.cpu(), rv2)

@@ -54,6 +54,8 @@ def test_fp32_model_matches_reference_golden(gpu_device, name, packed):
     label = H.golden_label(g)
     out, ld, grads = _fwd_bwd(model, cfg, commands, args, eps, label)
     H.check_against_golden(g, out, ld, grads, logit_rtol=1e-3, logit_atol=1e-5, loss_tol=1e-4, grad_norm_rtol=1e-3)
+    if "assignment" in g:       # Hungarian self-matching: the assignment the reference's perfect_matching returned
+        assert torch.equal(model.last_assignment.long().cpu(), torch.from_numpy(g["assignment"]))
     if eps is None:
         z = model(commands.to(DEV), args.to(DEV), None, None, encode_mode=True).cpu()
         assert torch.allclose(z, torch.from_numpy(g["z"]), rtol=1e-3, atol=1e-5)
@@ -293,3 +295,20 @@ def test_greedy_sample_and_encode_decode(gpu_device):
     assert z.shape == (1, 1, 4, 256)
     cy, ay = model.greedy_sample(z=z.permute(2, 1, 0, 3).contiguous(), concat_groups=False)
     assert cy.shape == (4, 8, 31) and ay.shape == (4, 8, 31, 11)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_self_matching_training_step(gpu_device, use_graph):
+    """HierarchicalSelfMatching through TrainStep (costs + exhaustive assignment + row permutation have no host round
+    trip, so the step is capturable): finite losses, and the assignment is a permutation per icon"""
+    from deepsvg_amd.trainer import TrainStep
+    cfg = H.build_cfg("selfmatch")
+    model = _hip_model(cfg, H.weights_for(deepsvg_amd.SVGTransformer(cfg), 3), torch.bfloat16).train()
+    commands, args = make_batch(32, seed=9)
+    step = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=1e-3, use_graph=use_graph)
+    commands, args = commands.to(DEV), args.to(DEV)
+    losses = [float(step.step(commands, args)["loss"]) for _ in range(3)]
+    assert all(l == l and abs(l) < 1e3 for l in losses), losses
+    a = model.last_assignment.cpu()
+    assert a.shape == (32, cfg.num_groups_proposal)
+    assert torch.equal(a.sort(dim=1).values, torch.arange(cfg.num_groups_proposal, dtype=a.dtype).expand_as(a))

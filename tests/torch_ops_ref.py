@@ -478,6 +478,52 @@ def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1
     return buf[:, :width]
 
 
+def match_costs(cmd_logits, args_logits, vis_logits, tgt_commands, tgt_args, cam, N, G, Gp, n_args, args_dim, n_cmd,
+                eos_id, weights=(2.0, 1.0, 1.0)):
+    """plain-torch restatement of dsvg_match_costs (deepsvg/model/model.py:311-339), written per (g, p) pair"""
+    S1 = tgt_commands.shape[-1]
+    S = S1 - 1
+    cl = cmd_logits[:, :n_cmd].float().reshape(N, Gp, S, n_cmd)
+    al = args_logits[:, :n_args * args_dim].float().reshape(N, Gp, S, n_args, args_dim)
+    vl = vis_logits[:, :2].float().reshape(N, Gp, 2)
+    tc = tgt_commands[..., 1:].long()                            # (N, G, S)  the sequence without SOS
+    ta = (tgt_args[..., 1:, :].long() + 1).clamp(0, args_dim - 1)
+    is_eos = tc == eos_id
+    vis = is_eos.sum(-1) < S - 1                                 # (N, G)
+    pm = (is_eos.cumsum(-1) == 0).float()
+    ext = pm.clone()
+    ext[..., 3:] = (pm[..., 3:] + pm[..., :-3]).clamp(max=1)
+    ext = ext * vis.unsqueeze(-1).float()
+    mask = cam[tc.clamp(0, n_cmd - 1)]                           # (N, G, S, n_args)
+    lpa, lpc, lpv = al.log_softmax(-1), cl.log_softmax(-1), vl.log_softmax(-1)
+    cost = torch.empty(N, G, Gp)
+    for g in range(G):
+        for p in range(Gp):
+            ce_a = -lpa[:, p].gather(-1, ta[:, g].unsqueeze(-1)).squeeze(-1)           # (N, S, n_args)
+            ce_c = -lpc[:, p].gather(-1, tc[:, g].clamp(0, n_cmd - 1).unsqueeze(-1)).squeeze(-1)
+            ce_v = -lpv[:, p].gather(-1, vis[:, g].long().unsqueeze(-1)).squeeze(-1)
+            la = (ce_a * mask[:, g]).sum((-1, -2)) / mask[:, g].sum((-1, -2))
+            lc = (ce_c * ext[:, g]).sum(-1) / ext[:, g].sum(-1)
+            cost[:, g, p] = weights[0] * la + weights[1] * lc + weights[2] * ce_v
+    return cost, vis.to(torch.int32)
+
+
+def match_assign(cost, vis):
+    """scipy's Hungarian solver, as the reference (deepsvg/model/model.py:341-348)"""
+    from scipy.optimize import linear_sum_assignment
+    N, G, Gp = cost.shape
+    assign = torch.empty(N, Gp, dtype=torch.int32)
+    for n in range(N):
+        rows = vis[n].bool()
+        a = linear_sum_assignment(cost[n][rows].double().numpy())[1].tolist() if bool(rows.any()) else []
+        assign[n] = torch.tensor(a + sorted(set(range(Gp)) - set(a)), dtype=torch.int32)
+    base = (torch.arange(N, dtype=torch.int32) * Gp).unsqueeze(1)
+    idx = (base + assign).reshape(-1)
+    inv = torch.empty_like(idx)
+    inv[idx.long()] = torch.arange(N * Gp, dtype=torch.int32)
+    return assign, idx, inv
+
+
 def sumsq(x, out=None):
     s = (x.double() ** 2).sum().to(torch.float32).reshape(1)
     if out is not None:
