@@ -59,6 +59,15 @@ class _DefaultConfig:
         return model_args
 
 
+class Sketchformer(_DefaultConfig):
+    """Transformer - autoregressive - one-stage, relative targets (deepsvg/model/config.py:74-80)"""
+
+    def __init__(self):
+        super().__init__()
+        self.pred_mode = "autoregressive"
+        self.rel_targets = True
+
+
 class OneStageOneShot(_DefaultConfig):
     """Transformer - one-shot - one-stage (deepsvg/model/config.py:83-89)"""
 

@@ -71,7 +71,7 @@ template <typename T, int SP, int HG>
 __global__ __launch_bounds__(HG * SP) void attn_fwd_kernel(
     const T* __restrict__ qkv, const uint64_t* __restrict__ key_mask, const int32_t* __restrict__ seq_off,
     long long total_rows, T* __restrict__ out, int Smax, int H, float scale, float drop_p, uint32_t drop_site,
-    const uint64_t* seed) {
+    const uint64_t* seed, int causal) {
     typedef AttnCfg<T, SP, HG> C;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* tile = reinterpret_cast<T*>(smem_raw);
@@ -98,7 +98,10 @@ __global__ __launch_bounds__(HG * SP) void attn_fwd_kernel(
     tile_copy_in<T, C::NT>(tile + 2 * C::W, C::LD, src + 2 * d, 3LL * d, S, C::W);       // v slab
     __syncthreads();
 
-    const uint64_t km = key_mask ? key_mask[b] : ~0ull;
+    // causal (autoregressive decoder, square_subsequent_mask of deepsvg/model/model.py:219-222,270): query row i sees
+    // the keys j <= i - folded into the lane's private key mask
+    const uint64_t km_all = key_mask ? key_mask[b] : ~0ull;
+    const uint64_t km = causal ? (km_all & (i >= 63 ? ~0ull : ((2ull << i) - 1ull))) : km_all;
     const DropCtx dc = drop_make(drop_p, seed, drop_site);
     const bool active = i < S;
     float o[32];
@@ -154,7 +157,7 @@ template <typename T, int SP, int HG>
 __global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
     const T* __restrict__ qkv, const uint64_t* __restrict__ key_mask, const int32_t* __restrict__ seq_off,
     long long total_rows, const T* __restrict__ dout, T* __restrict__ dqkv, int Smax, int H, float scale, float drop_p,
-    uint32_t drop_site, const uint64_t* seed) {
+    uint32_t drop_site, const uint64_t* seed, int causal) {
     typedef AttnCfg<T, SP, HG> C;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* tile = reinterpret_cast<T*>(smem_raw);                         // [Smax][LD]   q|k|v
@@ -188,7 +191,10 @@ __global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
     tile_copy_in<T, C::NT>(dtile, C::LDO, dout + (size_t)row0 * d + (size_t)hg * C::W, (long long)d, S, C::W);
     __syncthreads();
 
-    const uint64_t km = key_mask ? key_mask[b] : ~0ull;
+    const uint64_t km_all = key_mask ? key_mask[b] : ~0ull;
+    // pass 1 (lane = query row i): causal folds "keys j <= i" into the lane's key mask; pass 2 (lane = key row j = i)
+    // then only visits the query rows r >= j
+    const uint64_t km = causal ? (km_all & (i >= 63 ? ~0ull : ((2ull << i) - 1ull))) : km_all;
     const DropCtx dc = drop_make(drop_p, seed, drop_site);
     const bool active = i < S;
     const uint64_t hbase = ((uint64_t)b * H + h) * Smax;   // element id of (i, j) = (hbase + i) * Smax + j
@@ -264,12 +270,12 @@ __global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
     for (int c = 0; c < 32; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
     if (active) {
         const int j = i;
-        const bool kvalid = (km >> j) & 1ull;
+        const bool kvalid = (km_all >> j) & 1ull;
         float kr[32], vr[32];
         row32_load(tile + j * C::LD + C::W + hh * 32, kr);
         row32_load(tile + j * C::LD + 2 * C::W + hh * 32, vr);
         if (kvalid) {
-            for (int r = 0; r < S; ++r) {
+            for (int r = causal ? j : 0; r < S; ++r) {
                 float q[32], go[32];
                 row32_load(tile + r * C::LD + hh * 32, q);
                 row32_load(dtile + r * C::LDO + hh * 32, go);
@@ -303,28 +309,29 @@ __global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
 template <typename T, int SP, int HG>
 static int launch_fwd(const void* qkv, const uint64_t* km, const int32_t* seq_off, int64_t total_rows, void* out,
                       int64_t n_seq, int S, int H, float scale, float drop_p, uint32_t site, const uint64_t* seed,
-                      hipStream_t st) {
+                      int causal, hipStream_t st) {
     typedef AttnCfg<T, SP, HG> C;
     const size_t lds = (size_t)S * C::LD * sizeof(T);
     if (lds > 160 * 1024) { dsvg_set_error("attention_fwd: LDS image too large (%zu B)", lds); return -1; }
     auto kern = attn_fwd_kernel<T, SP, HG>;
     DSVG_ENSURE_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (total_rows > 0 ? 1u : 0u), H / HG), dim3(C::NT), lds, st, (const T*)qkv,
-                       km, seq_off, (long long)total_rows, (T*)out, S, H, scale, drop_p, site, seed);
+                       km, seq_off, (long long)total_rows, (T*)out, S, H, scale, drop_p, site, seed, causal);
     DSVG_LAUNCH_CHECK("attention_fwd");
     return 0;
 }
 template <typename T, int SP, int HG>
 static int launch_bwd(const void* qkv, const uint64_t* km, const int32_t* seq_off, int64_t total_rows, const void* dout,
                       void* dqkv, int64_t n_seq, int S, int H, float scale, float drop_p, uint32_t site,
-                      const uint64_t* seed, hipStream_t st) {
+                      const uint64_t* seed, int causal, hipStream_t st) {
     typedef AttnCfg<T, SP, HG> C;
     const size_t lds = (size_t)S * (C::LD + C::LDO) * sizeof(T) + (size_t)HG * SP * 2 * sizeof(float);
     if (lds > 160 * 1024) { dsvg_set_error("attention_bwd: LDS image too large (%zu B)", lds); return -1; }
     auto kern = attn_bwd_kernel<T, SP, HG>;
     DSVG_ENSURE_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (total_rows > 0 ? 1u : 0u), H / HG), dim3(C::NT), lds, st, (const T*)qkv,
-                       km, seq_off, (long long)total_rows, (const T*)dout, (T*)dqkv, S, H, scale, drop_p, site, seed);
+                       km, seq_off, (long long)total_rows, (const T*)dout, (T*)dqkv, S, H, scale, drop_p, site, seed,
+                       causal);
     DSVG_LAUNCH_CHECK("attention_bwd");
     return 0;
 }
@@ -430,12 +437,32 @@ extern "C" int dsvg_attention_fwd(int32_t dtype, const void* qkv, const uint64_t
                                        n_heads, scale, drop_p, drop_site, seed, st);
     if (dtype == DSVG_F32) {
         DSVG_ATTN_DISPATCH(launch_fwd, float, qkv, key_mask, seq_off, total_rows, out, n_seq, S, n_heads, scale, drop_p,
-                           drop_site, seed, st);
+                           drop_site, seed, 0, st);
     } else if (dtype == DSVG_BF16) {
         DSVG_ATTN_DISPATCH(launch_fwd, bf16_t, qkv, key_mask, seq_off, total_rows, out, n_seq, S, n_heads, scale, drop_p,
-                           drop_site, seed, st);
+                           drop_site, seed, 0, st);
     }
     dsvg_set_error("attention_fwd: unsupported dtype/shape (dtype=%d S=%d H=%d)", dtype, S, n_heads);
+    return -1;
+}
+
+// causal self-attention of the autoregressive decoder (dense layout; lane-per-query kernels for every dtype / length)
+extern "C" int dsvg_attention_causal_fwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, void* out,
+                                         int64_t n_seq, int32_t S, int32_t n_heads, float scale, float drop_p,
+                                         uint32_t drop_site, const uint64_t* seed, void* stream) {
+    DSVG_CHECK_ARG(qkv && out && n_seq > 0 && S > 0 && S <= 64 && n_heads > 0, "attention_causal_fwd: bad args (S=%d)", S);
+    DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_causal_fwd: dropout needs a seed pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t* seq_off = nullptr;
+    const int64_t total_rows = 0;
+    if (dtype == DSVG_F32) {
+        DSVG_ATTN_DISPATCH(launch_fwd, float, qkv, key_mask, seq_off, total_rows, out, n_seq, S, n_heads, scale, drop_p,
+                           drop_site, seed, 1, st);
+    } else if (dtype == DSVG_BF16) {
+        DSVG_ATTN_DISPATCH(launch_fwd, bf16_t, qkv, key_mask, seq_off, total_rows, out, n_seq, S, n_heads, scale, drop_p,
+                           drop_site, seed, 1, st);
+    }
+    dsvg_set_error("attention_causal_fwd: unsupported dtype/shape (dtype=%d S=%d H=%d)", dtype, S, n_heads);
     return -1;
 }
 
@@ -454,11 +481,30 @@ extern "C" int dsvg_attention_bwd(int32_t dtype, const void* qkv, const uint64_t
                                        n_seq, S, n_heads, scale, drop_p, drop_site, seed, st);
     if (dtype == DSVG_F32) {
         DSVG_ATTN_DISPATCH(launch_bwd, float, qkv, key_mask, seq_off, total_rows, dout, dqkv, n_seq, S, n_heads, scale,
-                           drop_p, drop_site, seed, st);
+                           drop_p, drop_site, seed, 0, st);
     } else if (dtype == DSVG_BF16) {
         DSVG_ATTN_DISPATCH(launch_bwd, bf16_t, qkv, key_mask, seq_off, total_rows, dout, dqkv, n_seq, S, n_heads, scale,
-                           drop_p, drop_site, seed, st);
+                           drop_p, drop_site, seed, 0, st);
     }
     dsvg_set_error("attention_bwd: unsupported dtype/shape (dtype=%d S=%d H=%d)", dtype, S, n_heads);
+    return -1;
+}
+
+extern "C" int dsvg_attention_causal_bwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const void* dout,
+                                         void* dqkv, int64_t n_seq, int32_t S, int32_t n_heads, float scale,
+                                         float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream) {
+    DSVG_CHECK_ARG(qkv && dout && dqkv && n_seq > 0 && S > 0 && S <= 64 && n_heads > 0, "attention_causal_bwd: bad args");
+    DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_causal_bwd: dropout needs a seed pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t* seq_off = nullptr;
+    const int64_t total_rows = 0;
+    if (dtype == DSVG_F32) {
+        DSVG_ATTN_DISPATCH(launch_bwd, float, qkv, key_mask, seq_off, total_rows, dout, dqkv, n_seq, S, n_heads, scale,
+                           drop_p, drop_site, seed, 1, st);
+    } else if (dtype == DSVG_BF16) {
+        DSVG_ATTN_DISPATCH(launch_bwd, bf16_t, qkv, key_mask, seq_off, total_rows, dout, dqkv, n_seq, S, n_heads, scale,
+                           drop_p, drop_site, seed, 1, st);
+    }
+    dsvg_set_error("attention_causal_bwd: unsupported dtype/shape (dtype=%d S=%d H=%d)", dtype, S, n_heads);
     return -1;
 }

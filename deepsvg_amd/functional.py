@@ -389,14 +389,18 @@ class LayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rt, x, key_mask, z, l, n_seq, S, n_heads, drop_rate, site0,
                 n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off=None, live=None,
-                tiles=None):
+                tiles=None, causal=False):
         p = rt.p(drop_rate)
         d = x.shape[1]
         scale = float(d // n_heads) ** -0.5
         xn1, mean1, rstd1 = ops.layernorm_fwd(x, n1w.detach(), n1b.detach())
         qkv = ops.gemm(xn1, rt.w(win), bias=bin_.detach())
-        ao = ops.attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, p, site0, rt.seed, seq_off=seq_off, tiles=tiles)
-        ctx.tiles = tiles
+        if causal:
+            ao = ops.attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, p, site0, rt.seed, causal=True)
+        else:
+            ao = ops.attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, p, site0, rt.seed, seq_off=seq_off,
+                                   tiles=tiles)
+        ctx.tiles, ctx.causal = tiles, causal
         x1 = ops.gemm(ao, rt.w(wo), bias=bo.detach(), res=x, drop_p=p, drop_site=site0 + 1, seed=rt.seed)
         if z is not None:
             g = ops.gemm(z, rt.w(wg), bias=bg.detach())
@@ -458,8 +462,11 @@ class LayerFn(torch.autograd.Function):
         dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao)
         dao = ops.gemm(dx1m, rt.w(wo), b_kc=False)
         del dx1m
-        dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed, seq_off=seq_off,
-                                 tiles=ctx.tiles)
+        if ctx.causal:
+            dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed, causal=True)
+        else:
+            dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed, seq_off=seq_off,
+                                     tiles=ctx.tiles)
         dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1)
         dxn1 = ops.gemm(dqkv, rt.w(win), b_kc=False)
         dx_out = None
@@ -471,7 +478,8 @@ class LayerFn(torch.autograd.Function):
         if ctx.live is not None:
             dx = dx_full
         return (None, dx, None, dz, dl, None, None, None, None, None,
-                dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, dwg2, dbg2, None, None, None)
+                dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, dwg2, dbg2, None, None, None,
+                None)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -237,8 +237,15 @@ class _Decoder(nn.Module):
             self.hierarchical_embedding = _ConstEmbedding(cfg, cfg.num_groups_proposal)
             self.hierarchical_decoder = _Stack(cfg.n_layers_decode, cfg.d_model, cfg.dim_feedforward, cfg.dim_z, dim_label)
             self.hierarchical_fcn = _HierarchFCN(cfg.d_model, cfg.dim_z)
-        seq_len = cfg.max_seq_len + 1 if cfg.decode_stages == 2 else cfg.max_total_len + 1
-        self.embedding = _ConstEmbedding(cfg, seq_len)
+        if cfg.pred_mode == "autoregressive":       # model.py:217-222
+            self.embedding = _SVGEmbedding(cfg, cfg.max_total_len, rel_args=cfg.rel_targets, use_group=True,
+                                           group_len=cfg.max_total_len)
+            sz = cfg.max_total_len + 1
+            mask = torch.triu(torch.full((sz, sz), float("-inf")), diagonal=1)      # utils.py:69-72
+            self.register_buffer("square_subsequent_mask", mask)
+        else:
+            seq_len = cfg.max_seq_len + 1 if cfg.decode_stages == 2 else cfg.max_total_len + 1
+            self.embedding = _ConstEmbedding(cfg, seq_len)
         self.decoder = _Stack(cfg.n_layers_decode, cfg.d_model, cfg.dim_feedforward, cfg.dim_z, dim_label)
         self.fcn = _FCN(cfg.d_model, cfg.n_commands, cfg.n_args, args_dim)
 
@@ -353,8 +360,11 @@ class SVGTransformer(nn.Module):
         self.cfg = cfg
         if cfg.model_type != "transformer":
             raise NotImplementedError("model_type='lstm' (SketchRNN baseline) is outside the MI355X hot path")
-        if cfg.pred_mode != "one_shot":
-            raise NotImplementedError("autoregressive decoding is not built yet (SURVEY.md §8(f)-3)")
+        if cfg.pred_mode not in ("one_shot", "autoregressive"):
+            raise ValueError(f"unknown pred_mode {cfg.pred_mode!r}")
+        if cfg.pred_mode == "autoregressive" and (cfg.decode_stages != 1 or cfg.max_total_len + 1 > 64):
+            raise NotImplementedError("autoregressive decoding is built for the one-stage decoder with max_total_len <= "
+                                      "63 (the causal attention kernel holds a sequence's key mask in 64 bits)")
         if cfg.d_model // cfg.n_heads != 32 or cfg.d_model % cfg.n_heads:
             raise NotImplementedError("the attention kernel is specialised for head_dim == 32")
         self.args_dim = 2 * cfg.args_dim if cfg.rel_targets else cfg.args_dim + 1
@@ -428,7 +438,8 @@ class SVGTransformer(nn.Module):
         return self._rt
 
     # ---- blocks ----------------------------------------------------------------------------------
-    def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site, seq_off=None, live=None, tiles=None, l=None):
+    def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site, seq_off=None, live=None, tiles=None, l=None,
+                   causal=False):
         """l: label embedding rows [n_seq, dim_label] of a label-conditioned config (memory2 of the reference layers,
         layers/improved_transformer.py:47-49,134-136)"""
         cfg = self.cfg
@@ -443,7 +454,7 @@ class SVGTransformer(nn.Module):
                 L.linear1.weight, L.linear1.bias, L.linear2.weight, L.linear2.bias,
                 L.linear_global.weight if has_g else None, L.linear_global.bias if has_g else None,
                 L.linear_global2.weight if has_l else None, L.linear_global2.bias if has_l else None,
-                seq_off, live, tiles)
+                seq_off, live, tiles, causal)
         return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps, live)
 
     def make_plan(self, commands_enc, args_enc, commands_dec, want_grad=True, args_dec=None):
@@ -596,7 +607,7 @@ class SVGTransformer(nn.Module):
         return z, mu, logsigma
 
     def _decode(self, rt, z, plan=None, lazy_args=False, label=None, hierarch_logits=None, return_hierarch=False,
-                match=None):
+                match=None, prefix=None):
         """z [N, dim_z] -> command_logits (N,G,S,n_cmd), args_logits (N,G,S,n_args,args_dim)[, visibility (N,G,1,2)];
         with lazy_args the second result is a thunk that computes args_logits when called.
         hierarch_logits [N*G, 2] given: z is the per-group latent [N*G, dim_z] and the first decoder stage is skipped
@@ -630,6 +641,8 @@ class SVGTransformer(nn.Module):
             n_seq = N
             if cfg.label_condition:
                 l_seq = self._label_rows(rt, dec, label, N)
+        if cfg.pred_mode == "autoregressive":
+            return self._decode_autoregressive(rt, z, prefix, l_seq, lazy_args)
         S = dec.embedding.seq_len
         pd = plan["dec"] if (plan is not None and cfg.decode_stages == 2) else None
         live = None
@@ -675,6 +688,39 @@ class SVGTransformer(nn.Module):
         if vis_logits is not None:
             vis_logits = vis_logits.view(N, G, 1, 2)
         return cmd_logits, args_logits, vis_logits
+
+    def _decode_autoregressive(self, rt, z, prefix, l_seq, lazy_args):
+        """pred_mode = "autoregressive" (model.py:263-277): the decoder embeds the shifted targets (teacher forcing) or
+        the prefix sampled so far and runs causal self-attention.  prefix = (commands (N, 1, S), args (N, 1, S, n_args))
+        batch-first float tensors; S <= max_total_len + 1."""
+        cfg = self.cfg
+        dec = self.decoder
+        emb = dec.embedding
+        commands, args = prefix
+        N, S = commands.shape[0], commands.shape[-1]
+        if commands.shape[1] != 1 or z.shape[0] != N:
+            raise ValueError("autoregressive decoding takes grouped sequences (N, 1, S) and one latent per icon")
+        if S > cfg.max_total_len + 1:
+            raise ValueError(f"decoder prefix of {S} tokens exceeds max_total_len + 1 = {cfg.max_total_len + 1}")
+        cmd = commands.to(torch.float32).contiguous().view(N, S)
+        arg = args.to(torch.float32).contiguous().view(N * S, -1)
+        key_mask, _vis, _gm = ops.build_masks(cmd, S, 0, EOS_ID)           # _get_key_padding_mask (model.py:269)
+        groups = ops.group_index(cmd, S, M_ID)                               # _get_group_mask (:264)
+        src = Fn.EmbedFn.apply(rt, cmd.view(-1), arg, groups, N, S, PE_DROPOUT, 4,
+                               emb.command_embed.weight, emb.arg_embed.weight, emb.embed_fcn.weight, emb.embed_fcn.bias,
+                               emb.pos_encoding.pos_embed.weight, emb.group_embed.weight)
+        out = self._run_stack(rt, dec.decoder, src, key_mask, z, N, S, 400, l=l_seq, causal=True)
+        cmd_logits = Fn.LinearFn.apply(rt, out, dec.fcn.command_fcn.weight, dec.fcn.command_fcn.bias, 0, None, 0.0, 0,
+                                       None)
+        n_args, args_dim, fcn = cfg.n_args, self.args_dim, dec.fcn.args_fcn
+
+        def make_args_logits():
+            al = Fn.LinearFn.apply(rt, out, fcn.weight, fcn.bias, 0, None, 0.0, 0, None)
+            return al.view(N, 1, S, n_args, args_dim)
+        args_logits = make_args_logits if lazy_args else make_args_logits()
+        self._head_in = out
+        self.last_live = None
+        return cmd_logits.view(N, 1, S, cfg.n_commands), args_logits, None
 
     # ---- public surface (model.py:352-412) ---------------------------------------------------------
     def forward(self, commands_enc, args_enc, commands_dec, args_dec, label=None, z=None, hierarch_logits=None,
@@ -725,8 +771,14 @@ class SVGTransformer(nn.Module):
             if cfg.decode_stages != 2:
                 raise ValueError("self-matching expects a two-stage decoder (model.py:385)")
             match = (commands_dec, args_dec)
+        prefix = None
+        if cfg.pred_mode == "autoregressive":
+            if commands_dec is None:
+                raise ValueError("autoregressive decoding needs commands_dec / args_dec (the prefix decoded so far)")
+            # train mode feeds the targets shifted by one: everything but the last token (model.py:376-377)
+            prefix = (commands_dec[..., :-1], args_dec[..., :-1, :]) if return_tgt else (commands_dec, args_dec)
         cmd_logits, args_logits, vis_logits = self._decode(rt, zz, plan, lazy_args=lazy_args, label=label,
-                                                           hierarch_logits=hl, match=match)
+                                                           hierarch_logits=hl, match=match, prefix=prefix)
         res = ModelOutput({"command_logits": cmd_logits})
         if lazy_args:
             res.set_lazy("args_logits", args_logits)
@@ -754,27 +806,74 @@ class SVGTransformer(nn.Module):
         self._head_in = None
         return res
 
-    # ---- sampling (model.py:414-459; inference-only host glue on the logits) -------------------------
+    # ---- sampling (model.py:414-479; inference-only host glue on the logits) -------------------------
     @torch.no_grad()
     def greedy_sample(self, commands_enc=None, args_enc=None, commands_dec=None, args_dec=None, label=None,
                       z=None, hierarch_logits=None, concat_groups=True, temperature=0.0001):
-        res = self.forward(commands_enc, args_enc, commands_dec, args_dec, label=label, z=z,
-                           hierarch_logits=hierarch_logits, return_tgt=False)
-        cl, al = res["command_logits"].float(), res["args_logits"].float()
-        commands_y = torch.distributions.Categorical(logits=cl / temperature).sample()
-        args_y = torch.distributions.Categorical(logits=al / temperature).sample()
-        args_y -= 1   # shift due to -1 PAD_VAL
-        visibility_y = None
-        if self.cfg.decode_stages == 2:
-            scores = torch.softmax(res["visibility_logits"].float(), dim=-1)[..., 1]
-            visibility_y = (scores > 0.7).squeeze(-1)
-        commands_y, args_y = self._make_valid(commands_y, args_y, visibility_y)
+        if self.cfg.pred_mode == "autoregressive":
+            commands_y, args_y = self._sample_autoregressive(commands_enc, args_enc, label, z, temperature)
+            visibility_y = None
+        else:
+            res = self.forward(commands_enc, args_enc, commands_dec, args_dec, label=label, z=z,
+                               hierarch_logits=hierarch_logits, return_tgt=False)
+            cl, al = res["command_logits"].float(), res["args_logits"].float()
+            commands_y = torch.distributions.Categorical(logits=cl / temperature).sample()
+            args_y = torch.distributions.Categorical(logits=al / temperature).sample()
+            args_y -= 1   # shift due to -1 PAD_VAL
+            visibility_y = None
+            if self.cfg.decode_stages == 2:
+                scores = torch.softmax(res["visibility_logits"].float(), dim=-1)[..., 1]
+                visibility_y = (scores > 0.7).squeeze(-1)
+            commands_y, args_y = self._make_valid(commands_y, args_y, visibility_y)
+        if self.cfg.rel_targets:
+            args_y = self._make_absolute(commands_y, args_y)
         if concat_groups:
             N = commands_y.size(0)
             pm = ((commands_y == EOS_ID).cumsum(dim=-1) == 0)
             commands_y = commands_y[pm].reshape(N, -1)
             args_y = args_y[pm].reshape(N, -1, self.cfg.n_args)
         return commands_y, args_y
+
+    def _sample_autoregressive(self, commands_enc, args_enc, label, z, temperature):
+        """model.py:424-441, for a whole batch: the reference decodes one icon at a time and re-runs the decoder on the
+        growing prefix for every new token; the same recurrence here, N icons side by side (the prefix re-computation is
+        kept - a key/value cache is the next step).  z: batch-first (N, 1, 1, dim_z) like the one-shot
+        path takes it, or None to encode commands_enc / args_enc."""
+        cfg = self.cfg
+        if z is None:
+            z = self.forward(commands_enc, args_enc, None, None, label=label, encode_mode=True).permute(2, 1, 0, 3)
+        N = z.shape[0]
+        dev = z.device
+        commands_y = torch.full((N, 1, 1), float(SOS_ID), device=dev)
+        args_y = torch.full((N, 1, 1, cfg.n_args), -1.0, device=dev)
+        cam = self.cmd_args_mask.to(dev).bool()
+        for _ in range(cfg.max_total_len):
+            res = self.forward(None, None, commands_y, args_y, label=label, z=z, return_tgt=False)
+            cl = res["command_logits"][:, :, -1].float()                  # only the newest position is sampled (:434)
+            al = res["args_logits"][:, :, -1].float()
+            cmd_new = torch.distributions.Categorical(logits=cl / temperature).sample()          # (N, 1)
+            arg_new = torch.distributions.Categorical(logits=al / temperature).sample() - 1      # shift due to PAD_VAL
+            arg_new[~cam[cmd_new]] = -1                                                           # _make_valid (:432)
+            commands_y = torch.cat([commands_y, cmd_new.unsqueeze(-1).float()], dim=-1)
+            args_y = torch.cat([args_y, arg_new.unsqueeze(-2).float()], dim=-2)
+        return commands_y[..., 1:].long(), args_y[..., 1:, :].long()       # discard SOS (:436)
+
+    def _make_absolute(self, commands_y, args_y):
+        """model.py:461-479, per sequence (the reference flattens the batch, which is only meaningful for one icon):
+        relative targets -> absolute coordinates by a running sum of the end positions of the real commands"""
+        cfg = self.cfg
+        cam = self.cmd_args_mask.to(commands_y.device).bool()
+        args_y = args_y.clone()
+        mask = cam[commands_y.long()]
+        args_y[mask] -= cfg.args_dim - 1
+        real = commands_y < EOS_ID                                           # (..., T)
+        end = torch.where(real.unsqueeze(-1), args_y[..., 9:11], torch.zeros_like(args_y[..., 9:11]))
+        before = end.cumsum(dim=-2) - end                                    # end positions of the earlier real commands
+        # columns 5..10 = control1 (x, y), control2 (x, y), end_pos (x, y): each pair shifted by (sum_x, sum_y)
+        shift = torch.stack([before[..., 0], before[..., 1]] * 3, dim=-1) * real.unsqueeze(-1).to(before.dtype)
+        args_y[..., 5:11] += shift.to(args_y.dtype)
+        _, args_y = self._make_valid(commands_y, args_y)
+        return args_y
 
     def _make_valid(self, commands_y, args_y, visibility_y=None, PAD_VAL=-1):
         if visibility_y is not None:

@@ -265,14 +265,22 @@ def attention_tiles(seq_off, n_seq, max_rows=32):
 
 
 def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None,
-                  tiles=None):
+                  tiles=None, causal=False):
     """seq_off (int32 [n_seq+1], device): packed layout, sequence b = rows seq_off[b]..seq_off[b+1]-1 (<= S rows, all
-    keys visible, key_mask must be None); rows past seq_off[n_seq] are zero-filled."""
+    keys visible, key_mask must be None); rows past seq_off[n_seq] are zero-filled.
+    causal: query i attends keys j <= i (autoregressive decoder; dense layout only)."""
     _chk(qkv, key_mask, seed, seq_off)
     rows = qkv.shape[0]
     assert qkv.is_contiguous() and qkv.shape[1] == 3 * 32 * n_heads, "attention needs head_dim == 32"
     assert (rows >= n_seq * S) if seq_off is None else (key_mask is None and seq_off.numel() == n_seq + 1)
     out = torch.empty((rows, 32 * n_heads), dtype=qkv.dtype, device=qkv.device)
+    if causal:
+        assert seq_off is None and rows == n_seq * S
+        _l.check(_l.load().dsvg_attention_causal_fwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), out.data_ptr(), n_seq, S,
+                                                     n_heads, float(scale), float(drop_p), int(drop_site),
+                                                     _p(seed) if drop_p > 0 else None, _stream()),
+                 "dsvg_attention_causal_fwd")
+        return out
     _l.check(_l.load().dsvg_attention_fwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), _p(seq_off), rows, _p(tiles),
                                           out.data_ptr(), n_seq, S, n_heads, float(scale), float(drop_p), int(drop_site),
                                           _p(seed) if drop_p > 0 else None, _stream()), "dsvg_attention_fwd")
@@ -280,11 +288,18 @@ def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site
 
 
 def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None,
-                  tiles=None):
+                  tiles=None, causal=False):
     _chk(qkv, key_mask, dout, seed, seq_off)
     assert qkv.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype
     assert seq_off is None or (key_mask is None and seq_off.numel() == n_seq + 1)
     dqkv = torch.empty_like(qkv)
+    if causal:
+        assert seq_off is None and qkv.shape[0] == n_seq * S
+        _l.check(_l.load().dsvg_attention_causal_bwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), dout.data_ptr(),
+                                                     dqkv.data_ptr(), n_seq, S, n_heads, float(scale), float(drop_p),
+                                                     int(drop_site), _p(seed) if drop_p > 0 else None, _stream()),
+                 "dsvg_attention_causal_bwd")
+        return dqkv
     _l.check(_l.load().dsvg_attention_bwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), _p(seq_off), qkv.shape[0],
                                           _p(tiles), dout.data_ptr(), dqkv.data_ptr(), n_seq, S, n_heads, float(scale),
                                           float(drop_p), int(drop_site), _p(seed) if drop_p > 0 else None, _stream()),

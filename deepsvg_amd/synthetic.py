@@ -66,7 +66,7 @@ def det_state_dict(model, seed=1234, scale=1.0):
     import zlib
     sd = {}
     for name, t in model.state_dict().items():
-        if not torch.is_floating_point(t) or name.endswith("cmd_args_mask"):
+        if not torch.is_floating_point(t) or name.endswith(("cmd_args_mask", "square_subsequent_mask")):  # constants
             sd[name] = t.clone()
             continue
         g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)

@@ -268,6 +268,16 @@ int dsvg_drop_apply(int32_t dtype, const void* x, void* y, int64_t n, float drop
                     const uint64_t* seed, void* stream);
 /* out[i] = a[i] + b[i] — the residual add of the latent ResNet (basic_blocks.py:59-65) */
 int dsvg_add(int32_t dtype, const void* a, const void* b, void* out, int64_t n, void* stream);
+/* Causal variant for the autoregressive decoder (pred_mode = "autoregressive": tgt_mask =
+ * square_subsequent_mask, deepsvg/model/model.py:219-222,270; layers/functional.py:228-233): query row i attends the
+ * keys j <= i that key_mask allows.  Dense layout only. */
+int dsvg_attention_causal_fwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, void* out, int64_t n_seq,
+                              int32_t S, int32_t n_heads, float scale, float drop_p, uint32_t drop_site,
+                              const uint64_t* seed, void* stream);
+int dsvg_attention_causal_bwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const void* dout, void* dqkv,
+                              int64_t n_seq, int32_t S, int32_t n_heads, float scale, float drop_p,
+                              uint32_t drop_site, const uint64_t* seed, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Hungarian self-matching (HierarchicalSelfMatching, deepsvg/model/config.py:101-108):
  * SVGTransformer.perfect_matching, deepsvg/model/model.py:311-350.

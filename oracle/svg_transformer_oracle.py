@@ -79,9 +79,9 @@ def key_visibility_mask(commands, seq_dim=0):
 # ---------------------------------------------------------------------------------------------------
 # layers
 # ---------------------------------------------------------------------------------------------------
-def mha(sd, pre, x, n_heads, kpm=None):
+def mha(sd, pre, x, n_heads, kpm=None, attn_mask=None):
     """layers/functional.py:8-256 for the self-attention case (q = k = v = x), eval mode.
-    x (L, B, E); kpm (B, L) bool, True = ignore key."""
+    x (L, B, E); kpm (B, L) bool, True = ignore key; attn_mask (L, L) float, added to the scores (:228-233)."""
     L, B, E = x.shape
     hd = E // n_heads
     qkv = F.linear(x, sd[pre + "in_proj_weight"], sd[pre + "in_proj_bias"])            # :92
@@ -91,6 +91,8 @@ def mha(sd, pre, x, n_heads, kpm=None):
     k = k.contiguous().view(L, B * n_heads, hd).transpose(0, 1)
     v = v.contiguous().view(L, B * n_heads, hd).transpose(0, 1)
     w = torch.bmm(q, k.transpose(1, 2))                                                    # :228
+    if attn_mask is not None:                                                              # :229-233
+        w = w + attn_mask.to(w.dtype).unsqueeze(0)
     if kpm is not None:                                                                    # :234-239
         w = w.view(B, n_heads, L, L).masked_fill(kpm.unsqueeze(1).unsqueeze(2), float("-inf")).view(B * n_heads, L, L)
     w = F.softmax(w, dim=-1)                                                               # :242
@@ -114,10 +116,10 @@ def encoder_layer(sd, pre, x, n_heads, kpm, memory2=None):
     return x + F.linear(h, sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
 
 
-def decoder_layer(sd, pre, x, memory, n_heads, memory2=None):
-    """layers/improved_transformer.py:126-141 (one-shot: no masks)"""
+def decoder_layer(sd, pre, x, memory, n_heads, memory2=None, tgt_mask=None, kpm=None):
+    """layers/improved_transformer.py:126-141 (one-shot: no masks; autoregressive: causal + key-padding masks)"""
     x1 = ln(sd, pre + "norm1.", x)
-    x = x + mha(sd, pre + "self_attn.", x1, n_heads, None)
+    x = x + mha(sd, pre + "self_attn.", x1, n_heads, kpm, tgt_mask)
     x = x + F.linear(memory, sd[pre + "linear_global.weight"], sd[pre + "linear_global.bias"])   # broadcast over seq
     if memory2 is not None:
         x = x + F.linear(memory2, sd[pre + "linear_global2.weight"], sd[pre + "linear_global2.bias"])
@@ -133,10 +135,10 @@ def encoder_stack(sd, pre, x, n_layers, n_heads, kpm, memory2=None):
     return ln(sd, pre + "norm.", x)
 
 
-def decoder_stack(sd, pre, x, memory, n_layers, n_heads, memory2=None):
+def decoder_stack(sd, pre, x, memory, n_layers, n_heads, memory2=None, tgt_mask=None, kpm=None):
     """layers/transformer.py:214-242"""
     for i in range(n_layers):
-        x = decoder_layer(sd, f"{pre}layers.{i}.", x, memory, n_heads, memory2)
+        x = decoder_layer(sd, f"{pre}layers.{i}.", x, memory, n_heads, memory2, tgt_mask, kpm)
     return ln(sd, pre + "norm.", x)
 
 
@@ -214,7 +216,7 @@ def resnet(sd, z):
     return z
 
 
-def decode(sd, cfg, z, label=None, hierarch_logits=None, return_hierarch=False):
+def decode(sd, cfg, z, label=None, hierarch_logits=None, return_hierarch=False, commands=None, args=None):
     """Decoder.forward model.py:243-285 (one_shot).  z (1, 1, N, dim_z) -> seq-first logits; with hierarch_logits
     (1, G, N, 2) the first stage is skipped and z is the per-group latent (1, G, N, dim_z) (:246-254)"""
     N = z.size(2)
@@ -234,9 +236,17 @@ def decode(sd, cfg, z, label=None, hierarch_logits=None, return_hierarch=False):
         hierarch_logits, z = pack(hierarch_logits), pack(z)                                 # (1, G*N, .)
         if return_hierarch:
             return unpack(N, hierarch_logits), unpack(N, z)                                 # :260-261
-    seq_len = cfg.max_seq_len + 1 if cfg.decode_stages == 2 else cfg.max_total_len + 1
-    src = const_embedding(sd, "decoder.embedding.", seq_len, z.size(1), z)
-    out = decoder_stack(sd, "decoder.decoder.", src, z, cfg.n_layers_decode, cfg.n_heads, l)
+    if cfg.pred_mode == "autoregressive":                                                   # :263-271
+        S = commands.size(0)                                                               # seq-first (S, G, N)
+        commands, args = pack(commands), pack(args)
+        src = svg_embedding(sd, "decoder.embedding.", commands, args, group_mask(commands, 0))
+        causal = torch.triu(torch.full((S, S), float("-inf")), diagonal=1)                 # utils.py:69-72
+        out = decoder_stack(sd, "decoder.decoder.", src, z, cfg.n_layers_decode, cfg.n_heads, l, causal,
+                            key_padding_mask(commands, 0))
+    else:
+        seq_len = cfg.max_seq_len + 1 if cfg.decode_stages == 2 else cfg.max_total_len + 1
+        src = const_embedding(sd, "decoder.embedding.", seq_len, z.size(1), z)
+        out = decoder_stack(sd, "decoder.decoder.", src, z, cfg.n_layers_decode, cfg.n_heads, l)
     S, GN, _ = out.shape
     command_logits = F.linear(out, sd["decoder.fcn.command_fcn.weight"], sd["decoder.fcn.command_fcn.bias"])
     args_dim = 2 * cfg.args_dim if cfg.rel_targets else cfg.args_dim + 1
@@ -285,7 +295,7 @@ def perfect_matching(cfg, command_logits, args_logits, hierarch_logits, tgt_comm
 
 
 def forward(sd, cfg, commands_enc, args_enc, commands_dec, args_dec, z=None, eps=None, encode_mode=False, label=None,
-            hierarch_logits=None, return_hierarch=False):
+            hierarch_logits=None, return_hierarch=False, return_tgt=True):
     """SVGTransformer.forward model.py:352-412, eval semantics (dropout = identity).
     Inputs batch-first (N, G, S) / (N, G, S, n_args).  `eps` replaces torch.randn_like in the VAE (model.py:185)."""
     dt = sd["decoder.fcn.command_fcn.weight"].dtype
@@ -306,12 +316,17 @@ def forward(sd, cfg, commands_enc, args_enc, commands_dec, args_dec, z=None, eps
         z = seq_first(z.to(dt))
     if encode_mode:
         return z
-    outs = decode(sd, cfg, z, label, hierarch_logits, return_hierarch)
+    cd = ad = None
+    if cfg.pred_mode == "autoregressive":
+        cd, ad = seq_first(commands_dec.to(dt)), seq_first(args_dec.to(dt))
+        if return_tgt:                                                                      # :376-377 train mode
+            cd, ad = cd[:-1], ad[:-1]
+    outs = decode(sd, cfg, z, label, hierarch_logits, return_hierarch, cd, ad)
     if return_hierarch:
         return outs                                                                         # :382-383, seq-first
     outs = tuple(seq_first(o) for o in outs)                                                # _make_batch_first
     assignment = None
-    if cfg.self_match and commands_dec is not None:                                         # :384-395 (train mode)
+    if cfg.self_match and commands_dec is not None and return_tgt:                          # :384-395 (train mode)
         cl, al, hl = outs
         assignment, _ = perfect_matching(cfg, cl, al, hl, commands_dec[..., 1:], args_dec[..., 1:, :])
         ix = assignment.unsqueeze(-1).unsqueeze(-1)
@@ -366,12 +381,12 @@ DEFAULT_WEIGHTS = {   # configs/deepsvg/default_icons.py:65-73 at step 0
 }
 
 
-def loss_and_grads(sd, cfg, commands, args, weights=None, eps=None, label=None):
+def loss_and_grads(sd, cfg, commands, args, weights=None, eps=None, label=None, args_dec=None):
     """forward + SVGLoss + autograd backward (the body of deepsvg/train.py:94-98 with dropout p = 0).
     Returns (output dict, loss dict, {name: grad})."""
     weights = weights or DEFAULT_WEIGHTS
     leaves = {k: v.detach().clone().requires_grad_(torch.is_floating_point(v)) for k, v in sd.items()}
-    out = forward(leaves, cfg, commands, args, commands, args, eps=eps, label=label)
+    out = forward(leaves, cfg, commands, args, commands, args if args_dec is None else args_dec, eps=eps, label=label)
     ld = svg_loss(cfg, out, weights)
     names = [k for k, v in leaves.items() if v.requires_grad]
     grads = torch.autograd.grad(ld["loss"], [leaves[k] for k in names], allow_unused=True)

@@ -58,6 +58,10 @@ def build_cfg(kind):
         cfg = ref_cfg.OneStageOneShot()
         cfg.max_total_len = 50
         cfg.use_vae = False
+    elif kind == "sketchformer":    # deepsvg/model/config.py:74-80 (transformer, autoregressive, one-stage, rel. targets)
+        cfg = ref_cfg.Sketchformer()
+        cfg.max_total_len = 50
+        cfg.use_vae = False
     elif kind == "selfmatch":       # deepsvg/model/config.py:101-108
         cfg = ref_cfg.HierarchicalSelfMatching()
         cfg.use_vae = False
@@ -76,10 +80,14 @@ def run_case(name, kind, n, seed, wseed):
     model = RefModel(cfg)
     sd = det_state_dict(model, seed=wseed)
     model.load_state_dict(sd)
-    if kind == "onestage":
+    if kind in ("onestage", "sketchformer"):
         commands, args = make_batch_onestage(n, total_len=cfg.max_total_len, seed=seed)
     else:
         commands, args = make_batch(n, G=cfg.max_num_groups, S=cfg.max_seq_len, seed=seed)
+    args_dec = args
+    if cfg.rel_targets:             # decoder side takes args_rel(_grouped) (model/config.py:52-53): SVGTensor.get_relative_args
+        args_dec = torch.stack([torch.stack([SVGTensor.from_cmd_args(commands[i, g], args[i, g]).get_relative_args()
+                                             for g in range(commands.shape[1])]) for i in range(n)])
     label = None
     if cfg.label_condition:
         label = torch.randint(0, cfg.n_labels, (n,), generator=torch.Generator().manual_seed(seed + 5))
@@ -104,12 +112,12 @@ def run_case(name, kind, n, seed, wseed):
         # ---- eval forward: logits ----
         model.eval()
         with torch.no_grad():
-            out = model(commands, args, commands, args, label=label, params={})
-            z = model(commands, args, commands, args, label=label, encode_mode=True)
+            out = model(commands, args, commands, args_dec, label=label, params={})
+            z = model(commands, args, commands, args_dec, label=label, encode_mode=True)
             hier = None
             if cfg.decode_stages == 2:
                 # GUI path (model.py:246-261,382-383): per-group latents out, then back in with hierarch_logits
-                hier = model(commands, args, commands, args, label=label, return_hierarch=True)
+                hier = model(commands, args, commands, args_dec, label=label, return_hierarch=True)
                 z_groups = hier[1].permute(2, 1, 0, 3).contiguous()     # batch-first for `z=` (model.py:369)
                 out2 = model(None, None, commands, args, label=label, z=z_groups, hierarch_logits=hier[0],
                              return_tgt=False)       # (with a VAE, return_tgt=True needs mu: model.py:408-410)
@@ -125,13 +133,13 @@ def run_case(name, kind, n, seed, wseed):
             if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
                 m.dropout = 0.0
         loss_fn = RefLoss(cfg)
-        out_t = model(commands, args, commands, args, label=label, params={})
+        out_t = model(commands, args, commands, args_dec, label=label, params={})
         ld_alias = loss_fn(out_t, None, weights=WEIGHTS)
         orig = ref_loss_mod._get_padding_mask
         ref_loss_mod._get_padding_mask = _canonical_padding_mask
         try:
             model.zero_grad()
-            out_t = model(commands, args, commands, args, label=label, params={})
+            out_t = model(commands, args, commands, args_dec, label=label, params={})
             ld = loss_fn(out_t, None, weights=WEIGHTS)
             ld["loss"].backward()
         finally:
@@ -144,7 +152,7 @@ def run_case(name, kind, n, seed, wseed):
             ref_model_mod._get_padding_mask = _ref_utils._get_padding_mask
 
     # ---- the oracle restatement must agree with the live reference ----
-    o_out = O.forward(sd, cfg, commands, args, commands, args, eps=eps, label=label)
+    o_out = O.forward(sd, cfg, commands, args, commands, args_dec, eps=eps, label=label)
     if hier is not None:
         o_hier = O.forward(sd, cfg, commands, args, commands, args, eps=eps, label=label, return_hierarch=True)
         assert (o_hier[0] - hier[0]).abs().max().item() < 2e-5 and (o_hier[1] - hier[1]).abs().max().item() < 2e-5
@@ -156,7 +164,7 @@ def run_case(name, kind, n, seed, wseed):
         if k in out:
             err = (o_out[k] - out[k]).abs().max().item()
             assert err < 2e-5, (name, k, err)
-    _, o_ld, o_grads = O.loss_and_grads(sd, cfg, commands, args, WEIGHTS, eps=eps, label=label)
+    _, o_ld, o_grads = O.loss_and_grads(sd, cfg, commands, args, WEIGHTS, eps=eps, label=label, args_dec=args_dec)
     for k in ld:
         assert abs(o_ld[k].item() - ld[k].item()) < 2e-5 * max(1.0, abs(ld[k].item())), (name, k, o_ld[k].item(), ld[k].item())
     worst = 0.0
@@ -184,6 +192,20 @@ def run_case(name, kind, n, seed, wseed):
         rec["eps"] = eps.numpy()
     if label is not None:
         rec["label"] = label.numpy()
+    if cfg.rel_targets:
+        rec["args_dec"] = args_dec.numpy().astype(np.float32)
+    if cfg.pred_mode == "autoregressive":
+        # autoregressive sampling (model.py:424-441), one icon at a time as the reference decodes; stored without the
+        # concat_groups squeeze so that the icons stack
+        model.eval()
+        cs, as_ = [], []
+        with torch.no_grad():
+            for i in range(n):
+                cy, ay = model.greedy_sample(commands[i:i + 1], args[i:i + 1], None, None, concat_groups=False)
+                cs.append(cy)
+                as_.append(ay)
+        rec["sample_commands"] = torch.cat(cs).numpy().astype(np.int64)
+        rec["sample_args"] = torch.cat(as_).numpy().astype(np.int64)
     if "assignment" in captured:
         rec["assignment"] = captured["assignment"].numpy().astype(np.int64)     # (N, Gp), of the last (train) pass
         assert torch.equal(o_out["_assignment"], captured["assignment"])
@@ -212,7 +234,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:           # regenerate selected cases only: make_golden.py <name> ...
         ALL = {"hier_ordered_n2": ("hier", 2, 11, 1234), "hier_ordered_n5": ("hier", 5, 12, 4321),
                "hier_vae_n3": ("hier_vae", 3, 13, 1234), "onestage50_n3": ("onestage", 3, 14, 1234),
-               "fonts_label_n4": ("fonts", 4, 15, 1234), "selfmatch_n6": ("selfmatch", 6, 16, 1234)}
+               "fonts_label_n4": ("fonts", 4, 15, 1234), "selfmatch_n6": ("selfmatch", 6, 16, 1234),
+               "sketchformer50_n4": ("sketchformer", 4, 17, 1234)}
         for nm in sys.argv[1:]:
             run_case(nm, *ALL[nm])
         sys.exit(0)
@@ -222,3 +245,4 @@ if __name__ == "__main__":
     run_case("onestage50_n3", "onestage", 3, 14, 1234)
     run_case("fonts_label_n4", "fonts", 4, 15, 1234)
     run_case("selfmatch_n6", "selfmatch", 6, 16, 1234)
+    run_case("sketchformer50_n4", "sketchformer", 4, 17, 1234)

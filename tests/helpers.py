@@ -55,6 +55,10 @@ def build_cfg(kind):
         cfg = C.OneStageOneShot()
         cfg.max_total_len = 50
         cfg.use_vae = False
+    elif kind == "sketchformer":    # deepsvg/model/config.py:74-80
+        cfg = C.Sketchformer()
+        cfg.max_total_len = 50
+        cfg.use_vae = False
     elif kind == "selfmatch":       # deepsvg/model/config.py:101-108
         cfg = C.HierarchicalSelfMatching()
         cfg.use_vae = False
@@ -65,6 +69,11 @@ def build_cfg(kind):
     else:
         raise ValueError(kind)
     return cfg
+
+
+def golden_args_dec(g, args):
+    """decoder-side arguments: relative targets for rel_targets configs (model/config.py:52-53), else the same tensor"""
+    return torch.from_numpy(g["args_dec"]) if "args_dec" in g else args
 
 
 def golden_label(g):

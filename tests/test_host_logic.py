@@ -11,7 +11,7 @@ from oracle import svg_transformer_oracle as O
 from tests import helpers as H
 
 
-def _run_model(cfg, sd, commands, args, eps=None, dtype=torch.float32, label=None):
+def _run_model(cfg, sd, commands, args, eps=None, dtype=torch.float32, label=None, args_dec=None):
     model = deepsvg_amd.SVGTransformer(cfg)
     model.load_state_dict(sd)
     model.set_compute_dtype(dtype)
@@ -25,7 +25,7 @@ def _run_model(cfg, sd, commands, args, eps=None, dtype=torch.float32, label=Non
         orig = torch.randn_like
         M.torch.randn_like = lambda t: eps.reshape(t.shape).to(t.dtype)
     try:
-        out = model(commands, args, commands, args, label=label, params={})
+        out = model(commands, args, commands, args if args_dec is None else args_dec, label=label, params={})
         ld = loss_fn(out, None, weights=O.DEFAULT_WEIGHTS)
         ld["loss"].backward()
     finally:
@@ -41,11 +41,15 @@ def test_model_matches_golden_with_emulated_ops(name, emulated_ops):
     ref_model = deepsvg_amd.SVGTransformer(cfg)
     sd = H.weights_for(ref_model, g["wseed"])
     label = H.golden_label(g)
-    model, out, ld, grads = _run_model(cfg, sd, commands, args, eps, label=label)
+    model, out, ld, grads = _run_model(cfg, sd, commands, args, eps, label=label, args_dec=H.golden_args_dec(g, args))
     H.check_against_golden(g, out, {k: v.item() for k, v in ld.items()}, grads, logit_rtol=1e-4, logit_atol=1e-5,
                            loss_tol=1e-5, grad_norm_rtol=2e-4)
     if "assignment" in g:       # Hungarian self-matching: the assignment the reference's perfect_matching returned
         assert torch.equal(model.last_assignment.long(), torch.from_numpy(g["assignment"]))
+    if "sample_commands" in g:  # autoregressive sampling, the whole batch at once vs the reference's icon-by-icon loop
+        cy, ay = model.greedy_sample(commands, args, None, None, concat_groups=False)
+        assert torch.equal(cy, torch.from_numpy(g["sample_commands"]))
+        assert torch.equal(ay, torch.from_numpy(g["sample_args"]))
     z = model(commands, args, commands, args, label=label, encode_mode=True) if eps is None else None
     if z is not None:
         assert z.shape == tuple(g["z"].shape)

@@ -323,6 +323,30 @@ def test_attention(gpu_device, dtype, S, n_seq, masked):
         _close(dq, dqr, 1e-5 if dtype == torch.float32 else 2e-2, f"attn bwd S={S} p={p}")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S,n_seq,masked", [(8, 9, False), (31, 20, True), (32, 7, True), (51, 13, True), (64, 5, False), (60, 5, True),
+                                            (1, 4, False), (17, 6, False)])
+def test_attention_causal(gpu_device, dtype, S, n_seq, masked):
+    """autoregressive decoder: query i attends keys j <= i (and only those the key-padding mask allows)"""
+    H = 8
+    qkv = _rand(n_seq * S, 3 * 32 * H, dtype=dtype, seed=S + 40)
+    km = _key_masks(n_seq, S, seed=S + 41, all_valid=not masked)        # valid prefixes: key 0 is always visible
+    scale = 32 ** -0.5
+    seed = _seed_tensor(0x0FEDCBA987654321)
+    for p in (0.0, 0.1):
+        o = ops.attention_fwd(qkv, km, n_seq, S, H, scale, p, 23, seed, causal=True)
+        orf = R.attention_fwd(qkv.float(), km, n_seq, S, H, scale, p, 23, seed, causal=True)
+        _close(o, orf, 3e-6 if dtype == torch.float32 else 1.5e-2, f"causal attn fwd S={S} p={p}")
+        do = _rand(n_seq * S, 32 * H, dtype=dtype, seed=S + 42)
+        dq = ops.attention_bwd(qkv, km, do, n_seq, S, H, scale, p, 23, seed, causal=True)
+        dqr = R.attention_bwd(qkv.float(), km, do.float(), n_seq, S, H, scale, p, 23, seed, causal=True)
+        _close(dq, dqr, 1e-5 if dtype == torch.float32 else 2e-2, f"causal attn bwd S={S} p={p}")
+    if S > 1:       # the first query row depends on key 0 alone: its output is v_0
+        v0 = qkv.float().view(n_seq, S, 3, H * 32)[:, 0, 2]
+        o0 = ops.attention_fwd(qkv, km, n_seq, S, H, scale, causal=True).float().view(n_seq, S, H * 32)[:, 0]
+        _close(o0, v0, 1e-6 if dtype == torch.float32 else 1e-2, "first causal row")
+
+
 # ----------------------------------------------------------------------------------------------------
 def _packed_case(n_seq, S, seed):
     """random valid-prefix lengths in 1..S -> (key_mask int64 [n_seq], seq_off int32 [n_seq+1], total)"""

@@ -23,7 +23,7 @@ def _hip_model(cfg, sd, dtype=torch.float32):
     return model
 
 
-def _fwd_bwd(model, cfg, commands, args, eps=None, label=None):
+def _fwd_bwd(model, cfg, commands, args, eps=None, label=None, args_dec=None):
     loss_fn = deepsvg_amd.SVGLoss(cfg).to(DEV)
     model.zero_grad()
     import deepsvg_amd.model as M
@@ -31,7 +31,7 @@ def _fwd_bwd(model, cfg, commands, args, eps=None, label=None):
     if eps is not None:
         M.torch.randn_like = lambda t: eps.reshape(t.shape).to(device=t.device, dtype=t.dtype)
     try:
-        out = model(commands.to(DEV), args.to(DEV), commands.to(DEV), args.to(DEV),
+        out = model(commands.to(DEV), args.to(DEV), commands.to(DEV), (args if args_dec is None else args_dec).to(DEV),
                     label=label.to(DEV) if label is not None else None, params={})
         ld = loss_fn(out, None, weights=O.DEFAULT_WEIGHTS)
         ld["loss"].backward()
@@ -52,8 +52,12 @@ def test_fp32_model_matches_reference_golden(gpu_device, name, packed):
     model.pack_encoder = model.skip_invisible_backward = model.compact_head_backward = packed
     model.eval()
     label = H.golden_label(g)
-    out, ld, grads = _fwd_bwd(model, cfg, commands, args, eps, label)
+    out, ld, grads = _fwd_bwd(model, cfg, commands, args, eps, label, H.golden_args_dec(g, args))
     H.check_against_golden(g, out, ld, grads, logit_rtol=1e-3, logit_atol=1e-5, loss_tol=1e-4, grad_norm_rtol=1e-3)
+    if "sample_commands" in g:  # autoregressive sampling, the whole batch at once vs the reference's icon-by-icon loop
+        cy, ay = model.greedy_sample(commands.to(DEV), args.to(DEV), None, None, concat_groups=False)
+        assert torch.equal(cy.cpu(), torch.from_numpy(g["sample_commands"]))
+        assert torch.equal(ay.cpu(), torch.from_numpy(g["sample_args"]))
     if "assignment" in g:       # Hungarian self-matching: the assignment the reference's perfect_matching returned
         assert torch.equal(model.last_assignment.long().cpu(), torch.from_numpy(g["assignment"]))
     if eps is None:

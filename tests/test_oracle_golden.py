@@ -29,14 +29,15 @@ def test_oracle_matches_reference_golden(name):
     g, cfg, commands, args, eps = H.golden_setup(name)
     sd = _oracle_weights(cfg, g["wseed"])
     label = H.golden_label(g)
-    out, ld, grads = O.loss_and_grads(sd, cfg, commands, args, O.DEFAULT_WEIGHTS, eps=eps, label=label)
+    args_dec = H.golden_args_dec(g, args)
+    out, ld, grads = O.loss_and_grads(sd, cfg, commands, args, O.DEFAULT_WEIGHTS, eps=eps, label=label, args_dec=args_dec)
     out = {k: v.detach() for k, v in out.items()}
     H.check_against_golden(g, out, {k: v.item() for k, v in ld.items()}, grads, logit_rtol=1e-5, logit_atol=2e-6,
                            loss_tol=2e-6, grad_norm_rtol=1e-5)
-    z = O.forward(sd, cfg, commands, args, commands, args, eps=eps, encode_mode=True, label=label)
+    z = O.forward(sd, cfg, commands, args, commands, args_dec, eps=eps, encode_mode=True, label=label)
     assert torch.allclose(z, torch.from_numpy(g["z"]), rtol=1e-5, atol=1e-6)
     if "hier_logits" in g:      # GUI path: first decoder stage only (model.py:246-261)
-        hl, zg = O.forward(sd, cfg, commands, args, commands, args, eps=eps, label=label, return_hierarch=True)
+        hl, zg = O.forward(sd, cfg, commands, args, commands, args_dec, eps=eps, label=label, return_hierarch=True)
         assert torch.allclose(hl, torch.from_numpy(g["hier_logits"]), rtol=1e-5, atol=2e-6)
         assert torch.allclose(zg, torch.from_numpy(g["hier_z"]), rtol=1e-5, atol=2e-6)
 

@@ -165,10 +165,12 @@ def _mask_bits(mask, S):
     return ((mask.unsqueeze(1) >> bits) & 1).bool()
 
 
-def _attn_probs(qkv, key_mask, n_seq, S, H, scale):
+def _attn_probs(qkv, key_mask, n_seq, S, H, scale, causal=False):
     d = 32 * H
     q, k, v = _f(qkv).view(n_seq, S, 3, H, 32).permute(2, 0, 3, 1, 4)      # each (n_seq, H, S, 32)
     s = (q * scale) @ k.transpose(-1, -2)
+    if causal:          # square_subsequent_mask: query i sees keys j <= i
+        s = s.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool, device=s.device), diagonal=1), float("-inf"))
     if key_mask is not None:
         valid = _mask_bits(key_mask, S)
         s = s.masked_fill(~valid.view(n_seq, 1, 1, S), float("-inf"))
@@ -221,7 +223,7 @@ def attention_tiles(seq_off, n_seq, max_rows=32):
 
 
 def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None,
-                  tiles=None):
+                  tiles=None, causal=False):
     if seq_off is not None:
         dense, idx, lens = _unpack_rows(qkv, seq_off, n_seq, S)
         o = attention_fwd(dense, _len_mask(lens), n_seq, S, n_heads, scale, drop_p, drop_site, seed)
@@ -230,14 +232,14 @@ def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site
         o = attention_fwd(qkv[:n_seq * S], key_mask, n_seq, S, n_heads, scale, drop_p, drop_site, seed)
         return torch.cat([o, torch.zeros((qkv.shape[0] - n_seq * S, o.shape[1]), dtype=o.dtype, device=o.device)])
     H = n_heads
-    q, k, v, P = _attn_probs(qkv, key_mask, n_seq, S, H, scale)
+    q, k, v, P = _attn_probs(qkv, key_mask, n_seq, S, H, scale, causal)
     Pd = P * _attn_drop(drop_p, seed, drop_site, n_seq, S, H, qkv.device)
     o = Pd @ v                                                               # (n_seq, H, S, 32)
     return o.permute(0, 2, 1, 3).reshape(n_seq * S, H * 32).to(qkv.dtype)
 
 
 def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None,
-                  tiles=None):
+                  tiles=None, causal=False):
     if seq_off is not None:
         dense, idx, lens = _unpack_rows(qkv, seq_off, n_seq, S)
         ddense, _, _ = _unpack_rows(dout, seq_off, n_seq, S)
@@ -247,7 +249,7 @@ def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, dro
         g = attention_bwd(qkv[:n_seq * S], key_mask, dout[:n_seq * S], n_seq, S, n_heads, scale, drop_p, drop_site, seed)
         return torch.cat([g, torch.zeros((qkv.shape[0] - n_seq * S, g.shape[1]), dtype=g.dtype, device=g.device)])
     H = n_heads
-    q, k, v, P = _attn_probs(qkv, key_mask, n_seq, S, H, scale)
+    q, k, v, P = _attn_probs(qkv, key_mask, n_seq, S, H, scale, causal)
     mult = _attn_drop(drop_p, seed, drop_site, n_seq, S, H, qkv.device)
     do = _f(dout).view(n_seq, S, H, 32).permute(0, 2, 1, 3)
     dv = (P * mult).transpose(-1, -2) @ do
