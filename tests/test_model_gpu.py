@@ -40,7 +40,7 @@ def _fwd_bwd(model, cfg, commands, args, eps=None, label=None, args_dec=None):
     torch.cuda.synchronize()
     grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()}
     out = {k: v.detach().float().cpu() for k, v in out.items() if torch.is_tensor(v)}
-    return out, {k: float(v) for k, v in ld.items()}, grads
+    return out, {k: float(v.detach()) for k, v in ld.items()}, grads
 
 
 @pytest.mark.parametrize("packed", [True, False])
