@@ -393,6 +393,7 @@ class SVGTransformer(nn.Module):
         # backward of the argument head only over the tokens that carry argument loss (exact under SVGLoss)
         self.compact_head_backward = os.environ.get("DSVG_COMPACT_HEAD", "1") != "0"
         self.last_head_rows = None
+        self.kv_cache = True         # autoregressive sampling: incremental decoding over a per-layer q|k|v cache
         self.last_assignment = None  # self-matching configs: (N, Gp) int32 assignment of the last training forward
         self._forced_plan = None
         self._decoder_grads_ready = None    # callback of a data-parallel trainer (TrainStep), see forward()
@@ -835,13 +836,17 @@ class SVGTransformer(nn.Module):
         return commands_y, args_y
 
     def _sample_autoregressive(self, commands_enc, args_enc, label, z, temperature):
-        """model.py:424-441, for a whole batch: the reference decodes one icon at a time and re-runs the decoder on the
-        growing prefix for every new token; the same recurrence here, N icons side by side (the prefix re-computation is
-        kept - a key/value cache is the next step).  z: batch-first (N, 1, 1, dim_z) like the one-shot
-        path takes it, or None to encode commands_enc / args_enc."""
+        """model.py:424-441, for a whole batch.  The reference decodes one icon per call and re-runs the decoder on the
+        growing prefix for every new token (O(T^2) token-layers).  Here N icons decode side by side and - causal
+        attention makes the earlier tokens' activations final - every step computes ONE new token per icon: its q|k|v
+        row goes into a per-layer cache the attention kernel reads (`kv_cache = False`: the reference's re-computation,
+        kept as the cross-check).  z: batch-first (N, 1, 1, dim_z) like the one-shot path takes it, or None to encode
+        commands_enc / args_enc."""
         cfg = self.cfg
         if z is None:
             z = self.forward(commands_enc, args_enc, None, None, label=label, encode_mode=True).permute(2, 1, 0, 3)
+        if self.kv_cache:
+            return self._sample_autoregressive_cached(z, label, temperature)
         N = z.shape[0]
         dev = z.device
         commands_y = torch.full((N, 1, 1), float(SOS_ID), device=dev)
@@ -857,6 +862,74 @@ class SVGTransformer(nn.Module):
             commands_y = torch.cat([commands_y, cmd_new.unsqueeze(-1).float()], dim=-1)
             args_y = torch.cat([args_y, arg_new.unsqueeze(-2).float()], dim=-2)
         return commands_y[..., 1:].long(), args_y[..., 1:, :].long()       # discard SOS (:436)
+
+    def _sample_autoregressive_cached(self, z, label, temperature):
+        """incremental decoding: per step one token row per icon through embedding, every layer and the heads; each
+        layer keeps the q|k|v rows of the tokens so far ([N, T + 1, 3 d], zero beyond the prefix) and the causal
+        attention kernel reads that cache - row s of its output is the new token's context"""
+        cfg, dec = self.cfg, self.decoder
+        emb = dec.embedding
+        dev = z.device
+        ops.require_device(dev)
+        training = self.training
+        self.eval()
+        try:
+            rt = self._runtime(dev)
+        finally:
+            self.train(training)
+        N, T, d, H = z.shape[0], cfg.max_total_len, cfg.d_model, cfg.n_heads
+        S = T + 1
+        dt = rt.dtype
+        zz = z.reshape(N, -1).to(dt).contiguous()
+        layers = list(dec.decoder.layers)
+        gz = [ops.gemm(zz, rt.w(L.linear_global.weight), bias=L.linear_global.bias.detach()) for L in layers]
+        g2 = None
+        if cfg.label_condition:
+            l_rows = Fn.LabelEmbedFn.apply(rt, label.reshape(-1), dec.label_embedding.label_embedding.weight)
+            g2 = [ops.gemm(l_rows, rt.w(L.linear_global2.weight), bias=L.linear_global2.bias.detach()) for L in layers]
+        cache = [torch.zeros(N * S, 3 * d, dtype=dt, device=dev) for _ in layers]
+        # the prefix so far, padded with SOS (any non-EOS value): the key-padding mask is "before the first EOS" (:269)
+        cmd_buf = torch.full((N, S), float(SOS_ID), device=dev)
+        commands_y = torch.empty(N, 1, T, dtype=torch.long, device=dev)
+        args_y = torch.empty(N, 1, T, cfg.n_args, dtype=torch.long, device=dev)
+        cam = self.cmd_args_mask.to(dev).bool()
+        pos = emb.pos_encoding.pos_embed.weight.detach()
+        cmd_s = torch.full((N,), float(SOS_ID), device=dev)
+        arg_s = torch.full((N, cfg.n_args), -1.0, device=dev)
+        n_m = torch.zeros(N, dtype=torch.int32, device=dev)                 # group index = number of `m` so far (:264)
+        scale = float(d // H) ** -0.5
+        fcn = dec.fcn
+        for s in range(T):
+            n_m = n_m + (cmd_s == M_ID).to(torch.int32)
+            A, R = ops.embed_gather(cmd_s.contiguous(), arg_s.contiguous(), emb.command_embed.weight.detach(),
+                                    emb.arg_embed.weight.detach(), dt, emb.group_embed.weight.detach(), n_m.contiguous())
+            pre = ops.gemm(A, rt.w(emb.embed_fcn.weight), bias=emb.embed_fcn.bias.detach(), res=R, res_pre=True)
+            x = ops.add_pos_fwd(pre, pos[s:s + 1].contiguous(), N, 1, dt)
+            key_mask, _v, _g = ops.build_masks(cmd_buf, S, 0, EOS_ID)
+            for li, L in enumerate(layers):
+                xn1, _, _ = ops.layernorm_fwd(x, L.norm1.weight.detach(), L.norm1.bias.detach())
+                qkv = ops.gemm(xn1, rt.w(L.self_attn.in_proj_weight), bias=L.self_attn.in_proj_bias.detach())
+                cache[li].view(N, S, 3 * d)[:, s] = qkv
+                ao = ops.attention_fwd(cache[li], key_mask, N, S, H, scale, causal=True).view(N, S, d)[:, s].contiguous()
+                x1 = ops.gemm(ao, rt.w(L.self_attn.out_proj.weight), bias=L.self_attn.out_proj.bias.detach(), res=x)
+                ops.bcast_add_fwd_(x1, gz[li], N, 1)
+                if g2 is not None:
+                    ops.bcast_add_fwd_(x1, g2[li], N, 1)
+                xn2, _, _ = ops.layernorm_fwd(x1, L.norm2.weight.detach(), L.norm2.bias.detach())
+                h = ops.gemm(xn2, rt.w(L.linear1.weight), bias=L.linear1.bias.detach(), act=ops.RELU)
+                x = ops.gemm(h, rt.w(L.linear2.weight), bias=L.linear2.bias.detach(), res=x1)
+            xo, _, _ = ops.layernorm_fwd(x, dec.decoder.norm.weight.detach(), dec.decoder.norm.bias.detach())
+            cl = ops.gemm(xo, rt.w(fcn.command_fcn.weight), bias=fcn.command_fcn.bias.detach()).float()
+            al = ops.gemm(xo, rt.w(fcn.args_fcn.weight), bias=fcn.args_fcn.bias.detach()).float() \
+                .view(N, cfg.n_args, self.args_dim)
+            cmd_new = torch.distributions.Categorical(logits=cl / temperature).sample()           # (N,)
+            arg_new = torch.distributions.Categorical(logits=al / temperature).sample() - 1       # (N, n_args)
+            arg_new[~cam[cmd_new]] = -1
+            commands_y[:, 0, s] = cmd_new
+            args_y[:, 0, s] = arg_new
+            cmd_s, arg_s = cmd_new.float(), arg_new.float()
+            cmd_buf[:, s + 1] = cmd_s
+        return commands_y, args_y
 
     def _make_absolute(self, commands_y, args_y):
         """model.py:461-479, per sequence (the reference flattens the batch, which is only meaningful for one icon):

@@ -252,3 +252,23 @@ def test_greedy_sample_shapes(emulated_ops):
     commands_y, args_y = model.greedy_sample(z=z, concat_groups=False)
     assert commands_y.shape == (3, 8, 31) and args_y.shape == (3, 8, 31, 11)
     assert args_y.min().item() >= -1 and args_y.max().item() <= 255
+
+
+def test_autoregressive_cached_sampling_equals_recompute(emulated_ops):
+    """incremental decoding over the per-layer q|k|v cache vs the reference's scheme (decoder re-run on the whole prefix
+    for every new token): same token sequences, on weights that make the sequences vary"""
+    from deepsvg_amd.synthetic import make_batch_onestage
+    cfg = H.build_cfg("sketchformer")
+    cfg.max_total_len = 24
+    model = deepsvg_amd.SVGTransformer(cfg)
+    sd = H.weights_for(model, 11)
+    sd["decoder.fcn.command_fcn.weight"] = sd["decoder.fcn.command_fcn.weight"] * 8      # spread the command logits
+    model.load_state_dict(sd)
+    model.eval()
+    commands, args = make_batch_onestage(5, total_len=cfg.max_total_len, seed=3)
+    outs = {}
+    for kv in (True, False):
+        model.kv_cache = kv
+        outs[kv] = model.greedy_sample(commands, args, None, None, concat_groups=False)
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    assert outs[True][0].unique().numel() > 1, "degenerate sample: the test would not see an ordering bug"

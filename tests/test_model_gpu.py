@@ -316,3 +316,36 @@ def test_self_matching_training_step(gpu_device, use_graph):
     a = model.last_assignment.cpu()
     assert a.shape == (32, cfg.num_groups_proposal)
     assert torch.equal(a.sort(dim=1).values, torch.arange(cfg.num_groups_proposal, dtype=a.dtype).expand_as(a))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_autoregressive_cached_sampling_equals_recompute(gpu_device, dtype):
+    """incremental decoding over the per-layer q|k|v cache vs re-running the decoder on the growing prefix (the
+    reference's scheme, model.py:428-436): same token sequences; the cached path does T instead of T^2/2 token-layers"""
+    import time
+    from deepsvg_amd.synthetic import make_batch_onestage
+    cfg = H.build_cfg("sketchformer")
+    cfg.max_total_len = 40
+    model = deepsvg_amd.SVGTransformer(cfg)
+    sd = H.weights_for(model, 11)
+    sd["decoder.fcn.command_fcn.weight"] = sd["decoder.fcn.command_fcn.weight"] * 8      # spread the command logits
+    model = _hip_model(cfg, sd, dtype).eval()
+    commands, args = make_batch_onestage(64, total_len=cfg.max_total_len, seed=3)
+    commands, args = commands.to(DEV), args.to(DEV)
+    outs, secs = {}, {}
+    for kv in (True, False):
+        model.kv_cache = kv
+        model.greedy_sample(commands[:2], args[:2], None, None, concat_groups=False)        # warm-up
+        torch.cuda.synchronize()
+        t0 = time.time()
+        outs[kv] = model.greedy_sample(commands, args, None, None, concat_groups=False)
+        torch.cuda.synchronize()
+        secs[kv] = time.time() - t0
+    print(f"autoregressive sampling, 64 icons x 40 tokens ({dtype}): cached {secs[True] * 1e3:.0f} ms, "
+          f"prefix re-computation {secs[False] * 1e3:.0f} ms")
+    same = (outs[True][0] == outs[False][0]).float().mean().item()
+    if dtype == torch.float32:
+        assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    else:       # bf16: a near-tie may flip one token, after which the two sequences legitimately diverge
+        assert same > 0.9, same
+    assert outs[True][0].unique().numel() > 1
