@@ -26,6 +26,10 @@ if [[ "$WHAT" == "all" || "$WHAT" == *bench* ]]; then
   run bench_bf16_padded 600 env DSVG_SKIP_INVISIBLE=0 DSVG_COMPACT_HEAD=0 python bench.py --pack-encoder 0 --no-cpu-baseline
   run bench_fp32 900 python bench.py --dtype fp32 --steps 5 --warmup 2 --no-cpu-baseline
 fi
+if [[ "$WHAT" == "all" || "$WHAT" == *second* ]]; then
+  run secondary_bench 600 python scripts/secondary_bench.py
+  run train_sanity 600 python scripts/train_sanity.py
+fi
 if [[ "$WHAT" == "all" || "$WHAT" == *prof* ]]; then
   bash scripts/gpu_prof.sh prof_round > gpurun_out/prof_round.txt 2>&1
   head -40 gpurun_out/prof_round.txt | cut -c1-150 >> gpurun_out/summary.log
