@@ -269,6 +269,7 @@ def test_autoregressive_cached_sampling_equals_recompute(emulated_ops):
     outs = {}
     for kv in (True, False):
         model.kv_cache = kv
+        torch.manual_seed(0)            # same categorical draws for both schemes
         outs[kv] = model.greedy_sample(commands, args, None, None, concat_groups=False)
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
     assert outs[True][0].unique().numel() > 1, "degenerate sample: the test would not see an ordering bug"
