@@ -228,3 +228,47 @@ extern "C" int dsvg_match_assign(const float* cost, const int32_t* visible, int6
     DSVG_LAUNCH_CHECK("match_assign");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// arg-max over the class axis of a logits matrix: logical row r of [rows, C] lives at logits + (r / group) * ld +
+// (r % group) * C (same addressing as the masked cross-entropy).  The temperature -> 0 limit of the reference's
+// _sample_categorical (deepsvg/model/utils.py:75-80), used by greedy_sample(temperature=0): no fp32 copy of the
+// logits, no softmax, no multinomial draw.  Ties go to the lowest class index.  One wave per row.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const T* __restrict__ logits, long long ld, int group,
+                                                          long long rows, int C, int32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const T* x = logits + (r / group) * ld + (r % group) * (long long)C;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = Elem<T>::ld(x + c);
+        if (v > best) { best = v; bi = c; }          // ascending c per lane: the first maximum wins
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) out[r] = bi == 0x7fffffff ? 0 : bi;
+}
+}  // namespace
+
+extern "C" int dsvg_argmax_rows(int32_t dtype, const void* logits, int64_t ld, int32_t group, int64_t rows, int32_t C,
+                                int32_t* out, void* stream) {
+    DSVG_CHECK_ARG(logits && out && rows > 0 && group > 0 && C > 0 && ld >= (int64_t)group * C, "argmax_rows: bad args");
+    const unsigned grid = (unsigned)dsvg_cdiv(rows, 4);
+    if (dtype == DSVG_BF16)
+        hipLaunchKernelGGL(argmax_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)logits, (long long)ld, group, (long long)rows, C, out);
+    else
+        hipLaunchKernelGGL(argmax_rows_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)logits, (long long)ld, group, (long long)rows, C, out);
+    DSVG_LAUNCH_CHECK("argmax_rows");
+    return 0;
+}

@@ -91,6 +91,7 @@ SIGNATURES = {
     "dsvg_match_costs": (c_i32, [c_i32, vp, c_i64, vp, c_i64, vp, c_i64, vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32,
                                  c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, vp, vp, vp]),
     "dsvg_match_assign": (c_i32, [vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp]),
+    "dsvg_argmax_rows": (c_i32, [c_i32, vp, c_i64, c_i32, c_i64, c_i32, vp, vp]),
     "dsvg_probe_trread": (c_i32, [vp, vp, vp]),
 }
 

@@ -817,9 +817,7 @@ class SVGTransformer(nn.Module):
         else:
             res = self.forward(commands_enc, args_enc, commands_dec, args_dec, label=label, z=z,
                                hierarch_logits=hierarch_logits, return_tgt=False)
-            cl, al = res["command_logits"].float(), res["args_logits"].float()
-            commands_y = torch.distributions.Categorical(logits=cl / temperature).sample()
-            args_y = torch.distributions.Categorical(logits=al / temperature).sample()
+            commands_y, args_y = self._sample(res["command_logits"], res["args_logits"], temperature)
             args_y -= 1   # shift due to -1 PAD_VAL
             visibility_y = None
             if self.cfg.decode_stages == 2:
@@ -833,6 +831,21 @@ class SVGTransformer(nn.Module):
             pm = ((commands_y == EOS_ID).cumsum(dim=-1) == 0)
             commands_y = commands_y[pm].reshape(N, -1)
             args_y = args_y[pm].reshape(N, -1, self.cfg.n_args)
+        return commands_y, args_y
+
+    def _sample(self, command_logits, args_logits, temperature):
+        """_sample_categorical (deepsvg/model/utils.py:75-80): a draw from softmax(logits / temperature) per slot.
+        temperature == 0 (an extension: the reference would divide by zero) takes the limit exactly - the arg-max
+        kernel reads the logits in their storage dtype, no fp32 copy / softmax / multinomial over the 2827-wide rows."""
+        if temperature == 0:
+            cs, as_ = command_logits.shape, args_logits.shape
+            cl = command_logits.reshape(-1, cs[-1])
+            al = args_logits.reshape(-1, as_[-2] * as_[-1])
+            cmd = ops.argmax_rows(cl if cl.stride(-1) == 1 else cl.contiguous(), cs[-1]).long().view(cs[:-1])
+            arg = ops.argmax_rows(al if al.stride(-1) == 1 else al.contiguous(), as_[-1], as_[-2]).long().view(as_[:-1])
+            return cmd, arg
+        commands_y = torch.distributions.Categorical(logits=command_logits.float() / temperature).sample()
+        args_y = torch.distributions.Categorical(logits=args_logits.float() / temperature).sample()
         return commands_y, args_y
 
     def _sample_autoregressive(self, commands_enc, args_enc, label, z, temperature):
@@ -854,10 +867,10 @@ class SVGTransformer(nn.Module):
         cam = self.cmd_args_mask.to(dev).bool()
         for _ in range(cfg.max_total_len):
             res = self.forward(None, None, commands_y, args_y, label=label, z=z, return_tgt=False)
-            cl = res["command_logits"][:, :, -1].float()                  # only the newest position is sampled (:434)
-            al = res["args_logits"][:, :, -1].float()
-            cmd_new = torch.distributions.Categorical(logits=cl / temperature).sample()          # (N, 1)
-            arg_new = torch.distributions.Categorical(logits=al / temperature).sample() - 1      # shift due to PAD_VAL
+            # only the newest position is sampled (:434)
+            cmd_new, arg_new = self._sample(res["command_logits"][:, :, -1].contiguous(),
+                                            res["args_logits"][:, :, -1].contiguous(), temperature)   # (N, 1[, n_args])
+            arg_new = arg_new - 1                                                                 # shift due to PAD_VAL
             arg_new[~cam[cmd_new]] = -1                                                           # _make_valid (:432)
             commands_y = torch.cat([commands_y, cmd_new.unsqueeze(-1).float()], dim=-1)
             args_y = torch.cat([args_y, arg_new.unsqueeze(-2).float()], dim=-2)
@@ -919,11 +932,11 @@ class SVGTransformer(nn.Module):
                 h = ops.gemm(xn2, rt.w(L.linear1.weight), bias=L.linear1.bias.detach(), act=ops.RELU)
                 x = ops.gemm(h, rt.w(L.linear2.weight), bias=L.linear2.bias.detach(), res=x1)
             xo, _, _ = ops.layernorm_fwd(x, dec.decoder.norm.weight.detach(), dec.decoder.norm.bias.detach())
-            cl = ops.gemm(xo, rt.w(fcn.command_fcn.weight), bias=fcn.command_fcn.bias.detach()).float()
-            al = ops.gemm(xo, rt.w(fcn.args_fcn.weight), bias=fcn.args_fcn.bias.detach()).float() \
+            cl = ops.gemm(xo, rt.w(fcn.command_fcn.weight), bias=fcn.command_fcn.bias.detach())
+            al = ops.gemm(xo, rt.w(fcn.args_fcn.weight), bias=fcn.args_fcn.bias.detach()) \
                 .view(N, cfg.n_args, self.args_dim)
-            cmd_new = torch.distributions.Categorical(logits=cl / temperature).sample()           # (N,)
-            arg_new = torch.distributions.Categorical(logits=al / temperature).sample() - 1       # (N, n_args)
+            cmd_new, arg_new = self._sample(cl, al, temperature)                                 # (N,), (N, n_args)
+            arg_new = arg_new - 1
             arg_new[~cam[cmd_new]] = -1
             commands_y[:, 0, s] = cmd_new
             args_y[:, 0, s] = arg_new

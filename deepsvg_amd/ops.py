@@ -605,6 +605,17 @@ def match_costs(cmd_logits, args_logits, vis_logits, tgt_commands, tgt_args, cam
     return cost, vis
 
 
+def argmax_rows(logits2d, C, group=1):
+    """logits2d [n_tok, >= group*C] (row-strided view) -> int32 [n_tok * group]: arg-max of every C-wide class slot"""
+    _chk(logits2d)
+    assert logits2d.dim() == 2 and logits2d.stride(1) == 1 and logits2d.shape[1] >= group * C
+    rows = logits2d.shape[0] * group
+    out = torch.empty(rows, dtype=torch.int32, device=logits2d.device)
+    _l.check(_l.load().dsvg_argmax_rows(_dt(logits2d), logits2d.data_ptr(), logits2d.stride(0), group, rows, C,
+                                        out.data_ptr(), _stream()), "dsvg_argmax_rows")
+    return out
+
+
 def match_assign(cost, vis):
     """cost f32 [N, G, Gp], visible int32 [N, G] -> assign [N, Gp], idx [N*Gp], inv [N*Gp] (all int32)"""
     _chk(cost, vis)

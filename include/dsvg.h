@@ -300,6 +300,12 @@ int dsvg_match_costs(int32_t dtype, const void* cmd_logits, int64_t ld_c, const 
 int dsvg_match_assign(const float* cost, const int32_t* visible, int64_t N, int32_t G, int32_t Gp,
                       int32_t* assign, int32_t* idx, int32_t* inv, void* stream);
 
+/* out[r] = argmax_c logits(r, c) for the logical rows r of a [rows, C] matrix stored like the masked-CE operand
+ * (row r at logits + (r / group) * ld + (r % group) * C); ties -> lowest class.  The temperature -> 0 limit of
+ * _sample_categorical (deepsvg/model/utils.py:75-80), used by greedy_sample(temperature=0). */
+int dsvg_argmax_rows(int32_t dtype, const void* logits, int64_t ld, int32_t group, int64_t rows, int32_t C,
+                     int32_t* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Device-side batch assembly.  Replaces, for a whole batch, the per-item chain of
  * SVGTensorDataset.get_data (deepsvg/svgtensor_dataset.py:164-205): SVGTensor.from_data(...).add_eos().add_sos()

@@ -65,6 +65,12 @@ def main():
         return out
     sec = timed(one_shot, 2)
     print(f"C5a one-shot decode from latents (8192 icons, G=8, S=30, bf16): {sec * 1e3:.0f} ms, {N / sec:,.0f} icons/s")
+
+    def one_shot_argmax():
+        return [model.greedy_sample(z=z[i:i + 1024], concat_groups=False, temperature=0) for i in range(0, N, 1024)]
+    sec = timed(one_shot_argmax, 2)
+    print(f"C5a' same with temperature = 0 (arg-max kernel on the bf16 logits instead of the categorical draw): "
+          f"{sec * 1e3:.0f} ms, {N / sec:,.0f} icons/s")
     del model
 
     # ---- C5b -------------------------------------------------------------------------------------------------
@@ -77,6 +83,8 @@ def main():
     sec = timed(lambda: model.greedy_sample(z=z, concat_groups=False), 2)
     print(f"C5b autoregressive sampling, q|k|v cache (8192 icons x 50 tokens, bf16): {sec * 1e3:.0f} ms, "
           f"{N / sec:,.0f} icons/s, {N * 50 / sec:,.0f} tokens/s")
+    sec = timed(lambda: model.greedy_sample(z=z, concat_groups=False, temperature=0), 2)
+    print(f"C5b'' cache + temperature = 0: {sec * 1e3:.0f} ms, {N / sec:,.0f} icons/s, {N * 50 / sec:,.0f} tokens/s")
     model.kv_cache = False
     n2 = 1024
     sec2 = timed(lambda: model.greedy_sample(z=z[:n2], concat_groups=False), 1)

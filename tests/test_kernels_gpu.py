@@ -680,3 +680,17 @@ def test_match_costs_and_assignment(gpu_device, dtype):
     a2, i2, v2 = ops.match_assign(cost2.to(DEV), vis2.to(torch.int32).to(DEV))
     r2, ri2, rv2 = R.match_assign(cost2, vis2.to(torch.int32))
     assert torch.equal(a2.cpu(), r2) and torch.equal(i2.cpu(), ri2) and torch.equal(v2.cpu(), rv2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_argmax_rows(gpu_device, dtype):
+    """arg-max over class slots stored like the masked-CE operand (row-padded buffer, 11 x 257 slots per token)"""
+    T, A, C, ld = 777, 11, 257, 2832
+    buf = _rand(T, ld, dtype=dtype, seed=3)
+    buf[5, 3 * C + 7] = buf[5, 3 * C + 200] = 100.0           # a tie: the lowest class wins
+    got = ops.argmax_rows(buf[:, :A * C], C, A)
+    want = R.argmax_rows(buf[:, :A * C].cpu(), C, A)
+    assert torch.equal(got.cpu(), want)
+    assert int(got[5 * A + 3]) == 7
+    cl = _rand(T, 8, dtype=dtype, seed=4)
+    assert torch.equal(ops.argmax_rows(cl[:, :7], 7).cpu(), R.argmax_rows(cl[:, :7].cpu(), 7))

@@ -351,3 +351,16 @@ def test_autoregressive_cached_sampling_equals_recompute(gpu_device, dtype):
     lo = 0.995 if dtype == torch.float32 else 0.9
     assert same_c >= lo and same_a >= lo, (same_c, same_a)
     assert outs[True][0].unique().numel() > 1
+
+
+def test_greedy_sample_temperature_zero_is_the_argmax(gpu_device):
+    """temperature = 0 (arg-max kernel on the stored logits) against the reference's temperature 1e-4 draw"""
+    cfg = H.build_cfg("hier")
+    model = _hip_model(cfg, H.weights_for(deepsvg_amd.SVGTransformer(cfg), 5)).eval()
+    commands, args = make_batch(8, seed=8)
+    z = model(commands.to(DEV), args.to(DEV), None, None, encode_mode=True).permute(2, 1, 0, 3).contiguous()
+    a = model.greedy_sample(z=z, concat_groups=False, temperature=0)
+    torch.manual_seed(0)
+    b = model.greedy_sample(z=z, concat_groups=False)
+    assert a[0].shape == b[0].shape and a[1].shape == b[1].shape
+    assert (a[0] == b[0]).float().mean().item() > 0.999 and (a[1] == b[1]).float().mean().item() > 0.999

@@ -510,6 +510,11 @@ def match_costs(cmd_logits, args_logits, vis_logits, tgt_commands, tgt_args, cam
     return cost, vis.to(torch.int32)
 
 
+def argmax_rows(logits2d, C, group=1):
+    n = logits2d.shape[0]
+    return logits2d[:, :group * C].float().reshape(n * group, C).argmax(-1).to(torch.int32)
+
+
 def match_assign(cost, vis):
     """scipy's Hungarian solver, as the reference (deepsvg/model/model.py:341-348)"""
     from scipy.optimize import linear_sum_assignment
