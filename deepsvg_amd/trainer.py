@@ -88,8 +88,11 @@ class TrainStep:
         return count / self.world
 
     # ---- one step ------------------------------------------------------------------------------------
-    def _step_body(self, commands, args, label=None):
+    def _step_body(self, commands, args, label=None, dec=None):
+        """dec = (commands_dec, args_dec) when the decoder side takes other tensors than the encoder side (relative
+        targets: model_args = [commands, args, commands, args_rel], deepsvg/model/config.py:52-53)"""
         model = self.model
+        cd, ad = dec if dec is not None else (commands, args)
         ops.advance_step_(self.step_count, self.seed)
         for p in model.store.params:
             p.grad = None
@@ -97,7 +100,7 @@ class TrainStep:
         if self.world > 1 and self.overlap_allreduce:
             model._decoder_grads_ready = self._launch_decoder_bucket    # hooked onto the bottleneck output in forward
         try:
-            out = model(commands, args, commands, args, label=label, params={})
+            out = model(commands, args, cd, ad, label=label, params={})
             ld = self.loss_fn(out, label, weights=self.weights)
             ld["loss"].backward()
         finally:
@@ -119,12 +122,17 @@ class TrainStep:
                         grad_scale=1.0 / self.world)
         return {k: v.detach() for k, v in ld.items()}
 
-    def step(self, commands, args, label=None):
-        """one training step on a batch; `label` (N,) for label-conditioned configs (deepsvg/train.py:94-96)"""
+    def step(self, commands, args, label=None, commands_dec=None, args_dec=None):
+        """one training step on a batch (the body of deepsvg/train.py:92-106): model(commands, args, commands_dec,
+        args_dec, label); the decoder-side tensors default to the encoder-side ones (every config without relative
+        targets); `label` (N,) for label-conditioned configs"""
         if not self._ready:
             self._setup(commands.device)
+        dec = None
+        if commands_dec is not None or args_dec is not None:
+            dec = (commands_dec if commands_dec is not None else commands, args_dec if args_dec is not None else args)
         if not commands.is_cuda:                    # CPU emulation (tests): no streams
-            return self._step_body(commands, args, label)
+            return self._step_body(commands, args, label, dec)
         model = self.model
         main = torch.cuda.current_stream()
         # The layout plan (a few tiny kernels + ONE host read) runs on its own stream so that the host read does not
@@ -137,7 +145,7 @@ class TrainStep:
         if not self.inputs_resident:
             ps.wait_stream(main)
         with torch.cuda.stream(ps):
-            plan = model.make_plan(commands, args, commands, True, args)
+            plan = model.make_plan(commands, args, dec[0] if dec else commands, True, dec[1] if dec else args)
         main.wait_stream(ps)
         for part in ("enc", "dec", "loss"):        # allocated on the plan stream, read by launches on the main stream
             for v in (plan[part] or {}).values():
@@ -147,22 +155,25 @@ class TrainStep:
         if not self.use_graph:
             model._forced_plan = plan
             try:
-                res = self._step_body(commands, args, label)
+                res = self._step_body(commands, args, label, dec)
             finally:
                 model._forced_plan = None
             self._note_layout(plan, commands)
             return res
         key, plan = self._bucketed(plan, commands)
-        key = key + (label is not None,)
+        key = key + (label is not None, dec is not None)
         entry = self._graphs.get(key)
         if entry is None:
-            entry = self._capture(key, commands, args, plan, label)
+            entry = self._capture(key, commands, args, plan, label, dec)
         else:
-            graph, (sc, sa, sl), splan, res = entry
+            graph, (sc, sa, sl, sdec), splan, res = entry
             sc.copy_(commands)
             sa.copy_(args)
             if sl is not None:
                 sl.copy_(label)
+            if sdec is not None:
+                sdec[0].copy_(dec[0])
+                sdec[1].copy_(dec[1])
             for part in ("enc", "dec", "loss"):
                 if splan[part] is not None:
                     for k, v in splan[part].items():
@@ -210,10 +221,11 @@ class TrainStep:
         m.last_head_rows = ((plan["loss"]["n_live"], n_seq * (commands.shape[2] - 1))
                             if plan["loss"] is not None else None)
 
-    def _capture(self, key, commands, args, plan, label=None):
+    def _capture(self, key, commands, args, plan, label=None, dec=None):
         model = self.model
         sc, sa = commands.clone(), args.clone()
         sl = label.clone() if label is not None else None
+        sdec = (dec[0].clone(), dec[1].clone()) if dec is not None else None
         def _static(v):
             if torch.is_tensor(v):
                 return v.clone()
@@ -231,7 +243,7 @@ class TrainStep:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    self._step_body(sc, sa, sl)
+                    self._step_body(sc, sa, sl, sdec)
                 for t, s0 in zip(state, saved):
                     t.copy_(s0)
             torch.cuda.current_stream().wait_stream(side)
@@ -240,10 +252,10 @@ class TrainStep:
                 self._pool = torch.cuda.graph_pool_handle()     # graphs replay one at a time: one shared pool
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self._pool):
-                res = self._step_body(sc, sa, sl)
+                res = self._step_body(sc, sa, sl, sdec)
         finally:
             model._forced_plan = None
-        entry = (g, (sc, sa, sl), splan, res)
+        entry = (g, (sc, sa, sl, sdec), splan, res)
         self._graphs[key] = entry
         return entry
 

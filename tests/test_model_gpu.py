@@ -364,3 +364,22 @@ def test_greedy_sample_temperature_zero_is_the_argmax(gpu_device):
     b = model.greedy_sample(z=z, concat_groups=False)
     assert a[0].shape == b[0].shape and a[1].shape == b[1].shape
     assert (a[0] == b[0]).float().mean().item() > 0.999 and (a[1] == b[1]).float().mean().item() > 0.999
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_autoregressive_training_step(gpu_device, use_graph):
+    """Sketchformer-style config (teacher forcing through the causal kernels, relative decoder targets) through
+    TrainStep: the loss goes down on a fixed batch"""
+    from deepsvg_amd.synthetic import make_batch_onestage
+    from deepsvg_amd.trainer import TrainStep
+    from oracle import batch_assembly_oracle as B
+    cfg = H.build_cfg("sketchformer")
+    model = _hip_model(cfg, H.weights_for(deepsvg_amd.SVGTransformer(cfg), 3), torch.bfloat16).train()
+    commands, args = make_batch_onestage(32, total_len=cfg.max_total_len, seed=9)
+    rel = torch.stack([torch.from_numpy(B.relative_args(commands[i, 0].numpy(), args[i, 0].numpy())) for i in range(32)])
+    args_rel = rel.unsqueeze(1)
+    step = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=1e-3, use_graph=use_graph)
+    commands, args, args_rel = commands.to(DEV), args.to(DEV), args_rel.to(DEV)
+    losses = [float(step.step(commands, args, args_dec=args_rel)["loss"]) for _ in range(12)]
+    assert all(l == l and abs(l) < 1e3 for l in losses), losses
+    assert sum(losses[-3:]) < sum(losses[:3]), losses
