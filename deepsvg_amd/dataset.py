@@ -320,4 +320,5 @@ def load_dataset(cfg):
     """deepsvg/svgtensor_dataset.py:230-233"""
     return SVGTensorDataset(cfg.data_dir, cfg.meta_filepath, cfg.model_args, cfg.max_num_groups, cfg.max_seq_len,
                             cfg.max_total_len, cfg.filter_uni, cfg.filter_platform, cfg.filter_category,
-                            cfg.train_ratio, deferred=getattr(cfg, "collate_fn", None) is device_collate)
+                            cfg.train_ratio, deferred=getattr(cfg, "collate_fn", None) is device_collate,
+                            device=getattr(cfg, "device", "cuda"))

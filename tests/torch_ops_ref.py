@@ -480,6 +480,35 @@ def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1
     return buf[:, :width]
 
 
+def assemble_batch(rows, slot_off, variant, G, L, grouped, want_args=True, want_rel=False, pad_val=-1.0, args_dim=256):
+    """restatement of dsvg_assemble_batch on the packed store (per sequence: SOS, rows, EOS, EOS padding)"""
+    from oracle import batch_assembly_oracle as B
+    N = variant.numel()
+    Gs = 1 if grouped else G
+    cmds = torch.empty(N, Gs, L)
+    args = torch.empty(N, Gs, L, 11) if want_args else None
+    rel = torch.empty(N, Gs, L, 11) if want_rel else None
+    r16 = rows.numpy().astype("float32")
+    off = slot_off.numpy()
+    for n in range(N):
+        v = int(variant[n])
+        for g in range(Gs):
+            lo = off[v * G + (0 if grouped else g)]
+            hi = off[v * G + (G if grouped else g + 1)]
+            c = torch.full((L,), 4.0)
+            a = torch.full((L, 11), float(pad_val))
+            c[0] = 5.0
+            k = min(int(hi - lo), L - 2)
+            c[1:1 + k] = torch.from_numpy(r16[lo:lo + k, 0])
+            a[1:1 + k] = torch.from_numpy(r16[lo:lo + k, 1:])
+            cmds[n, g] = c
+            if want_args:
+                args[n, g] = a
+            if want_rel:
+                rel[n, g] = torch.from_numpy(B.relative_args(c.numpy(), a.numpy(), pad_val, args_dim))
+    return cmds, args, rel
+
+
 def match_costs(cmd_logits, args_logits, vis_logits, tgt_commands, tgt_args, cam, N, G, Gp, n_args, args_dim, n_cmd,
                 eos_id, weights=(2.0, 1.0, 1.0)):
     """plain-torch restatement of dsvg_match_costs (deepsvg/model/model.py:311-339), written per (g, p) pair"""
