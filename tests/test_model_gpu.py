@@ -383,3 +383,45 @@ def test_autoregressive_training_step(gpu_device, use_graph):
     losses = [float(step.step(commands, args, args_dec=args_rel)["loss"]) for _ in range(12)]
     assert all(l == l and abs(l) < 1e3 for l in losses), losses
     assert sum(losses[-3:]) < sum(losses[:3]), losses
+
+
+def test_self_matching_full_size_properties(gpu_device):
+    """BASELINE's batch (512 icons): the assignment is a permutation per icon and - being the exact minimum - costs no
+    more than the identity pairing or any random pairing of the visible targets"""
+    from deepsvg_amd import ops
+    from deepsvg_amd.svgtensor import CMD_ARGS_MASK
+    cfg = H.build_cfg("selfmatch")
+    model = _hip_model(cfg, H.weights_for(deepsvg_amd.SVGTransformer(cfg), 2), torch.bfloat16).eval()
+    commands, args = make_batch(512, seed=12)
+    c, a = commands.to(DEV), args.to(DEV)
+    with torch.no_grad():
+        plain = model(c, a, c, a, return_tgt=False)                         # predictions in their own order
+        G = cfg.num_groups_proposal
+        S = c.shape[-1] - 1
+        cl = plain["command_logits"].reshape(512 * G * S, -1)
+        al = plain["args_logits"].reshape(512 * G * S, -1)
+        vl = plain["visibility_logits"].reshape(512 * G, 2)
+        cost, vis = ops.match_costs(cl, al, vl, c, a, CMD_ARGS_MASK.float().to(DEV), 512, G, G, cfg.n_args,
+                                    model.args_dim, cfg.n_commands, 4)
+        assign, idx, inv = ops.match_assign(cost, vis)
+        matched = model(c, a, c, a)                                         # train-mode call: matched order
+    assert torch.equal(model.last_assignment, assign)
+    assert torch.equal(assign.sort(dim=1).values, torch.arange(G, device=DEV, dtype=assign.dtype).expand(512, G))
+    assert torch.equal(idx[inv.long()], torch.arange(512 * G, device=DEV, dtype=idx.dtype))
+    # output slot j carries prediction assign[j]
+    want = plain["command_logits"].gather(1, assign.long().view(512, G, 1, 1).expand_as(plain["command_logits"]))
+    assert torch.equal(matched["command_logits"], want)
+    # optimality: total cost of the visible targets under the assignment <= identity and <= random pairings
+    cost = torch.nan_to_num(cost, nan=0.0)
+    n_vis = vis.sum(1)
+    rank = (vis.cumsum(1) - 1).clamp_min(0).long()                          # j-th visible target -> slot j
+    picked = assign.long().gather(1, rank)                                  # prediction matched to target g
+    tot = (cost.gather(2, picked.unsqueeze(-1)).squeeze(-1) * vis).sum(1)
+    ident = (cost.diagonal(dim1=1, dim2=2) * vis).sum(1)
+    assert bool((tot <= ident + 1e-4).all())
+    gen = torch.Generator().manual_seed(0)
+    for _ in range(4):
+        perm = torch.stack([torch.randperm(G, generator=gen) for _ in range(512)]).to(DEV)
+        rnd = (cost.gather(2, perm.unsqueeze(-1)).squeeze(-1) * vis).sum(1)
+        assert bool((tot <= rnd + 1e-4).all())
+    assert int(n_vis.min()) >= 1
