@@ -661,7 +661,9 @@ extern "C" int dsvg_masked_mean_bwd(int32_t dtype, const void* dout, const uint6
 }
 
 // ---------------------------------------------------------------------------------------------
-// x[t] += drop(g[t / S])   (improved_transformer.py:131-136), one block per sequence
+// x[t] += drop(g)[t / S]   (improved_transformer.py:131-136), one block per sequence.  The reference applies the dropout
+// to linear_global(memory) - one row per sequence - BEFORE the implicit broadcast, so a dropped (sequence, channel) is
+// dropped at every position: the mask id is b * d + c, drawn once per thread, not per token.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void bcast_add_fwd_kernel(T* __restrict__ x, const T* __restrict__ g, int S, int d, float drop_p,
@@ -669,12 +671,9 @@ __global__ void bcast_add_fwd_kernel(T* __restrict__ x, const T* __restrict__ g,
     const DropCtx dc = drop_make(drop_p, seed, site);
     const long long b = blockIdx.x;
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
-        const float gv = Elem<T>::ld(g + b * d + c);
-        for (int i = 0; i < S; ++i) {
-            const long long t = b * S + i;
-            T* px = x + t * d + c;
-            Elem<T>::st(px, Elem<T>::ld(px) + gv * drop_mult(dc, (uint64_t)t * d + c));
-        }
+        const float gv = Elem<T>::ld(g + b * d + c) * drop_mult(dc, (uint64_t)b * d + c);
+        T* px = x + b * S * d + c;
+        for (int i = 0; i < S; ++i, px += d) Elem<T>::st(px, Elem<T>::ld(px) + gv);
     }
 }
 template <typename T>
@@ -684,11 +683,9 @@ __global__ void bcast_add_bwd_kernel(const T* __restrict__ dx, T* __restrict__ d
     const long long b = blockIdx.x;
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
         float s = 0.f;
-        for (int i = 0; i < S; ++i) {
-            const long long t = b * S + i;
-            s += Elem<T>::ld(dx + t * d + c) * drop_mult(dc, (uint64_t)t * d + c);
-        }
-        Elem<T>::st(dg + b * d + c, s);
+        const T* px = dx + b * S * d + c;
+        for (int i = 0; i < S; ++i, px += d) s += Elem<T>::ld(px);
+        Elem<T>::st(dg + b * d + c, s * drop_mult(dc, (uint64_t)b * d + c));
     }
 }
 extern "C" int dsvg_bcast_add_fwd(int32_t dtype, void* x, const void* g, int64_t n_seq, int32_t S, int32_t d,

@@ -200,9 +200,10 @@ int dsvg_masked_mean_bwd(int32_t dtype, const void* dout, const uint64_t* mask, 
                          int64_t total_rows, void* dx, int64_t n_seq, int32_t S, int32_t d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * x[t,:] += drop(g[t / S, :])      "implicit broadcast" add of linear_global(z)
- * (deepsvg/model/layers/improved_transformer.py:131-136).
- * bwd: dg[b,:] = sum_s (dx*mask)[b*S+s,:]
+ * x[t,:] += drop(g)[t / S, :]      "implicit broadcast" add of linear_global(z)
+ * (deepsvg/model/layers/improved_transformer.py:131-136): the dropout acts on the per-sequence row BEFORE the
+ * broadcast, as in the reference, so one mask element (id b*d + c) covers every position of sequence b.
+ * bwd: dg[b,:] = mask[b,:] * sum_s dx[b*S+s,:]
  * ------------------------------------------------------------------------------------------ */
 int dsvg_bcast_add_fwd(int32_t dtype, void* x, const void* g, int64_t n_seq, int32_t S, int32_t d,
                        float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream);

@@ -379,16 +379,18 @@ def masked_mean_bwd(dout, mask, n_seq, S, seq_off=None, total_rows=None):
 
 
 def bcast_add_fwd_(x, g, n_seq, S, drop_p=0.0, drop_site=0, seed=None):
+    """x[t] += drop(g)[t // S]: the dropout acts on the per-sequence row before the broadcast (mask id = b * d + c)"""
     d = x.shape[1]
-    gv = _f(g).unsqueeze(1).expand(n_seq, S, d).reshape(n_seq * S, d)
-    x.copy_((_f(x) + gv * drop_mult(drop_p, seed, drop_site, _ids(n_seq * S, d, x.device))).to(x.dtype))
+    gd = _f(g) * drop_mult(drop_p, seed, drop_site, _ids(n_seq, d, x.device))
+    gv = gd.unsqueeze(1).expand(n_seq, S, d).reshape(n_seq * S, d)
+    x.copy_((_f(x) + gv).to(x.dtype))
     return x
 
 
 def bcast_add_bwd(dx, n_seq, S, drop_p=0.0, drop_site=0, seed=None):
     d = dx.shape[1]
-    g = _f(dx) * drop_mult(drop_p, seed, drop_site, _ids(n_seq * S, d, dx.device))
-    return g.view(n_seq, S, d).sum(1).to(dx.dtype)
+    g = _f(dx).view(n_seq, S, d).sum(1) * drop_mult(drop_p, seed, drop_site, _ids(n_seq, d, dx.device))
+    return g.to(dx.dtype)
 
 
 def loss_targets(tgt_commands, tgt_args, cmd_args_mask, eos_id=4):
