@@ -55,6 +55,14 @@ def build_cfg(kind):
         cfg = C.OneStageOneShot()
         cfg.max_total_len = 50
         cfg.use_vae = False
+    elif kind == "onestage_label":
+        cfg = C.OneStageOneShot()
+        cfg.max_total_len = 50
+        cfg.label_condition = True
+    elif kind == "hier_rel":
+        cfg = C.Hierarchical()
+        cfg.rel_targets = True
+        cfg.use_vae = False
     elif kind == "sketchformer":    # deepsvg/model/config.py:74-80
         cfg = C.Sketchformer()
         cfg.max_total_len = 50
