@@ -21,23 +21,23 @@ __global__ void loss_targets_kernel(const float* __restrict__ tc, const float* _
     if (b >= n_seq) return;
     const int S = S1 - 1;
     const float* row = tc + b * S1;
-    uint64_t pm = 0;   // S1 <= 64
-    int n_eos = 0;
-    bool seen = false;
-    for (int s = 0; s < S1; ++s) {
+    // padding mask = positions before the first EOS (utils.py:20-24), `extended` by the mask shifted 3 positions
+    // (utils.py:25-30, canonical non-aliased reading): position t is on iff t < fe or (t >= 3 and t - 3 < fe)
+    int n_eos = 0, fe = S1;
+    for (int s = S1 - 1; s >= 0; --s) {
         const bool e = ((int)row[s] == eos);
-        seen |= e;
         n_eos += e;
-        if (!seen) pm |= (1ull << s);
+        if (e) fe = s;
     }
-    const uint64_t ext = pm | (pm << 3);
     const int vis = (n_eos < S1 - 1) ? 1 : 0;
     vis_tgt[b] = vis;
     for (int s = 0; s < S; ++s) {
         int c = (int)row[s + 1];
         c = min(max(c, 0), n_cmd - 1);
         cmd_tgt[b * S + s] = c;
-        cmd_w[b * S + s] = (((ext >> (s + 1)) & 1ull) && vis) ? 1.f : 0.f;
+        const int t = s + 1;
+        const bool ext = t < fe || (t >= 3 && t - 3 < fe);
+        cmd_w[b * S + s] = (ext && vis) ? 1.f : 0.f;
         for (int a = 0; a < n_args; ++a) {
             arg_tgt[(b * S + s) * n_args + a] = (int)ta[(b * S1 + s + 1) * n_args + a] + 1;
             arg_w[(b * S + s) * n_args + a] = cam[c * n_args + a];
@@ -51,7 +51,7 @@ extern "C" int dsvg_loss_targets(const float* tgt_commands, const float* tgt_arg
                                  void* stream) {
     DSVG_CHECK_ARG(tgt_commands && tgt_args && cmd_args_mask && cmd_tgt && cmd_w && arg_tgt && arg_w && vis_tgt,
                    "loss_targets: null pointer");
-    DSVG_CHECK_ARG(n_seq > 0 && S1 > 1 && S1 <= 61, "loss_targets: bad shape (S1=%d)", S1);
+    DSVG_CHECK_ARG(n_seq > 0 && S1 > 1 && S1 <= 4096, "loss_targets: bad shape (S1=%d)", S1);
     hipLaunchKernelGGL(loss_targets_kernel, dim3(dsvg_cdiv(n_seq, 64)), dim3(64), 0, (hipStream_t)stream, tgt_commands,
                        tgt_args, cmd_args_mask, (long long)n_seq, S1, n_args, n_cmd, eos_id, cmd_tgt, cmd_w, arg_tgt,
                        arg_w, vis_tgt);

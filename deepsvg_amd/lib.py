@@ -88,6 +88,11 @@ SIGNATURES = {
                                     vp]),
     "dsvg_attention_causal_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
     "dsvg_attention_causal_bwd": (c_i32, [c_i32, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
+    "dsvg_seq_lens": (c_i32, [vp, c_i64, c_i32, c_i32, vp, vp]),
+    "dsvg_attention_long_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_f32, c_u32, vp, vp]),
+    "dsvg_attention_long_bwd": (c_i32, [c_i32, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_f32, c_u32, vp, vp]),
+    "dsvg_prefix_mean_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, vp]),
+    "dsvg_prefix_mean_bwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, vp]),
     "dsvg_match_costs": (c_i32, [c_i32, vp, c_i64, vp, c_i64, vp, c_i64, vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32,
                                  c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, vp, vp, vp]),
     "dsvg_match_assign": (c_i32, [vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp]),

@@ -362,9 +362,14 @@ class SVGTransformer(nn.Module):
             raise NotImplementedError("model_type='lstm' (SketchRNN baseline) is outside the MI355X hot path")
         if cfg.pred_mode not in ("one_shot", "autoregressive"):
             raise ValueError(f"unknown pred_mode {cfg.pred_mode!r}")
-        if cfg.pred_mode == "autoregressive" and (cfg.decode_stages != 1 or cfg.max_total_len + 1 > 64):
-            raise NotImplementedError("autoregressive decoding is built for the one-stage decoder with max_total_len <= "
-                                      "63 (the causal attention kernel holds a sequence's key mask in 64 bits)")
+        if cfg.pred_mode == "autoregressive" and cfg.decode_stages != 1:
+            raise NotImplementedError("autoregressive decoding is built for the one-stage decoder")
+        longest = (cfg.max_total_len if cfg.encode_stages == 1 or cfg.decode_stages == 1 else cfg.max_seq_len) + 2
+        if longest > 256:
+            raise NotImplementedError(f"sequences of {longest} tokens: the long-sequence attention kernel holds one "
+                                      "sequence per workgroup in LDS, at most 256 tokens")
+        if (cfg.encode_stages == 2 or cfg.decode_stages == 2) and cfg.max_seq_len + 2 > 64:
+            raise NotImplementedError("two-stage configs are built for groups of at most 62 commands")
         if cfg.d_model // cfg.n_heads != 32 or cfg.d_model % cfg.n_heads:
             raise NotImplementedError("the attention kernel is specialised for head_dim == 32")
         self.args_dim = 2 * cfg.args_dim if cfg.rel_targets else cfg.args_dim + 1

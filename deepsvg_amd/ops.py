@@ -274,6 +274,13 @@ def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site
     assert qkv.is_contiguous() and qkv.shape[1] == 3 * 32 * n_heads, "attention needs head_dim == 32"
     assert (rows >= n_seq * S) if seq_off is None else (key_mask is None and seq_off.numel() == n_seq + 1)
     out = torch.empty((rows, 32 * n_heads), dtype=qkv.dtype, device=qkv.device)
+    if S > 64:      # long sequences: key_mask holds valid-prefix lengths (build_masks)
+        assert seq_off is None and rows == n_seq * S and (key_mask is None or key_mask.dtype == torch.int32)
+        _l.check(_l.load().dsvg_attention_long_fwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), out.data_ptr(), n_seq, S,
+                                                   n_heads, float(scale), 1 if causal else 0, float(drop_p),
+                                                   int(drop_site), _p(seed) if drop_p > 0 else None, _stream()),
+                 "dsvg_attention_long_fwd")
+        return out
     if causal:
         assert seq_off is None and rows == n_seq * S
         _l.check(_l.load().dsvg_attention_causal_fwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), out.data_ptr(), n_seq, S,
@@ -293,6 +300,13 @@ def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, dro
     assert qkv.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype
     assert seq_off is None or (key_mask is None and seq_off.numel() == n_seq + 1)
     dqkv = torch.empty_like(qkv)
+    if S > 64:
+        assert seq_off is None and qkv.shape[0] == n_seq * S and (key_mask is None or key_mask.dtype == torch.int32)
+        _l.check(_l.load().dsvg_attention_long_bwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), dout.data_ptr(),
+                                                   dqkv.data_ptr(), n_seq, S, n_heads, float(scale), 1 if causal else 0,
+                                                   float(drop_p), int(drop_site), _p(seed) if drop_p > 0 else None,
+                                                   _stream()), "dsvg_attention_long_bwd")
+        return dqkv
     if causal:
         assert seq_off is None and qkv.shape[0] == n_seq * S
         _l.check(_l.load().dsvg_attention_causal_bwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), dout.data_ptr(),
@@ -310,10 +324,25 @@ def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, dro
 # ------------------------------------------------------------------------------------------------
 # masks / embedding / positional / pooling
 # ------------------------------------------------------------------------------------------------
-def build_masks(commands, S, G=0, eos_id=4, want_group_mask=False):
-    """commands: float32 [n_seq, S] -> key_mask int64[n_seq], seq_visible int32[n_seq], group_mask int64[n_seq/G]"""
+def seq_lens(commands, S, eos_id=4):
+    """commands float32 [n_seq, S] -> int32 [n_seq]: index of the first EOS (S if none) = number of valid keys"""
     _chk(commands)
     assert commands.dtype == torch.float32 and commands.is_contiguous()
+    n_seq = commands.numel() // S
+    lens = torch.empty(n_seq, dtype=torch.int32, device=commands.device)
+    _l.check(_l.load().dsvg_seq_lens(commands.data_ptr(), n_seq, S, eos_id, lens.data_ptr(), _stream()), "dsvg_seq_lens")
+    return lens
+
+
+def build_masks(commands, S, G=0, eos_id=4, want_group_mask=False):
+    """commands: float32 [n_seq, S] -> key_mask int64[n_seq], seq_visible int32[n_seq], group_mask int64[n_seq/G].
+    S > 64 (one-stage / autoregressive sequences): the key mask is returned as valid-prefix LENGTHS (int32 [n_seq]),
+    which attention_fwd/bwd and masked_mean_fwd/bwd accept in its place; no group masks at that length."""
+    _chk(commands)
+    assert commands.dtype == torch.float32 and commands.is_contiguous()
+    if S > 64:
+        assert not want_group_mask
+        return seq_lens(commands, S, eos_id), None, None
     n_seq = commands.numel() // S
     dev = commands.device
     key_mask = torch.empty(n_seq, dtype=torch.int64, device=dev)
@@ -402,6 +431,11 @@ def masked_mean_fwd(x, mask, n_seq, S, seq_off=None):
     assert x.is_contiguous() and (mask is not None or seq_off is not None)
     d = x.shape[1]
     out = torch.empty((n_seq, d), dtype=x.dtype, device=x.device)
+    if S > 64:      # long sequences: `mask` holds valid-prefix lengths (build_masks)
+        assert seq_off is None and mask.dtype == torch.int32
+        _l.check(_l.load().dsvg_prefix_mean_fwd(_dt(x), x.data_ptr(), mask.data_ptr(), out.data_ptr(), n_seq, S, d,
+                                                _stream()), "dsvg_prefix_mean_fwd")
+        return out
     _l.check(_l.load().dsvg_masked_mean_fwd(_dt(x), x.data_ptr(), _p(mask), _p(seq_off), out.data_ptr(), n_seq, S, d,
                                             _stream()), "dsvg_masked_mean_fwd")
     return out
@@ -413,6 +447,11 @@ def masked_mean_bwd(dout, mask, n_seq, S, seq_off=None, total_rows=None):
     d = dout.shape[1]
     rows = n_seq * S if seq_off is None else int(total_rows)
     dx = torch.empty((rows, d), dtype=dout.dtype, device=dout.device)
+    if S > 64:
+        assert seq_off is None and mask.dtype == torch.int32
+        _l.check(_l.load().dsvg_prefix_mean_bwd(_dt(dout), dout.data_ptr(), mask.data_ptr(), dx.data_ptr(), n_seq, S, d,
+                                                _stream()), "dsvg_prefix_mean_bwd")
+        return dx
     _l.check(_l.load().dsvg_masked_mean_bwd(_dt(dout), dout.data_ptr(), _p(mask), _p(seq_off), rows, dx.data_ptr(),
                                             n_seq, S, d, _stream()), "dsvg_masked_mean_bwd")
     return dx

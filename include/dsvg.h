@@ -280,6 +280,27 @@ int dsvg_attention_causal_bwd(int32_t dtype, const void* qkv, const uint64_t* ke
                               uint32_t drop_site, const uint64_t* seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Sequences of more than 64 tokens (one-stage / autoregressive configs at the reference's default
+ * max_total_len = 240, deepsvg/model/config.py:43,74-89).  The command masks are "before the first EOS"
+ * (deepsvg/model/utils.py:7-32), i.e. a valid-prefix LENGTH per sequence instead of a 64-bit word:
+ *   seq_lens:       lens[b] = index of the first EOS of commands[b, :] (S if there is none)
+ *   attention_long: same contract as dsvg_attention_fwd/bwd on the dense layout (keys j < seq_len[b], NULL = all;
+ *                   causal != 0: additionally j <= i), S <= 256, same dropout element ids
+ *   prefix_mean:    out[b,:] = mean_{s < lens[b]} x[b*S + s, :]  (deepsvg/model/model.py:137) and its backward
+ * ------------------------------------------------------------------------------------------ */
+int dsvg_seq_lens(const float* commands, int64_t n_seq, int32_t S, int32_t eos_id, int32_t* lens, void* stream);
+int dsvg_attention_long_fwd(int32_t dtype, const void* qkv, const int32_t* seq_len, void* out, int64_t n_seq, int32_t S,
+                            int32_t n_heads, float scale, int32_t causal, float drop_p, uint32_t drop_site,
+                            const uint64_t* seed, void* stream);
+int dsvg_attention_long_bwd(int32_t dtype, const void* qkv, const int32_t* seq_len, const void* dout, void* dqkv,
+                            int64_t n_seq, int32_t S, int32_t n_heads, float scale, int32_t causal, float drop_p,
+                            uint32_t drop_site, const uint64_t* seed, void* stream);
+int dsvg_prefix_mean_fwd(int32_t dtype, const void* x, const int32_t* lens, void* out, int64_t n_seq, int32_t S, int32_t d,
+                         void* stream);
+int dsvg_prefix_mean_bwd(int32_t dtype, const void* dout, const int32_t* lens, void* dx, int64_t n_seq, int32_t S,
+                         int32_t d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Hungarian self-matching (HierarchicalSelfMatching, deepsvg/model/config.py:101-108):
  * SVGTransformer.perfect_matching, deepsvg/model/model.py:311-350.
  *  match_costs: cost[n, g, p] = w_args * mean_{masked (s,a)} CE(args_logits[n,p,s,a,:], tgt_args[n,g,s+1,a] + 1)

@@ -58,6 +58,12 @@ def build_cfg(kind):
         cfg = ref_cfg.OneStageOneShot()
         cfg.max_total_len = 50
         cfg.use_vae = False
+    elif kind == "onestage240":     # OneStageOneShot as the reference defines it: max_total_len = 240 (242-token sequences)
+        cfg = ref_cfg.OneStageOneShot()
+        cfg.use_vae = False
+    elif kind == "sketchformer240":  # Sketchformer as the reference defines it (241-token causal decoder)
+        cfg = ref_cfg.Sketchformer()
+        cfg.use_vae = False
     elif kind == "onestage_label":  # SURVEY.md C4 with the optional label conditioning (one-stage, VAE, n_labels = 100)
         cfg = ref_cfg.OneStageOneShot()
         cfg.max_total_len = 50
@@ -88,7 +94,7 @@ def run_case(name, kind, n, seed, wseed):
     model = RefModel(cfg)
     sd = det_state_dict(model, seed=wseed)
     model.load_state_dict(sd)
-    if kind in ("onestage", "sketchformer", "onestage_label"):
+    if kind in ("onestage", "sketchformer", "onestage_label", "onestage240", "sketchformer240"):
         commands, args = make_batch_onestage(n, total_len=cfg.max_total_len, seed=seed)
     else:
         commands, args = make_batch(n, G=cfg.max_num_groups, S=cfg.max_seq_len, seed=seed)
@@ -244,7 +250,8 @@ if __name__ == "__main__":
                "hier_vae_n3": ("hier_vae", 3, 13, 1234), "onestage50_n3": ("onestage", 3, 14, 1234),
                "fonts_label_n4": ("fonts", 4, 15, 1234), "selfmatch_n6": ("selfmatch", 6, 16, 1234),
                "sketchformer50_n4": ("sketchformer", 4, 17, 1234), "onestage50_label_n3": ("onestage_label", 3, 18, 1234),
-               "hier_rel_n3": ("hier_rel", 3, 19, 1234)}
+               "hier_rel_n3": ("hier_rel", 3, 19, 1234), "onestage240_n2": ("onestage240", 2, 20, 1234),
+               "sketchformer240_n2": ("sketchformer240", 2, 21, 1234)}
         for nm in sys.argv[1:]:
             run_case(nm, *ALL[nm])
         sys.exit(0)
@@ -257,3 +264,5 @@ if __name__ == "__main__":
     run_case("sketchformer50_n4", "sketchformer", 4, 17, 1234)
     run_case("onestage50_label_n3", "onestage_label", 3, 18, 1234)
     run_case("hier_rel_n3", "hier_rel", 3, 19, 1234)
+    run_case("onestage240_n2", "onestage240", 2, 20, 1234)
+    run_case("sketchformer240_n2", "sketchformer240", 2, 21, 1234)

@@ -55,6 +55,12 @@ def build_cfg(kind):
         cfg = C.OneStageOneShot()
         cfg.max_total_len = 50
         cfg.use_vae = False
+    elif kind == "onestage240":
+        cfg = C.OneStageOneShot()
+        cfg.use_vae = False
+    elif kind == "sketchformer240":
+        cfg = C.Sketchformer()
+        cfg.use_vae = False
     elif kind == "onestage_label":
         cfg = C.OneStageOneShot()
         cfg.max_total_len = 50

@@ -694,3 +694,60 @@ def test_argmax_rows(gpu_device, dtype):
     assert int(got[5 * A + 3]) == 7
     cl = _rand(T, 8, dtype=dtype, seed=4)
     assert torch.equal(ops.argmax_rows(cl[:, :7], 7).cpu(), R.argmax_rows(cl[:, :7].cpu(), 7))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sequences of more than 64 tokens (csrc/long_seq.hip)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S,n_seq,masked,causal", [(65, 5, True, False), (100, 4, False, True), (242, 6, True, False),
+                                                   (241, 5, True, True), (256, 3, False, False), (130, 7, True, True)])
+def test_attention_long(gpu_device, dtype, S, n_seq, masked, causal):
+    H = 8
+    qkv = _rand(n_seq * S, 3 * 32 * H, dtype=dtype, seed=S + 60)
+    lens = None
+    if masked:
+        g = torch.Generator().manual_seed(S)
+        lens = torch.randint(1, S + 1, (n_seq,), generator=g).to(torch.int32)
+        lens[0], lens[-1] = S, 1
+        lens = lens.to(DEV)
+    scale = 32 ** -0.5
+    seed = _seed_tensor(0x13572468ACE02468)
+    for p in (0.0, 0.1):
+        o = ops.attention_fwd(qkv, lens, n_seq, S, H, scale, p, 29, seed, causal=causal)
+        orf = R.attention_fwd(qkv.float(), lens, n_seq, S, H, scale, p, 29, seed, causal=causal)
+        _close(o, orf, 5e-6 if dtype == torch.float32 else 1.5e-2, f"long attn fwd S={S} p={p}")
+        do = _rand(n_seq * S, 32 * H, dtype=dtype, seed=S + 61)
+        dq = ops.attention_bwd(qkv, lens, do, n_seq, S, H, scale, p, 29, seed, causal=causal)
+        dqr = R.attention_bwd(qkv.float(), lens, do.float(), n_seq, S, H, scale, p, 29, seed, causal=causal)
+        _close(dq, dqr, 2e-5 if dtype == torch.float32 else 2e-2, f"long attn bwd S={S} p={p}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_long_sequence_masks_mean_and_targets(gpu_device, dtype):
+    from deepsvg_amd.synthetic import make_batch_onestage
+    from deepsvg_amd.svgtensor import CMD_ARGS_MASK
+    n, T = 9, 240
+    commands, args = make_batch_onestage(n, total_len=T, seed=4)
+    commands[0, 0, 1:] = 4                                   # EOS right after SOS
+    commands[1, 0, :] = 2
+    commands[1, 0, 0] = 5                                    # no EOS at all
+    S = T + 2
+    cmd = commands.view(n, S).to(DEV)
+    lens, vis, gm = ops.build_masks(cmd, S, 0, 4)
+    want, _, _ = R.build_masks(cmd.cpu(), S, 0, 4)
+    assert vis is None and gm is None and lens.dtype == torch.int32 and torch.equal(lens.cpu(), want)
+    assert int(lens[0]) == 1 and int(lens[1]) == S
+    x = _rand(n * S, 256, dtype=dtype, seed=9)
+    _close(ops.masked_mean_fwd(x, lens, n, S), R.masked_mean_fwd(x.float().cpu(), want, n, S).to(DEV),
+           1e-6 if dtype == torch.float32 else 1e-2, "prefix mean fwd")
+    dz = _rand(n, 256, dtype=dtype, seed=10)
+    _close(ops.masked_mean_bwd(dz, lens, n, S), R.masked_mean_bwd(dz.float().cpu(), want, n, S).to(DEV),
+           1e-6 if dtype == torch.float32 else 1e-2, "prefix mean bwd")
+    if dtype == torch.float32:
+        tc = commands.view(n, S).to(DEV)
+        ta = args.view(n, S, 11).to(DEV)
+        got = ops.loss_targets(tc, ta, CMD_ARGS_MASK.float().to(DEV), 4)
+        ref = R.loss_targets(tc.cpu(), ta.cpu(), CMD_ARGS_MASK.float(), 4)
+        for a, b, name in zip(got, ref, ("cmd_tgt", "cmd_w", "arg_tgt", "arg_w", "vis_tgt")):
+            assert torch.equal(a.cpu().reshape(-1).float(), b.reshape(-1).float()), name

@@ -160,8 +160,10 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, res=None, dgamma=None, dbeta=None
 
 
 def _mask_bits(mask, S):
-    """int64 [n] bitmask -> bool [n, S]"""
+    """int64 [n] bitmask (S <= 64) or int32 [n] valid-prefix lengths (longer sequences) -> bool [n, S]"""
     bits = torch.arange(S, device=mask.device, dtype=torch.int64)
+    if mask.dtype == torch.int32:
+        return bits.unsqueeze(0) < mask.long().unsqueeze(1)
     return ((mask.unsqueeze(1) >> bits) & 1).bool()
 
 
@@ -262,7 +264,15 @@ def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, dro
     return out.to(qkv.dtype)
 
 
+def seq_lens(commands, S, eos_id=4):
+    valid = (commands.view(-1, S).long() == eos_id).cumsum(1) == 0
+    return valid.sum(1).to(torch.int32)
+
+
 def build_masks(commands, S, G=0, eos_id=4, want_group_mask=False):
+    if S > 64:
+        assert not want_group_mask
+        return seq_lens(commands, S, eos_id), None, None
     cmd = commands.view(-1, S)
     n_seq = cmd.shape[0]
     is_eos = (cmd.long() == eos_id)
