@@ -376,30 +376,36 @@ __global__ __launch_bounds__(256) void embed_scatter_row_kernel(const float* __r
                                                                 const int* __restrict__ groups,
                                                                 const T* __restrict__ dR, float* __restrict__ part_cmd,
                                                                 float* __restrict__ part_grp, long long T_tok, int d,
-                                                                int n_cmd, int n_groups) {
-    extern __shared__ float acc[];   // [n_cmd * d] then [n_groups * d]
+                                                                int n_cmd, int n_groups, int g_lo, int g_win) {
+    // one pass covers the group-table rows [g_lo, g_lo + g_win) (a long group table - the autoregressive decoder's has
+    // max_total_len + 2 rows - does not fit LDS in one piece); the command table rides on the first pass
+    extern __shared__ float acc[];   // [n_cmd * d] then [g_win * d]
     float* acc_c = acc;
     float* acc_g = acc + n_cmd * d;
-    for (int i = threadIdx.x; i < (n_cmd + n_groups) * d; i += 256) acc[i] = 0.f;
+    const bool do_cmd = g_lo == 0;
+    for (int i = threadIdx.x; i < (n_cmd + g_win) * d; i += 256) acc[i] = 0.f;
     __syncthreads();
     const long long t0 = (long long)blockIdx.x * ES_TOK_PER_BLOCK;
     const long long t1 = min(T_tok, t0 + ES_TOK_PER_BLOCK);
     for (long long t = t0; t < t1; ++t) {
         int ic = (int)commands[t];
         ic = min(max(ic, 0), n_cmd - 1);
-        const int ig = part_grp ? groups[t] : 0;
+        const int ig = part_grp ? groups[t] - g_lo : -1;
+        const bool in_win = ig >= 0 && ig < g_win;
         for (int c = threadIdx.x; c < d; c += 256) {
             const float g = Elem<T>::ld(dR + t * d + c);
             if (g != 0.f) {     // column c of every table row belongs to this thread alone: plain read-modify-write
-                acc_c[ic * d + c] += g;
-                if (part_grp) acc_g[ig * d + c] += g;
+                if (do_cmd) acc_c[ic * d + c] += g;
+                if (in_win) acc_g[ig * d + c] += g;
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_cmd * d; i += 256) part_cmd[(size_t)blockIdx.x * n_cmd * d + i] = acc_c[i];
+    if (do_cmd)
+        for (int i = threadIdx.x; i < n_cmd * d; i += 256) part_cmd[(size_t)blockIdx.x * n_cmd * d + i] = acc_c[i];
     if (part_grp)
-        for (int i = threadIdx.x; i < n_groups * d; i += 256) part_grp[(size_t)blockIdx.x * n_groups * d + i] = acc_g[i];
+        for (int i = threadIdx.x; i < g_win * d; i += 256)
+            part_grp[(size_t)blockIdx.x * n_groups * d + (size_t)g_lo * d + i] = acc_g[i];
 }
 
 extern "C" int64_t dsvg_embed_scatter_workspace_bytes(int64_t T_tok, int32_t n_args, int32_t E, int32_t d,
@@ -426,24 +432,33 @@ extern "C" int dsvg_embed_scatter(int32_t dtype, const float* commands, const fl
     float* part_cmd = part_arg + (size_t)nb * tab;
     float* part_grp = n_groups ? part_cmd + (size_t)nb * n_cmd * d : nullptr;
     const size_t lds_a = (size_t)tab * sizeof(float);
-    const size_t lds_r = (size_t)(n_cmd + n_groups) * d * sizeof(float);
-    DSVG_CHECK_ARG(lds_a <= 160 * 1024 && lds_r <= 160 * 1024, "embed_scatter: tables too large for LDS");
+    // group-table rows per pass: what fits 128 KiB next to the command table
+    int g_cap = (int)((128 * 1024) / ((size_t)d * sizeof(float))) - n_cmd;
+    DSVG_CHECK_ARG(lds_a <= 160 * 1024 && g_cap >= 1, "embed_scatter: tables too large for LDS");
+    const int g_win0 = n_groups < g_cap ? n_groups : g_cap;
+    const size_t lds_r = (size_t)(n_cmd + g_win0) * d * sizeof(float);
     if (dtype == DSVG_F32) {
         auto ka = embed_scatter_arg_kernel<float>;
         auto kr = embed_scatter_row_kernel<float>;
         DSVG_ENSURE_LDS(ka, lds_a);
         DSVG_ENSURE_LDS(kr, lds_r);
         hipLaunchKernelGGL(ka, dim3(nb), dim3(256), lds_a, st, args, (const float*)dA, part_arg, (long long)T_tok, n_args, E, n_argvals);
-        hipLaunchKernelGGL(kr, dim3(nb), dim3(256), lds_r, st, commands, groups, (const float*)dR, part_cmd, part_grp,
-                           (long long)T_tok, d, n_cmd, n_groups);
+        for (int g_lo = 0; g_lo == 0 || g_lo < n_groups; g_lo += g_cap) {
+            const int win = n_groups - g_lo < g_cap ? n_groups - g_lo : g_cap;
+            hipLaunchKernelGGL(kr, dim3(nb), dim3(256), lds_r, st, commands, groups, (const float*)dR, part_cmd, part_grp,
+                               (long long)T_tok, d, n_cmd, n_groups, g_lo, win > 0 ? win : 0);
+        }
     } else if (dtype == DSVG_BF16) {
         auto ka = embed_scatter_arg_kernel<bf16_t>;
         auto kr = embed_scatter_row_kernel<bf16_t>;
         DSVG_ENSURE_LDS(ka, lds_a);
         DSVG_ENSURE_LDS(kr, lds_r);
         hipLaunchKernelGGL(ka, dim3(nb), dim3(256), lds_a, st, args, (const bf16_t*)dA, part_arg, (long long)T_tok, n_args, E, n_argvals);
-        hipLaunchKernelGGL(kr, dim3(nb), dim3(256), lds_r, st, commands, groups, (const bf16_t*)dR, part_cmd, part_grp,
-                           (long long)T_tok, d, n_cmd, n_groups);
+        for (int g_lo = 0; g_lo == 0 || g_lo < n_groups; g_lo += g_cap) {
+            const int win = n_groups - g_lo < g_cap ? n_groups - g_lo : g_cap;
+            hipLaunchKernelGGL(kr, dim3(nb), dim3(256), lds_r, st, commands, groups, (const bf16_t*)dR, part_cmd, part_grp,
+                               (long long)T_tok, d, n_cmd, n_groups, g_lo, win > 0 ? win : 0);
+        }
     } else { dsvg_set_error("embed_scatter: bad dtype"); return -1; }
     DSVG_LAUNCH_CHECK("embed_scatter");
     int rc = dsvg_reduce_partials_strided(part_arg, nb, tab, tab, d_arg_embed, 0, st);
