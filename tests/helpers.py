@@ -90,6 +90,18 @@ def golden_args_dec(g, args):
     return torch.from_numpy(g["args_dec"]) if "args_dec" in g else args
 
 
+def check_sampled_sequences(cy, ay, g):
+    """autoregressive samples against the reference's: the commands exactly; the arguments through their increments
+    along the sequence - the draw at temperature 1e-4 is an arg-max except where two logits tie within ~1e-3, and one
+    flipped relative argument shifts every later absolute coordinate (cumulative sum, model.py:461-479)"""
+    want_c, want_a = torch.from_numpy(g["sample_commands"]), torch.from_numpy(g["sample_args"])
+    assert torch.equal(cy.cpu(), want_c)
+    got_d = torch.diff(ay.cpu().long(), dim=-2, prepend=torch.zeros_like(want_a[..., :1, :]))
+    want_d = torch.diff(want_a.long(), dim=-2, prepend=torch.zeros_like(want_a[..., :1, :]))
+    same = (got_d == want_d).float().mean().item()
+    assert same > 0.99, f"only {same:.4f} of the sampled argument increments agree with the reference"
+
+
 def golden_label(g):
     """class labels of a label-conditioned fixture (None otherwise)"""
     return torch.from_numpy(g["label"]) if "label" in g else None

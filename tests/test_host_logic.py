@@ -48,8 +48,7 @@ def test_model_matches_golden_with_emulated_ops(name, emulated_ops):
         assert torch.equal(model.last_assignment.long(), torch.from_numpy(g["assignment"]))
     if "sample_commands" in g:  # autoregressive sampling, the whole batch at once vs the reference's icon-by-icon loop
         cy, ay = model.greedy_sample(commands, args, None, None, concat_groups=False)
-        assert torch.equal(cy, torch.from_numpy(g["sample_commands"]))
-        assert torch.equal(ay, torch.from_numpy(g["sample_args"]))
+        H.check_sampled_sequences(cy, ay, g)
     z = model(commands, args, commands, args, label=label, encode_mode=True) if eps is None else None
     if z is not None:
         assert z.shape == tuple(g["z"].shape)

@@ -56,8 +56,7 @@ def test_fp32_model_matches_reference_golden(gpu_device, name, packed):
     H.check_against_golden(g, out, ld, grads, logit_rtol=1e-3, logit_atol=1e-5, loss_tol=1e-4, grad_norm_rtol=1e-3)
     if "sample_commands" in g:  # autoregressive sampling, the whole batch at once vs the reference's icon-by-icon loop
         cy, ay = model.greedy_sample(commands.to(DEV), args.to(DEV), None, None, concat_groups=False)
-        assert torch.equal(cy.cpu(), torch.from_numpy(g["sample_commands"]))
-        assert torch.equal(ay.cpu(), torch.from_numpy(g["sample_args"]))
+        H.check_sampled_sequences(cy, ay, g)
     if "assignment" in g:       # Hungarian self-matching: the assignment the reference's perfect_matching returned
         assert torch.equal(model.last_assignment.long().cpu(), torch.from_numpy(g["assignment"]))
     if eps is None:
