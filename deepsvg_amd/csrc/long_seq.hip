@@ -70,6 +70,76 @@ __global__ __launch_bounds__(AL_THREADS) void attn_long_fwd_kernel(const T* __re
     }
 }
 
+// One query row per (sequence, head): the incremental decoding step (query = the newest token `row`, keys = the cached
+// rows j <= row that the length mask allows).  Lane j scores key j; block-wide max / sum; 32 lanes then accumulate the
+// output columns.  O(S) per step instead of the O(S^2) of re-running every query row.
+template <typename T>
+__global__ __launch_bounds__(AL_THREADS) void attn_long_row_kernel(const T* __restrict__ qkv,
+                                                                   const int32_t* __restrict__ seq_len,
+                                                                   T* __restrict__ out, int S, int H, float scale,
+                                                                   int row, float drop_p, uint32_t site,
+                                                                   const uint64_t* seed) {
+    extern __shared__ float sm[];
+    float* Vs = sm;                     // [S][33]
+    float* pr = Vs + S * AL_LD;         // [S] probabilities (already multiplied by the dropout mask)
+    __shared__ float red[AL_THREADS / 64];
+    __shared__ float bc[2];
+    const int b = blockIdx.x, h = blockIdx.y, d = H * 32;
+    const T* base = qkv + (size_t)b * S * 3 * d + h * 32;
+    const int len = seq_len ? min(max(seq_len[b], 0), S) : S;
+    const int jend = min(len, row + 1);
+    stage_slab<T>(Vs, base + 2 * d, 3LL * d, jend);
+    const DropCtx dc = drop_make(drop_p, seed, site);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float s_own[(AL_MAX_S + AL_THREADS - 1) / AL_THREADS];
+    float mx = -INFINITY;
+    for (int j = threadIdx.x, k = 0; j < S; j += AL_THREADS, ++k) {
+        float s = -INFINITY;
+        if (j < jend) {
+            s = 0.f;
+            const T* qr = base + (size_t)row * 3 * d;
+            const T* kr = base + (size_t)j * 3 * d + d;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) s = fmaf(Elem<T>::ld(qr + c) * scale, Elem<T>::ld(kr + c), s);
+        }
+        s_own[k] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = red[0];
+        for (int w = 1; w < AL_THREADS / 64; ++w) m = fmaxf(m, red[w]);
+        bc[0] = m;
+    }
+    __syncthreads();
+    const float m = bc[0];
+    float sum = 0.f;
+    const uint64_t ebase = (((uint64_t)b * H + h) * S + row) * S;
+    for (int j = threadIdx.x, k = 0; j < S; j += AL_THREADS, ++k) {
+        const float e = j < jend ? __expf(s_own[k] - m) : 0.f;
+        sum += e;
+        if (j < S) pr[j] = e * drop_mult(dc, ebase + j);
+    }
+    sum = wave_sum(sum);
+    __syncthreads();                    // red[] was read by thread 0 above
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float l = 0.f;
+        for (int w = 0; w < AL_THREADS / 64; ++w) l += red[w];
+        bc[1] = jend > 0 ? 1.f / l : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int c = threadIdx.x;
+        float o = 0.f;
+        for (int j = 0; j < jend; ++j) o = fmaf(pr[j], Vs[j * AL_LD + c], o);
+        Elem<T>::st(out + ((size_t)b * S + row) * d + h * 32 + c, o * bc[1]);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(AL_THREADS) void attn_long_bwd_kernel(const T* __restrict__ qkv,
                                                                    const int32_t* __restrict__ seq_len,
@@ -213,14 +283,31 @@ extern "C" int dsvg_seq_lens(const float* commands, int64_t n_seq, int32_t S, in
 }
 
 extern "C" int dsvg_attention_long_fwd(int32_t dtype, const void* qkv, const int32_t* seq_len, void* out, int64_t n_seq,
-                                       int32_t S, int32_t n_heads, float scale, int32_t causal, float drop_p,
-                                       uint32_t drop_site, const uint64_t* seed, void* stream) {
+                                       int32_t S, int32_t n_heads, float scale, int32_t causal, int32_t only_row,
+                                       float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream) {
     DSVG_CHECK_ARG(qkv && out && n_seq > 0 && S > 0 && S <= AL_MAX_S && n_heads > 0 && n_seq < (1ll << 31),
                    "attention_long_fwd: bad args (S=%d, at most %d)", S, AL_MAX_S);
     DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_long_fwd: dropout needs a seed pointer");
-    const size_t lds = (size_t)2 * S * AL_LD * sizeof(float);
+    DSVG_CHECK_ARG(only_row < S && (only_row < 0 || causal), "attention_long_fwd: only_row is the causal decoding step");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)n_seq, (unsigned)n_heads);
+    if (only_row >= 0) {            // incremental decoding: one query row, everything else of `out` untouched
+        const size_t lds1 = ((size_t)S * AL_LD + S) * sizeof(float);
+        if (dtype == DSVG_F32) {
+            auto kern = attn_long_row_kernel<float>;
+            DSVG_ENSURE_LDS(kern, lds1);
+            hipLaunchKernelGGL(kern, grid, dim3(AL_THREADS), lds1, st, (const float*)qkv, seq_len, (float*)out, S, n_heads,
+                               scale, only_row, drop_p, drop_site, seed);
+        } else if (dtype == DSVG_BF16) {
+            auto kern = attn_long_row_kernel<bf16_t>;
+            DSVG_ENSURE_LDS(kern, lds1);
+            hipLaunchKernelGGL(kern, grid, dim3(AL_THREADS), lds1, st, (const bf16_t*)qkv, seq_len, (bf16_t*)out, S,
+                               n_heads, scale, only_row, drop_p, drop_site, seed);
+        } else { dsvg_set_error("attention_long_fwd: bad dtype"); return -1; }
+        DSVG_LAUNCH_CHECK("attention_long_row");
+        return 0;
+    }
+    const size_t lds = (size_t)2 * S * AL_LD * sizeof(float);
     if (dtype == DSVG_F32) {
         auto kern = attn_long_fwd_kernel<float>;
         DSVG_ENSURE_LDS(kern, lds);

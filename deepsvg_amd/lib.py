@@ -89,7 +89,8 @@ SIGNATURES = {
     "dsvg_attention_causal_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
     "dsvg_attention_causal_bwd": (c_i32, [c_i32, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
     "dsvg_seq_lens": (c_i32, [vp, c_i64, c_i32, c_i32, vp, vp]),
-    "dsvg_attention_long_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_f32, c_u32, vp, vp]),
+    "dsvg_attention_long_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_i32, c_f32, c_u32, vp,
+                                        vp]),
     "dsvg_attention_long_bwd": (c_i32, [c_i32, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_f32, c_u32, vp, vp]),
     "dsvg_prefix_mean_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, vp]),
     "dsvg_prefix_mean_bwd": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, vp]),

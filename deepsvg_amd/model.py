@@ -906,6 +906,7 @@ class SVGTransformer(nn.Module):
             l_rows = Fn.LabelEmbedFn.apply(rt, label.reshape(-1), dec.label_embedding.label_embedding.weight)
             g2 = [ops.gemm(l_rows, rt.w(L.linear_global2.weight), bias=L.linear_global2.bias.detach()) for L in layers]
         cache = [torch.zeros(N * S, 3 * d, dtype=dt, device=dev) for _ in layers]
+        ctx_buf = torch.zeros(N * S, d, dtype=dt, device=dev) if S > 64 else None
         # the prefix so far, padded with SOS (any non-EOS value): the key-padding mask is "before the first EOS" (:269)
         cmd_buf = torch.full((N, S), float(SOS_ID), device=dev)
         commands_y = torch.empty(N, 1, T, dtype=torch.long, device=dev)
@@ -928,7 +929,11 @@ class SVGTransformer(nn.Module):
                 xn1, _, _ = ops.layernorm_fwd(x, L.norm1.weight.detach(), L.norm1.bias.detach())
                 qkv = ops.gemm(xn1, rt.w(L.self_attn.in_proj_weight), bias=L.self_attn.in_proj_bias.detach())
                 cache[li].view(N, S, 3 * d)[:, s] = qkv
-                ao = ops.attention_fwd(cache[li], key_mask, N, S, H, scale, causal=True).view(N, S, d)[:, s].contiguous()
+                if S > 64:      # long sequences: the newest query row alone (O(S) per step)
+                    ops.attention_fwd(cache[li], key_mask, N, S, H, scale, causal=True, only_row=s, out=ctx_buf)
+                    ao = ctx_buf.view(N, S, d)[:, s].contiguous()
+                else:
+                    ao = ops.attention_fwd(cache[li], key_mask, N, S, H, scale, causal=True).view(N, S, d)[:, s].contiguous()
                 x1 = ops.gemm(ao, rt.w(L.self_attn.out_proj.weight), bias=L.self_attn.out_proj.bias.detach(), res=x)
                 ops.bcast_add_fwd_(x1, gz[li], N, 1)
                 if g2 is not None:

@@ -265,7 +265,7 @@ def attention_tiles(seq_off, n_seq, max_rows=32):
 
 
 def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None,
-                  tiles=None, causal=False):
+                  tiles=None, causal=False, only_row=None, out=None):
     """seq_off (int32 [n_seq+1], device): packed layout, sequence b = rows seq_off[b]..seq_off[b+1]-1 (<= S rows, all
     keys visible, key_mask must be None); rows past seq_off[n_seq] are zero-filled.
     causal: query i attends keys j <= i (autoregressive decoder; dense layout only)."""
@@ -273,11 +273,14 @@ def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site
     rows = qkv.shape[0]
     assert qkv.is_contiguous() and qkv.shape[1] == 3 * 32 * n_heads, "attention needs head_dim == 32"
     assert (rows >= n_seq * S) if seq_off is None else (key_mask is None and seq_off.numel() == n_seq + 1)
-    out = torch.empty((rows, 32 * n_heads), dtype=qkv.dtype, device=qkv.device)
+    if out is None:
+        out = torch.empty((rows, 32 * n_heads), dtype=qkv.dtype, device=qkv.device)
     if S > 64:      # long sequences: key_mask holds valid-prefix lengths (build_masks)
+        # only_row (with causal): the incremental decoding step - that query row alone is computed into `out`
         assert seq_off is None and rows == n_seq * S and (key_mask is None or key_mask.dtype == torch.int32)
         _l.check(_l.load().dsvg_attention_long_fwd(_dt(qkv), qkv.data_ptr(), _p(key_mask), out.data_ptr(), n_seq, S,
-                                                   n_heads, float(scale), 1 if causal else 0, float(drop_p),
+                                                   n_heads, float(scale), 1 if causal else 0,
+                                                   -1 if only_row is None else int(only_row), float(drop_p),
                                                    int(drop_site), _p(seed) if drop_p > 0 else None, _stream()),
                  "dsvg_attention_long_fwd")
         return out

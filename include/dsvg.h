@@ -285,13 +285,14 @@ int dsvg_attention_causal_bwd(int32_t dtype, const void* qkv, const uint64_t* ke
  * (deepsvg/model/utils.py:7-32), i.e. a valid-prefix LENGTH per sequence instead of a 64-bit word:
  *   seq_lens:       lens[b] = index of the first EOS of commands[b, :] (S if there is none)
  *   attention_long: same contract as dsvg_attention_fwd/bwd on the dense layout (keys j < seq_len[b], NULL = all;
- *                   causal != 0: additionally j <= i), S <= 256, same dropout element ids
+ *                   causal != 0: additionally j <= i), S <= 256, same dropout element ids; only_row >= 0 (forward,
+ *                   causal): compute that query row alone (incremental decoding step), other rows of out untouched
  *   prefix_mean:    out[b,:] = mean_{s < lens[b]} x[b*S + s, :]  (deepsvg/model/model.py:137) and its backward
  * ------------------------------------------------------------------------------------------ */
 int dsvg_seq_lens(const float* commands, int64_t n_seq, int32_t S, int32_t eos_id, int32_t* lens, void* stream);
 int dsvg_attention_long_fwd(int32_t dtype, const void* qkv, const int32_t* seq_len, void* out, int64_t n_seq, int32_t S,
-                            int32_t n_heads, float scale, int32_t causal, float drop_p, uint32_t drop_site,
-                            const uint64_t* seed, void* stream);
+                            int32_t n_heads, float scale, int32_t causal, int32_t only_row, float drop_p,
+                            uint32_t drop_site, const uint64_t* seed, void* stream);
 int dsvg_attention_long_bwd(int32_t dtype, const void* qkv, const int32_t* seq_len, const void* dout, void* dqkv,
                             int64_t n_seq, int32_t S, int32_t n_heads, float scale, int32_t causal, float drop_p,
                             uint32_t drop_site, const uint64_t* seed, void* stream);

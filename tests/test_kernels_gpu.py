@@ -751,3 +751,20 @@ def test_long_sequence_masks_mean_and_targets(gpu_device, dtype):
         ref = R.loss_targets(tc.cpu(), ta.cpu(), CMD_ARGS_MASK.float(), 4)
         for a, b, name in zip(got, ref, ("cmd_tgt", "cmd_w", "arg_tgt", "arg_w", "vis_tgt")):
             assert torch.equal(a.cpu().reshape(-1).float(), b.reshape(-1).float()), name
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_long_single_row_step(gpu_device, dtype):
+    """incremental decoding on long sequences: the newest query row alone == that row of the full causal forward"""
+    H, S, n_seq = 8, 241, 6
+    qkv = _rand(n_seq * S, 3 * 32 * H, dtype=dtype, seed=91)
+    lens = torch.tensor([241, 1, 77, 200, 5, 130], dtype=torch.int32, device=DEV)
+    full = ops.attention_fwd(qkv, lens, n_seq, S, H, 32 ** -0.5, causal=True).view(n_seq, S, -1)
+    for row in (0, 3, 64, 150, 240):
+        buf = torch.full((n_seq * S, 32 * H), 7.0, dtype=dtype, device=DEV)
+        ops.attention_fwd(qkv, lens, n_seq, S, H, 32 ** -0.5, causal=True, only_row=row, out=buf)
+        got = buf.view(n_seq, S, -1)
+        _close(got[:, row], full[:, row], 5e-6 if dtype == torch.float32 else 1e-2, f"row {row}")
+        mask = torch.ones(S, dtype=torch.bool, device=DEV)
+        mask[row] = False
+        assert bool((got[:, mask] == 7.0).all()), "only_row wrote other rows"

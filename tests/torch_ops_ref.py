@@ -225,7 +225,16 @@ def attention_tiles(seq_off, n_seq, max_rows=32):
 
 
 def attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None,
-                  tiles=None, causal=False):
+                  tiles=None, causal=False, only_row=None, out=None):
+    if only_row is not None or out is not None:     # incremental decoding step: one row of a caller-owned buffer
+        full = attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, drop_p, drop_site, seed, causal=causal)
+        if out is None:
+            return full
+        if only_row is None:
+            out.copy_(full)
+        else:
+            out.view(n_seq, S, -1)[:, only_row] = full.view(n_seq, S, -1)[:, only_row]
+        return out
     if seq_off is not None:
         dense, idx, lens = _unpack_rows(qkv, seq_off, n_seq, S)
         o = attention_fwd(dense, _len_mask(lens), n_seq, S, n_heads, scale, drop_p, drop_site, seed)
