@@ -20,9 +20,10 @@ def _free_port():
     return p
 
 
-def _make(cfg_small=True):
+def _make(kind="hier"):
     import deepsvg_amd
-    cfg = H.build_cfg("hier")
+    cfg = H.build_cfg(kind)
+    cfg.use_vae = False       # (a sampled latent would differ between the two-rank and the one-process run)
     cfg.n_layers = cfg.n_layers_decode = 1
     torch.manual_seed(0)
     model = deepsvg_amd.SVGTransformer(cfg)
@@ -31,7 +32,13 @@ def _make(cfg_small=True):
     return cfg, model, deepsvg_amd.SVGLoss(cfg)
 
 
-def _worker(rank, world, port, ret):
+def _labels(cfg, n):
+    if not cfg.label_condition:
+        return None
+    return torch.randint(0, cfg.n_labels, (n,), generator=torch.Generator().manual_seed(3))
+
+
+def _worker(rank, world, port, ret, kind):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,13 +47,14 @@ def _worker(rank, world, port, ret):
         install_emulated_ops()
         from deepsvg_amd.trainer import TrainStep
         from deepsvg_amd.synthetic import make_batch
-        cfg, model, loss_fn = _make()
+        cfg, model, loss_fn = _make(kind)
         commands, args = make_batch(8, seed=21)
+        label = _labels(cfg, 8)
         per = commands.shape[0] // world
         c, a = commands[rank * per:(rank + 1) * per], args[rank * per:(rank + 1) * per]
         ts = TrainStep(model, loss_fn, lr=1e-2)
         assert ts.overlap_allreduce
-        ld = ts.step(c, a)
+        ld = ts.step(c, a, label=label[rank * per:(rank + 1) * per] if label is not None else None)
         # the decoder bucket went out from inside the backward pass (hook on the bottleneck output's gradient)
         assert ts._pending is not None and 0 < ts._pending[0] < model.store.flat.numel()
         ret[rank] = (model.store.flat.clone(), ts.grad_norm(), {k: v.item() for k, v in ld.items()},
@@ -55,22 +63,25 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_step_equals_single_process_step():
+@pytest.mark.parametrize("kind", ["hier", "fonts", "selfmatch"])
+def test_two_rank_gloo_step_equals_single_process_step(kind):
+    """hier: the north-star config; fonts: label conditioning (label tables + linear_global2); selfmatch: Hungarian
+    assignment per icon before the loss"""
     world = 2
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, kind), nprocs=world, join=True)
 
     from tests.conftest import install_emulated_ops, restore_ops
     saved = install_emulated_ops()
     try:
         from deepsvg_amd.trainer import TrainStep
         from deepsvg_amd.synthetic import make_batch
-        cfg, model, loss_fn = _make()
+        cfg, model, loss_fn = _make(kind)
         commands, args = make_batch(8, seed=21)
         ts = TrainStep(model, loss_fn, lr=1e-2)
-        ld = ts.step(commands, args)
+        ld = ts.step(commands, args, label=_labels(cfg, 8))
         flat_ref, gn_ref = model.store.flat.clone(), ts.grad_norm()
         grad_ref = model.store.grad_buffer(0).clone()
     finally:
