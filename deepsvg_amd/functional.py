@@ -189,10 +189,25 @@ class ResBlockFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------------
+class LivePrefix(tuple):
+    """(n_live_sequences, n_live_rows) of a stage whose backward MAY be restricted to that row prefix: the rest of
+    every incoming gradient is zero and the rest of every returned gradient is never read.  That holds only under a
+    loss that ignores everything outside the prefix - deepsvg_amd.SVGLoss on the visible-first order of the second
+    decoder stage (loss.py:36,51-54) - so the restriction is DISARMED (full backward, correct under any loss) until
+    such a loss arms it on the very output it consumes (SVGLoss.forward: output["_dsvg_live"].armed = True)."""
+    armed = False
+
+
 def _live_rows(live, full_rows):
-    """`live` = (n_live_sequences, n_live_rows) or None: backward only has to cover that row prefix (the rest of every
-    incoming gradient is known to be zero and the rest of every returned gradient is never read)."""
+    """the LivePrefix to remember at forward time, or None when it would not shorten anything"""
     if live is None or live[1] >= full_rows:
+        return None
+    return live
+
+
+def _armed(live):
+    """backward-time decision: the remembered prefix if the loss armed it (plain tuples - tests - count as armed)"""
+    if live is None or not getattr(live, "armed", True):
         return None
     return live
 
@@ -210,11 +225,12 @@ class LayerNormFn(torch.autograd.Function):
         rt = ctx.rt
         x, mean, rstd, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
-        if ctx.live is None:
+        live = _armed(ctx.live)
+        if live is None:
             dx, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, gamma.detach(),
                                            dgamma=rt.grad_out(gamma), dbeta=rt.grad_out(beta))
         else:
-            R = ctx.live[1]
+            R = live[1]
             dx = torch.empty_like(x)
             _, dg, db = ops.layernorm_bwd(dy[:R], x[:R], mean[:R], rstd[:R], gamma.detach(), dx=dx[:R],
                                           dgamma=rt.grad_out(gamma), dbeta=rt.grad_out(beta))
@@ -231,9 +247,8 @@ class AddPosFn(torch.autograd.Function):
         y = ops.add_pos_fwd(x, pos_weight.detach(), n_seq, S, rt.dtype, p, site, rt.seed)
         ctx.rt, ctx.n_seq, ctx.S, ctx.p, ctx.site = rt, n_seq, S, p, site
         ctx.has_x = x is not None
-        if _live_rows(live, n_seq * S) is not None:
-            assert x is None, "live-prefix backward is only wired for the constant embedding"
-            ctx.n_seq = live[0]
+        ctx.live = _live_rows(live, n_seq * S)
+        assert ctx.live is None or x is None, "live-prefix backward is only wired for the constant embedding"
         ctx.save_for_backward(pos_weight)
         return y
 
@@ -244,8 +259,10 @@ class AddPosFn(torch.autograd.Function):
         dpos = rt.grad_out(pos_weight)
         if pos_weight.shape[0] > ctx.S:
             dpos[ctx.S:].zero_()
-        dy = dy.contiguous()[:ctx.n_seq * ctx.S]
-        dx = ops.add_pos_bwd(dy, ctx.n_seq, ctx.S, dpos[:ctx.S], want_dx=ctx.has_x, drop_p=ctx.p,
+        live = _armed(ctx.live)
+        n_seq = live[0] if live is not None else ctx.n_seq
+        dy = dy.contiguous()[:n_seq * ctx.S]
+        dx = ops.add_pos_bwd(dy, n_seq, ctx.S, dpos[:ctx.S], want_dx=ctx.has_x, drop_p=ctx.p,
                              drop_site=ctx.site, seed=rt.seed)
         return None, dx, dpos, None, None, None, None, None
 
@@ -316,9 +333,10 @@ class GatherGroupsFn(torch.autograd.Function):
     def backward(ctx, dy):
         inv, = ctx.saved_tensors
         dy = dy.contiguous()
-        if ctx.live is None:
+        live = _armed(ctx.live)
+        if live is None:
             return ops.gather_groups(dy, inv, ctx.n_groups, ctx.S), None, None, None, None, None
-        n_cover = min(ctx.n_groups, -(-ctx.live[1] // ctx.S))
+        n_cover = min(ctx.n_groups, -(-live[1] // ctx.S))
         dx = torch.empty_like(dy)
         ops.gather_groups(dy, inv, n_cover, ctx.S, out=dx)
         return dx, None, None, None, None, None
@@ -427,8 +445,9 @@ class LayerFn(torch.autograd.Function):
          n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off) = ctx.saved_tensors
         dx2 = dx2.contiguous()
         full_rows, n_seq_full = x.shape[0], n_seq
-        if ctx.live is not None:        # backward over the live row prefix only (visible-first decoder order)
-            n_seq, R = ctx.live
+        live = _armed(ctx.live)
+        if live is not None:            # backward over the live row prefix only (visible-first decoder order)
+            n_seq, R = live
             (dx2, x, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h) = (
                 t[:R] for t in (dx2, x, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h))
         inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
@@ -470,12 +489,12 @@ class LayerFn(torch.autograd.Function):
         dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1)
         dxn1 = ops.gemm(dqkv, rt.w(win), b_kc=False)
         dx_out = None
-        if ctx.live is not None:
+        if live is not None:
             dx_full = torch.empty((full_rows, x.shape[1]), dtype=x.dtype, device=x.device)
             dx_out = dx_full[:x.shape[0]]
         dx, dn1w, dn1b = ops.layernorm_bwd(dxn1, x, mean1, rstd1, n1w.detach(), res=dx1, dx=dx_out,
                                            dgamma=rt.grad_out(n1w), dbeta=rt.grad_out(n1b))
-        if ctx.live is not None:
+        if live is not None:
             dx = dx_full
         return (None, dx, None, dz, dl, None, None, None, None, None,
                 dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, dwg2, dbg2, None, None, None,

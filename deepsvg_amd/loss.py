@@ -20,7 +20,8 @@ class SVGLoss(nn.Module):
         self.args_dim = 2 * cfg.args_dim if cfg.rel_targets else cfg.args_dim + 1
         self.register_buffer("cmd_args_mask", CMD_ARGS_MASK.clone())
         self._cam_f32 = None
-        # data-parallel hook (deepsvg_amd/trainer.py): count_reducer(name, local_count) -> global_count / world
+        # data-parallel hook (deepsvg_amd/trainer.py): count_reducer(float32 [3] local counts of the visibility / command /
+        # argument cross-entropies) -> global counts / world, ONE collective per step
         self.count_reducer = None
 
     def _cam(self, device):
@@ -48,6 +49,11 @@ class SVGLoss(nn.Module):
         S = S1 - 1
         # the model's forward may have prepared the targets and the list of tokens that carry argument loss
         # (SVGTransformer._plan): the argument head's backward then runs on those tokens only
+        lp = output.get("_dsvg_live")
+        if lp is not None and lp["tgt_commands"] is tgt_commands:
+            # this loss ignores every position of an invisible target group (loss.py:36,51-54): the model's second
+            # decoder stage may restrict its backward to the visible-first prefix (functional.LivePrefix)
+            lp["live"].armed = True
         head = output.get("_dsvg_head")
         if head is not None and not (head["tgt_commands"] is tgt_commands and head["tgt_args"] is tgt_args
                                      and torch.is_grad_enabled()):
@@ -59,26 +65,33 @@ class SVGLoss(nn.Module):
             ta = tgt_args.to(device=device, dtype=torch.float32).contiguous().view(N * G, S1, n_args)
             cmd_tgt, cmd_w, arg_tgt, arg_w, vis_tgt = ops.loss_targets(tc, ta, self._cam(device), EOS_ID)
 
+        # data-parallel: the three means are taken over the GLOBAL selected-element counts.  The counts depend on the
+        # targets only, so they are known before any logit is read: one 3-element all-reduce up front
         red = self.count_reducer
+        cnt = None
+        if red is not None:
+            local = torch.stack([torch.full((), float(N * G), device=device),
+                                 (cmd_w != 0).sum().float(), (arg_w != 0).sum().float()])
+            cnt = red(local)
         if cfg.decode_stages == 2:
             vl = output["visibility_logits"].reshape(N * G, 2)
-            loss_visibility, sc_v = Fn.MaskedCEFn.apply(vl, vis_tgt, None, 2, 1, (lambda c: red("vis", c)) if red else None)
+            loss_visibility, sc_v = Fn.MaskedCEFn.apply(vl, vis_tgt, None, 2, 1, (lambda c: cnt[0]) if red else None)
             loss = loss + weights["loss_visibility_weight"] * loss_visibility
             res["loss_visibility"] = loss_visibility
 
         cl = command_logits.reshape(N * G * S, cfg.n_commands)
         loss_cmd, sc_c = Fn.MaskedCEFn.apply(cl, cmd_tgt.view(-1), cmd_w.view(-1), cfg.n_commands, 1,
-                                             (lambda c: red("cmd", c)) if red else None)
+                                             (lambda c: cnt[1]) if red else None)
         if head is not None:
             # fused argument head + loss on the loss-carrying tokens (forward and backward); the dense args_logits of
             # the result dict stays unmaterialised
             loss_args, sc_a = Fn.ArgsHeadLossFn.apply(head["rt"], head["x"], head["weight"], head["bias"],
                                                       arg_tgt.view(-1), arg_w.view(-1), self.args_dim, n_args,
-                                                      (lambda c: red("args", c)) if red else None, head["live"])
+                                                      (lambda c: cnt[2]) if red else None, head["live"])
         else:
             al = output["args_logits"].reshape(N * G * S, n_args * self.args_dim)
             loss_args, sc_a = Fn.MaskedCEFn.apply(al, arg_tgt.view(-1), arg_w.view(-1), self.args_dim, n_args,
-                                                  (lambda c: red("args", c)) if red else None)
+                                                  (lambda c: cnt[2]) if red else None)
         loss = loss + weights["loss_cmd_weight"] * loss_cmd + weights["loss_args_weight"] * loss_args
         res.update({"loss": loss, "loss_cmd": loss_cmd, "loss_args": loss_args})
         return res

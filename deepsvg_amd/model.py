@@ -270,6 +270,20 @@ class ParamStore:
         self.total = 0
         self._lp_views = {}      # id(param) -> view of the bf16 image (views are re-used: ~2000 lookups per step)
         self._grad_views = [{}, {}]
+        self._in_flight = set()  # id(param): its slot of gbuf[0] was handed to a backward node, not yet accumulated
+        self._hooks = []
+
+    # a copied / unpickled module gets an empty store that re-flattens lazily on its first forward: the index is keyed
+    # by id(param) and the views point into THIS module's buffers (copy.deepcopy(model) for EMA / best-model snapshots,
+    # torch.save(model))
+    def __deepcopy__(self, memo):
+        return ParamStore(memo.get(id(self.module)))
+
+    def __getstate__(self):
+        return {"module": self.module}
+
+    def __setstate__(self, state):
+        self.__init__(state["module"])
 
     def _flatten(self, device):
         params = [p for p in self.module.parameters()]
@@ -291,17 +305,32 @@ class ParamStore:
         self.gbuf = [None, None]
         self._lp_views = {}
         self._grad_views = [{}, {}]
+        self._in_flight = set()
+        for h in self._hooks:
+            h.remove()
+        # a slot of the flat gradient buffer is free again once AccumulateGrad has consumed it (see grad_view)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._accumulated) for p in params if p.requires_grad]
+
+    def _accumulated(self, param):
+        self._in_flight.discard(id(param))
 
     def ensure(self, device, dtype):
         params = self.params
         stale = self.flat is None or self.flat.device != device or not params
         if not stale:
-            first, last = params[0], params[-1]
-            base = self.flat.data_ptr()
-            stale = (first.data_ptr() != base + 4 * self.index[id(first)][0] or
-                     last.data_ptr() != base + 4 * self.index[id(last)][0])
+            # every parameter must still be the view of the flat buffer it was given (a re-assigned .data, an added or
+            # replaced nn.Parameter, load_state_dict(assign=True) ... all re-flatten)
+            base, index, n = self.flat.data_ptr(), self.index, 0
+            for p in self.module.parameters():
+                ent = index.get(id(p))
+                if ent is None or p.data_ptr() != base + 4 * ent[0]:
+                    stale = True
+                    break
+                n += 1
+            stale = stale or n != len(params)
         if stale:
             self._flatten(device)
+        self._in_flight.clear()     # a forward starts a new graph: nothing handed out earlier can still be pending
         if dtype != torch.float32:
             if self.flat_lp is None or self.flat_lp.dtype != dtype:
                 self.flat_lp = torch.empty(self.flat.numel(), dtype=dtype, device=device)
@@ -338,8 +367,17 @@ class ParamStore:
 
     def grad_view(self, param):
         v = self._grad_view(param, 0)
+        if v is None:
+            return None
+        key = id(param)
+        if key in self._in_flight:
+            # a second backward node asks for this parameter's gradient before AccumulateGrad has consumed the first
+            # one (two forwards + one backward, a weight used by two Functions): autograd SUMS the contributions, so
+            # they must not share memory - hand out a private tensor
+            return torch.empty(param.shape, dtype=torch.float32, device=v.device)
+        self._in_flight.add(key)
         # autograd accumulates into an existing .grad: never hand it a view that aliases that .grad
-        if v is not None and param.grad is not None and param.grad.data_ptr() == v.data_ptr():
+        if param.grad is not None and param.grad.data_ptr() == v.data_ptr():
             v = self._grad_view(param, 1)
         # a fresh tensor object per call: AccumulateGrad only adopts ("steals") a gradient nobody else references,
         # otherwise it deep-copies it - the cached view itself would cost one copy launch per parameter per step
@@ -404,6 +442,7 @@ class SVGTransformer(nn.Module):
         self._decoder_grads_ready = None    # callback of a data-parallel trainer (TrainStep), see forward()
         self._side_stream = None    # set by a trainer that calls join_side_stream() after backward (TrainStep)
         self._rt = None
+        self._live = None
 
     # ---- runtime plumbing ------------------------------------------------------------------------
     def set_compute_dtype(self, dtype):
@@ -656,9 +695,10 @@ class SVGTransformer(nn.Module):
             # visible-first order: sequence `new` of the stage is group old_of_new[new]; backward covers the prefix
             # (any prefix that contains every visible sequence is exact; a graph bucket rounds it up)
             nv = max(pd["n_visible"], pd.get("n_live", 0))
-            live = (nv, min((nv * S + 127) // 128 * 128, n_seq * S))
+            live = Fn.LivePrefix((nv, min((nv * S + 127) // 128 * 128, n_seq * S)))
             z = Fn.GatherGroupsFn.apply(z, pd["old_of_new"], pd["new_of_old"], n_seq, 1, None)
         self.last_live = (live[0], n_seq) if live is not None else None
+        self._live = live
         src = Fn.AddPosFn.apply(rt, None, dec.embedding.PE.pos_embed.weight, n_seq, S, PE_DROPOUT, 4, live)
         out = self._run_stack(rt, dec.decoder, src, None, z, n_seq, S, 400, live=live, l=l_seq)
         if live is not None:        # back to the caller's group order before the heads
@@ -753,6 +793,15 @@ class SVGTransformer(nn.Module):
         else:
             # externally supplied z is batch-first (N, 1, 1, dim_z), or (N, G, 1, dim_z) per-group latents together
             # with hierarch_logits  (model.py:369, 249-253)
+            if (hierarch_logits is not None and z.dim() == 4 and z.shape[0] == 1 and z.shape[2] > 1
+                    and tuple(z.shape[1:3]) == tuple(hierarch_logits.shape[-3:-1])):
+                # per-group latents handed back exactly as return_hierarch produced them, seq-first (1, G, N, dim_z) like
+                # hierarch_logits (the reference's notebooks do this with N = 1, where both layouts coincide; for N > 1
+                # the reference's own _make_seq_first would scramble them): take them as what they are
+                z = z.permute(2, 1, 0, 3)
+            elif hierarch_logits is not None and z.dim() == 4 and z.shape[0] != hierarch_logits.shape[-2]:
+                raise ValueError(f"z {tuple(z.shape)} does not match hierarch_logits {tuple(hierarch_logits.shape)}: "
+                                 "expected batch-first per-group latents (N, G, 1, dim_z) with (1, G, N, 2) logits")
             zz = z.reshape(-1, z.shape[-1]).to(rt.dtype).contiguous()
         if encode_mode:
             return zz.to(torch.float32).view(1, 1, zz.shape[0], zz.shape[1])   # seq-first, as model.py:371
@@ -806,10 +855,15 @@ class SVGTransformer(nn.Module):
                                          targets=pl["targets"], live=(pl["live"], n_rows),
                                          tgt_commands=commands_dec, tgt_args=args_dec)
                 self.last_head_rows = (pl["n_live"], T_dec)
+            if getattr(self, "_live", None) is not None:
+                # the live-prefix backward of the second decoder stage is exact under SVGLoss only: deepsvg_amd.SVGLoss
+                # arms it when it consumes THIS output; any other loss gets the full backward (functional.LivePrefix)
+                res["_dsvg_live"] = dict(live=self._live, tgt_commands=commands_dec)
             if cfg.use_vae and mu is not None:
                 res["mu"] = mu.view(mu.shape[0], 1, 1, -1)
                 res["logsigma"] = logsigma.view(logsigma.shape[0], 1, 1, -1)
         self._head_in = None
+        self._live = None
         return res
 
     # ---- sampling (model.py:414-479; inference-only host glue on the logits) -------------------------

@@ -54,7 +54,7 @@ class TrainStep:
         self.side_stream = os.environ.get("DSVG_SIDE_STREAM", "0") != "0"
         model._own_seed = False          # the trainer advances the dropout seed once per step
         if self.exact_global_mean:
-            loss_fn.count_reducer = self._reduce_count
+            loss_fn.count_reducer = self._reduce_counts
 
     # ---- lazily created device state -----------------------------------------------------------------
     def _setup(self, device):
@@ -83,9 +83,10 @@ class TrainStep:
         flat_g = self.model.store.grad_buffer(0)
         self._pending = (lo, dist.all_reduce(flat_g[lo:hi], group=self.pg, async_op=True))
 
-    def _reduce_count(self, name, count):
-        dist.all_reduce(count, group=self.pg)
-        return count / self.world
+    def _reduce_counts(self, counts):
+        """[n] local selected-element counts of the cross-entropies -> global counts / world, in ONE all-reduce"""
+        dist.all_reduce(counts, group=self.pg)
+        return counts / self.world
 
     # ---- one step ------------------------------------------------------------------------------------
     def _step_body(self, commands, args, label=None, dec=None):
@@ -107,6 +108,14 @@ class TrainStep:
             model._decoder_grads_ready = None
         model.join_side_stream()        # weight gradients are computed on a second stream (functional.Runtime)
         flat_g = model.store.grad_buffer(0)
+        # the norm / AdamW below read the WHOLE flat gradient buffer: a parameter that received no gradient in this step
+        # must contribute zero, not its gradient of an earlier step (torch's AdamW skips grad-less parameters; no shipped
+        # config has one, so this loop normally finds nothing and launches nothing)
+        for p in model.store.params:
+            if p.grad is None and p.requires_grad:
+                v = model.store._grad_view(p, 0)
+                if v is not None:
+                    v.zero_()
         if self.world > 1:
             if self._pending is not None:
                 # two buckets: the decoder half went out while the encoder's backward was running

@@ -391,3 +391,45 @@ def loss_and_grads(sd, cfg, commands, args, weights=None, eps=None, label=None, 
     names = [k for k, v in leaves.items() if v.requires_grad]
     grads = torch.autograd.grad(ld["loss"], [leaves[k] for k in names], allow_unused=True)
     return out, ld, {k: g for k, g in zip(names, grads)}
+
+
+# ---------------------------------------------------------------------------------------------------
+# one-shot sampling — deepsvg/model/model.py:414-423,442-459, deepsvg/model/utils.py:75-84
+# ---------------------------------------------------------------------------------------------------
+def make_valid(commands_y, args_y, visibility_y=None, pad_val=-1):
+    """SVGTransformer._make_valid (model.py:450-459): invisible groups -> [m, EOS, ...], unused argument slots -> -1"""
+    commands_y, args_y = commands_y.clone(), args_y.clone()
+    if visibility_y is not None:
+        S = commands_y.size(-1)
+        commands_y[~visibility_y] = commands_y.new_tensor([M] + [EOS] * (S - 1))
+        args_y[~visibility_y] = pad_val
+    mask = CMD_ARGS_MASK.to(commands_y.device)[commands_y.long()].bool()
+    args_y[~mask] = pad_val
+    return commands_y, args_y
+
+
+def greedy_sample(sd, cfg, commands_enc=None, args_enc=None, label=None, z=None, hierarch_logits=None,
+                  concat_groups=True, eps=None):
+    """SVGTransformer.greedy_sample for pred_mode == "one_shot" (model.py:414-423,442-448).  The reference draws from
+    Categorical(logits / 1e-4) (utils.py:75-79), which is the arg-max except where the two largest logits lie within
+    ~1e-3 of each other; the restatement takes the arg-max and also returns the top-2 gap of every argument slot /
+    command so that a checker can exclude the near-ties.
+    -> (commands_y, args_y, cmd_gap, args_gap); with concat_groups the first two are flattened per icon as the reference
+    does (all icons must then keep the same number of tokens, as in the reference)."""
+    assert cfg.pred_mode == "one_shot" and not cfg.rel_targets
+    res = forward(sd, cfg, commands_enc, args_enc, None, None, z=z, eps=eps, label=label,
+                  hierarch_logits=hierarch_logits, return_tgt=False)
+    cl, al = res["command_logits"], res["args_logits"]
+    commands_y, args_y = cl.argmax(-1), al.argmax(-1) - 1                                   # :417-418
+    t2c, t2a = cl.topk(2, dim=-1).values, al.topk(2, dim=-1).values
+    cmd_gap, args_gap = t2c[..., 0] - t2c[..., 1], t2a[..., 0] - t2a[..., 1]
+    vis = None
+    if cfg.decode_stages == 2:                                                              # :419, utils.py:82-84
+        vis = F.softmax(res["visibility_logits"], dim=-1)[..., 1] > 0.7
+        vis = vis.squeeze(-1)
+    commands_y, args_y = make_valid(commands_y, args_y, vis)                                # :420
+    if concat_groups:                                                                       # :442-446
+        N = commands_y.size(0)
+        pm = padding_mask(commands_y, seq_dim=-1).bool()
+        commands_y, args_y = commands_y[pm].reshape(N, -1), args_y[pm].reshape(N, -1, cfg.n_args)
+    return commands_y, args_y, cmd_gap, args_gap

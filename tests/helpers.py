@@ -14,7 +14,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def golden_cases():
     """the model / loss fixtures (tests/golden/make_golden.py); batch_assembly.npz belongs to the data path"""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith("batch_")]
+    return [n for n in names if not n.startswith("batch_") and n != "greedy_sample"]
 
 
 BATCH_KEYS = ["commands", "args", "args_rel", "commands_grouped", "args_grouped", "args_rel_grouped", "filling"]
@@ -171,3 +171,60 @@ def check_against_golden(g, out, losses=None, grads=None, *, logit_rtol=1e-3, lo
             rms = ref_norm / max(gr.numel(), 1) ** 0.5
             atol = grad_sample_atol if grad_sample_atol is not None else 5e-3 * rms + 1e-6
             assert torch.allclose(s, ref_sample, rtol=2e-3, atol=atol), (n, (s - ref_sample).abs().max().item())
+
+
+# ---- one-shot greedy_sample fixtures (tests/golden/make_golden_sample.py) ------------------------------------------
+SAMPLE_TIE = 2e-3       # the reference draws from Categorical(logits / 1e-4): slots whose two best logits lie closer are near-ties
+
+
+def sample_cases():
+    return ["hier5", "fonts4"]
+
+
+def sample_fixture(tag):
+    """-> (dict of that case's arrays as tensors, cfg)"""
+    z = np.load(os.path.join(GOLDEN_DIR, "greedy_sample.npz"), allow_pickle=False)
+    g = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(tag + "/")}
+    cfg = build_cfg(str(g["kind"]))
+    t = {k: (torch.from_numpy(v.astype(np.int64)) if v.dtype == np.int16 else
+             torch.from_numpy(v.astype(np.float32)) if v.dtype == np.float16 else
+             torch.from_numpy(v) if v.dtype.kind in "fi" and v.ndim else v) for k, v in g.items()}
+    return t, cfg
+
+
+def check_sample(got_c, got_a, want_c, want_a, cmd_gap, args_gap):
+    """commands / arguments equal to the reference's draw wherever that draw is not a near-tie (a flipped command also
+    changes which argument slots are valid, so arguments are compared under safe commands)"""
+    got_c, got_a = got_c.cpu().long(), got_a.cpu().long()
+    assert got_c.shape == want_c.shape and got_a.shape == want_a.shape
+    okc = cmd_gap > SAMPLE_TIE
+    assert torch.equal(got_c[okc], want_c[okc]), "sampled commands differ from the reference outside near-ties"
+    oka = (args_gap > SAMPLE_TIE) & okc.unsqueeze(-1)
+    assert torch.equal(got_a[oka], want_a[oka]), "sampled arguments differ from the reference outside near-ties"
+    assert okc.float().mean().item() > 0.98 and oka.float().mean().item() > 0.95     # the check is not vacuous
+
+
+def run_sample_checks(sample_fn, t, cfg, device="cpu", eps_ctx=None):
+    """sample_fn(commands, args, label, z, hierarch_logits, concat_groups, icon) -> (commands_y, args_y); every leg of
+    the fixture: from the inputs, from z, forced visibility (one visible group / none), concat_groups per icon"""
+    dev = lambda x: x.to(device) if torch.is_tensor(x) else x                       # noqa: E731
+    label = dev(t["label"]) if "label" in t else None
+    c, a = dev(t["commands"]), dev(t["args"])
+    cy, ay = sample_fn(c, a, label, None, None, False, None)
+    check_sample(cy, ay, t["cy"], t["ay"], t["cmd_gap"], t["args_gap"])
+    cy, ay = sample_fn(None, None, label, dev(t["z"]), None, False, None)
+    check_sample(cy, ay, t["cy_z"], t["ay_z"], t["cmd_gap"], t["args_gap"])
+    cy, ay = sample_fn(None, None, label, dev(t["hz"]), dev(t["hl"]), False, None)
+    check_sample(cy, ay, t["cy_h"], t["ay_h"], t["cmd_gap_h"], t["args_gap_h"])
+    inv = torch.tensor([0] + [4] * 30)
+    assert torch.equal(cy[1].cpu().long(), inv.expand(8, 31)) and bool((ay[1] == -1).all())
+    assert all(torch.equal(cy[0, g].cpu().long(), inv) for g in range(8) if g != 3)
+    off = 0
+    for i, n_tok in enumerate(t["cat_len"].tolist()):
+        li = label[i:i + 1] if label is not None else None
+        c1, a1 = sample_fn(c[i:i + 1], a[i:i + 1], li, None, None, True, i)
+        assert c1.shape == (1, n_tok) and a1.shape == (1, n_tok, cfg.n_args)
+        if bool((t["cmd_gap"][i] > SAMPLE_TIE).all()) and bool((t["args_gap"][i] > SAMPLE_TIE).all()):
+            assert torch.equal(c1[0].cpu().long(), t["cat_c"][off:off + n_tok])
+            assert torch.equal(a1[0].cpu().long(), t["cat_a"][off:off + n_tok])
+        off += n_tok

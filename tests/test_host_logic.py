@@ -253,6 +253,30 @@ def test_greedy_sample_shapes(emulated_ops):
     assert args_y.min().item() >= -1 and args_y.max().item() <= 255
 
 
+@pytest.mark.parametrize("tag", H.sample_cases())
+def test_greedy_sample_matches_reference_golden_with_emulated_ops(tag, emulated_ops):
+    """the product's one-shot greedy_sample host glue (draw, visibility threshold, _make_valid, concat_groups) against
+    the reference's own samples, every leg of tests/golden/make_golden_sample.py"""
+    import deepsvg_amd.model as M
+    t, cfg = H.sample_fixture(tag)
+    model = deepsvg_amd.SVGTransformer(cfg)
+    model.load_state_dict(H.weights_for(model, int(t["wseed"])))
+    model.eval()
+    eps = t.get("eps")
+
+    def sample(c, a, label, z, hl, concat, icon):
+        orig = torch.randn_like
+        if eps is not None:
+            e = eps if icon is None else eps[:, :, icon:icon + 1]
+            M.torch.randn_like = lambda x: e.reshape(x.shape).to(x.dtype)
+        try:
+            torch.manual_seed(0)
+            return model.greedy_sample(c, a, None, None, label=label, z=z, hierarch_logits=hl, concat_groups=concat)
+        finally:
+            M.torch.randn_like = orig
+    H.run_sample_checks(sample, t, cfg)
+
+
 def test_autoregressive_cached_sampling_equals_recompute(emulated_ops):
     """incremental decoding over the per-layer q|k|v cache vs the reference's scheme (decoder re-run on the whole prefix
     for every new token): same token sequences, on weights that make the sequences vary"""
@@ -272,3 +296,111 @@ def test_autoregressive_cached_sampling_equals_recompute(emulated_ops):
         outs[kv] = model.greedy_sample(commands, args, None, None, concat_groups=False)
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
     assert outs[True][0].unique().numel() > 1, "degenerate sample: the test would not see an ordering bug"
+
+
+# ---- round-1 advisor findings ---------------------------------------------------------------------------------------
+def _loss_of(model, lf, c, a):
+    return lf(model(c, a, c, a, params={}), None, weights=O.DEFAULT_WEIGHTS)["loss"]
+
+
+def test_two_forwards_one_backward_sum_their_gradients(emulated_ops):
+    """(L(model(x1)) + L(model(x2))).backward(): two backward nodes ask for the same parameter's gradient before
+    AccumulateGrad runs - they must not be handed the same slot of the flat gradient buffer (ParamStore.grad_view)"""
+    from deepsvg_amd.synthetic import make_batch
+    cfg = H.build_cfg("hier")
+    cfg.n_layers = cfg.n_layers_decode = 1
+    model = deepsvg_amd.SVGTransformer(cfg).eval()
+    lf = deepsvg_amd.SVGLoss(cfg)
+    b1, b2 = make_batch(3, seed=1), make_batch(3, seed=2)
+    model.zero_grad()
+    for c, a in (b1, b2):
+        _loss_of(model, lf, c, a).backward()
+    want = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.zero_grad()
+    (_loss_of(model, lf, *b1) + _loss_of(model, lf, *b2)).backward()
+    for n, p in model.named_parameters():
+        assert H.rel_l2(p.grad, want[n]) < 1e-5, n
+
+
+def test_other_losses_get_the_full_backward(emulated_ops):
+    """the live-prefix backward of the second decoder stage is exact under SVGLoss only: a loss that touches the logits
+    of invisible groups must see the same gradients with the skip on (default) and off"""
+    from deepsvg_amd.synthetic import make_batch
+    cfg = H.build_cfg("hier")
+    cfg.n_layers = cfg.n_layers_decode = 1
+    c, a = make_batch(6, seed=3)
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 4)
+    grads = {}
+    for skip in (True, False):
+        model = deepsvg_amd.SVGTransformer(cfg).eval()
+        model.load_state_dict(sd)
+        model.skip_invisible_backward = skip
+        out = model(c, a, c, a, params={})
+        assert (model.last_live is not None) == skip
+        (out["command_logits"].float().pow(2).sum() + out["visibility_logits"].float().sum()).backward()
+        grads[skip] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert grads[True].keys() == grads[False].keys()
+    for n in grads[True]:
+        assert H.rel_l2(grads[True][n], grads[False][n]) < 1e-5, n
+    # ... while SVGLoss arms the restriction (and stays exact: test_packed_encoder_equals_padded_encoder)
+    model = deepsvg_amd.SVGTransformer(cfg).eval()
+    out = model(c, a, c, a, params={})
+    live = dict.get(out, "_dsvg_live")["live"]
+    assert not live.armed
+    deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
+    assert live.armed
+
+
+def test_model_survives_deepcopy_pickle_and_parameter_reassignment(emulated_ops):
+    import copy
+    import io
+    from deepsvg_amd.synthetic import make_batch
+    cfg = H.build_cfg("hier")
+    cfg.n_layers = cfg.n_layers_decode = 1
+    model = deepsvg_amd.SVGTransformer(cfg).eval()
+    lf = deepsvg_amd.SVGLoss(cfg)
+    c, a = make_batch(3, seed=1)
+
+    def grads(m):
+        m.zero_grad()
+        _loss_of(m, lf, c, a).backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+    g0 = grads(model)                        # the flat store now exists
+    clone = copy.deepcopy(model)             # EMA / best-model snapshot
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=False)
+    for m in (clone, loaded):
+        g = grads(m)
+        assert all(torch.equal(g[n], g0[n]) for n in g0)
+        assert m.store is not model.store and m.store.flat.data_ptr() != model.store.flat.data_ptr()
+    # a re-assigned .data of a parameter in the MIDDLE of the flat buffer is noticed (the buffer is rebuilt)
+    name = "encoder.encoder.layers.0.linear1.weight"
+    p = dict(model.named_parameters())[name]
+    p.data = p.data.clone() * 0.5
+    g1 = grads(model)
+    other = "encoder.encoder.layers.0.linear2.weight"
+    assert not torch.equal(g1[other], g0[other])
+    assert p.data_ptr() == model.store.flat.data_ptr() + 4 * model.store.index[id(p)][0]
+
+
+def test_hierarch_outputs_feed_straight_back_for_a_batch(emulated_ops):
+    """return_hierarch hands out (1, G, N, 2) and (1, G, N, dim_z), both seq-first; feeding them straight back (as the
+    reference's notebooks do with N = 1) must give the full forward's logits for N > 1 too, and the documented
+    batch-first per-group latents keep working"""
+    from deepsvg_amd.synthetic import make_batch
+    cfg = H.build_cfg("hier")
+    cfg.n_layers = cfg.n_layers_decode = 1
+    model = deepsvg_amd.SVGTransformer(cfg).eval()
+    c, a = make_batch(3, seed=5)
+    with torch.no_grad():
+        full = model(c, a, c, a, return_tgt=False)
+        hl, zg = model(c, a, None, None, return_hierarch=True, return_tgt=False)
+        assert hl.shape == (1, 8, 3, 2) and zg.shape == (1, 8, 3, cfg.dim_z)
+        back = model(None, None, None, None, z=zg, hierarch_logits=hl, return_tgt=False)
+        back2 = model(None, None, None, None, z=zg.permute(2, 1, 0, 3).contiguous(), hierarch_logits=hl, return_tgt=False)
+    for k in ("command_logits", "args_logits"):
+        assert torch.allclose(back[k], full[k], atol=1e-5) and torch.allclose(back2[k], full[k], atol=1e-5), k
+    with pytest.raises(ValueError):
+        model(None, None, None, None, z=zg[:, :, :2].permute(2, 1, 0, 3).contiguous(), hierarch_logits=hl, return_tgt=False)

@@ -42,6 +42,23 @@ def test_oracle_matches_reference_golden(name):
         assert torch.allclose(zg, torch.from_numpy(g["hier_z"]), rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("tag", H.sample_cases())
+def test_oracle_greedy_sample_matches_reference_golden(tag):
+    """one-shot greedy_sample (+ _make_valid, visibility threshold, concat_groups) against the reference's own samples
+    (tests/golden/make_golden_sample.py)"""
+    t, cfg = H.sample_fixture(tag)
+    sd = _oracle_weights(cfg, int(t["wseed"]))
+    eps = t.get("eps")
+
+    def sample(c, a, label, z, hl, concat, icon):
+        e = None
+        if eps is not None and z is None:
+            e = eps if icon is None else eps[:, :, icon:icon + 1]
+        cy, ay, _, _ = O.greedy_sample(sd, cfg, c, a, label=label, z=z, hierarch_logits=hl, concat_groups=concat, eps=e)
+        return cy, ay
+    H.run_sample_checks(sample, t, cfg)
+
+
 def test_extended_padding_mask_semantics():
     """canonical `extended` mask = mask | mask shifted by 3"""
     cmd = torch.tensor([[5, 0, 1, 2, 1, 4, 4, 4, 4, 4, 4, 4.0]])
