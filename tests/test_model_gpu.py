@@ -216,10 +216,12 @@ def test_packed_encoder_equals_padded_encoder(gpu_device, dtype):
 # deviates by 1.6e-2 / 2.1e-2 / 9.2e-3 abs on the three logit tensors and flips 0.43 % / 1.5 % of the arg-maxes
 BF16_BOUNDS = {
     # name: (cmd logit abs, args logit abs, cmd argmax agreement, loss rel, grad-norm median rel, grad-norm max rel)
-    "hier_ordered_n2": (0.15, 0.15, 0.97, 0.02, 0.03, 0.25),
-    "hier_ordered_n5": (0.15, 0.15, 0.97, 0.02, 0.03, 0.25),
-    "onestage50_n3": (0.15, 0.15, 0.97, 0.02, 0.03, 0.25),
-    "fonts_label_n4": (0.15, 0.15, 0.97, 0.02, 0.03, 0.25),
+    # measured: cmd 4.3e-2 / 3.3e-2 / 2.9e-2 / 4.1e-2, args 2.9e-2 .. 4.7e-2, agreement 0.990 .. 1.0, loss 0.7e-3 .. 3.0e-3,
+    # grad-norm median 1.3e-3 .. 2.9e-3, max 1.0e-2 .. 3.5e-2
+    "hier_ordered_n2": (0.09, 0.10, 0.98, 6e-3, 6e-3, 7e-2),
+    "hier_ordered_n5": (0.09, 0.10, 0.98, 6e-3, 6e-3, 7e-2),
+    "onestage50_n3": (0.09, 0.10, 0.98, 6e-3, 6e-3, 7e-2),
+    "fonts_label_n4": (0.09, 0.10, 0.98, 6e-3, 6e-3, 7e-2),
 }
 
 
