@@ -98,6 +98,9 @@ SIGNATURES = {
                                  c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, vp, vp, vp]),
     "dsvg_match_assign": (c_i32, [vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp]),
     "dsvg_argmax_rows": (c_i32, [c_i32, vp, c_i64, c_i32, c_i64, c_i32, vp, vp]),
+    "dsvg_ffn_pack_bytes": (c_i64, [c_i32, c_i32]),
+    "dsvg_ffn_pack": (c_i32, [vp, vp, c_i32, c_i32, c_i32, vp, vp, vp, vp]),
+    "dsvg_ffn_fwd": (c_i32, [vp, vp, vp, vp, vp, c_i64, c_f32, c_f32, c_u32, c_u32, vp, c_i32, vp]),
     "dsvg_probe_trread": (c_i32, [vp, vp, vp]),
 }
 

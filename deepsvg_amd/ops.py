@@ -738,6 +738,69 @@ def cast_weights(src, dst=None, dst_t=None):
     return dst, dst_t
 
 
+# ------------------------------------------------------------------------------------------------
+# fused FFN sub-block (bf16, d_model 256 / dim_ff 512)
+# ------------------------------------------------------------------------------------------------
+FFN_FWD_CHUNKS, FFN_FWD_LAYER_ELEMS, FFN_BWD_LAYER_ELEMS = 16, 16 * 32 * 512, 16 * 48 * 512
+_FFN_STAGES = int(os.environ.get("DSVG_FFN_STAGES", "0"))     # LDS ring depth of the fused kernels (0 = default), tuning knob
+
+
+def ffn_pack(flat, offs, n_layers, packed_fwd=None, packed_bwd=None, b1f=None):
+    """fragment-major bf16 images of linear1 / linear2 of n_layers layers, straight from the fp32 master buffer `flat`,
+    with the LayerNorm affine folded into linear1 (include/dsvg.h).  offs: int64 device tensor [n_layers, 5] of element
+    offsets (linear1.weight, linear1.bias, linear2.weight, norm.weight, norm.bias).  -> (packed_fwd, packed_bwd, b1f)"""
+    _chk(flat, offs, packed_fwd, packed_bwd, b1f)
+    assert flat.dtype == torch.float32 and offs.dtype == torch.int64 and tuple(offs.shape) == (n_layers, 5)
+    assert offs.is_contiguous()
+    dev = flat.device
+    if packed_fwd is None:
+        packed_fwd = torch.empty(n_layers * FFN_FWD_LAYER_ELEMS, dtype=torch.bfloat16, device=dev)
+    if packed_bwd is None:
+        packed_bwd = torch.empty(n_layers * FFN_BWD_LAYER_ELEMS, dtype=torch.bfloat16, device=dev)
+    if b1f is None:
+        b1f = torch.empty((n_layers, 512), dtype=torch.float32, device=dev)
+    assert packed_fwd.numel() == n_layers * FFN_FWD_LAYER_ELEMS and packed_bwd.numel() == n_layers * FFN_BWD_LAYER_ELEMS
+    assert b1f.numel() == n_layers * 512 and b1f.dtype == torch.float32
+    _l.check(_l.load().dsvg_ffn_pack(flat.data_ptr(), offs.data_ptr(), n_layers, 256, 512, packed_fwd.data_ptr(),
+                                     packed_bwd.data_ptr(), b1f.data_ptr(), _stream()), "dsvg_ffn_pack")
+    return packed_fwd, packed_bwd, b1f
+
+
+def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, site_res=0, seed=None, out=None):
+    """y = x + drop_r(linear2(drop_h(relu(linear1(LayerNorm(x))))))  (x bf16 [rows, 256]; the LayerNorm's gamma / beta
+    are inside packed_fwd_layer / b1f, see ffn_pack)"""
+    _chk(x, packed_fwd_layer, b1f, b2, seed, out)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
+    assert packed_fwd_layer.numel() == FFN_FWD_LAYER_ELEMS and packed_fwd_layer.is_contiguous()
+    assert b1f.numel() == 512 and b2.numel() == 256 and b1f.dtype == torch.float32 and b2.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(x)
+    ev = _prof_begin()
+    _l.check(_l.load().dsvg_ffn_fwd(x.data_ptr(), packed_fwd_layer.data_ptr(), b1f.data_ptr(), b2.data_ptr(),
+                                    out.data_ptr(), x.shape[0], float(eps), float(drop_p), int(site_hidden),
+                                    int(site_res), _p(seed) if drop_p > 0 else None, _FFN_STAGES, _stream()),
+             "dsvg_ffn_fwd")
+    # 2 GEMMs of 2 * 256 * 512 FLOP per row; algorithmic bytes: the row in, the row out (SURVEY.md 8(d))
+    _prof_end(ev, 4.0 * 256 * 512 * x.shape[0], 2.0 * 512 * x.shape[0], dict(op="ffn_fwd", rows=x.shape[0]))
+    return out
+
+
+def _prof_begin():
+    if not (PROFILE_ON and _TAG is not None):
+        return None
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    return ev0
+
+
+def _prof_end(ev0, flops, alg_bytes, spec):
+    if ev0 is None:
+        return
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev1.record()
+    PROFILE.append((_TAG, ev0, ev1, float(flops), float(alg_bytes), spec))
+
+
 def gate_mul(dy, y, scale=1.0):
     """out = dy * scale where y > 0 else 0   (backward of relu [+ dropout] from the saved output)"""
     _chk(dy, y)

@@ -347,6 +347,29 @@ int dsvg_assemble_batch(const int16_t* rows, int64_t n_rows, const int32_t* slot
                         const int32_t* variant, int64_t n_items, int32_t G, int32_t grouped, int32_t L,
                         float pad_val, int32_t args_dim, float* commands, float* args, float* args_rel,
                         void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused FFN sub-block, bf16, d_model = 256 / dim_feedforward = 512 (csrc/ffn_fused.hip):
+ *     y = x + drop_r( linear2( drop_h( relu( linear1( LayerNorm(x) ) ) ) ) )
+ * replaces norm2 + linear1 + activation + dropout + linear2 + dropout2 + the residual add of
+ * deepsvg/model/layers/improved_transformer.py:51-53 (encoder layer) and :138-140 (decoder layer) in ONE launch;
+ * the normalised rows and the hidden activations never reach HBM.
+ *   dsvg_ffn_pack   once per optimiser step: re-lays linear1.weight [512,256] / linear2.weight [256,512] of n_layers
+ *                   layers out as bf16 MFMA-fragment-major chunk images, straight from the fp32 master parameters
+ *                   `flat_f32`; offs = int64 device array [n_layers][5] of element offsets of (linear1.weight,
+ *                   linear1.bias, linear2.weight, norm.weight, norm.bias).  The LayerNorm's affine part is folded into
+ *                   linear1: W1' = W1 diag(gamma), b1' = b1 + W1 beta (b1_folded, fp32 [n_layers][512]).
+ *                   packed_fwd [n_layers][16][32 KiB], packed_bwd [n_layers][16][48 KiB] (dsvg_ffn_pack_bytes(n, 0 | 1)).
+ *   dsvg_ffn_fwd    x, y bf16 [rows, 256] (row stride 256); packed_fwd_layer / b1_folded = that layer's slices; b2 fp32;
+ *                   dropout sites / seed as everywhere else (draw scheme "v2", private to the fused kernels);
+ *                   stages = LDS ring depth (0 = default).
+ * Buffers are caller-owned; all work is enqueued on `stream`. */
+int64_t dsvg_ffn_pack_bytes(int32_t n_layers, int32_t which);
+int dsvg_ffn_pack(const float* flat_f32, const int64_t* offs, int32_t n_layers, int32_t d_model, int32_t d_ff,
+                  void* packed_fwd, void* packed_bwd, float* b1_folded, void* stream);
+int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const float* b1_folded, const float* b2, void* y,
+                 int64_t rows, float eps, float drop_p, uint32_t site_hidden, uint32_t site_res, const void* seed,
+                 int32_t stages, void* stream);
 /* test hook: raw ds_read_b64_tr_b16 on a 4 KiB LDS image img[i]=i, lane l reads at byte offset off[l] */
 int dsvg_probe_trread(const int* off, short* out, void* stream);
 

@@ -768,3 +768,103 @@ def test_attention_long_single_row_step(gpu_device, dtype):
         mask = torch.ones(S, dtype=torch.bool, device=DEV)
         mask[row] = False
         assert bool((got[:, mask] == 7.0).all()), "only_row wrote other rows"
+
+
+# ----------------------------------------------------------------------------------------------------
+# fused FFN sub-block (csrc/ffn_fused.hip)
+# ----------------------------------------------------------------------------------------------------
+FFN_LAYER_PARAMS = 131072 + 512 + 131072 + 256 + 256 + 8     # W1, b1, W2, gamma, beta (+ padding)
+
+
+def _ffn_setup(rows, seed=0, n_layers=2):
+    """fp32 'master' buffer with n_layers x (linear1.weight, linear1.bias, linear2.weight, norm.weight, norm.bias), the
+    offsets table dsvg_ffn_pack takes, a bf16 activation matrix and linear2's bias"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    flat = torch.zeros(8 + n_layers * FFN_LAYER_PARAMS)
+    offs = []
+    for i in range(n_layers):
+        o = 8 + i * FFN_LAYER_PARAMS
+        ent = [o, o + 131072, o + 131072 + 512, o + 262144 + 512, o + 262144 + 768]
+        flat[ent[0]:ent[0] + 131072] = torch.randn(131072, generator=g) * 0.06
+        flat[ent[1]:ent[1] + 512] = torch.randn(512, generator=g) * 0.3
+        flat[ent[2]:ent[2] + 131072] = torch.randn(131072, generator=g) * 0.06
+        flat[ent[3]:ent[3] + 256] = 1 + 0.2 * torch.randn(256, generator=g)
+        flat[ent[4]:ent[4] + 256] = 0.2 * torch.randn(256, generator=g)
+        offs.append(ent)
+    x = (torch.randn(rows, 256, generator=g) * 1.5 + 0.3).to(DEV).to(torch.bfloat16)
+    b2 = (0.3 * torch.randn(256, generator=g)).to(DEV)
+    return flat.to(DEV), torch.tensor(offs, dtype=torch.int64, device=DEV), x, b2
+
+
+def _ffn_params(flat, offs, layer):
+    o1, ob1, o2, og, ob = (int(v) for v in offs[layer])
+    return (flat[o1:o1 + 131072].view(512, 256), flat[ob1:ob1 + 512], flat[o2:o2 + 131072].view(256, 512),
+            flat[og:og + 256], flat[ob:ob + 256])
+
+
+def test_ffn_pack_layouts(gpu_device):
+    """every fragment of the packed images against the index formulas of csrc/ffn_fused.hip (lane l = (i, half), 8
+    elements e): forward [W1' chunk | W2 chunk], backward [W1' chunk | W2^T chunk | W1'^T chunk], W1' = W1 diag(gamma)
+    rounded to bf16 once, and the folded bias b1 + W1 beta"""
+    flat, offs, _, _ = _ffn_setup(8, seed=3)
+    pf, pb, b1f = ops.ffn_pack(flat, offs, 2)
+    pf = pf.view(2, 16, 32, 64, 8).cpu().float()
+    pb = pb.view(2, 16, 48, 64, 8).cpu().float()
+    lane = torch.arange(64)
+    i, half = (lane & 31).view(64, 1), (lane >> 5).view(64, 1)
+    e = torch.arange(8).view(1, 8)
+    for layer in range(2):
+        W1, b1, W2, gamma, beta = (t.cpu() for t in _ffn_params(flat, offs, layer))
+        W1g = (W1 * gamma).to(torch.bfloat16).float()
+        W2 = W2.to(torch.bfloat16).float()
+        assert torch.allclose(b1f[layer].cpu(), b1 + W1 @ beta, rtol=1e-5, atol=1e-5)
+        for c in (0, 7, 15):
+            for ks in range(16):
+                want = W1g[32 * c + i, 16 * ks + 8 * half + e]
+                assert torch.equal(pf[layer, c, ks], want) and torch.equal(pb[layer, c, ks], want)
+                assert torch.equal(pb[layer, c, 16 + ks], W2[16 * ks + 8 * half + e, 32 * c + i])
+            for t in range(8):
+                for ks2 in range(2):
+                    hid = (e & 3) + 8 * (2 * ks2 + (e >> 2)) + 4 * half
+                    assert torch.equal(pf[layer, c, 16 + 2 * t + ks2], W2[32 * t + i, 32 * c + hid])
+                    assert torch.equal(pb[layer, c, 32 + 2 * t + ks2], W1g[32 * c + hid, 32 * t + i])
+
+
+@pytest.mark.parametrize("rows", [256, 1000, 4096 + 37])
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_ffn_fwd_matches_reference(gpu_device, rows, drop_p):
+    """fused LayerNorm + linear1 + ReLU + dropout + linear2 + dropout + residual against the fp32 restatement (same
+    bf16 rounding points: normalised rows, folded weights, hidden activations), incl. ragged row counts and the
+    dropout replay"""
+    flat, offs, x, b2 = _ffn_setup(rows, seed=rows)
+    pf, pb, b1f = ops.ffn_pack(flat, offs, 2)
+    epf, _, eb1f = R.ffn_pack(flat, offs, 2)
+    assert torch.equal(pf.view(2, -1)[:, :10], pf.view(2, -1)[:, :10])
+    seed = _seed_tensor(0x0123456789ABCDEF)
+    for layer in (0, 1):
+        sl = slice(layer * ops.FFN_FWD_LAYER_ELEMS, (layer + 1) * ops.FFN_FWD_LAYER_ELEMS)
+        y = ops.ffn_fwd(x, pf[sl], b1f[layer], b2, 1e-5, drop_p, 403 + layer, 404 + layer, seed)
+        want = R.ffn_fwd(x, epf[sl], eb1f[layer], b2, 1e-5, drop_p, 403 + layer, 404 + layer, seed)
+        _close(y, want, 1.5e-2, f"ffn_fwd rows={rows} p={drop_p} layer={layer}")
+        # rounding-level agreement on the bulk, not just the max
+        assert (y.float() - want.float()).abs().mean().item() < 2e-3 * want.float().abs().mean().item()
+    if drop_p > 0:      # the masks are a pure function of (seed, site, id): another seed gives another output
+        pl = pf[:ops.FFN_FWD_LAYER_ELEMS]
+        y1 = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, drop_p, 403, 404, _seed_tensor(7))
+        y2 = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, drop_p, 403, 404, _seed_tensor(7))
+        y3 = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, drop_p, 403, 404, _seed_tensor(8))
+        assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+
+
+def test_ffn_fwd_equals_unfused_kernels(gpu_device):
+    """eval mode: the fused kernel against the three launches it replaces (layernorm_fwd + 2 GEMMs on the bf16 weights);
+    the fused path rounds W1 diag(gamma) and the un-scaled normalised rows to bf16 instead of W1 and the scaled rows"""
+    rows = 2048
+    flat, offs, x, b2 = _ffn_setup(rows, seed=11)
+    pf, _, b1f = ops.ffn_pack(flat, offs, 2)
+    W1, b1, W2, gamma, beta = _ffn_params(flat, offs, 0)
+    xn, _, _ = ops.layernorm_fwd(x, gamma.contiguous(), beta.contiguous())
+    h = ops.gemm(xn, W1.to(torch.bfloat16), bias=b1.contiguous(), act=ops.RELU)
+    want = ops.gemm(h, W2.to(torch.bfloat16), bias=b2, res=x)
+    y = ops.ffn_fwd(x, pf[:ops.FFN_FWD_LAYER_ELEMS], b1f[0], b2)
+    _close(y, want, 1.2e-2, "fused vs unfused FFN")

@@ -60,6 +60,31 @@ def drop_mult(p, seed, site, idx):
                        torch.full((), scale, dtype=torch.float32, device=idx.device))
 
 
+def drop2_mult(p, seed, site, idx):
+    """draw scheme "v2" of the fused kernels (csrc/ffn_fused.hip drop2_*): one counter hash per 16 consecutive ids, a
+    one-multiply finaliser per pair of 16-bit draws; same thresholds / scale / seed mixing as drop_mult"""
+    if p <= 0 or seed is None:
+        return torch.ones(idx.shape, dtype=torch.float32, device=idx.device)
+    s = int(seed.reshape(-1)[0].item()) & 0xFFFFFFFFFFFFFFFF
+    s0 = _hash32_int((s & M32) ^ ((site * 0x9E3779B1) & M32))
+    s1 = _hash32_int(((s >> 32) + site * 0x85EBCA77 + 0x165667B1) & M32)
+    thresh = min(65535, int(np.float32(np.float32(p) * np.float32(65536.0) + np.float32(0.5))))
+    scale = float(np.float32(65536.0) / np.float32(65536 - thresh))
+    idx = idx.to(torch.int64)
+    g = idx >> 4
+    slot = idx & 15
+    lo, hi = g & M32, (g >> 32) & M32
+    h = _hash32_t(lo ^ s0)
+    h = _hash32_t((h + hi * 0x9E3779B1 + s1) & M32)
+    w = (h + ((slot >> 1) + 1) * 0x9E3779B9) & M32
+    w = w ^ (w >> 16)
+    w = (w * 0x7FEB352D) & M32
+    w = w ^ (w >> 15)
+    draw = torch.where((slot & 1) == 1, w >> 16, w & 0xFFFF)
+    return torch.where(draw < thresh, torch.zeros((), dtype=torch.float32, device=idx.device),
+                       torch.full((), scale, dtype=torch.float32, device=idx.device))
+
+
 def _ids(rows, cols, device, ld=None):
     ld = cols if ld is None else ld
     return torch.arange(rows, device=device, dtype=torch.int64).unsqueeze(1) * ld + \
@@ -625,6 +650,74 @@ def advance_step_(counter, seed):
         if z >= 1 << 63:
             z -= 1 << 64
         seed.fill_(z)
+
+
+# ----------------------------------------------------------------------------------------------------
+# fused FFN sub-block.  The emulated "packed" images simply carry the two weight matrices in bf16 with the LayerNorm
+# affine folded into linear1 exactly as csrc/ffn_fused.hip does: per layer packed_fwd = [W1' (512 x 256) | W2 (256 x 512)],
+# packed_bwd = [W1' | W2 | unused]; b1f = b1 + W1 beta
+# ----------------------------------------------------------------------------------------------------
+FFN_FWD_LAYER_ELEMS, FFN_BWD_LAYER_ELEMS = 16 * 32 * 512, 16 * 48 * 512
+
+
+def ffn_pack(flat, offs, n_layers, packed_fwd=None, packed_bwd=None, b1f=None):
+    dev = flat.device
+    if packed_fwd is None:
+        packed_fwd = torch.empty(n_layers * FFN_FWD_LAYER_ELEMS, dtype=torch.bfloat16, device=dev)
+    if packed_bwd is None:
+        packed_bwd = torch.zeros(n_layers * FFN_BWD_LAYER_ELEMS, dtype=torch.bfloat16, device=dev)
+    if b1f is None:
+        b1f = torch.empty((n_layers, 512), dtype=torch.float32, device=dev)
+    for i in range(n_layers):
+        o1, ob1, o2, og, ob = (int(v) for v in offs[i])
+        W1 = flat[o1:o1 + 131072].view(512, 256)
+        gamma, beta = flat[og:og + 256], flat[ob:ob + 256]
+        w = torch.cat([(W1 * gamma).reshape(-1), flat[o2:o2 + 131072]]).to(torch.bfloat16)
+        packed_fwd[i * FFN_FWD_LAYER_ELEMS:(i + 1) * FFN_FWD_LAYER_ELEMS] = w
+        packed_bwd[i * FFN_BWD_LAYER_ELEMS:i * FFN_BWD_LAYER_ELEMS + 262144] = w
+        b1f.view(n_layers, 512)[i] = flat[ob1:ob1 + 512] + W1 @ beta
+    return packed_fwd, packed_bwd, b1f
+
+
+def _ffn_weights(packed_layer):
+    return packed_layer[:131072].view(512, 256), packed_layer[131072:262144].view(256, 512)
+
+
+def _ffn_normalise(x, eps):
+    """xh = (x - mean) * rstd rounded to the storage dtype (no affine: it is folded into the packed linear1)"""
+    xf = _f(x)
+    mean = xf.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(((xf - mean) ** 2).mean(-1, keepdim=True) + eps)
+    return ((xf - mean) * rstd).to(x.dtype), mean.squeeze(-1), rstd.squeeze(-1)
+
+
+def _ffn_hidden_ids(rows, device):
+    """dropout ids of the hidden site in the order the fused kernels' lanes own them: unit j = 32 c + 8 q + 4 half + e
+    (q < 4, e < 4) of token t has id 512 t + 32 c + 16 half + 4 q + e"""
+    j = torch.arange(512, device=device, dtype=torch.int64)
+    jl = j & 31
+    perm = (j - jl) + 16 * ((jl >> 2) & 1) + 4 * (jl >> 3) + (jl & 3)
+    return torch.arange(rows, device=device, dtype=torch.int64).unsqueeze(1) * 512 + perm.unsqueeze(0)
+
+
+def _ffn_hidden(xn, W1, b1, drop_p, site_hidden, seed):
+    """drop_h(relu(linear1(xn))) rounded to the storage dtype, and the multiplier mask"""
+    pre = _f(xn) @ _f(W1).t() + b1
+    m = drop2_mult(drop_p, seed, site_hidden, _ffn_hidden_ids(xn.shape[0], xn.device))
+    return (torch.relu(pre) * m).to(xn.dtype), pre, m
+
+
+def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, site_res=0, seed=None, out=None):
+    W1, W2 = _ffn_weights(packed_fwd_layer)
+    xh, _, _ = _ffn_normalise(x, eps)
+    h, _, _ = _ffn_hidden(xh, W1, b1f, drop_p, site_hidden, seed)
+    y = _f(h) @ _f(W2).t() + b2
+    y = y * drop2_mult(drop_p, seed, site_res, _ids(x.shape[0], 256, x.device)) + _f(x)
+    y = y.to(x.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def gate_mul(dy, y, scale=1.0):
