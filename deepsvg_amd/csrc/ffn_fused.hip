@@ -164,6 +164,17 @@ __device__ __forceinline__ void drop2_mult8(const DropCtx& c, uint32_t h, int hi
 // LDS-DMA of one wave's 4 consecutive 1 KiB pieces (hidden from hipcc, see the header).  src: per-lane address of the
 // first piece (+ lane * 16 included); lds: wave-uniform LDS byte address of the first piece.
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dma2(const void* src, uint32_t lds) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+}
 __device__ __forceinline__ void dma4(const void* src, uint32_t lds) {
     // the instruction's immediate offset advances BOTH addresses (global: src + offset, LDS: M0 + offset + lane * 16)
     uint32_t keep;
@@ -441,6 +452,397 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, kernel 1 of 2: the hidden tile.  Per 32-token wave and hidden chunk c:
+//     pre  = W1'[chunk] . xh            (recomputed: the forward pass stores nothing but x)
+//     dh   = W2[:, chunk]^T . dym       (dym = dy * residual-dropout mask, replayed)
+//     h    = drop_h(relu(pre + b1')),  dpre = dh * [pre + b1' > 0] * drop_h mask
+// and writes, for the weight-gradient GEMMs and kernel 2: h and dpre (bf16 [T, 512], hidden columns in FRAGMENT ORDER:
+// position 32 c + 16 s + 8 b + 4 a + e holds unit 32 c + 16 s + 8 a + 4 b + e - exactly the 8 values a lane owns per K
+// step, so every store is one aligned 16-byte piece and kernel 2 reads its B operands back with one 16-byte load),
+// xh = (x - mean) * rstd and dym (bf16 [T, 256]).  The two 16-deep MFMA chains (pre, dh) are independent and issued
+// alternately, so no dependent MFMA sits right behind its predecessor's LDS read.
+// LDS ring: [W1' chunk | W2^T chunk] = the first 32 KiB of every 48 KiB backward chunk.
+// (stores are in flight inside the loop and vmcnt also counts them, out of order with respect to loads: every wait is 0)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void ffn_bwd_hidden_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                const bf16_t* __restrict__ img, const float* __restrict__ b1,
+                                                                bf16_t* __restrict__ h_out, bf16_t* __restrict__ dpre_out,
+                                                                bf16_t* __restrict__ xh_out, bf16_t* __restrict__ dym_out,
+                                                                int M, float eps, float drop_p,
+                                                                const uint64_t* __restrict__ seed, uint32_t site_h,
+                                                                uint32_t site_r) {
+    constexpr int NBUF = 3;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [3 x 32 KiB | b1' (2 KiB)]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = wave >= 4;
+    const int tok = lane & 31, half = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)DSVG_LDS_PTR(smem);
+    float* sb1 = reinterpret_cast<float*>(smem + NBUF * FWD_CHUNK);
+
+    const char* my_src = reinterpret_cast<const char*>(img) + wave * 4096 + lane * 16;
+    const uint32_t my_dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);
+    auto issue = [&](int c) { dma4(my_src + (size_t)c * BWD_CHUNK, my_dst + (uint32_t)(c % NBUF) * FWD_CHUNK); };
+    issue(0);
+    issue(1);
+    sb1[tid] = b1[tid];
+
+    const int row0 = blockIdx.x * TOK_PER_WG + wave * 32;
+    const int m = row0 + tok;
+    const bool live = m < M;
+    const int my_row = min(m, M - 1);
+    const DropCtx dh_ctx = drop_make(drop_p, seed, site_h);
+    const DropCtx dr_ctx = drop_make(drop_p, seed, site_r);
+
+    // ---- xh fragments (LayerNorm without the affine part) and their copy for the weight-gradient GEMM ---------------------
+    bf16x8 xf[16];
+    {
+        const char* xr = reinterpret_cast<const char*>(x) + (size_t)my_row * (FD * 2) + half * 16;
+        uint4 raw[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) raw[ks] = *reinterpret_cast<const uint4*>(xr + 32 * ks);
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            float v[8];
+            unpack8(raw[ks], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[e];
+        }
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.f / FD);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            float v[8];
+            unpack8(raw[ks], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; ss += d * d; }
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        const float rstd = rsqrtf(ss * (1.f / FD) + eps);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
+        char* xo = reinterpret_cast<char*>(xh_out) + (size_t)my_row * (FD * 2) + half * 16;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            float v[8];
+            unpack8(raw[ks], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd;
+            Frag8 f;
+            f.u = pack8(v);
+            xf[ks] = f.v;
+            if (live) *reinterpret_cast<uint4*>(xo + 32 * ks) = f.u;
+        }
+    }
+    // ---- dym fragments: dy with the residual dropout replayed (ids m * 256 + column, groups of 16) ------------------------
+    bf16x8 df[16];
+    {
+        const char* dr = reinterpret_cast<const char*>(dy) + (size_t)my_row * (FD * 2) + half * 16;
+        char* dm_o = reinterpret_cast<char*>(dym_out) + (size_t)my_row * (FD * 2) + half * 16;
+        uint4 raw[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) raw[ks] = *reinterpret_cast<const uint4*>(dr + 32 * ks);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            Frag8 f;
+            if (dr_ctx.on) {
+                float v[8], mm[8];
+                unpack8(raw[ks], v);
+                const uint32_t hr = drop2_group(dr_ctx, ((uint64_t)m * FD + 16 * ks) >> 4);
+                drop2_mult8(dr_ctx, hr, half, mm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= mm[e];
+                f.u = pack8(v);
+                if (live) *reinterpret_cast<uint4*>(dm_o + 32 * ks) = f.u;
+            } else {
+                f.u = raw[ks];      // no dropout: dym == dy, the caller passes dy itself to the weight-gradient GEMM
+            }
+            df[ks] = f.v;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    floatx16 pre, dh;
+    uint4 ring[4];
+    const char* lbase = smem + lane * 16;
+    auto slot_of = [&](int c) -> const char* { return lbase + (c % NBUF) * FWD_CHUNK; };
+    auto ld = [&](const char* p) -> uint4 { return *reinterpret_cast<const uint4*>(p); };
+    auto sync = [&](int k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (k + 2 < NCH) issue(k + 2);
+    };
+    // fragment stream of a chunk in consumption order: W1'[0], W2T[0], W1'[1], W2T[1], ... (fragment n -> n / 2 + 16 (n & 1))
+    auto frag_at = [&](const char* sc, int n) -> const char* { return sc + ((n >> 1) + 16 * (n & 1)) * FRAG; };
+    auto GEMMS = [&](const char* sc, const char* sn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { pre[r] = 0.f; dh[r] = 0.f; }
+#pragma unroll
+        for (int n = 0; n < 32; ++n) {
+            Frag8 a;
+            a.u = ring[n & 3];
+            if (n & 1) dh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, df[n >> 1], dh, 0, 0, 0);
+            else pre = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, xf[n >> 1], pre, 0, 0, 0);
+            if (n + 4 < 32) ring[n & 3] = ld(frag_at(sc, n + 4));
+            else if (sn) ring[n & 3] = ld(frag_at(sn, n + 4 - 32));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto EPI = [&](int c) {
+        const uint64_t id0 = (uint64_t)m * FF + (uint32_t)(CH * c + 16 * half);
+        const uint32_t hh = dh_ctx.on ? drop2_group(dh_ctx, id0 >> 4) : 0u;
+        char* ho = reinterpret_cast<char*>(h_out) + (size_t)my_row * (FF * 2) + (CH * c + 8 * half) * 2;
+        char* po = reinterpret_cast<char*>(dpre_out) + (size_t)my_row * (FF * 2) + (CH * c + 8 * half) * 2;
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            float hv[8], pv[8], mm[8];
+            if (dh_ctx.on) drop2_mult8(dh_ctx, hh, ks2, mm);
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * ks2 + qq;
+                const float4 bb = *reinterpret_cast<const float4*>(sb1 + CH * c + 8 * q + 4 * half);
+                const float bq[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = pre[4 * q + e] + bq[e];
+                    const float keep = dh_ctx.on ? mm[4 * qq + e] : 1.f;
+                    const bool act = p > 0.f;
+                    hv[4 * qq + e] = act ? p * keep : 0.f;
+                    pv[4 * qq + e] = act ? dh[4 * q + e] * keep : 0.f;
+                }
+            }
+            if (live) {
+                *reinterpret_cast<uint4*>(ho + 32 * ks2) = pack8(hv);
+                *reinterpret_cast<uint4*>(po + 32 * ks2) = pack8(pv);
+            }
+        }
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();           // chunks 0 and 1 (and b1') are in LDS
+    {
+        const char* s0 = slot_of(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ring[i] = ld(frag_at(s0, i));
+    }
+    for (int c = 0; c < NCH; ++c) {
+        const char* sc = slot_of(c);
+        const char* sn = (c + 1 < NCH) ? slot_of(c + 1) : nullptr;
+        if (!late) sync(c);
+        GEMMS(sc, sn);
+        if (late) sync(c);
+        EPI(c);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, kernel 2 of 2: dx = dy + LayerNorm'( dpre . W1' ).  Token-stationary like the forward kernel; the B operands
+// (dpre in fragment order, see kernel 1) come straight from global memory, one chunk ahead; W1'^T chunks (the last 16
+// KiB of every 48 KiB backward chunk) stream through a 4-slot LDS ring.  The LayerNorm backward needs no gamma (it is
+// inside W1'): dx = dy + rstd * (g - mean(g) - xh * mean(g * xh)), g = dxh, statistics over the row in registers.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __restrict__ dpre, const bf16_t* __restrict__ x,
+                                                            const bf16_t* __restrict__ dy, const bf16_t* __restrict__ img,
+                                                            bf16_t* __restrict__ dx, int M, float eps) {
+    constexpr int NBUF = 4, SLOT = 16 * FRAG;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [4 x 16 KiB]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tok = lane & 31, half = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)DSVG_LDS_PTR(smem);
+    // this wave moves pieces 2 wave, 2 wave + 1 of every 16-piece chunk
+    const char* my_src = reinterpret_cast<const char*>(img) + 32 * FRAG + wave * 2048 + lane * 16;
+    const uint32_t my_dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 2048);
+    auto issue = [&](int c) { dma2(my_src + (size_t)c * BWD_CHUNK, my_dst + (uint32_t)(c % NBUF) * SLOT); };
+    issue(0);
+    issue(1);
+
+    const int row0 = blockIdx.x * TOK_PER_WG + wave * 32;
+    const int m = row0 + tok;
+    const int my_row = min(m, M - 1);
+    const char* pr = reinterpret_cast<const char*>(dpre) + (size_t)my_row * (FF * 2) + half * 16;
+    auto bfrag = [&](int c, int ks2) -> uint4 { return *reinterpret_cast<const uint4*>(pr + (CH * c + 16 * ks2) * 2); };
+
+    floatx16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    uint4 bcur[2], bnext[2];
+    bcur[0] = bfrag(0, 0); bcur[1] = bfrag(0, 1);
+    const char* lbase = smem + lane * 16;
+    for (int c = 0; c < NCH; ++c) {
+        // chunk c landed for everybody, slot of chunk c - 2 is free again (only DMA and the B-operand loads are in
+        // flight: loads return in order, every wait is conservative)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c + 2 < NCH) issue(c + 2);
+        if (c + 1 < NCH) { bnext[0] = bfrag(c + 1, 0); bnext[1] = bfrag(c + 1, 1); }
+        const char* sc = lbase + (c % NBUF) * SLOT;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            Frag8 a, b;
+            a.u = *reinterpret_cast<const uint4*>(sc + n * FRAG);
+            b.u = bcur[n & 1];
+            acc[n >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[n >> 1], 0, 0, 0);
+        }
+        bcur[0] = bnext[0]; bcur[1] = bnext[1];
+    }
+
+    // ---- epilogue: LayerNorm backward on the rows in registers ------------------------------------------------------------
+    // tiles -> the lane's 16 consecutive columns per tile (in place), x row in the same layout
+    const char* xrow = reinterpret_cast<const char*>(x) + (size_t)my_row * (FD * 2);
+    uint4 xr[16];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        xr[2 * t] = *reinterpret_cast<const uint4*>(xrow + (32 * t + 16 * half) * 2);
+        xr[2 * t + 1] = *reinterpret_cast<const uint4*>(xrow + (32 * t + 16 * half + 8) * 2);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        uint32_t xc[4][4];
+        tile_to_cols16(acc[t], xc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * q + e] = __uint_as_float(xc[q][e]);      // column 4 q + e of the 16
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v[8];
+        unpack8(xr[i], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+    }
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.f / FD);
+    // (opaque copies between the passes: hipcc would otherwise keep the 128 unpacked floats alive next to the 128 accumulators)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(xr[i].x), "+v"(xr[i].y), "+v"(xr[i].z), "+v"(xr[i].w));
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v[8];
+        unpack8(xr[i], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; ss += d * d; }
+    }
+    ss += __shfl_xor(ss, 32, 64);
+    const float rstd = rsqrtf(ss * (1.f / FD) + eps);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(xr[i].x), "+v"(xr[i].y), "+v"(xr[i].z), "+v"(xr[i].w));
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            float v[8];
+            unpack8(xr[2 * t + cb], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float g = acc[t][8 * cb + e];
+                c1 += g;
+                c2 += g * ((v[e] - mean) * rstd);
+            }
+        }
+    c1 += __shfl_xor(c1, 32, 64);
+    c2 += __shfl_xor(c2, 32, 64);
+    c1 *= (1.f / FD);
+    c2 *= (1.f / FD);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(xr[i].x), "+v"(xr[i].y), "+v"(xr[i].z), "+v"(xr[i].w));
+    // w = rstd * (g - c1 - xh * c2) in place; then the x registers are dead and make room for dy
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            float v[8];
+            unpack8(xr[2 * t + cb], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[t][8 * cb + e] = rstd * (acc[t][8 * cb + e] - c1 - (v[e] - mean) * rstd * c2);
+        }
+    // (the dy loads below must not be hoisted above the pass that frees the x registers: an address offset that is
+    // opaque to the compiler - always 0 - and ordered behind the last value of that pass pins them here)
+    uint32_t zoff = 0;
+    asm volatile("" : "+v"(zoff) : "v"(acc[7][15]), "v"(acc[0][0]));
+    const char* dyrow = reinterpret_cast<const char*>(dy) + (size_t)my_row * (FD * 2) + zoff;
+    char* orow = reinterpret_cast<char*>(dx) + (size_t)my_row * (FD * 2);
+    uint4 dr[16];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        dr[2 * t] = *reinterpret_cast<const uint4*>(dyrow + (32 * t + 16 * half) * 2);
+        dr[2 * t + 1] = *reinterpret_cast<const uint4*>(dyrow + (32 * t + 16 * half + 8) * 2);
+    }
+    if (m < M) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                float v[8];
+                unpack8(dr[2 * t + cb], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += acc[t][8 * cb + e];
+                *reinterpret_cast<uint4*>(orow + (32 * t + 16 * half + 8 * cb) * 2) = pack8(v);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradients, last step.  The two split-K GEMMs deliver G1p = dpre^T xh [512 (fragment order), 256], its row sums
+// db1p [512 (fragment order)] and G2p = dym^T h [256, 512 (fragment order)]; this kernel undoes the fragment order
+// (position p(j): bits 2 and 3 of j swapped) and the LayerNorm fold (see ffn_pack_kernel):
+//     dW1[j][k] = gamma[k] G1p[p(j)][k] + beta[k] db1p[p(j)],   db1[j] = db1p[p(j)],   dW2[o][j] = G2p[o][p(j)],
+//     dgamma[k] = sum_j W1[j][k] G1p[p(j)][k],                  dbeta[k] = sum_j W1[j][k] db1p[p(j)]
+// One workgroup per 4 columns k (and 4 rows o of dW2); fixed summation order (deterministic).
+// ---------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline int frag_pos(int j) { return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1); }
+
+__global__ __launch_bounds__(256) void ffn_wgrad_finish_kernel(const float* __restrict__ G1p, const float* __restrict__ db1p,
+                                                               const float* __restrict__ G2p, const float* __restrict__ W1,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ dW1, float* __restrict__ db1,
+                                                               float* __restrict__ dW2, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+    __shared__ float red[2][4][256];
+    const int t = threadIdx.x;
+    const int k0 = blockIdx.x * 4;
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + k0);
+    const float4 be = *reinterpret_cast<const float4*>(beta + k0);
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = t + 256 * jj, pj = frag_pos(j);
+        const float4 g = *reinterpret_cast<const float4*>(G1p + (size_t)pj * FD + k0);
+        const float4 w = *reinterpret_cast<const float4*>(W1 + (size_t)j * FD + k0);
+        const float b = db1p[pj];
+        *reinterpret_cast<float4*>(dW1 + (size_t)j * FD + k0) =
+            make_float4(ga.x * g.x + be.x * b, ga.y * g.y + be.y * b, ga.z * g.z + be.z * b, ga.w * g.w + be.w * b);
+        dg[0] += w.x * g.x; dg[1] += w.y * g.y; dg[2] += w.z * g.z; dg[3] += w.w * g.w;
+        db[0] += w.x * b; db[1] += w.y * b; db[2] += w.z * b; db[3] += w.w * b;
+        if (blockIdx.x == 0) db1[j] = b;
+        // rows o = k0 .. k0 + 3 of dW2 (blockIdx.x < 64 covers all 256 rows)
+#pragma unroll
+        for (int oo = 0; oo < 4; ++oo) dW2[(size_t)(k0 + oo) * FF + j] = G2p[(size_t)(k0 + oo) * FF + pj];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[0][i][t] = dg[i]; red[1][i][t] = db[i]; }
+    __syncthreads();
+    if (t < 8) {        // fixed-order sums: thread t < 4 -> dgamma[k0 + t], t >= 4 -> dbeta[k0 + t - 4]
+        const float* r = red[t >> 2][t & 3];
+        float a = 0.f;
+        for (int i = 0; i < 256; ++i) a += r[i];
+        if (t < 4) dgamma[k0 + t] = a; else dbeta[k0 + t - 4] = a;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -490,5 +892,38 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
     else { dsvg_set_error("ffn_fwd: stages must be 3 or 4"); return -1; }
 #undef DSVG_FFN_FWD
     DSVG_LAUNCH_CHECK("ffn_fwd");
+    return 0;
+}
+
+extern "C" int dsvg_ffn_bwd(const void* x, const void* dy, const void* packed_bwd_layer, const float* b1_folded, void* h,
+                            void* dpre, void* xh, void* dym, void* dx, int64_t rows, float eps, float drop_p,
+                            uint32_t site_hidden, uint32_t site_res, const void* seed, void* stream) {
+    DSVG_CHECK_ARG(x && dy && packed_bwd_layer && b1_folded && h && dpre && xh && dx, "ffn_bwd: null pointer");
+    DSVG_CHECK_ARG(rows > 0 && rows < (1ll << 31) - TOK_PER_WG, "ffn_bwd: bad row count");
+    DSVG_CHECK_ARG(!(drop_p > 0.f) || (seed && dym), "ffn_bwd: dropout needs a seed and the dym buffer");
+    DSVG_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)h | (uintptr_t)dpre | (uintptr_t)xh | (uintptr_t)dym |
+                     (uintptr_t)dx | (uintptr_t)packed_bwd_layer) & 15) == 0, "ffn_bwd: operands must be 16-byte aligned");
+    const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds1 = 3 * FWD_CHUNK + 2048, lds2 = 4 * 16 * FRAG;
+    DSVG_ENSURE_LDS(ffn_bwd_hidden_kernel, lds1);
+    hipLaunchKernelGGL(ffn_bwd_hidden_kernel, dim3(nb), dim3(512), lds1, st, (const bf16_t*)x, (const bf16_t*)dy,
+                       (const bf16_t*)packed_bwd_layer, b1_folded, (bf16_t*)h, (bf16_t*)dpre, (bf16_t*)xh, (bf16_t*)dym,
+                       (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res);
+    DSVG_LAUNCH_CHECK("ffn_bwd (hidden)");
+    hipLaunchKernelGGL(ffn_bwd_dx_kernel, dim3(nb), dim3(512), lds2, st, (const bf16_t*)dpre, (const bf16_t*)x,
+                       (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps);
+    DSVG_LAUNCH_CHECK("ffn_bwd (dx)");
+    return 0;
+}
+
+extern "C" int dsvg_ffn_wgrad_finish(const float* g1p, const float* db1p, const float* g2p, const float* w1,
+                                     const float* gamma, const float* beta, float* dw1, float* db1, float* dw2,
+                                     float* dgamma, float* dbeta, void* stream) {
+    DSVG_CHECK_ARG(g1p && db1p && g2p && w1 && gamma && beta && dw1 && db1 && dw2 && dgamma && dbeta,
+                   "ffn_wgrad_finish: null pointer");
+    hipLaunchKernelGGL(ffn_wgrad_finish_kernel, dim3(FD / 4), dim3(256), 0, (hipStream_t)stream, g1p, db1p, g2p, w1, gamma,
+                       beta, dw1, db1, dw2, dgamma, dbeta);
+    DSVG_LAUNCH_CHECK("ffn_wgrad_finish");
     return 0;
 }

@@ -785,6 +785,43 @@ def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, s
     return out
 
 
+def ffn_bwd(x, dy, packed_bwd_layer, b1f, eps=1e-5, drop_p=0.0, site_hidden=0, site_res=0, seed=None):
+    """backward of ffn_fwd with respect to x, plus the operands of the weight-gradient GEMMs (include/dsvg.h):
+    -> (dx, h, dpre, xh, dym); h / dpre [rows, 512] have their hidden columns in fragment order; dym is dy itself
+    when there is no dropout"""
+    _chk(x, dy, packed_bwd_layer, b1f, seed)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
+    assert dy.dtype == x.dtype and dy.shape == x.shape and dy.is_contiguous()
+    assert packed_bwd_layer.numel() == FFN_BWD_LAYER_ELEMS and packed_bwd_layer.is_contiguous() and b1f.numel() == 512
+    rows = x.shape[0]
+    dx, xh = torch.empty_like(x), torch.empty_like(x)
+    dym = torch.empty_like(x) if drop_p > 0 else dy
+    h = torch.empty((rows, 512), dtype=x.dtype, device=x.device)
+    dpre = torch.empty((rows, 512), dtype=x.dtype, device=x.device)
+    ev = _prof_begin()
+    _l.check(_l.load().dsvg_ffn_bwd(x.data_ptr(), dy.data_ptr(), packed_bwd_layer.data_ptr(), b1f.data_ptr(),
+                                    h.data_ptr(), dpre.data_ptr(), xh.data_ptr(), dym.data_ptr() if drop_p > 0 else None,
+                                    dx.data_ptr(), rows, float(eps), float(drop_p), int(site_hidden), int(site_res),
+                                    _p(seed) if drop_p > 0 else None, _stream()), "dsvg_ffn_bwd")
+    # algorithmic work of the two launches: dh and dxh (2 GEMMs); the recomputed pre-activation is not counted.
+    # bytes: x, dy in; dx out; h, dpre, xh (, dym) out for the weight-gradient GEMMs; dpre read back by kernel 2
+    _prof_end(ev, 4.0 * 256 * 512 * rows, (3 * 512 + 3 * 1024 + 512 + (512 if drop_p > 0 else 0)) * float(rows),
+              dict(op="ffn_bwd", rows=rows))
+    return dx, h, dpre, xh, dym
+
+
+def ffn_wgrad_finish(g1p, db1p, g2p, w1, gamma, beta, dw1, db1, dw2, dgamma, dbeta):
+    """(G1p = dpre^T xh, its row sums, G2p = dym^T h) in fragment order -> gradients of linear1.weight / bias,
+    linear2.weight, norm.weight, norm.bias (include/dsvg.h)"""
+    ts = (g1p, db1p, g2p, w1, gamma, beta, dw1, db1, dw2, dgamma, dbeta)
+    _chk(*ts)
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+    assert g1p.numel() == 131072 and g2p.numel() == 131072 and db1p.numel() == 512 and w1.numel() == 131072
+    assert dw1.numel() == 131072 and dw2.numel() == 131072 and db1.numel() == 512 and dgamma.numel() == 256
+    assert dbeta.numel() == 256 and gamma.numel() == 256 and beta.numel() == 256
+    _l.check(_l.load().dsvg_ffn_wgrad_finish(*(t.data_ptr() for t in ts), _stream()), "dsvg_ffn_wgrad_finish")
+
+
 def _prof_begin():
     if not (PROFILE_ON and _TAG is not None):
         return None

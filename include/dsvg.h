@@ -370,6 +370,22 @@ int dsvg_ffn_pack(const float* flat_f32, const int64_t* offs, int32_t n_layers, 
 int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const float* b1_folded, const float* b2, void* y,
                  int64_t rows, float eps, float drop_p, uint32_t site_hidden, uint32_t site_res, const void* seed,
                  int32_t stages, void* stream);
+/* Backward of the fused FFN sub-block (two launches; csrc/ffn_fused.hip):
+ *   kernel 1 recomputes the hidden tile from x, replays both dropout masks and writes what the weight-gradient GEMMs
+ *            need: h, dpre bf16 [rows, 512] with the hidden columns in FRAGMENT ORDER (position p(j) = j with bits 2 and 3
+ *            swapped), xh = (x - mean) * rstd and dym = dy * residual-dropout mask, bf16 [rows, 256] (dym may be NULL
+ *            when drop_p == 0: then dym == dy);
+ *   kernel 2 dx = dy + LayerNorm'(dpre . W1').
+ * The caller then runs G2p = dym^T h [256, 512], G1p = dpre^T xh [512, 256] (+ row sums db1p, and db2 = colsum(dym))
+ * with dsvg_gemm, and dsvg_ffn_wgrad_finish turns (G1p, db1p, G2p) into the gradients of linear1.weight / bias,
+ * linear2.weight and of the LayerNorm's gamma / beta (w1 = fp32 master linear1.weight [512, 256]).
+ * Replaces the autograd backward of deepsvg/model/layers/improved_transformer.py:51-53 / :138-140. */
+int dsvg_ffn_bwd(const void* x, const void* dy, const void* packed_bwd_layer, const float* b1_folded, void* h, void* dpre,
+                 void* xh, void* dym, void* dx, int64_t rows, float eps, float drop_p, uint32_t site_hidden,
+                 uint32_t site_res, const void* seed, void* stream);
+int dsvg_ffn_wgrad_finish(const float* g1p, const float* db1p, const float* g2p, const float* w1, const float* gamma,
+                          const float* beta, float* dw1, float* db1, float* dw2, float* dgamma, float* dbeta,
+                          void* stream);
 /* test hook: raw ds_read_b64_tr_b16 on a 4 KiB LDS image img[i]=i, lane l reads at byte offset off[l] */
 int dsvg_probe_trread(const int* off, short* out, void* stream);
 

@@ -720,6 +720,45 @@ def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, s
     return y
 
 
+def _ffn_frag_perm(device):
+    """position p(j) of hidden unit j in the fragment-ordered h / dpre matrices: bits 2 and 3 of j swapped"""
+    j = torch.arange(512, device=device)
+    return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1)
+
+
+def ffn_bwd(x, dy, packed_bwd_layer, b1f, eps=1e-5, drop_p=0.0, site_hidden=0, site_res=0, seed=None):
+    W1, W2 = _ffn_weights(packed_bwd_layer)
+    rows = x.shape[0]
+    xh, mean, rstd = _ffn_normalise(x, eps)
+    h, pre, m_h = _ffn_hidden(xh, W1, b1f, drop_p, site_hidden, seed)
+    if drop_p > 0:
+        dym = (_f(dy) * drop2_mult(drop_p, seed, site_res, _ids(rows, 256, x.device))).to(x.dtype)
+    else:
+        dym = dy
+    dh = _f(dym) @ _f(W2)
+    dpre = torch.where(pre > 0, dh * m_h, torch.zeros_like(dh)).to(x.dtype)
+    g = _f(dpre) @ _f(W1)                                                    # gradient wrt the normalised rows
+    xhf = (_f(x) - mean.unsqueeze(-1)) * rstd.unsqueeze(-1)
+    dx = _f(dy) + rstd.unsqueeze(-1) * (g - g.mean(-1, keepdim=True) - xhf * (g * xhf).mean(-1, keepdim=True))
+    perm = _ffn_frag_perm(x.device)
+    hp, dp = torch.empty_like(h), torch.empty_like(dpre)
+    hp[:, perm] = h
+    dp[:, perm] = dpre
+    return dx.to(x.dtype), hp, dp, xh, dym
+
+
+def ffn_wgrad_finish(g1p, db1p, g2p, w1, gamma, beta, dw1, db1, dw2, dgamma, dbeta):
+    perm = _ffn_frag_perm(g1p.device)
+    G1 = g1p.view(512, 256)[perm]                   # G1[j] = G1p[p(j)]
+    b = db1p.view(512)[perm]
+    W1 = w1.view(512, 256)
+    dw1.view(512, 256).copy_(G1 * gamma + b.unsqueeze(1) * beta)
+    db1.view(512).copy_(b)
+    dw2.view(256, 512).copy_(g2p.view(256, 512)[:, perm])
+    dgamma.view(256).copy_((W1 * G1).sum(0))
+    dbeta.view(256).copy_(W1.t() @ b)
+
+
 def gate_mul(dy, y, scale=1.0):
     return torch.where(_f(y) > 0, _f(dy) * scale, torch.zeros_like(_f(dy))).to(dy.dtype)
 
