@@ -23,10 +23,11 @@
 //     the hidden tile goes accumulator -> bias / ReLU / dropout -> bf16 -> MFMA operand without touching LDS.
 //   * epilogue: two v_permlane32_swap rounds turn each 32 x 32 accumulator tile into 16 consecutive output columns per
 //     lane; bias, dropout, residual and the bf16 stores (32 contiguous bytes per lane and tile) run from registers.
-//   * dropout draws ("v2", private to the fused kernels' sites): ONE counter hash per 16 consecutive elements and a
-//     one-multiply finaliser per pair of 16-bit draws (0.75 v_mul_lo_u32 per element instead of 1.5), still 16-bit
-//     thresholds (p = 0.1 -> 6554 / 65536).  The hidden-site ids are taken in the order the lane owns them
-//     (tok * 512 + 32 c + 16 (lane >> 5) + r), the backward kernel replays the same ids.
+//   * dropout draws of the hidden site ("v2", private to the fused kernels): ONE counter hash per 16 consecutive elements
+//     and a one-multiply finaliser per pair of 16-bit draws (0.75 v_mul_lo_u32 per element instead of 1.5), still 16-bit
+//     thresholds (p = 0.1 -> 6554 / 65536).  The ids are taken in the order the lane owns them (tok * 512 + 32 c + 16
+//     (lane >> 5) + r); the backward pass never re-draws them, it reads the gate off the stored h (h > 0 <=> the unit
+//     passed the ReLU and was kept).  The residual site uses the library's standard draws (dsvg_drop_apply replays it).
 #include "dsvg_common.h"
 #include "../../include/dsvg.h"
 
@@ -120,6 +121,25 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__
         }
     }
     *reinterpret_cast<uint4*>(dst) = pack8(v);
+}
+
+// position of hidden unit j in the fragment-ordered h / dpre matrices (and back: an involution): bits 2 and 3 swapped
+__host__ __device__ inline int frag_pos(int j) { return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1); }
+
+// w2p[layer][o][p] = bf16(W2[o][frag_pos(p)]): linear2.weight with fragment-ordered columns, a plain row-major matrix for
+// the unfused input-gradient GEMM (dpre = dym . W2p, gated by the fragment-ordered h)
+__global__ __launch_bounds__(256) void ffn_w2p_kernel(const float* __restrict__ flat, const int64_t* __restrict__ offs,
+                                                      int n_layers, bf16_t* __restrict__ w2p) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;        // one thread per 8 output elements
+    if (gid >= (long long)n_layers * (FD * FF / 8)) return;
+    const int layer = (int)(gid / (FD * FF / 8));
+    const int r = (int)(gid % (FD * FF / 8));
+    const int o = r / (FF / 8), p0 = (r % (FF / 8)) * 8;
+    const float* W2 = flat + offs[layer * 5 + 2] + (size_t)o * FF;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = W2[frag_pos(p0 + e)];
+    *reinterpret_cast<uint4*>(w2p + (size_t)layer * FD * FF + (size_t)o * FF + p0) = pack8(v);
 }
 
 // b1'[layer][j] = b1[j] + sum_k W1[j][k] beta[k]: one wave per hidden unit
@@ -225,10 +245,18 @@ __device__ __forceinline__ void tile_to_cols16(const floatx16& c, uint32_t (&x)[
 //     stage (waves that leave a barrier together otherwise stay in lockstep and the matrix pipe idles during E1).
 //   * A fragments go through a 4-deep register ring that is refilled right behind each MFMA (prefetch distance 4 MFMAs,
 //     continuous across stages and chunks): ds_read latency is covered by the wave's own MFMAs, not only by its partner.
-template <int NBUF>
+//   * TRAIN: the kernel also hands the unfused backward what it needs - h (bf16 [T, 512], hidden columns in FRAGMENT
+//     ORDER: position 32 c + 16 s + 8 b + 4 a + e holds unit 32 c + 16 s + 8 a + 4 b + e, i.e. exactly the 8 values a
+//     lane owns per K step: one aligned 16-byte store each), xh = (x - mean) * rstd (bf16) and rstd (fp32).  vmcnt
+//     counts stores too, out of order with respect to loads, so the only safe DMA wait is vmcnt(0); the h stores of a
+//     chunk are therefore held back in 8 registers and issued right BEHIND the next sync point, which gives them (and
+//     the DMA) a whole iteration to drain before the next wait.
+template <int NBUF, bool TRAIN>
 __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ img,
                                                          const float* __restrict__ b1, const float* __restrict__ b2,
-                                                         bf16_t* __restrict__ y, int M, float eps, float drop_p,
+                                                         bf16_t* __restrict__ y, bf16_t* __restrict__ h_out,
+                                                         bf16_t* __restrict__ xh_out, float* __restrict__ rstd_out,
+                                                         int M, float eps, float drop_p,
                                                          const uint64_t* __restrict__ seed, uint32_t site_h,
                                                          uint32_t site_r, int n_chunks) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // [NBUF chunk slots | b1 (2 KiB) | b2 (1 KiB)]
@@ -245,8 +273,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
     const char* my_src = reinterpret_cast<const char*>(img) + wave * 4096 + lane * 16;
     const uint32_t my_dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);
     auto issue = [&](int c) { dma4(my_src + (size_t)c * FWD_CHUNK, my_dst + (uint32_t)(c % NBUF) * FWD_CHUNK); };
-    // DMA distance: DIST = NBUF - 1 chunks ahead of the compute (NBUF = 3: 2, NBUF = 4: 3)
-    constexpr int DIST = NBUF - 1;
+    // DMA distance: DIST = NBUF - 1 chunks ahead of the compute (NBUF = 3: 2, NBUF = 4: 3; TRAIN: always 2, see above)
+    constexpr int DIST = TRAIN ? 2 : NBUF - 1;
 #pragma unroll
     for (int c = 0; c < DIST; ++c)
         if (c < n_chunks) issue(c);
@@ -290,6 +318,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
         const float rstd = rsqrtf(ss * (1.f / FD) + eps);
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
+        char* xo = TRAIN ? reinterpret_cast<char*>(xh_out) + (size_t)my_row * (FD * 2) + half * 16 : nullptr;
+        const bool st = TRAIN && row0 + tok < M;
+        if (st && half == 0) rstd_out[my_row] = rstd;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {       // (gamma / beta live in the packed W1' / b1', see ffn_pack_kernel)
             float v[8];
@@ -299,6 +330,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
             Frag8 f;
             f.u = pack8(v);
             xf[ks] = f.v;
+            if (st) *reinterpret_cast<uint4*>(xo + 32 * ks) = f.u;
         }
     }
     __builtin_amdgcn_sched_barrier(0);      // (the 128 accumulator zeroes below must not be hoisted above the LayerNorm)
@@ -322,11 +354,25 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
     // sync(k): afterwards chunks <= k + 1 are readable (this wave's pieces: counted vmcnt, the others': the barrier) and
     // chunk k + DIST is on its way into the slot chunk k - 1 has left; with NBUF = 4 chunk k + 2 stays in flight across
     // the barrier (4 pieces per wave and chunk)
+    uint4 stash[2];                 // TRAIN: the packed h chunk waiting for its store slot
+    int stash_c = -1;
+    char* hrow = TRAIN ? reinterpret_cast<char*>(h_out) + (size_t)my_row * (FF * 2) + half * 16 : nullptr;
+    const bool hst = TRAIN && row0 + tok < M;
+    auto flush = [&]() {
+        if (TRAIN && stash_c >= 0) {
+            if (hst) {
+                *reinterpret_cast<uint4*>(hrow + (CH * stash_c) * 2) = stash[0];
+                *reinterpret_cast<uint4*>(hrow + (CH * stash_c + 16) * 2) = stash[1];
+            }
+            stash_c = -1;
+        }
+    };
     auto sync = [&](int k) {
-        if (DIST == 3 && k + 2 < n_chunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (!TRAIN && DIST == 3 && k + 2 < n_chunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (k + DIST < n_chunks) issue(k + DIST);
+        flush();
     };
     // G1: hid[unit][token] = sum_k W1[32 c + unit][k] xn[token][k]; the ring runs on into `cont` (4 more fragments)
     auto G1 = [&](const char* w1, const char* cont) {
@@ -367,7 +413,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
             Frag8 f;
             f.u = pack8(v);
             hf[ks2] = f.v;
+            if (TRAIN) stash[ks2] = f.u;
         }
+        if (TRAIN) stash_c = c;
     };
     // G2: y[out][token] += sum_unit W2[out][32 c + unit] hid[unit][token]; the ring runs on into `cont`
     auto G2 = [&](const char* w2, const char* cont) {
@@ -386,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
     // Both wave groups run the SAME straight-line code G1 E1 G2 per chunk; only the position of their one barrier per
     // chunk differs (before G1 for waves 0-3, before G2 for waves 4-7), which holds waves 4-7 one stage (G1 + E1) ahead.
     if (n_chunks > 0) {
-        if (DIST == 3 && n_chunks > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (!TRAIN && DIST == 3 && n_chunks > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // chunks 0 and 1 are in LDS
         {
@@ -403,6 +451,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
             if (late) sync(c);
             G2(sc + 16 * FRAG, sn);
         }
+        flush();
     }
 
     // ---- epilogue: + b2, dropout, + residual, bf16 rows ---------------------------------------------------------------
@@ -423,7 +472,6 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
         uint32_t xc[4][4];
         tile_to_cols16(yacc[t], xc);
         const int n16 = 32 * t + 16 * half;
-        const uint32_t hr = dr.on ? drop2_group(dr, ((uint64_t)m * FD + n16) >> 4) : 0u;
         uint4 pk[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
@@ -434,9 +482,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
             const float4 b1v = *reinterpret_cast<const float4*>(sb2 + n16 + 8 * cb + 4);
             v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
             v[4] += b1v.x; v[5] += b1v.y; v[6] += b1v.z; v[7] += b1v.w;
-            if (dr.on) {
-                float dm[8];
-                drop2_mult8(dr, hr, cb, dm);
+            if (dr.on) {        // residual site: the library's standard draws (ids m * 256 + column, groups of 8), so that
+                float dm[8];    // dsvg_drop_apply replays the mask for the unfused backward GEMMs
+                drop_mult8(dr, (uint64_t)m * FD + n16 + 8 * cb, dm);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= dm[e];
             }
@@ -540,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_hidden_kernel(const bf16_t* __
             if (live) *reinterpret_cast<uint4*>(xo + 32 * ks) = f.u;
         }
     }
-    // ---- dym fragments: dy with the residual dropout replayed (ids m * 256 + column, groups of 16) ------------------------
+    // ---- dym fragments: dy with the residual dropout replayed (ids m * 256 + column, standard draws) ----------------------
     bf16x8 df[16];
     {
         const char* dr = reinterpret_cast<const char*>(dy) + (size_t)my_row * (FD * 2) + half * 16;
@@ -554,8 +602,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_hidden_kernel(const bf16_t* __
             if (dr_ctx.on) {
                 float v[8], mm[8];
                 unpack8(raw[ks], v);
-                const uint32_t hr = drop2_group(dr_ctx, ((uint64_t)m * FD + 16 * ks) >> 4);
-                drop2_mult8(dr_ctx, hr, half, mm);
+                drop_mult8(dr_ctx, (uint64_t)m * FD + 16 * ks + 8 * half, mm);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= mm[e];
                 f.u = pack8(v);
@@ -573,8 +620,12 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_hidden_kernel(const bf16_t* __
     const char* lbase = smem + lane * 16;
     auto slot_of = [&](int c) -> const char* { return lbase + (c % NBUF) * FWD_CHUNK; };
     auto ld = [&](const char* p) -> uint4 { return *reinterpret_cast<const uint4*>(p); };
+    // vmcnt counts the h / dpre stores too, and stores retire out of order with respect to loads: the only safe wait is
+    // vmcnt(0).  It sits right behind the GEMMs of a chunk - BEFORE that chunk's stores are issued - so that it covers
+    // the DMA issued one GEMM phase earlier and the stores of the PREVIOUS chunk, which have had a whole GEMM phase to
+    // drain; the barrier itself then needs no wait (every wave confirmed its pieces of chunk k + 1 before reaching it).
+    auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     auto sync = [&](int k) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (k + 2 < NCH) issue(k + 2);
     };
@@ -636,6 +687,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_hidden_kernel(const bf16_t* __
         const char* sn = (c + 1 < NCH) ? slot_of(c + 1) : nullptr;
         if (!late) sync(c);
         GEMMS(sc, sn);
+        landed();
         if (late) sync(c);
         EPI(c);
     }
@@ -675,26 +727,37 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
     for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    uint4 bcur[2], bnext[2];
-    bcur[0] = bfrag(0, 0); bcur[1] = bfrag(0, 1);
+    // B operands: a register ring 4 chunks deep (a chunk is 0.25 us of MFMA work per wave, a global load 1 - 2 us under
+    // load).  Per iteration this wave issues 2 DMA pieces (chunk c + 2) and 2 B loads (chunk c + 4), all loads, returned
+    // in order: "everything but the 4 newest has landed" = chunk c's DMA (issued 2 iterations ago) and its B operands.
+    uint4 bq[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bq[i][0] = bfrag(i, 0); bq[i][1] = bfrag(i, 1); }
     const char* lbase = smem + lane * 16;
-    for (int c = 0; c < NCH; ++c) {
-        // chunk c landed for everybody, slot of chunk c - 2 is free again (only DMA and the B-operand loads are in
-        // flight: loads return in order, every wait is conservative)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+    auto chunk = [&](int c, uint4 (&b)[2], bool more, int pend) {
+        // pend = loads this wave may leave in flight: the previous iteration's (4 in the steady state, 2 / 0 in the tail)
+        if (pend == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();       // chunk c landed for everybody; the slot of chunk c - 2 is free again
         if (c + 2 < NCH) issue(c + 2);
-        if (c + 1 < NCH) { bnext[0] = bfrag(c + 1, 0); bnext[1] = bfrag(c + 1, 1); }
         const char* sc = lbase + (c % NBUF) * SLOT;
+        Frag8 b0, b1;
+        b0.u = b[0]; b1.u = b[1];
+        if (more) { b[0] = bfrag(c + 4, 0); b[1] = bfrag(c + 4, 1); }
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
-            Frag8 a, b;
+            Frag8 a;
             a.u = *reinterpret_cast<const uint4*>(sc + n * FRAG);
-            b.u = bcur[n & 1];
-            acc[n >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[n >> 1], 0, 0, 0);
+            acc[n >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, (n & 1) ? b1.v : b0.v, acc[n >> 1], 0, 0, 0);
         }
-        bcur[0] = bnext[0]; bcur[1] = bnext[1];
+    };
+    for (int c = 0; c < NCH - 4; c += 4) {
+        chunk(c, bq[0], true, 4); chunk(c + 1, bq[1], true, 4); chunk(c + 2, bq[2], true, 4); chunk(c + 3, bq[3], true, 4);
     }
+    // tail: no more B loads, only the last two DMA issues (2 pieces each) are left to overlap with
+    chunk(NCH - 4, bq[0], false, 0); chunk(NCH - 3, bq[1], false, 2); chunk(NCH - 2, bq[2], false, 2);
+    chunk(NCH - 1, bq[3], false, 0);
 
     // ---- epilogue: LayerNorm backward on the rows in registers ------------------------------------------------------------
     // tiles -> the lane's 16 consecutive columns per tile (in place), x row in the same layout
@@ -803,8 +866,6 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
 //     dgamma[k] = sum_j W1[j][k] G1p[p(j)][k],                  dbeta[k] = sum_j W1[j][k] db1p[p(j)]
 // One workgroup per 4 columns k (and 4 rows o of dW2); fixed summation order (deterministic).
 // ---------------------------------------------------------------------------------------------------------------------
-__host__ __device__ inline int frag_pos(int j) { return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1); }
-
 __global__ __launch_bounds__(256) void ffn_wgrad_finish_kernel(const float* __restrict__ G1p, const float* __restrict__ db1p,
                                                                const float* __restrict__ G2p, const float* __restrict__ W1,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -853,7 +914,7 @@ extern "C" int64_t dsvg_ffn_pack_bytes(int32_t n_layers, int32_t which) {
 }
 
 extern "C" int dsvg_ffn_pack(const float* flat_f32, const int64_t* offs, int32_t n_layers, int32_t d_model, int32_t d_ff,
-                             void* packed_fwd, void* packed_bwd, float* b1_folded, void* stream) {
+                             void* packed_fwd, void* packed_bwd, float* b1_folded, void* w2p, void* stream) {
     DSVG_CHECK_ARG(flat_f32 && offs && packed_fwd && packed_bwd && b1_folded, "ffn_pack: null pointer");
     DSVG_CHECK_ARG(d_model == FD && d_ff == FF, "ffn_pack: the fused FFN kernels are built for d_model 256 / dim_ff 512");
     DSVG_CHECK_ARG(n_layers > 0, "ffn_pack: bad layer count");
@@ -862,33 +923,42 @@ extern "C" int dsvg_ffn_pack(const float* flat_f32, const int64_t* offs, int32_t
                        n_layers, (bf16_t*)packed_fwd, (bf16_t*)packed_bwd);
     hipLaunchKernelGGL(ffn_fold_bias_kernel, dim3((unsigned)((n_layers * FF + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        flat_f32, offs, n_layers, b1_folded);
+    if (w2p) {
+        const long long n8 = (long long)n_layers * (FD * FF / 8);
+        hipLaunchKernelGGL(ffn_w2p_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat_f32, offs,
+                           n_layers, (bf16_t*)w2p);
+    }
     DSVG_LAUNCH_CHECK("ffn_pack");
     return 0;
 }
 
 extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const float* b1_folded, const float* b2, void* y,
-                            int64_t rows, float eps, float drop_p, uint32_t site_hidden, uint32_t site_res, const void* seed,
-                            int32_t stages, void* stream) {
+                            void* h_out, void* xh_out, float* rstd_out, int64_t rows, float eps, float drop_p,
+                            uint32_t site_hidden, uint32_t site_res, const void* seed, int32_t stages, void* stream) {
     DSVG_CHECK_ARG(x && packed_fwd_layer && b1_folded && b2 && y, "ffn_fwd: null pointer");
     DSVG_CHECK_ARG(rows > 0 && rows < (1ll << 31) - TOK_PER_WG, "ffn_fwd: bad row count");
     DSVG_CHECK_ARG(!(drop_p > 0.f) || seed, "ffn_fwd: dropout needs a seed");
-    DSVG_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)packed_fwd_layer) & 15) == 0,
+    const bool train = h_out != nullptr;
+    DSVG_CHECK_ARG(!train || (xh_out && rstd_out), "ffn_fwd: h_out, xh_out and rstd_out come together");
+    DSVG_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)packed_fwd_layer | (uintptr_t)h_out | (uintptr_t)xh_out) & 15) == 0,
                    "ffn_fwd: operands must be 16-byte aligned");
     const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
     hipStream_t st = (hipStream_t)stream;
     if (stages == 0) stages = 4;
+    if (train) stages = 3;
     // timing probe only (results are wrong below 16): number of hidden chunks actually processed
     static const int dbg_chunks = getenv("DSVG_FFN_DBG_CHUNKS") ? atoi(getenv("DSVG_FFN_DBG_CHUNKS")) : NCH;
-#define DSVG_FFN_FWD(NB)                                                                                              \
+#define DSVG_FFN_FWD(NB, TR)                                                                                          \
     do {                                                                                                              \
         const size_t lds = (size_t)NB * FWD_CHUNK + 3072;                                                             \
-        DSVG_ENSURE_LDS((ffn_fwd_kernel<NB>), lds);                                                                   \
-        hipLaunchKernelGGL((ffn_fwd_kernel<NB>), dim3(nb), dim3(512), lds, st, (const bf16_t*)x,                       \
-                           (const bf16_t*)packed_fwd_layer, b1_folded, b2, (bf16_t*)y, (int)rows, eps, drop_p,        \
-                           (const uint64_t*)seed, site_hidden, site_res, dbg_chunks);                                 \
+        DSVG_ENSURE_LDS((ffn_fwd_kernel<NB, TR>), lds);                                                               \
+        hipLaunchKernelGGL((ffn_fwd_kernel<NB, TR>), dim3(nb), dim3(512), lds, st, (const bf16_t*)x,                   \
+                           (const bf16_t*)packed_fwd_layer, b1_folded, b2, (bf16_t*)y, (bf16_t*)h_out, (bf16_t*)xh_out,\
+                           rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res, dbg_chunks); \
     } while (0)
-    if (stages == 3) DSVG_FFN_FWD(3);
-    else if (stages == 4) DSVG_FFN_FWD(4);
+    if (train) DSVG_FFN_FWD(3, true);
+    else if (stages == 3) DSVG_FFN_FWD(3, false);
+    else if (stages == 4) DSVG_FFN_FWD(4, false);
     else { dsvg_set_error("ffn_fwd: stages must be 3 or 4"); return -1; }
 #undef DSVG_FFN_FWD
     DSVG_LAUNCH_CHECK("ffn_fwd");
@@ -914,6 +984,20 @@ extern "C" int dsvg_ffn_bwd(const void* x, const void* dy, const void* packed_bw
     hipLaunchKernelGGL(ffn_bwd_dx_kernel, dim3(nb), dim3(512), lds2, st, (const bf16_t*)dpre, (const bf16_t*)x,
                        (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps);
     DSVG_LAUNCH_CHECK("ffn_bwd (dx)");
+    return 0;
+}
+
+extern "C" int dsvg_ffn_bwd_dx(const void* dpre, const void* x, const void* dy, const void* packed_bwd_layer, void* dx,
+                               int64_t rows, float eps, void* stream) {
+    DSVG_CHECK_ARG(dpre && x && dy && packed_bwd_layer && dx, "ffn_bwd_dx: null pointer");
+    DSVG_CHECK_ARG(rows > 0 && rows < (1ll << 31) - TOK_PER_WG, "ffn_bwd_dx: bad row count");
+    DSVG_CHECK_ARG((((uintptr_t)dpre | (uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)packed_bwd_layer) & 15) == 0,
+                   "ffn_bwd_dx: operands must be 16-byte aligned");
+    const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
+    const size_t lds2 = 4 * 16 * FRAG;
+    hipLaunchKernelGGL(ffn_bwd_dx_kernel, dim3(nb), dim3(512), lds2, (hipStream_t)stream, (const bf16_t*)dpre,
+                       (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps);
+    DSVG_LAUNCH_CHECK("ffn_bwd_dx");
     return 0;
 }
 

@@ -15,10 +15,17 @@ plain-torch restatements in tests/torch_ops_ref.py to exercise this host logic w
 """
 import math
 import contextlib
+import os
 
 import torch
 
 from . import ops
+
+# fused FFN backward (hidden tile recomputed in the kernel) instead of the default: see LayerFn.backward
+FFN_BWD_FUSED = os.environ.get("DSVG_FFN_BWD_FUSED", "0") != "0"
+# the fused FFN kernels own 256 token rows per workgroup: below ~16k rows they cannot fill the 256 CUs and the three
+# unfused launches are faster (measured: 4096 rows 39-50 us fused vs 33 us unfused; 41k rows 56 vs 71 us)
+FFN_MIN_ROWS = int(os.environ.get("DSVG_FFN_MIN_ROWS", "16384"))
 
 
 class Runtime:
@@ -426,10 +433,26 @@ class LayerFn(torch.autograd.Function):
         if l is not None:
             g2 = ops.gemm(l, rt.w(wg2), bias=bg2.detach())
             ops.bcast_add_fwd_(x1, g2, n_seq, S, p, site0 + 5, rt.seed)
-        xn2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach())
-        with ops.tag("ffn"):
-            h = ops.gemm(xn2, rt.w(w1), bias=b1.detach(), act=ops.RELU, drop_p=p, drop_site=site0 + 3, seed=rt.seed)
-            x2 = ops.gemm(h, rt.w(w2), bias=b2.detach(), res=x1, drop_p=p, drop_site=site0 + 4, seed=rt.seed)
+        ffn = rt.store.ffn(w1) if (rt.store is not None and x.dtype == torch.bfloat16 and x.shape[0] >= FFN_MIN_ROWS) else None
+        ctx.ffn_fused = ffn is not None
+        if ffn is not None:
+            # one launch: LayerNorm (folded into the packed linear1), linear1, ReLU, dropout, linear2, dropout, residual
+            # (csrc/ffn_fused.hip).  With a backward pass ahead it also stores h (fragment-ordered columns) and the
+            # normalised rows xh; the inference call stores nothing but the result.
+            mean2 = rstd2 = None
+            want_bwd = any(ctx.needs_input_grad)         # (grad mode itself is off inside Function.forward)
+            with ops.tag("ffn"):
+                if want_bwd and not FFN_BWD_FUSED:
+                    x2, h, xn2, _rstd = ops.ffn_fwd(x1, ffn[0], ffn[2], b2.detach(), 1e-5, p, site0 + 3, site0 + 4, rt.seed,
+                                                    train=True)
+                else:
+                    xn2 = h = None
+                    x2 = ops.ffn_fwd(x1, ffn[0], ffn[2], b2.detach(), 1e-5, p, site0 + 3, site0 + 4, rt.seed)
+        else:
+            xn2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach())
+            with ops.tag("ffn"):
+                h = ops.gemm(xn2, rt.w(w1), bias=b1.detach(), act=ops.RELU, drop_p=p, drop_site=site0 + 3, seed=rt.seed)
+                x2 = ops.gemm(h, rt.w(w2), bias=b2.detach(), res=x1, drop_p=p, drop_site=site0 + 4, seed=rt.seed)
         ctx.rt, ctx.n_seq, ctx.S, ctx.n_heads, ctx.p, ctx.site0, ctx.scale = rt, n_seq, S, n_heads, p, site0, scale
         assert seq_off is None or (z is None and l is None), "packed layout: no per-sequence conditioning adds"
         ctx.live = _live_rows(live, x.shape[0])
@@ -449,19 +472,56 @@ class LayerFn(torch.autograd.Function):
         if live is not None:            # backward over the live row prefix only (visible-first decoder order)
             n_seq, R = live
             (dx2, x, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h) = (
-                t[:R] for t in (dx2, x, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h))
+                (t[:R] if t is not None else None) for t in (dx2, x, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h))
         inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
-        # ---- FFN: x2 = x1 + drop4(h W2^T + b2),  h = drop3(relu(xn2 W1^T + b1)) ----
-        # the mask of the residual dropout is replayed ONCE into dx2m; the three consumers read plain data
-        dx2m = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
-        with ops.tag("ffn"):
-            dw2, db2 = _wbgrad(rt, w2, b2, dx2m, h)
-            dh = ops.gemm(dx2m, rt.w(w2), b_kc=False, gate=h, gate_scale=inv_keep)   # (h > 0) <=> relu passed AND kept
-            dw1, db1 = _wbgrad(rt, w1, b1, dh, xn2)
-            dxn2 = ops.gemm(dh, rt.w(w1), b_kc=False)
-        del dx2m
-        dx1, dn2w, dn2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w.detach(), res=dx2,
-                                            dgamma=rt.grad_out(n2w), dbeta=rt.grad_out(n2b))
+        if ctx.ffn_fused:
+            pb, b1f, w2p = rt.store.ffn(w1)[1:]
+            T = x1.shape[0]
+            with ops.tag("ffn"):
+                if h is None:
+                    # fully fused variant (opt-in, DSVG_FFN_BWD_FUSED=1): hidden tile recomputed from x1, both dropout
+                    # masks replayed in the kernel; measured slower than the default below (it writes h, dpre, xh AND dym)
+                    dx1, hp, dpre, xh, dym = ops.ffn_bwd(x1, dx2, pb, b1f, 1e-5, p, s0 + 3, s0 + 4, rt.seed)
+                else:
+                    # default: the forward kernel stored h (fragment order) and xh.  dym = residual mask replayed once;
+                    # dpre = (dym . W2p) gated by h (h > 0 <=> ReLU passed AND kept) in one GEMM; dx by the fused kernel
+                    # (dpre . W1' with the LayerNorm backward in its epilogue)
+                    hp, xh = h, xn2
+                    dym = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
+                    dpre = ops.gemm(dym, w2p, b_kc=False, gate=hp, gate_scale=inv_keep)
+                    dx1 = ops.ffn_bwd_dx(dpre, x1, dx2, pb)
+                g2p = torch.empty((256, 512), dtype=torch.float32, device=x1.device)
+                g1p = torch.empty((512, 256), dtype=torch.float32, device=x1.device)
+                db1p = torch.empty(512, dtype=torch.float32, device=x1.device)
+                db2 = rt.grad_out(b2)
+                with rt.on_side(dym, hp, dpre, xh):
+                    s2, s1 = ops.split_k_for(256, 512, T), ops.split_k_for(512, 256, T)
+                    if s2 > 1:
+                        ops.gemm(dym, hp, a_kc=False, b_kc=False, out=g2p, split_k=s2, rowsum=db2)
+                    else:
+                        ops.gemm(dym, hp, a_kc=False, b_kc=False, out=g2p)
+                        ops.colsum(dym, out=db2)
+                    if s1 > 1:
+                        ops.gemm(dpre, xh, a_kc=False, b_kc=False, out=g1p, split_k=s1, rowsum=db1p)
+                    else:
+                        ops.gemm(dpre, xh, a_kc=False, b_kc=False, out=g1p)
+                        ops.colsum(dpre, out=db1p)
+                    dw1, db1, dw2 = rt.grad_out(w1), rt.grad_out(b1), rt.grad_out(w2)
+                    dn2w, dn2b = rt.grad_out(n2w), rt.grad_out(n2b)
+                    ops.ffn_wgrad_finish(g1p, db1p, g2p, w1.detach(), n2w.detach(), n2b.detach(), dw1, db1, dw2, dn2w, dn2b)
+            del hp, dpre, xh, dym
+        else:
+            # ---- FFN: x2 = x1 + drop4(h W2^T + b2),  h = drop3(relu(xn2 W1^T + b1)) ----
+            # the mask of the residual dropout is replayed ONCE into dx2m; the three consumers read plain data
+            dx2m = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
+            with ops.tag("ffn"):
+                dw2, db2 = _wbgrad(rt, w2, b2, dx2m, h)
+                dh = ops.gemm(dx2m, rt.w(w2), b_kc=False, gate=h, gate_scale=inv_keep)   # (h > 0) <=> relu passed AND kept
+                dw1, db1 = _wbgrad(rt, w1, b1, dh, xn2)
+                dxn2 = ops.gemm(dh, rt.w(w1), b_kc=False)
+            del dx2m
+            dx1, dn2w, dn2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w.detach(), res=dx2,
+                                                dgamma=rt.grad_out(n2w), dbeta=rt.grad_out(n2b))
         # ---- conditioning adds ----
         dz = dl = dwg = dbg = dwg2 = dbg2 = None
         if l is not None:

@@ -272,6 +272,7 @@ class ParamStore:
         self._grad_views = [{}, {}]
         self._in_flight = set()  # id(param): its slot of gbuf[0] was handed to a backward node, not yet accumulated
         self._hooks = []
+        self._ffn = None         # fused-FFN weight images (see _ffn_setup)
 
     # a copied / unpickled module gets an empty store that re-flattens lazily on its first forward: the index is keyed
     # by id(param) and the views point into THIS module's buffers (copy.deepcopy(model) for EMA / best-model snapshots,
@@ -306,6 +307,7 @@ class ParamStore:
         self._lp_views = {}
         self._grad_views = [{}, {}]
         self._in_flight = set()
+        self._ffn_setup(device)
         for h in self._hooks:
             h.remove()
         # a slot of the flat gradient buffer is free again once AccumulateGrad has consumed it (see grad_view)
@@ -313,6 +315,46 @@ class ParamStore:
 
     def _accumulated(self, param):
         self._in_flight.discard(id(param))
+
+    def _ffn_setup(self, device):
+        """transformer layers whose FFN fits the fused bf16 kernels (d_model 256, dim_feedforward 512; csrc/ffn_fused.hip):
+        offsets of (linear1.weight, linear1.bias, linear2.weight, norm2.weight, norm2.bias) in the flat buffer and the
+        buffers of the packed weight images (filled by ensure() on every forward: the weights move every step)"""
+        self._ffn = None
+        if os.environ.get("DSVG_FFN_FUSED", "1") == "0":
+            return
+        rows, index = [], {}
+        for m in self.module.modules():
+            l1, l2, n2 = getattr(m, "linear1", None), getattr(m, "linear2", None), getattr(m, "norm2", None)
+            if not (isinstance(l1, nn.Linear) and isinstance(l2, nn.Linear) and isinstance(n2, nn.LayerNorm)):
+                continue
+            if tuple(l1.weight.shape) != (512, 256) or tuple(l2.weight.shape) != (256, 512) or l1.bias is None:
+                continue
+            ps = (l1.weight, l1.bias, l2.weight, n2.weight, n2.bias)
+            if any(id(p) not in self.index for p in ps):
+                continue
+            index[id(l1.weight)] = len(rows)
+            rows.append([self.index[id(p)][0] for p in ps])
+        if not rows:
+            return
+        n = len(rows)
+        self._ffn = dict(n=n, index=index, offs=torch.tensor(rows, dtype=torch.int64, device=device),
+                         fwd=torch.empty(n * ops.FFN_FWD_LAYER_ELEMS, dtype=torch.bfloat16, device=device),
+                         bwd=torch.empty(n * ops.FFN_BWD_LAYER_ELEMS, dtype=torch.bfloat16, device=device),
+                         b1f=torch.empty((n, 512), dtype=torch.float32, device=device),
+                         w2p=torch.empty((n, 256, 512), dtype=torch.bfloat16, device=device))
+
+    def ffn(self, w1):
+        """(packed forward image, packed backward image, folded linear1 bias, linear2.weight with fragment-ordered
+        columns) of the layer whose linear1.weight is w1, or None when that layer does not run on the fused FFN kernels"""
+        f = self._ffn
+        if f is None or self.flat_lp is None or self.flat_lp.dtype != torch.bfloat16:
+            return None
+        i = f["index"].get(id(w1))
+        if i is None:
+            return None
+        return (f["fwd"][i * ops.FFN_FWD_LAYER_ELEMS:(i + 1) * ops.FFN_FWD_LAYER_ELEMS],
+                f["bwd"][i * ops.FFN_BWD_LAYER_ELEMS:(i + 1) * ops.FFN_BWD_LAYER_ELEMS], f["b1f"][i], f["w2p"][i])
 
     def ensure(self, device, dtype):
         params = self.params
@@ -336,6 +378,9 @@ class ParamStore:
                 self.flat_lp = torch.empty(self.flat.numel(), dtype=dtype, device=device)
                 self._lp_views = {}
             ops.cast_weights(self.flat, self.flat_lp)
+            if dtype == torch.bfloat16 and self._ffn is not None:
+                f = self._ffn
+                ops.ffn_pack(self.flat, f["offs"], f["n"], f["fwd"], f["bwd"], f["b1f"], f["w2p"])
 
     def lp(self, param):
         v = self._lp_views.get(id(param))

@@ -745,10 +745,11 @@ FFN_FWD_CHUNKS, FFN_FWD_LAYER_ELEMS, FFN_BWD_LAYER_ELEMS = 16, 16 * 32 * 512, 16
 _FFN_STAGES = int(os.environ.get("DSVG_FFN_STAGES", "0"))     # LDS ring depth of the fused kernels (0 = default), tuning knob
 
 
-def ffn_pack(flat, offs, n_layers, packed_fwd=None, packed_bwd=None, b1f=None):
+def ffn_pack(flat, offs, n_layers, packed_fwd=None, packed_bwd=None, b1f=None, w2p=None):
     """fragment-major bf16 images of linear1 / linear2 of n_layers layers, straight from the fp32 master buffer `flat`,
     with the LayerNorm affine folded into linear1 (include/dsvg.h).  offs: int64 device tensor [n_layers, 5] of element
-    offsets (linear1.weight, linear1.bias, linear2.weight, norm.weight, norm.bias).  -> (packed_fwd, packed_bwd, b1f)"""
+    offsets (linear1.weight, linear1.bias, linear2.weight, norm.weight, norm.bias).  w2p (optional bf16
+    [n_layers, 256, 512]): linear2.weight with fragment-ordered columns.  -> (packed_fwd, packed_bwd, b1f)"""
     _chk(flat, offs, packed_fwd, packed_bwd, b1f)
     assert flat.dtype == torch.float32 and offs.dtype == torch.int64 and tuple(offs.shape) == (n_layers, 5)
     assert offs.is_contiguous()
@@ -761,28 +762,38 @@ def ffn_pack(flat, offs, n_layers, packed_fwd=None, packed_bwd=None, b1f=None):
         b1f = torch.empty((n_layers, 512), dtype=torch.float32, device=dev)
     assert packed_fwd.numel() == n_layers * FFN_FWD_LAYER_ELEMS and packed_bwd.numel() == n_layers * FFN_BWD_LAYER_ELEMS
     assert b1f.numel() == n_layers * 512 and b1f.dtype == torch.float32
+    assert w2p is None or (w2p.dtype == torch.bfloat16 and w2p.numel() == n_layers * 131072 and w2p.is_contiguous())
     _l.check(_l.load().dsvg_ffn_pack(flat.data_ptr(), offs.data_ptr(), n_layers, 256, 512, packed_fwd.data_ptr(),
-                                     packed_bwd.data_ptr(), b1f.data_ptr(), _stream()), "dsvg_ffn_pack")
+                                     packed_bwd.data_ptr(), b1f.data_ptr(), _p(w2p), _stream()), "dsvg_ffn_pack")
     return packed_fwd, packed_bwd, b1f
 
 
-def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, site_res=0, seed=None, out=None):
+def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, site_res=0, seed=None, out=None,
+            train=False):
     """y = x + drop_r(linear2(drop_h(relu(linear1(LayerNorm(x))))))  (x bf16 [rows, 256]; the LayerNorm's gamma / beta
-    are inside packed_fwd_layer / b1f, see ffn_pack)"""
+    are inside packed_fwd_layer / b1f, see ffn_pack).  train: -> (y, h, xh, rstd) with h bf16 [rows, 512] in fragment
+    order, xh = (x - mean) * rstd bf16, rstd fp32 [rows] (what the backward pass needs)"""
     _chk(x, packed_fwd_layer, b1f, b2, seed, out)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
     assert packed_fwd_layer.numel() == FFN_FWD_LAYER_ELEMS and packed_fwd_layer.is_contiguous()
     assert b1f.numel() == 512 and b2.numel() == 256 and b1f.dtype == torch.float32 and b2.dtype == torch.float32
+    rows = x.shape[0]
     if out is None:
         out = torch.empty_like(x)
+    h = xh = rstd = None
+    if train:
+        h = torch.empty((rows, 512), dtype=x.dtype, device=x.device)
+        xh = torch.empty_like(x)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     ev = _prof_begin()
     _l.check(_l.load().dsvg_ffn_fwd(x.data_ptr(), packed_fwd_layer.data_ptr(), b1f.data_ptr(), b2.data_ptr(),
-                                    out.data_ptr(), x.shape[0], float(eps), float(drop_p), int(site_hidden),
-                                    int(site_res), _p(seed) if drop_p > 0 else None, _FFN_STAGES, _stream()),
-             "dsvg_ffn_fwd")
-    # 2 GEMMs of 2 * 256 * 512 FLOP per row; algorithmic bytes: the row in, the row out (SURVEY.md 8(d))
-    _prof_end(ev, 4.0 * 256 * 512 * x.shape[0], 2.0 * 512 * x.shape[0], dict(op="ffn_fwd", rows=x.shape[0]))
-    return out
+                                    out.data_ptr(), _p(h), _p(xh), _p(rstd), rows, float(eps), float(drop_p),
+                                    int(site_hidden), int(site_res), _p(seed) if drop_p > 0 else None, _FFN_STAGES,
+                                    _stream()), "dsvg_ffn_fwd")
+    # 2 GEMMs of 2 * 256 * 512 FLOP per row; algorithmic bytes: the row in, the row out (SURVEY.md 8(d)), plus - in
+    # training - h and xh for the backward pass
+    _prof_end(ev, 4.0 * 256 * 512 * rows, (2.0 * 512 + (1536.0 if train else 0.0)) * rows, dict(op="ffn_fwd", rows=rows))
+    return (out, h, xh, rstd) if train else out
 
 
 def ffn_bwd(x, dy, packed_bwd_layer, b1f, eps=1e-5, drop_p=0.0, site_hidden=0, site_res=0, seed=None):
@@ -808,6 +819,21 @@ def ffn_bwd(x, dy, packed_bwd_layer, b1f, eps=1e-5, drop_p=0.0, site_hidden=0, s
     _prof_end(ev, 4.0 * 256 * 512 * rows, (3 * 512 + 3 * 1024 + 512 + (512 if drop_p > 0 else 0)) * float(rows),
               dict(op="ffn_bwd", rows=rows))
     return dx, h, dpre, xh, dym
+
+
+def ffn_bwd_dx(dpre, x, dy, packed_bwd_layer, eps=1e-5):
+    """dx = dy + LayerNorm'(dpre . W1')  (dpre bf16 [rows, 512] in fragment order; include/dsvg.h)"""
+    _chk(dpre, x, dy, packed_bwd_layer)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
+    assert dy.dtype == x.dtype and dy.shape == x.shape and dy.is_contiguous()
+    assert dpre.dtype == x.dtype and tuple(dpre.shape) == (x.shape[0], 512) and dpre.is_contiguous()
+    assert packed_bwd_layer.numel() == FFN_BWD_LAYER_ELEMS and packed_bwd_layer.is_contiguous()
+    dx = torch.empty_like(x)
+    ev = _prof_begin()
+    _l.check(_l.load().dsvg_ffn_bwd_dx(dpre.data_ptr(), x.data_ptr(), dy.data_ptr(), packed_bwd_layer.data_ptr(),
+                                       dx.data_ptr(), x.shape[0], float(eps), _stream()), "dsvg_ffn_bwd_dx")
+    _prof_end(ev, 2.0 * 256 * 512 * x.shape[0], (1024.0 + 3 * 512) * x.shape[0], dict(op="ffn_bwd_dx", rows=x.shape[0]))
+    return dx
 
 
 def ffn_wgrad_finish(g1p, db1p, g2p, w1, gamma, beta, dw1, db1, dw2, dgamma, dbeta):

@@ -360,16 +360,20 @@ int dsvg_assemble_batch(const int16_t* rows, int64_t n_rows, const int32_t* slot
  *                   linear1.bias, linear2.weight, norm.weight, norm.bias).  The LayerNorm's affine part is folded into
  *                   linear1: W1' = W1 diag(gamma), b1' = b1 + W1 beta (b1_folded, fp32 [n_layers][512]).
  *                   packed_fwd [n_layers][16][32 KiB], packed_bwd [n_layers][16][48 KiB] (dsvg_ffn_pack_bytes(n, 0 | 1)).
+ *                   w2p (optional, bf16 [n_layers][256][512]): linear2.weight with its columns in fragment order, the B
+ *                   operand of the unfused input-gradient GEMM dpre = dym . W2p.
  *   dsvg_ffn_fwd    x, y bf16 [rows, 256] (row stride 256); packed_fwd_layer / b1_folded = that layer's slices; b2 fp32;
  *                   dropout sites / seed as everywhere else (draw scheme "v2", private to the fused kernels);
- *                   stages = LDS ring depth (0 = default).
+ *                   stages = LDS ring depth (0 = default).  Training calls pass h_out (bf16 [rows, 512], hidden columns in
+ *                   FRAGMENT ORDER: position p(j) = j with bits 2 and 3 swapped), xh_out = (x - mean) * rstd (bf16
+ *                   [rows, 256]) and rstd_out (fp32 [rows]) for the backward pass; inference passes NULL for all three.
  * Buffers are caller-owned; all work is enqueued on `stream`. */
 int64_t dsvg_ffn_pack_bytes(int32_t n_layers, int32_t which);
 int dsvg_ffn_pack(const float* flat_f32, const int64_t* offs, int32_t n_layers, int32_t d_model, int32_t d_ff,
-                  void* packed_fwd, void* packed_bwd, float* b1_folded, void* stream);
+                  void* packed_fwd, void* packed_bwd, float* b1_folded, void* w2p, void* stream);
 int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const float* b1_folded, const float* b2, void* y,
-                 int64_t rows, float eps, float drop_p, uint32_t site_hidden, uint32_t site_res, const void* seed,
-                 int32_t stages, void* stream);
+                 void* h_out, void* xh_out, float* rstd_out, int64_t rows, float eps, float drop_p,
+                 uint32_t site_hidden, uint32_t site_res, const void* seed, int32_t stages, void* stream);
 /* Backward of the fused FFN sub-block (two launches; csrc/ffn_fused.hip):
  *   kernel 1 recomputes the hidden tile from x, replays both dropout masks and writes what the weight-gradient GEMMs
  *            need: h, dpre bf16 [rows, 512] with the hidden columns in FRAGMENT ORDER (position p(j) = j with bits 2 and 3
@@ -383,6 +387,10 @@ int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const float* b1_fo
 int dsvg_ffn_bwd(const void* x, const void* dy, const void* packed_bwd_layer, const float* b1_folded, void* h, void* dpre,
                  void* xh, void* dym, void* dx, int64_t rows, float eps, float drop_p, uint32_t site_hidden,
                  uint32_t site_res, const void* seed, void* stream);
+/* kernel 2 alone: dx = dy + LayerNorm'(dpre . W1') from a dpre (bf16 [rows, 512], fragment order) the caller produced
+ * (training default: dpre = (dym . W2p) gated by the h the forward kernel stored, one dsvg_gemm) */
+int dsvg_ffn_bwd_dx(const void* dpre, const void* x, const void* dy, const void* packed_bwd_layer, void* dx, int64_t rows,
+                    float eps, void* stream);
 int dsvg_ffn_wgrad_finish(const float* g1p, const float* db1p, const float* g2p, const float* w1, const float* gamma,
                           const float* beta, float* dw1, float* db1, float* dw2, float* dgamma, float* dbeta,
                           void* stream);

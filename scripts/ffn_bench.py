@@ -51,8 +51,10 @@ def main():
     quick = '--quick' in sys.argv
     if '--pmc' in sys.argv:      # a few plain launches for rocprofv3 --pmc (no timing loop)
         x = torch.randn(131072, 256, generator=g).to(DEV).to(torch.bfloat16)
+        dy = torch.randn(131072, 256, generator=g).to(DEV).to(torch.bfloat16)
         for _ in range(3):
             ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 3, 4, seed)
+            ops.ffn_bwd(x, dy, pb[:ops.FFN_BWD_LAYER_ELEMS], b1f[0], 1e-5, 0.1, 3, 4, seed)
         torch.cuda.synchronize()
         return
     for rows in ((4096, 131072) if quick else (4096, 40960, 71680, 126976, 131072, 262144)):
@@ -71,7 +73,45 @@ def main():
             for p in (0.1, 0.0):
                 tf = timeit(lambda: ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, p, 3, 4, seed, out=y))
                 line += f" fused s{st} p{p}: {tf:6.1f} us {flops / tf * 1e-6:5.0f} TF/s ({flops / tf * 1e-6 / 2500 * 100:4.1f} %) |"
+        ops._FFN_STAGES = 0
+        tt = timeit(lambda: ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 3, 4, seed, out=y, train=True))
+        line += f" TRAIN (writes h, xh): {tt:6.1f} us {flops / tt * 1e-6:5.0f} TF/s |"
         print(line, flush=True)
+        if quick:
+            continue
+        # ---- backward: fused (2 launches + 2 weight-gradient GEMMs + finish) vs the unfused sequence ----
+        dy = torch.randn(rows, 256, generator=g).to(DEV).to(torch.bfloat16)
+        pbl = pb[:ops.FFN_BWD_LAYER_ELEMS]
+        W1m = flat[8:8 + 131072].view(512, 256)
+        outs = [torch.empty(n, device=DEV) for n in (131072, 512, 131072, 256, 256)]
+        g2p, g1p = torch.empty(256, 512, device=DEV), torch.empty(512, 256, device=DEV)
+        db1p, db2 = torch.empty(512, device=DEV), torch.empty(256, device=DEV)
+        s2, s1 = ops.split_k_for(256, 512, rows), ops.split_k_for(512, 256, rows)
+
+        def fused_bwd_kernels(p=0.1):
+            return ops.ffn_bwd(x, dy, pbl, b1f[0], 1e-5, p, 3, 4, seed)
+        dx, hp, dpre, xh, dym = fused_bwd_kernels()
+
+        def fused_wgrad():
+            ops.gemm(dym, hp, a_kc=False, b_kc=False, out=g2p, split_k=s2, rowsum=db2)
+            ops.gemm(dpre, xh, a_kc=False, b_kc=False, out=g1p, split_k=s1, rowsum=db1p)
+            ops.ffn_wgrad_finish(g1p, db1p, g2p, W1m, gamma, beta, *outs)
+        xn, mean, rstd = ops.layernorm_fwd(x, gamma, beta)
+        h = ops.gemm(xn, W1, bias=b1, act=ops.RELU, drop_p=0.1, drop_site=3, seed=seed)
+        dw2, dw1 = torch.empty(256, 512, device=DEV), torch.empty(512, 256, device=DEV)
+        dg, dbt = torch.empty(256, device=DEV), torch.empty(256, device=DEV)
+
+        def unfused_bwd():
+            dm = ops.drop_apply(dy, 0.1, 4, seed)
+            ops.gemm(dm, h, a_kc=False, b_kc=False, out=dw2, split_k=s2, rowsum=db2)
+            dh = ops.gemm(dm, W2, b_kc=False, gate=h, gate_scale=1.0 / 0.9)
+            ops.gemm(dh, xn, a_kc=False, b_kc=False, out=dw1, split_k=s1, rowsum=db1p)
+            dxn = ops.gemm(dh, W1, b_kc=False)
+            ops.layernorm_bwd(dxn, x, mean, rstd, gamma, res=dy, dgamma=dg, dbeta=dbt)
+        t1, t2, t3 = timeit(fused_bwd_kernels), timeit(fused_wgrad), timeit(unfused_bwd)
+        fl = 8.0 * 256 * 512 * rows
+        print(f"   backward rows {rows:7d}: fused dX kernels {t1:7.1f} us + wgrad GEMMs/finish {t2:7.1f} us = {t1 + t2:7.1f} us "
+              f"({fl / (t1 + t2) * 1e-6:5.0f} TF/s algorithmic) | unfused {t3:7.1f} us ({fl / t3 * 1e-6:5.0f} TF/s)", flush=True)
 
 
 if __name__ == "__main__":

@@ -404,3 +404,34 @@ def test_hierarch_outputs_feed_straight_back_for_a_batch(emulated_ops):
         assert torch.allclose(back[k], full[k], atol=1e-5) and torch.allclose(back2[k], full[k], atol=1e-5), k
     with pytest.raises(ValueError):
         model(None, None, None, None, z=zg[:, :, :2].permute(2, 1, 0, 3).contiguous(), hierarch_logits=hl, return_tgt=False)
+
+
+def test_fused_ffn_path_matches_unfused_with_emulated_ops(emulated_ops):
+    """bf16 compute: every layer's FFN runs through ffn_fwd / ffn_bwd / wgrad_finish (LayerNorm folded into the packed
+    linear1, fragment-ordered weight gradients) - the wiring must reproduce the unfused layer's loss and gradients up
+    to bf16 rounding, including the live-prefix backward of the second decoder stage"""
+    from deepsvg_amd.synthetic import make_batch
+    import deepsvg_amd.functional as Fn
+    cfg = H.build_cfg("hier")
+    cfg.n_layers = cfg.n_layers_decode = 2
+    c, a = make_batch(6, seed=3)
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 4)
+    res = {}
+    monkey_min_rows, Fn.FFN_MIN_ROWS = Fn.FFN_MIN_ROWS, 0       # (the production threshold is far above this batch)
+    for fused in (True, False):
+        model = deepsvg_amd.SVGTransformer(cfg).eval()
+        model.load_state_dict(sd)
+        model.set_compute_dtype(torch.bfloat16)
+        if not fused:
+            model.store._ffn_setup = lambda device: None
+        out = model(c, a, c, a, params={})
+        assert (model.store._ffn is not None) == fused
+        ld = deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
+        ld["loss"].backward()
+        res[fused] = (float(ld["loss"]), {n: p.grad.clone() for n, p in model.named_parameters()})
+    Fn.FFN_MIN_ROWS = monkey_min_rows
+    assert abs(res[True][0] - res[False][0]) < 2e-2 * abs(res[False][0])
+    worst, name = max((H.rel_l2(res[True][1][n], res[False][1][n]), n) for n in res[True][1])
+    assert worst < 0.12, (worst, name)
+    med = sorted(H.rel_l2(res[True][1][n], res[False][1][n]) for n in res[True][1])[len(res[True][1]) // 2]
+    assert med < 0.05, med

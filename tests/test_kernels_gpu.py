@@ -807,7 +807,11 @@ def test_ffn_pack_layouts(gpu_device):
     elements e): forward [W1' chunk | W2 chunk], backward [W1' chunk | W2^T chunk | W1'^T chunk], W1' = W1 diag(gamma)
     rounded to bf16 once, and the folded bias b1 + W1 beta"""
     flat, offs, _, _ = _ffn_setup(8, seed=3)
-    pf, pb, b1f = ops.ffn_pack(flat, offs, 2)
+    w2p = torch.empty((2, 256, 512), dtype=torch.bfloat16, device=DEV)
+    pf, pb, b1f = ops.ffn_pack(flat, offs, 2, w2p=w2p)
+    perm = R._ffn_frag_perm(DEV)
+    for layer in range(2):      # linear2.weight with fragment-ordered columns: w2p[:, p(j)] = W2[:, j]
+        assert torch.equal(w2p[layer][:, perm], _ffn_params(flat, offs, layer)[2].to(torch.bfloat16))
     pf = pf.view(2, 16, 32, 64, 8).cpu().float()
     pb = pb.view(2, 16, 48, 64, 8).cpu().float()
     lane = torch.arange(64)
@@ -848,6 +852,17 @@ def test_ffn_fwd_matches_reference(gpu_device, rows, drop_p):
         _close(y, want, 1.5e-2, f"ffn_fwd rows={rows} p={drop_p} layer={layer}")
         # rounding-level agreement on the bulk, not just the max
         assert (y.float() - want.float()).abs().mean().item() < 2e-3 * want.float().abs().mean().item()
+    # training call: same y, plus h (fragment order), xh and rstd for the backward pass
+    pl = pf[:ops.FFN_FWD_LAYER_ELEMS]
+    y0 = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, drop_p, 403, 404, seed)
+    yt, h, xh, rstd = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, drop_p, 403, 404, seed, train=True)
+    wy, wh, wxh, wrstd = R.ffn_fwd(x, epf[:ops.FFN_FWD_LAYER_ELEMS], eb1f[0], b2, 1e-5, drop_p, 403, 404, seed, train=True)
+    assert torch.equal(yt, y0)
+    same = (h != 0) == (wh != 0)        # ReLU gates within rounding of zero may differ (other fp32 summation order)
+    assert (~same).float().mean().item() < 2e-3
+    _close(torch.where(same, h, torch.zeros_like(h)), torch.where(same, wh, torch.zeros_like(wh)), 1.5e-2, "ffn_fwd train h")
+    _close(xh, wxh, 1.5e-2, "ffn_fwd train xh")
+    assert torch.allclose(rstd, wrstd, rtol=1e-4, atol=1e-6)
     if drop_p > 0:      # the masks are a pure function of (seed, site, id): another seed gives another output
         pl = pf[:ops.FFN_FWD_LAYER_ELEMS]
         y1 = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, drop_p, 403, 404, _seed_tensor(7))
@@ -942,3 +957,40 @@ def test_ffn_wgrad_finish_and_full_gradients(gpu_device):
         # ReLU gates that flip under bf16 rounding of the pre-activation (~0.1 % of the units on this data) put an
         # O(sqrt(flip fraction)) floor under everything downstream of dpre; dW2 / db2 do not depend on the gate
         assert rel < (2e-2 if name in ("dW2", "db2") else 8e-2), (name, rel)
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_ffn_training_path_matches_reference(gpu_device, drop_p):
+    """the default training path: forward kernel with train=True (stores h in fragment order + xh), then in the backward
+    pass drop_apply -> gated GEMM on W2p -> ffn_bwd_dx; every step against its restatement, and end to end against the
+    fully fused backward kernels (same dx up to rounding)"""
+    rows = 2000
+    flat, offs, x, b2 = _ffn_setup(rows, seed=21)
+    w2p = torch.empty((2, 256, 512), dtype=torch.bfloat16, device=DEV)
+    pf, pb, b1f = ops.ffn_pack(flat, offs, 2, w2p=w2p)
+    ew2p = torch.empty_like(w2p)
+    epf, epb, eb1f = R.ffn_pack(flat, offs, 2, w2p=ew2p)
+    assert torch.equal(w2p, ew2p)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    dy = torch.randn(rows, 256, generator=g).to(DEV).to(torch.bfloat16)
+    seed = _seed_tensor(0x0123456789ABCDEF)
+    pl, pbl = pf[:ops.FFN_FWD_LAYER_ELEMS], pb[:ops.FFN_BWD_LAYER_ELEMS]
+    y, h, xh, rstd = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, drop_p, 403, 404, seed, train=True)
+    inv_keep = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
+    dym = ops.drop_apply(dy, drop_p, 404, seed)
+    dpre = ops.gemm(dym, w2p[0], b_kc=False, gate=h, gate_scale=inv_keep)
+    dx = ops.ffn_bwd_dx(dpre, x, dy, pbl)
+    # restatement of the same three steps on the kernel's own h (the gate)
+    edym = R.drop_apply(dy, drop_p, 404, seed)
+    edpre = R.gemm(edym, ew2p[0], b_kc=False, gate=h, gate_scale=inv_keep)
+    edx = R.ffn_bwd_dx(edpre, x, dy, epb[:ops.FFN_BWD_LAYER_ELEMS])
+    assert torch.equal(dym, edym)
+    _close(dpre, edpre, 1.5e-2, "training path dpre")
+    _close(dx, edx, 2e-2, "training path dx")
+    # and against the fully fused backward (which recomputes h and replays the hidden mask itself)
+    dx_f, h_f, dpre_f, xh_f, dym_f = ops.ffn_bwd(x, dy, pbl, b1f[0], 1e-5, drop_p, 403, 404, seed)
+    assert torch.equal(h_f, h) and torch.equal(xh_f, xh)
+    if drop_p > 0:
+        assert torch.equal(dym_f, dym)
+    _close(dpre_f, dpre, 1.5e-2, "fused vs training-path dpre")
+    _close(dx_f, dx, 2e-2, "fused vs training-path dx")

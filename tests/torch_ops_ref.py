@@ -660,7 +660,7 @@ def advance_step_(counter, seed):
 FFN_FWD_LAYER_ELEMS, FFN_BWD_LAYER_ELEMS = 16 * 32 * 512, 16 * 48 * 512
 
 
-def ffn_pack(flat, offs, n_layers, packed_fwd=None, packed_bwd=None, b1f=None):
+def ffn_pack(flat, offs, n_layers, packed_fwd=None, packed_bwd=None, b1f=None, w2p=None):
     dev = flat.device
     if packed_fwd is None:
         packed_fwd = torch.empty(n_layers * FFN_FWD_LAYER_ELEMS, dtype=torch.bfloat16, device=dev)
@@ -676,6 +676,8 @@ def ffn_pack(flat, offs, n_layers, packed_fwd=None, packed_bwd=None, b1f=None):
         packed_fwd[i * FFN_FWD_LAYER_ELEMS:(i + 1) * FFN_FWD_LAYER_ELEMS] = w
         packed_bwd[i * FFN_BWD_LAYER_ELEMS:i * FFN_BWD_LAYER_ELEMS + 262144] = w
         b1f.view(n_layers, 512)[i] = flat[ob1:ob1 + 512] + W1 @ beta
+        if w2p is not None:
+            w2p.view(n_layers, 256, 512)[i] = flat[o2:o2 + 131072].view(256, 512)[:, _ffn_frag_perm(dev)].to(torch.bfloat16)
     return packed_fwd, packed_bwd, b1f
 
 
@@ -707,17 +709,22 @@ def _ffn_hidden(xn, W1, b1, drop_p, site_hidden, seed):
     return (torch.relu(pre) * m).to(xn.dtype), pre, m
 
 
-def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, site_res=0, seed=None, out=None):
+def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, site_res=0, seed=None, out=None,
+            train=False):
     W1, W2 = _ffn_weights(packed_fwd_layer)
-    xh, _, _ = _ffn_normalise(x, eps)
+    xh, _, rstd = _ffn_normalise(x, eps)
     h, _, _ = _ffn_hidden(xh, W1, b1f, drop_p, site_hidden, seed)
     y = _f(h) @ _f(W2).t() + b2
-    y = y * drop2_mult(drop_p, seed, site_res, _ids(x.shape[0], 256, x.device)) + _f(x)
+    y = y * drop_mult(drop_p, seed, site_res, _ids(x.shape[0], 256, x.device)) + _f(x)
     y = y.to(x.dtype)
     if out is not None:
         out.copy_(y)
-        return out
-    return y
+        y = out
+    if not train:
+        return y
+    hp = torch.empty_like(h)
+    hp[:, _ffn_frag_perm(x.device)] = h
+    return y, hp, xh, rstd
 
 
 def _ffn_frag_perm(device):
@@ -732,7 +739,7 @@ def ffn_bwd(x, dy, packed_bwd_layer, b1f, eps=1e-5, drop_p=0.0, site_hidden=0, s
     xh, mean, rstd = _ffn_normalise(x, eps)
     h, pre, m_h = _ffn_hidden(xh, W1, b1f, drop_p, site_hidden, seed)
     if drop_p > 0:
-        dym = (_f(dy) * drop2_mult(drop_p, seed, site_res, _ids(rows, 256, x.device))).to(x.dtype)
+        dym = (_f(dy) * drop_mult(drop_p, seed, site_res, _ids(rows, 256, x.device))).to(x.dtype)
     else:
         dym = dy
     dh = _f(dym) @ _f(W2)
@@ -745,6 +752,15 @@ def ffn_bwd(x, dy, packed_bwd_layer, b1f, eps=1e-5, drop_p=0.0, site_hidden=0, s
     hp[:, perm] = h
     dp[:, perm] = dpre
     return dx.to(x.dtype), hp, dp, xh, dym
+
+
+def ffn_bwd_dx(dpre, x, dy, packed_bwd_layer, eps=1e-5):
+    W1, _ = _ffn_weights(packed_bwd_layer)
+    _, mean, rstd = _ffn_normalise(x, eps)
+    g = _f(dpre)[:, _ffn_frag_perm(x.device)] @ _f(W1)          # dpre[:, p(j)] is unit j
+    xhf = (_f(x) - mean.unsqueeze(-1)) * rstd.unsqueeze(-1)
+    dx = _f(dy) + rstd.unsqueeze(-1) * (g - g.mean(-1, keepdim=True) - xhf * (g * xhf).mean(-1, keepdim=True))
+    return dx.to(x.dtype)
 
 
 def ffn_wgrad_finish(g1p, db1p, g2p, w1, gamma, beta, dw1, db1, dw2, dgamma, dbeta):
