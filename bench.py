@@ -7,13 +7,18 @@ on N MI355X (one process per GPU, RCCL gradient all-reduce).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     FFN GEMMs (linear1/linear2 forward + their dX/dW backward GEMMs; 3.2716 GFLOP per trained icon on
-               the padded layout) timed live with HIP events on the launch stream in a few extra
-               eager steps.  `achieved` counts the FLOPs the launches EXECUTED (padding that is skipped is not
-               counted as achieved work; the skipped fraction is reported beside it)
-  cpu_baseline the CPU restatement of the reference step (oracle/, kind "port") timed on the host cores on a
-               bounded sample
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  roofline     the FFN sub-block of the 16 layers (fused forward kernel on the large stages, linear1 / linear2 GEMMs on
+               the small ones, the backward launches: dropout replay, gated dX GEMM, fused dx + LayerNorm-backward
+               kernel, the two weight-gradient GEMMs + their split-K reductions, the finishing kernel), timed live with
+               HIP events on the launch stream in a few extra eager steps.  bound = "mfma": `frac` = ALGORITHMIC FLOPs the
+               launches executed (524,288 FLOP per token-layer forward, x3 trained; padding that is
+               skipped is not counted, recomputation is not counted) / that time / 2.5 PFLOP/s.  `fused_fwd_kernel` is
+               the dominant kernel alone; `hbm_view` prices the same time against §8(d)'s fused byte count;
+               `traffic` is a committed rocprofv3 --pmc measurement (labelled `traffic_source`), not taken in this run.
+  fp32         the parity path (fp32 storage, exact-fp32 MFMA): ms/step and icons/s of the same step, same batch
+  cpu_baseline the CPU restatement of the reference step (oracle/, kind "port") at batch 60 (the reference's per-GPU
+               default) on 16 threads and on all host cores, each on a bounded sample
 """
 import argparse
 import json
@@ -52,44 +57,80 @@ def parse():
     ap.add_argument("--ffn-replay", type=int, default=0,
                     help="N > 0: after the roofline leg replay ONLY the step's FFN GEMM launches N times on random "
                          "operands of the recorded shapes (for a rocprofv3 --pmc pass, scripts/gpu_ffn_traffic.sh)")
-    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-batch", type=int, default=60)
     ap.add_argument("--cpu-steps", type=int, default=40)
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-path sub-record")
+    ap.add_argument("--cpu-leg", type=int, default=0, help="internal: run one CPU-baseline leg on this many threads and exit")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd, batch, steps):
-    """the reference train step restated on CPU (oracle): forward + SVGLoss + backward + clip + AdamW, fp32"""
+def _cpu_leg_fn(cfg, sd, batch, steps):
+    """the reference train step restated on CPU (oracle): forward + SVGLoss + backward + clip + AdamW, fp32, at the
+    reference's per-GPU batch (60); returns leg(threads, time box in s) -> (icons/s, threads, steps done, s/step)"""
     from oracle import svg_transformer_oracle as O
     from deepsvg_amd.synthetic import make_batch
-    # Many-core hosts make PyTorch's small CPU ops crawl when every core joins each parallel region, so the
-    # thread count is capped (default 16) and REPORTED as `cores`; the leg is also time-boxed.
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(ncores, int(os.environ.get("DSVG_CPU_THREADS", "16")))))
     commands, args = make_batch(batch, seed=4242)
-    leaves = {k: v.detach().clone().requires_grad_(torch.is_floating_point(v)) for k, v in sd.items()}
-    params = [v for v in leaves.values() if v.requires_grad]
-    opt = torch.optim.AdamW(params, lr=1e-3)
 
-    def one():
-        opt.zero_grad()
-        out = O.forward(leaves, cfg, commands, args, commands, args)
-        ld = O.svg_loss(cfg, out, O.DEFAULT_WEIGHTS)
-        ld["loss"].backward()
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
-        opt.step()
+    def leg(threads, box):
+        torch.set_num_threads(max(1, threads))
+        leaves = {k: v.detach().clone().requires_grad_(torch.is_floating_point(v)) for k, v in sd.items()}
+        params = [v for v in leaves.values() if v.requires_grad]
+        opt = torch.optim.AdamW(params, lr=1e-3)
 
-    t0 = time.perf_counter()
-    one()                                   # warm-up (also the fallback sample when the host is very slow)
-    first = time.perf_counter() - t0
-    done, t0 = 0, time.perf_counter()
-    while done < steps and (time.perf_counter() - t0) + first < 25.0:
-        one()
-        done += 1
-    dt = (time.perf_counter() - t0) / done if done else first
-    return {"value": round(batch / dt, 2), "unit": "icons/s", "cores": torch.get_num_threads(),
-            "host_cores": ncores, "kind": "port",
-            "sample": f"{max(done, 1)} train step(s) of batch {batch} (fwd+SVGLoss+bwd+clip+AdamW, dropout off, fp32, "
-                      f"oracle/svg_transformer_oracle.py), {dt * 1e3:.0f} ms/step"}
+        def one():
+            opt.zero_grad()
+            out = O.forward(leaves, cfg, commands, args, commands, args)
+            ld = O.svg_loss(cfg, out, O.DEFAULT_WEIGHTS)
+            ld["loss"].backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+
+        t0 = time.perf_counter()
+        one()                               # warm-up (also the fallback sample when the host is very slow)
+        first = time.perf_counter() - t0
+        done, t0 = 0, time.perf_counter()
+        while done < steps and (time.perf_counter() - t0) + first < box:
+            one()
+            done += 1
+        dt = (time.perf_counter() - t0) / done if done else first
+        return batch / dt, torch.get_num_threads(), max(done, 1), dt
+
+    return leg
+
+
+def cpu_baseline(cfg, sd, batch, steps):
+    """16 threads in-process; every host core in a child process with a hard time limit (on a 256-core host PyTorch's
+    small CPU ops crawl when every core joins each parallel region: one step can take minutes - the child is killed after
+    40 s and the leg is reported as not finished)"""
+    import subprocess
+    ncores = os.cpu_count() or 1
+    leg = _cpu_leg_fn(cfg, sd, batch, steps)
+    v16, c16, n16, dt16 = leg(min(ncores, int(os.environ.get("DSVG_CPU_THREADS", "16"))), 12.0)
+    allc = None
+    if ncores > c16:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", str(ncores), "--cpu-batch", str(batch)],
+                               capture_output=True, text=True, timeout=40)
+            allc = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:      # TimeoutExpired: not one step in 40 s
+            allc = {"value": None, "note": f"all-core leg did not finish in 40 s ({type(e).__name__})"}
+    by = {str(c16): round(v16, 2)}
+    if allc is not None:
+        by[str(ncores)] = allc.get("value")
+    return {"value": round(v16, 2), "unit": "icons/s", "cores": c16, "host_cores": ncores, "kind": "port",
+            "by_threads": by, "all_cores": allc,
+            "sample": f"{n16} train step(s) of batch {batch} (fwd+SVGLoss+bwd+clip+AdamW, dropout off, fp32, "
+                      f"oracle/svg_transformer_oracle.py), {dt16 * 1e3:.0f} ms/step on {c16} threads"}
+
+
+def cpu_leg_main(threads, batch):
+    """child process of cpu_baseline: one leg on `threads` threads, prints one JSON line"""
+    import deepsvg_amd
+    from deepsvg_amd.synthetic import det_state_dict
+    cfg = deepsvg_amd.HierarchicalOrdered()
+    sd = det_state_dict(deepsvg_amd.SVGTransformer(cfg), seed=42)
+    v, c, n, dt = _cpu_leg_fn(cfg, sd, batch, 40)(threads, 10.0)
+    print(json.dumps({"value": round(v, 2), "cores": c, "steps": n, "ms_per_step": round(dt * 1e3, 1)}), flush=True)
 
 
 def replay_ffn(specs, n, device):
@@ -135,6 +176,9 @@ def log(msg):
 
 def main():
     a = parse()
+    if a.cpu_leg > 0:
+        cpu_leg_main(a.cpu_leg, a.cpu_batch)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -246,48 +290,89 @@ def main():
             ffn = [r for r in ops.PROFILE if r[0] == "ffn"]
             ffn_ms = sum(r[1].elapsed_time(r[2]) for r in ffn) / n_prof
             n_ffn = len(ffn) // n_prof
-            flop_exec = sum(r[3] for r in ffn) / n_prof             # what the launches executed
-            bytes_exec = sum(r[4] for r in ffn) / n_prof            # operands + outputs of those launches, once each
+            # algorithmic FLOPs of the FFN sub-block = linear1 + linear2 forward, dX and dW; recomputed or
+            # auxiliary launches (dropout replay, reductions, finishing kernel) carry 0 FLOPs but their time counts
+            flop_exec = sum(r[3] for r in ffn) / n_prof
             flop_padded = a.batch * FFN_FLOP_PER_ICON_TRAIN         # the reference's padded layout
             tf = flop_exec / (ffn_ms * 1e-3) / 1e12
             peak_tf = PEAK_TFLOPS[a.dtype]
-            gbs = bytes_exec / (ffn_ms * 1e-3) / 1e9
-            # Which roofline bounds these kernels: an unfused d_model = 256 GEMM has ~170 FLOP per algorithmic byte,
-            # below the ~310 FLOP/B ridge of 2.5 PFLOP/s over 8 TB/s -> HBM-bound in bf16 (PMC: measured traffic =
-            # algorithmic bytes); the exact-fp32 MFMA path (157 TFLOP/s peak) is compute-bound.  Both views are given.
-            hbm_bound = a.dtype == "bf16"
-            mfma_view = {"achieved_TFLOPs": round(tf, 2), "peak_TFLOPs": peak_tf, "frac": round(tf / peak_tf, 4),
-                         "executed_gflop_per_step": round(flop_exec / 1e9, 1),
-                         "padded_layout_gflop_per_step": round(flop_padded / 1e9, 1),
-                         "padding_skipped_frac": round(1.0 - flop_exec / flop_padded, 4)}
-            hbm_view = {"achieved_GBps": round(gbs, 1), "peak_GBps": 8000.0, "frac": round(gbs / 8000.0, 4),
-                        "algorithmic_GB_per_step": round(bytes_exec / 1e9, 3)}
-            roofline = {"bound": "hbm" if hbm_bound else "mfma",
-                        "kernel": "FFN GEMMs (linear1/linear2 fwd + dX + dW), %d launches per step" % n_ffn,
-                        "achieved": hbm_view["achieved_GBps"] if hbm_bound else mfma_view["achieved_TFLOPs"],
-                        "peak": 8000.0 if hbm_bound else peak_tf, "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                        "frac": hbm_view["frac"] if hbm_bound else mfma_view["frac"], "traffic": None,
+            # SURVEY.md 8(d) fused byte count: 512 B in + 512 B out per token-layer forward; the backward pass in the same
+            # spirit: dy and x in, dx out (weights and their gradients are O(1) per token)
+            fwd_rows = sum(r[5].get("rows", 0) for r in ffn if r[5].get("op") == "ffn_fwd") / n_prof
+            unf_fwd_rows = sum(r[5]["a"][0] for r in ffn if r[5].get("act") == 1) / n_prof      # linear1 of an unfused layer
+            bwd_rows = sum(r[5].get("rows", 0) for r in ffn if r[5].get("op") in ("ffn_bwd_dx", "ffn_bwd")) / n_prof
+            unf_bwd_rows = sum(r[5]["a"][0] for r in ffn if r[5].get("gate")) / n_prof - bwd_rows   # gated dX GEMM: all layers
+            fused_bytes = 1024.0 * (fwd_rows + unf_fwd_rows) + 1536.0 * (bwd_rows + max(unf_bwd_rows, 0.0))
+            gbs = fused_bytes / (ffn_ms * 1e-3) / 1e9
+            fk = [r for r in ffn if r[5].get("op") == "ffn_fwd"]
+            fk_ms = sum(r[1].elapsed_time(r[2]) for r in fk) / n_prof
+            fk_flop = sum(r[3] for r in fk) / n_prof
+            fused_fwd = None
+            if fk:
+                big = max(r[5]["rows"] for r in fk)
+                bigs = [r for r in fk if r[5]["rows"] == big]
+                big_us = sum(r[1].elapsed_time(r[2]) for r in bigs) / len(bigs) * 1e3
+                fused_fwd = {"kernel": "ffn_fwd_kernel (LayerNorm + linear1 + ReLU + dropout + linear2 + dropout + residual, "
+                                       "training variant: also stores h and xh for the backward pass)",
+                             "launches_per_step": len(fk) // n_prof, "ms_per_step": round(fk_ms, 3),
+                             "achieved_TFLOPs": round(fk_flop / (fk_ms * 1e-3) / 1e12, 1),
+                             "frac": round(fk_flop / (fk_ms * 1e-3) / 1e12 / peak_tf, 4),
+                             "largest_launch": {"rows": big, "avg_us": round(big_us, 1),
+                                                "TFLOPs": round(4.0 * 256 * 512 * big / big_us * 1e-6, 1),
+                                                "frac": round(4.0 * 256 * 512 * big / big_us * 1e-6 / peak_tf, 4)}}
+            roofline = {"bound": "mfma",
+                        "kernel": "FFN sub-block of the 16 layers (fused forward kernel / linear1+linear2 GEMMs, dX, dW), "
+                                  "%d launches per step" % n_ffn,
+                        "achieved": round(tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tf / peak_tf, 4),
+                        "traffic": None, "traffic_source": None,
                         "launches_per_step": n_ffn, "ffn_ms_per_step": round(ffn_ms, 3),
                         "avg_launch_us": round(ffn_ms * 1e3 / n_ffn, 2),
-                        "algorithmic_MB_per_launch": round(bytes_exec / n_ffn / 1e6, 2),
-                        "hbm_view": hbm_view, "mfma_view": mfma_view}
-            # HBM traffic of exactly these launches, measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the
-            # --ffn-replay mode of this script (scripts/gpu_ffn_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md
-            # prescribes for 16-byte streaming reads on gfx950); committed under profiles/, keyed by the executed FLOPs
+                        "executed_gflop_per_step": round(flop_exec / 1e9, 1),
+                        "padded_layout_gflop_per_step": round(flop_padded / 1e9, 1),
+                        "padding_skipped_frac": round(1.0 - flop_exec / flop_padded, 4),
+                        "fused_fwd_kernel": fused_fwd,
+                        "hbm_view": {"achieved_GBps": round(gbs, 1), "peak_GBps": 8000.0, "frac": round(gbs / 8000.0, 4),
+                                     "fused_algorithmic_GB_per_step": round(fused_bytes / 1e9, 3),
+                                     "definition": "SURVEY.md 8(d) fused byte count: 1024 B per token-layer forward; "
+                                                   "1536 B per token-layer backward (dy, x in; dx out)"}}
+            # HBM traffic of the dominant kernel, measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (scripts/
+            # gpu_ffn_pmc.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte streaming reads on
+            # gfx950): a COMMITTED measurement (profiles/ffn_traffic.json), not taken in this run
             tj = os.path.join(ROOT, "profiles", "ffn_traffic.json")
             if os.path.exists(tj):
                 t = json.load(open(tj))
-                if abs(t.get("executed_gflop_per_step", 0) - flop_exec / 1e9) < 0.02 * flop_exec / 1e9 \
-                        and t.get("dtype") == a.dtype:
-                    roofline["traffic"] = round(t["hbm_GB_per_step"] * 1e3 / n_ffn, 2)
-                    roofline["traffic_unit"] = "MB per launch (mean over the FFN launches; rocprofv3 --pmc, " + \
-                                               t["source"] + ")"
-                    roofline["traffic_over_algorithmic"] = round(t["hbm_GB_per_step"] / (bytes_exec / 1e9), 3)
+                if t.get("dtype") == a.dtype and "MB_per_launch" in t:
+                    roofline["traffic"] = t["MB_per_launch"]
+                    roofline["traffic_source"] = "committed: " + t["source"]
+                    roofline["traffic_over_fused_algorithmic"] = t.get("over_fused_algorithmic")
             if a.ffn_replay > 0:
-                specs = [r[5] for r in ffn[:n_ffn]]
+                specs = [r[5] for r in ffn[:n_ffn] if "a" in r[5]]
                 replay_ffn(specs, a.ffn_replay, device)
 
     log(f"roofline leg done: {roofline}")
+    fp32 = None
+    if rank == 0 and world == 1 and a.dtype == "bf16" and not a.no_fp32:
+        # the parity path (what the 1e-3 tolerance of the north star is tested on): same step, same batch, eager launches
+        m32 = deepsvg_amd.SVGTransformer(cfg)
+        m32.load_state_dict(sd_cpu)
+        m32.to(device).set_compute_dtype(torch.float32)
+        m32.pack_encoder = bool(a.pack_encoder)
+        m32.train()
+        t32 = TrainStep(m32, deepsvg_amd.SVGLoss(cfg).to(device), lr=1e-3, grad_clip=1.0, use_graph=False)
+        for _ in range(2):
+            ld32 = t32.step(commands, args)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n32 = 5
+        for _ in range(n32):
+            ld32 = t32.step(commands, args)
+        torch.cuda.synchronize()
+        dt32 = (time.perf_counter() - t1) / n32
+        fp32 = {"ms_per_step": round(dt32 * 1e3, 3), "icons_per_s": round(a.batch / dt32, 1), "steps": n32,
+                "launch": "eager", "loss": round(float(ld32["loss"]), 4),
+                "note": "fp32 storage, exact-fp32 MFMA (157.3 TFLOP/s peak): the path the 1e-3 parity tests run on"}
+        del m32, t32
+        log(f"fp32 leg done: {fp32}")
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(cfg, sd_cpu, a.cpu_batch, a.cpu_steps)
@@ -306,7 +391,7 @@ def main():
                        "encoder_layout": ("packed (valid tokens only, exact)" if model.last_packing else "padded"),
                        "encoder_valid_token_frac": (round(model.last_packing[0] / model.last_packing[1], 4)
                                                     if model.last_packing else 1.0)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "fp32": fp32, "cpu_baseline": cpu,
         }
         print(json.dumps(rec), flush=True)
     if world > 1:

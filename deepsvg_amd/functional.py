@@ -449,8 +449,8 @@ class LayerFn(torch.autograd.Function):
                     xn2 = h = None
                     x2 = ops.ffn_fwd(x1, ffn[0], ffn[2], b2.detach(), 1e-5, p, site0 + 3, site0 + 4, rt.seed)
         else:
-            xn2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach())
-            with ops.tag("ffn"):
+            with ops.tag("ffn"):        # (norm2 belongs to the FFN sub-block: the fused kernel contains it)
+                xn2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach())
                 h = ops.gemm(xn2, rt.w(w1), bias=b1.detach(), act=ops.RELU, drop_p=p, drop_site=site0 + 3, seed=rt.seed)
                 x2 = ops.gemm(h, rt.w(w2), bias=b2.detach(), res=x1, drop_p=p, drop_site=site0 + 4, seed=rt.seed)
         ctx.rt, ctx.n_seq, ctx.S, ctx.n_heads, ctx.p, ctx.site0, ctx.scale = rt, n_seq, S, n_heads, p, site0, scale
@@ -513,15 +513,15 @@ class LayerFn(torch.autograd.Function):
         else:
             # ---- FFN: x2 = x1 + drop4(h W2^T + b2),  h = drop3(relu(xn2 W1^T + b1)) ----
             # the mask of the residual dropout is replayed ONCE into dx2m; the three consumers read plain data
-            dx2m = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
             with ops.tag("ffn"):
+                dx2m = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
                 dw2, db2 = _wbgrad(rt, w2, b2, dx2m, h)
                 dh = ops.gemm(dx2m, rt.w(w2), b_kc=False, gate=h, gate_scale=inv_keep)   # (h > 0) <=> relu passed AND kept
                 dw1, db1 = _wbgrad(rt, w1, b1, dh, xn2)
                 dxn2 = ops.gemm(dh, rt.w(w1), b_kc=False)
+                dx1, dn2w, dn2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w.detach(), res=dx2,
+                                                    dgamma=rt.grad_out(n2w), dbeta=rt.grad_out(n2b))
             del dx2m
-            dx1, dn2w, dn2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w.detach(), res=dx2,
-                                                dgamma=rt.grad_out(n2w), dbeta=rt.grad_out(n2b))
         # ---- conditioning adds ----
         dz = dl = dwg = dbg = dwg2 = dbg2 = None
         if l is not None:

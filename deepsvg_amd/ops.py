@@ -222,9 +222,11 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     y = torch.empty_like(x)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    ev = _prof_begin()
     _l.check(_l.load().dsvg_layernorm_fwd(_dt(x), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                           mean.data_ptr(), rstd.data_ptr(), rows, d, float(eps), _stream()),
              "dsvg_layernorm_fwd")
+    _prof_end(ev, 0.0, 0.0, dict(op="layernorm_fwd"))
     return y, mean, rstd
 
 
@@ -243,10 +245,12 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, res=None, dgamma=None, dbeta=None
         assert res.is_contiguous() and res.shape == x.shape and res.dtype == x.dtype
     L = _l.load()
     ws = _ws(L.dsvg_layernorm_bwd_workspace_bytes(rows, d), x.device)
+    ev = _prof_begin()
     _l.check(L.dsvg_layernorm_bwd(_dt(x), dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                   gamma.data_ptr(), _p(res), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                   int(accumulate), rows, d, ws.data_ptr(), ws.numel() * 4, _stream()),
              "dsvg_layernorm_bwd")
+    _prof_end(ev, 0.0, 0.0, dict(op="layernorm_bwd"))
     return dx, dgamma, dbeta
 
 
@@ -845,7 +849,9 @@ def ffn_wgrad_finish(g1p, db1p, g2p, w1, gamma, beta, dw1, db1, dw2, dgamma, dbe
     assert g1p.numel() == 131072 and g2p.numel() == 131072 and db1p.numel() == 512 and w1.numel() == 131072
     assert dw1.numel() == 131072 and dw2.numel() == 131072 and db1.numel() == 512 and dgamma.numel() == 256
     assert dbeta.numel() == 256 and gamma.numel() == 256 and beta.numel() == 256
+    ev = _prof_begin()
     _l.check(_l.load().dsvg_ffn_wgrad_finish(*(t.data_ptr() for t in ts), _stream()), "dsvg_ffn_wgrad_finish")
+    _prof_end(ev, 0.0, 0.0, dict(op="ffn_wgrad_finish"))
 
 
 def _prof_begin():
@@ -881,8 +887,10 @@ def drop_apply(x, drop_p, drop_site, seed):
     _chk(x, seed)
     assert x.is_contiguous()
     y = torch.empty_like(x)
+    ev = _prof_begin()
     _l.check(_l.load().dsvg_drop_apply(_dt(x), x.data_ptr(), y.data_ptr(), x.numel(), float(drop_p), int(drop_site),
                                        seed.data_ptr(), _stream()), "dsvg_drop_apply")
+    _prof_end(ev, 0.0, 0.0, dict(op="drop_apply"))
     return y
 
 

@@ -49,12 +49,18 @@ def main():
     seed = torch.tensor([1234567], dtype=torch.int64, device=DEV)
     pl = pf[:ops.FFN_FWD_LAYER_ELEMS]
     quick = '--quick' in sys.argv
-    if '--pmc' in sys.argv:      # a few plain launches for rocprofv3 --pmc (no timing loop)
-        x = torch.randn(131072, 256, generator=g).to(DEV).to(torch.bfloat16)
-        dy = torch.randn(131072, 256, generator=g).to(DEV).to(torch.bfloat16)
+    if '--pmc' in sys.argv:      # a few plain launches for rocprofv3 --pmc (no timing loop): BASELINE C2's decoder stage 2
+        rows = 126976
+        x = torch.randn(rows, 256, generator=g).to(DEV).to(torch.bfloat16)
+        dy = torch.randn(rows, 256, generator=g).to(DEV).to(torch.bfloat16)
+        w2p = torch.empty((2, 256, 512), dtype=torch.bfloat16, device=DEV)
+        ops.ffn_pack(flat, offs, 2, pf, pb, b1f, w2p)
         for _ in range(3):
             ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 3, 4, seed)
-            ops.ffn_bwd(x, dy, pb[:ops.FFN_BWD_LAYER_ELEMS], b1f[0], 1e-5, 0.1, 3, 4, seed)
+            y, h, xh, rstd = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 3, 4, seed, train=True)
+            dym = ops.drop_apply(dy, 0.1, 4, seed)
+            dpre = ops.gemm(dym, w2p[0], b_kc=False, gate=h, gate_scale=1.0 / 0.9)
+            ops.ffn_bwd_dx(dpre, x, dy, pb[:ops.FFN_BWD_LAYER_ELEMS])
         torch.cuda.synchronize()
         return
     for rows in ((4096, 131072) if quick else (4096, 40960, 71680, 126976, 131072, 262144)):

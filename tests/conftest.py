@@ -11,6 +11,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle / restatements run on the host: on a 256-core GPU box PyTorch's small CPU ops crawl (minutes per
+    # call) when every core joins each parallel region
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
 def install_emulated_ops():

@@ -142,7 +142,6 @@ def test_fp32_model_matches_oracle_at_benchmark_size_512(gpu_device):
     model = _hip_model(cfg, sd).eval()
     out, ld, grads = _fwd_bwd(model, cfg, commands, args)
     assert model.last_packing is not None and model.last_live is not None       # the default (skipping) layouts ran
-    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
     o_out, o_ld, o_grads = O.loss_and_grads(sd, cfg, commands, args)
     worst_l = 0.0
     for k in ("command_logits", "args_logits", "visibility_logits"):
