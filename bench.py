@@ -182,18 +182,34 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    # DSVG_BENCH_EMULATE=1: CPU dry run of THIS script's launch / timing / reporting logic under torch.distributed.run
+    # with the gloo backend and the plain-torch restatements of the ops (tests/test_bench_ddp_cpu.py): it proves the
+    # multi-process path is launchable where no multi-GPU node is available; it measures nothing
+    emulate = os.environ.get("DSVG_BENCH_EMULATE") == "1"
+    if emulate:
+        from tests.conftest import install_emulated_ops
+        install_emulated_ops()
+        device = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=device)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    def sync():
+        if not emulate:
+            torch.cuda.synchronize()
 
     import deepsvg_amd
     from deepsvg_amd import lib, ops
     from deepsvg_amd.synthetic import make_batch, det_state_dict
     from deepsvg_amd.trainer import TrainStep
-    lib.load()   # no fallback: fail loudly when the HIP extension is missing
+    if not emulate:
+        lib.load()   # no fallback: fail loudly when the HIP extension is missing
 
     torch.manual_seed(42)                                   # deepsvg/train.py:15
     cfg = deepsvg_amd.HierarchicalOrdered()
@@ -213,7 +229,7 @@ def main():
     log(f"model on {device}, dtype={a.dtype}, batch={a.batch}, world={world}")
     # hipGraph replay of the whole step is verified on one GPU; with RCCL collectives inside the captured region it
     # is opt-in (DSVG_BENCH_GRAPH_DDP=1) because it cannot be exercised on the single-GPU development boxes
-    graph_ok = world == 1 or os.environ.get("DSVG_BENCH_GRAPH_DDP") == "1"
+    graph_ok = (world == 1 or os.environ.get("DSVG_BENCH_GRAPH_DDP") == "1") and not emulate
     use_graph = a.graph != 0 and graph_ok
     ts = TrainStep(model, loss_fn, lr=1e-3 * world, grad_clip=1.0, use_graph=use_graph)
     ts.inputs_resident = True       # the synthetic batch sits in HBM before the timed region (bench contract)
@@ -233,7 +249,7 @@ def main():
         ts = TrainStep(model, loss_fn, lr=1e-3 * world, grad_clip=1.0, use_graph=False)
         ts.step(commands, args)
 
-    torch.cuda.synchronize()
+    sync()
     log(f"first step done (graph={use_graph}); warmup {a.warmup}")
     if a.graph < 0 and use_graph:
         # launch-mode calibration inside the (untimed) warm-up: same TrainStep, same state, both launch paths
@@ -241,11 +257,11 @@ def main():
         for mode in (True, False):
             ts.use_graph = mode
             ts.step(commands, args)
-            torch.cuda.synchronize()
+            sync()
             t1 = time.perf_counter()
             for _ in range(max(a.warmup, 3)):
                 ts.step(commands, args)
-            torch.cuda.synchronize()
+            sync()
             t_mode[mode] = (time.perf_counter() - t1) / max(a.warmup, 3)
         use_graph = t_mode[True] <= t_mode[False]
         ts.use_graph = use_graph
@@ -254,14 +270,14 @@ def main():
         ts.step(commands, args)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         ld = ts.step(commands, args)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -274,7 +290,7 @@ def main():
     icons_per_s = a.batch * world / (elapsed / a.steps)
 
     roofline = None
-    if rank == 0 and not a.no_roofline:
+    if rank == 0 and not a.no_roofline and not emulate:
         # FFN GEMM time: a few extra eager steps with HIP events (torch.cuda.Event records on the stream the
         # kernels are launched on: ops launch on torch's current stream)
         ts_prof = TrainStep(model, loss_fn, lr=0.0, grad_clip=1.0, use_graph=False) if world == 1 else None
@@ -285,7 +301,7 @@ def main():
             n_prof = 3
             for _ in range(n_prof):
                 ts_prof.step(commands, args)
-            torch.cuda.synchronize()
+            sync()
             ops.PROFILE_ON = False
             ffn = [r for r in ops.PROFILE if r[0] == "ffn"]
             ffn_ms = sum(r[1].elapsed_time(r[2]) for r in ffn) / n_prof
@@ -351,7 +367,7 @@ def main():
 
     log(f"roofline leg done: {roofline}")
     fp32 = None
-    if rank == 0 and world == 1 and a.dtype == "bf16" and not a.no_fp32:
+    if rank == 0 and world == 1 and a.dtype == "bf16" and not a.no_fp32 and not emulate:
         # the parity path (what the 1e-3 tolerance of the north star is tested on): same step, same batch, eager launches
         m32 = deepsvg_amd.SVGTransformer(cfg)
         m32.load_state_dict(sd_cpu)
@@ -361,12 +377,12 @@ def main():
         t32 = TrainStep(m32, deepsvg_amd.SVGLoss(cfg).to(device), lr=1e-3, grad_clip=1.0, use_graph=False)
         for _ in range(2):
             ld32 = t32.step(commands, args)
-        torch.cuda.synchronize()
+        sync()
         t1 = time.perf_counter()
         n32 = 5
         for _ in range(n32):
             ld32 = t32.step(commands, args)
-        torch.cuda.synchronize()
+        sync()
         dt32 = (time.perf_counter() - t1) / n32
         fp32 = {"ms_per_step": round(dt32 * 1e3, 3), "icons_per_s": round(a.batch / dt32, 1), "steps": n32,
                 "launch": "eager", "loss": round(float(ld32["loss"]), 4),
@@ -374,7 +390,7 @@ def main():
         del m32, t32
         log(f"fp32 leg done: {fp32}")
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not emulate:
         cpu = cpu_baseline(cfg, sd_cpu, a.cpu_batch, a.cpu_steps)
         log(f"cpu baseline done: {cpu}")
 

@@ -1,0 +1,35 @@
+"""bench.py's own main loop under `python -m torch.distributed.run --nproc-per-node 2` (what the driver launches for
+N > 1), on CPU: gloo backend + the plain-torch restatements of the ops (DSVG_BENCH_EMULATE=1).  No 8-GPU node is
+available to the builder, so this is the proof that the multi-process script path - rendezvous from the env, per-rank
+seeds and batches, TrainStep with the gradient all-reduce and the single 3-count loss all-reduce, barrier-bracketed
+timing, MAX over ranks, ONE JSON line from rank 0 - is launchable; it measures nothing."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_main_loop_two_ranks_gloo():
+    env = dict(os.environ, DSVG_BENCH_EMULATE="1", PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="2",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "3", "--dtype", "fp32"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout              # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch"] == 6 and rec["config"]["parallelism"] == "dp2"
+    assert rec["value"] > 0 and abs(rec["value"] - 6 / (rec["ms_per_step"] * 1e-3)) < 0.01 * rec["value"]
+    assert rec["config"]["loss"] == rec["config"]["loss"]       # finite
