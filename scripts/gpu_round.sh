@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call that mirrors the driver's round-end checks: smoke, the GPU test-suite, the default bench line (with
-# roofline + cpu_baseline), the fp32 parity-path bench, eager and padded-layout variants, and a kernel profile.
+# roofline + fp32 + cpu_baseline), the unfused-FFN A/B, secondary workloads, train sanity and a kernel profile.
 # Everything is wrapped in `timeout`; logs go to gpurun_out/ (merged back by gpurun).
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
@@ -11,20 +11,20 @@ run() { # name, timeout, cmd...
   echo "=== $name" | tee -a gpurun_out/summary.log
   ( time timeout "$t" "$@" ) > "gpurun_out/$name.log" 2>&1
   echo "rc=$? ($name)" | tee -a gpurun_out/summary.log
-  tail -n 4 "gpurun_out/$name.log" | cut -c1-1800 | tee -a gpurun_out/summary.log
+  tail -n 4 "gpurun_out/$name.log" | cut -c1-2500 | tee -a gpurun_out/summary.log
 }
 : > gpurun_out/summary.log
 if [[ "$WHAT" == "all" || "$WHAT" == *smoke* ]]; then
   run smoke 600 python -c "import __graft_entry__ as g; g.smoke()"
 fi
 if [[ "$WHAT" == "all" || "$WHAT" == *test* ]]; then
-  run pytest_gpu 900 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600
+  run pytest_gpu 1200 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 -s
 fi
 if [[ "$WHAT" == "all" || "$WHAT" == *bench* ]]; then
   run bench_default 900 python bench.py
-  run bench_bf16_eager 600 python bench.py --graph 0 --no-cpu-baseline
-  run bench_bf16_padded 600 env DSVG_SKIP_INVISIBLE=0 DSVG_COMPACT_HEAD=0 python bench.py --pack-encoder 0 --no-cpu-baseline
-  run bench_fp32 900 python bench.py --dtype fp32 --steps 5 --warmup 2 --no-cpu-baseline
+  run bench_unfused_ffn 600 env DSVG_FFN_FUSED=0 python bench.py --no-cpu-baseline --no-fp32
+  run bench_bf16_eager 600 python bench.py --graph 0 --no-cpu-baseline --no-fp32
+  run bench_bf16_padded 600 env DSVG_SKIP_INVISIBLE=0 DSVG_COMPACT_HEAD=0 python bench.py --pack-encoder 0 --no-cpu-baseline --no-fp32
 fi
 if [[ "$WHAT" == "all" || "$WHAT" == *second* ]]; then
   run secondary_bench 600 python scripts/secondary_bench.py
