@@ -222,3 +222,6 @@ __host__ __device__ inline size_t dsvg_splitk_slice(size_t M, size_t N, bool row
 // out[j] = (accumulate ? out[j] : 0) + sum_{q<P} part[q*stride + j], j < n   (deterministic order; gemm.hip)
 int dsvg_reduce_partials_strided(const float* part, int64_t P, int64_t stride, int64_t n, float* out,
                                  int32_t accumulate, hipStream_t st);
+// same, with the columns j < n_bf16 of every slice stored as packed bf16 from the slice's start (gemm.hip)
+int dsvg_reduce_partials_mixed(const float* part, int64_t P, int64_t stride, int64_t n, int64_t n_bf16, float* out,
+                               int32_t accumulate, hipStream_t st);

@@ -8,6 +8,8 @@
 #include "dsvg_common.h"
 #include "../../include/dsvg.h"
 #include "gemm_common.h"
+#include <mutex>
+#include <vector>
 
 // ---------------------------------------------------------------------------------------------
 // reference kernel: one thread per output element (debug / odd-stride fallback)
@@ -305,10 +307,14 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(dsvg_gemm_desc p, in
 // out[j] = [out[j] +] sum_q part[q*stride + j].  Block = 64 column lanes x 4 slices of the partial index;
 // each slice keeps 4 independent accumulators (fixed summation tree -> bit-reproducible), the 4 slices are
 // combined through LDS.  VEC = 4 (float4 lanes) when stride, n and the pointers allow it.
-template <int VEC, int TX>
+// n_bf16 > 0 (VEC = 4 only): columns j < n_bf16 of every slice are stored as bf16, packed from the slice's start
+// (element j at byte 2 j), the rest as fp32 at their usual float index - the split-K partials of the bf16 weight-gradient
+// GEMM (gemm_bf16_glds.hip) with its fp32 row sums behind them.
+template <int VEC, int TX, bool BF>
 __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const float* __restrict__ part, long long P,
                                                                       long long stride, long long n,
-                                                                      float* __restrict__ out, int accumulate) {
+                                                                      float* __restrict__ out, int accumulate,
+                                                                      long long n_bf16) {
     constexpr int TY = 256 / TX;           // slices over the partial index
     __shared__ float red[TY][TX][VEC];
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -319,26 +325,33 @@ __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const floa
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[u][e] = 0.f;
     if (j < n) {
+        const bool bf = BF && j < n_bf16;
+        auto ld4 = [&](long long q) -> float4 {
+            if (BF && bf) {
+                const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(part + q * stride) + j);
+                return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
+                                   __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
+            }
+            return *reinterpret_cast<const float4*>(part + q * stride + j);
+        };
         long long q = ty;
         for (; q + 3 * TY < P; q += 4 * TY) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float* p = part + (q + TY * u) * stride + j;
                 if (VEC == 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(p);
+                    const float4 v = ld4(q + TY * u);
                     acc[u][0] += v.x; acc[u][1 % VEC] += v.y; acc[u][2 % VEC] += v.z; acc[u][3 % VEC] += v.w;
                 } else {
-                    acc[u][0] += p[0];
+                    acc[u][0] += part[(q + TY * u) * stride + j];
                 }
             }
         }
         for (; q < P; q += TY) {
-            const float* p = part + q * stride + j;
             if (VEC == 4) {
-                const float4 v = *reinterpret_cast<const float4*>(p);
+                const float4 v = ld4(q);
                 acc[0][0] += v.x; acc[0][1 % VEC] += v.y; acc[0][2 % VEC] += v.z; acc[0][3 % VEC] += v.w;
             } else {
-                acc[0][0] += p[0];
+                acc[0][0] += part[q * stride + j];
             }
         }
     }
@@ -359,16 +372,158 @@ __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const floa
 
 int dsvg_reduce_partials_strided(const float* part, int64_t P, int64_t stride, int64_t n, float* out,
                                  int32_t accumulate, hipStream_t st) {
+    return dsvg_reduce_partials_mixed(part, P, stride, n, 0, out, accumulate, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// deferred reductions: inside a dsvg_defer_scope every reduction of this file's funnel is QUEUED (its partials stay in
+// the caller's workspace) and dsvg_flush_deferred performs all of them in one launch per 64 queued segments - the
+// parameter-gradient reductions of a backward pass (80 split-K weight gradients, 28 LayerNorm gamma/beta pairs, ...)
+// are 6 us launches of 1-2 us of memory work each.  The segment table travels in the kernel arguments, so the launch
+// is hipGraph-capturable without any host staging buffer.  Summation order is fixed (bit-reproducible).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct DeferSeg {
+    const float* part; float* out; long long stride;
+    int n, n_bf16, P, first_block, accumulate, pad;
+};
+constexpr int DEFER_MAX = 64;
+struct DeferTable { DeferSeg s[DEFER_MAX]; int n_seg; };
+static_assert(sizeof(DeferTable) <= 3600, "the segment table must fit the kernel-argument segment");
+
+struct DeferQueue {
+    std::mutex mu;                 // autograd runs backward nodes on its own device thread
+    int scope = 0;
+    hipStream_t st = nullptr;
+    std::vector<DeferSeg> q;
+};
+DeferQueue& defer_queue() { static DeferQueue d; return d; }
+
+constexpr int DF_TX = 32, DF_TY = 8;       // 32 float4 column lanes x 8 groups over the partial index per block
+
+__global__ __launch_bounds__(256) void reduce_deferred_kernel(const DeferTable t) {
+    __shared__ float4 red[DF_TY][DF_TX];
+    int s = 0;
+    while (s + 1 < t.n_seg && (int)blockIdx.x >= t.s[s + 1].first_block) ++s;
+    const float* __restrict__ part = t.s[s].part;
+    const long long stride = t.s[s].stride;
+    const int n = t.s[s].n, n_bf16 = t.s[s].n_bf16, P = t.s[s].P;
+    const int tx = threadIdx.x % DF_TX, ty = threadIdx.x / DF_TX;
+    const int j = (((int)blockIdx.x - t.s[s].first_block) * DF_TX + tx) * 4;
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < n) {
+        const bool bf = j < n_bf16;
+        auto ld4 = [&](int q) -> float4 {
+            if (bf) {
+                const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(part + q * stride) + j);
+                return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                   __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+            }
+            return *reinterpret_cast<const float4*>(part + q * stride + j);
+        };
+        int q = ty;
+        for (; q + 3 * DF_TY < P; q += 4 * DF_TY) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ld4(q + DF_TY * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w; }
+        }
+        for (; q < P; q += DF_TY) {
+            const float4 v = ld4(q);
+            acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+        }
+    }
+    red[ty][tx] = make_float4((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x), (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y),
+                              (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z), (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w));
+    __syncthreads();
+    if (ty == 0 && j < n) {
+        float4 r = red[0][tx];
+#pragma unroll
+        for (int u = 1; u < DF_TY; ++u) { const float4 v = red[u][tx]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        float4* o = reinterpret_cast<float4*>(t.s[s].out + j);
+        if (t.s[s].accumulate) { const float4 v = *o; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        *o = r;
+    }
+}
+
+int defer_flush_locked(DeferQueue& d) {
+    size_t at = 0;
+    while (at < d.q.size()) {
+        DeferTable t;
+        int blocks = 0, k = 0;
+        for (; k < DEFER_MAX && at < d.q.size(); ++k, ++at) {
+            t.s[k] = d.q[at];
+            t.s[k].first_block = blocks;
+            blocks += dsvg_cdiv(t.s[k].n, DF_TX * 4);
+        }
+        t.n_seg = k;
+        hipLaunchKernelGGL(reduce_deferred_kernel, dim3(blocks), dim3(256), 0, d.st, t);
+    }
+    d.q.clear();
+    DSVG_LAUNCH_CHECK("reduce_deferred");
+    return 0;
+}
+
+// true when [out, out + n) overlaps the destination of a queued segment (the queue must then be flushed first)
+bool defer_overlaps(const DeferQueue& d, const float* out, int64_t n) {
+    for (const DeferSeg& g : d.q)
+        if (out < g.out + g.n && g.out < out + n) return true;
+    return false;
+}
+}  // namespace
+
+extern "C" int dsvg_defer_scope(int32_t on) {
+    DeferQueue& d = defer_queue();
+    std::lock_guard<std::mutex> lk(d.mu);
+    d.scope = on ? 1 : 0;
+    return (int)d.q.size();
+}
+
+extern "C" int dsvg_flush_deferred(void* stream) {
+    DeferQueue& d = defer_queue();
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (d.q.empty()) return 0;
+    if (stream && d.st != (hipStream_t)stream) {
+        dsvg_set_error("flush_deferred: the queued reductions were enqueued for another stream");
+        return -1;
+    }
+    return defer_flush_locked(d);
+}
+
+int dsvg_reduce_partials_mixed(const float* part, int64_t P, int64_t stride, int64_t n, int64_t n_bf16, float* out,
+                               int32_t accumulate, hipStream_t st) {
     if (n <= 0) return 0;
-    const bool vec = !(n & 3) && !(stride & 3) && !((uintptr_t)part & 15) && !((uintptr_t)out & 15);
+    const bool vec = !(n & 3) && !(stride & 3) && !((uintptr_t)part & 15) && !((uintptr_t)out & 15) && !(n_bf16 & 3);
+    {
+        DeferQueue& d = defer_queue();
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (!d.q.empty() && (d.st != st || defer_overlaps(d, out, n))) {
+            // a second write to a queued destination (or work for another stream): order matters, run the queue now
+            hipStream_t keep = d.st;
+            (void)keep;
+            int rc = defer_flush_locked(d);
+            if (rc) return rc;
+        }
+        if (d.scope && vec && n < (1ll << 30) && P < (1ll << 30)) {
+            d.st = st;
+            d.q.push_back(DeferSeg{part, out, (long long)stride, (int)n, (int)n_bf16, (int)P, 0, accumulate, 0});
+            return 0;
+        }
+    }
+    if (n_bf16 > 0 && !vec) { dsvg_set_error("reduce_partials: bf16 partials need 16-byte aligned, 4-column-multiple data"); return -1; }
     const long long cols = vec ? n / 4 : n;
     // few columns + many partial rows (bias / LayerNorm gradients): 16 slices over the partial index per block;
     // many columns (weight gradients): 64 column lanes x 4 slices
     const bool wide = cols >= 64 * 128 || P <= 16;
-#define DSVG_RP(V, X) hipLaunchKernelGGL((reduce_partials_strided_kernel<V, X>), dim3(dsvg_cdiv(cols, X)), dim3(256), 0,   \
-                                         st, part, (long long)P, (long long)stride, (long long)n, out, accumulate)
-    if (vec) { if (wide) DSVG_RP(4, 64); else DSVG_RP(4, 16); }
-    else     { if (wide) DSVG_RP(1, 64); else DSVG_RP(1, 16); }
+#define DSVG_RP(V, X, B) hipLaunchKernelGGL((reduce_partials_strided_kernel<V, X, B>), dim3(dsvg_cdiv(cols, X)), dim3(256), 0, \
+                                            st, part, (long long)P, (long long)stride, (long long)n, out, accumulate,      \
+                                            (long long)n_bf16)
+    if (n_bf16 > 0) { if (wide) DSVG_RP(4, 64, true); else DSVG_RP(4, 16, true); }
+    else if (vec) { if (wide) DSVG_RP(4, 64, false); else DSVG_RP(4, 16, false); }
+    else     { if (wide) DSVG_RP(1, 64, false); else DSVG_RP(1, 16, false); }
 #undef DSVG_RP
     DSVG_LAUNCH_CHECK("reduce_partials");
     return 0;
@@ -487,7 +642,7 @@ extern "C" int dsvg_colsum(int32_t dtype, const void* A, int64_t lda, int64_t M,
 }
 
 int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, float* part, float* rs_part,
-                          hipStream_t st);  // gemm_bf16.hip
+                          hipStream_t st, int* part_is_bf16);  // gemm_bf16.hip
 
 extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
     DSVG_CHECK_ARG(dp, "gemm: null desc");
@@ -517,6 +672,7 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
     float* rs_part = d.rowsum ? part + (size_t)d.M * d.N : nullptr;   // row sums of slice 0 (slices are interleaved)
     const size_t slice = dsvg_splitk_slice(d.M, d.N, d.rowsum != nullptr);
 
+    int part_bf16 = 0;
     bool use_naive = d.impl == 1;
     if (d.dtype == DSVG_F32) {
         // the MFMA kernel needs 16-byte aligned rows
@@ -559,8 +715,17 @@ extern "C" int dsvg_gemm(const dsvg_gemm_desc* dp, void* stream) {
 #undef DSVG_F32V
         DSVG_LAUNCH_CHECK("gemm_f32_mfma");
     } else {
-        int rc = dsvg_gemm_bf16_launch(d, k_chunk, nsplit, part, rs_part, st);
+        int rc = dsvg_gemm_bf16_launch(d, k_chunk, nsplit, part, rs_part, st, &part_bf16);
         if (rc) return rc;
+    }
+    if (part && part_bf16) {    // bf16 partials (fp32 row sums behind them at their usual float index): one mixed reduction
+        const int64_t mn = (int64_t)d.M * d.N;
+        if (rs_part && d.rowsum == (float*)d.C + mn && !(d.M & 3))
+            return dsvg_reduce_partials_mixed(part, nsplit, (int64_t)slice, mn + d.M, mn, (float*)d.C, d.accumulate, st);
+        int rc = dsvg_reduce_partials_mixed(part, nsplit, (int64_t)slice, mn, mn, (float*)d.C, d.accumulate, st);
+        if (rc) return rc;
+        if (rs_part) return dsvg_reduce_partials_strided(rs_part, nsplit, (int64_t)slice, d.M, d.rowsum, d.accumulate, st);
+        return 0;
     }
     if (part) {
         const int64_t mn = (int64_t)d.M * d.N;

@@ -14,7 +14,8 @@ enum {
 };
 
 // Launches the LDS-DMA kernel when the call is eligible (see gemm_bf16_glds.hip); returns false otherwise.
+// part_is_bf16 (split-K only, may be NULL): set to 1 when the slices were written as packed bf16 (see the kernel)
 bool dsvg_gemm_bf16_glds_try(const dsvg_gemm_desc& d, int epi, dim3 grid, int tiles_n, int nwg, int k_chunk,
-                             float* part, float* rs_part, int mode, hipStream_t st);
+                             float* part, float* rs_part, int mode, hipStream_t st, int* part_is_bf16);
 // Launches the weight-stationary kernel when the call is eligible (see gemm_bf16_ws.hip); returns false otherwise.
 bool dsvg_gemm_bf16_ws_try(const dsvg_gemm_desc& d, int epi, hipStream_t st);

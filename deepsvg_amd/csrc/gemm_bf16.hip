@@ -390,7 +390,8 @@ static void launch_variant(const dsvg_gemm_desc& d, dim3 grid, int tiles_n, int 
 }
 
 int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, float* part, float* rs_part,
-                          hipStream_t st) {
+                          hipStream_t st, int* part_is_bf16) {
+    *part_is_bf16 = 0;
     const int Kp = (d.K + 7) / 8 * 8;   // k-contiguous operands are read in 8-element chunks (tail masked)
     const bool aligned = !(d.lda & 7) && !(d.ldb & 7) && !((uintptr_t)d.A & 15) && !((uintptr_t)d.B & 15) &&
                          (!d.a_kc || d.lda >= Kp) && (!d.b_kc || d.ldb >= Kp);
@@ -420,7 +421,7 @@ int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, floa
     const bool adrop = d.a_drop_p > 0.f;
 #define DSVG_V(AK, BK, AD, EP) launch_variant<AK, BK, AD, EP>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, st)
     if (part) {     // split-K slices: dedicated variants that contain no epilogue code at all
-        if (dsvg_gemm_bf16_glds_try(d, EPI_PARTIAL, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, st)) {
+        if (dsvg_gemm_bf16_glds_try(d, EPI_PARTIAL, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, st, part_is_bf16)) {
             DSVG_LAUNCH_CHECK("gemm_bf16_glds(split-k)");
             return 0;
         }
@@ -451,7 +452,7 @@ int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, floa
         DSVG_LAUNCH_CHECK("gemm_bf16_ws");
         return 0;
     }
-    if (epi_dma != EPI_GENERIC && dsvg_gemm_bf16_glds_try(d, epi_dma, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, st)) {
+    if (epi_dma != EPI_GENERIC && dsvg_gemm_bf16_glds_try(d, epi_dma, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, st, nullptr)) {
         DSVG_LAUNCH_CHECK("gemm_bf16_glds");
         return 0;
     }

@@ -52,7 +52,7 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
 template <bool AKC, bool BKC, int EPI, int NST, int OCC>
 __global__ __launch_bounds__(256, NST == 1 ? OCC : 2) void gemm_bf16_glds_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
                                                                               int k_chunk, float* part, float* rs_part,
-                                                                              int mode) {
+                                                                              int mode, int part_bf16) {
     __shared__ __attribute__((aligned(1024))) bf16_t smem[NST * 2 * IMG];
 
     // tile schedule: identical to gemm_bf16.hip modes 0 and 1 (workgroup b runs on XCD b % 8)
@@ -215,7 +215,26 @@ __global__ __launch_bounds__(256, NST == 1 ? OCC : 2) void gemm_bf16_glds_kernel
                         make_float4(c[4 * gq], c[4 * gq + 1], c[4 * gq + 2], c[4 * gq + 3]);
             }
         };
-        put(acc00, 0, 0); put(acc01, 0, 1); put(acc10, 1, 0); put(acc11, 1, 1);
+        // bf16 slices (default for the bf16 weight-gradient GEMMs, N % 8 == 0): the partials are 40 % of such a GEMM's HBM
+        // traffic and everything of the reduction's; a slice sums ~1-2 k tokens, 32-64 slices are added in fp32 in a fixed
+        // order, so the rounding (2^-9 relative per slice, independent) stays far below the bf16 operand rounding.  One
+        // v_permlane32_swap pair per two quads gives each lane 8 consecutive columns: one 16-byte store.
+        auto put_bf16 = [&](const floatx16& c, int jn, int im) {
+            const int m = mrow + 32 * im;
+            bf16_t* base = reinterpret_cast<bf16_t*>(my_part);
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const uint32_t a0 = f2bf_pk(c[8 * gp + 0], c[8 * gp + 1]), a1 = f2bf_pk(c[8 * gp + 2], c[8 * gp + 3]);
+                const uint32_t b0 = f2bf_pk(c[8 * gp + 4], c[8 * gp + 5]), b1 = f2bf_pk(c[8 * gp + 6], c[8 * gp + 7]);
+                auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                const int n = ncol + 32 * jn + 16 * gp + 8 * h;
+                if (m < p.M && n < p.N)
+                    *reinterpret_cast<uint4*>(base + (size_t)m * p.N + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            }
+        };
+        if (part_bf16) { put_bf16(acc00, 0, 0); put_bf16(acc01, 0, 1); put_bf16(acc10, 1, 0); put_bf16(acc11, 1, 1); }
+        else { put(acc00, 0, 0); put(acc01, 0, 1); put(acc10, 1, 0); put(acc11, 1, 1); }
         if (do_rs) {                // lanes l and l+32 hold the two k halves of token row (lane & 31)
             rs0 += __shfl_xor(rs0, 32, 64);
             rs1 += __shfl_xor(rs1, 32, 64);
@@ -354,23 +373,24 @@ __global__ __launch_bounds__(256, NST == 1 ? OCC : 2) void gemm_bf16_glds_kernel
 
 template <bool AKC, bool BKC, int EPI>
 void launch(const dsvg_gemm_desc& d, dim3 grid, int tiles_n, int nwg, int k_chunk, float* part, float* rs_part, int mode,
-            int nst, hipStream_t st) {
+            int nst, hipStream_t st, int pbf = 0) {
     static const int occ = getenv("DSVG_GEMM_OCC") ? atoi(getenv("DSVG_GEMM_OCC")) : 4;
     if (nst == 2)
         hipLaunchKernelGGL((gemm_bf16_glds_kernel<AKC, BKC, EPI, 2, 4>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk,
-                           part, rs_part, mode);
+                           part, rs_part, mode, pbf);
     else if (occ == 5)
         hipLaunchKernelGGL((gemm_bf16_glds_kernel<AKC, BKC, EPI, 1, 5>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk,
-                           part, rs_part, mode);
+                           part, rs_part, mode, pbf);
     else
         hipLaunchKernelGGL((gemm_bf16_glds_kernel<AKC, BKC, EPI, 1, 4>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk,
-                           part, rs_part, mode);
+                           part, rs_part, mode, pbf);
 }
 
 }  // namespace
 
 bool dsvg_gemm_bf16_glds_try(const dsvg_gemm_desc& d, int epi, dim3 grid, int tiles_n, int nwg, int k_chunk, float* part,
-                             float* rs_part, int mode, hipStream_t st) {
+                             float* rs_part, int mode, hipStream_t st, int* part_is_bf16) {
+    static const bool pbf_on = !(getenv("DSVG_SPLITK_BF16") && atoi(getenv("DSVG_SPLITK_BF16")) == 0);      // A/B knob
     static const bool disabled = getenv("DSVG_GEMM_NOGLDS") != nullptr;         // A/B knob
     static const int nst_env = getenv("DSVG_GEMM_STAGES") ? atoi(getenv("DSVG_GEMM_STAGES")) : 1;
     if (disabled || d.impl == 2 || mode == 2 || d.a_drop_p > 0.f) return false;
@@ -388,7 +408,12 @@ bool dsvg_gemm_bf16_glds_try(const dsvg_gemm_desc& d, int epi, dim3 grid, int ti
     if (span_a * 2 >= (1ull << 32) || span_b * 2 >= (1ull << 32)) return false;
     if (part) {
         if (((uintptr_t)part & 15) || (d.N & 3)) return false;
-        if (!d.a_kc && !d.b_kc) { launch<false, false, EPI_PARTIAL>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, nst, st); return true; }
+        if (!d.a_kc && !d.b_kc) {
+            const int pbf = (pbf_on && part_is_bf16 && !(d.N & 7)) ? 1 : 0;
+            launch<false, false, EPI_PARTIAL>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, nst, st, pbf);
+            if (part_is_bf16) *part_is_bf16 = pbf;
+            return true;
+        }
         return false;
     }
     if (d.bias && ((uintptr_t)d.bias & 15)) return false;

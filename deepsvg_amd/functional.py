@@ -15,6 +15,7 @@ plain-torch restatements in tests/torch_ops_ref.py to exercise this host logic w
 """
 import math
 import contextlib
+import functools
 import os
 
 import torch
@@ -28,11 +29,17 @@ FFN_BWD_FUSED = os.environ.get("DSVG_FFN_BWD_FUSED", "0") != "0"
 FFN_MIN_ROWS = int(os.environ.get("DSVG_FFN_MIN_ROWS", "16384"))
 
 
+_NULL_CTX = contextlib.nullcontext()
+
+
 class Runtime:
     """Per-forward execution context shared by the Functions."""
 
-    def __init__(self, dtype=torch.float32, seed=None, store=None, training=False, side_stream=None):
+    def __init__(self, dtype=torch.float32, seed=None, store=None, training=False, side_stream=None, defer=False):
         self.dtype = dtype
+        # queue the partial-sum reductions of the parameter gradients (ops.DEFER) instead of launching ~130 of them one
+        # by one: only a caller that flushes before anything reads a gradient may set it (TrainStep)
+        self.defer = bool(defer) and side_stream is None
         self.seed = seed          # int64[1] device tensor holding the dropout seed of this step
         self.store = store        # ParamStore or None
         self.training = training
@@ -50,6 +57,10 @@ class Runtime:
         side.wait_stream(torch.cuda.current_stream())
         self._keep.extend(operands)
         return torch.cuda.stream(side)
+
+    def deferring(self):
+        """context manager around launches whose reductions write parameter gradients"""
+        return ops.DEFER if self.defer else _NULL_CTX
 
     def join(self):
         """make the current stream wait for the side stream; only then may the kept operands be released"""
@@ -85,7 +96,7 @@ def _wgrad(rt, param, dy, x, *, a_drop_p=0.0, a_drop_site=0):
     out = rt.grad_out(param)
     n_out, k_in = param.shape
     T = dy.shape[0]
-    with rt.on_side(dy, x):
+    with rt.on_side(dy, x), rt.deferring():
         ops.gemm(dy, x, a_kc=False, b_kc=False, out=out.view(n_out, k_in), a_drop_p=a_drop_p, a_drop_site=a_drop_site,
                  seed=rt.seed, split_k=ops.split_k_for(n_out, k_in, T))
     return out
@@ -99,7 +110,7 @@ def _wbgrad(rt, weight, bias, dy, x):
     split = ops.split_k_for(n_out, k_in, dy.shape[0])
     dw = rt.grad_out(weight)
     db = rt.grad_out(bias)
-    with rt.on_side(dy, x):
+    with rt.on_side(dy, x), rt.deferring():
         if split > 1:
             ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in), split_k=split, rowsum=db)
         else:
@@ -110,7 +121,8 @@ def _wbgrad(rt, weight, bias, dy, x):
 
 def _bgrad(rt, param, dy, *, drop_p=0.0, drop_site=0):
     out = rt.grad_out(param)
-    ops.colsum(dy, out=out, drop_p=drop_p, drop_site=drop_site, seed=rt.seed)
+    with rt.deferring():
+        ops.colsum(dy, out=out, drop_p=drop_p, drop_site=drop_site, seed=rt.seed)
     return out
 
 
@@ -233,14 +245,15 @@ class LayerNormFn(torch.autograd.Function):
         x, mean, rstd, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
         live = _armed(ctx.live)
-        if live is None:
-            dx, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, gamma.detach(),
-                                           dgamma=rt.grad_out(gamma), dbeta=rt.grad_out(beta))
-        else:
-            R = live[1]
-            dx = torch.empty_like(x)
-            _, dg, db = ops.layernorm_bwd(dy[:R], x[:R], mean[:R], rstd[:R], gamma.detach(), dx=dx[:R],
-                                          dgamma=rt.grad_out(gamma), dbeta=rt.grad_out(beta))
+        with rt.deferring():
+            if live is None:
+                dx, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, gamma.detach(),
+                                               dgamma=rt.grad_out(gamma), dbeta=rt.grad_out(beta))
+            else:
+                R = live[1]
+                dx = torch.empty_like(x)
+                _, dg, db = ops.layernorm_bwd(dy[:R], x[:R], mean[:R], rstd[:R], gamma.detach(), dx=dx[:R],
+                                              dgamma=rt.grad_out(gamma), dbeta=rt.grad_out(beta))
         return None, dx, dg, db, None, None
 
 
@@ -494,7 +507,7 @@ class LayerFn(torch.autograd.Function):
                 g1p = torch.empty((512, 256), dtype=torch.float32, device=x1.device)
                 db1p = torch.empty(512, dtype=torch.float32, device=x1.device)
                 db2 = rt.grad_out(b2)
-                with rt.on_side(dym, hp, dpre, xh):
+                with rt.on_side(dym, hp, dpre, xh), rt.deferring():
                     s2, s1 = ops.split_k_for(256, 512, T), ops.split_k_for(512, 256, T)
                     if s2 > 1:
                         ops.gemm(dym, hp, a_kc=False, b_kc=False, out=g2p, split_k=s2, rowsum=db2)
@@ -508,7 +521,12 @@ class LayerFn(torch.autograd.Function):
                         ops.colsum(dpre, out=db1p)
                     dw1, db1, dw2 = rt.grad_out(w1), rt.grad_out(b1), rt.grad_out(w2)
                     dn2w, dn2b = rt.grad_out(n2w), rt.grad_out(n2b)
-                    ops.ffn_wgrad_finish(g1p, db1p, g2p, w1.detach(), n2w.detach(), n2b.detach(), dw1, db1, dw2, dn2w, dn2b)
+                    finish = functools.partial(ops.ffn_wgrad_finish, g1p, db1p, g2p, w1.detach(), n2w.detach(),
+                                               n2b.detach(), dw1, db1, dw2, dn2w, dn2b)
+                    if rt.defer:
+                        ops.defer_post(finish)      # reads the queued reductions' outputs: runs right after the flush
+                    else:
+                        finish()
             del hp, dpre, xh, dym
         else:
             # ---- FFN: x2 = x1 + drop4(h W2^T + b2),  h = drop3(relu(xn2 W1^T + b1)) ----
@@ -519,8 +537,9 @@ class LayerFn(torch.autograd.Function):
                 dh = ops.gemm(dx2m, rt.w(w2), b_kc=False, gate=h, gate_scale=inv_keep)   # (h > 0) <=> relu passed AND kept
                 dw1, db1 = _wbgrad(rt, w1, b1, dh, xn2)
                 dxn2 = ops.gemm(dh, rt.w(w1), b_kc=False)
-                dx1, dn2w, dn2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w.detach(), res=dx2,
-                                                    dgamma=rt.grad_out(n2w), dbeta=rt.grad_out(n2b))
+                with rt.deferring():
+                    dx1, dn2w, dn2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w.detach(), res=dx2,
+                                                        dgamma=rt.grad_out(n2w), dbeta=rt.grad_out(n2b))
             del dx2m
         # ---- conditioning adds ----
         dz = dl = dwg = dbg = dwg2 = dbg2 = None
@@ -552,8 +571,9 @@ class LayerFn(torch.autograd.Function):
         if live is not None:
             dx_full = torch.empty((full_rows, x.shape[1]), dtype=x.dtype, device=x.device)
             dx_out = dx_full[:x.shape[0]]
-        dx, dn1w, dn1b = ops.layernorm_bwd(dxn1, x, mean1, rstd1, n1w.detach(), res=dx1, dx=dx_out,
-                                           dgamma=rt.grad_out(n1w), dbeta=rt.grad_out(n1b))
+        with rt.deferring():
+            dx, dn1w, dn1b = ops.layernorm_bwd(dxn1, x, mean1, rstd1, n1w.detach(), res=dx1, dx=dx_out,
+                                               dgamma=rt.grad_out(n1w), dbeta=rt.grad_out(n1b))
         if live is not None:
             dx = dx_full
         return (None, dx, None, dz, dl, None, None, None, None, None,

@@ -418,7 +418,9 @@ class ParamStore:
         if key in self._in_flight:
             # a second backward node asks for this parameter's gradient before AccumulateGrad has consumed the first
             # one (two forwards + one backward, a weight used by two Functions): autograd SUMS the contributions, so
-            # they must not share memory - hand out a private tensor
+            # they must not share memory - hand out a private tensor.  (A trainer may have queued the reduction that
+            # fills the first one: autograd is about to read it.)
+            ops.flush_deferred()
             return torch.empty(param.shape, dtype=torch.float32, device=v.device)
         self._in_flight.add(key)
         # autograd accumulates into an existing .grad: never hand it a view that aliases that .grad
@@ -486,6 +488,9 @@ class SVGTransformer(nn.Module):
         self._forced_plan = None
         self._decoder_grads_ready = None    # callback of a data-parallel trainer (TrainStep), see forward()
         self._side_stream = None    # set by a trainer that calls join_side_stream() after backward (TrainStep)
+        # queue the parameter-gradient reductions of the backward pass (ops.DEFER): only a trainer that calls
+        # ops.flush_deferred() before anything reads a gradient may set it (TrainStep)
+        self._defer_wgrad = False
         self._rt = None
         self._live = None
 
@@ -524,7 +529,8 @@ class SVGTransformer(nn.Module):
         seed = self.seed_tensor(device) if training else None
         if training and self._own_seed:
             ops.advance_step_(None, seed)
-        self._rt = Fn.Runtime(self.compute_dtype, seed, self._store, training, side_stream=self._side_stream)
+        self._rt = Fn.Runtime(self.compute_dtype, seed, self._store, training, side_stream=self._side_stream,
+                              defer=self._defer_wgrad and not ops.PROFILE_ON)
         return self._rt
 
     # ---- blocks ----------------------------------------------------------------------------------

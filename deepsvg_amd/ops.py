@@ -66,7 +66,54 @@ def _stream():
 
 
 def _ws(nbytes, device):
-    return torch.empty(max(int(nbytes), 4) // 4 + 1, dtype=torch.float32, device=device)
+    t = torch.empty(max(int(nbytes), 4) // 4 + 1, dtype=torch.float32, device=device)
+    if _DEFER.depth:
+        _DEFER.keep.append(t)       # a queued reduction reads it at flush_deferred()
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# deferred parameter-gradient reductions (include/dsvg.h: dsvg_defer_scope / dsvg_flush_deferred)
+# ------------------------------------------------------------------------------------------------
+class _DeferScope:
+    """`with ops.DEFER:` - partial-sum reductions launched inside (split-K slices, LayerNorm gamma/beta partials, bias
+    column sums, embedding-table gradients) are queued; their outputs are valid after flush_deferred().  Only a caller
+    that owns the whole backward pass may open it (TrainStep): nothing may read those outputs in between."""
+    depth = 0
+    keep = []
+    post = []
+
+    def __enter__(self):
+        if _DeferScope.depth == 0:
+            _l.load().dsvg_defer_scope(1)
+        _DeferScope.depth += 1
+
+    def __exit__(self, *exc):
+        _DeferScope.depth -= 1
+        if _DeferScope.depth == 0:
+            _l.load().dsvg_defer_scope(0)
+        return False
+
+
+_DEFER = _DeferScope
+DEFER = _DeferScope()
+
+
+def defer_post(fn):
+    """run fn() right after the queued reductions at the next flush_deferred() (work that reads their outputs)"""
+    _DEFER.post.append(fn)
+
+
+def flush_deferred():
+    """perform every queued reduction (one launch per 64), then the work registered with defer_post"""
+    if not (_DEFER.keep or _DEFER.post):
+        return
+    if torch.cuda.is_available():
+        _l.check(_l.load().dsvg_flush_deferred(_stream()), "dsvg_flush_deferred")
+    post, _DEFER.post = _DEFER.post, []
+    for fn in post:
+        fn()
+    _DEFER.keep.clear()
 
 
 def _rowmajor(t):

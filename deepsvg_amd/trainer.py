@@ -52,6 +52,7 @@ class TrainStep:
         # weight-gradient GEMMs on a second stream: measured 2-4 % SLOWER on one MI355X (event fork/join per GEMM costs
         # more than the overlap with the small kernels of the group stages returns), so it is opt-in
         self.side_stream = os.environ.get("DSVG_SIDE_STREAM", "0") != "0"
+        self.defer_reductions = os.environ.get("DSVG_DEFER_REDUCE", "1") != "0"
         model._own_seed = False          # the trainer advances the dropout seed once per step
         if self.exact_global_mean:
             loss_fn.count_reducer = self._reduce_counts
@@ -80,6 +81,7 @@ class TrainStep:
         """called from the backward pass when every decoder gradient is final (model.forward registers the hook)"""
         lo, hi = self.model.decoder_param_range()
         self.model.join_side_stream()       # (opt-in) weight-gradient stream: its decoder work must be complete too
+        ops.flush_deferred()                # the queued split-K / LayerNorm reductions of the decoder's gradients
         flat_g = self.model.store.grad_buffer(0)
         self._pending = (lo, dist.all_reduce(flat_g[lo:hi], group=self.pg, async_op=True))
 
@@ -100,12 +102,18 @@ class TrainStep:
         self._pending = None
         if self.world > 1 and self.overlap_allreduce:
             model._decoder_grads_ready = self._launch_decoder_bucket    # hooked onto the bottleneck output in forward
+        # the ~130 partial-sum reductions of the parameter gradients (split-K slices, LayerNorm gamma/beta partials) are
+        # queued during backward and performed by ONE launch per 64 right after it (ops.flush_deferred): nothing reads a
+        # gradient in between (the overlapped decoder bucket flushes first, see _launch_decoder_bucket)
+        model._defer_wgrad = self.defer_reductions
         try:
             out = model(commands, args, cd, ad, label=label, params={})
             ld = self.loss_fn(out, label, weights=self.weights)
             ld["loss"].backward()
         finally:
             model._decoder_grads_ready = None
+            model._defer_wgrad = False
+            ops.flush_deferred()
         model.join_side_stream()        # weight gradients are computed on a second stream (functional.Runtime)
         flat_g = model.store.grad_buffer(0)
         # the norm / AdamW below read the WHOLE flat gradient buffer: a parameter that received no gradient in this step

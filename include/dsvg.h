@@ -75,6 +75,18 @@ int64_t dsvg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int dsvg_reduce_partials(const float* partial, int64_t P, int64_t n, float* out, int32_t accumulate,
                          void* stream);
 
+/* Deferred parameter-gradient reductions.  While a scope is open (dsvg_defer_scope(1) ... dsvg_defer_scope(0)) every
+ * partial-sum reduction issued by this library (split-K slices of dsvg_gemm, the gamma/beta partials of
+ * dsvg_layernorm_bwd, dsvg_colsum, dsvg_add_pos_bwd, dsvg_embed_scatter) whose data allows 16-byte accesses is queued
+ * instead of launched: its destination is NOT valid and its workspace must stay untouched until dsvg_flush_deferred,
+ * which performs all queued reductions in one launch per 64 of them (a backward pass of the benchmark model queues
+ * ~130: the per-reduction launches were 0.85 ms of a 10.5 ms step).  A reduction whose destination overlaps a queued
+ * one flushes the queue first, so write-after-write order is kept; reads of a queued destination are the caller's
+ * responsibility (deepsvg_amd/trainer.py flushes right after loss.backward(), the reference's train.py:98).
+ * dsvg_defer_scope returns the number of reductions currently queued. */
+int dsvg_defer_scope(int32_t on);
+int dsvg_flush_deferred(void* stream);
+
 /* out[n] (+)= sum_m drop(A[m*lda+n])  — bias gradients (autograd of the `+ b` in every nn.Linear).
  * workspace: at least dsvg_colsum_workspace_bytes(M,N) bytes. */
 int dsvg_colsum(int32_t dtype, const void* A, int64_t lda, int64_t M, int32_t N, float* out,

@@ -389,6 +389,36 @@ def test_greedy_sample_and_encode_decode(gpu_device):
     assert cy.shape == (4, 8, 31) and ay.shape == (4, 8, 31, 11)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_deferred_gradient_reductions_equal_immediate_ones(gpu_device, dtype, use_graph):
+    """TrainStep queues the ~130 partial-sum reductions of the parameter gradients and performs them in a few launches
+    after backward (ops.DEFER / flush_deferred); DSVG_DEFER_REDUCE=0 (ts.defer_reductions = False) launches them one by
+    one.  Same partial sums, another summation tree: the flat gradient must agree to fp32 rounding, the loss exactly."""
+    from deepsvg_amd.trainer import TrainStep
+    cfg = H.build_cfg("hier")
+    cfg.dropout = 0.1
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 77)
+    c, a = make_batch(640 if dtype == torch.bfloat16 else 48, seed=21)      # 640 icons: the fused FFN path (>= 16384 rows)
+    c, a = c.to(DEV), a.to(DEV)
+    runs = {}
+    for defer in (False, True):
+        torch.manual_seed(99)
+        model = _hip_model(cfg, sd, dtype).train()
+        ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=0.0, use_graph=use_graph)
+        ts.defer_reductions = defer
+        for _ in range(2):
+            ld = ts.step(c, a)
+        torch.cuda.synchronize()
+        runs[defer] = (float(ld["loss"]), model.store.grad_buffer(0).detach().clone(), ts.grad_norm())
+    assert runs[True][0] == runs[False][0]
+    g1, g0 = runs[True][1], runs[False][1]
+    assert torch.isfinite(g1).all() and g0.abs().max().item() > 0
+    err = (g1 - g0).abs().max().item()
+    assert err <= 3e-6 * g0.abs().max().item() + 1e-9, f"deferred vs immediate gradient: {err:.3e} (max |g| {g0.abs().max().item():.3e})"
+    assert abs(runs[True][2] - runs[False][2]) <= 1e-5 * runs[False][2]
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_self_matching_training_step(gpu_device, use_graph):
     """HierarchicalSelfMatching through TrainStep (costs + exhaustive assignment + row permutation have no host round
