@@ -521,8 +521,11 @@ class LayerFn(torch.autograd.Function):
                         ops.colsum(dpre, out=db1p)
                     dw1, db1, dw2 = rt.grad_out(w1), rt.grad_out(b1), rt.grad_out(w2)
                     dn2w, dn2b = rt.grad_out(n2w), rt.grad_out(n2b)
+                    # (aliases of the gradient tensors: AccumulateGrad adopts a returned gradient only while nobody else
+                    # holds a reference to that tensor object, otherwise it clones it - here before it is even written)
                     finish = functools.partial(ops.ffn_wgrad_finish, g1p, db1p, g2p, w1.detach(), n2w.detach(),
-                                               n2b.detach(), dw1, db1, dw2, dn2w, dn2b)
+                                               n2b.detach(), dw1.detach(), db1.detach(), dw2.detach(), dn2w.detach(),
+                                               dn2b.detach())
                     if rt.defer:
                         ops.defer_post(finish)      # reads the queued reductions' outputs: runs right after the flush
                     else:

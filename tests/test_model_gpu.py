@@ -399,18 +399,23 @@ def test_deferred_gradient_reductions_equal_immediate_ones(gpu_device, dtype, us
     cfg = H.build_cfg("hier")
     cfg.dropout = 0.1
     sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 77)
-    c, a = make_batch(640 if dtype == torch.bfloat16 else 48, seed=21)      # 640 icons: the fused FFN path (>= 16384 rows)
-    c, a = c.to(DEV), a.to(DEV)
+    n = 640 if dtype == torch.bfloat16 else 48          # 640 icons: the fused FFN path (>= 16384 rows)
+    batches = [tuple(t.to(DEV) for t in make_batch(n, seed=sd_)) for sd_ in (21, 22)]
     runs = {}
     for defer in (False, True):
         torch.manual_seed(99)
         model = _hip_model(cfg, sd, dtype).train()
         ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=0.0, use_graph=use_graph)
         ts.defer_reductions = defer
-        for _ in range(2):
+        for c, a in batches:            # (lr = 0 and two different batches: a stale gradient of step 1 would show)
             ld = ts.step(c, a)
         torch.cuda.synchronize()
-        runs[defer] = (float(ld["loss"]), model.store.grad_buffer(0).detach().clone(), ts.grad_norm())
+        flat = model.store.grad_buffer(0)
+        if not use_graph:
+            # every parameter's .grad is still the view of the flat buffer the kernels wrote into (no clone on the way)
+            for name, p in model.named_parameters():
+                assert p.grad is not None and p.grad.data_ptr() == model.store._grad_view(p, 0).data_ptr(), name
+        runs[defer] = (float(ld["loss"]), flat.detach().clone(), ts.grad_norm())
     assert runs[True][0] == runs[False][0]
     g1, g0 = runs[True][1], runs[False][1]
     assert torch.isfinite(g1).all() and g0.abs().max().item() > 0
