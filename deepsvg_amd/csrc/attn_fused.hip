@@ -1,0 +1,551 @@
+// Fused attention sub-block of the pre-LN transformer layers, d_model = 256, 8 heads of 32, sequences of at most 32
+// tokens, bf16 storage, fp32 accumulation and statistics:
+//     x1 = x + drop_r( Wo . MHA( LN(x) ) + bo ),   MHA = per-head softmax(q k^T * scale) with dropout on the probabilities
+// (deepsvg/model/layers/improved_transformer.py:43-46,127-131 with layers/attention.py / layers/functional.py:168,197-248).
+// One launch replaces LayerNorm + in_proj GEMM + attention + out_proj GEMM: q|k|v, the probabilities and the head outputs
+// stay on the chip; the inference call reads 512 B and writes 512 B per token.  The training call also stores what the
+// (unfused) backward pass reads: LN(x), q|k|v, the head outputs and the row statistics.
+//
+// Structure (same skeleton as ffn_fused.hip):
+//   * token-stationary waves: a wave owns ONE attention tile - up to 32 consecutive rows that hold whole sequences (the
+//     packed encoder layout of dsvg_attention_tiles: block-diagonal attention inside the tile; or one padded sequence of
+//     the dense layouts) - and keeps its LayerNorm-ed rows as 16 MFMA operand fragments in registers.  A 512-thread
+//     workgroup = 8 consecutive tiles.
+//   * the weights stream through an LDS ring of 32 KiB slots as ready-made MFMA A fragments (dsvg_attn_pack), 20 chunks per
+//     layer: per head h [Wq_h | Wk_h] (32 fragments) and [Wv_h] (16), then out_proj in 4 chunks of two 32-row blocks.
+//   * per head: q^T, k^T, v^T = W_frag x X_frag (transposed accumulators: lane = token, registers = head dims), + bias,
+//     -> bf16.  S^T = K Q^T takes the packed q / k registers directly as MFMA operands (K order = register order on both
+//     sides); softmax over the keys = 16 registers + one exchange with lane ^ 32; v^T goes through a 2.5 KiB per-wave
+//     staging tile and comes back as the A operand of O^T = V^T P^T by hardware-transposed LDS reads.  The packed head
+//     output is the B operand of out_proj, whose K index runs in that register order (dsvg_attn_pack lays Wo out so).
+//   * out_proj: per 32-row block of outputs 16 MFMAs over the 8 heads x 2 K steps, then bias, dropout (the library's
+//     standard draws: dsvg_drop_apply replays the mask for the backward pass), residual, bf16 stores (32 B per lane).
+//   * TRAIN: q, k, v, head output go through the staging tile so that every global store is a full 64-byte row segment;
+//     the stores of a stage are held in registers and issued right behind the next ring synchronisation (vmcnt counts
+//     stores, out of order with respect to loads: the only safe DMA wait is vmcnt(0), so stores need a stage to drain).
+#include "fused_common.h"
+#include "../../include/dsvg.h"
+
+typedef short shortx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int AD = 256;                 // d_model
+constexpr int AH = 8;                   // heads
+constexpr int SLOT = 32 * FRAG;         // ring slot = the largest chunk
+constexpr int N_CHUNK = 20;             // 8 x (qk, v) + 4 x out_proj
+constexpr int IMG_FRAGS = 512;          // 384 in_proj + 128 out_proj fragments per layer
+constexpr int TILES_PER_WG = 8;
+constexpr int VLD = 40;                 // row stride (elements) of the per-wave staging tile [32 tokens][32 dims]
+constexpr int SMALL_LDS = (768 + 256 + 256 + 256) * 4;      // in_proj bias | out_proj bias | gamma | beta
+constexpr int STAGE_LDS = TILES_PER_WG * 32 * VLD * 2;
+
+__host__ __device__ inline int rowmap(int r, int h2) { return (r & 3) + 8 * (r >> 2) + 4 * h2; }
+// byte offset of chunk c in the layer image; chunks 2 h + 1 (v of head h) have 16 fragments, all others 32
+__device__ __forceinline__ int chunk_off(int c) {
+    return c < 16 ? ((c >> 1) * 48 + (c & 1) * 32) * FRAG : (384 + (c - 16) * 32) * FRAG;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight packing: fp32 master parameters -> bf16 fragment images.  offs[layer][0..1] = element offsets of in_proj_weight
+// [768, 256] and out_proj.weight [256, 256] in `flat`.  Fragment f of a layer, lane l = (i = l & 31, half = l >> 5), slot e:
+//   f = 48 h + 16 sel + ks  (sel = 0 q, 1 k, 2 v):  Win[256 sel + 32 h + i][16 ks + 8 half + e]
+//   f = 384 + 16 t + 2 h + ks2:                      Wo[32 t + i][32 h + rowmap(8 ks2 + e, half)]
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict__ flat, const int64_t* __restrict__ offs,
+                                                        int n_layers, bf16_t* __restrict__ img) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)n_layers * IMG_FRAGS * 64) return;
+    const int layer = (int)(gid / (IMG_FRAGS * 64));
+    const int s = (int)(gid % (IMG_FRAGS * 64));
+    const int l = s & 63, f = s >> 6;
+    const int i = l & 31, half = l >> 5;
+    float v[8];
+    if (f < 384) {
+        const float* Win = flat + offs[layer * 2 + 0];
+        const int h = f / 48, g = f % 48, sel = g >> 4, ks = g & 15;
+        const float* row = Win + (size_t)(256 * sel + 32 * h + i) * AD + 16 * ks + 8 * half;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = row[e];
+    } else {
+        const float* Wo = flat + offs[layer * 2 + 1];
+        const int g = f - 384, t = g >> 4, h = (g & 15) >> 1, ks2 = g & 1;
+        const float* row = Wo + (size_t)(32 * t + i) * AD + 32 * h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = row[rowmap(8 * ks2 + e, half)];
+    }
+    *reinterpret_cast<uint4*>(img + ((size_t)layer * IMG_FRAGS + f) * 512 + l * 8) = pack8(v);
+}
+
+// A[i = column c (lane & 31)][K slot e] = img[row rowmap(8 ks + e, lane >> 5)][col0 + c]: two hardware-transposed 4 x 16
+// reads (the same access attention_mfma.hip uses for V^T)
+__device__ __forceinline__ bf16x8 col_frag(const bf16_t* img, int ld, int col0, int ks, int lane) {
+    const int g = lane >> 4, q16 = lane & 15;
+    const int row = 16 * ks + 4 * (g >> 1) + (q16 >> 2);
+    const int col = col0 + 16 * (g & 1) + 4 * (q16 & 3);
+    union { bf16x8 v; shortx4 h[2]; } f;
+    f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(&img[row * ld + col]));
+    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(&img[(row + 8) * ld + col]));
+    return f.v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NBUF, bool TRAIN, bool TILED>
+__global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
+        const bf16_t* __restrict__ x, const bf16_t* __restrict__ img, const float* __restrict__ in_bias,
+        const float* __restrict__ out_bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+        const uint64_t* __restrict__ key_mask, const int32_t* __restrict__ seq_off, const int32_t* __restrict__ tile_first,
+        int n_seq, int Smax, long long total_rows, bf16_t* __restrict__ x1, bf16_t* __restrict__ xn_out,
+        bf16_t* __restrict__ qkv_out, bf16_t* __restrict__ ao_out, float* __restrict__ mean_out,
+        float* __restrict__ rstd_out, float eps, float scale, float drop_p, const uint64_t* __restrict__ seed,
+        uint32_t site_p, uint32_t site_r) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];   // [NBUF slots | biases, gamma, beta | 8 staging tiles]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, h2 = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)DSVG_LDS_PTR(smem);
+    float* sbin = reinterpret_cast<float*>(smem + NBUF * SLOT);
+    float* sbo = sbin + 768;
+    float* sga = sbo + 256;
+    float* sbe = sga + 256;
+    bf16_t* stg = reinterpret_cast<bf16_t*>(smem + NBUF * SLOT + SMALL_LDS) + wave * (32 * VLD);
+
+    // ---- weight stream ---------------------------------------------------------------------------------------------------
+    const char* img_b = reinterpret_cast<const char*>(img) + lane * 16;
+    auto issue = [&](int c) {
+        const uint32_t slot = lds0 + (uint32_t)(c % NBUF) * SLOT;
+        const char* src = img_b + chunk_off(c);
+        if (c < 16 && (c & 1)) dma2(src + wave * 2048, __builtin_amdgcn_readfirstlane(slot + wave * 2048));
+        else dma4(src + wave * 4096, __builtin_amdgcn_readfirstlane(slot + wave * 4096));
+    };
+    constexpr int DIST = 2;
+    issue(0);
+    issue(1);
+
+    for (int i = tid; i < 768; i += 512) sbin[i] = in_bias[i];
+    if (tid < 256) { sbo[tid] = out_bias[tid]; sga[tid] = gamma[tid]; sbe[tid] = beta[tid]; }
+
+    // ---- this wave's tile: rows [row0, row0 + S) ----------------------------------------------------------------------------
+    const int b = blockIdx.x * TILES_PER_WG + wave;
+    const int n_tiles = TILED ? tile_first[n_seq + 1] : n_seq;
+    const long long real_rows = TILED ? (long long)seq_off[n_seq] : (long long)n_seq * Smax;
+    long long row0 = 0;
+    int S = 0, s_first = 0, n_in = 1;
+    bool pad_tile = false;
+    if (b < n_tiles) {
+        if (TILED) {
+            s_first = tile_first[b];
+            n_in = tile_first[b + 1] - s_first;
+            row0 = seq_off[s_first];
+            S = seq_off[s_first + n_in] - (int)row0;
+        } else {
+            s_first = b;
+            row0 = (long long)b * Smax;
+            S = Smax;
+        }
+    } else {        // rows past the last sequence (bucket padding): tiles of 32 rows that attend to themselves only
+        pad_tile = true;
+        row0 = real_rows + 32ll * (b - n_tiles);
+        const long long left = total_rows - row0;
+        S = left > 32 ? 32 : (left > 0 ? (int)left : 0);
+    }
+    S = __builtin_amdgcn_readfirstlane(S);
+    if (__syncthreads_count(S > 0) == 0) {          // (also publishes the staged biases)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    // the lane's query row: its sequence, the first row of that sequence inside the tile and its length
+    int my_seq = s_first, my_start = 0, my_len = S;
+    if (pad_tile) {
+        my_start = li;
+        my_len = 1;
+    } else if (TILED) {
+        const int so = seq_off[s_first + min(lane, n_in)];       // lanes 0 .. n_in (<= 32) hold the tile's offsets
+        int qi = 0;
+        for (int q = 1; q < n_in; ++q)
+            if (row0 + li >= __shfl(so, q, 64)) qi = q;
+        const int a0 = __shfl(so, qi, 64), a1 = __shfl(so, qi + 1, 64);
+        my_seq = s_first + qi;
+        my_start = a0 - (int)row0;
+        my_len = a1 - a0;
+    }
+    uint32_t km;
+    if (TILED || pad_tile) km = (uint32_t)(((1ull << my_len) - 1ull) << my_start);
+    else km = (key_mask ? (uint32_t)key_mask[b] : ~0u) & (uint32_t)((1ull << S) - 1ull);
+    const bool row_live = li < S;
+    long long my_row = row0 + (S > 0 ? min(li, S - 1) : 0);     // rows past S: a clamped copy, computed but never stored
+    if (S <= 0 || my_row >= total_rows) my_row = 0;
+
+    // ---- LayerNorm in registers -> 16 operand fragments ----------------------------------------------------------------
+    bf16x8 xf[16];
+    {
+        const char* xr = reinterpret_cast<const char*>(x) + (size_t)my_row * (AD * 2) + h2 * 16;
+        uint4 raw[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) raw[ks] = *reinterpret_cast<const uint4*>(xr + 32 * ks);
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            float v[8];
+            unpack8(raw[ks], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[e];
+        }
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.f / AD);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            float v[8];
+            unpack8(raw[ks], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; ss += d * d; }
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        const float rstd = rsqrtf(ss * (1.f / AD) + eps);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
+        char* xo = TRAIN ? reinterpret_cast<char*>(xn_out) + (size_t)my_row * (AD * 2) + h2 * 16 : nullptr;
+        const bool st = TRAIN && row_live;
+        if (st && h2 == 0) { mean_out[my_row] = mean; rstd_out[my_row] = rstd; }
+        // gamma / beta come from LDS one K step at a time: `zoff` (always 0) is made to depend on the previous step's result,
+        // otherwise hipcc hoists all 64 reads (256 registers) above the loop and spills the prologue
+        int zoff = 8 * h2;
+        asm volatile("" : "+v"(zoff));
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            float v[8];
+            unpack8(raw[ks], v);
+            const float4 g0 = *reinterpret_cast<const float4*>(sga + 16 * ks + zoff);
+            const float4 g1 = *reinterpret_cast<const float4*>(sga + 16 * ks + zoff + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(sbe + 16 * ks + zoff);
+            const float4 b1 = *reinterpret_cast<const float4*>(sbe + 16 * ks + zoff + 4);
+            v[0] = (v[0] - mean) * rstd * g0.x + b0.x; v[1] = (v[1] - mean) * rstd * g0.y + b0.y;
+            v[2] = (v[2] - mean) * rstd * g0.z + b0.z; v[3] = (v[3] - mean) * rstd * g0.w + b0.w;
+            v[4] = (v[4] - mean) * rstd * g1.x + b1.x; v[5] = (v[5] - mean) * rstd * g1.y + b1.y;
+            v[6] = (v[6] - mean) * rstd * g1.z + b1.z; v[7] = (v[7] - mean) * rstd * g1.w + b1.w;
+            Frag8 f;
+            f.u = pack8(v);
+            xf[ks] = f.v;
+            if (st) *reinterpret_cast<uint4*>(xo + 32 * ks) = f.u;
+            asm volatile("" : "+v"(zoff) : "v"(f.u.x) : "memory");
+        }
+    }
+
+    __builtin_amdgcn_sched_barrier(0);      // (the zeroed operand queue below must not be hoisted above the LayerNorm)
+    const DropCtx dp = drop_make(drop_p, seed, site_p);
+    const DropCtx dr = drop_make(drop_p, seed, site_r);
+    const char* lbase = smem + lane * 16;
+    auto ld = [&](const char* p) -> uint4 { return *reinterpret_cast<const uint4*>(p); };
+
+    // TRAIN: row segments waiting for their store slot (issued right behind the next sync point)
+    // (a lane owns the 16-byte pieces `lane` and `lane + 64` of a staged 32 x 32 tile: token piece >> 2, dims 8 (piece & 3) ..)
+    uint4 pa0, pa1, pb0, pb1;       // (named registers: as an array they end up in scratch memory)
+    pa0 = pa1 = pb0 = pb1 = make_uint4(0u, 0u, 0u, 0u);
+    const bool ok0 = TRAIN && (lane >> 2) < S, ok1 = TRAIN && (lane >> 2) + 16 < S;
+    char* qb = TRAIN ? reinterpret_cast<char*>(qkv_out) + ((size_t)(row0 + (lane >> 2)) * (3 * AD) + 8 * (lane & 3)) * 2 : nullptr;
+    char* ab = TRAIN ? reinterpret_cast<char*>(ao_out) + ((size_t)(row0 + (lane >> 2)) * AD + 8 * (lane & 3)) * 2 : nullptr;
+    // sync(k): chunk k is readable afterwards, chunk k + 2 on its way; behind it the stores of the stage before: k odd = the
+    // q | k tiles of head (k - 1) / 2, k even (2 .. 16) = the v and head-output tiles of head k / 2 - 1
+    auto sync = [&](int k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (k + DIST < N_CHUNK) issue(k + DIST);
+        if (TRAIN && k >= 1 && k <= 16) {
+            const int hp = (k - 1) >> 1;
+            char* d0 = (k & 1) ? qb + 64 * hp : qb + 4 * AD + 64 * hp;
+            char* d1 = (k & 1) ? qb + 2 * AD + 64 * hp : ab + 64 * hp;
+            const int far0 = 16 * 3 * AD * 2, far1 = (k & 1) ? 16 * 3 * AD * 2 : 16 * AD * 2;
+            if (ok0) { *reinterpret_cast<uint4*>(d0) = pa0; *reinterpret_cast<uint4*>(d1) = pb0; }
+            if (ok1) { *reinterpret_cast<uint4*>(d0 + far0) = pa1; *reinterpret_cast<uint4*>(d1 + far1) = pb1; }
+        }
+    };
+    // the packed 32 x 32 tile (lane: token li, dims 8 g + 4 h2 + 0..3 as piece g) -> staging tile [token][dim]
+    auto stage_put = [&](const Frag8 (&f)[2]) {
+        asm volatile("" ::: "memory");      // (one wave, in-order LDS: only the compiler must keep put / take / col_frag in order)
+        *reinterpret_cast<uint2*>(&stg[li * VLD + 0 + 4 * h2]) = make_uint2(f[0].u.x, f[0].u.y);
+        *reinterpret_cast<uint2*>(&stg[li * VLD + 8 + 4 * h2]) = make_uint2(f[0].u.z, f[0].u.w);
+        *reinterpret_cast<uint2*>(&stg[li * VLD + 16 + 4 * h2]) = make_uint2(f[1].u.x, f[1].u.y);
+        *reinterpret_cast<uint2*>(&stg[li * VLD + 24 + 4 * h2]) = make_uint2(f[1].u.z, f[1].u.w);
+        asm volatile("" ::: "memory");
+    };
+    // staging tile -> two pending 16-byte row pieces per lane: token (lane + 64 j) >> 2, dims 8 ((lane + 64 j) & 3) ..
+    auto stage_take = [&](uint4& near, uint4& far) {
+        near = *reinterpret_cast<const uint4*>(&stg[(lane >> 2) * VLD + 8 * (lane & 3)]);
+        far = *reinterpret_cast<const uint4*>(&stg[((lane >> 2) + 16) * VLD + 8 * (lane & 3)]);
+    };
+
+    bf16x8 aof[16];         // the out_proj operand queue: every head shifts it by two fragments and appends its own
+
+    // ---- heads -----------------------------------------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int h = 0; h < AH; ++h) {
+        sync(2 * h);
+        Frag8 qf[2], kf[2];
+        {
+            const char* sl = lbase + ((2 * h) % NBUF) * SLOT;
+            floatx16 qa, ka;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { qa[r] = 0.f; ka[r] = 0.f; }
+            uint4 ring[4];
+            // consumption order q0 k0 q1 k1 ...: fragment of step n = 16 (n & 1) + (n >> 1)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) ring[n] = ld(sl + (16 * (n & 1) + (n >> 1)) * FRAG);
+#pragma unroll
+            for (int n = 0; n < 32; ++n) {
+                Frag8 a;
+                a.u = ring[n & 3];
+                if (n & 1) ka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, xf[n >> 1], ka, 0, 0, 0);
+                else qa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, xf[n >> 1], qa, 0, 0, 0);
+                if (n + 4 < 32) ring[n & 3] = ld(sl + (16 * ((n + 4) & 1) + ((n + 4) >> 1)) * FRAG);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                float vq[8], vk[8];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q4 = 2 * ks2 + qq;
+                    const float4 bq = *reinterpret_cast<const float4*>(sbin + 32 * h + 8 * q4 + 4 * h2);
+                    const float4 bk = *reinterpret_cast<const float4*>(sbin + 256 + 32 * h + 8 * q4 + 4 * h2);
+                    vq[4 * qq + 0] = qa[4 * q4 + 0] + bq.x; vq[4 * qq + 1] = qa[4 * q4 + 1] + bq.y;
+                    vq[4 * qq + 2] = qa[4 * q4 + 2] + bq.z; vq[4 * qq + 3] = qa[4 * q4 + 3] + bq.w;
+                    vk[4 * qq + 0] = ka[4 * q4 + 0] + bk.x; vk[4 * qq + 1] = ka[4 * q4 + 1] + bk.y;
+                    vk[4 * qq + 2] = ka[4 * q4 + 2] + bk.z; vk[4 * qq + 3] = ka[4 * q4 + 3] + bk.w;
+                }
+                qf[ks2].u = pack8(vq);
+                kf[ks2].u = pack8(vk);
+            }
+            if (TRAIN) {
+                stage_put(qf);
+                stage_take(pa0, pa1);
+                stage_put(kf);
+                stage_take(pb0, pb1);
+            }
+        }
+        sync(2 * h + 1);
+        {
+            const char* sl = lbase + ((2 * h + 1) % NBUF) * SLOT;
+            // scores first (their operands are in registers): st[r] = q_li . k_key(r, h2)
+            floatx16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0].v, qf[0].v, st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1].v, qf[1].v, st, 0, 0, 0);
+            floatx16 va;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) va[r] = 0.f;
+            uint4 ring[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) ring[n] = ld(sl + n * FRAG);
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                Frag8 a;
+                a.u = ring[n & 3];
+                va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, xf[n], va, 0, 0, 0);
+                if (n + 4 < 16) ring[n & 3] = ld(sl + (n + 4) * FRAG);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // softmax over the keys of the lane's query row
+            float p[16];
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = rowmap(r, h2);
+                p[r] = ((km >> key) & 1u) ? st[r] * scale : -INFINITY;
+                m = fmaxf(m, p[r]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = (p[r] == -INFINITY) ? 0.f : __expf(p[r] - m);
+                l += p[r];
+            }
+            l += __shfl_xor(l, 32, 64);
+            const float inv = 1.f / l;
+            // element id of (query i, key j) of sequence s: ((s H + h) Smax + i) Smax + j, i and j counted inside the sequence
+            const uint64_t ebase = (((uint64_t)my_seq * AH + h) * Smax + (li - my_start)) * Smax - my_start;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = p[r] * inv * drop_mult(dp, ebase + rowmap(r, h2));
+            if (!row_live) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] = 0.f;     // padded query row: keep the NaNs of an all-masked row out of the MFMA
+            }
+            // v^T + bias -> staging tile (token-major), read back transposed as the A operand of O^T = V^T P^T
+            Frag8 vf[2];
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                float vv[8];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q4 = 2 * ks2 + qq;
+                    const float4 bv = *reinterpret_cast<const float4*>(sbin + 512 + 32 * h + 8 * q4 + 4 * h2);
+                    vv[4 * qq + 0] = va[4 * q4 + 0] + bv.x; vv[4 * qq + 1] = va[4 * q4 + 1] + bv.y;
+                    vv[4 * qq + 2] = va[4 * q4 + 2] + bv.z; vv[4 * qq + 3] = va[4 * q4 + 3] + bv.w;
+                }
+                vf[ks2].u = pack8(vv);
+            }
+            stage_put(vf);
+            if (TRAIN) stage_take(pa0, pa1);
+            floatx16 ot;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag8 pf;
+                pf.u = make_uint4(f2bf_pk(p[8 * ks + 0], p[8 * ks + 1]), f2bf_pk(p[8 * ks + 2], p[8 * ks + 3]),
+                                  f2bf_pk(p[8 * ks + 4], p[8 * ks + 5]), f2bf_pk(p[8 * ks + 6], p[8 * ks + 7]));
+                ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(stg, VLD, 0, ks, lane), pf.v, ot, 0, 0, 0);
+            }
+            // ot[r] = O[token li][dim rowmap(r, h2)] -> packed, appended to the out_proj operand queue (oldest head first)
+            Frag8 of[2];
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                float vo[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vo[e] = ot[8 * ks2 + e];
+                of[ks2].u = pack8(vo);
+            }
+#pragma unroll
+            for (int i = 0; i < 14; ++i) aof[i] = aof[i + 2];
+            aof[14] = of[0].v;
+            aof[15] = of[1].v;
+            if (TRAIN) {
+                stage_put(of);
+                stage_take(pb0, pb1);
+            }
+        }
+    }
+
+    // ---- out_proj: two 32-row blocks of outputs per chunk, + bias, dropout, residual ---------------------------------------------
+    const long long m = row0 + li;
+    const char* xres = reinterpret_cast<const char*>(x) + (size_t)my_row * (AD * 2);
+    char* yrow = reinterpret_cast<char*>(x1) + (size_t)my_row * (AD * 2);
+#pragma unroll 1
+    for (int u = 0; u < 4; ++u) {
+        sync(16 + u);
+        const char* sl = lbase + ((16 + u) % NBUF) * SLOT;
+        uint4 res[4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            res[2 * tt] = *reinterpret_cast<const uint4*>(xres + (32 * (2 * u + tt) + 16 * h2) * 2);
+            res[2 * tt + 1] = *reinterpret_cast<const uint4*>(xres + (32 * (2 * u + tt) + 16 * h2 + 8) * 2);
+        }
+        floatx16 ya[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ya[0][r] = 0.f; ya[1][r] = 0.f; }
+        uint4 ring[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) ring[n] = ld(sl + (16 * (n & 1) + (n >> 1)) * FRAG);
+#pragma unroll
+        for (int n = 0; n < 32; ++n) {
+            Frag8 a;
+            a.u = ring[n & 3];
+            ya[n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, aof[n >> 1], ya[n & 1], 0, 0, 0);
+            if (n + 4 < 32) ring[n & 3] = ld(sl + (16 * ((n + 4) & 1) + ((n + 4) >> 1)) * FRAG);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            uint32_t xc[4][4];
+            tile_to_cols16(ya[tt], xc);
+            const int n16 = 32 * (2 * u + tt) + 16 * h2;
+            uint4 pk[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                float v[8], rv[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(xc[2 * cb][e]); v[4 + e] = __uint_as_float(xc[2 * cb + 1][e]); }
+                const float4 b0 = *reinterpret_cast<const float4*>(sbo + n16 + 8 * cb);
+                const float4 b1 = *reinterpret_cast<const float4*>(sbo + n16 + 8 * cb + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                if (dr.on) {
+                    float dm[8];
+                    drop_mult8(dr, (uint64_t)m * AD + n16 + 8 * cb, dm);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= dm[e];
+                }
+                unpack8(res[2 * tt + cb], rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                pk[cb] = pack8(v);
+            }
+            if (row_live) {
+                *reinterpret_cast<uint4*>(yrow + n16 * 2) = pk[0];
+                *reinterpret_cast<uint4*>(yrow + n16 * 2 + 16) = pk[1];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int64_t dsvg_attn_pack_bytes(int32_t n_layers) { return (int64_t)n_layers * IMG_FRAGS * FRAG; }
+
+extern "C" int dsvg_attn_pack(const float* flat_f32, const int64_t* offs, int32_t n_layers, int32_t d_model, int32_t n_heads,
+                              void* packed, void* stream) {
+    DSVG_CHECK_ARG(flat_f32 && offs && packed, "attn_pack: null pointer");
+    DSVG_CHECK_ARG(d_model == AD && n_heads == AH, "attn_pack: the fused attention block is built for d_model 256 / 8 heads");
+    DSVG_CHECK_ARG(n_layers > 0, "attn_pack: bad layer count");
+    const long long n = (long long)n_layers * IMG_FRAGS * 64;
+    hipLaunchKernelGGL(attn_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat_f32, offs,
+                       n_layers, (bf16_t*)packed);
+    DSVG_LAUNCH_CHECK("attn_pack");
+    return 0;
+}
+
+extern "C" int dsvg_attn_block_fwd(const void* x, const void* packed_layer, const float* in_bias, const float* out_bias,
+                                   const float* gamma, const float* beta, const uint64_t* key_mask, const int32_t* seq_off,
+                                   const int32_t* tile_first, int64_t n_seq, int32_t S, int64_t rows, void* x1, void* xn_out,
+                                   void* qkv_out, void* ao_out, float* mean_out, float* rstd_out, float eps, float scale,
+                                   float drop_p, uint32_t site_probs, uint32_t site_res, const void* seed, void* stream) {
+    DSVG_CHECK_ARG(x && packed_layer && in_bias && out_bias && gamma && beta && x1, "attn_block_fwd: null pointer");
+    DSVG_CHECK_ARG(S >= 1 && S <= 32, "attn_block_fwd: sequences of at most 32 tokens (got %d)", S);
+    DSVG_CHECK_ARG(n_seq > 0 && rows > 0 && rows < (1ll << 31), "attn_block_fwd: bad sizes");
+    DSVG_CHECK_ARG(!(drop_p > 0.f) || seed, "attn_block_fwd: dropout needs a seed");
+    const bool tiled = seq_off != nullptr;
+    DSVG_CHECK_ARG(!tiled || (tile_first && !key_mask), "attn_block_fwd: the packed layout needs its tile list and no key mask");
+    DSVG_CHECK_ARG(tiled || rows >= n_seq * S, "attn_block_fwd: %lld rows for %lld sequences of %d", (long long)rows,
+                   (long long)n_seq, S);
+    const bool train = xn_out != nullptr;
+    DSVG_CHECK_ARG(!train || (qkv_out && ao_out && mean_out && rstd_out), "attn_block_fwd: the training outputs come together");
+    DSVG_CHECK_ARG((((uintptr_t)x | (uintptr_t)x1 | (uintptr_t)packed_layer | (uintptr_t)xn_out | (uintptr_t)qkv_out |
+                     (uintptr_t)ao_out) & 15) == 0, "attn_block_fwd: operands must be 16-byte aligned");
+    // waves: one per attention tile + one per 32 rows of bucket padding behind the last sequence.  Adjacent tiles of the
+    // packed layout hold more than 32 rows together, so there are at most rows / 16 + 1 of them (and at most n_seq)
+    long long waves;
+    if (tiled) {
+        const long long a = n_seq + (rows + 31) / 32, b = rows / 16 + 2;
+        waves = a < b ? a : b;
+    } else {
+        waves = n_seq + (rows - n_seq * S + 31) / 32;
+    }
+    const int nb = (int)((waves + TILES_PER_WG - 1) / TILES_PER_WG);
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int NB = 3;
+    const size_t lds = (size_t)NB * SLOT + SMALL_LDS + STAGE_LDS;
+#define DSVG_ATTN_FWD(TR, TI)                                                                                          \
+    do {                                                                                                               \
+        DSVG_ENSURE_LDS((attn_block_fwd_kernel<NB, TR, TI>), lds);                                                     \
+        hipLaunchKernelGGL((attn_block_fwd_kernel<NB, TR, TI>), dim3(nb), dim3(512), lds, st, (const bf16_t*)x,        \
+                           (const bf16_t*)packed_layer, in_bias, out_bias, gamma, beta, key_mask, seq_off, tile_first, \
+                           (int)n_seq, (int)S, (long long)rows, (bf16_t*)x1, (bf16_t*)xn_out, (bf16_t*)qkv_out,        \
+                           (bf16_t*)ao_out, mean_out, rstd_out, eps, scale, drop_p, (const uint64_t*)seed, site_probs, \
+                           site_res);                                                                                  \
+    } while (0)
+    if (train) { if (tiled) DSVG_ATTN_FWD(true, true); else DSVG_ATTN_FWD(true, false); }
+    else { if (tiled) DSVG_ATTN_FWD(false, true); else DSVG_ATTN_FWD(false, false); }
+#undef DSVG_ATTN_FWD
+    DSVG_LAUNCH_CHECK("attn_block_fwd");
+    return 0;
+}

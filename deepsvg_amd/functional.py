@@ -27,6 +27,8 @@ FFN_BWD_FUSED = os.environ.get("DSVG_FFN_BWD_FUSED", "0") != "0"
 # the fused FFN kernels own 256 token rows per workgroup: below ~16k rows they cannot fill the 256 CUs and the three
 # unfused launches are faster (measured: 4096 rows 39-50 us fused vs 33 us unfused; 41k rows 56 vs 71 us)
 FFN_MIN_ROWS = int(os.environ.get("DSVG_FFN_MIN_ROWS", "16384"))
+# the fused attention block owns 8 tiles of <= 32 rows per workgroup (same granularity: unfused launches below this)
+ATTN_MIN_ROWS = int(os.environ.get("DSVG_ATTN_MIN_ROWS", "16384"))
 
 
 _NULL_CTX = contextlib.nullcontext()
@@ -431,15 +433,31 @@ class LayerFn(torch.autograd.Function):
         p = rt.p(drop_rate)
         d = x.shape[1]
         scale = float(d // n_heads) ** -0.5
-        xn1, mean1, rstd1 = ops.layernorm_fwd(x, n1w.detach(), n1b.detach())
-        qkv = ops.gemm(xn1, rt.w(win), bias=bin_.detach())
-        if causal:
-            ao = ops.attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, p, site0, rt.seed, causal=True)
+        want_bwd = any(ctx.needs_input_grad)         # (grad mode itself is off inside Function.forward)
+        att = None
+        if (rt.store is not None and x.dtype == torch.bfloat16 and x.shape[0] >= ATTN_MIN_ROWS and S <= 32 and not causal
+                and n_heads == 8 and d == 256 and (seq_off is None or tiles is not None)
+                and (key_mask is None or key_mask.dtype == torch.int64)):
+            att = rt.store.attn(win)
+        if att is not None:
+            # one launch: LayerNorm, in_proj, the 8 heads, out_proj, dropout, residual (csrc/attn_fused.hip).  With a
+            # backward pass ahead it also stores LN(x), q|k|v, the head outputs and the row statistics
+            res = ops.attn_block_fwd(x, att, bin_.detach(), bo.detach(), n1w.detach(), n1b.detach(), key_mask, n_seq, S,
+                                     scale, 1e-5, p, site0, site0 + 1, rt.seed, seq_off=seq_off, tiles=tiles, train=want_bwd)
+            if want_bwd:
+                x1, xn1, qkv, ao, mean1, rstd1 = res
+            else:
+                x1, xn1, qkv, ao, mean1, rstd1 = res, None, None, None, None, None
         else:
-            ao = ops.attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, p, site0, rt.seed, seq_off=seq_off,
-                                   tiles=tiles)
+            xn1, mean1, rstd1 = ops.layernorm_fwd(x, n1w.detach(), n1b.detach())
+            qkv = ops.gemm(xn1, rt.w(win), bias=bin_.detach())
+            if causal:
+                ao = ops.attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, p, site0, rt.seed, causal=True)
+            else:
+                ao = ops.attention_fwd(qkv, key_mask, n_seq, S, n_heads, scale, p, site0, rt.seed, seq_off=seq_off,
+                                       tiles=tiles)
+            x1 = ops.gemm(ao, rt.w(wo), bias=bo.detach(), res=x, drop_p=p, drop_site=site0 + 1, seed=rt.seed)
         ctx.tiles, ctx.causal = tiles, causal
-        x1 = ops.gemm(ao, rt.w(wo), bias=bo.detach(), res=x, drop_p=p, drop_site=site0 + 1, seed=rt.seed)
         if z is not None:
             g = ops.gemm(z, rt.w(wg), bias=bg.detach())
             ops.bcast_add_fwd_(x1, g, n_seq, S, p, site0 + 2, rt.seed)
@@ -453,7 +471,6 @@ class LayerFn(torch.autograd.Function):
             # (csrc/ffn_fused.hip).  With a backward pass ahead it also stores h (fragment-ordered columns) and the
             # normalised rows xh; the inference call stores nothing but the result.
             mean2 = rstd2 = None
-            want_bwd = any(ctx.needs_input_grad)         # (grad mode itself is off inside Function.forward)
             with ops.tag("ffn"):
                 if want_bwd and not FFN_BWD_FUSED:
                     x2, h, xn2, _rstd = ops.ffn_fwd(x1, ffn[0], ffn[2], b2.detach(), 1e-5, p, site0 + 3, site0 + 4, rt.seed,

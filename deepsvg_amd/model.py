@@ -273,6 +273,7 @@ class ParamStore:
         self._in_flight = set()  # id(param): its slot of gbuf[0] was handed to a backward node, not yet accumulated
         self._hooks = []
         self._ffn = None         # fused-FFN weight images (see _ffn_setup)
+        self._attn = None        # fused attention-block weight images (see _attn_setup)
 
     # a copied / unpickled module gets an empty store that re-flattens lazily on its first forward: the index is keyed
     # by id(param) and the views point into THIS module's buffers (copy.deepcopy(model) for EMA / best-model snapshots,
@@ -308,6 +309,7 @@ class ParamStore:
         self._grad_views = [{}, {}]
         self._in_flight = set()
         self._ffn_setup(device)
+        self._attn_setup(device)
         for h in self._hooks:
             h.remove()
         # a slot of the flat gradient buffer is free again once AccumulateGrad has consumed it (see grad_view)
@@ -343,6 +345,41 @@ class ParamStore:
                          bwd=torch.empty(n * ops.FFN_BWD_LAYER_ELEMS, dtype=torch.bfloat16, device=device),
                          b1f=torch.empty((n, 512), dtype=torch.float32, device=device),
                          w2p=torch.empty((n, 256, 512), dtype=torch.bfloat16, device=device))
+
+    def _attn_setup(self, device):
+        """transformer layers whose attention sub-block fits the fused bf16 kernel (d_model 256, 8 heads;
+        csrc/attn_fused.hip): offsets of (in_proj_weight, out_proj.weight) in the flat buffer and the buffer of the packed
+        weight images (filled by ensure() on every forward)"""
+        self._attn = None
+        if os.environ.get("DSVG_ATTN_FUSED", "1") == "0":
+            return
+        rows, index = [], {}
+        for m in self.module.modules():
+            w_in, op = getattr(m, "in_proj_weight", None), getattr(m, "out_proj", None)
+            if not (isinstance(w_in, nn.Parameter) and isinstance(op, nn.Linear)):
+                continue
+            if tuple(w_in.shape) != (768, 256) or tuple(op.weight.shape) != (256, 256):
+                continue
+            if id(w_in) not in self.index or id(op.weight) not in self.index:
+                continue
+            index[id(w_in)] = len(rows)
+            rows.append([self.index[id(w_in)][0], self.index[id(op.weight)][0]])
+        if not rows:
+            return
+        n = len(rows)
+        self._attn = dict(n=n, index=index, offs=torch.tensor(rows, dtype=torch.int64, device=device),
+                          img=torch.empty(n * ops.ATTN_LAYER_ELEMS, dtype=torch.bfloat16, device=device))
+
+    def attn(self, w_in):
+        """packed in_proj / out_proj image of the layer whose in_proj_weight is w_in, or None when that layer does not run
+        on the fused attention kernel"""
+        a = self._attn
+        if a is None or self.flat_lp is None or self.flat_lp.dtype != torch.bfloat16:
+            return None
+        i = a["index"].get(id(w_in))
+        if i is None:
+            return None
+        return a["img"][i * ops.ATTN_LAYER_ELEMS:(i + 1) * ops.ATTN_LAYER_ELEMS]
 
     def ffn(self, w1):
         """(packed forward image, packed backward image, folded linear1 bias, linear2.weight with fragment-ordered
@@ -381,6 +418,9 @@ class ParamStore:
             if dtype == torch.bfloat16 and self._ffn is not None:
                 f = self._ffn
                 ops.ffn_pack(self.flat, f["offs"], f["n"], f["fwd"], f["bwd"], f["b1f"], f["w2p"])
+            if dtype == torch.bfloat16 and self._attn is not None:
+                a = self._attn
+                ops.attn_pack(self.flat, a["offs"], a["n"], a["img"])
 
     def lp(self, param):
         v = self._lp_views.get(id(param))

@@ -901,6 +901,58 @@ def ffn_wgrad_finish(g1p, db1p, g2p, w1, gamma, beta, dw1, db1, dw2, dgamma, dbe
     _prof_end(ev, 0.0, 0.0, dict(op="ffn_wgrad_finish"))
 
 
+# ------------------------------------------------------------------------------------------------
+# fused attention sub-block (csrc/attn_fused.hip)
+# ------------------------------------------------------------------------------------------------
+ATTN_LAYER_ELEMS = 512 * 512        # bf16 elements of one layer's packed in_proj + out_proj image (512 KiB)
+
+
+def attn_pack(flat, offs, n_layers, packed=None):
+    """bf16 MFMA-fragment images of in_proj_weight / out_proj.weight of n_layers layers from the fp32 master buffer
+    (include/dsvg.h).  offs: int64 device tensor [n_layers, 2] of element offsets (in_proj_weight, out_proj.weight)."""
+    _chk(flat, offs, packed)
+    assert flat.dtype == torch.float32 and offs.dtype == torch.int64 and tuple(offs.shape) == (n_layers, 2)
+    assert offs.is_contiguous()
+    if packed is None:
+        packed = torch.empty(n_layers * ATTN_LAYER_ELEMS, dtype=torch.bfloat16, device=flat.device)
+    assert packed.numel() == n_layers * ATTN_LAYER_ELEMS and packed.dtype == torch.bfloat16
+    _l.check(_l.load().dsvg_attn_pack(flat.data_ptr(), offs.data_ptr(), n_layers, 256, 8, packed.data_ptr(), _stream()),
+             "dsvg_attn_pack")
+    return packed
+
+
+def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_seq, S, scale, eps=1e-5, drop_p=0.0,
+                   site_probs=0, site_res=0, seed=None, seq_off=None, tiles=None, train=False):
+    """x1 = x + drop_r(out_proj(MHA(LayerNorm(x))))  (x bf16 [rows, 256], 8 heads, S <= 32) in one launch.
+    train=False -> x1;  train=True -> (x1, xn, qkv, ao, mean, rstd): what the unfused backward reads."""
+    _chk(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, seed, seq_off, tiles)
+    rows = x.shape[0]
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[1] == 256
+    assert packed_layer.numel() == ATTN_LAYER_ELEMS and packed_layer.is_contiguous()
+    assert in_bias.numel() == 768 and out_bias.numel() == 256 and gamma.numel() == 256 and beta.numel() == 256
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in (in_bias, out_bias, gamma, beta))
+    assert (seq_off is None) == (tiles is None) and (seq_off is None or key_mask is None)
+    x1 = torch.empty_like(x)
+    xn = qkv = ao = mean = rstd = None
+    if train:
+        xn = torch.empty_like(x)
+        qkv = torch.empty((rows, 768), dtype=x.dtype, device=x.device)
+        ao = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    ev = _prof_begin()
+    _l.check(_l.load().dsvg_attn_block_fwd(x.data_ptr(), packed_layer.data_ptr(), in_bias.data_ptr(), out_bias.data_ptr(),
+                                           gamma.data_ptr(), beta.data_ptr(), _p(key_mask), _p(seq_off), _p(tiles), n_seq,
+                                           S, rows, x1.data_ptr(), _p(xn), _p(qkv), _p(ao), _p(mean), _p(rstd), float(eps),
+                                           float(scale), float(drop_p), int(site_probs), int(site_res),
+                                           _p(seed) if drop_p > 0 else None, _stream()), "dsvg_attn_block_fwd")
+    _prof_end(ev, 2.0 * rows * 256 * 1024 + 4.0 * rows * 32 * 256, 1024.0 * rows + (2560.0 * rows if train else 0.0),
+              dict(op="attn_block_fwd", rows=rows, train=bool(train)))
+    if train:
+        return x1, xn, qkv, ao, mean, rstd
+    return x1
+
+
 def _prof_begin():
     if not (PROFILE_ON and _TAG is not None):
         return None

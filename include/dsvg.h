@@ -406,6 +406,32 @@ int dsvg_ffn_bwd_dx(const void* dpre, const void* x, const void* dy, const void*
 int dsvg_ffn_wgrad_finish(const float* g1p, const float* db1p, const float* g2p, const float* w1, const float* gamma,
                           const float* beta, float* dw1, float* db1, float* dw2, float* dgamma, float* dbeta,
                           void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused attention sub-block (d_model 256, 8 heads of 32, sequences of at most 32 tokens, bf16):
+ *     x1 = x + drop_r( out_proj( MHA( LayerNorm(x) ) ) )
+ * one launch instead of LayerNorm + in_proj GEMM + attention + out_proj GEMM
+ * (deepsvg/model/layers/improved_transformer.py:43-46 and :127-131, layers/attention.py, layers/functional.py:168,197-248).
+ * dsvg_attn_pack: bf16 MFMA-fragment images (dsvg_attn_pack_bytes(n_layers) bytes, 512 KiB per layer) of in_proj_weight
+ *   and out_proj.weight straight from the fp32 master buffer; offs = int64 [n_layers][2] element offsets of
+ *   (in_proj_weight, out_proj.weight).  Re-pack after every optimiser step.
+ * dsvg_attn_block_fwd: x bf16 [rows, 256].  Layouts as dsvg_attention_fwd: dense (seq_off NULL: sequence b = rows
+ *   b*S .. b*S+S-1, optional key_mask bit j = key j visible) or packed (seq_off + tile_first from dsvg_attention_tiles,
+ *   block-diagonal attention inside each tile of <= 32 rows).  Rows behind the last sequence (bucket padding up to
+ *   `rows`) get finite values.  Dropout: site_probs on the probabilities (same element ids as dsvg_attention_fwd),
+ *   site_res on the residual branch (ids row*256 + col, replayable by dsvg_drop_apply).
+ *   Training outputs (all NULL for inference, all set otherwise) are what the unfused backward reads:
+ *   xn_out = LayerNorm(x) bf16 [rows,256], qkv_out bf16 [rows,768], ao_out = head outputs bf16 [rows,256],
+ *   mean_out / rstd_out fp32 [rows].
+ * ------------------------------------------------------------------------------------------ */
+int64_t dsvg_attn_pack_bytes(int32_t n_layers);
+int dsvg_attn_pack(const float* flat_f32, const int64_t* offs, int32_t n_layers, int32_t d_model, int32_t n_heads,
+                   void* packed, void* stream);
+int dsvg_attn_block_fwd(const void* x, const void* packed_layer, const float* in_bias, const float* out_bias,
+                        const float* gamma, const float* beta, const uint64_t* key_mask, const int32_t* seq_off,
+                        const int32_t* tile_first, int64_t n_seq, int32_t S, int64_t rows, void* x1, void* xn_out,
+                        void* qkv_out, void* ao_out, float* mean_out, float* rstd_out, float eps, float scale,
+                        float drop_p, uint32_t site_probs, uint32_t site_res, const void* seed, void* stream);
 /* test hook: raw ds_read_b64_tr_b16 on a 4 KiB LDS image img[i]=i, lane l reads at byte offset off[l] */
 int dsvg_probe_trread(const int* off, short* out, void* stream);
 

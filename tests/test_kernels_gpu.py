@@ -1049,3 +1049,118 @@ def test_ffn_training_path_matches_reference(gpu_device, drop_p):
         assert torch.equal(dym_f, dym)
     _close(dpre_f, dpre, 1.5e-2, "fused vs training-path dpre")
     _close(dx_f, dx, 2e-2, "fused vs training-path dx")
+
+
+# ----------------------------------------------------------------------------------------------------
+# fused attention sub-block (csrc/attn_fused.hip)
+# ----------------------------------------------------------------------------------------------------
+def _attn_setup(seed=0, n_layers=2):
+    """fp32 'master' buffer with n_layers x (in_proj_weight, out_proj.weight) and the offsets table dsvg_attn_pack takes;
+    biases and the LayerNorm affine of the layer under test"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    per = 768 * 256 + 256 * 256
+    flat = torch.zeros(8 + n_layers * per)
+    offs = []
+    for i in range(n_layers):
+        o = 8 + i * per
+        flat[o:o + 196608] = torch.randn(196608, generator=g) * 0.06
+        flat[o + 196608:o + per] = torch.randn(65536, generator=g) * 0.06
+        offs.append([o, o + 196608])
+    extra = dict(in_bias=0.2 * torch.randn(768, generator=g), out_bias=0.2 * torch.randn(256, generator=g),
+                 gamma=1 + 0.2 * torch.randn(256, generator=g), beta=0.2 * torch.randn(256, generator=g))
+    return flat.to(DEV), torch.tensor(offs, dtype=torch.int64, device=DEV), {k: v.to(DEV) for k, v in extra.items()}
+
+
+def test_attn_pack_layout(gpu_device):
+    """every fragment of the packed image against the index formulas of csrc/attn_fused.hip"""
+    flat, offs, _ = _attn_setup(seed=5)
+    img = ops.attn_pack(flat, offs, 2).view(2, 512, 64, 8).cpu().float()
+    lane = torch.arange(64)
+    i, half = (lane & 31).view(64, 1), (lane >> 5).view(64, 1)
+    e = torch.arange(8).view(1, 8)
+    for layer in range(2):
+        oi, oo = (int(v) for v in offs[layer])
+        Win = flat[oi:oi + 196608].view(768, 256).to(torch.bfloat16).float().cpu()
+        Wo = flat[oo:oo + 65536].view(256, 256).to(torch.bfloat16).float().cpu()
+        for f in (0, 17, 47, 48, 100, 383):
+            h, g = f // 48, f % 48
+            sel, ks = g >> 4, g & 15
+            assert torch.equal(img[layer, f], Win[256 * sel + 32 * h + i, 16 * ks + 8 * half + e]), f
+        for f in (384, 385, 399, 400, 470, 511):
+            g = f - 384
+            t, h, ks2 = g >> 4, (g & 15) >> 1, g & 1
+            r = 8 * ks2 + e
+            col = 32 * h + (r & 3) + 8 * (r >> 2) + 4 * half
+            assert torch.equal(img[layer, f], Wo[32 * t + i, col]), f
+
+
+def _attn_case(kind, seed):
+    """-> (rows, n_seq, S, key_mask, seq_off, tiles, n_real_rows)"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    if kind == "packed":
+        n_seq, S = 700, 30
+        lens = torch.randint(1, S + 1, (n_seq,), generator=g)
+        lens[::7] = torch.randint(1, 6, (len(lens[::7]),), generator=g)         # short sequences: several per tile
+        off = torch.zeros(n_seq + 1, dtype=torch.int32)
+        off[1:] = lens.cumsum(0)
+        real = int(off[-1])
+        rows = (real + 255) // 256 * 256 + 64          # bucket padding behind the last sequence
+        seq_off = off.to(DEV)
+        return rows, n_seq, S, None, seq_off, ops.attention_tiles(seq_off, n_seq, 32), real
+    if kind == "dense31":
+        return 300 * 31, 300, 31, None, None, None, 300 * 31
+    if kind == "dense32_masked":
+        n_seq, S = 257, 32
+        lens = torch.randint(1, S + 1, (n_seq,), generator=g)
+        km = ((torch.ones(n_seq, dtype=torch.int64) << lens) - 1).to(DEV)
+        return n_seq * S, n_seq, S, km, None, None, n_seq * S
+    if kind == "dense8_masked_tail":
+        n_seq, S = 1000, 8
+        lens = torch.randint(1, S + 1, (n_seq,), generator=g)
+        km = ((torch.ones(n_seq, dtype=torch.int64) << lens) - 1).to(DEV)
+        return n_seq * S + 40, n_seq, S, km, None, None, n_seq * S
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind", ["packed", "dense31", "dense32_masked", "dense8_masked_tail"])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attn_block_fwd_equals_unfused_kernels(gpu_device, kind, p):
+    """the fused attention block against the four launches it replaces (LayerNorm, in_proj GEMM, attention, out_proj GEMM
+    with dropout + residual), same weights, same dropout seed and sites: result and every tensor it hands the backward pass.
+    Both paths round q|k|v and the head outputs to bf16 at the same points; they differ in fp32 summation order only."""
+    flat, offs, prm = _attn_setup(seed=11)
+    rows, n_seq, S, km, seq_off, tiles, real = _attn_case(kind, seed=21)
+    x = (_rand(rows, 256, seed=31) * 1.5 + 0.3).to(torch.bfloat16)
+    img = ops.attn_pack(flat, offs, 2)
+    layer = 1
+    packed = img[layer * ops.ATTN_LAYER_ELEMS:(layer + 1) * ops.ATTN_LAYER_ELEMS]
+    oi, oo = (int(v) for v in offs[layer])
+    win = flat[oi:oi + 196608].view(768, 256).to(torch.bfloat16)
+    wo = flat[oo:oo + 65536].view(256, 256).to(torch.bfloat16)
+    seed = _seed_tensor(0x0BADC0FFEE123457)
+    scale = 32 ** -0.5
+    # unfused
+    xn0, mean0, rstd0 = ops.layernorm_fwd(x, prm["gamma"], prm["beta"], 1e-5)
+    qkv0 = ops.gemm(xn0, win, bias=prm["in_bias"])
+    ao0 = ops.attention_fwd(qkv0, km, n_seq, S, 8, scale, p, 7, seed, seq_off=seq_off, tiles=tiles)
+    want = ops.gemm(ao0, wo, bias=prm["out_bias"], res=x, drop_p=p, drop_site=8, seed=seed)
+    # fused
+    x1, xn, qkv, ao, mean, rstd = ops.attn_block_fwd(x, packed, prm["in_bias"], prm["out_bias"], prm["gamma"], prm["beta"],
+                                                     km, n_seq, S, scale, 1e-5, p, 7, 8, seed, seq_off=seq_off, tiles=tiles,
+                                                     train=True)
+    x1i = ops.attn_block_fwd(x, packed, prm["in_bias"], prm["out_bias"], prm["gamma"], prm["beta"], km, n_seq, S, scale,
+                             1e-5, p, 7, 8, seed, seq_off=seq_off, tiles=tiles, train=False)
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x1i), "training and inference variants differ"
+    for t in (x1, xn, qkv, ao, mean, rstd):
+        assert torch.isfinite(t.float()).all(), "non-finite values (padding rows included)"
+    r = slice(0, real)
+    _close(mean[r], mean0[r], 1e-5, "mean")
+    _close(rstd[r], rstd0[r], 1e-5, "rstd")
+    _close(xn[r], xn0[r], 8e-3, "LN(x)")
+    _close(qkv[r], qkv0[r], 1.2e-2, "q|k|v")
+    _close(ao[r], ao0[r], 2e-2, "head outputs")
+    _close(x1[r], want[r], 2e-2, "x1")
+    # the typical element agrees far better than the worst one
+    assert ((x1[r].float() - want[r].float()).abs().mean() <= 2e-3 * want[r].float().abs().mean()).item()
+    assert ((qkv[r].float() - qkv0[r].float()).abs().mean() <= 1e-3 * qkv0[r].float().abs().mean()).item()

@@ -775,6 +775,35 @@ def ffn_wgrad_finish(g1p, db1p, g2p, w1, gamma, beta, dw1, db1, dw2, dgamma, dbe
     dbeta.view(256).copy_(W1.t() @ b)
 
 
+# ------------------------------------------------------------------------------------------------
+# fused attention sub-block.  The emulated "packed" image carries in_proj_weight | out_proj.weight in bf16.
+# ------------------------------------------------------------------------------------------------
+ATTN_LAYER_ELEMS = 512 * 512
+
+
+def attn_pack(flat, offs, n_layers, packed=None):
+    if packed is None:
+        packed = torch.empty(n_layers * ATTN_LAYER_ELEMS, dtype=torch.bfloat16, device=flat.device)
+    for i in range(n_layers):
+        oi, oo = (int(v) for v in offs[i])
+        packed[i * ATTN_LAYER_ELEMS:(i + 1) * ATTN_LAYER_ELEMS] = torch.cat(
+            [flat[oi:oi + 196608], flat[oo:oo + 65536]]).to(torch.bfloat16)
+    return packed
+
+
+def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_seq, S, scale, eps=1e-5, drop_p=0.0,
+                   site_probs=0, site_res=0, seed=None, seq_off=None, tiles=None, train=False):
+    """the unfused launches, composed (LayerNorm -> in_proj -> attention -> out_proj + dropout + residual)"""
+    win, wo = packed_layer[:196608].view(768, 256), packed_layer[196608:].view(256, 256)
+    xn, mean, rstd = layernorm_fwd(x, gamma, beta, eps)
+    qkv = gemm(xn, win, bias=in_bias)
+    ao = attention_fwd(qkv, key_mask, n_seq, S, 8, scale, drop_p, site_probs, seed, seq_off=seq_off, tiles=tiles)
+    x1 = gemm(ao, wo, bias=out_bias, res=x, drop_p=drop_p, drop_site=site_res, seed=seed)
+    if train:
+        return x1, xn, qkv, ao, mean, rstd
+    return x1
+
+
 def gate_mul(dy, y, scale=1.0):
     return torch.where(_f(y) > 0, _f(dy) * scale, torch.zeros_like(_f(dy))).to(dy.dtype)
 
