@@ -106,6 +106,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, h2 = lane >> 5;
+    const bool late = wave >= 4;
     const uint32_t lds0 = (uint32_t)(uintptr_t)DSVG_LDS_PTR(smem);
     float* sbin = reinterpret_cast<float*>(smem + NBUF * SLOT);
     float* sbo = sbin + 768;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
             f.u = pack8(v);
             xf[ks] = f.v;
             if (st) *reinterpret_cast<uint4*>(xo + 32 * ks) = f.u;
-            asm volatile("" : "+v"(zoff) : "v"(f.u.x) : "memory");
+            asm volatile("" : "+v"(zoff) : "v"(f.u.x), "v"(f.u.y), "v"(f.u.z), "v"(f.u.w) : "memory");
         }
     }
 
@@ -250,17 +251,22 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
     const bool ok0 = TRAIN && (lane >> 2) < S, ok1 = TRAIN && (lane >> 2) + 16 < S;
     char* qb = TRAIN ? reinterpret_cast<char*>(qkv_out) + ((size_t)(row0 + (lane >> 2)) * (3 * AD) + 8 * (lane & 3)) * 2 : nullptr;
     char* ab = TRAIN ? reinterpret_cast<char*>(ao_out) + ((size_t)(row0 + (lane >> 2)) * AD + 8 * (lane & 3)) * 2 : nullptr;
-    // sync(k): chunk k is readable afterwards, chunk k + 2 on its way; behind it the stores of the stage before: k odd = the
-    // q | k tiles of head (k - 1) / 2, k even (2 .. 16) = the v and head-output tiles of head k / 2 - 1
+    // sync(k): afterwards chunks <= k + 1 are readable and chunk k + 2 is on its way into the slot chunk k - 1 has left.
+    // The two waves of a SIMD (w, w + 4) run one stage apart: waves 0-3 pass sync(k) BEFORE the stage of chunk k, waves 4-7
+    // AFTER it (same straight-line code, only the barrier position differs), so the MFMA-bound projection stage of one
+    // sits beside the VALU-bound softmax stage of the other.  Behind the barrier go the stores of the stage the wave has
+    // just finished: the q | k tiles (chunk 2 h) or the v and head-output tiles (chunk 2 h + 1) of head h.
     auto sync = [&](int k) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (k + DIST < N_CHUNK) issue(k + DIST);
-        if (TRAIN && k >= 1 && k <= 16) {
-            const int hp = (k - 1) >> 1;
-            char* d0 = (k & 1) ? qb + 64 * hp : qb + 4 * AD + 64 * hp;
-            char* d1 = (k & 1) ? qb + 2 * AD + 64 * hp : ab + 64 * hp;
-            const int far0 = 16 * 3 * AD * 2, far1 = (k & 1) ? 16 * 3 * AD * 2 : 16 * AD * 2;
+        const int done = late ? k : k - 1;         // chunk whose stage this wave finished last
+        if (TRAIN && done >= 0 && done < 16) {
+            const int hp = done >> 1;
+            const bool qk = !(done & 1);
+            char* d0 = qk ? qb + 64 * hp : qb + 4 * AD + 64 * hp;
+            char* d1 = qk ? qb + 2 * AD + 64 * hp : ab + 64 * hp;
+            const int far0 = 16 * 3 * AD * 2, far1 = qk ? 16 * 3 * AD * 2 : 16 * AD * 2;
             if (ok0) { *reinterpret_cast<uint4*>(d0) = pa0; *reinterpret_cast<uint4*>(d1) = pb0; }
             if (ok1) { *reinterpret_cast<uint4*>(d0 + far0) = pa1; *reinterpret_cast<uint4*>(d1 + far1) = pb1; }
         }
@@ -283,9 +289,11 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
     bf16x8 aof[16];         // the out_proj operand queue: every head shifts it by two fragments and appends its own
 
     // ---- heads -----------------------------------------------------------------------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();           // chunks 0 and 1 are in LDS
 #pragma unroll 1
     for (int h = 0; h < AH; ++h) {
-        sync(2 * h);
+        if (!late) sync(2 * h);
         Frag8 qf[2], kf[2];
         {
             const char* sl = lbase + ((2 * h) % NBUF) * SLOT;
@@ -328,7 +336,8 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
                 stage_take(pb0, pb1);
             }
         }
-        sync(2 * h + 1);
+        if (late) sync(2 * h);
+        else sync(2 * h + 1);
         {
             const char* sl = lbase + ((2 * h + 1) % NBUF) * SLOT;
             // scores first (their operands are in registers): st[r] = q_li . k_key(r, h2)
@@ -421,6 +430,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
                 stage_take(pb0, pb1);
             }
         }
+        if (late) sync(2 * h + 1);
     }
 
     // ---- out_proj: two 32-row blocks of outputs per chunk, + bias, dropout, residual ---------------------------------------------
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
     char* yrow = reinterpret_cast<char*>(x1) + (size_t)my_row * (AD * 2);
 #pragma unroll 1
     for (int u = 0; u < 4; ++u) {
-        sync(16 + u);
+        if (!late) sync(16 + u);
         const char* sl = lbase + ((16 + u) % NBUF) * SLOT;
         uint4 res[4];
 #pragma unroll
@@ -482,6 +492,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
                 *reinterpret_cast<uint4*>(yrow + n16 * 2 + 16) = pk[1];
             }
         }
+        if (late) sync(16 + u);
     }
 }
 
