@@ -22,6 +22,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from .svgtensor import EOS_ID
 
 DEFAULT_WEIGHTS = {   # configs/deepsvg/default_icons.py:65-73 at step 0
     "kl_tolerance": 0.1, "loss_kl_weight": 0.0, "loss_hierarch_weight": 1.0, "loss_cmd_weight": 1.0,
@@ -31,21 +32,25 @@ DEFAULT_WEIGHTS = {   # configs/deepsvg/default_icons.py:65-73 at step 0
 
 class TrainStep:
     def __init__(self, model, loss_fn, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_clip=1.0,
-                 weights=None, process_group=None, use_graph=False, exact_global_mean=True):
+                 weights=None, process_group=None, use_graph=False, exact_global_mean=True, force_ddp=False):
         self.model, self.loss_fn = model, loss_fn
         self.betas, self.eps, self.weight_decay, self.grad_clip = betas, eps, weight_decay, grad_clip
         self.weights = dict(weights or DEFAULT_WEIGHTS)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        # force_ddp: run the data-parallel code path (collectives included) on a one-rank group - how the single-GPU
+        # development boxes exercise RCCL and the graph / collective / optimiser split below
+        self.ddp = self.world > 1 or (force_ddp and dist.is_available() and dist.is_initialized())
         self.use_graph = use_graph
-        self.exact_global_mean = exact_global_mean and self.world > 1
+        self.exact_global_mean = exact_global_mean and self.ddp
+        self._counts = None             # graph + DDP: the global loss counts, filled before every replay
         self._lr_value = float(lr)
         self._ready = False
         self._graphs = {}               # bucket key -> (graph, static inputs, static plan, static results)
         self._plan_stream = None
         self.inputs_resident = False    # see step(): set by callers whose input tensors are complete well before step()
         # gradient all-reduce in two buckets, the decoder's overlapped with the encoder's backward (eager launches only)
-        self.overlap_allreduce = os.environ.get("DSVG_DDP_OVERLAP", "1") != "0" and not use_graph
+        self.overlap_allreduce = os.environ.get("DSVG_DDP_OVERLAP", "1") != "0"
         self._pending = None
         self._pool = None
         self.row_bucket, self.seq_bucket = 1024, 64
@@ -87,12 +92,39 @@ class TrainStep:
 
     def _reduce_counts(self, counts):
         """[n] local selected-element counts of the cross-entropies -> global counts / world, in ONE all-reduce"""
+        if self._counts is not None and self.use_graph:
+            return self._counts         # hipGraph + DDP: reduced before the replay (see _global_counts)
         dist.all_reduce(counts, group=self.pg)
         return counts / self.world
 
+    def _global_counts(self, commands_dec, args_dec, plan):
+        """hipGraph + DDP: the cross-entropy normalisers depend on the targets only (deepsvg/model/loss.py:33-57), so their
+        one 3-element all-reduce runs eagerly BEFORE the captured forward + backward and lands in a static tensor"""
+        N, G = commands_dec.shape[0], commands_dec.shape[1]
+        if plan["loss"] is not None:
+            targets = plan["loss"]["targets"]
+        else:
+            tc = commands_dec.to(torch.float32).contiguous().view(N * G, -1)
+            ta = args_dec.to(torch.float32).contiguous().view(N * G, tc.shape[1], -1)
+            targets = ops.loss_targets(tc, ta, self.loss_fn._cam(tc.device), EOS_ID)
+        local = torch.stack([torch.full((), float(N * G), device=commands_dec.device),
+                             (targets[1] != 0).sum().float(), (targets[3] != 0).sum().float()])
+        dist.all_reduce(local, group=self.pg)
+        local /= self.world
+        if self._counts is None:
+            self._counts = local.clone()
+        else:
+            self._counts.copy_(local)
+
     # ---- one step ------------------------------------------------------------------------------------
     def _step_body(self, commands, args, label=None, dec=None):
-        """dec = (commands_dec, args_dec) when the decoder side takes other tensors than the encoder side (relative
+        ld = self._step_front(commands, args, label, dec)
+        self._step_back()
+        return ld
+
+    def _step_front(self, commands, args, label=None, dec=None):
+        """forward, loss, backward: everything up to the (local) gradient in the flat buffer.
+        dec = (commands_dec, args_dec) when the decoder side takes other tensors than the encoder side (relative
         targets: model_args = [commands, args, commands, args_rel], deepsvg/model/config.py:52-53)"""
         model = self.model
         cd, ad = dec if dec is not None else (commands, args)
@@ -100,7 +132,7 @@ class TrainStep:
         for p in model.store.params:
             p.grad = None
         self._pending = None
-        if self.world > 1 and self.overlap_allreduce:
+        if self.ddp and self.overlap_allreduce and not self.use_graph:
             model._decoder_grads_ready = self._launch_decoder_bucket    # hooked onto the bottleneck output in forward
         # the ~130 partial-sum reductions of the parameter gradients (split-K slices, LayerNorm gamma/beta partials) are
         # queued during backward and performed by ONE launch per 64 right after it (ops.flush_deferred): nothing reads a
@@ -124,7 +156,13 @@ class TrainStep:
                 v = model.store._grad_view(p, 0)
                 if v is not None:
                     v.zero_()
-        if self.world > 1:
+        return {k: v.detach() for k, v in ld.items()}
+
+    def _step_back(self):
+        """gradient all-reduce (data parallel), global-norm clip and AdamW on the flat buffers (train.py:99-106)"""
+        model = self.model
+        flat_g = model.store.grad_buffer(0)
+        if self.ddp:
             if self._pending is not None:
                 # two buckets: the decoder half went out while the encoder's backward was running
                 lo, work = self._pending
@@ -137,7 +175,6 @@ class TrainStep:
                         beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay,
                         gnorm_sq=self.gnorm_sq if self.grad_clip else None, max_norm=float(self.grad_clip or 0.0),
                         grad_scale=1.0 / self.world)
-        return {k: v.detach() for k, v in ld.items()}
 
     def step(self, commands, args, label=None, commands_dec=None, args_dec=None):
         """one training step on a batch (the body of deepsvg/train.py:92-106): model(commands, args, commands_dec,
@@ -177,6 +214,11 @@ class TrainStep:
                 model._forced_plan = None
             self._note_layout(plan, commands)
             return res
+        if self.ddp:
+            # data parallel: the graph holds forward + backward only.  The loss normalisers go out before it, the gradient
+            # all-reduce and the optimiser run eagerly behind it (graph -> all-reduce -> clip + AdamW): no collective is
+            # ever captured, and a rank that has to capture a new bucket issues exactly the collectives of a replaying one
+            self._global_counts(dec[0] if dec else commands, dec[1] if dec else args, plan)
         key, plan = self._bucketed(plan, commands)
         key = key + (label is not None, dec is not None)
         entry = self._graphs.get(key)
@@ -201,6 +243,8 @@ class TrainStep:
                                 dst.copy_(src)
         self._note_layout(plan, commands)
         entry[0].replay()
+        if self.ddp:
+            self._step_back()
         return entry[3]
 
     def _bucketed(self, plan, commands):
@@ -252,7 +296,9 @@ class TrainStep:
         splan = {part: (None if plan[part] is None else {k: _static(v) for k, v in plan[part].items()})
                  for part in ("enc", "dec", "loss")}
         model._forced_plan = splan
-        # the warm-up steps (allocator pools, lazy buffers, RCCL communicators) must not train the model
+        # the warm-up steps (allocator pools, lazy buffers) must not train the model.  Data parallel: the captured part
+        # (and its warm-up) is forward + backward only - no collective, see step()
+        body = self._step_front if self.ddp else self._step_body
         state = [model.store.flat, self.m, self.v, self.step_count, self.seed]
         saved = [t.clone() for t in state]
         try:
@@ -260,7 +306,7 @@ class TrainStep:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    self._step_body(sc, sa, sl, sdec)
+                    body(sc, sa, sl, sdec)
                 for t, s0 in zip(state, saved):
                     t.copy_(s0)
             torch.cuda.current_stream().wait_stream(side)
@@ -269,7 +315,7 @@ class TrainStep:
                 self._pool = torch.cuda.graph_pool_handle()     # graphs replay one at a time: one shared pool
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self._pool):
-                res = self._step_body(sc, sa, sl, sdec)
+                res = body(sc, sa, sl, sdec)
         finally:
             model._forced_plan = None
         entry = (g, (sc, sa, sl, sdec), splan, res)

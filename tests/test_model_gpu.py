@@ -389,6 +389,45 @@ def test_greedy_sample_and_encode_decode(gpu_device):
     assert cy.shape == (4, 8, 31) and ay.shape == (4, 8, 31, 11)
 
 
+def test_data_parallel_step_over_rccl_one_rank(gpu_device):
+    """The data-parallel TrainStep on a ONE-rank RCCL group (force_ddp): eager (count all-reduce inside the loss, two
+    overlapped gradient buckets) and hipGraph mode (count all-reduce before the graph, graph = forward + backward, gradient
+    all-reduce + clip + AdamW eagerly behind it - no collective is captured) must both track the plain single-GPU trainer."""
+    import os
+    import torch.distributed as dist
+    from deepsvg_amd.trainer import TrainStep
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29600 + os.getpid() % 300}", rank=0, world_size=1)
+        created = True
+    try:
+        cfg = H.build_cfg("hier")
+        cfg.dropout = 0.1
+        sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 321)
+        batches = [tuple(t.to(DEV) for t in make_batch(64, seed=s_)) for s_ in (5, 6, 5)]
+        runs = {}
+        for name, kw in (("plain", dict(use_graph=True)), ("ddp_graph", dict(use_graph=True, force_ddp=True)),
+                         ("ddp_eager", dict(use_graph=False, force_ddp=True))):
+            torch.manual_seed(7)
+            model = _hip_model(cfg, sd, torch.bfloat16).train()
+            ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=1e-3, **kw)
+            assert ts.ddp == ("force_ddp" in kw)
+            losses = [float(ts.step(c, a)["loss"]) for c, a in batches]
+            torch.cuda.synchronize()
+            runs[name] = (losses, model.store.flat.detach().clone(), ts.grad_norm())
+            if name == "ddp_graph":
+                assert len(ts._graphs) >= 1 and ts._counts is not None
+        for name in ("ddp_graph", "ddp_eager"):
+            for a, b in zip(runs[name][0], runs["plain"][0]):
+                assert abs(a - b) <= 2e-2 * abs(b), (name, runs[name][0], runs["plain"][0])
+            d = (runs[name][1] - runs["plain"][1]).abs()
+            assert d.max().item() <= 4e-3 and d.mean().item() <= 1e-4, (name, d.max().item(), d.mean().item())
+            assert abs(runs[name][2] - runs["plain"][2]) <= 5e-2 * runs["plain"][2]
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_deferred_gradient_reductions_equal_immediate_ones(gpu_device, dtype, use_graph):
