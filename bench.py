@@ -196,7 +196,7 @@ def main():
         assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
-        if world > 1:
+        if world > 1 or (os.environ.get("DSVG_FORCE_DDP") == "1" and "MASTER_ADDR" in os.environ):
             dist.init_process_group("nccl", device_id=device)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
@@ -231,7 +231,9 @@ def main():
     # and clip + AdamW eagerly behind it (TrainStep.step) - no collective is captured.  DSVG_BENCH_GRAPH_DDP=0: eager
     graph_ok = (world == 1 or os.environ.get("DSVG_BENCH_GRAPH_DDP", "1") != "0") and not emulate
     use_graph = a.graph != 0 and graph_ok
-    ts = TrainStep(model, loss_fn, lr=1e-3 * world, grad_clip=1.0, use_graph=use_graph)
+    # DSVG_FORCE_DDP=1 under a one-rank launch: the data-parallel path (RCCL collectives included) on a single GPU
+    force_ddp = os.environ.get("DSVG_FORCE_DDP") == "1" and dist.is_available() and dist.is_initialized()
+    ts = TrainStep(model, loss_fn, lr=1e-3 * world, grad_clip=1.0, use_graph=use_graph, force_ddp=force_ddp)
     ts.inputs_resident = True       # the synthetic batch sits in HBM before the timed region (bench contract)
     try:
         ts.step(commands, args)
@@ -342,6 +344,24 @@ def main():
                              "largest_launch": {"rows": big, "avg_us": round(big_us, 1),
                                                 "TFLOPs": round(4.0 * 256 * 512 * big / big_us * 1e-6, 1),
                                                 "frac": round(4.0 * 256 * 512 * big / big_us * 1e-6 / peak_tf, 4)}}
+            # the second fused kernel of the step: the attention sub-block of the layers with >= 16384 rows (forward)
+            ak = [r for r in ops.PROFILE if r[0] == "attn" and r[5].get("op") == "attn_block_fwd"]
+            fused_attn = None
+            if ak:
+                ak_ms = sum(r[1].elapsed_time(r[2]) for r in ak) / n_prof
+                ak_flop = sum(r[3] for r in ak) / n_prof
+                big = max(r[5]["rows"] for r in ak)
+                bigs = [r for r in ak if r[5]["rows"] == big]
+                big_us = sum(r[1].elapsed_time(r[2]) for r in bigs) / len(bigs) * 1e3
+                big_flop = bigs[0][3]
+                fused_attn = {"kernel": "attn_block_fwd_kernel (LayerNorm + in_proj + 8-head attention + out_proj + dropout "
+                                        "+ residual, training variant: also stores LN(x), q|k|v and the head outputs)",
+                              "launches_per_step": len(ak) // n_prof, "ms_per_step": round(ak_ms, 3),
+                              "achieved_TFLOPs": round(ak_flop / (ak_ms * 1e-3) / 1e12, 1),
+                              "frac": round(ak_flop / (ak_ms * 1e-3) / 1e12 / peak_tf, 4),
+                              "largest_launch": {"rows": big, "avg_us": round(big_us, 1),
+                                                 "TFLOPs": round(big_flop / big_us * 1e-6, 1),
+                                                 "frac": round(big_flop / big_us * 1e-6 / peak_tf, 4)}}
             roofline = {"bound": "mfma",
                         "kernel": "FFN sub-block of the 16 layers (fused forward kernel / linear1+linear2 GEMMs, dX, dW), "
                                   "%d launches per step" % n_ffn,
@@ -356,6 +376,7 @@ def main():
                                                  "frac": round(flop_exec / (mm_ms * 1e-3) / 1e12 / peak_tf, 4),
                                                  "note": "round 1's accounting: launches that execute FLOPs only"},
                         "fused_fwd_kernel": fused_fwd,
+                        "fused_attn_fwd_kernel": fused_attn,
                         "hbm_view": {"achieved_GBps": round(gbs, 1), "peak_GBps": 8000.0, "frac": round(gbs / 8000.0, 4),
                                      "fused_algorithmic_GB_per_step": round(fused_bytes / 1e9, 3),
                                      "definition": "SURVEY.md 8(d) fused byte count: 1024 B per token-layer forward; "

@@ -486,10 +486,7 @@ extern "C" int dsvg_flush_deferred(void* stream) {
     DeferQueue& d = defer_queue();
     std::lock_guard<std::mutex> lk(d.mu);
     if (d.q.empty()) return 0;
-    if (stream && d.st != (hipStream_t)stream) {
-        dsvg_set_error("flush_deferred: the queued reductions were enqueued for another stream");
-        return -1;
-    }
+    d.st = (hipStream_t)stream;     // the caller has ordered this stream behind every producer of the queued partials
     return defer_flush_locked(d);
 }
 
@@ -500,10 +497,8 @@ int dsvg_reduce_partials_mixed(const float* part, int64_t P, int64_t stride, int
     {
         DeferQueue& d = defer_queue();
         std::lock_guard<std::mutex> lk(d.mu);
-        if (!d.q.empty() && (d.st != st || defer_overlaps(d, out, n))) {
-            // a second write to a queued destination (or work for another stream): order matters, run the queue now
-            hipStream_t keep = d.st;
-            (void)keep;
+        if (!d.q.empty() && defer_overlaps(d, out, n)) {
+            // a second write to a queued destination: order matters, run the queue now (on the stream of the last push)
             int rc = defer_flush_locked(d);
             if (rc) return rc;
         }

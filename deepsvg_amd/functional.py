@@ -29,6 +29,7 @@ FFN_BWD_FUSED = os.environ.get("DSVG_FFN_BWD_FUSED", "0") != "0"
 FFN_MIN_ROWS = int(os.environ.get("DSVG_FFN_MIN_ROWS", "16384"))
 # the fused attention block owns 8 tiles of <= 32 rows per workgroup (same granularity: unfused launches below this)
 ATTN_MIN_ROWS = int(os.environ.get("DSVG_ATTN_MIN_ROWS", "16384"))
+SIDE_MAX_ROWS = int(os.environ.get("DSVG_SIDE_MAX_ROWS", "16384"))
 
 
 _NULL_CTX = contextlib.nullcontext()
@@ -41,7 +42,7 @@ class Runtime:
         self.dtype = dtype
         # queue the partial-sum reductions of the parameter gradients (ops.DEFER) instead of launching ~130 of them one
         # by one: only a caller that flushes before anything reads a gradient may set it (TrainStep)
-        self.defer = bool(defer) and side_stream is None
+        self.defer = bool(defer)
         self.seed = seed          # int64[1] device tensor holding the dropout seed of this step
         self.store = store        # ParamStore or None
         self.training = training
@@ -51,11 +52,13 @@ class Runtime:
         self.side_stream = side_stream
         self._keep = []           # operands of side-stream work, kept alive until join()
 
-    def on_side(self, *operands):
-        """context manager: run the enclosed launches on the side stream, ordered after everything enqueued so far"""
+    def on_side(self, *operands, rows=0):
+        """context manager: run the enclosed launches on the side stream, ordered after everything enqueued so far.
+        Only the weight gradients of the SMALL stages go there (rows < SIDE_MAX_ROWS: launch-latency-bound GEMMs that a
+        captured graph can run beside the main chain); the big ones are HBM-bound and gain nothing from overlap."""
         side = self.side_stream
-        if side is None:
-            return contextlib.nullcontext()
+        if side is None or rows >= SIDE_MAX_ROWS:
+            return _NULL_CTX
         side.wait_stream(torch.cuda.current_stream())
         self._keep.extend(operands)
         return torch.cuda.stream(side)
@@ -98,7 +101,7 @@ def _wgrad(rt, param, dy, x, *, a_drop_p=0.0, a_drop_site=0):
     out = rt.grad_out(param)
     n_out, k_in = param.shape
     T = dy.shape[0]
-    with rt.on_side(dy, x), rt.deferring():
+    with rt.on_side(dy, x, rows=T), rt.deferring():
         ops.gemm(dy, x, a_kc=False, b_kc=False, out=out.view(n_out, k_in), a_drop_p=a_drop_p, a_drop_site=a_drop_site,
                  seed=rt.seed, split_k=ops.split_k_for(n_out, k_in, T))
     return out
@@ -112,7 +115,7 @@ def _wbgrad(rt, weight, bias, dy, x):
     split = ops.split_k_for(n_out, k_in, dy.shape[0])
     dw = rt.grad_out(weight)
     db = rt.grad_out(bias)
-    with rt.on_side(dy, x), rt.deferring():
+    with rt.on_side(dy, x, rows=dy.shape[0]), rt.deferring():
         if split > 1:
             ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in), split_k=split, rowsum=db)
         else:
@@ -442,8 +445,10 @@ class LayerFn(torch.autograd.Function):
         if att is not None:
             # one launch: LayerNorm, in_proj, the 8 heads, out_proj, dropout, residual (csrc/attn_fused.hip).  With a
             # backward pass ahead it also stores LN(x), q|k|v, the head outputs and the row statistics
-            res = ops.attn_block_fwd(x, att, bin_.detach(), bo.detach(), n1w.detach(), n1b.detach(), key_mask, n_seq, S,
-                                     scale, 1e-5, p, site0, site0 + 1, rt.seed, seq_off=seq_off, tiles=tiles, train=want_bwd)
+            with ops.tag("attn"):
+                res = ops.attn_block_fwd(x, att, bin_.detach(), bo.detach(), n1w.detach(), n1b.detach(), key_mask, n_seq,
+                                         S, scale, 1e-5, p, site0, site0 + 1, rt.seed, seq_off=seq_off, tiles=tiles,
+                                         train=want_bwd)
             if want_bwd:
                 x1, xn1, qkv, ao, mean1, rstd1 = res
             else:
@@ -524,7 +529,7 @@ class LayerFn(torch.autograd.Function):
                 g1p = torch.empty((512, 256), dtype=torch.float32, device=x1.device)
                 db1p = torch.empty(512, dtype=torch.float32, device=x1.device)
                 db2 = rt.grad_out(b2)
-                with rt.on_side(dym, hp, dpre, xh), rt.deferring():
+                with rt.on_side(dym, hp, dpre, xh, rows=T), rt.deferring():
                     s2, s1 = ops.split_k_for(256, 512, T), ops.split_k_for(512, 256, T)
                     if s2 > 1:
                         ops.gemm(dym, hp, a_kc=False, b_kc=False, out=g2p, split_k=s2, rowsum=db2)

@@ -145,8 +145,8 @@ class TrainStep:
         finally:
             model._decoder_grads_ready = None
             model._defer_wgrad = False
+            model.join_side_stream()    # (opt-in) small weight-gradient GEMMs run on a second stream (functional.Runtime)
             ops.flush_deferred()
-        model.join_side_stream()        # weight gradients are computed on a second stream (functional.Runtime)
         flat_g = model.store.grad_buffer(0)
         # the norm / AdamW below read the WHOLE flat gradient buffer: a parameter that received no gradient in this step
         # must contribute zero, not its gradient of an earlier step (torch's AdamW skips grad-less parameters; no shipped

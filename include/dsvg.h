@@ -82,7 +82,8 @@ int dsvg_reduce_partials(const float* partial, int64_t P, int64_t n, float* out,
  * which performs all queued reductions in one launch per 64 of them (a backward pass of the benchmark model queues
  * ~130: the per-reduction launches were 0.85 ms of a 10.5 ms step).  A reduction whose destination overlaps a queued
  * one flushes the queue first, so write-after-write order is kept; reads of a queued destination are the caller's
- * responsibility (deepsvg_amd/trainer.py flushes right after loss.backward(), the reference's train.py:98).
+ * responsibility (deepsvg_amd/trainer.py flushes right after loss.backward(), the reference's train.py:98), and so
+ * is ordering the flush stream behind every stream that produced queued partials.
  * dsvg_defer_scope returns the number of reductions currently queued. */
 int dsvg_defer_scope(int32_t on);
 int dsvg_flush_deferred(void* stream);

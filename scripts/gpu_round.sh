@@ -23,10 +23,14 @@ fi
 if [[ "$WHAT" == "all" || "$WHAT" == *bench* ]]; then
   run bench_default 900 python bench.py
   run bench_unfused_ffn 600 env DSVG_FFN_FUSED=0 python bench.py --no-cpu-baseline --no-fp32
+  run bench_unfused_attn 600 env DSVG_ATTN_FUSED=0 python bench.py --no-cpu-baseline --no-fp32 --no-roofline
+  run bench_immediate_reduce 600 env DSVG_DEFER_REDUCE=0 python bench.py --no-cpu-baseline --no-fp32 --no-roofline
+  run bench_rccl_one_rank 600 env DSVG_FORCE_DDP=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29713 bench.py --gpus 1 --no-cpu-baseline --no-fp32 --no-roofline
   run bench_bf16_eager 600 python bench.py --graph 0 --no-cpu-baseline --no-fp32
   run bench_bf16_padded 600 env DSVG_SKIP_INVISIBLE=0 DSVG_COMPACT_HEAD=0 python bench.py --pack-encoder 0 --no-cpu-baseline --no-fp32
 fi
 if [[ "$WHAT" == "all" || "$WHAT" == *second* ]]; then
+  run attn_microbench 300 python scripts/attn_bench.py
   run secondary_bench 600 python scripts/secondary_bench.py
   run train_sanity 600 python scripts/train_sanity.py
 fi
