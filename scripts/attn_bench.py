@@ -36,6 +36,14 @@ def main():
     ga, be = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
     seed = torch.tensor([12345], dtype=torch.int64, device=DEV)
     scale = 32 ** -0.5
+    if "--pmc" in sys.argv:         # counter collection (scripts/gpu_attn_pmc.sh): three launches of each variant, no timing
+        n_seq, S = 4096, 31
+        x = (torch.randn(n_seq * S, 256, generator=g) * 1.5).to(DEV).to(torch.bfloat16)
+        for _ in range(3):
+            ops.attn_block_fwd(x, img, bi, bo, ga, be, None, n_seq, S, scale, 1e-5, 0.1, 7, 8, seed, train=True)
+            ops.attn_block_fwd(x, img, bi, bo, ga, be, None, n_seq, S, scale, 1e-5, 0.1, 7, 8, seed, train=False)
+        torch.cuda.synchronize()
+        return
     for name in ("dense31", "packed"):
         if name == "dense31":
             n_seq, S = 4096, 31

@@ -435,3 +435,47 @@ def test_fused_ffn_path_matches_unfused_with_emulated_ops(emulated_ops):
     assert worst < 0.12, (worst, name)
     med = sorted(H.rel_l2(res[True][1][n], res[False][1][n]) for n in res[True][1])[len(res[True][1]) // 2]
     assert med < 0.05, med
+
+
+def test_fused_attention_path_matches_unfused_with_emulated_ops(emulated_ops):
+    """bf16 compute, every layer's attention sub-block through attn_pack / attn_block_fwd (packed tiles of the first
+    encoder stage, dense key-masked group stages, the live-prefix decoder stage): with the emulated ops the fused call is
+    the composition of the unfused ones, so loss and gradients must be IDENTICAL - this pins the wiring (which tensors
+    the forward hands the unfused backward, dropout sites, masks / tiles, the per-layer weight image)"""
+    from deepsvg_amd.synthetic import make_batch
+    import deepsvg_amd.functional as Fn
+    from deepsvg_amd import ops
+    cfg = H.build_cfg("hier")
+    cfg.n_layers = cfg.n_layers_decode = 2
+    cfg.dropout = 0.1
+    c, a = make_batch(6, seed=5)
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 8)
+    res, calls = {}, {}
+    saved = (Fn.ATTN_MIN_ROWS, Fn.FFN_MIN_ROWS, ops.attn_block_fwd)
+    Fn.ATTN_MIN_ROWS, Fn.FFN_MIN_ROWS = 0, 1 << 40
+    try:
+        for fused in (True, False):
+            n_calls = [0]
+
+            def counted(*args, _f=saved[2], **kw):
+                n_calls[0] += 1
+                return _f(*args, **kw)
+            ops.attn_block_fwd = counted
+            torch.manual_seed(3)
+            model = deepsvg_amd.SVGTransformer(cfg).train()
+            model.load_state_dict(sd)
+            model.set_compute_dtype(torch.bfloat16)
+            if not fused:
+                model.store._attn_setup = lambda device: None
+            out = model(c, a, c, a, params={})
+            assert (model.store._attn is not None) == fused
+            ld = deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
+            ld["loss"].backward()
+            res[fused] = (float(ld["loss"]), {n: p.grad.clone() for n, p in model.named_parameters()})
+            calls[fused] = n_calls[0]
+    finally:
+        Fn.ATTN_MIN_ROWS, Fn.FFN_MIN_ROWS, ops.attn_block_fwd = saved
+    assert calls[True] == 8 and calls[False] == 0        # 4 stacks x 2 layers
+    assert res[True][0] == res[False][0]
+    for n in res[True][1]:
+        assert torch.equal(res[True][1][n], res[False][1][n]), n

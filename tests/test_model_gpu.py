@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import deepsvg_amd
+from deepsvg_amd import ops
 from deepsvg_amd.synthetic import make_batch
 from oracle import svg_transformer_oracle as O
 from tests import helpers as H
@@ -156,6 +157,40 @@ def test_fp32_model_matches_oracle_at_benchmark_size_512(gpu_device):
     print(f"N=512 fp32 vs oracle: worst logit abs err {worst_l:.3e}, loss {ld['loss']:.6f} vs {o_ld['loss'].item():.6f}, "
           f"worst gradient rel L2 {worst:.2e} ({name})")
     assert worst < 1e-3, f"worst per-tensor gradient relative L2 error {worst:.2e} ({name})"
+    # the same batch on the bf16 throughput path - at this size the fused FFN and fused attention kernels run (>= 16,384
+    # rows) - against the same oracle results, with the bounds of the bf16 golden tests; then once more with both fused
+    # kernels switched off: the two bf16 paths must agree with each other far better than either does with fp32
+    import deepsvg_amd.functional as Fn
+    res = {}
+    for fused in (True, False):
+        saved = (Fn.FFN_MIN_ROWS, Fn.ATTN_MIN_ROWS)
+        if not fused:
+            Fn.FFN_MIN_ROWS = Fn.ATTN_MIN_ROWS = 1 << 40
+        try:
+            mb = _hip_model(cfg, sd, torch.bfloat16).eval()
+            ops.PROFILE.clear()
+            ops.PROFILE_ON = True
+            b_out, b_ld, b_grads = _fwd_bwd(mb, cfg, commands, args)
+            ops.PROFILE_ON = False
+            n_fused = sum(1 for r in ops.PROFILE if r[5].get("op") in ("ffn_fwd", "attn_block_fwd"))
+            ops.PROFILE.clear()
+        finally:
+            ops.PROFILE_ON = False
+            Fn.FFN_MIN_ROWS, Fn.ATTN_MIN_ROWS = saved
+        assert (n_fused == 16) if fused else (n_fused == 0), n_fused     # 8 large layers x (FFN, attention)
+        e_c = (b_out["command_logits"].float() - o_out["command_logits"]).abs().max().item()
+        e_a = (b_out["args_logits"].float() - o_out["args_logits"]).abs().max().item()
+        agree = (b_out["command_logits"].argmax(-1) == o_out["command_logits"].argmax(-1)).float().mean().item()
+        lrel = max(abs(b_ld[k] - o_ld[k].item()) / max(1.0, abs(o_ld[k].item())) for k in o_ld)
+        rel = sorted(abs(b_grads[n].double().norm().item() - o_grads[n].double().norm().item())
+                     / max(o_grads[n].double().norm().item(), 1e-8) for n in o_grads)
+        _parity_log(f"N=512 bf16 ({'fused FFN + attention kernels' if fused else 'unfused launches'}) vs fp32 oracle: "
+                    f"command_logits max abs {e_c:.3e} (argmax agree {agree:.4f}), args_logits max abs {e_a:.3e}, "
+                    f"worst loss-term rel {lrel:.3e}, grad-norm rel median {rel[len(rel) // 2]:.3e} max {rel[-1]:.3e}")
+        assert e_c < 0.09 and e_a < 0.12 and agree > 0.98 and lrel < 6e-3
+        assert rel[len(rel) // 2] < 6e-3 and rel[-1] < 7e-2
+        res[fused] = (b_ld["loss"], b_out["command_logits"].float())
+    assert abs(res[True][0] - res[False][0]) <= 2e-3 * abs(res[False][0])
 
 
 @pytest.mark.parametrize("tag", H.sample_cases())
