@@ -131,7 +131,9 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
 
     // ---- this wave's tile: rows [row0, row0 + S) ----------------------------------------------------------------------------
     const int b = blockIdx.x * TILES_PER_WG + wave;
-    const int n_tiles = TILED ? tile_first[n_seq + 1] : n_seq;
+    // dense layouts: a tile holds per = 32 / Smax whole sequences (one for the 17..32-token stages, four for 8-token groups)
+    const int per = TILED ? 1 : 32 / Smax;
+    const int n_tiles = TILED ? tile_first[n_seq + 1] : (n_seq + per - 1) / per;
     const long long real_rows = TILED ? (long long)seq_off[n_seq] : (long long)n_seq * Smax;
     long long row0 = 0;
     int S = 0, s_first = 0, n_in = 1;
@@ -143,9 +145,10 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
             row0 = seq_off[s_first];
             S = seq_off[s_first + n_in] - (int)row0;
         } else {
-            s_first = b;
-            row0 = (long long)b * Smax;
-            S = Smax;
+            s_first = b * per;
+            n_in = min(per, n_seq - s_first);
+            row0 = (long long)s_first * Smax;
+            S = n_in * Smax;
         }
     } else {        // rows past the last sequence (bucket padding): tiles of 32 rows that attend to themselves only
         pad_tile = true;
@@ -172,10 +175,15 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
         my_seq = s_first + qi;
         my_start = a0 - (int)row0;
         my_len = a1 - a0;
+    } else {
+        const int qi = min(li / Smax, n_in - 1);
+        my_seq = s_first + qi;
+        my_start = qi * Smax;
+        my_len = Smax;
     }
-    uint32_t km;
-    if (TILED || pad_tile) km = (uint32_t)(((1ull << my_len) - 1ull) << my_start);
-    else km = (key_mask ? (uint32_t)key_mask[b] : ~0u) & (uint32_t)((1ull << S) - 1ull);
+    uint32_t km = (uint32_t)((1ull << my_len) - 1ull);
+    if (!TILED && !pad_tile && key_mask) km &= (uint32_t)key_mask[my_seq];
+    km <<= my_start;
     const bool row_live = li < S;
     long long my_row = row0 + (S > 0 ? min(li, S - 1) : 0);     // rows past S: a clamped copy, computed but never stored
     if (S <= 0 || my_row >= total_rows) my_row = 0;
@@ -539,7 +547,8 @@ extern "C" int dsvg_attn_block_fwd(const void* x, const void* packed_layer, cons
         const long long a = n_seq + (rows + 31) / 32, b = rows / 16 + 2;
         waves = a < b ? a : b;
     } else {
-        waves = n_seq + (rows - n_seq * S + 31) / 32;
+        const int per = 32 / S;                     // whole sequences per tile
+        waves = (n_seq + per - 1) / per + (rows - n_seq * S + 31) / 32;
     }
     const int nb = (int)((waves + TILES_PER_WG - 1) / TILES_PER_WG);
     hipStream_t st = (hipStream_t)stream;

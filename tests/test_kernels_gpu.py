@@ -1115,14 +1115,16 @@ def _attn_case(kind, seed):
         km = ((torch.ones(n_seq, dtype=torch.int64) << lens) - 1).to(DEV)
         return n_seq * S, n_seq, S, km, None, None, n_seq * S
     if kind == "dense8_masked_tail":
-        n_seq, S = 1000, 8
+        n_seq, S = 1001, 8            # four sequences per 32-row tile, the last tile holds one
         lens = torch.randint(1, S + 1, (n_seq,), generator=g)
         km = ((torch.ones(n_seq, dtype=torch.int64) << lens) - 1).to(DEV)
         return n_seq * S + 40, n_seq, S, km, None, None, n_seq * S
+    if kind == "dense10":           # three sequences per tile (30 of 32 rows)
+        return 500 * 10, 500, 10, None, None, None, 500 * 10
     raise KeyError(kind)
 
 
-@pytest.mark.parametrize("kind", ["packed", "dense31", "dense32_masked", "dense8_masked_tail"])
+@pytest.mark.parametrize("kind", ["packed", "dense31", "dense32_masked", "dense8_masked_tail", "dense10"])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_attn_block_fwd_equals_unfused_kernels(gpu_device, kind, p):
     """the fused attention block against the four launches it replaces (LayerNorm, in_proj GEMM, attention, out_proj GEMM
