@@ -362,6 +362,19 @@ def main():
                               "largest_launch": {"rows": big, "avg_us": round(big_us, 1),
                                                  "TFLOPs": round(big_flop / big_us * 1e-6, 1),
                                                  "frac": round(big_flop / big_us * 1e-6 / peak_tf, 4)}}
+            # the launches that take the most time in the step are not MFMA-bound: the weight-gradient GEMMs (token-major
+            # operands of 0.5-1.5 KB per token read once, a 256 x 256 .. 768 x 256 result) are HBM-bound.  Timed with their
+            # split-K reductions (immediate in this leg; queued and batched in the timed step)
+            wg = [r for r in ops.PROFILE if len(r[5]) and r[5].get("split_k", 1) > 1 and r[0] in ("wgrad", "ffn")]
+            wgrad = None
+            if wg:
+                wg_ms = sum(r[1].elapsed_time(r[2]) for r in wg) / n_prof
+                wg_bytes = sum(r[4] for r in wg) / n_prof
+                wgrad = {"kernel": "weight-gradient GEMMs (dW = dY^T X over all tokens, split-K) incl. their reductions",
+                         "bound": "hbm", "launches_per_step": len(wg) // n_prof, "ms_per_step": round(wg_ms, 3),
+                         "algorithmic_GB_per_step": round(wg_bytes / 1e9, 3),
+                         "achieved_GBps": round(wg_bytes / (wg_ms * 1e-3) / 1e9, 1), "peak_GBps": 8000.0,
+                         "frac": round(wg_bytes / (wg_ms * 1e-3) / 1e9 / 8000.0, 4)}
             roofline = {"bound": "mfma",
                         "kernel": "FFN sub-block of the 16 layers (fused forward kernel / linear1+linear2 GEMMs, dX, dW), "
                                   "%d launches per step" % n_ffn,
@@ -377,6 +390,7 @@ def main():
                                                  "note": "round 1's accounting: launches that execute FLOPs only"},
                         "fused_fwd_kernel": fused_fwd,
                         "fused_attn_fwd_kernel": fused_attn,
+                        "weight_grad_gemms": wgrad,
                         "hbm_view": {"achieved_GBps": round(gbs, 1), "peak_GBps": 8000.0, "frac": round(gbs / 8000.0, 4),
                                      "fused_algorithmic_GB_per_step": round(fused_bytes / 1e9, 3),
                                      "definition": "SURVEY.md 8(d) fused byte count: 1024 B per token-layer forward; "

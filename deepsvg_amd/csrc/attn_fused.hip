@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
         int n_seq, int Smax, long long total_rows, bf16_t* __restrict__ x1, bf16_t* __restrict__ xn_out,
         bf16_t* __restrict__ qkv_out, bf16_t* __restrict__ ao_out, float* __restrict__ mean_out,
         float* __restrict__ rstd_out, float eps, float scale, float drop_p, const uint64_t* __restrict__ seed,
-        uint32_t site_p, uint32_t site_r) {
+        uint32_t site_p, uint32_t site_r, const bf16_t* __restrict__ gadd, uint32_t site_g) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];   // [NBUF slots | biases, gamma, beta | 8 staging tiles]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -249,6 +249,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
     __builtin_amdgcn_sched_barrier(0);      // (the zeroed operand queue below must not be hoisted above the LayerNorm)
     const DropCtx dp = drop_make(drop_p, seed, site_p);
     const DropCtx dr = drop_make(drop_p, seed, site_r);
+    const DropCtx dg = drop_make(drop_p, seed, site_g);
     const char* lbase = smem + lane * 16;
     auto ld = [&](const char* p) -> uint4 { return *reinterpret_cast<const uint4*>(p); };
 
@@ -444,16 +445,23 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
     // ---- out_proj: two 32-row blocks of outputs per chunk, + bias, dropout, residual ---------------------------------------------
     const long long m = row0 + li;
     const char* xres = reinterpret_cast<const char*>(x) + (size_t)my_row * (AD * 2);
+    // optional per-sequence conditioning row (the decoder's linear_global(z), improved_transformer.py:131-136): x1 += drop(g)
+    // with one mask element per (sequence, channel) - ids seq * 256 + column - as dsvg_bcast_add_fwd draws them
+    const char* grow = gadd ? reinterpret_cast<const char*>(gadd) + (size_t)my_seq * (AD * 2) : nullptr;
     char* yrow = reinterpret_cast<char*>(x1) + (size_t)my_row * (AD * 2);
 #pragma unroll 1
     for (int u = 0; u < 4; ++u) {
         if (!late) sync(16 + u);
         const char* sl = lbase + ((16 + u) % NBUF) * SLOT;
-        uint4 res[4];
+        uint4 res[4], gr[4];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             res[2 * tt] = *reinterpret_cast<const uint4*>(xres + (32 * (2 * u + tt) + 16 * h2) * 2);
             res[2 * tt + 1] = *reinterpret_cast<const uint4*>(xres + (32 * (2 * u + tt) + 16 * h2 + 8) * 2);
+            if (grow) {
+                gr[2 * tt] = *reinterpret_cast<const uint4*>(grow + (32 * (2 * u + tt) + 16 * h2) * 2);
+                gr[2 * tt + 1] = *reinterpret_cast<const uint4*>(grow + (32 * (2 * u + tt) + 16 * h2 + 8) * 2);
+            }
         }
         floatx16 ya[2];
 #pragma unroll
@@ -493,6 +501,18 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
                 unpack8(res[2 * tt + cb], rv);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                if (grow) {
+                    float gv[8];
+                    unpack8(gr[2 * tt + cb], gv);
+                    if (dg.on) {
+                        float gm[8];
+                        drop_mult8(dg, (uint64_t)my_seq * AD + n16 + 8 * cb, gm);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gv[e] *= gm[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += gv[e];
+                }
                 pk[cb] = pack8(v);
             }
             if (row_live) {
@@ -527,7 +547,8 @@ extern "C" int dsvg_attn_block_fwd(const void* x, const void* packed_layer, cons
                                    const float* gamma, const float* beta, const uint64_t* key_mask, const int32_t* seq_off,
                                    const int32_t* tile_first, int64_t n_seq, int32_t S, int64_t rows, void* x1, void* xn_out,
                                    void* qkv_out, void* ao_out, float* mean_out, float* rstd_out, float eps, float scale,
-                                   float drop_p, uint32_t site_probs, uint32_t site_res, const void* seed, void* stream) {
+                                   float drop_p, uint32_t site_probs, uint32_t site_res, const void* seed,
+                                   const void* seq_add, uint32_t site_seq_add, void* stream) {
     DSVG_CHECK_ARG(x && packed_layer && in_bias && out_bias && gamma && beta && x1, "attn_block_fwd: null pointer");
     DSVG_CHECK_ARG(S >= 1 && S <= 32, "attn_block_fwd: sequences of at most 32 tokens (got %d)", S);
     DSVG_CHECK_ARG(n_seq > 0 && rows > 0 && rows < (1ll << 31), "attn_block_fwd: bad sizes");
@@ -539,7 +560,8 @@ extern "C" int dsvg_attn_block_fwd(const void* x, const void* packed_layer, cons
     const bool train = xn_out != nullptr;
     DSVG_CHECK_ARG(!train || (qkv_out && ao_out && mean_out && rstd_out), "attn_block_fwd: the training outputs come together");
     DSVG_CHECK_ARG((((uintptr_t)x | (uintptr_t)x1 | (uintptr_t)packed_layer | (uintptr_t)xn_out | (uintptr_t)qkv_out |
-                     (uintptr_t)ao_out) & 15) == 0, "attn_block_fwd: operands must be 16-byte aligned");
+                     (uintptr_t)ao_out | (uintptr_t)seq_add) & 15) == 0, "attn_block_fwd: operands must be 16-byte aligned");
+    DSVG_CHECK_ARG(!seq_add || !tiled, "attn_block_fwd: the per-sequence add is wired for the dense layouts");
     // waves: one per attention tile + one per 32 rows of bucket padding behind the last sequence.  Adjacent tiles of the
     // packed layout hold more than 32 rows together, so there are at most rows / 16 + 1 of them (and at most n_seq)
     long long waves;
@@ -561,7 +583,7 @@ extern "C" int dsvg_attn_block_fwd(const void* x, const void* packed_layer, cons
                            (const bf16_t*)packed_layer, in_bias, out_bias, gamma, beta, key_mask, seq_off, tile_first, \
                            (int)n_seq, (int)S, (long long)rows, (bf16_t*)x1, (bf16_t*)xn_out, (bf16_t*)qkv_out,        \
                            (bf16_t*)ao_out, mean_out, rstd_out, eps, scale, drop_p, (const uint64_t*)seed, site_probs, \
-                           site_res);                                                                                  \
+                           site_res, (const bf16_t*)seq_add, site_seq_add);                                            \
     } while (0)
     if (train) { if (tiled) DSVG_ATTN_FWD(true, true); else DSVG_ATTN_FWD(true, false); }
     else { if (tiled) DSVG_ATTN_FWD(false, true); else DSVG_ATTN_FWD(false, false); }

@@ -96,12 +96,17 @@ class Runtime:
         return torch.empty(param.shape, dtype=torch.float32, device=param.device)
 
 
+def _wgrad_tag():
+    """profiling label of the weight-gradient GEMMs outside the FFN sub-block (bench.py's roofline leg)"""
+    return ops.tag_default("wgrad") if ops.PROFILE_ON else _NULL_CTX
+
+
 def _wgrad(rt, param, dy, x, *, a_drop_p=0.0, a_drop_site=0):
     """dW[n_out, k_in] = sum_t drop(dy)[t, n_out] * x[t, k_in]   (both operands token-major: a TN GEMM)"""
     out = rt.grad_out(param)
     n_out, k_in = param.shape
     T = dy.shape[0]
-    with rt.on_side(dy, x, rows=T), rt.deferring():
+    with rt.on_side(dy, x, rows=T), rt.deferring(), _wgrad_tag():
         ops.gemm(dy, x, a_kc=False, b_kc=False, out=out.view(n_out, k_in), a_drop_p=a_drop_p, a_drop_site=a_drop_site,
                  seed=rt.seed, split_k=ops.split_k_for(n_out, k_in, T))
     return out
@@ -115,7 +120,7 @@ def _wbgrad(rt, weight, bias, dy, x):
     split = ops.split_k_for(n_out, k_in, dy.shape[0])
     dw = rt.grad_out(weight)
     db = rt.grad_out(bias)
-    with rt.on_side(dy, x, rows=dy.shape[0]), rt.deferring():
+    with rt.on_side(dy, x, rows=dy.shape[0]), rt.deferring(), _wgrad_tag():
         if split > 1:
             ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in), split_k=split, rowsum=db)
         else:
@@ -442,13 +447,19 @@ class LayerFn(torch.autograd.Function):
                 and n_heads == 8 and d == 256 and (seq_off is None or tiles is not None)
                 and (key_mask is None or key_mask.dtype == torch.int64)):
             att = rt.store.attn(win)
+        z_fused = False
         if att is not None:
-            # one launch: LayerNorm, in_proj, the 8 heads, out_proj, dropout, residual (csrc/attn_fused.hip).  With a
+            # one launch: LayerNorm, in_proj, the 8 heads, out_proj, dropout, residual (csrc/attn_fused.hip) - and the
+            # decoder's per-sequence conditioning add when the layout is dense and every row belongs to a sequence.  With a
             # backward pass ahead it also stores LN(x), q|k|v, the head outputs and the row statistics
+            g = None
+            if z is not None and seq_off is None and x.shape[0] == n_seq * S:
+                g = ops.gemm(z, rt.w(wg), bias=bg.detach())
+                z_fused = True
             with ops.tag("attn"):
                 res = ops.attn_block_fwd(x, att, bin_.detach(), bo.detach(), n1w.detach(), n1b.detach(), key_mask, n_seq,
                                          S, scale, 1e-5, p, site0, site0 + 1, rt.seed, seq_off=seq_off, tiles=tiles,
-                                         train=want_bwd)
+                                         train=want_bwd, seq_add=g, site_seq_add=site0 + 2)
             if want_bwd:
                 x1, xn1, qkv, ao, mean1, rstd1 = res
             else:
@@ -463,7 +474,7 @@ class LayerFn(torch.autograd.Function):
                                        tiles=tiles)
             x1 = ops.gemm(ao, rt.w(wo), bias=bo.detach(), res=x, drop_p=p, drop_site=site0 + 1, seed=rt.seed)
         ctx.tiles, ctx.causal = tiles, causal
-        if z is not None:
+        if z is not None and not z_fused:
             g = ops.gemm(z, rt.w(wg), bias=bg.detach())
             ops.bcast_add_fwd_(x1, g, n_seq, S, p, site0 + 2, rt.seed)
         if l is not None:

@@ -34,6 +34,16 @@ class tag:
         return False
 
 
+class tag_default(tag):
+    """like tag, but keeps an enclosing tag (the weight-gradient GEMMs inside the FFN sub-block stay "ffn")"""
+
+    def __enter__(self):
+        global _TAG
+        self.prev = _TAG
+        if _TAG is None:
+            _TAG = self.name
+
+
 def _dt(t):
     if t.dtype == torch.float32:
         return F32
@@ -922,8 +932,9 @@ def attn_pack(flat, offs, n_layers, packed=None):
 
 
 def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_seq, S, scale, eps=1e-5, drop_p=0.0,
-                   site_probs=0, site_res=0, seed=None, seq_off=None, tiles=None, train=False):
-    """x1 = x + drop_r(out_proj(MHA(LayerNorm(x))))  (x bf16 [rows, 256], 8 heads, S <= 32) in one launch.
+                   site_probs=0, site_res=0, seed=None, seq_off=None, tiles=None, train=False, seq_add=None, site_seq_add=0):
+    """x1 = x + drop_r(out_proj(MHA(LayerNorm(x)))) [+ drop(seq_add[sequence])]  (x bf16 [rows, 256], 8 heads, S <= 32)
+    in one launch.  seq_add (bf16 [n_seq, 256], dense layouts): the decoder's per-sequence conditioning term.
     train=False -> x1;  train=True -> (x1, xn, qkv, ao, mean, rstd): what the unfused backward reads."""
     _chk(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, seed, seq_off, tiles)
     rows = x.shape[0]
@@ -932,6 +943,9 @@ def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_
     assert in_bias.numel() == 768 and out_bias.numel() == 256 and gamma.numel() == 256 and beta.numel() == 256
     assert all(t.dtype == torch.float32 and t.is_contiguous() for t in (in_bias, out_bias, gamma, beta))
     assert (seq_off is None) == (tiles is None) and (seq_off is None or key_mask is None)
+    if seq_add is not None:
+        _chk(seq_add)
+        assert seq_off is None and seq_add.dtype == x.dtype and seq_add.is_contiguous() and tuple(seq_add.shape) == (n_seq, 256)
     x1 = torch.empty_like(x)
     xn = qkv = ao = mean = rstd = None
     if train:
@@ -945,7 +959,8 @@ def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_
                                            gamma.data_ptr(), beta.data_ptr(), _p(key_mask), _p(seq_off), _p(tiles), n_seq,
                                            S, rows, x1.data_ptr(), _p(xn), _p(qkv), _p(ao), _p(mean), _p(rstd), float(eps),
                                            float(scale), float(drop_p), int(site_probs), int(site_res),
-                                           _p(seed) if drop_p > 0 else None, _stream()), "dsvg_attn_block_fwd")
+                                           _p(seed) if drop_p > 0 else None, _p(seq_add), int(site_seq_add), _stream()),
+             "dsvg_attn_block_fwd")
     _prof_end(ev, 2.0 * rows * 256 * 1024 + 4.0 * rows * 32 * 256, 1024.0 * rows + (2560.0 * rows if train else 0.0),
               dict(op="attn_block_fwd", rows=rows, train=bool(train)))
     if train:

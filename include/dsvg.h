@@ -421,6 +421,9 @@ int dsvg_ffn_wgrad_finish(const float* g1p, const float* db1p, const float* g2p,
  *   block-diagonal attention inside each tile of <= 32 rows).  Rows behind the last sequence (bucket padding up to
  *   `rows`) get finite values.  Dropout: site_probs on the probabilities (same element ids as dsvg_attention_fwd),
  *   site_res on the residual branch (ids row*256 + col, replayable by dsvg_drop_apply).
+ *   seq_add (optional, dense layouts): bf16 [n_seq, 256], x1 += drop(seq_add[sequence]) with one mask element per
+ *   (sequence, channel), site_seq_add - the decoder's linear_global(z) term (improved_transformer.py:131-136), same draws
+ *   as dsvg_bcast_add_fwd, whose backward (dsvg_bcast_add_bwd) applies unchanged.
  *   Training outputs (all NULL for inference, all set otherwise) are what the unfused backward reads:
  *   xn_out = LayerNorm(x) bf16 [rows,256], qkv_out bf16 [rows,768], ao_out = head outputs bf16 [rows,256],
  *   mean_out / rstd_out fp32 [rows].
@@ -432,7 +435,8 @@ int dsvg_attn_block_fwd(const void* x, const void* packed_layer, const float* in
                         const float* gamma, const float* beta, const uint64_t* key_mask, const int32_t* seq_off,
                         const int32_t* tile_first, int64_t n_seq, int32_t S, int64_t rows, void* x1, void* xn_out,
                         void* qkv_out, void* ao_out, float* mean_out, float* rstd_out, float eps, float scale,
-                        float drop_p, uint32_t site_probs, uint32_t site_res, const void* seed, void* stream);
+                        float drop_p, uint32_t site_probs, uint32_t site_res, const void* seed,
+                        const void* seq_add, uint32_t site_seq_add, void* stream);
 /* test hook: raw ds_read_b64_tr_b16 on a 4 KiB LDS image img[i]=i, lane l reads at byte offset off[l] */
 int dsvg_probe_trread(const int* off, short* out, void* stream);
 

@@ -1166,3 +1166,12 @@ def test_attn_block_fwd_equals_unfused_kernels(gpu_device, kind, p):
     # the typical element agrees far better than the worst one
     assert ((x1[r].float() - want[r].float()).abs().mean() <= 2e-3 * want[r].float().abs().mean()).item()
     assert ((qkv[r].float() - qkv0[r].float()).abs().mean() <= 1e-3 * qkv0[r].float().abs().mean()).item()
+    if seq_off is None and rows == n_seq * S:
+        # the decoder's per-sequence conditioning term in the same launch: x1 += drop(g[sequence]), one mask element per
+        # (sequence, channel) - against dsvg_bcast_add_fwd on the unfused result
+        g = (_rand(n_seq, 256, seed=41) * 0.7).to(torch.bfloat16)
+        want_g = ops.bcast_add_fwd_(want.clone(), g, n_seq, S, p, 9, seed)
+        x1g = ops.attn_block_fwd(x, packed, prm["in_bias"], prm["out_bias"], prm["gamma"], prm["beta"], km, n_seq, S, scale,
+                                 1e-5, p, 7, 8, seed, train=False, seq_add=g, site_seq_add=9)
+        _close(x1g, want_g, 2e-2, "x1 with the per-sequence add")
+        assert not torch.equal(x1g, x1)

@@ -792,13 +792,15 @@ def attn_pack(flat, offs, n_layers, packed=None):
 
 
 def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_seq, S, scale, eps=1e-5, drop_p=0.0,
-                   site_probs=0, site_res=0, seed=None, seq_off=None, tiles=None, train=False):
-    """the unfused launches, composed (LayerNorm -> in_proj -> attention -> out_proj + dropout + residual)"""
+                   site_probs=0, site_res=0, seed=None, seq_off=None, tiles=None, train=False, seq_add=None, site_seq_add=0):
+    """the unfused launches, composed (LayerNorm -> in_proj -> attention -> out_proj + dropout + residual [-> bcast add])"""
     win, wo = packed_layer[:196608].view(768, 256), packed_layer[196608:].view(256, 256)
     xn, mean, rstd = layernorm_fwd(x, gamma, beta, eps)
     qkv = gemm(xn, win, bias=in_bias)
     ao = attention_fwd(qkv, key_mask, n_seq, S, 8, scale, drop_p, site_probs, seed, seq_off=seq_off, tiles=tiles)
     x1 = gemm(ao, wo, bias=out_bias, res=x, drop_p=drop_p, drop_site=site_res, seed=seed)
+    if seq_add is not None:
+        bcast_add_fwd_(x1, seq_add, n_seq, S, drop_p, site_seq_add, seed)
     if train:
         return x1, xn, qkv, ao, mean, rstd
     return x1
