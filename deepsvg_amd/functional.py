@@ -30,6 +30,8 @@ FFN_MIN_ROWS = int(os.environ.get("DSVG_FFN_MIN_ROWS", "16384"))
 # the fused attention block owns 8 tiles of <= 32 rows per workgroup (same granularity: unfused launches below this)
 ATTN_MIN_ROWS = int(os.environ.get("DSVG_ATTN_MIN_ROWS", "16384"))
 SIDE_MAX_ROWS = int(os.environ.get("DSVG_SIDE_MAX_ROWS", "16384"))
+# fused-FFN backward: weight-gradient GEMMs right behind the producers of their operands (1) or at the end (0)
+FFN_BWD_ORDER = os.environ.get("DSVG_FFN_BWD_ORDER", "1") != "0"
 
 
 _NULL_CTX = contextlib.nullcontext()
@@ -524,45 +526,62 @@ class LayerFn(torch.autograd.Function):
             pb, b1f, w2p = rt.store.ffn(w1)[1:]
             T = x1.shape[0]
             with ops.tag("ffn"):
-                if h is None:
-                    # fully fused variant (opt-in, DSVG_FFN_BWD_FUSED=1): hidden tile recomputed from x1, both dropout
-                    # masks replayed in the kernel; measured slower than the default below (it writes h, dpre, xh AND dym)
-                    dx1, hp, dpre, xh, dym = ops.ffn_bwd(x1, dx2, pb, b1f, 1e-5, p, s0 + 3, s0 + 4, rt.seed)
-                else:
-                    # default: the forward kernel stored h (fragment order) and xh.  dym = residual mask replayed once;
-                    # dpre = (dym . W2p) gated by h (h > 0 <=> ReLU passed AND kept) in one GEMM; dx by the fused kernel
-                    # (dpre . W1' with the LayerNorm backward in its epilogue)
-                    hp, xh = h, xn2
-                    dym = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
-                    dpre = ops.gemm(dym, w2p, b_kc=False, gate=hp, gate_scale=inv_keep)
-                    dx1 = ops.ffn_bwd_dx(dpre, x1, dx2, pb)
                 g2p = torch.empty((256, 512), dtype=torch.float32, device=x1.device)
                 g1p = torch.empty((512, 256), dtype=torch.float32, device=x1.device)
                 db1p = torch.empty(512, dtype=torch.float32, device=x1.device)
                 db2 = rt.grad_out(b2)
-                with rt.on_side(dym, hp, dpre, xh, rows=T), rt.deferring():
-                    s2, s1 = ops.split_k_for(256, 512, T), ops.split_k_for(512, 256, T)
-                    if s2 > 1:
-                        ops.gemm(dym, hp, a_kc=False, b_kc=False, out=g2p, split_k=s2, rowsum=db2)
-                    else:
-                        ops.gemm(dym, hp, a_kc=False, b_kc=False, out=g2p)
-                        ops.colsum(dym, out=db2)
-                    if s1 > 1:
-                        ops.gemm(dpre, xh, a_kc=False, b_kc=False, out=g1p, split_k=s1, rowsum=db1p)
-                    else:
-                        ops.gemm(dpre, xh, a_kc=False, b_kc=False, out=g1p)
-                        ops.colsum(dpre, out=db1p)
-                    dw1, db1, dw2 = rt.grad_out(w1), rt.grad_out(b1), rt.grad_out(w2)
-                    dn2w, dn2b = rt.grad_out(n2w), rt.grad_out(n2b)
-                    # (aliases of the gradient tensors: AccumulateGrad adopts a returned gradient only while nobody else
-                    # holds a reference to that tensor object, otherwise it clones it - here before it is even written)
-                    finish = functools.partial(ops.ffn_wgrad_finish, g1p, db1p, g2p, w1.detach(), n2w.detach(),
-                                               n2b.detach(), dw1.detach(), db1.detach(), dw2.detach(), dn2w.detach(),
-                                               dn2b.detach())
-                    if rt.defer:
-                        ops.defer_post(finish)      # reads the queued reductions' outputs: runs right after the flush
-                    else:
-                        finish()
+                s2, s1 = ops.split_k_for(256, 512, T), ops.split_k_for(512, 256, T)
+
+                def wgrad2(dym, hp):        # G2p = dym^T h (fragment-ordered columns), db2 = its row sums
+                    with rt.on_side(dym, hp, rows=T), rt.deferring():
+                        if s2 > 1:
+                            ops.gemm(dym, hp, a_kc=False, b_kc=False, out=g2p, split_k=s2, rowsum=db2)
+                        else:
+                            ops.gemm(dym, hp, a_kc=False, b_kc=False, out=g2p)
+                            ops.colsum(dym, out=db2)
+
+                def wgrad1(dpre, xh):       # G1p = dpre^T xh, db1' = its row sums
+                    with rt.on_side(dpre, xh, rows=T), rt.deferring():
+                        if s1 > 1:
+                            ops.gemm(dpre, xh, a_kc=False, b_kc=False, out=g1p, split_k=s1, rowsum=db1p)
+                        else:
+                            ops.gemm(dpre, xh, a_kc=False, b_kc=False, out=g1p)
+                            ops.colsum(dpre, out=db1p)
+
+                if h is None:
+                    # fully fused variant (opt-in, DSVG_FFN_BWD_FUSED=1): hidden tile recomputed from x1, both dropout
+                    # masks replayed in the kernel; measured slower than the default below (it writes h, dpre, xh AND dym)
+                    dx1, hp, dpre, xh, dym = ops.ffn_bwd(x1, dx2, pb, b1f, 1e-5, p, s0 + 3, s0 + 4, rt.seed)
+                    wgrad2(dym, hp)
+                    wgrad1(dpre, xh)
+                else:
+                    # default: the forward kernel stored h (fragment order) and xh.  dym = residual mask replayed once;
+                    # dpre = (dym . W2p) gated by h (h > 0 <=> ReLU passed AND kept) in one GEMM; dx by the fused kernel
+                    # (dpre . W1' with the LayerNorm backward in its epilogue).  Each weight-gradient GEMM runs right
+                    # behind the launch that produced its token-major operand (dym, dpre: 65 / 130 MB that are then still
+                    # partly in the memory-side cache) instead of at the end
+                    hp, xh = h, xn2
+                    dym = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
+                    if FFN_BWD_ORDER:
+                        wgrad2(dym, hp)
+                    dpre = ops.gemm(dym, w2p, b_kc=False, gate=hp, gate_scale=inv_keep)
+                    if FFN_BWD_ORDER:
+                        wgrad1(dpre, xh)
+                    dx1 = ops.ffn_bwd_dx(dpre, x1, dx2, pb)
+                    if not FFN_BWD_ORDER:
+                        wgrad2(dym, hp)
+                        wgrad1(dpre, xh)
+                dw1, db1, dw2 = rt.grad_out(w1), rt.grad_out(b1), rt.grad_out(w2)
+                dn2w, dn2b = rt.grad_out(n2w), rt.grad_out(n2b)
+                # (aliases of the gradient tensors: AccumulateGrad adopts a returned gradient only while nobody else
+                # holds a reference to that tensor object, otherwise it clones it - here before it is even written)
+                finish = functools.partial(ops.ffn_wgrad_finish, g1p, db1p, g2p, w1.detach(), n2w.detach(),
+                                           n2b.detach(), dw1.detach(), db1.detach(), dw2.detach(), dn2w.detach(),
+                                           dn2b.detach())
+                if rt.defer:
+                    ops.defer_post(finish)      # reads the queued reductions' outputs: runs right after the flush
+                else:
+                    finish()
             del hp, dpre, xh, dym
         else:
             # ---- FFN: x2 = x1 + drop4(h W2^T + b2),  h = drop3(relu(xn2 W1^T + b1)) ----
