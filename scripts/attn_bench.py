@@ -36,6 +36,16 @@ def main():
     ga, be = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
     seed = torch.tensor([12345], dtype=torch.int64, device=DEV)
     scale = 32 ** -0.5
+    if "--pmc-unfused" in sys.argv:     # the four launches the fused kernel replaces, same shape (FETCH / WRITE passes)
+        n_seq, S = 4096, 31
+        x = (torch.randn(n_seq * S, 256, generator=g) * 1.5).to(DEV).to(torch.bfloat16)
+        for _ in range(3):
+            xn, m, r = ops.layernorm_fwd(x, ga, be, 1e-5)
+            qkv = ops.gemm(xn, win, bias=bi)
+            ao = ops.attention_fwd(qkv, None, n_seq, S, 8, scale, 0.1, 7, seed)
+            ops.gemm(ao, wo, bias=bo, res=x, drop_p=0.1, drop_site=8, seed=seed)
+        torch.cuda.synchronize()
+        return
     if "--pmc" in sys.argv:         # counter collection (scripts/gpu_attn_pmc.sh): three launches of each variant, no timing
         n_seq, S = 4096, 31
         x = (torch.randn(n_seq * S, 256, generator=g) * 1.5).to(DEV).to(torch.bfloat16)
