@@ -135,11 +135,12 @@ __global__ __launch_bounds__(HG * SP) void attn_fwd_kernel(
             l += s[j];
         }
         const float inv = 1.f / l;
-        const uint64_t ebase = (((uint64_t)b * H + h) * Smax + i) * Smax;
+        const uint64_t drow = ((uint64_t)b * H + h) * Smax + i;       // dropout row of this (sequence, head, query)
+        const uint32_t hr0 = attn_drop_row(dc, drow, 0), hr1 = SP > 32 ? attn_drop_row(dc, drow, 1) : 0u;
 #pragma unroll
         for (int j = 0; j < SP; ++j) {
             if (j < S) {
-                const float pj = s[j] * inv * drop_mult(dc, ebase + j);
+                const float pj = s[j] * inv * attn_drop_key(dc, j < 32 ? hr0 : hr1, j);
                 float vr[32];
                 row32_load(tile + j * C::LD + 2 * C::W + hh * 32, vr);
 #pragma unroll
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
     const uint64_t km = causal ? (km_all & (i >= 63 ? ~0ull : ((2ull << i) - 1ull))) : km_all;
     const DropCtx dc = drop_make(drop_p, seed, drop_site);
     const bool active = i < S;
-    const uint64_t hbase = ((uint64_t)b * H + h) * Smax;   // element id of (i, j) = (hbase + i) * Smax + j
+    const uint64_t hbase = ((uint64_t)b * H + h) * Smax;   // dropout row of query i = hbase + i, key j counted in the sequence
 
     float dq[32];
 #pragma unroll
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
         const float lse = m + __logf(l);
         float dp[SP];
         float D = 0.f;
+        const uint32_t hr0 = attn_drop_row(dc, hbase + i, 0), hr1 = SP > 32 ? attn_drop_row(dc, hbase + i, 1) : 0u;
 #pragma unroll
         for (int j = 0; j < SP; ++j) {
             dp[j] = 0.f;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
 #pragma unroll
                 for (int c = 0; c < 32; ++c) acc = fmaf(go[c], vr[c], acc);
                 s[j] *= inv;                                                  // P_ij
-                dp[j] = acc * drop_mult(dc, (hbase + i) * Smax + j);            // dP_ij
+                dp[j] = acc * attn_drop_key(dc, j < 32 ? hr0 : hr1, j);        // dP_ij
                 D = fmaf(s[j], dp[j], D);
             }
         }
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(HG * SP) void attn_bwd_kernel(
                 for (int c = 0; c < 32; ++c) { sacc = fmaf(q[c], kr[c], sacc); dacc = fmaf(go[c], vr[c], dacc); }
                 const float lse = stat[(hh * SP + r) * 2 + 0];
                 const float D = stat[(hh * SP + r) * 2 + 1];
-                const float mult = drop_mult(dc, (hbase + r) * Smax + j);
+                const float mult = attn_drop_mult(dc, hbase + r, j);
                 const float p = __expf(sacc * scale - lse);
                 const float pd = p * mult;                                   // dropped probability used in O = P~ V
                 const float ds = p * (dacc * mult - D) * scale;             // dS_rj * scale (q unscaled below)

@@ -200,10 +200,10 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.f / l;
-    // element id of (query i, key j) of sequence s: ((s H + h) Smax + i) Smax + j with i, j counted inside the sequence
-    const uint64_t ebase = (((uint64_t)my_seq * H + h) * Smax + (li - my_start)) * Smax - my_start;
+    // dropout row of (sequence s, head h, query i) = (s H + h) Smax + i; query and key counted inside the sequence
+    const uint32_t hrow = attn_drop_row(dc, ((uint64_t)my_seq * H + h) * Smax + (li - my_start), 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p[r] = p[r] * inv * drop_mult(dc, ebase + rowmap(r, h2));
+    for (int r = 0; r < 16; ++r) p[r] = p[r] * inv * attn_drop_key(dc, hrow, (uint32_t)(rowmap(r, h2) - my_start));
     if (li >= S) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) p[r] = 0.f;     // padded query row: keep NaNs of an all-masked row out of the MFMA
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
     bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);          // [32][LD]   q|k|v
     bf16_t* dtile = tile + 32 * LD;                              // [32][LDO]  dO
     float* stat = reinterpret_cast<float*>(dtile + 32 * LDO);    // [HG][32][2] lse, D
-    int* soff = reinterpret_cast<int*>(stat + HG * 64);          // [34] sequence offsets of the tile (TILED)
+    int* soff = reinterpret_cast<int*>(stat + HG * 96);          // [34] sequence offsets of the tile (TILED)
     const int b = blockIdx.x, hg = blockIdx.y, d = H * 32;
     const int lane = threadIdx.x & 63, hh = threadIdx.x >> 6;
     const int li = lane & 31, h2 = lane >> 5;
@@ -282,9 +282,9 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
                                    : ((key_mask ? (uint32_t)key_mask[b] : ~0u) & (uint32_t)((1ull << S) - 1ull));
     const DropCtx dc = drop_make(drop_p, seed, drop_site);
     const int qc = hh * 32, kc = W + hh * 32, vc = 2 * W + hh * 32, oc = hh * 32;
-    // id(q, key) = ((seq H + h) Smax + q_local) Smax + key_local; q and key are tile rows of the lane's own sequence
+    // dropout row of query tile-row q = hbase + q (= (seq H + h) Smax + q_local); keys counted inside the sequence
     const uint64_t hbase = ((uint64_t)my_seq * H + h) * Smax - my_start;
-    float* my_stat = stat + hh * 64;
+    float* my_stat = stat + hh * 96;        // [32 queries][lse, D, dropout row hash]
 
     floatx16 acc, acc2;
     float p[16], g[16];
@@ -315,17 +315,18 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
     const float inv = 1.f / l;
     const float lse = m + __logf(l);
     float D = 0.f;
+    const uint32_t hrow = attn_drop_row(dc, hbase + li, 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         p[r] *= inv;                                                               // P[q][key]
-        g[r] = acc2[r] * drop_mult(dc, (hbase + li) * Smax + rowmap(r, h2) - my_start);   // dP[q][key]
+        g[r] = acc2[r] * attn_drop_key(dc, hrow, (uint32_t)(rowmap(r, h2) - my_start));   // dP[q][key]
         D = fmaf(p[r], g[r], D);
     }
     D += __shfl_xor(D, 32, 64);
     const bool qvalid = li < S;
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = qvalid ? p[r] * (g[r] - D) * scale : 0.f;  // scale * dS[q][key]
-    if (h2 == 0) { my_stat[li * 2 + 0] = lse; my_stat[li * 2 + 1] = D; }
+    if (h2 == 0) { my_stat[li * 3 + 0] = lse; my_stat[li * 3 + 1] = D; my_stat[li * 3 + 2] = __uint_as_float(hrow); }
     floatx16 dq;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[r] = 0.f;
@@ -361,10 +362,10 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
         for (int e = 0; e < 2; ++e) {
             const int r = 2 * c + e;
             const int q = rowmap(r, h2);
-            const float lse_q = my_stat[q * 2 + 0], D_q = my_stat[q * 2 + 1];
+            const float lse_q = my_stat[q * 3 + 0], D_q = my_stat[q * 3 + 1];
             const bool ok = kvalid && q < S && (!TILED || ((km >> q) & 1u));
             const float pr = ok ? __expf(acc[r] * scale - lse_q) : 0.f;               // P[q][key = li]
-            const float mult = drop_mult(dc, (hbase + q) * Smax + li - my_start);
+            const float mult = attn_drop_key(dc, __float_as_uint(my_stat[q * 3 + 2]), (uint32_t)(li - my_start));
             pv[e] = pr * mult;                                                        // P~ (as used by O = P~ V)
             gv[e] = ok ? pr * (acc2[r] * mult - D_q) * scale : 0.f;                   // scale * dS[q][key]
         }
@@ -419,7 +420,7 @@ int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const int
                             const int32_t* tile_first, const void* dout, void* dqkv, int64_t n_seq, int32_t S,
                             int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
                             hipStream_t st) {
-    const size_t lds = (size_t)32 * (LD + LDO) * sizeof(bf16_t) + (size_t)HG * 64 * sizeof(float) + 34 * sizeof(int);
+    const size_t lds = (size_t)32 * (LD + LDO) * sizeof(bf16_t) + (size_t)HG * 96 * sizeof(float) + 34 * sizeof(int);
     auto kern = tile_first ? attn_bwd_mfma_kernel<true> : attn_bwd_mfma_kernel<false>;
     DSVG_ENSURE_LDS(attn_bwd_mfma_kernel<true>, lds);
     DSVG_ENSURE_LDS(attn_bwd_mfma_kernel<false>, lds);

@@ -387,10 +387,10 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
             }
             l += __shfl_xor(l, 32, 64);
             const float inv = 1.f / l;
-            // element id of (query i, key j) of sequence s: ((s H + h) Smax + i) Smax + j, i and j counted inside the sequence
-            const uint64_t ebase = (((uint64_t)my_seq * AH + h) * Smax + (li - my_start)) * Smax - my_start;
+            // dropout row of (sequence s, head h, query i) = (s H + h) Smax + i; i and the keys counted inside the sequence
+            const uint32_t hrow = attn_drop_row(dp, ((uint64_t)my_seq * AH + h) * Smax + (li - my_start), 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = p[r] * inv * drop_mult(dp, ebase + rowmap(r, h2));
+            for (int r = 0; r < 16; ++r) p[r] = p[r] * inv * attn_drop_key(dp, hrow, (uint32_t)(rowmap(r, h2) - my_start));
             if (!row_live) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) p[r] = 0.f;     // padded query row: keep the NaNs of an all-masked row out of the MFMA

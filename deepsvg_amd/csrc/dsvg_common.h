@@ -197,6 +197,27 @@ __device__ __forceinline__ void drop_mult8(const DropCtx& c, uint64_t idx8, floa
     }
 }
 
+// Dropout of the attention probabilities ("row draws", every attention kernel + tests/torch_ops_ref.py attn_drop_mult):
+// element (row, key) with row = (sequence * heads + head) * S + query and key counted inside the sequence.  ONE counter
+// hash per (row, block of 32 keys) and a one-multiply finaliser per pair of keys - a query row's 32 draws cost one hash
+// + 16 multiplies instead of 3 hashes per element (the per-element ids made the draw 40-60 % of an attention launch).
+__device__ __forceinline__ uint32_t attn_drop_row(const DropCtx& c, uint64_t row, uint32_t key_block) {
+    const uint64_t g = row * 8ull + key_block;          // <= 8 blocks = 256 keys per row
+    const uint32_t h = dsvg_hash32((uint32_t)g ^ c.s0);
+    return dsvg_hash32(h + (uint32_t)(g >> 32) * 0x9e3779b1u + c.s1);
+}
+__device__ __forceinline__ float attn_drop_key(const DropCtx& c, uint32_t hrow, uint32_t key) {
+    if (!c.on) return 1.f;
+    uint32_t w = hrow + (((key & 31u) >> 1) + 1u) * 0x9e3779b9u;
+    w ^= w >> 16; w *= 0x7feb352du; w ^= w >> 15;
+    const uint32_t draw = (key & 1u) ? (w >> 16) : (w & 0xffffu);
+    return draw < c.thresh ? 0.f : c.scale;
+}
+__device__ __forceinline__ float attn_drop_mult(const DropCtx& c, uint64_t row, uint32_t key) {
+    if (!c.on) return 1.f;
+    return attn_drop_key(c, attn_drop_row(c, row, key >> 5), key);
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave-level reductions (64 lanes) and width-limited group reductions
 // ---------------------------------------------------------------------------------------------

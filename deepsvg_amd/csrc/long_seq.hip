@@ -48,8 +48,10 @@ __global__ __launch_bounds__(AL_THREADS) void attn_long_fwd_kernel(const T* __re
         for (int c = 0; c < 32; ++c) { q[c] = Elem<T>::ld(base + (size_t)i * 3 * d + c) * scale; o[c] = 0.f; }
         const int jend = causal ? min(len, i + 1) : len;
         float m = -INFINITY, l = 0.f;
-        const uint64_t ebase = (((uint64_t)b * H + h) * S + i) * S;
+        const uint64_t drow = ((uint64_t)b * H + h) * S + i;         // dropout row (dsvg_common.h: attn_drop_*)
+        uint32_t hrow = 0;
         for (int j = 0; j < jend; ++j) {
+            if ((j & 31) == 0) hrow = attn_drop_row(dc, drow, j >> 5);
             const float* kr = Ks + j * AL_LD;
             float s = 0.f;
 #pragma unroll
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(AL_THREADS) void attn_long_fwd_kernel(const T* __re
             const float mn = fmaxf(m, s);
             const float corr = __expf(m - mn), e = __expf(s - mn);
             l = l * corr + e;
-            const float pe = e * drop_mult(dc, ebase + j);
+            const float pe = e * attn_drop_key(dc, hrow, j);
             const float* vr = Vs + j * AL_LD;
 #pragma unroll
             for (int c = 0; c < 32; ++c) o[c] = fmaf(pe, vr[c], o[c] * corr);
@@ -116,11 +118,11 @@ __global__ __launch_bounds__(AL_THREADS) void attn_long_row_kernel(const T* __re
     __syncthreads();
     const float m = bc[0];
     float sum = 0.f;
-    const uint64_t ebase = (((uint64_t)b * H + h) * S + row) * S;
+    const uint64_t drow = ((uint64_t)b * H + h) * S + row;
     for (int j = threadIdx.x, k = 0; j < S; j += AL_THREADS, ++k) {
         const float e = j < jend ? __expf(s_own[k] - m) : 0.f;
         sum += e;
-        if (j < S) pr[j] = e * drop_mult(dc, ebase + j);
+        if (j < S) pr[j] = e * attn_drop_mult(dc, drow, j);
     }
     sum = wave_sum(sum);
     __syncthreads();                    // red[] was read by thread 0 above
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(AL_THREADS) void attn_long_bwd_kernel(const T* __re
     __syncthreads();
     const int len = seq_len ? min(max(seq_len[b], 0), S) : S;
     const DropCtx dc = drop_make(drop_p, seed, site);
-    const uint64_t hbase = ((uint64_t)b * H + h) * S;       // element id of (i, j) = (hbase + i) * S + j
+    const uint64_t hbase = ((uint64_t)b * H + h) * S;       // dropout row of query i = hbase + i
     T* dbase = dqkv + (size_t)b * S * 3 * d + h * 32;
 
     // ---- pass 1: lane = query row i: lse_i, D_i = sum_j P_ij dP_ij, dq_i ---------------------------------------
@@ -185,14 +187,16 @@ __global__ __launch_bounds__(AL_THREADS) void attn_long_bwd_kernel(const T* __re
         float D = 0.f, A[32], Bv[32];
 #pragma unroll
         for (int c = 0; c < 32; ++c) { A[c] = 0.f; Bv[c] = 0.f; }
+        uint32_t hrow = 0;
         for (int j = 0; j < jend; ++j) {
+            if ((j & 31) == 0) hrow = attn_drop_row(dc, hbase + i, j >> 5);
             const float* kr = Ks + j * AL_LD;
             const float* vr = Vs + j * AL_LD;
             float s = 0.f, dp = 0.f;
 #pragma unroll
             for (int c = 0; c < 32; ++c) { s = fmaf(q[c], kr[c], s); dp = fmaf(go[c], vr[c], dp); }
             const float p = __expf(s - lse);
-            dp *= drop_mult(dc, (hbase + i) * S + j);
+            dp *= attn_drop_key(dc, hrow, j);
             const float pd = p * dp;
             D += pd;
 #pragma unroll
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(AL_THREADS) void attn_long_bwd_kernel(const T* __re
 #pragma unroll
                 for (int c = 0; c < 32; ++c) { s = fmaf(qr[c], k[c], s); dpv = fmaf(gr[c], v[c], dpv); }
                 const float p = __expf(s * scale - lse_s[r]);
-                const float mult = drop_mult(dc, (hbase + r) * S + j);
+                const float mult = attn_drop_mult(dc, hbase + r, j);
                 const float pd = p * mult;
                 const float ds = p * (dpv * mult - D_s[r]) * scale;
 #pragma unroll

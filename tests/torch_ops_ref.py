@@ -204,9 +204,35 @@ def _attn_probs(qkv, key_mask, n_seq, S, H, scale, causal=False):
     return q, k, v, torch.softmax(s, dim=-1)
 
 
+def attn_drop_mult(p, seed, site, row, key):
+    """dropout of the attention probabilities (dsvg_common.h attn_drop_row / attn_drop_key): one counter hash per
+    (row = (sequence * heads + head) * S + query, block of 32 keys), a one-multiply finaliser per pair of keys"""
+    shape = torch.broadcast_shapes(row.shape, key.shape)
+    if p <= 0 or seed is None:
+        return torch.ones(shape, dtype=torch.float32, device=row.device)
+    s = int(seed.reshape(-1)[0].item()) & 0xFFFFFFFFFFFFFFFF
+    s0 = _hash32_int((s & M32) ^ ((site * 0x9E3779B1) & M32))
+    s1 = _hash32_int(((s >> 32) + site * 0x85EBCA77 + 0x165667B1) & M32)
+    thresh = min(65535, int(np.float32(np.float32(p) * np.float32(65536.0) + np.float32(0.5))))
+    scale = float(np.float32(65536.0) / np.float32(65536 - thresh))
+    row, key = row.to(torch.int64), key.to(torch.int64)
+    g = row * 8 + (key >> 5)
+    lo, hi = g & M32, (g >> 32) & M32
+    h = _hash32_t(lo ^ s0)
+    h = _hash32_t((h + hi * 0x9E3779B1 + s1) & M32)
+    w = (h + (((key & 31) >> 1) + 1) * 0x9E3779B9) & M32
+    w = w ^ (w >> 16)
+    w = (w * 0x7FEB352D) & M32
+    w = w ^ (w >> 15)
+    draw = torch.where((key & 1) == 1, w >> 16, w & 0xFFFF)
+    return torch.where(draw < thresh, torch.zeros((), dtype=torch.float32, device=row.device),
+                       torch.full((), scale, dtype=torch.float32, device=row.device))
+
+
 def _attn_drop(p, seed, site, n_seq, S, H, device):
-    idx = torch.arange(n_seq * H * S * S, device=device, dtype=torch.int64).view(n_seq, H, S, S)
-    return drop_mult(p, seed, site, idx)
+    row = torch.arange(n_seq * H * S, device=device, dtype=torch.int64).view(n_seq, H, S, 1)
+    key = torch.arange(S, device=device, dtype=torch.int64).view(1, 1, 1, S)
+    return attn_drop_mult(p, seed, site, row, key)
 
 
 # packed layout helpers: seq_off int32 [n_seq+1]; sequence b = rows seq_off[b]..seq_off[b+1]-1
