@@ -1,4 +1,4 @@
 cd "$(dirname "$0")/.."
 export PYTHONDONTWRITEBYTECODE=1 TMPDIR=/tmp
 mkdir -p gpurun_out
-( timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 ) > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed|Error|error" gpurun_out/pytest_gpu.log | cut -c1-300 | tail -6
+( timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider --timeout 600 -k "attn_" ) > gpurun_out/pytest_q.log 2>&1; grep -E "passed|failed|Error|error|^E " gpurun_out/pytest_q.log | cut -c1-300 | tail -12

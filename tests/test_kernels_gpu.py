@@ -1121,10 +1121,24 @@ def _attn_case(kind, seed):
         return n_seq * S + 40, n_seq, S, km, None, None, n_seq * S
     if kind == "dense10":           # three sequences per tile (30 of 32 rows)
         return 500 * 10, 500, 10, None, None, None, 500 * 10
+    if kind == "tiny_dense5":       # one workgroup, one partly filled tile (3 sequences of 5)
+        return 15, 3, 5, None, None, None, 15
+    if kind == "one_sequence_32":
+        return 32, 1, 32, None, None, None, 32
+    if kind == "packed_extremes":   # lengths 1 and 32 mixed: tiles of one full sequence next to tiles of up to 32 singletons
+        n_seq, S = 300, 32
+        lens = torch.where(torch.rand(n_seq, generator=g) < 0.5, torch.tensor(1), torch.tensor(32))
+        lens[40:100] = 1            # 60 singletons in a row
+        off = torch.zeros(n_seq + 1, dtype=torch.int32)
+        off[1:] = lens.cumsum(0)
+        real = int(off[-1])
+        seq_off = off.to(DEV)
+        return real, n_seq, S, None, seq_off, ops.attention_tiles(seq_off, n_seq, 32), real
     raise KeyError(kind)
 
 
-@pytest.mark.parametrize("kind", ["packed", "dense31", "dense32_masked", "dense8_masked_tail", "dense10"])
+@pytest.mark.parametrize("kind", ["packed", "dense31", "dense32_masked", "dense8_masked_tail", "dense10", "tiny_dense5",
+                                  "one_sequence_32", "packed_extremes"])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_attn_block_fwd_equals_unfused_kernels(gpu_device, kind, p):
     """the fused attention block against the four launches it replaces (LayerNorm, in_proj GEMM, attention, out_proj GEMM
