@@ -454,7 +454,7 @@ def main():
             "roofline": roofline, "fp32": fp32, "cpu_baseline": cpu,
         }
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
