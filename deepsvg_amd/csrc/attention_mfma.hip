@@ -119,7 +119,10 @@ __device__ __forceinline__ void zero_slab_rows(bf16_t* dst, long long ld, long l
     }
 }
 
-template <bool TILED>
+// MODE 0: dense, one sequence of 17..32 rows per workgroup.  MODE 1: packed layout, tiles of whole sequences from
+// dsvg_attention_tiles.  MODE 2: dense layout with short sequences (<= 16 rows): 32 / Smax whole sequences per tile, an
+// optional key mask per sequence (the 8-token group stages: 4 icons per tile instead of the lane-per-query VALU kernel).
+template <int MODE>
 __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                             const uint64_t* __restrict__ key_mask,
                                                             const int32_t* __restrict__ seq_off, long long total_rows,
@@ -133,20 +136,29 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
     const int lane = threadIdx.x & 63, hh = threadIdx.x >> 6;
     const int li = lane & 31, h2 = lane >> 5;
     const int h = hg * HG + hh;
+    constexpr bool TILED = MODE != 0;
     long long row0 = (long long)b * Smax;
     int S = Smax;                   // rows of this workgroup's tile; dropout ids keep the Smax-based numbering
     if (total_rows > 0 && b == (int)gridDim.x - 1) {     // tail workgroup: rows past the last sequence <- 0
-        zero_slab_rows(out + (size_t)hg * W, (long long)d, seq_off ? (long long)seq_off[n_seq] : row0, total_rows, W);
+        zero_slab_rows(out + (size_t)hg * W, (long long)d,
+                       seq_off ? (long long)seq_off[n_seq] : (MODE == 2 ? (long long)n_seq * Smax : row0), total_rows, W);
         return;
     }
-    // packed layout with tiles (dsvg_attention_tiles): the workgroup owns the sequences tile_first[b]..tile_first[b+1]-1,
-    // at most 32 rows in total, block-diagonal attention inside the 32x32 score tile
+    // tiles (MODE 1: dsvg_attention_tiles; MODE 2: 32 / Smax consecutive dense sequences): the workgroup owns the sequences
+    // s_first .. s_last - 1, at most 32 rows in total, block-diagonal attention inside the 32x32 score tile
     int s_first = b, s_last = b + 1;
-    if (TILED) {
+    if (MODE == 1) {
         if (b >= tile_first[n_seq + 1]) return;
         s_first = tile_first[b];
         s_last = tile_first[b + 1];
         if ((int)threadIdx.x <= s_last - s_first) soff[threadIdx.x] = seq_off[s_first + threadIdx.x];   // <= 33 entries
+    } else if (MODE == 2) {
+        const int per = 32 / Smax;
+        s_first = b * per;
+        s_last = min(n_seq, s_first + per);
+        if ((int)threadIdx.x <= s_last - s_first) soff[threadIdx.x] = (s_first + (int)threadIdx.x) * Smax;
+        row0 = (long long)s_first * Smax;
+        S = (s_last - s_first) * Smax;
     }
     if (seq_off) {
         row0 = seq_off[s_first];
@@ -169,9 +181,10 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
         my_len = soff[qi + 1] - soff[qi];
     }
 
-    // keys visible to this lane's query: the rows of its own sequence
-    const uint32_t km = TILED ? (uint32_t)(((1ull << my_len) - 1ull) << my_start)
-                                   : ((key_mask ? (uint32_t)key_mask[b] : ~0u) & (uint32_t)((1ull << S) - 1ull));
+    // keys visible to this lane's query: the rows of its own sequence (MODE 2: those its key mask lets through)
+    const uint32_t km = MODE == 2 ? (((key_mask ? (uint32_t)key_mask[my_seq] : ~0u) & (uint32_t)((1ull << my_len) - 1ull)) << my_start)
+                        : TILED ? (uint32_t)(((1ull << my_len) - 1ull) << my_start)
+                                : ((key_mask ? (uint32_t)key_mask[b] : ~0u) & (uint32_t)((1ull << S) - 1ull));
     const DropCtx dc = drop_make(drop_p, seed, drop_site);
     const int qc = hh * 32, kc = W + hh * 32, vc = 2 * W + hh * 32;
 
@@ -220,7 +233,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
     store_slab(out + (size_t)row0 * d + (size_t)hg * W, (long long)d, tile, LD, S, W);
 }
 
-template <bool TILED>
+template <int MODE>
 __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                             const uint64_t* __restrict__ key_mask,
                                                             const int32_t* __restrict__ seq_off, long long total_rows,
@@ -237,22 +250,30 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
     const int lane = threadIdx.x & 63, hh = threadIdx.x >> 6;
     const int li = lane & 31, h2 = lane >> 5;
     const int h = hg * HG + hh;
+    constexpr bool TILED = MODE != 0;
     long long row0 = (long long)b * Smax;
     int S = Smax;
     if (total_rows > 0 && b == (int)gridDim.x - 1) {     // tail workgroup: rows past the last sequence <- 0
-        const long long first = seq_off ? (long long)seq_off[n_seq] : row0;
+        const long long first = seq_off ? (long long)seq_off[n_seq] : (MODE == 2 ? (long long)n_seq * Smax : row0);
         bf16_t* z = dqkv + (size_t)hg * W;
         zero_slab_rows(z, 3LL * d, first, total_rows, W);
         zero_slab_rows(z + d, 3LL * d, first, total_rows, W);
         zero_slab_rows(z + 2 * d, 3LL * d, first, total_rows, W);
         return;
     }
-    int s_first = b, s_last = b + 1;        // tile mode: see the forward kernel
-    if (TILED) {
+    int s_first = b, s_last = b + 1;        // tile modes: see the forward kernel
+    if (MODE == 1) {
         if (b >= tile_first[n_seq + 1]) return;
         s_first = tile_first[b];
         s_last = tile_first[b + 1];
         if ((int)threadIdx.x <= s_last - s_first) soff[threadIdx.x] = seq_off[s_first + threadIdx.x];   // <= 33 entries
+    } else if (MODE == 2) {
+        const int per = 32 / Smax;
+        s_first = b * per;
+        s_last = min(n_seq, s_first + per);
+        if ((int)threadIdx.x <= s_last - s_first) soff[threadIdx.x] = (s_first + (int)threadIdx.x) * Smax;
+        row0 = (long long)s_first * Smax;
+        S = (s_last - s_first) * Smax;
     }
     if (seq_off) {
         row0 = seq_off[s_first];
@@ -277,9 +298,11 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
         my_len = soff[qi + 1] - soff[qi];
     }
 
-    // rows of this lane's sequence: the keys its query sees (pass A) = the queries that see its key (pass B)
-    const uint32_t km = TILED ? (uint32_t)(((1ull << my_len) - 1ull) << my_start)
-                                   : ((key_mask ? (uint32_t)key_mask[b] : ~0u) & (uint32_t)((1ull << S) - 1ull));
+    // km: the keys this lane's query sees (pass A); qm: the queries that see this lane's key (pass B) = the rows of the
+    // lane's own sequence (queries are never masked)
+    const uint32_t qm = TILED ? (uint32_t)(((1ull << my_len) - 1ull) << my_start) : 0u;
+    const uint32_t km = MODE == 2 ? (((key_mask ? (uint32_t)key_mask[my_seq] : ~0u) << my_start) & qm)
+                        : TILED ? qm : ((key_mask ? (uint32_t)key_mask[b] : ~0u) & (uint32_t)((1ull << S) - 1ull));
     const DropCtx dc = drop_make(drop_p, seed, drop_site);
     const int qc = hh * 32, kc = W + hh * 32, vc = 2 * W + hh * 32, oc = hh * 32;
     // dropout row of query tile-row q = hbase + q (= (seq H + h) Smax + q_local); keys counted inside the sequence
@@ -352,7 +375,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dtile, LDO, li, oc, step, h2),
                                                        row_frag(tile, LD, li, vc, step, h2), acc2, 0, 0, 0);    // dO V^T
     }
-    const bool kvalid = TILED ? (li < S) : (bool)((km >> li) & 1u);
+    const bool kvalid = MODE == 1 ? (li < S) : (li < S && (bool)((km >> li) & 1u));
     // P~ and dS go straight to packed bf16 pairs (they are only MFMA operands from here on): 16 registers instead of 32
     uint32_t pp[8], gp[8];
 #pragma unroll
@@ -363,7 +386,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
             const int r = 2 * c + e;
             const int q = rowmap(r, h2);
             const float lse_q = my_stat[q * 3 + 0], D_q = my_stat[q * 3 + 1];
-            const bool ok = kvalid && q < S && (!TILED || ((km >> q) & 1u));
+            const bool ok = kvalid && q < S && (!TILED || ((qm >> q) & 1u));
             const float pr = ok ? __expf(acc[r] * scale - lse_q) : 0.f;               // P[q][key = li]
             const float mult = attn_drop_key(dc, __float_as_uint(my_stat[q * 3 + 2]), (uint32_t)(li - my_start));
             pv[e] = pr * mult;                                                        // P~ (as used by O = P~ V)
@@ -401,15 +424,19 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
 
 bool dsvg_attention_mfma_ok(int32_t dtype, int32_t S, int32_t n_heads) {
     static const bool off = getenv("DSVG_ATTN_VALU") != nullptr;
-    return !off && dtype == DSVG_BF16 && S > 16 && S <= 32 && (n_heads % HG) == 0;
+    // S <= 16 (dense): several sequences per 32-row tile (MODE 2); DSVG_ATTN_MFMA_MIN_S raises the lower limit again
+    static const int min_s = getenv("DSVG_ATTN_MFMA_MIN_S") ? atoi(getenv("DSVG_ATTN_MFMA_MIN_S")) : 2;
+    return !off && dtype == DSVG_BF16 && S >= min_s && S <= 32 && (n_heads % HG) == 0;
 }
 
 int dsvg_attention_fwd_mfma(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
                             const int32_t* tile_first, void* out, int64_t n_seq, int32_t S, int32_t n_heads,
                             float scale, float drop_p, uint32_t drop_site, const uint64_t* seed, hipStream_t st) {
     const size_t lds = (size_t)32 * LD * sizeof(bf16_t) + 34 * sizeof(int);
-    auto kern = tile_first ? attn_fwd_mfma_kernel<true> : attn_fwd_mfma_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (total_rows > 0 ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
+    const bool multi = !tile_first && !seq_off && S <= 16;      // dense short sequences: 32 / S of them per tile
+    auto kern = tile_first ? attn_fwd_mfma_kernel<1> : (multi ? attn_fwd_mfma_kernel<2> : attn_fwd_mfma_kernel<0>);
+    const int64_t n_wg = multi ? (n_seq + 32 / S - 1) / (32 / S) : n_seq;
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg + (total_rows > 0 ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
                        (const bf16_t*)qkv, key_mask, seq_off, (long long)total_rows, tile_first, (int)n_seq, (bf16_t*)out,
                        S, n_heads, scale, drop_p, drop_site, seed);
     DSVG_LAUNCH_CHECK("attention_fwd_mfma");
@@ -421,10 +448,13 @@ int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const int
                             int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
                             hipStream_t st) {
     const size_t lds = (size_t)32 * (LD + LDO) * sizeof(bf16_t) + (size_t)HG * 96 * sizeof(float) + 34 * sizeof(int);
-    auto kern = tile_first ? attn_bwd_mfma_kernel<true> : attn_bwd_mfma_kernel<false>;
-    DSVG_ENSURE_LDS(attn_bwd_mfma_kernel<true>, lds);
-    DSVG_ENSURE_LDS(attn_bwd_mfma_kernel<false>, lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_seq + (total_rows > 0 ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
+    const bool multi = !tile_first && !seq_off && S <= 16;
+    auto kern = tile_first ? attn_bwd_mfma_kernel<1> : (multi ? attn_bwd_mfma_kernel<2> : attn_bwd_mfma_kernel<0>);
+    DSVG_ENSURE_LDS(attn_bwd_mfma_kernel<0>, lds);
+    DSVG_ENSURE_LDS(attn_bwd_mfma_kernel<1>, lds);
+    DSVG_ENSURE_LDS(attn_bwd_mfma_kernel<2>, lds);
+    const int64_t n_wg = multi ? (n_seq + 32 / S - 1) / (32 / S) : n_seq;
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg + (total_rows > 0 ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
                        (const bf16_t*)qkv, key_mask, seq_off, (long long)total_rows, tile_first, (int)n_seq,
                        (const bf16_t*)dout, (bf16_t*)dqkv, S, n_heads, scale, drop_p, drop_site, seed);
     DSVG_LAUNCH_CHECK("attention_bwd_mfma");
