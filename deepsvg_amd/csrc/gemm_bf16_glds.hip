@@ -46,14 +46,56 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
     return make_uint4(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]), f2bf_pk(v[4], v[5]), f2bf_pk(v[6], v[7]));
 }
 
-// NST: LDS stages (1: 32 KiB, 2: 64 KiB); OCC: waves per SIMD the register allocation is held to (4 -> 128 VGPRs, no
+// One K step of both operands by LDS-DMA issued from inline asm (8 instructions per wave: 4 pieces of A, 4 of B), for the
+// 4-stage variant: hipcc drains vmcnt(0) before the first ds_read after a *builtin* LDS-DMA, which would serialise a deep
+// prefetch; from asm the waits are ours (counted s_waitcnt vmcnt, only loads in flight inside the K loop).
+// a0..a3 / b0..b3: per-lane global addresses of the pieces; lds_a / lds_b: wave-uniform LDS byte addresses of piece 0.
+__device__ __forceinline__ void dma_step8(const char* a0, const char* a1, const char* a2, const char* a3, const char* b0,
+                                          const char* b1, const char* b2, const char* b3, uint32_t lds_a, uint32_t lds_b) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %9\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, off\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, off\n\t"
+        "s_mov_b32 m0, %10\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %5, off\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %6, off\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %7, off\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %8, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "s"(lds_a), "s"(lds_b)
+        : "memory", "scc");
+}
+
+// NST: LDS stages (1: 32 KiB, 2: 64 KiB; 4: 128 KiB of dynamic LDS, asm DMA three K steps ahead - for launches of at most
+// one workgroup per CU, where nothing else on the CU hides the ~1.4 us of a DMA round trip per K step); OCC: waves per SIMD the register allocation is held to (4 -> 128 VGPRs, no
 // spills; 5 -> 96 VGPRs, a few epilogue values spill, but all five 32-KiB workgroups a CU's LDS can hold are resident:
 // the packed / live-prefix GEMMs launch ~1.25 x 1024 workgroups, which then run as one wave of workgroups, not two)
 template <bool AKC, bool BKC, int EPI, int NST, int OCC>
 __global__ __launch_bounds__(256, NST == 1 ? OCC : 2) void gemm_bf16_glds_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
                                                                               int k_chunk, float* part, float* rs_part,
                                                                               int mode, int part_bf16) {
-    __shared__ __attribute__((aligned(1024))) bf16_t smem[NST * 2 * IMG];
+    __shared__ __attribute__((aligned(1024))) bf16_t smem_static[NST <= 2 ? NST * 2 * IMG : 8];
+    extern __shared__ __attribute__((aligned(1024))) bf16_t smem_dynamic[];
+    bf16_t* const smem = NST <= 2 ? smem_static : smem_dynamic;
 
     // tile schedule: identical to gemm_bf16.hip modes 0 and 1 (workgroup b runs on XCD b % 8)
     const int bid = blockIdx.x;
@@ -181,7 +223,29 @@ __global__ __launch_bounds__(256, NST == 1 ? OCC : 2) void gemm_bf16_glds_kernel
         }
     };
 
-    if (NST == 1) {
+    if (NST == 4) {
+        // stage s lives in slot s % 4; stages s + 1 .. s + 3 are in flight while stage s is consumed
+        const uint32_t lds0 = (uint32_t)(uintptr_t)DSVG_LDS_PTR(smem) + wave * 4096;
+        auto issue = [&](int s) {
+            const int k0 = k_begin + s * GBK;
+            const char* ab = (const char*)p.A + (AKC ? (size_t)k0 * 2 : (size_t)k0 * p.lda * 2);
+            const char* bb = (const char*)p.B + (BKC ? (size_t)k0 * 2 : (size_t)k0 * p.ldb * 2);
+            const uint32_t la = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(s & 3) * (2 * IMG * 2));
+            dma_step8(ab + offa[0], ab + offa[1], ab + offa[2], ab + offa[3], bb + offb[0], bb + offb[1], bb + offb[2],
+                      bb + offb[3], la, la + IMG * 2);
+        };
+        const int n_steps = (k_end - k_begin + GBK - 1) / GBK;
+        for (int s = 0; s < 3 && s < n_steps; ++s) issue(s);
+        for (int s = 0; s < n_steps; ++s) {
+            const int ahead = min(n_steps - 1, s + 2) - s;      // stages issued behind stage s (8 DMA instructions each)
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();       // stage s landed everywhere; everybody is done with stage s - 1's slot
+            if (s + 3 < n_steps) issue(s + 3);
+            compute(s & 3);
+        }
+    } else if (NST == 1) {
         for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
             stage(k0, 0);
             __syncthreads();            // every wave drains its DMA (vmcnt 0) before the barrier
@@ -375,7 +439,17 @@ template <bool AKC, bool BKC, int EPI>
 void launch(const dsvg_gemm_desc& d, dim3 grid, int tiles_n, int nwg, int k_chunk, float* part, float* rs_part, int mode,
             int nst, hipStream_t st, int pbf = 0) {
     static const int occ = getenv("DSVG_GEMM_OCC") ? atoi(getenv("DSVG_GEMM_OCC")) : 4;
-    if (nst == 2)
+    if (nst == 4) {
+        const size_t lds = (size_t)4 * 2 * IMG * sizeof(bf16_t);
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AKC, BKC, EPI, 4, 4>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            once = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AKC, BKC, EPI, 4, 4>), grid, dim3(256), lds, st, d, tiles_n, nwg, k_chunk,
+                           part, rs_part, mode, pbf);
+    } else if (nst == 2)
         hipLaunchKernelGGL((gemm_bf16_glds_kernel<AKC, BKC, EPI, 2, 4>), grid, dim3(256), 0, st, d, tiles_n, nwg, k_chunk,
                            part, rs_part, mode, pbf);
     else if (occ == 5)
@@ -394,7 +468,11 @@ bool dsvg_gemm_bf16_glds_try(const dsvg_gemm_desc& d, int epi, dim3 grid, int ti
     static const bool disabled = getenv("DSVG_GEMM_NOGLDS") != nullptr;         // A/B knob
     static const int nst_env = getenv("DSVG_GEMM_STAGES") ? atoi(getenv("DSVG_GEMM_STAGES")) : 1;
     if (disabled || d.impl == 2 || mode == 2 || d.a_drop_p > 0.f) return false;
-    const int nst = d.impl == 3 ? 2 : (d.impl == 4 ? 1 : nst_env);
+    // launches of at most one workgroup per CU (the 4096-row group stages: 64-192 workgroups) take the 4-stage variant:
+    // nothing else on the CU hides a DMA round trip per K step there.  impl 6 forces it (tests), DSVG_GEMM_DEEP_WGS = 0 disables
+    static const int deep_wgs = getenv("DSVG_GEMM_DEEP_WGS") ? atoi(getenv("DSVG_GEMM_DEEP_WGS")) : 256;
+    const long long n_wgs = (long long)grid.x * grid.y * grid.z;
+    const int nst = d.impl == 6 ? 4 : (d.impl == 3 ? 2 : (d.impl == 4 ? 1 : (n_wgs <= deep_wgs ? 4 : nst_env)));
     if ((d.K % GBK) || (part && (k_chunk % GBK))) return false;
     if ((d.lda & 7) || (d.ldb & 7) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) return false;
     // token-major (mn-contiguous) operands are read in 8-element chunks: the row must be padded to a multiple of 8

@@ -64,7 +64,9 @@ typedef struct dsvg_gemm_desc {
     int32_t impl;                               /* 0 = best MFMA kernel, 1 = one-thread-per-output,
                                                    2 = register-staged MFMA kernel only, 3 / 4 = LDS-DMA
                                                    kernel with 2 / 1 LDS stages when eligible, 5 = weight-
-                                                   stationary kernel when eligible (test knobs)     */
+                                                   stationary kernel when eligible, 6 = LDS-DMA kernel with
+                                                   4 stages (asm DMA three K steps ahead; the default for
+                                                   launches of <= 256 workgroups) (test knobs)      */
 } dsvg_gemm_desc;
 
 int dsvg_gemm(const dsvg_gemm_desc* d, void* stream);

@@ -140,7 +140,7 @@ def test_gemm_weight_grad_with_fused_bias_rowsum(gpu_device, dtype, T, n_out, k_
     _close(db, dy.float().sum(0), 1e-5 * T ** 0.5 if dtype == torch.float32 else 1e-2, "fused bias grad")
 
 
-@pytest.mark.parametrize("stages", [4, 3])
+@pytest.mark.parametrize("stages", [4, 3, 6])
 @pytest.mark.parametrize("M,N,K", [(384, 512, 256), (1000, 264, 512), (129, 8, 64), (4096, 768, 256)])
 def test_gemm_lds_dma_kernel_equals_register_staged_kernel(gpu_device, stages, M, N, K):
     """The LDS-DMA bf16 kernel (impl 3/4: swizzled DMA images, swapped MFMA, register epilogue) must reproduce the
@@ -196,7 +196,7 @@ def test_gemm_weight_stationary_ragged_head(gpu_device):
     _close(outs[0], R.gemm(x, w, bias=bias, out_dtype=torch.float32), _tol(dtype, K), "ragged-N forward (ws)")
 
 
-@pytest.mark.parametrize("stages", [4, 3])
+@pytest.mark.parametrize("stages", [4, 3, 6])
 def test_gemm_lds_dma_ragged_head_shapes(gpu_device, stages):
     """N = 523 (like the 2827-wide argument head: not a multiple of 8) in a row-padded buffer: forward through the
     LDS-DMA kernel (last 8-column chunk finished element-wise), bit-identical to the register-staged kernel, and the
@@ -227,7 +227,7 @@ def test_gemm_lds_dma_ragged_head_shapes(gpu_device, stages):
     _close(res[0][1], dy.float().sum(0), 1e-2, "ragged-M bias grad")
 
 
-@pytest.mark.parametrize("stages", [4, 3])
+@pytest.mark.parametrize("stages", [4, 3, 6])
 @pytest.mark.parametrize("T,n_out,k_in,split", [(4096, 512, 256, 16), (1920, 256, 512, 8), (640, 264, 704, 3),
                                                 (8192, 768, 256, 64)])
 def test_gemm_lds_dma_weight_grad(gpu_device, stages, T, n_out, k_in, split):
