@@ -387,16 +387,26 @@ __global__ __launch_bounds__(256) void embed_scatter_row_kernel(const float* __r
     __syncthreads();
     const long long t0 = (long long)blockIdx.x * ES_TOK_PER_BLOCK;
     const long long t1 = min(T_tok, t0 + ES_TOK_PER_BLOCK);
-    for (long long t = t0; t < t1; ++t) {
-        int ic = (int)commands[t];
-        ic = min(max(ic, 0), n_cmd - 1);
-        const int ig = part_grp ? groups[t] - g_lo : -1;
-        const bool in_win = ig >= 0 && ig < g_win;
-        for (int c = threadIdx.x; c < d; c += 256) {
-            const float g = Elem<T>::ld(dR + t * d + c);
-            if (g != 0.f) {     // column c of every table row belongs to this thread alone: plain read-modify-write
-                if (do_cmd) acc_c[ic * d + c] += g;
-                if (in_win) acc_g[ig * d + c] += g;
+    // tokens 8 at a time with all of their loads (command, group, gradient element) issued before the first table update:
+    // one token per iteration was a chain of 128 dependent ~1 us global loads per workgroup
+    constexpr int TU = 8;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        for (long long tb = t0; tb < t1; tb += TU) {
+            float g[TU];
+            int ic[TU], ig[TU];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const long long t = min(tb + u, t1 - 1);        // clamped address, selected below
+                g[u] = Elem<T>::ld(dR + t * d + c);
+                ic[u] = (int)commands[t];
+                ig[u] = part_grp ? groups[t] - g_lo : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                if (tb + u < t1 && g[u] != 0.f) {   // column c of every table row belongs to this thread alone: plain RMW
+                    if (do_cmd) acc_c[min(max(ic[u], 0), n_cmd - 1) * d + c] += g[u];
+                    if (ig[u] >= 0 && ig[u] < g_win) acc_g[ig[u] * d + c] += g[u];
+                }
             }
         }
     }

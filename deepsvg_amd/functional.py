@@ -670,20 +670,27 @@ class ArgsHeadLossFn(torch.autograd.Function):
     `live` = (token list int32 padded with -1, number of rows to process >= number of listed tokens)."""
 
     @staticmethod
-    def forward(ctx, rt, x, weight, bias, target, w, C_, group, count_fn, live):
+    def forward(ctx, rt, x, weight, bias, target, w, C_, group, count_fn, live, slot_lo=0):
+        """target / w: [n_tok * group] for the `group` argument slots slot_lo .. slot_lo + group - 1 (the slots that
+        carry loss in this batch: the head's other output rows get exact zero gradients)"""
         R = min(int(live[1]), x.shape[0])
         idx = live[0][:R]
         xc = ops.gather_groups(x, idx, R, 1)                       # rows of list padding read token 0 (weight 0)
-        n_out = weight.shape[0]
+        r0, r1 = slot_lo * C_, (slot_lo + group) * C_              # the head's output rows in use
+        n_out = r1 - r0
+        w_used = rt.w(weight)[r0:r1]
+        b_used = bias.detach()[r0:r1]
+        if b_used.data_ptr() % 16:
+            b_used = b_used.clone()                                # (the GEMM epilogue reads the bias in 16-byte pieces)
         mult = 4 if xc.dtype == torch.float32 else 8
         ld = (n_out + mult - 1) // mult * mult
         buf = torch.empty((R, ld), dtype=xc.dtype, device=xc.device)
         logits_c = buf[:, :n_out]
-        ops.gemm(xc, rt.w(weight), bias=bias.detach(), out=logits_c)
+        ops.gemm(xc, w_used, bias=b_used, out=logits_c)
         lse, sc = ops.masked_ce_fwd(logits_c, target, w, C_, group, tok_idx=idx)
         if count_fn is not None:
             sc = torch.stack([sc[0], count_fn(sc[1].clone()).to(sc.dtype).reshape(())])
-        ctx.rt, ctx.C_, ctx.group, ctx.rows_full = rt, C_, group, x.shape[0]
+        ctx.rt, ctx.C_, ctx.group, ctx.rows_full, ctx.rows_used = rt, C_, group, x.shape[0], (r0, r1)
         ctx.save_for_backward(xc, weight, bias, logits_c, target, w, lse, sc, idx)
         return sc[0] / sc[1], sc
 
@@ -695,8 +702,22 @@ class ArgsHeadLossFn(torch.autograd.Function):
         mult = 4 if logits_c.dtype == torch.float32 else 8
         dl = ops.masked_ce_bwd(logits_c, target, w, lse, sc, g, 1.0, ctx.C_, ctx.group, pad_to=mult, tok_idx=idx,
                                logits_compact=True)
-        dw, db = _wbgrad(rt, weight, bias, dl, xc)
-        dxc = ops.gemm(dl, rt.w(weight), b_kc=False)
+        r0, r1 = ctx.rows_used
+        if (r0, r1) == (0, weight.shape[0]):
+            dw, db = _wbgrad(rt, weight, bias, dl, xc)
+            dxc = ops.gemm(dl, rt.w(weight), b_kc=False)
+        else:
+            # only the output rows [r0, r1) of the head saw a loss term: their gradient comes from the GEMMs, the rest is 0
+            dw, db = rt.grad_out(weight), rt.grad_out(bias)
+            dw[:r0].zero_(); dw[r1:].zero_(); db[:r0].zero_(); db[r1:].zero_()
+            split = ops.split_k_for(r1 - r0, weight.shape[1], dl.shape[0])
+            with rt.deferring(), _wgrad_tag():
+                if split > 1:
+                    ops.gemm(dl, xc, a_kc=False, b_kc=False, out=dw[r0:r1], split_k=split, rowsum=db[r0:r1])
+                else:
+                    ops.gemm(dl, xc, a_kc=False, b_kc=False, out=dw[r0:r1])
+                    ops.colsum(dl, out=db[r0:r1])
+            dxc = ops.gemm(dl, rt.w(weight)[r0:r1], b_kc=False)
         dx = torch.zeros((ctx.rows_full, xc.shape[1]), dtype=xc.dtype, device=xc.device)
         ops.scatter_rows(dxc, idx, dx)
-        return None, dx, dw, db, None, None, None, None, None, None
+        return None, dx, dw, db, None, None, None, None, None, None, None

@@ -85,9 +85,15 @@ class SVGLoss(nn.Module):
         if head is not None:
             # fused argument head + loss on the loss-carrying tokens (forward and backward); the dense args_logits of
             # the result dict stays unmaterialised
-            loss_args, sc_a = Fn.ArgsHeadLossFn.apply(head["rt"], head["x"], head["weight"], head["bias"],
-                                                      arg_tgt.view(-1), arg_w.view(-1), self.args_dim, n_args,
-                                                      (lambda c: cnt[2]) if red else None, head["live"])
+            lo, hi = head.get("slots", (0, n_args))
+            tr = head.get("targets_r")
+            if tr is not None:      # the slots [lo, hi) are the only ones that carry loss in this batch
+                a_t, a_w, slots = tr[0], tr[1], (lo, hi)
+            else:
+                a_t, a_w, slots = arg_tgt.view(-1), arg_w.view(-1), (0, n_args)
+            loss_args, sc_a = Fn.ArgsHeadLossFn.apply(head["rt"], head["x"], head["weight"], head["bias"], a_t, a_w,
+                                                      self.args_dim, slots[1] - slots[0],
+                                                      (lambda c: cnt[2]) if red else None, head["live"], slots[0])
         else:
             al = output["args_logits"].reshape(N * G * S, n_args * self.args_dim)
             loss_args, sc_a = Fn.MaskedCEFn.apply(al, arg_tgt.view(-1), arg_w.view(-1), self.args_dim, n_args,

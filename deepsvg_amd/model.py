@@ -522,6 +522,8 @@ class SVGTransformer(nn.Module):
         self.last_live = None
         # backward of the argument head only over the tokens that carry argument loss (exact under SVGLoss)
         self.compact_head_backward = os.environ.get("DSVG_COMPACT_HEAD", "1") != "0"
+        # argument head + loss on the argument slots that carry loss in the batch only (see _plan)
+        self.head_slot_range = os.environ.get("DSVG_HEAD_SLOT_RANGE", "1") != "0"
         self.last_head_rows = None
         self.kv_cache = True         # autoregressive sampling: incremental decoding over a per-layer q|k|v cache
         self.last_assignment = None  # self-matching configs: (N, Gp) int32 assignment of the last training forward
@@ -646,9 +648,13 @@ class SVGTransformer(nn.Module):
             ta = args_dec.to(torch.float32).contiguous().view(N * G, S1, -1)
             cam = self.cmd_args_mask.to(device=tc.device, dtype=torch.float32).contiguous()
             targets = ops.loss_targets(tc, ta, cam, EOS_ID)
-            live, n_live = ops.live_rows(targets[3].view(-1), ta.shape[-1])
+            n_args = ta.shape[-1]
+            live, n_live = ops.live_rows(targets[3].view(-1), n_args)
             plan["loss"] = dict(targets=targets, live=live)
             counts.append(n_live)
+            # which argument slots carry loss anywhere in this batch (CMD_ARGS_MASK columns of the commands present: real
+            # DeepSVG data has no arcs, so slots 0-4 never do): the head then runs on that slot range only
+            counts.append((targets[3].view(-1, n_args) != 0).any(0).to(torch.int32))
         if counts:
             vals = (torch.cat(counts) if len(counts) > 1 else counts[0]).tolist()      # the one host read
             if plan["enc"] is not None:
@@ -657,6 +663,14 @@ class SVGTransformer(nn.Module):
                 plan["dec"]["n_visible"] = int(vals.pop(0))
             if plan["loss"] is not None:
                 plan["loss"]["n_live"] = int(vals.pop(0))
+                used = [i for i, v in enumerate(vals) if v]         # (the slot flags are the tail of the read)
+                n_args = len(vals)
+                lo, hi = (used[0], used[-1] + 1) if (used and self.head_slot_range) else (0, n_args)
+                plan["loss"]["slot_lo"], plan["loss"]["slot_hi"] = lo, hi
+                if (lo, hi) != (0, n_args):
+                    t = plan["loss"]["targets"]
+                    plan["loss"]["targets_r"] = (t[2].view(-1, n_args)[:, lo:hi].contiguous().view(-1),
+                                                 t[3].view(-1, n_args)[:, lo:hi].contiguous().view(-1))
         return plan
 
 
@@ -944,7 +958,9 @@ class SVGTransformer(nn.Module):
                 fcn = self.decoder.fcn.args_fcn
                 res["_dsvg_head"] = dict(rt=rt, x=self._head_in, weight=fcn.weight, bias=fcn.bias,
                                          targets=pl["targets"], live=(pl["live"], n_rows),
-                                         tgt_commands=commands_dec, tgt_args=args_dec)
+                                         tgt_commands=commands_dec, tgt_args=args_dec,
+                                         slots=(pl.get("slot_lo", 0), pl.get("slot_hi", args_dec.shape[-1])),
+                                         targets_r=pl.get("targets_r"))
                 self.last_head_rows = (pl["n_live"], T_dec)
             if getattr(self, "_live", None) is not None:
                 # the live-prefix backward of the second decoder stage is exact under SVGLoss only: deepsvg_amd.SVGLoss

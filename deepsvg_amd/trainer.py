@@ -270,6 +270,7 @@ class TrainStep:
             rows = min((plan["loss"]["n_live"] + rb - 1) // rb * rb, n_seq * (commands.shape[2] - 1))
             plan["loss"]["rows"] = rows
             key.append(rows)
+            key.append((plan["loss"].get("slot_lo", 0), plan["loss"].get("slot_hi", -1)))
         else:
             key.append(-1)
         return tuple(key), plan

@@ -425,6 +425,30 @@ def test_greedy_sample_and_encode_decode(gpu_device):
     assert cy.shape == (4, 8, 31) and ay.shape == (4, 8, 31, 11)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_head_on_the_loss_carrying_slot_range_is_exact(gpu_device, dtype):
+    """The argument head + loss run on the argument slots that carry loss somewhere in the batch only (the synthetic and
+    the real data have no arcs: slots 0-4 never do).  The skipped slots' logits never enter the loss and their gradients
+    are exact zeros: same loss, same gradients as the full 11-slot head; the skipped rows of the head's weight gradient
+    are written as zeros."""
+    cfg = H.build_cfg("hier")
+    commands, args = make_batch(24, seed=31)
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 17)
+    res = {}
+    for on in (True, False):
+        model = _hip_model(cfg, sd, dtype).eval()
+        model.head_slot_range = on
+        out, ld, grads = _fwd_bwd(model, cfg, commands, args)
+        res[on] = (ld, grads)
+    tol = 1e-5 if dtype == torch.float32 else 3e-3
+    for k in res[True][0]:
+        assert abs(res[True][0][k] - res[False][0][k]) <= tol * max(1.0, abs(res[False][0][k])), k
+    worst, name = max((H.rel_l2(res[True][1][n], res[False][1][n]), n) for n in res[True][1])
+    assert worst < (1e-4 if dtype == torch.float32 else 3e-2), (worst, name)
+    gw = res[True][1]["decoder.fcn.args_fcn.weight"]
+    assert torch.count_nonzero(gw[:5 * 257]) == 0 and torch.count_nonzero(gw[5 * 257:]) > 0
+
+
 def test_data_parallel_step_over_rccl_one_rank(gpu_device):
     """The data-parallel TrainStep on a ONE-rank RCCL group (force_ddp): eager (count all-reduce inside the loss, two
     overlapped gradient buckets) and hipGraph mode (count all-reduce before the graph, graph = forward + backward, gradient
