@@ -626,7 +626,9 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_hidden_kernel(const bf16_t* __
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __restrict__ dpre, const bf16_t* __restrict__ x,
                                                             const bf16_t* __restrict__ dy, const bf16_t* __restrict__ img,
-                                                            bf16_t* __restrict__ dx, int M, float eps) {
+                                                            bf16_t* __restrict__ dx, int M, float eps,
+                                                            bf16_t* __restrict__ dxm, float drop_p,
+                                                            const uint64_t* __restrict__ seed, uint32_t site_m) {
     constexpr int NBUF = 4, SLOT = 16 * FRAG;
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // [4 x 16 KiB]
     const int tid = threadIdx.x;
@@ -763,6 +765,9 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
     asm volatile("" : "+v"(zoff) : "v"(acc[7][15]), "v"(acc[0][0]));
     const char* dyrow = reinterpret_cast<const char*>(dy) + (size_t)my_row * (FD * 2) + zoff;
     char* orow = reinterpret_cast<char*>(dx) + (size_t)my_row * (FD * 2);
+    // optional second output: dx with the dropout mask of the attention sub-block's residual site replayed on it (what
+    // dsvg_drop_apply would make of the rounded dx: the next two GEMMs of the backward pass read it)
+    char* mrow = dxm ? reinterpret_cast<char*>(dxm) + (size_t)my_row * (FD * 2) : nullptr;
     uint4 dr[16];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -780,6 +785,26 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
                 for (int e = 0; e < 8; ++e) v[e] += acc[t][8 * cb + e];
                 *reinterpret_cast<uint4*>(orow + (32 * t + 16 * half + 8 * cb) * 2) = pack8(v);
             }
+    }
+    if (mrow && m < M) {
+        // second pass, from the rows this lane has just stored (L2-hot; the registers above are all in use in the first
+        // pass): wait for the stores, then read back through an address the compiler cannot match with them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t zo2 = 0;
+        asm volatile("" : "+v"(zo2));
+        const char* back = orow + zo2;
+        const DropCtx dcm = drop_make(drop_p, seed, site_m);
+#pragma unroll 2
+        for (int i = 0; i < 16; ++i) {
+            const int col = 32 * (i >> 1) + 16 * half + 8 * (i & 1);
+            const uint4 pk = *reinterpret_cast<const uint4*>(back + col * 2);
+            float w[8], mm[8];
+            unpack8(pk, w);
+            drop_mult8(dcm, (uint64_t)m * FD + col, mm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] *= mm[e];
+            *reinterpret_cast<uint4*>(mrow + col * 2) = pack8(w);
+        }
     }
 }
 
@@ -907,21 +932,26 @@ extern "C" int dsvg_ffn_bwd(const void* x, const void* dy, const void* packed_bw
                        (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res);
     DSVG_LAUNCH_CHECK("ffn_bwd (hidden)");
     hipLaunchKernelGGL(ffn_bwd_dx_kernel, dim3(nb), dim3(512), lds2, st, (const bf16_t*)dpre, (const bf16_t*)x,
-                       (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps);
+                       (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps, (bf16_t*)nullptr, 0.f,
+                       (const uint64_t*)nullptr, 0u);
     DSVG_LAUNCH_CHECK("ffn_bwd (dx)");
     return 0;
 }
 
 extern "C" int dsvg_ffn_bwd_dx(const void* dpre, const void* x, const void* dy, const void* packed_bwd_layer, void* dx,
-                               int64_t rows, float eps, void* stream) {
+                               int64_t rows, float eps, void* dx_masked, float drop_p, uint32_t drop_site, const void* seed,
+                               void* stream) {
     DSVG_CHECK_ARG(dpre && x && dy && packed_bwd_layer && dx, "ffn_bwd_dx: null pointer");
+    DSVG_CHECK_ARG(!dx_masked || !(drop_p > 0.f) || seed, "ffn_bwd_dx: the masked output needs a seed");
+    DSVG_CHECK_ARG(((uintptr_t)dx_masked & 15) == 0, "ffn_bwd_dx: operands must be 16-byte aligned");
     DSVG_CHECK_ARG(rows > 0 && rows < (1ll << 31) - TOK_PER_WG, "ffn_bwd_dx: bad row count");
     DSVG_CHECK_ARG((((uintptr_t)dpre | (uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)packed_bwd_layer) & 15) == 0,
                    "ffn_bwd_dx: operands must be 16-byte aligned");
     const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
     const size_t lds2 = 4 * 16 * FRAG;
     hipLaunchKernelGGL(ffn_bwd_dx_kernel, dim3(nb), dim3(512), lds2, (hipStream_t)stream, (const bf16_t*)dpre,
-                       (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps);
+                       (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps,
+                       (bf16_t*)dx_masked, drop_p, (const uint64_t*)seed, drop_site);
     DSVG_LAUNCH_CHECK("ffn_bwd_dx");
     return 0;
 }

@@ -32,6 +32,9 @@ ATTN_MIN_ROWS = int(os.environ.get("DSVG_ATTN_MIN_ROWS", "16384"))
 SIDE_MAX_ROWS = int(os.environ.get("DSVG_SIDE_MAX_ROWS", "16384"))
 # fused-FFN backward: weight-gradient GEMMs right behind the producers of their operands (1) or at the end (0)
 FFN_BWD_ORDER = os.environ.get("DSVG_FFN_BWD_ORDER", "1") != "0"
+# dx and its dropout-masked copy from one ffn_bwd_dx launch instead of a drop_apply launch: measured SLOWER (8.52 vs 8.43
+# ms/step: the extra pass sits on the tail of a one-workgroup-per-CU kernel), so it is opt-in
+FFN_BWD_MASKED = os.environ.get("DSVG_FFN_BWD_MASKED", "0") != "0"
 
 
 _NULL_CTX = contextlib.nullcontext()
@@ -522,6 +525,7 @@ class LayerFn(torch.autograd.Function):
             (dx2, x, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h) = (
                 (t[:R] if t is not None else None) for t in (dx2, x, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h))
         inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
+        dx1m = None
         if ctx.ffn_fused:
             pb, b1f, w2p = rt.store.ffn(w1)[1:]
             T = x1.shape[0]
@@ -567,7 +571,11 @@ class LayerFn(torch.autograd.Function):
                     dpre = ops.gemm(dym, w2p, b_kc=False, gate=hp, gate_scale=inv_keep)
                     if FFN_BWD_ORDER:
                         wgrad1(dpre, xh)
-                    dx1 = ops.ffn_bwd_dx(dpre, x1, dx2, pb)
+                    # (the same launch also hands over dx1 with the attention residual's dropout mask replayed on it)
+                    if FFN_BWD_MASKED:
+                        dx1, dx1m = ops.ffn_bwd_dx(dpre, x1, dx2, pb, masked=(p, s0 + 1, rt.seed))
+                    else:
+                        dx1 = ops.ffn_bwd_dx(dpre, x1, dx2, pb)
                     if not FFN_BWD_ORDER:
                         wgrad2(dym, hp)
                         wgrad1(dpre, xh)
@@ -611,7 +619,8 @@ class LayerFn(torch.autograd.Function):
             if ctx.needs_input_grad[3]:
                 dz = ops.gemm(dg, rt.w(wg), b_kc=False)
         # ---- attention: x1 = x + drop1(ao Wo^T + bo) ----
-        dx1m = ops.drop_apply(dx1, p, s0 + 1, rt.seed)
+        if dx1m is None:
+            dx1m = ops.drop_apply(dx1, p, s0 + 1, rt.seed)
         dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao)
         dao = ops.gemm(dx1m, rt.w(wo), b_kc=False)
         del dx1m

@@ -882,18 +882,27 @@ def ffn_bwd(x, dy, packed_bwd_layer, b1f, eps=1e-5, drop_p=0.0, site_hidden=0, s
     return dx, h, dpre, xh, dym
 
 
-def ffn_bwd_dx(dpre, x, dy, packed_bwd_layer, eps=1e-5):
-    """dx = dy + LayerNorm'(dpre . W1')  (dpre bf16 [rows, 512] in fragment order; include/dsvg.h)"""
+def ffn_bwd_dx(dpre, x, dy, packed_bwd_layer, eps=1e-5, masked=None):
+    """dx = dy + LayerNorm'(dpre . W1')  (dpre bf16 [rows, 512] in fragment order; include/dsvg.h).
+    masked = (drop_p, drop_site, seed): also return drop_apply(dx, drop_p, drop_site, seed) from the same launch -> (dx, dxm)"""
     _chk(dpre, x, dy, packed_bwd_layer)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
     assert dy.dtype == x.dtype and dy.shape == x.shape and dy.is_contiguous()
     assert dpre.dtype == x.dtype and tuple(dpre.shape) == (x.shape[0], 512) and dpre.is_contiguous()
     assert packed_bwd_layer.numel() == FFN_BWD_LAYER_ELEMS and packed_bwd_layer.is_contiguous()
     dx = torch.empty_like(x)
+    dxm, mp, msite, mseed = None, 0.0, 0, None
+    if masked is not None and masked[0] > 0:
+        mp, msite, mseed = float(masked[0]), int(masked[1]), masked[2]
+        _chk(mseed)
+        dxm = torch.empty_like(x)
     ev = _prof_begin()
     _l.check(_l.load().dsvg_ffn_bwd_dx(dpre.data_ptr(), x.data_ptr(), dy.data_ptr(), packed_bwd_layer.data_ptr(),
-                                       dx.data_ptr(), x.shape[0], float(eps), _stream()), "dsvg_ffn_bwd_dx")
+                                       dx.data_ptr(), x.shape[0], float(eps), _p(dxm), mp, msite, _p(mseed), _stream()),
+             "dsvg_ffn_bwd_dx")
     _prof_end(ev, 2.0 * 256 * 512 * x.shape[0], (1024.0 + 3 * 512) * x.shape[0], dict(op="ffn_bwd_dx", rows=x.shape[0]))
+    if masked is not None:
+        return dx, (dxm if dxm is not None else dx)
     return dx
 
 

@@ -403,9 +403,12 @@ int dsvg_ffn_bwd(const void* x, const void* dy, const void* packed_bwd_layer, co
                  void* xh, void* dym, void* dx, int64_t rows, float eps, float drop_p, uint32_t site_hidden,
                  uint32_t site_res, const void* seed, void* stream);
 /* kernel 2 alone: dx = dy + LayerNorm'(dpre . W1') from a dpre (bf16 [rows, 512], fragment order) the caller produced
- * (training default: dpre = (dym . W2p) gated by the h the forward kernel stored, one dsvg_gemm) */
-int dsvg_ffn_bwd_dx(const void* dpre, const void* x, const void* dy, const void* packed_bwd_layer, void* dx, int64_t rows,
-                    float eps, void* stream);
+ * (training default: dpre = (dym . W2p) gated by the h the forward kernel stored, one dsvg_gemm).
+ * dx_masked (optional): a second output, dx with the dropout mask (drop_p, drop_site, ids row * 256 + column) replayed on
+ * it - exactly dsvg_drop_apply(dx) - for the attention sub-block's backward, which starts from it */
+int dsvg_ffn_bwd_dx(const void* dpre, const void* x, const void* dy, const void* packed_bwd_layer, void* dx,
+                    int64_t rows, float eps, void* dx_masked, float drop_p, uint32_t drop_site, const void* seed,
+                    void* stream);
 int dsvg_ffn_wgrad_finish(const float* g1p, const float* db1p, const float* g2p, const float* w1, const float* gamma,
                           const float* beta, float* dw1, float* db1, float* dw2, float* dgamma, float* dbeta,
                           void* stream);

@@ -974,6 +974,25 @@ def test_ffn_bwd_matches_reference(gpu_device, rows, drop_p):
         assert (got[4] == 0).float().mean().item() > 0.08 and y.isfinite().all()
 
 
+def test_ffn_bwd_dx_masked_second_output(gpu_device):
+    """dsvg_ffn_bwd_dx can hand back dx with a dropout mask replayed on it from the same launch: bit-identical to
+    dsvg_drop_apply on its first output (same ids row * 256 + column, applied to the bf16-rounded dx)"""
+    rows = 4133
+    flat, offs, x, _ = _ffn_setup(rows, seed=9)
+    _, pb, _ = ops.ffn_pack(flat, offs, 2)
+    dpre = (_rand(rows, 512, seed=91) * 0.3).to(torch.bfloat16)
+    dy = _rand(rows, 256, seed=92).to(torch.bfloat16)
+    seed = _seed_tensor(0x00C0FFEE12345678)
+    layer = pb[ops.FFN_BWD_LAYER_ELEMS:2 * ops.FFN_BWD_LAYER_ELEMS]
+    dx0 = ops.ffn_bwd_dx(dpre, x, dy, layer)
+    dx, dxm = ops.ffn_bwd_dx(dpre, x, dy, layer, masked=(0.1, 77, seed))
+    assert torch.equal(dx, dx0)
+    assert torch.equal(dxm, ops.drop_apply(dx0, 0.1, 77, seed))
+    assert 0.05 < (dxm == 0).float().mean().item() < 0.15
+    dx2, dxm2 = ops.ffn_bwd_dx(dpre, x, dy, layer, masked=(0.0, 77, seed))
+    assert torch.equal(dx2, dx0) and dxm2 is dx2
+
+
 def test_ffn_wgrad_finish_and_full_gradients(gpu_device):
     """fused forward + backward + the two weight-gradient GEMMs + wgrad_finish against autograd on the unfused fp32
     formulation (LayerNorm with gamma / beta, linear1, ReLU, linear2, residual; no dropout): dx, dW1, db1, dW2, db2,

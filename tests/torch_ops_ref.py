@@ -780,7 +780,10 @@ def ffn_bwd(x, dy, packed_bwd_layer, b1f, eps=1e-5, drop_p=0.0, site_hidden=0, s
     return dx.to(x.dtype), hp, dp, xh, dym
 
 
-def ffn_bwd_dx(dpre, x, dy, packed_bwd_layer, eps=1e-5):
+def ffn_bwd_dx(dpre, x, dy, packed_bwd_layer, eps=1e-5, masked=None):
+    if masked is not None:
+        dx = ffn_bwd_dx(dpre, x, dy, packed_bwd_layer, eps)
+        return dx, drop_apply(dx, masked[0], masked[1], masked[2])
     W1, _ = _ffn_weights(packed_bwd_layer)
     _, mean, rstd = _ffn_normalise(x, eps)
     g = _f(dpre)[:, _ffn_frag_perm(x.device)] @ _f(W1)          # dpre[:, p(j)] is unit j
