@@ -111,10 +111,7 @@ class TrainStep:
                              (targets[1] != 0).sum().float(), (targets[3] != 0).sum().float()])
         dist.all_reduce(local, group=self.pg)
         local /= self.world
-        if self._counts is None:
-            self._counts = local.clone()
-        else:
-            self._counts.copy_(local)
+        return local
 
     # ---- one step ------------------------------------------------------------------------------------
     def _step_body(self, commands, args, label=None, dec=None):
@@ -198,9 +195,16 @@ class TrainStep:
         ps = self._plan_stream
         if not self.inputs_resident:
             ps.wait_stream(main)
+        counts = None
         with torch.cuda.stream(ps):
             plan = model.make_plan(commands, args, dec[0] if dec else commands, True, dec[1] if dec else args)
+            if self.ddp and self.use_graph:
+                # data parallel + hipGraph: the 3-element count all-reduce rides on the plan stream too (under the
+                # previous step's graph); its result is copied into the graph's static tensor right before the replay
+                counts = self._global_counts(dec[0] if dec else commands, dec[1] if dec else args, plan)
         main.wait_stream(ps)
+        if counts is not None:
+            counts.record_stream(main)
         for part in ("enc", "dec", "loss"):        # allocated on the plan stream, read by launches on the main stream
             for v in (plan[part] or {}).values():
                 for t in (v if isinstance(v, tuple) else (v,)):
@@ -218,7 +222,10 @@ class TrainStep:
             # data parallel: the graph holds forward + backward only.  The loss normalisers go out before it, the gradient
             # all-reduce and the optimiser run eagerly behind it (graph -> all-reduce -> clip + AdamW): no collective is
             # ever captured, and a rank that has to capture a new bucket issues exactly the collectives of a replaying one
-            self._global_counts(dec[0] if dec else commands, dec[1] if dec else args, plan)
+            if self._counts is None:
+                self._counts = counts.clone()
+            else:
+                self._counts.copy_(counts)
         key, plan = self._bucketed(plan, commands)
         key = key + (label is not None, dec is not None)
         entry = self._graphs.get(key)

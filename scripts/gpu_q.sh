@@ -1,4 +1,4 @@
 cd "$(dirname "$0")/.."
 export PYTHONDONTWRITEBYTECODE=1 TMPDIR=/tmp
-show='import sys,json; r=json.loads(sys.stdin.read()); print(r["ms_per_step"], r["value"])'
-for v in 1 0 1 0 1 0; do echo "--- masked copy from ffn_bwd_dx: $v"; DSVG_FFN_BWD_MASKED=$v timeout 600 python bench.py --no-cpu-baseline --no-fp32 --no-roofline 2>&1 | grep '^{"metric"' | python -c "$show"; done
+( timeout 600 python -m pytest tests/test_model_gpu.py -m gpu -q -p no:cacheprovider --timeout 600 -k "rccl" ) 2>&1 | grep -E "passed|failed" | tail -2
+timeout 400 python scripts/ddp_probe.py 2>&1 | grep "force_ddp\|alone" | head -8
