@@ -305,9 +305,17 @@ def main():
             ops.PROFILE.clear()
             ops.PROFILE_ON = True
             n_prof = 3
+            # the eager launches of a step take the host longer than the GPU needs to run them: an interval between two
+            # events would then include the host's gap before the launch.  ~30 ms of unrelated GPU work in front of
+            # every profiled step lets the host enqueue the whole step first, so every interval is kernel time only
+            ballast = torch.randn(8192, 8192, device=device)
             for _ in range(n_prof):
+                sync()
+                for _b in range(3):
+                    ballast @ ballast
                 ts_prof.step(commands, args)
             sync()
+            del ballast
             ops.PROFILE_ON = False
             ffn = [r for r in ops.PROFILE if r[0] == "ffn"]
             ffn_ms = sum(r[1].elapsed_time(r[2]) for r in ffn) / n_prof
