@@ -657,9 +657,15 @@ __global__ void masked_mean_bwd_kernel(const T* __restrict__ dout, const uint64_
     long long row0 = b * S;
     uint64_t m;
     if (seq_off) {
-        if (b == (long long)gridDim.x - 1) {
-            for (long long r = seq_off[b]; r < total_rows; ++r)
-                for (int c = threadIdx.x; c < d; c += blockDim.x) Elem<T>::st(dx + r * d + c, 0.f);
+        if (b == (long long)gridDim.x - 1) {       // rows behind the last sequence (bucket padding) <- 0, 16 bytes per store
+            const long long e0 = (long long)seq_off[b] * d, e1 = total_rows * d;
+            constexpr int V = 16 / (int)sizeof(T);
+            if (((uintptr_t)(dx + e0) & 15) == 0 && ((e1 - e0) % V) == 0) {
+                uint4* z = reinterpret_cast<uint4*>(dx + e0);
+                for (long long i = threadIdx.x; i < (e1 - e0) / V; i += blockDim.x) z[i] = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                for (long long i = e0 + threadIdx.x; i < e1; i += blockDim.x) Elem<T>::st(dx + i, 0.f);
+            }
             return;
         }
         row0 = seq_off[b];

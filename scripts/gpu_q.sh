@@ -1,10 +1,6 @@
 cd "$(dirname "$0")/.."
 export PYTHONDONTWRITEBYTECODE=1 TMPDIR=/tmp
-timeout 600 python bench.py --no-cpu-baseline --no-fp32 2>&1 | grep '^{"metric"' | python -c '
-import sys,json
-r=json.loads(sys.stdin.read()); rf=r["roofline"]
-print(r["ms_per_step"], r["value"])
-print({k:rf[k] for k in ("frac","ffn_ms_per_step","launches_per_step")}, rf["matrix_launches_only"])
-print(rf["fused_fwd_kernel"]["frac"], rf["fused_fwd_kernel"]["largest_launch"])
-print(rf["fused_attn_fwd_kernel"]["ms_per_step"], rf["fused_attn_fwd_kernel"]["frac"], rf["fused_attn_fwd_kernel"]["largest_launch"])
-print(rf["weight_grad_gemms"])'
+mkdir -p gpurun_out
+( timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -p no:cacheprovider --timeout 600 -k "masked_mean or packed or golden or slot_range or graph_replay" ) > gpurun_out/pytest_q.log 2>&1; grep -E "passed|failed|Error|error|^E " gpurun_out/pytest_q.log | cut -c1-300 | tail -6
+show='import sys,json; r=json.loads(sys.stdin.read()); print(r["ms_per_step"], r["value"])'
+for i in 1 2 3; do timeout 600 python bench.py --no-cpu-baseline --no-fp32 --no-roofline 2>&1 | grep '^{"metric"' | python -c "$show"; done
