@@ -32,6 +32,7 @@ fi
 if [[ "$WHAT" == "all" || "$WHAT" == *second* ]]; then
   run attn_microbench 300 python scripts/attn_bench.py
   run secondary_bench 600 python scripts/secondary_bench.py
+  bash scripts/gpu_prof_graph.sh prof_graph > gpurun_out/prof_graph.txt 2>&1
   run train_sanity 600 python scripts/train_sanity.py
 fi
 if [[ "$WHAT" == "all" || "$WHAT" == *prof* ]]; then
