@@ -322,7 +322,10 @@ class TrainStep:
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()     # graphs replay one at a time: one shared pool
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._pool):
+            # thread-local capture mode: other threads of the process keep calling the runtime while this one captures -
+            # with an initialised process group the RCCL watchdog thread polls its work events (hipEventQuery), which the
+            # default global mode answers by invalidating the capture and the watchdog by aborting the process
+            with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
                 res = body(sc, sa, sl, sdec)
         finally:
             model._forced_plan = None

@@ -130,7 +130,7 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
     return out
 
 
-def split_k_for(M, N, K, target_blocks=512):
+def split_k_for(M, N, K, target_blocks=256):
     """same policy as deepsvg_amd.ops.split_k_for (the emulated gemm ignores the value, but the host logic that
     decides whether the bias gradient can ride on the weight-gradient GEMM depends on it)"""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
