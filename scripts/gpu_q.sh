@@ -1,7 +1,6 @@
 cd "$(dirname "$0")/.."
 export PYTHONDONTWRITEBYTECODE=1 TMPDIR=/tmp
 mkdir -p gpurun_out
-for i in 1 2 3 4; do
-( DSVG_FORCE_DDP=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 2971$i bench.py --gpus 1 --no-cpu-baseline --no-fp32 --no-roofline ) > gpurun_out/rccl_$i.log 2>&1; echo "run $i rc=$?"; grep -o '"ms_per_step": [0-9.]*\|"hip_graph": [a-z]*\|capture failed' gpurun_out/rccl_$i.log | tr '\n' ' '; echo
-done
-( timeout 600 python -m pytest tests/test_model_gpu.py -m gpu -q -p no:cacheprovider --timeout 600 -k "rccl or graph_replay or self_matching or autoregressive_training" ) 2>&1 | grep -E "passed|failed" | tail -2
+( timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -p no:cacheprovider --timeout 600 -k "expand_rows or golden or slot_range or graph_replay or benchmark_size" ) > gpurun_out/pytest_q.log 2>&1; grep -E "passed|failed|Error|error|^E " gpurun_out/pytest_q.log | cut -c1-300 | tail -6
+show='import sys,json; r=json.loads(sys.stdin.read()); print(r["ms_per_step"], r["value"])'
+for v in 1 0 1 0; do echo "--- head dX by expand_rows: $v"; DSVG_HEAD_EXPAND=$v timeout 600 python bench.py --no-cpu-baseline --no-fp32 --no-roofline 2>&1 | grep '^{"metric"' | python -c "$show"; done
