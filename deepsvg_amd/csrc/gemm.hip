@@ -8,6 +8,7 @@
 #include "dsvg_common.h"
 #include "../../include/dsvg.h"
 #include "gemm_common.h"
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -391,13 +392,19 @@ constexpr int DEFER_MAX = 64;
 struct DeferTable { DeferSeg s[DEFER_MAX]; int n_seg; };
 static_assert(sizeof(DeferTable) <= 3600, "the segment table must fit the kernel-argument segment");
 
+// One queue per STREAM (a stream belongs to one device): the reductions of a launch sequence are queued on, and flushed to,
+// the stream that sequence runs on, so two models / trainers / devices in one process never see each other's entries.  The
+// table itself is process-wide and mutex-protected because autograd runs backward nodes on its own device thread (same
+// stream, another host thread than the one that opened the scope).
 struct DeferQueue {
-    std::mutex mu;                 // autograd runs backward nodes on its own device thread
     int scope = 0;
-    hipStream_t st = nullptr;
     std::vector<DeferSeg> q;
 };
-DeferQueue& defer_queue() { static DeferQueue d; return d; }
+struct DeferTableOfQueues {
+    std::mutex mu;
+    std::map<hipStream_t, DeferQueue> by_stream;
+};
+DeferTableOfQueues& defer_queues() { static DeferTableOfQueues d; return d; }
 
 constexpr int DF_TX = 32, DF_TY = 8;       // 32 float4 column lanes x 8 groups over the partial index per block
 
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(256) void reduce_deferred_kernel(const DeferTable t
     }
 }
 
-int defer_flush_locked(DeferQueue& d) {
+int defer_flush_locked(DeferQueue& d, hipStream_t st) {
     size_t at = 0;
     while (at < d.q.size()) {
         DeferTable t;
@@ -460,7 +467,7 @@ int defer_flush_locked(DeferQueue& d) {
             blocks += dsvg_cdiv(t.s[k].n, DF_TX * 4);
         }
         t.n_seg = k;
-        hipLaunchKernelGGL(reduce_deferred_kernel, dim3(blocks), dim3(256), 0, d.st, t);
+        hipLaunchKernelGGL(reduce_deferred_kernel, dim3(blocks), dim3(256), 0, st, t);
     }
     d.q.clear();
     DSVG_LAUNCH_CHECK("reduce_deferred");
@@ -475,19 +482,29 @@ bool defer_overlaps(const DeferQueue& d, const float* out, int64_t n) {
 }
 }  // namespace
 
-extern "C" int dsvg_defer_scope(int32_t on) {
-    DeferQueue& d = defer_queue();
-    std::lock_guard<std::mutex> lk(d.mu);
-    d.scope = on ? 1 : 0;
-    return (int)d.q.size();
+extern "C" int dsvg_defer_scope(int32_t on, void* stream) {
+    DeferTableOfQueues& t = defer_queues();
+    std::lock_guard<std::mutex> lk(t.mu);
+    auto it = t.by_stream.find((hipStream_t)stream);
+    if (it == t.by_stream.end()) {
+        if (!on) return 0;
+        it = t.by_stream.emplace((hipStream_t)stream, DeferQueue{}).first;
+    }
+    it->second.scope = on ? 1 : 0;
+    const int queued = (int)it->second.q.size();
+    if (!on && queued == 0) t.by_stream.erase(it);      // closed and drained: forget the stream
+    return queued;
 }
 
 extern "C" int dsvg_flush_deferred(void* stream) {
-    DeferQueue& d = defer_queue();
-    std::lock_guard<std::mutex> lk(d.mu);
-    if (d.q.empty()) return 0;
-    d.st = (hipStream_t)stream;     // the caller has ordered this stream behind every producer of the queued partials
-    return defer_flush_locked(d);
+    DeferTableOfQueues& t = defer_queues();
+    std::lock_guard<std::mutex> lk(t.mu);
+    auto it = t.by_stream.find((hipStream_t)stream);
+    if (it == t.by_stream.end() || it->second.q.empty()) return 0;
+    // (the queued partials were produced on this very stream: the launch below is ordered behind all of them)
+    const int rc = defer_flush_locked(it->second, (hipStream_t)stream);
+    if (!it->second.scope) t.by_stream.erase(it);
+    return rc;
 }
 
 int dsvg_reduce_partials_mixed(const float* part, int64_t P, int64_t stride, int64_t n, int64_t n_bf16, float* out,
@@ -495,17 +512,20 @@ int dsvg_reduce_partials_mixed(const float* part, int64_t P, int64_t stride, int
     if (n <= 0) return 0;
     const bool vec = !(n & 3) && !(stride & 3) && !((uintptr_t)part & 15) && !((uintptr_t)out & 15) && !(n_bf16 & 3);
     {
-        DeferQueue& d = defer_queue();
-        std::lock_guard<std::mutex> lk(d.mu);
-        if (!d.q.empty() && defer_overlaps(d, out, n)) {
-            // a second write to a queued destination: order matters, run the queue now (on the stream of the last push)
-            int rc = defer_flush_locked(d);
-            if (rc) return rc;
-        }
-        if (d.scope && vec && n < (1ll << 30) && P < (1ll << 30)) {
-            d.st = st;
-            d.q.push_back(DeferSeg{part, out, (long long)stride, (int)n, (int)n_bf16, (int)P, 0, accumulate, 0});
-            return 0;
+        DeferTableOfQueues& t = defer_queues();
+        std::lock_guard<std::mutex> lk(t.mu);
+        auto it = t.by_stream.find(st);
+        if (it != t.by_stream.end()) {
+            DeferQueue& d = it->second;
+            if (!d.q.empty() && defer_overlaps(d, out, n)) {
+                // a second write to a queued destination: order matters, run the queue now (same stream: ordered)
+                int rc = defer_flush_locked(d, st);
+                if (rc) return rc;
+            }
+            if (d.scope && vec && n < (1ll << 30) && P < (1ll << 30)) {
+                d.q.push_back(DeferSeg{part, out, (long long)stride, (int)n, (int)n_bf16, (int)P, 0, accumulate, 0});
+                return 0;
+            }
         }
     }
     if (n_bf16 > 0 && !vec) { dsvg_set_error("reduce_partials: bf16 partials need 16-byte aligned, 4-column-multiple data"); return -1; }

@@ -1,5 +1,5 @@
 // Shared declarations of the bf16 GEMM kernels (gemm_bf16.hip: register-staged, any shape; gemm_bf16_glds.hip:
-// LDS-DMA staged 128x128 tiles, aligned shapes; gemm_bf16_ws.hip: weight-stationary, long token streams).
+// LDS-DMA staged 128x128 tiles, aligned shapes).
 #pragma once
 #include "dsvg_common.h"
 #include "../../include/dsvg.h"
@@ -17,5 +17,3 @@ enum {
 // part_is_bf16 (split-K only, may be NULL): set to 1 when the slices were written as packed bf16 (see the kernel)
 bool dsvg_gemm_bf16_glds_try(const dsvg_gemm_desc& d, int epi, dim3 grid, int tiles_n, int nwg, int k_chunk,
                              float* part, float* rs_part, int mode, hipStream_t st, int* part_is_bf16);
-// Launches the weight-stationary kernel when the call is eligible (see gemm_bf16_ws.hip); returns false otherwise.
-bool dsvg_gemm_bf16_ws_try(const dsvg_gemm_desc& d, int epi, hipStream_t st);

@@ -448,10 +448,6 @@ int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, floa
                           (!d.gate || (!(d.ldgate & 7) && !((uintptr_t)d.gate & 15)));
     const int epi_dma = classify(vec_base);
     const int epi = classify(vec_base && !(d.N & 7));
-    if (epi_dma != EPI_GENERIC && dsvg_gemm_bf16_ws_try(d, epi_dma, st)) {
-        DSVG_LAUNCH_CHECK("gemm_bf16_ws");
-        return 0;
-    }
     if (epi_dma != EPI_GENERIC && dsvg_gemm_bf16_glds_try(d, epi_dma, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, st, nullptr)) {
         DSVG_LAUNCH_CHECK("gemm_bf16_glds");
         return 0;

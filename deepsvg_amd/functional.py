@@ -29,7 +29,6 @@ FFN_BWD_FUSED = os.environ.get("DSVG_FFN_BWD_FUSED", "0") != "0"
 FFN_MIN_ROWS = int(os.environ.get("DSVG_FFN_MIN_ROWS", "16384"))
 # the fused attention block owns 8 tiles of <= 32 rows per workgroup (same granularity: unfused launches below this)
 ATTN_MIN_ROWS = int(os.environ.get("DSVG_ATTN_MIN_ROWS", "16384"))
-SIDE_MAX_ROWS = int(os.environ.get("DSVG_SIDE_MAX_ROWS", "16384"))
 # fused-FFN backward: weight-gradient GEMMs right behind the producers of their operands (1) or at the end (0)
 FFN_BWD_ORDER = os.environ.get("DSVG_FFN_BWD_ORDER", "1") != "0"
 # dx and its dropout-masked copy from one ffn_bwd_dx launch instead of a drop_apply launch: measured SLOWER (8.52 vs 8.43
@@ -43,7 +42,7 @@ _NULL_CTX = contextlib.nullcontext()
 class Runtime:
     """Per-forward execution context shared by the Functions."""
 
-    def __init__(self, dtype=torch.float32, seed=None, store=None, training=False, side_stream=None, defer=False):
+    def __init__(self, dtype=torch.float32, seed=None, store=None, training=False, defer=False):
         self.dtype = dtype
         # queue the partial-sum reductions of the parameter gradients (ops.DEFER) instead of launching ~130 of them one
         # by one: only a caller that flushes before anything reads a gradient may set it (TrainStep)
@@ -51,32 +50,10 @@ class Runtime:
         self.seed = seed          # int64[1] device tensor holding the dropout seed of this step
         self.store = store        # ParamStore or None
         self.training = training
-        # optional second stream for the weight-gradient GEMMs (+ their split-K reductions): they are off the critical
-        # path of the backward pass, and a third of the step is launch-latency-bound small kernels they can overlap
-        # with.  Only a trainer that joins the stream before it touches the gradients may set it (TrainStep).
-        self.side_stream = side_stream
-        self._keep = []           # operands of side-stream work, kept alive until join()
-
-    def on_side(self, *operands, rows=0):
-        """context manager: run the enclosed launches on the side stream, ordered after everything enqueued so far.
-        Only the weight gradients of the SMALL stages go there (rows < SIDE_MAX_ROWS: launch-latency-bound GEMMs that a
-        captured graph can run beside the main chain); the big ones are HBM-bound and gain nothing from overlap."""
-        side = self.side_stream
-        if side is None or rows >= SIDE_MAX_ROWS:
-            return _NULL_CTX
-        side.wait_stream(torch.cuda.current_stream())
-        self._keep.extend(operands)
-        return torch.cuda.stream(side)
 
     def deferring(self):
         """context manager around launches whose reductions write parameter gradients"""
         return ops.DEFER if self.defer else _NULL_CTX
-
-    def join(self):
-        """make the current stream wait for the side stream; only then may the kept operands be released"""
-        if self.side_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.side_stream)
-        self._keep.clear()
 
     def p(self, rate):
         """effective dropout probability"""
@@ -111,7 +88,7 @@ def _wgrad(rt, param, dy, x, *, a_drop_p=0.0, a_drop_site=0):
     out = rt.grad_out(param)
     n_out, k_in = param.shape
     T = dy.shape[0]
-    with rt.on_side(dy, x, rows=T), rt.deferring(), _wgrad_tag():
+    with rt.deferring(), _wgrad_tag():
         ops.gemm(dy, x, a_kc=False, b_kc=False, out=out.view(n_out, k_in), a_drop_p=a_drop_p, a_drop_site=a_drop_site,
                  seed=rt.seed, split_k=ops.split_k_for(n_out, k_in, T))
     return out
@@ -125,7 +102,7 @@ def _wbgrad(rt, weight, bias, dy, x):
     split = ops.split_k_for(n_out, k_in, dy.shape[0])
     dw = rt.grad_out(weight)
     db = rt.grad_out(bias)
-    with rt.on_side(dy, x, rows=dy.shape[0]), rt.deferring(), _wgrad_tag():
+    with rt.deferring(), _wgrad_tag():
         if split > 1:
             ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in), split_k=split, rowsum=db)
         else:
@@ -537,7 +514,7 @@ class LayerFn(torch.autograd.Function):
                 s2, s1 = ops.split_k_for(256, 512, T), ops.split_k_for(512, 256, T)
 
                 def wgrad2(dym, hp):        # G2p = dym^T h (fragment-ordered columns), db2 = its row sums
-                    with rt.on_side(dym, hp, rows=T), rt.deferring():
+                    with rt.deferring():
                         if s2 > 1:
                             ops.gemm(dym, hp, a_kc=False, b_kc=False, out=g2p, split_k=s2, rowsum=db2)
                         else:
@@ -545,7 +522,7 @@ class LayerFn(torch.autograd.Function):
                             ops.colsum(dym, out=db2)
 
                 def wgrad1(dpre, xh):       # G1p = dpre^T xh, db1' = its row sums
-                    with rt.on_side(dpre, xh, rows=T), rt.deferring():
+                    with rt.deferring():
                         if s1 > 1:
                             ops.gemm(dpre, xh, a_kc=False, b_kc=False, out=g1p, split_k=s1, rowsum=db1p)
                         else:

@@ -461,6 +461,12 @@ class ParamStore:
             # they must not share memory - hand out a private tensor.  (A trainer may have queued the reduction that
             # fills the first one: autograd is about to read it.)
             ops.flush_deferred()
+            if getattr(self.module, "_defer_wgrad", False) or ops.defer_active():
+                # the reduction that fills this private tensor would be QUEUED, and autograd sums the two contributions
+                # as soon as the node returns - before any flush.  No shipped config shares a parameter between two
+                # Functions; one that does has to run with immediate reductions
+                raise RuntimeError("a parameter used by two autograd nodes received a second gradient while deferred "
+                                   "reductions are on: use TrainStep(...).defer_reductions = False (DSVG_DEFER_REDUCE=0)")
             return torch.empty(param.shape, dtype=torch.float32, device=v.device)
         self._in_flight.add(key)
         # autograd accumulates into an existing .grad: never hand it a view that aliases that .grad
@@ -529,7 +535,6 @@ class SVGTransformer(nn.Module):
         self.last_assignment = None  # self-matching configs: (N, Gp) int32 assignment of the last training forward
         self._forced_plan = None
         self._decoder_grads_ready = None    # callback of a data-parallel trainer (TrainStep), see forward()
-        self._side_stream = None    # set by a trainer that calls join_side_stream() after backward (TrainStep)
         # queue the parameter-gradient reductions of the backward pass (ops.DEFER): only a trainer that calls
         # ops.flush_deferred() before anything reads a gradient may set it (TrainStep)
         self._defer_wgrad = False
@@ -551,11 +556,6 @@ class SVGTransformer(nn.Module):
             "decoder parameters are expected at the end of the flat buffer"
         return lo, st.flat.numel()
 
-    def join_side_stream(self):
-        """after backward: wait for the weight-gradient work on the side stream (no-op without one)"""
-        if self._rt is not None:
-            self._rt.join()
-
     @property
     def store(self):
         return self._store
@@ -571,7 +571,7 @@ class SVGTransformer(nn.Module):
         seed = self.seed_tensor(device) if training else None
         if training and self._own_seed:
             ops.advance_step_(None, seed)
-        self._rt = Fn.Runtime(self.compute_dtype, seed, self._store, training, side_stream=self._side_stream,
+        self._rt = Fn.Runtime(self.compute_dtype, seed, self._store, training,
                               defer=self._defer_wgrad and not ops.PROFILE_ON)
         return self._rt
 

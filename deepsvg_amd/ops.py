@@ -77,31 +77,52 @@ def _stream():
 
 def _ws(nbytes, device):
     t = torch.empty(max(int(nbytes), 4) // 4 + 1, dtype=torch.float32, device=device)
-    if _DEFER.depth:
-        _DEFER.keep.append(t)       # a queued reduction reads it at flush_deferred()
+    st = _DEFER.state.get(_stream_key())
+    if st is not None and st.depth:
+        st.keep.append(t)           # a queued reduction reads it at flush_deferred()
     return t
 
 
 # ------------------------------------------------------------------------------------------------
 # deferred parameter-gradient reductions (include/dsvg.h: dsvg_defer_scope / dsvg_flush_deferred)
 # ------------------------------------------------------------------------------------------------
+def _stream_key():
+    """identity of the stream the ops launch on (0 on the CPU emulation path of the test-suite)"""
+    return _stream() if torch.cuda.is_available() else 0
+
+
+class _DeferState:
+    __slots__ = ("depth", "keep", "post")
+
+    def __init__(self):
+        self.depth, self.keep, self.post = 0, [], []
+
+
 class _DeferScope:
-    """`with ops.DEFER:` - partial-sum reductions launched inside (split-K slices, LayerNorm gamma/beta partials, bias
-    column sums, embedding-table gradients) are queued; their outputs are valid after flush_deferred().  Only a caller
-    that owns the whole backward pass may open it (TrainStep): nothing may read those outputs in between."""
-    depth = 0
-    keep = []
-    post = []
+    """`with ops.DEFER:` - partial-sum reductions launched inside ON THE CURRENT STREAM (split-K slices, LayerNorm
+    gamma/beta partials, bias column sums, embedding-table gradients) are queued; their outputs are valid after
+    flush_deferred() on that stream.  Only a caller that owns the whole backward pass may open it (TrainStep): nothing
+    may read those outputs in between.  All state is per stream - the library's queue (csrc/gemm.hip) and the
+    workspaces / follow-up work kept here - so two models or trainers on different streams or devices do not interact."""
+    state = {}          # stream -> _DeferState
 
     def __enter__(self):
-        if _DeferScope.depth == 0:
-            _l.load().dsvg_defer_scope(1)
-        _DeferScope.depth += 1
+        key = _stream_key()
+        st = _DeferScope.state.get(key)
+        if st is None:
+            st = _DeferScope.state[key] = _DeferState()
+        if st.depth == 0 and torch.cuda.is_available():
+            _l.load().dsvg_defer_scope(1, key)
+        st.depth += 1
+        self._keys = getattr(self, "_keys", [])
+        self._keys.append(key)
 
     def __exit__(self, *exc):
-        _DeferScope.depth -= 1
-        if _DeferScope.depth == 0:
-            _l.load().dsvg_defer_scope(0)
+        key = self._keys.pop()
+        st = _DeferScope.state[key]
+        st.depth -= 1
+        if st.depth == 0 and torch.cuda.is_available():
+            _l.load().dsvg_defer_scope(0, key)
         return False
 
 
@@ -109,21 +130,38 @@ _DEFER = _DeferScope
 DEFER = _DeferScope()
 
 
+def defer_active():
+    """True while a deferral scope is open on the current stream"""
+    st = _DEFER.state.get(_stream_key())
+    return st is not None and st.depth > 0
+
+
 def defer_post(fn):
-    """run fn() right after the queued reductions at the next flush_deferred() (work that reads their outputs)"""
-    _DEFER.post.append(fn)
+    """run fn() right after the queued reductions at the next flush_deferred() on this stream (work that reads their
+    outputs); without an open scope on this stream nothing is queued, so fn runs now"""
+    st = _DEFER.state.get(_stream_key())
+    if st is None:
+        fn()
+    else:
+        st.post.append(fn)
 
 
 def flush_deferred():
-    """perform every queued reduction (one launch per 64), then the work registered with defer_post"""
-    if not (_DEFER.keep or _DEFER.post):
+    """perform every reduction queued on the current stream (one launch per 64), then the work registered with defer_post"""
+    key = _stream_key()
+    st = _DEFER.state.get(key)
+    if st is None or not (st.keep or st.post):
+        if st is not None and st.depth == 0:
+            _DEFER.state.pop(key, None)
         return
     if torch.cuda.is_available():
-        _l.check(_l.load().dsvg_flush_deferred(_stream()), "dsvg_flush_deferred")
-    post, _DEFER.post = _DEFER.post, []
+        _l.check(_l.load().dsvg_flush_deferred(key), "dsvg_flush_deferred")
+    post, st.post = st.post, []
     for fn in post:
         fn()
-    _DEFER.keep.clear()
+    st.keep.clear()
+    if st.depth == 0:
+        _DEFER.state.pop(key, None)
 
 
 def _rowmajor(t):

@@ -16,6 +16,7 @@ flat buffers, one process per GPU.
     rows / sequences are inert by construction - and one graph is captured per bucket pair on first use; the layout
     plan (a few tiny kernels + one host read) runs eagerly before each replay and is copied into the graph's buffers.
 """
+import collections
 import os
 
 import torch
@@ -44,23 +45,32 @@ class TrainStep:
         self.use_graph = use_graph
         self.exact_global_mean = exact_global_mean and self.ddp
         self._counts = None             # graph + DDP: the global loss counts, filled before every replay
+        self._in_own_step = False       # True only while this trainer's captured / replayed step is being enqueued
         self._lr_value = float(lr)
         self._ready = False
-        self._graphs = {}               # bucket key -> (graph, static inputs, static plan, static results)
+        # bucket key -> (graph, static inputs, static plan, static results), least recently used first.  Real data lands in
+        # tens of (packed rows, visible sequences, loss rows, slot range) buckets; each graph keeps its static tensors and
+        # its share of the pool alive, so the cache is bounded: beyond `max_graphs` the least recently used one is dropped
+        # (its bucket is simply captured again if it ever comes back).
+        self._graphs = collections.OrderedDict()
+        self.max_graphs = int(os.environ.get("DSVG_MAX_GRAPHS", "24"))
+        self.graphs_captured = 0        # statistics: captures so far (re-captures after an eviction included)
+        self.graphs_evicted = 0
         self._plan_stream = None
         self.inputs_resident = False    # see step(): set by callers whose input tensors are complete well before step()
         # gradient all-reduce in two buckets, the decoder's overlapped with the encoder's backward (eager launches only)
         self.overlap_allreduce = os.environ.get("DSVG_DDP_OVERLAP", "1") != "0"
         self._pending = None
         self._pool = None
+        self._gradless_known, self._gradless_slots = False, []
         self.row_bucket, self.seq_bucket = 1024, 64
-        # weight-gradient GEMMs on a second stream: measured 2-4 % SLOWER on one MI355X (event fork/join per GEMM costs
-        # more than the overlap with the small kernels of the group stages returns), so it is opt-in
-        self.side_stream = os.environ.get("DSVG_SIDE_STREAM", "0") != "0"
         self.defer_reductions = os.environ.get("DSVG_DEFER_REDUCE", "1") != "0"
         model._own_seed = False          # the trainer advances the dropout seed once per step
         if self.exact_global_mean:
+            # (a loss_fn serves one data-parallel trainer at a time: a newer TrainStep takes the reducer over)
             loss_fn.count_reducer = self._reduce_counts
+        elif getattr(loss_fn, "count_reducer", None) is not None and not self.ddp:
+            loss_fn.count_reducer = None    # a single-process trainer must not inherit another trainer's reducer
 
     # ---- lazily created device state -----------------------------------------------------------------
     def _setup(self, device):
@@ -73,8 +83,6 @@ class TrainStep:
         self.step_count = torch.zeros(1, dtype=torch.int64, device=device)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=device)
         self.seed = model.seed_tensor(device)
-        if self.side_stream and device.type == "cuda":
-            model._side_stream = torch.cuda.Stream(device=device)
         self._ready = True
 
     def set_lr(self, lr):
@@ -85,15 +93,17 @@ class TrainStep:
     def _launch_decoder_bucket(self):
         """called from the backward pass when every decoder gradient is final (model.forward registers the hook)"""
         lo, hi = self.model.decoder_param_range()
-        self.model.join_side_stream()       # (opt-in) weight-gradient stream: its decoder work must be complete too
         ops.flush_deferred()                # the queued split-K / LayerNorm reductions of the decoder's gradients
         flat_g = self.model.store.grad_buffer(0)
         self._pending = (lo, dist.all_reduce(flat_g[lo:hi], group=self.pg, async_op=True))
 
     def _reduce_counts(self, counts):
         """[n] local selected-element counts of the cross-entropies -> global counts / world, in ONE all-reduce"""
-        if self._counts is not None and self.use_graph:
-            return self._counts         # hipGraph + DDP: reduced before the replay (see _global_counts)
+        if self._in_own_step and self.use_graph and self._counts is not None:
+            # hipGraph + DDP, inside this trainer's own captured step: the counts were all-reduced before the replay
+            # into a static tensor (see _global_counts).  Every other caller of the loss - a validation loss, a metric,
+            # another trainer - gets a real all-reduce of ITS counts, exactly as in eager mode.
+            return self._counts
         dist.all_reduce(counts, group=self.pg)
         return counts / self.world
 
@@ -129,6 +139,12 @@ class TrainStep:
         for p in model.store.params:
             p.grad = None
         self._pending = None
+        # the norm / AdamW / all-reduce read the WHOLE flat gradient buffer: a parameter that receives no gradient in a step
+        # must contribute zero, not its gradient of an earlier step.  Which parameters those are is known from the previous
+        # step (no shipped config has one); their slots are zeroed BEFORE backward, i.e. before an overlapped decoder
+        # all-reduce can be in flight over them (and inside the captured part of a graph step)
+        for v in self._gradless_slots:
+            v.zero_()
         if self.ddp and self.overlap_allreduce and not self.use_graph:
             model._decoder_grads_ready = self._launch_decoder_bucket    # hooked onto the bottleneck output in forward
         # the ~130 partial-sum reductions of the parameter gradients (split-K slices, LayerNorm gamma/beta partials) are
@@ -142,16 +158,17 @@ class TrainStep:
         finally:
             model._decoder_grads_ready = None
             model._defer_wgrad = False
-            model.join_side_stream()    # (opt-in) small weight-gradient GEMMs run on a second stream (functional.Runtime)
             ops.flush_deferred()
-        flat_g = model.store.grad_buffer(0)
-        # the norm / AdamW below read the WHOLE flat gradient buffer: a parameter that received no gradient in this step
-        # must contribute zero, not its gradient of an earlier step (torch's AdamW skips grad-less parameters; no shipped
-        # config has one, so this loop normally finds nothing and launches nothing)
-        for p in model.store.params:
-            if p.grad is None and p.requires_grad:
-                v = model.store._grad_view(p, 0)
-                if v is not None:
+        if not self._gradless_known:
+            # first step: find the parameters without a gradient (torch's AdamW skips them) and zero their slots now, once,
+            # after everything that may be in flight over the buffer has been waited for
+            self._gradless_known = True
+            slots = [model.store._grad_view(p, 0) for p in model.store.params if p.grad is None and p.requires_grad]
+            self._gradless_slots = [v for v in slots if v is not None]
+            if self._gradless_slots:
+                if self._pending is not None:
+                    self._pending[1].wait()
+                for v in self._gradless_slots:
                     v.zero_()
         return {k: v.detach() for k, v in ld.items()}
 
@@ -232,6 +249,7 @@ class TrainStep:
         if entry is None:
             entry = self._capture(key, commands, args, plan, label, dec)
         else:
+            self._graphs.move_to_end(key)
             graph, (sc, sa, sl, sdec), splan, res = entry
             sc.copy_(commands)
             sa.copy_(args)
@@ -253,6 +271,16 @@ class TrainStep:
         if self.ddp:
             self._step_back()
         return entry[3]
+
+    def rccl_ranks(self):
+        """number of ranks that take part in this trainer's collectives, measured by one all-reduce of ones (1 without a
+        process group): bench.py reports it so that a scaling run can be checked to have used N ranks"""
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        dev = self.model.store.flat.device if self._ready else None
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(one, group=self.pg)
+        return int(round(one.item()))
 
     def _bucketed(self, plan, commands):
         """round the plan's two data-dependent sizes up to buckets -> (graph cache key, plan with the rounded sizes)"""
@@ -304,6 +332,7 @@ class TrainStep:
         splan = {part: (None if plan[part] is None else {k: _static(v) for k, v in plan[part].items()})
                  for part in ("enc", "dec", "loss")}
         model._forced_plan = splan
+        self._in_own_step = True        # (the warm-up runs and the capture read the pre-reduced loss counts, see _reduce_counts)
         # the warm-up steps (allocator pools, lazy buffers) must not train the model.  Data parallel: the captured part
         # (and its warm-up) is forward + backward only - no collective, see step()
         body = self._step_front if self.ddp else self._step_body
@@ -329,8 +358,16 @@ class TrainStep:
                 res = body(sc, sa, sl, sdec)
         finally:
             model._forced_plan = None
+            self._in_own_step = False
         entry = (g, (sc, sa, sl, sdec), splan, res)
         self._graphs[key] = entry
+        self.graphs_captured += 1
+        while len(self._graphs) > max(1, self.max_graphs):
+            old_key, old = self._graphs.popitem(last=False)    # least recently used
+            self.graphs_evicted += 1
+            # nothing of the evicted graph can still be running: graphs replay one at a time on this stream and the
+            # capture above synchronised the device; dropping the entry releases its static tensors and pool blocks
+            del old
         return entry
 
     def grad_norm(self):

@@ -77,17 +77,19 @@ int64_t dsvg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int dsvg_reduce_partials(const float* partial, int64_t P, int64_t n, float* out, int32_t accumulate,
                          void* stream);
 
-/* Deferred parameter-gradient reductions.  While a scope is open (dsvg_defer_scope(1) ... dsvg_defer_scope(0)) every
- * partial-sum reduction issued by this library (split-K slices of dsvg_gemm, the gamma/beta partials of
+/* Deferred parameter-gradient reductions.  While a scope is open ON A STREAM (dsvg_defer_scope(1, s) ...
+ * dsvg_defer_scope(0, s)) every partial-sum reduction this library is asked to launch on that stream (split-K slices of dsvg_gemm, the gamma/beta partials of
  * dsvg_layernorm_bwd, dsvg_colsum, dsvg_add_pos_bwd, dsvg_embed_scatter) whose data allows 16-byte accesses is queued
  * instead of launched: its destination is NOT valid and its workspace must stay untouched until dsvg_flush_deferred,
  * which performs all queued reductions in one launch per 64 of them (a backward pass of the benchmark model queues
  * ~130: the per-reduction launches were 0.85 ms of a 10.5 ms step).  A reduction whose destination overlaps a queued
  * one flushes the queue first, so write-after-write order is kept; reads of a queued destination are the caller's
- * responsibility (deepsvg_amd/trainer.py flushes right after loss.backward(), the reference's train.py:98), and so
- * is ordering the flush stream behind every stream that produced queued partials.
- * dsvg_defer_scope returns the number of reductions currently queued. */
-int dsvg_defer_scope(int32_t on);
+ * responsibility (deepsvg_amd/trainer.py flushes right after loss.backward(), the reference's train.py:98).
+ * The queue is keyed by the stream (hence by device): launches on other streams - another model, another trainer,
+ * nn.DataParallel's per-device threads - are neither queued nor flushed by it, and the flush runs on the stream that
+ * produced the queued partials, ordered behind them.  No state besides these per-stream queues is kept.
+ * dsvg_defer_scope returns the number of reductions currently queued on that stream. */
+int dsvg_defer_scope(int32_t on, void* stream);
 int dsvg_flush_deferred(void* stream);
 
 /* out[n] (+)= sum_m drop(A[m*lda+n])  — bias gradients (autograd of the `+ b` in every nn.Linear).
