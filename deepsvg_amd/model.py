@@ -572,7 +572,7 @@ class SVGTransformer(nn.Module):
         if training and self._own_seed:
             ops.advance_step_(None, seed)
         self._rt = Fn.Runtime(self.compute_dtype, seed, self._store, training,
-                              defer=self._defer_wgrad and not ops.PROFILE_ON)
+                              defer=self._defer_wgrad and (not ops.PROFILE_ON or ops.PROFILE_KEEP_DEFER))
         return self._rt
 
     # ---- blocks ----------------------------------------------------------------------------------

@@ -14,8 +14,19 @@ RELU = 1
 
 # optional per-launch timing of tagged GEMMs (bench.py roofline leg): HIP events on the launch stream
 PROFILE_ON = False
-PROFILE = []          # (tag, start_event, end_event, flops of the launch, algorithmic bytes of the launch)
+PROFILE = []          # (tag, start_event, end_event, flops of the launch, algorithmic bytes of the launch, spec)
+# events recorded while a hipGraph is being captured become event-record NODES of that graph (hipEventRecordExternal), so
+# the launches of the very graph whose replays are timed can be timed one by one after a replay
+PROFILE_EXTERNAL = False
+# keep the deferred reductions of the train step on while profiling (the profiled sequence = the timed one)
+PROFILE_KEEP_DEFER = False
 _TAG = None
+
+
+def _event():
+    if PROFILE_EXTERNAL:
+        return torch.cuda.Event(enable_timing=True, external=True)
+    return torch.cuda.Event(enable_timing=True)
 
 
 class tag:
@@ -80,6 +91,8 @@ def _ws(nbytes, device):
     st = _DEFER.state.get(_stream_key())
     if st is not None and st.depth:
         st.keep.append(t)           # a queued reduction reads it at flush_deferred()
+        if PROFILE_ON:
+            st.bytes_by_tag[_TAG] = st.bytes_by_tag.get(_TAG, 0) + t.numel() * 4
     return t
 
 
@@ -92,10 +105,10 @@ def _stream_key():
 
 
 class _DeferState:
-    __slots__ = ("depth", "keep", "post")
+    __slots__ = ("depth", "keep", "post", "bytes_by_tag")
 
     def __init__(self):
-        self.depth, self.keep, self.post = 0, [], []
+        self.depth, self.keep, self.post, self.bytes_by_tag = 0, [], [], {}
 
 
 class _DeferScope:
@@ -143,7 +156,7 @@ def defer_post(fn):
     if st is None:
         fn()
     else:
-        st.post.append(fn)
+        st.post.append((fn, _TAG))
 
 
 def flush_deferred():
@@ -155,10 +168,26 @@ def flush_deferred():
             _DEFER.state.pop(key, None)
         return
     if torch.cuda.is_available():
+        ev = None
+        if PROFILE_ON and st.keep:
+            ev = _event()
+            ev.record()
         _l.check(_l.load().dsvg_flush_deferred(key), "dsvg_flush_deferred")
+        if ev is not None:
+            # one record for the batched reduction launches; `by_tag` = workspace bytes each tag queued (the share of the
+            # launch time a sub-block is charged with)
+            ev1 = _event()
+            ev1.record()
+            PROFILE.append(("reduce", ev, ev1, 0.0, float(sum(st.bytes_by_tag.values())),
+                            dict(op="reduce_deferred", by_tag=dict(st.bytes_by_tag))))
+    st.bytes_by_tag = {}
     post, st.post = st.post, []
-    for fn in post:
-        fn()
+    for fn, t in post:
+        if t is None:
+            fn()
+        else:
+            with tag(t):
+                fn()
     st.keep.clear()
     if st.depth == 0:
         _DEFER.state.pop(key, None)
@@ -260,7 +289,7 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     L = _l.load()
     if PROFILE_ON and _TAG is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0, ev1 = _event(), _event()
         ev0.record()
         _l.check(L.dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
         ev1.record()
@@ -1021,7 +1050,7 @@ def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_
 def _prof_begin():
     if not (PROFILE_ON and _TAG is not None):
         return None
-    ev0 = torch.cuda.Event(enable_timing=True)
+    ev0 = _event()
     ev0.record()
     return ev0
 
@@ -1029,7 +1058,7 @@ def _prof_begin():
 def _prof_end(ev0, flops, alg_bytes, spec):
     if ev0 is None:
         return
-    ev1 = torch.cuda.Event(enable_timing=True)
+    ev1 = _event()
     ev1.record()
     PROFILE.append((_TAG, ev0, ev1, float(flops), float(alg_bytes), spec))
 

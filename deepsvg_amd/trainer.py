@@ -63,6 +63,7 @@ class TrainStep:
         self._pending = None
         self._pool = None
         self._gradless_known, self._gradless_slots = False, []
+        self.on_capture_begin = None    # optional callback right before a graph capture starts (bench.py's profiled graph)
         self.row_bucket, self.seq_bucket = 1024, 64
         self.defer_reductions = os.environ.get("DSVG_DEFER_REDUCE", "1") != "0"
         model._own_seed = False          # the trainer advances the dropout seed once per step
@@ -245,11 +246,8 @@ class TrainStep:
                 self._counts.copy_(counts)
         key, plan = self._bucketed(plan, commands)
         key = key + (label is not None, dec is not None)
-        entry = self._graphs.get(key)
-        if entry is None:
-            entry = self._capture(key, commands, args, plan, label, dec)
-        else:
-            self._graphs.move_to_end(key)
+        entry, fresh = self._graph_entry(key, lambda: self._capture(key, commands, args, plan, label, dec))
+        if not fresh:
             graph, (sc, sa, sl, sdec), splan, res = entry
             sc.copy_(commands)
             sa.copy_(args)
@@ -271,6 +269,23 @@ class TrainStep:
         if self.ddp:
             self._step_back()
         return entry[3]
+
+    def _graph_entry(self, key, capture):
+        """the cached graph of a bucket key (marked most recently used), or a freshly captured one; the cache holds at most
+        `max_graphs` graphs, least recently used out first -> (entry, True when it was captured by this call)"""
+        entry = self._graphs.get(key)
+        if entry is not None:
+            self._graphs.move_to_end(key)
+            return entry, False
+        entry = capture()
+        self._graphs[key] = entry
+        self.graphs_captured += 1
+        while len(self._graphs) > max(1, self.max_graphs):
+            # nothing of the evicted graph can still be running: graphs replay one at a time on this stream and a capture
+            # synchronises the device; dropping the entry releases its static tensors and its blocks of the shared pool
+            self._graphs.popitem(last=False)
+            self.graphs_evicted += 1
+        return entry, True
 
     def rccl_ranks(self):
         """number of ranks that take part in this trainer's collectives, measured by one all-reduce of ones (1 without a
@@ -351,6 +366,8 @@ class TrainStep:
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()     # graphs replay one at a time: one shared pool
             g = torch.cuda.CUDAGraph()
+            if self.on_capture_begin is not None:
+                self.on_capture_begin()
             # thread-local capture mode: other threads of the process keep calling the runtime while this one captures -
             # with an initialised process group the RCCL watchdog thread polls its work events (hipEventQuery), which the
             # default global mode answers by invalidating the capture and the watchdog by aborting the process
@@ -359,16 +376,7 @@ class TrainStep:
         finally:
             model._forced_plan = None
             self._in_own_step = False
-        entry = (g, (sc, sa, sl, sdec), splan, res)
-        self._graphs[key] = entry
-        self.graphs_captured += 1
-        while len(self._graphs) > max(1, self.max_graphs):
-            old_key, old = self._graphs.popitem(last=False)    # least recently used
-            self.graphs_evicted += 1
-            # nothing of the evicted graph can still be running: graphs replay one at a time on this stream and the
-            # capture above synchronised the device; dropping the entry releases its static tensors and pool blocks
-            del old
-        return entry
+        return (g, (sc, sa, sl, sdec), splan, res)
 
     def grad_norm(self):
         """global gradient L2 norm of the last step (after the all-reduce averaging)"""

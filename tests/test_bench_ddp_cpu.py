@@ -33,3 +33,5 @@ def test_bench_main_loop_two_ranks_gloo():
     assert rec["config"]["global_batch"] == 6 and rec["config"]["parallelism"] == "dp2"
     assert rec["value"] > 0 and abs(rec["value"] - 6 / (rec["ms_per_step"] * 1e-3)) < 0.01 * rec["value"]
     assert rec["config"]["loss"] == rec["config"]["loss"]       # finite
+    assert rec["rccl_ranks"] == 2, "rank 0 must report the number of ranks its collectives actually span"
+    assert rec["graphs"]["batches_rotated"] == 8
