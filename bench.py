@@ -443,11 +443,17 @@ def main():
             allr = [(r[0], _Ms(r[1]), None, r[2], r[3], r[4]) for r in recs]
             ffn = [r for r in allr if r[0] == "ffn"]
             n_ffn = len(ffn)
+            # the fused per-layer kernels of the 4096-row group stages contain the FFN sub-block: it is charged with the
+            # share of their time that its FLOPs have in the launch (about half: the rest is in_proj / attention / out_proj)
+            gsr = [r for r in allr if r[0] == "gs" and r[3] > 0]
+            gs_ffn_ms = sum(r[1].elapsed_time(r[2]) * r[5]["ffn_flops"] / r[3] for r in gsr)
+            gs_ffn_flop = sum(r[5]["ffn_flops"] for r in gsr)
             # the FFN sub-block's time = its launches + its share (by queued workspace bytes) of the batched reductions
-            ffn_ms = sum(r[1].elapsed_time(r[2]) for r in ffn) + ffn_red_ms
+            ffn_ms = sum(r[1].elapsed_time(r[2]) for r in ffn) + ffn_red_ms + gs_ffn_ms
+            n_ffn += len(gsr)
             # algorithmic FLOPs of the FFN sub-block = linear1 + linear2 forward, dX and dW; recomputed or
             # auxiliary launches (dropout replay, reductions, finishing kernel) carry 0 FLOPs but their time counts
-            flop_exec = sum(r[3] for r in ffn) / n_prof
+            flop_exec = sum(r[3] for r in ffn) / n_prof + gs_ffn_flop
             flop_padded = a.batch * FFN_FLOP_PER_ICON_TRAIN         # the reference's padded layout
             tf = flop_exec / (ffn_ms * 1e-3) / 1e12
             peak_tf = PEAK_TFLOPS[a.dtype]
@@ -457,7 +463,9 @@ def main():
             unf_fwd_rows = sum(r[5]["a"][0] for r in ffn if r[5].get("act") == 1) / n_prof      # linear1 of an unfused layer
             bwd_rows = sum(r[5].get("rows", 0) for r in ffn if r[5].get("op") in ("ffn_bwd_dx", "ffn_bwd")) / n_prof
             unf_bwd_rows = sum(r[5]["a"][0] for r in ffn if r[5].get("gate")) / n_prof - bwd_rows   # gated dX GEMM: all layers
-            fused_bytes = 1024.0 * (fwd_rows + unf_fwd_rows) + 1536.0 * (bwd_rows + max(unf_bwd_rows, 0.0))
+            gs_fwd_rows = sum(r[5]["rows"] for r in gsr if r[5]["op"] == "gs_layer_fwd")
+            gs_bwd_rows = sum(r[5]["rows"] for r in gsr if r[5]["op"] == "gs_layer_bwd")
+            fused_bytes = 1024.0 * (fwd_rows + unf_fwd_rows + gs_fwd_rows) + 1536.0 * (bwd_rows + max(unf_bwd_rows, 0.0) + gs_bwd_rows)
             gbs = fused_bytes / (ffn_ms * 1e-3) / 1e9
             # like-for-like with round 1's definition (matrix launches only: norm2, dropout replay, finishing kernel left out)
             mm_ms = sum(r[1].elapsed_time(r[2]) for r in ffn if r[3] > 0) / n_prof
@@ -524,6 +532,11 @@ def main():
                         "matrix_launches_only": {"ms_per_step": round(mm_ms, 3),
                                                  "frac": round(flop_exec / (mm_ms * 1e-3) / 1e12 / peak_tf, 4),
                                                  "note": "round 1's accounting: launches that execute FLOPs only"},
+                        "group_stage_layers": {"kernel": "gs_layer_fwd / gs_layer_bwd (one launch per layer and direction for the "
+                                                         "4096-row stages: LN + in_proj + attention + out_proj + LN + FFN)",
+                                               "launches_per_step": len(gsr),
+                                               "ms_per_step": round(sum(r[1].elapsed_time(r[2]) for r in gsr), 3),
+                                               "ffn_share_ms": round(gs_ffn_ms, 3)} if gsr else None,
                         "fused_fwd_kernel": fused_fwd,
                         "fused_attn_fwd_kernel": fused_attn,
                         "weight_grad_gemms": wgrad,

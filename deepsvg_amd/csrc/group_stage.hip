@@ -1,0 +1,1086 @@
+// One launch per transformer layer for the SHORT-sequence stages of the hierarchical model - the two "group" stages
+// (hierarchical_encoder, deepsvg/model/model.py:153-161; hierarchical_decoder, :246-254): N x 8 rows of d_model 256,
+// sequences of 8 group tokens - forward and backward of the whole pre-LN block
+//     x1 = x  + drop( Wo . MHA( LN1(x) ) + bo ) [+ drop( g[sequence] )]          improved_transformer.py:43-49,127-136
+//     x2 = x1 + drop( W2 . drop( relu( W1 . LN2(x1) + b1 ) ) + b2 )                                      :51-53,138-140
+// bf16 storage, fp32 accumulation and statistics.  These stages are 3 % of the model's FLOPs but ran as ~33 launches of
+// 5-12 us per layer and direction (4096 rows cannot fill 256 CUs with token-stationary 256-row workgroups, and every
+// unfused GEMM of this size is one exposed memory round trip per K step).
+//
+// Decomposition (both kernels): a 512-thread workgroup owns ONE tile of 32 rows (32 / S whole sequences), its 8 waves split
+// the OUTPUT FEATURES of every matrix product - wave w computes the 32-wide column block w (its attention head, in the
+// in_proj / attention phases) - so a wave issues ~130 MFMAs per layer and the launch is bound by what every CU has to
+// ingest: the layer's 1 MiB of weights.  They stream from L2 straight into MFMA A-operand registers through a per-wave
+// prefetch ring (dsvg_gs_pack lays them out wave-major in consumption order: one contiguous 128 KiB stream per wave
+// and layer, independent of the activations, so it runs ahead across every phase boundary).  Activations move between
+// the phases through row-major LDS images [32 rows][features] whose row stride is an odd number of 16-byte units:
+// every MFMA B operand is one conflict-free ds_read_b128 (`row_frag`), every result tile goes back as four 8-byte
+// pieces per lane (`stage_rows`), V^T / dO^T / column sums over tokens use hardware-transposed reads (`col_frag`), and
+// everything the other direction or the weight-gradient GEMMs need leaves the chip as full rows, cooperatively, 16 bytes
+// per lane (`store_image`).
+// The attention phases are the bodies of attention_mfma.hip's MODE 2 kernels (same dropout draws, same masks).
+// Dropout draws are the library's standard ones at every site, so the fused and the unfused launches are
+// interchangeable between forward and backward (tests/test_kernels_gpu.py runs all four combinations).
+#include "fused_common.h"
+#include "../../include/dsvg.h"
+
+typedef short shortx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int GD = 256;                 // d_model
+constexpr int GF = 512;                 // dim_feedforward
+constexpr int GH = 8;                   // heads = waves per workgroup
+constexpr int LDX = GD + 8;             // row stride (elements) of a [32][256] image: 528 B = 33 x 16 B
+constexpr int LDQ = 3 * GD + 8;         // q|k|v image: 1552 B = 97 x 16 B
+constexpr int LDH = GF + 8;             // hidden image: 1040 B = 65 x 16 B
+constexpr int GS_FRAGS = 128;           // weight fragments per wave and layer (both directions)
+constexpr int PF = 12;                  // prefetch distance of the weight stream (fragments = KiB in flight per wave)
+
+__host__ __device__ inline int rowmap(int r, int h2) { return (r & 3) + 8 * (r >> 2) + 4 * h2; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight packing: fp32 master parameters -> bf16 MFMA A fragments, wave-major, in consumption order.
+// offs[layer][0..3] = element offsets of in_proj_weight [768,256], out_proj.weight [256,256], linear1.weight [512,256],
+// linear2.weight [256,512] in `flat`.  Fragment i of wave w, lane l = (row = l & 31, half = l >> 5), slot e; k = 16 ks + 8
+// half + e is always the NATURAL index of the reduced dimension (the B operands come from row-major images):
+//   forward image                                      backward image (the transposed products)
+//   i <  48: Win[256 (i%3) + 32 w + row][k], ks = i/3   i <  32: W2[k][64 w + 32 (i&1) + row],  ks = i>>1   (dh  = dym . W2)
+//   i <  64: Wo [32 w + row][k],            ks = i-48   i <  64: W1[k][32 w + row],             ks = i-32   (dxn2 = dpre . W1)
+//   i <  96: W1 [64 w + 32 (i&1) + row][k], ks = (i-64)>>1   i <  80: Wo[k][32 w + row],         ks = i-64   (dao = dx1m . Wo)
+//   i < 128: W2 [32 w + row][k],            ks = i-96   i < 128: Win[k][32 w + row],            ks = i-80   (dxn1 = dqkv . Win)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gs_pack_kernel(const float* __restrict__ flat, const int64_t* __restrict__ offs,
+                                                      int n_layers, bf16_t* __restrict__ fwd, bf16_t* __restrict__ bwd) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;       // one thread per 16-byte lane slot
+    const long long per_layer = 2ll * GH * GS_FRAGS * 64;
+    if (gid >= (long long)n_layers * per_layer) return;
+    const int layer = (int)(gid / per_layer);
+    int s = (int)(gid % per_layer);
+    const int dir = s / (GH * GS_FRAGS * 64);
+    s %= GH * GS_FRAGS * 64;
+    const int l = s & 63, i = (s >> 6) % GS_FRAGS, w = s / (64 * GS_FRAGS);
+    const int row = l & 31, half = l >> 5;
+    const float* Win = flat + offs[layer * 4 + 0];
+    const float* Wo = flat + offs[layer * 4 + 1];
+    const float* W1 = flat + offs[layer * 4 + 2];
+    const float* W2 = flat + offs[layer * 4 + 3];
+    float v[8];
+    if (dir == 0) {
+        const float* src;
+        if (i < 48) src = Win + (size_t)(256 * (i % 3) + 32 * w + row) * GD + 16 * (i / 3) + 8 * half;
+        else if (i < 64) src = Wo + (size_t)(32 * w + row) * GD + 16 * (i - 48) + 8 * half;
+        else if (i < 96) src = W1 + (size_t)(64 * w + 32 * (i & 1) + row) * GD + 16 * ((i - 64) >> 1) + 8 * half;
+        else src = W2 + (size_t)(32 * w + row) * GF + 16 * (i - 96) + 8 * half;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[e];
+    } else {
+        const float* src;
+        size_t ld;
+        if (i < 32) { src = W2 + (size_t)(16 * (i >> 1) + 8 * half) * GF + 64 * w + 32 * (i & 1) + row; ld = GF; }
+        else if (i < 64) { src = W1 + (size_t)(16 * (i - 32) + 8 * half) * GD + 32 * w + row; ld = GD; }
+        else if (i < 80) { src = Wo + (size_t)(16 * (i - 64) + 8 * half) * GD + 32 * w + row; ld = GD; }
+        else { src = Win + (size_t)(16 * (i - 80) + 8 * half) * GD + 32 * w + row; ld = GD; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[(size_t)e * ld];
+    }
+    bf16_t* dst = (dir == 0 ? fwd : bwd) + (((size_t)layer * GH + w) * GS_FRAGS + i) * 512 + l * 8;
+    *reinterpret_cast<uint4*>(dst) = pack8(v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS image helpers
+// ---------------------------------------------------------------------------------------------------------------------
+// B operand: B[k = 16 step + 8 h2 + e][column = row `row` of the image] - one 16-byte read
+__device__ __forceinline__ bf16x8 row_frag(const bf16_t* img, int ld, int row, int col0, int step, int h2) {
+    Frag8 f;
+    f.u = *reinterpret_cast<const uint4*>(&img[row * ld + col0 + 16 * step + 8 * h2]);
+    return f.v;
+}
+// A operand: A[i = column col0 + (lane & 31)][k slot e] = img[row rowmap(8 ks + e, lane >> 5)][that column]
+__device__ __forceinline__ bf16x8 col_frag(const bf16_t* img, int ld, int col0, int ks, int lane) {
+    const int g = lane >> 4, q16 = lane & 15;
+    const int row = 16 * ks + 4 * (g >> 1) + (q16 >> 2);
+    const int col = col0 + 16 * (g & 1) + 4 * (q16 & 3);
+    union { bf16x8 v; shortx4 h[2]; } f;
+    f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(&img[row * ld + col]));
+    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(&img[(row + 8) * ld + col]));
+    return f.v;
+}
+__device__ __forceinline__ bf16x8 pack_regs(const float (&p)[16], int ks) {
+    Frag8 f;
+    f.u = make_uint4(f2bf_pk(p[8 * ks + 0], p[8 * ks + 1]), f2bf_pk(p[8 * ks + 2], p[8 * ks + 3]),
+                     f2bf_pk(p[8 * ks + 4], p[8 * ks + 5]), f2bf_pk(p[8 * ks + 6], p[8 * ks + 7]));
+    return f.v;
+}
+// a transposed 32 x 32 result tile (lane: row `row`, columns col0 + rowmap(r, h2)) -> four 8-byte pieces per lane
+__device__ __forceinline__ void stage_rows(bf16_t* img, int ld, int row, int col0, int h2, const float (&v)[16]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint2 t;
+        t.x = f2bf_pk(v[4 * c + 0], v[4 * c + 1]);
+        t.y = f2bf_pk(v[4 * c + 2], v[4 * c + 3]);
+        *reinterpret_cast<uint2*>(&img[row * ld + col0 + 8 * c + 4 * h2]) = t;
+    }
+}
+// the lane's 16 values of such a tile, read back (bf16 -> fp32)
+__device__ __forceinline__ void load_rows(const bf16_t* img, int ld, int row, int col0, int h2, float (&v)[16]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint2 t = *reinterpret_cast<const uint2*>(&img[row * ld + col0 + 8 * c + 4 * h2]);
+        v[4 * c + 0] = __uint_as_float(t.x << 16); v[4 * c + 1] = __uint_as_float(t.x & 0xffff0000u);
+        v[4 * c + 2] = __uint_as_float(t.y << 16); v[4 * c + 3] = __uint_as_float(t.y & 0xffff0000u);
+    }
+}
+// rows [0, S) x `cols` columns of an image -> global rows (16 bytes per lane, whole workgroup)
+__device__ __forceinline__ void store_image(bf16_t* dst, long long ld_dst, const bf16_t* img, int ld, int col0, int S, int cols) {
+    const int cpr = cols / 8;
+    for (int idx = threadIdx.x; idx < S * cpr; idx += 512) {
+        const int r = idx / cpr, c = idx % cpr;
+        *reinterpret_cast<uint4*>(dst + (long long)r * ld_dst + 8 * c) = *reinterpret_cast<const uint4*>(img + r * ld + col0 + 8 * c);
+    }
+}
+// global rows -> image (rows >= S: a copy of row S - 1, finite values that are computed on but never stored)
+__device__ __forceinline__ void load_image(bf16_t* img, int ld, int col0, const bf16_t* src, long long ld_src, int S, int cols) {
+    const int cpr = cols / 8;
+    for (int idx = threadIdx.x; idx < 32 * cpr; idx += 512) {
+        const int r = idx / cpr, c = idx % cpr;
+        *reinterpret_cast<uint4*>(img + r * ld + col0 + 8 * c) =
+            *reinterpret_cast<const uint4*>(src + (long long)min(r, S - 1) * ld_src + 8 * c);
+    }
+}
+// LDS-only workgroup barrier: the weight prefetch (global loads) stays in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// drop_make on a seed that is already in a register (the kernels read it once, BEFORE the weight stream starts)
+__device__ __forceinline__ DropCtx drop_make_v(float p, bool has_seed, uint64_t seed, uint32_t site) {
+    DropCtx c;
+    c.on = (p > 0.f) && has_seed;
+    if (c.on) {
+        c.s0 = dsvg_hash32((uint32_t)seed ^ (site * 0x9e3779b1u));
+        c.s1 = dsvg_hash32((uint32_t)(seed >> 32) + site * 0x85ebca77u + 0x165667b1u);
+        uint32_t t = (uint32_t)(p * 65536.f + 0.5f);
+        c.thresh = t > 65535u ? 65535u : t;
+        c.scale = 65536.f / (float)(65536u - c.thresh);
+    } else {
+        c.s0 = c.s1 = 0; c.thresh = 0; c.scale = 1.f;
+    }
+    return c;
+}
+
+// the per-wave weight stream: fragment i of the layer is `ring[i % PF]` once `take(i)` has been called in order
+struct WStream {
+    const char* base;       // this lane's 16 bytes of fragment 0
+    uint4 ring[PF];
+    __device__ __forceinline__ void start(const bf16_t* img, int wave, int lane) {
+        base = reinterpret_cast<const char*>(img) + ((size_t)wave * GS_FRAGS) * FRAG + lane * 16;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) ring[i] = *reinterpret_cast<const uint4*>(base + (size_t)i * FRAG);
+    }
+};
+// fragment I (compile-time) as an MFMA operand, and the refill of its ring slot with fragment I + PF
+#define GS_TAKE(ws, I, dst)                                                                                      \
+    do {                                                                                                         \
+        (dst).u = (ws).ring[(I) % PF];                                                                           \
+        if ((I) + PF < GS_FRAGS) (ws).ring[(I) % PF] = *reinterpret_cast<const uint4*>((ws).base + (size_t)((I) + PF) * FRAG); \
+    } while (0)
+
+struct GsFwdArgs {
+    const bf16_t* x; const bf16_t* img;
+    const float* in_bias; const float* out_bias; const float* b1; const float* b2;
+    const float* g1; const float* be1; const float* g2; const float* be2;
+    const uint64_t* key_mask; const bf16_t* gadd; const uint64_t* seed;
+    bf16_t* x2;
+    float* mean1; float* rstd1; bf16_t* xn1; bf16_t* qkv; bf16_t* ao; bf16_t* x1;
+    float* mean2; float* rstd2; bf16_t* xn2; bf16_t* h;
+    int n_seq, S;
+    float eps, scale, drop_p;
+    uint32_t site0;
+};
+
+// LDS layout of the forward kernel (bytes)
+constexpr int F_XN = 0;                                 // [32][LDX]  LN1(x); later LN2(x1); at the end x2
+constexpr int F_AO = F_XN + 32 * LDX * 2;               // [32][LDX]  head outputs; later x1
+constexpr int F_QKV = F_AO + 32 * LDX * 2;              // [32][LDQ]  q|k|v;  later the hidden activations [32][LDH]
+constexpr int F_SMALL = F_QKV + 32 * LDQ * 2;           // in_bias 768 | out_bias 256 | b1 512 | b2 256 | g1 be1 g2 be2 4 x 256
+constexpr int F_STAT = F_SMALL + (768 + 256 + 512 + 256 + 1024) * 4;    // [2][8][32] row-statistic partials
+constexpr int F_LDS = F_STAT + 2 * 8 * 32 * 4;
+
+// row statistics of a [32][256] fp32 tile spread as (lane: row li, 16 columns of block w) over the 8 waves: returns the
+// row sum of `v` over all 256 columns (one LDS round)
+__device__ __forceinline__ float row_total(float part, float* stat, int wave, int li, int h2) {
+    part += __shfl_xor(part, 32, 64);
+    if (h2 == 0) stat[wave * 32 + li] = part;
+    lds_barrier();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += stat[w * 32 + li];
+    return t;
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    bf16_t* XN = reinterpret_cast<bf16_t*>(smem + F_XN);
+    bf16_t* AO = reinterpret_cast<bf16_t*>(smem + F_AO);
+    bf16_t* QKV = reinterpret_cast<bf16_t*>(smem + F_QKV);
+    bf16_t* HI = QKV;
+    float* sbin = reinterpret_cast<float*>(smem + F_SMALL);
+    float* sbo = sbin + 768;
+    float* sb1 = sbo + 256;
+    float* sb2 = sb1 + 512;
+    float* sg1 = sb2 + 256;
+    float* sbe1 = sg1 + 256;
+    float* sg2 = sbe1 + 256;
+    float* sbe2 = sg2 + 256;
+    float* stat = reinterpret_cast<float*>(smem + F_STAT);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, h2 = lane >> 5;
+    const int Smax = a.S;
+    const int per = 32 / Smax;                          // whole sequences per tile
+    const int s_first = blockIdx.x * per;
+    const int n_in = min(per, a.n_seq - s_first);
+    const int S = n_in * Smax;                          // live rows of this tile
+    const long long row0 = (long long)s_first * Smax;
+
+    // the tile's own loads go out BEFORE the weight stream starts: loads return in order, so a value issued behind the
+    // prefetch ring could only be waited for together with the whole ring
+    const int r0 = wave * 4 + (lane >> 4), c00 = (lane & 15) * 16;
+    const long long gr0 = row0 + min(r0, S - 1);
+    const uint4 ra = *reinterpret_cast<const uint4*>(a.x + gr0 * GD + c00);
+    const uint4 rb = *reinterpret_cast<const uint4*>(a.x + gr0 * GD + c00 + 8);
+    const bool has_seed = a.seed != nullptr && a.drop_p > 0.f;
+    const uint64_t seedv = has_seed ? *a.seed : 0ull;
+    for (int i = tid; i < 768; i += 512) sbin[i] = a.in_bias[i];
+    sb1[tid] = a.b1[tid];
+    if (tid < 256) {
+        sbo[tid] = a.out_bias[tid]; sb2[tid] = a.b2[tid];
+        sg1[tid] = a.g1[tid]; sbe1[tid] = a.be1[tid]; sg2[tid] = a.g2[tid]; sbe2[tid] = a.be2[tid];
+    }
+    WStream ws;
+    ws.start(a.img, wave, lane);
+
+    // ---- phase 0: LayerNorm 1, 16 lanes per row (wave w: rows 4 w .. 4 w + 3), 16 columns per lane -----------------------
+    {
+        const int r = r0, c0 = c00;
+        const long long gr = gr0;
+        float v[16];
+        {
+            float t[8];
+            unpack8(ra, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = t[e];
+            unpack8(rb, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[8 + e] = t[e];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += v[e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * (1.f / GD);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float d = v[e] - mean; ss += d * d; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float rstd = rsqrtf(ss * (1.f / GD) + a.eps);
+        lds_barrier();              // gamma / beta (and the biases) staged
+        float y[8], z[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            y[e] = (v[e] - mean) * rstd * sg1[c0 + e] + sbe1[c0 + e];
+            z[e] = (v[8 + e] - mean) * rstd * sg1[c0 + 8 + e] + sbe1[c0 + 8 + e];
+        }
+        const uint4 pa = pack8(y), pb = pack8(z);
+        *reinterpret_cast<uint4*>(&XN[r * LDX + c0]) = pa;
+        *reinterpret_cast<uint4*>(&XN[r * LDX + c0 + 8]) = pb;
+        if (TRAIN && r < S) {
+            *reinterpret_cast<uint4*>(a.xn1 + gr * GD + c0) = pa;
+            *reinterpret_cast<uint4*>(a.xn1 + gr * GD + c0 + 8) = pb;
+            if ((lane & 15) == 0) { a.mean1[gr] = mean; a.rstd1[gr] = rstd; }
+        }
+    }
+    lds_barrier();
+
+    // ---- the lane's attention row: its sequence, the first row of that sequence inside the tile, visible keys -------------
+    const int qi = min(li / Smax, n_in - 1);
+    const int my_seq = s_first + qi, my_start = qi * Smax;
+    const uint32_t seqbits = (uint32_t)((1ull << Smax) - 1ull);
+    const uint32_t km = (((a.key_mask ? (uint32_t)a.key_mask[my_seq] : ~0u) & seqbits) << my_start);
+    const DropCtx dp = drop_make_v(a.drop_p, has_seed, seedv, a.site0);
+    const DropCtx dr1 = drop_make_v(a.drop_p, has_seed, seedv, a.site0 + 1);
+    const DropCtx dg = drop_make_v(a.drop_p, has_seed, seedv, a.site0 + 2);
+    const DropCtx dh = drop_make_v(a.drop_p, has_seed, seedv, a.site0 + 3);
+    const DropCtx dr2 = drop_make_v(a.drop_p, has_seed, seedv, a.site0 + 4);
+    const long long m = row0 + li;                      // this lane's row (result tiles: lane = row li)
+    const bool live = li < S;
+    const long long mrow = row0 + min(li, S - 1);
+    const int qc = wave * 32, kc = GD + wave * 32, vc = 2 * GD + wave * 32;
+
+    // ---- phase 1: in_proj of head `wave` (q, k, v column blocks) + attention ----------------------------------------------
+    {
+        floatx16 qa, ka, va;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { qa[r] = 0.f; ka[r] = 0.f; va[r] = 0.f; }
+        bf16x8 b = row_frag(XN, LDX, li, 0, 0, h2);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const bf16x8 bn = ks + 1 < 16 ? row_frag(XN, LDX, li, 0, ks + 1, h2) : b;
+            Frag8 w0, w1, w2;
+            GS_TAKE(ws, 3 * ks + 0, w0);
+            GS_TAKE(ws, 3 * ks + 1, w1);
+            GS_TAKE(ws, 3 * ks + 2, w2);
+            qa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.v, b, qa, 0, 0, 0);
+            ka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.v, b, ka, 0, 0, 0);
+            va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2.v, b, va, 0, 0, 0);
+            b = bn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = qa[r] + sbin[qc + rowmap(r, h2)];
+        stage_rows(QKV, LDQ, li, qc, h2, t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = ka[r] + sbin[kc + rowmap(r, h2)];
+        stage_rows(QKV, LDQ, li, kc, h2, t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = va[r] + sbin[vc + rowmap(r, h2)];
+        stage_rows(QKV, LDQ, li, vc, h2, t);
+    }
+    // the head's q | k | v slabs were written and are read by this wave only (in-order LDS): no workgroup barrier
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        floatx16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int step = 0; step < 2; ++step)
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(QKV, LDQ, li, kc, step, h2), row_frag(QKV, LDQ, li, qc, step, h2),
+                                                         st, 0, 0, 0);
+        // st[r] = q_li . k_key(r, h2): softmax over the keys of the lane's own sequence that its key mask lets through
+        float p[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = ((km >> rowmap(r, h2)) & 1u) ? st[r] * a.scale : -INFINITY;
+            mx = fmaxf(mx, p[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = (p[r] == -INFINITY) ? 0.f : __expf(p[r] - mx);
+            l += p[r];
+        }
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.f / l;
+        // dropout row of (sequence s, head h, query i) = (s H + h) Smax + i; query and key counted inside the sequence
+        const uint32_t hrow = attn_drop_row(dp, ((uint64_t)my_seq * GH + wave) * Smax + (li - my_start), 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = p[r] * inv * attn_drop_key(dp, hrow, (uint32_t)(rowmap(r, h2) - my_start));
+        if (!live) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = 0.f;
+        }
+        floatx16 ot;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(QKV, LDQ, vc, ks, lane), pack_regs(p, ks), ot, 0, 0, 0);
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = ot[r];
+        stage_rows(AO, LDX, li, qc, h2, t);             // ot[r] = O[row li][dim rowmap(r, h2)] of head `wave`
+    }
+    lds_barrier();                                       // B1: q|k|v and the head outputs of all heads are in LDS
+    if (TRAIN) {
+        store_image(a.qkv + row0 * (3 * GD), 3 * GD, QKV, LDQ, 0, S, 3 * GD);
+        store_image(a.ao + row0 * GD, GD, AO, LDX, 0, S, GD);
+    }
+
+    // ---- phase 2: out_proj column block `wave`, bias, dropout, residual (+ the per-sequence conditioning row), LayerNorm 2 --
+    float x1v[16];
+    {
+        // the residual row pieces (L2-hot: phase 0 read them) and the conditioning row, issued ahead of the product
+        uint2 xr[4], gr4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            xr[c] = *reinterpret_cast<const uint2*>(a.x + mrow * GD + qc + 8 * c + 4 * h2);
+            if (a.gadd) gr4[c] = *reinterpret_cast<const uint2*>(a.gadd + (long long)my_seq * GD + qc + 8 * c + 4 * h2);
+        }
+        floatx16 ya;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ya[r] = 0.f;
+        bf16x8 b = row_frag(AO, LDX, li, 0, 0, h2);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const bf16x8 bn = ks + 1 < 16 ? row_frag(AO, LDX, li, 0, ks + 1, h2) : b;
+            Frag8 w0;
+            GS_TAKE(ws, 48 + ks, w0);
+            ya = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.v, b, ya, 0, 0, 0);
+            b = bn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // columns qc + 8 c + 4 h2 .. + 3: half of the aligned group of 8 the standard draws are made for
+            float dm[8], gm[8];
+            drop_mult8(dr1, (uint64_t)m * GD + qc + 8 * c, dm);
+            if (a.gadd) drop_mult8(dg, (uint64_t)my_seq * GD + qc + 8 * c, gm);
+            const float xv[4] = {__uint_as_float(xr[c].x << 16), __uint_as_float(xr[c].x & 0xffff0000u),
+                                 __uint_as_float(xr[c].y << 16), __uint_as_float(xr[c].y & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = (ya[4 * c + e] + sbo[qc + 8 * c + 4 * h2 + e]) * dm[4 * h2 + e] + xv[e];
+                if (a.gadd) {
+                    const uint32_t gw = e < 2 ? gr4[c].x : gr4[c].y;
+                    const float gv = (e & 1) ? __uint_as_float(gw & 0xffff0000u) : __uint_as_float(gw << 16);
+                    v += gv * gm[4 * h2 + e];
+                }
+                // (the value every later stage sees is the stored bf16 one, as on the unfused path)
+                x1v[4 * c + e] = bf2f(f2bf(v));
+            }
+        }
+    }
+    float mean2, rstd2;
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += x1v[r];
+        mean2 = row_total(s, stat, wave, li, h2) * (1.f / GD);                 // (barrier B2a inside)
+        float ss = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = x1v[r] - mean2; ss += d * d; }
+        rstd2 = rsqrtf(row_total(ss, stat + 256, wave, li, h2) * (1.f / GD) + a.eps);      // (B2b)
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col = qc + rowmap(r, h2);
+            t[r] = (x1v[r] - mean2) * rstd2 * sg2[col] + sbe2[col];
+        }
+        // every wave is past B2a: nobody reads XN (in_proj) or AO (out_proj) any more
+        stage_rows(XN, LDX, li, qc, h2, t);
+        if (TRAIN) stage_rows(AO, LDX, li, qc, h2, x1v);
+    }
+    lds_barrier();                                       // B2c: LN2(x1) (and x1) complete
+    if (TRAIN) {
+        store_image(a.xn2 + row0 * GD, GD, XN, LDX, 0, S, GD);
+        store_image(a.x1 + row0 * GD, GD, AO, LDX, 0, S, GD);
+        if (wave == 0 && h2 == 0 && live) { a.mean2[m] = mean2; a.rstd2[m] = rstd2; }
+    }
+
+    // ---- phase 3: linear1 hidden column blocks 2 w, 2 w + 1, bias, ReLU, dropout -> hidden image -------------------------------
+    {
+        floatx16 h0, h1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
+        bf16x8 b = row_frag(XN, LDX, li, 0, 0, h2);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const bf16x8 bn = ks + 1 < 16 ? row_frag(XN, LDX, li, 0, ks + 1, h2) : b;
+            Frag8 w0, w1;
+            GS_TAKE(ws, 64 + 2 * ks + 0, w0);
+            GS_TAKE(ws, 64 + 2 * ks + 1, w1);
+            h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.v, b, h0, 0, 0, 0);
+            h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.v, b, h1, 0, 0, 0);
+            b = bn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // (the q|k|v image is dead: its last readers - the training stores behind B1 - finished before their wave reached B2a)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int hc = 64 * wave + 32 * jj;
+            float t[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float dm[8];
+                drop_mult8(dh, (uint64_t)m * GF + hc + 8 * c, dm);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pre = (jj ? h1[4 * c + e] : h0[4 * c + e]) + sb1[hc + 8 * c + 4 * h2 + e];
+                    t[4 * c + e] = fmaxf(pre, 0.f) * dm[4 * h2 + e];
+                }
+            }
+            stage_rows(HI, LDH, li, hc, h2, t);
+        }
+    }
+    lds_barrier();                                       // B3: the hidden activations of the tile are in LDS
+    if (TRAIN) store_image(a.h + row0 * GF, GF, HI, LDH, 0, S, GF);
+
+    // ---- phase 4: linear2 column block `wave`, bias, dropout, residual -> x2 ----------------------------------------------------
+    {
+        floatx16 ya;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ya[r] = 0.f;
+        bf16x8 b = row_frag(HI, LDH, li, 0, 0, h2);
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+            const bf16x8 bn = ks + 1 < 32 ? row_frag(HI, LDH, li, 0, ks + 1, h2) : b;
+            Frag8 w0;
+            GS_TAKE(ws, 96 + ks, w0);
+            ya = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.v, b, ya, 0, 0, 0);
+            b = bn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float t[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float dm[8];
+            drop_mult8(dr2, (uint64_t)m * GD + qc + 8 * c, dm);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                t[4 * c + e] = (ya[4 * c + e] + sb2[qc + 8 * c + 4 * h2 + e]) * dm[4 * h2 + e] + x1v[4 * c + e];
+        }
+        // every wave is past B3: nobody reads XN (linear1) any more
+        stage_rows(XN, LDX, li, qc, h2, t);
+    }
+    lds_barrier();                                       // B4
+    store_image(a.x2 + row0 * GD, GD, XN, LDX, 0, S, GD);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward: from dx2 = dL/dx2 and what the forward pass saved to dx = dL/dx, the token-major operands of the layer's four
+// weight-gradient GEMMs (dym = drop-mask(dx2), dpre, dx1m = drop-mask(dx1), dqkv; the other operands - h, LN2(x1), the head
+// outputs, LN1(x) - were stored by the forward pass), dx1 (for the conditioning row's gradient) and per-tile partial sums of
+// the four LayerNorm parameter gradients (column sums over the tile's rows by MFMA against ones).
+// ---------------------------------------------------------------------------------------------------------------------
+struct GsBwdArgs {
+    const bf16_t* dx2; const bf16_t* img;
+    const bf16_t* x; const float* mean1; const float* rstd1; const bf16_t* qkv;
+    const bf16_t* x1; const float* mean2; const float* rstd2; const bf16_t* h;
+    const float* g1; const float* g2;
+    const uint64_t* key_mask; const uint64_t* seed;
+    bf16_t* dx; bf16_t* dx1; bf16_t* dym; bf16_t* dpre; bf16_t* dx1m; bf16_t* dqkv;
+    float* ln_part;         // [tiles][4][256]: dgamma2, dbeta2, dgamma1, dbeta1
+    int n_seq, S;
+    float scale, drop_p;
+    uint32_t site0;
+};
+
+constexpr int B_A0 = 0;                                 // [32][LDX]  dx2; later dx1m; later g1 * xh1
+constexpr int B_A1 = B_A0 + 32 * LDX * 2;               // [32][LDX]  dym; later g2; later g1
+constexpr int B_DO = B_A1 + 32 * LDX * 2;               // [32][LDX]  g2 * xh2; later the head-output gradients
+constexpr int B_HI = B_DO + 32 * LDX * 2;               // [32][LDH]  dpre; later dx1 / dx as [32][LDX]
+constexpr int B_QKV = B_HI + 32 * LDH * 2;              // [32][LDQ]  q|k|v; later dq|dk|dv
+constexpr int B_SMALL = B_QKV + 32 * LDQ * 2;           // gamma1 | gamma2
+constexpr int B_STAT = B_SMALL + 2 * 256 * 4;           // [2][8][32] row sums of the LayerNorm backward
+constexpr int B_ASTAT = B_STAT + 2 * 8 * 32 * 4;        // [8][96]    lse, D, dropout row hash per head and query
+constexpr int B_LDS = B_ASTAT + 8 * 96 * 4;
+
+// LayerNorm backward of a row spread over the 8 waves (lane: row li, columns col0 + rowmap(r, h2)):
+//   gh = g * gamma;  out = res + rstd * (gh - mean(gh) - xh * mean(gh * xh));  t1 = g * xh, t2 = g (parameter-gradient addends)
+__device__ __forceinline__ void ln_bwd_rows(const float (&g)[16], const float (&xv)[16], float mean, float rstd,
+                                            const float* gamma, int col0, int h2, const float (&res)[16], float* stat,
+                                            int wave, int li, bool live, float (&out)[16], float (&t1)[16], float (&t2)[16]) {
+    float gh[16], xh[16];
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        xh[r] = (xv[r] - mean) * rstd;
+        gh[r] = g[r] * gamma[col0 + rowmap(r, h2)];
+        sa += gh[r];
+        sb = fmaf(gh[r], xh[r], sb);
+    }
+    sa += __shfl_xor(sa, 32, 64);
+    sb += __shfl_xor(sb, 32, 64);
+    if (h2 == 0) { stat[wave * 32 + li] = sa; stat[256 + wave * 32 + li] = sb; }
+    lds_barrier();
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { c1 += stat[w * 32 + li]; c2 += stat[256 + w * 32 + li]; }
+    c1 *= (1.f / GD);
+    c2 *= (1.f / GD);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        out[r] = res[r] + rstd * (gh[r] - c1 - xh[r] * c2);
+        t1[r] = live ? g[r] * xh[r] : 0.f;
+        t2[r] = live ? g[r] : 0.f;
+    }
+}
+
+// column sums over the 32 rows of two staged images (columns col0 .. col0 + 31) -> part[0 .. 255] / part[256 .. 511]
+__device__ __forceinline__ void col_sums(const bf16_t* imgA, const bf16_t* imgB, int col0, int lane, float* part) {
+    Frag8 ones;
+    ones.u = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    floatx16 sa, sb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(imgA, LDX, col0, ks, lane), ones.v, sa, 0, 0, 0);
+        sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(imgB, LDX, col0, ks, lane), ones.v, sb, 0, 0, 0);
+    }
+    if ((lane & 31) == 0) {         // every result column holds the same sums: lanes 0 and 32 own 16 features each
+        const int h2 = lane >> 5;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            *reinterpret_cast<float4*>(part + col0 + 8 * c + 4 * h2) = make_float4(sa[4 * c], sa[4 * c + 1], sa[4 * c + 2], sa[4 * c + 3]);
+            *reinterpret_cast<float4*>(part + 256 + col0 + 8 * c + 4 * h2) = make_float4(sb[4 * c], sb[4 * c + 1], sb[4 * c + 2], sb[4 * c + 3]);
+        }
+    }
+}
+
+__device__ __forceinline__ void unpack4(const uint2 t, float* v) {
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+
+__global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    bf16_t* A0 = reinterpret_cast<bf16_t*>(smem + B_A0);
+    bf16_t* A1 = reinterpret_cast<bf16_t*>(smem + B_A1);
+    bf16_t* DO = reinterpret_cast<bf16_t*>(smem + B_DO);
+    bf16_t* HI = reinterpret_cast<bf16_t*>(smem + B_HI);
+    bf16_t* QKV = reinterpret_cast<bf16_t*>(smem + B_QKV);
+    float* sg1 = reinterpret_cast<float*>(smem + B_SMALL);
+    float* sg2 = sg1 + 256;
+    float* stat = reinterpret_cast<float*>(smem + B_STAT);
+    float* my_stat = reinterpret_cast<float*>(smem + B_ASTAT) + (threadIdx.x >> 6) * 96;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, h2 = lane >> 5;
+    const int Smax = a.S;
+    const int per = 32 / Smax;
+    const int s_first = blockIdx.x * per;
+    const int n_in = min(per, a.n_seq - s_first);
+    const int S = n_in * Smax;
+    const long long row0 = (long long)s_first * Smax;
+    const long long m = row0 + li;
+    const bool live = li < S;
+    const long long mrow = row0 + min(li, S - 1);
+    const int qc = wave * 32, kc = GD + wave * 32, vc = 2 * GD + wave * 32;
+
+    // ---- phase 0: everything the tile reads up front goes out before the weight stream starts ----------------------------------
+    const int r0 = wave * 4 + (lane >> 4), c00 = (lane & 15) * 16;
+    const long long gr0 = row0 + min(r0, S - 1);
+    const uint4 ra = *reinterpret_cast<const uint4*>(a.dx2 + gr0 * GD + c00);
+    const uint4 rb = *reinterpret_cast<const uint4*>(a.dx2 + gr0 * GD + c00 + 8);
+    // the q|k|v rows of the tile: 32 x 96 pieces of 16 bytes, 6 per thread (named registers: an array lands in scratch memory)
+#define GS_QV_SRC(k) (a.qkv + (row0 + min((tid + 512 * (k)) / 96, S - 1)) * (3 * GD) + 8 * ((tid + 512 * (k)) % 96))
+    const uint4 qv0 = *reinterpret_cast<const uint4*>(GS_QV_SRC(0)), qv1 = *reinterpret_cast<const uint4*>(GS_QV_SRC(1));
+    const uint4 qv2 = *reinterpret_cast<const uint4*>(GS_QV_SRC(2)), qv3 = *reinterpret_cast<const uint4*>(GS_QV_SRC(3));
+    const uint4 qv4 = *reinterpret_cast<const uint4*>(GS_QV_SRC(4)), qv5 = *reinterpret_cast<const uint4*>(GS_QV_SRC(5));
+#undef GS_QV_SRC
+    const bool has_seed = a.seed != nullptr && a.drop_p > 0.f;
+    const uint64_t seedv = has_seed ? *a.seed : 0ull;
+    const float g1v = tid < 256 ? a.g1[tid] : a.g2[tid - 256];
+    const float mean2 = a.mean2[mrow], rstd2 = a.rstd2[mrow], mean1 = a.mean1[mrow], rstd1 = a.rstd1[mrow];
+    // hidden activations at this lane's positions of the two hidden column blocks (gate of the ReLU + dropout backward)
+    uint2 hq[2][4], x1q[4], xq[4];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            hq[jj][c] = *reinterpret_cast<const uint2*>(a.h + mrow * GF + 64 * wave + 32 * jj + 8 * c + 4 * h2);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        x1q[c] = *reinterpret_cast<const uint2*>(a.x1 + mrow * GD + qc + 8 * c + 4 * h2);
+        xq[c] = *reinterpret_cast<const uint2*>(a.x + mrow * GD + qc + 8 * c + 4 * h2);
+    }
+    const int qi = min(li / Smax, n_in - 1);
+    const int my_seq = s_first + qi, my_start = qi * Smax;
+    const uint32_t kmask_raw = a.key_mask ? (uint32_t)a.key_mask[my_seq] : ~0u;
+    WStream ws;
+    ws.start(a.img, wave, lane);
+
+    const DropCtx dp = drop_make_v(a.drop_p, has_seed, seedv, a.site0);
+    const DropCtx dr1 = drop_make_v(a.drop_p, has_seed, seedv, a.site0 + 1);
+    const DropCtx dr2 = drop_make_v(a.drop_p, has_seed, seedv, a.site0 + 4);
+    const float inv_keep = (a.drop_p > 0.f && has_seed) ? dr2.scale : 1.f;     // (same p at every site of the layer)
+    (tid < 256 ? sg1[tid] : sg2[tid - 256]) = g1v;
+    {
+        // dx2 -> A0, dym = dx2 * mask(FFN residual site) -> A1 and to memory (the B operand of dh and of dW2)
+        float v[8], mm[8];
+        *reinterpret_cast<uint4*>(&A0[r0 * LDX + c00]) = ra;
+        *reinterpret_cast<uint4*>(&A0[r0 * LDX + c00 + 8]) = rb;
+        unpack8(ra, v);
+        drop_mult8(dr2, (uint64_t)gr0 * GD + c00, mm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= mm[e];
+        const uint4 pa = pack8(v);
+        unpack8(rb, v);
+        drop_mult8(dr2, (uint64_t)gr0 * GD + c00 + 8, mm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= mm[e];
+        const uint4 pb = pack8(v);
+        *reinterpret_cast<uint4*>(&A1[r0 * LDX + c00]) = pa;
+        *reinterpret_cast<uint4*>(&A1[r0 * LDX + c00 + 8]) = pb;
+        if (r0 < S) {
+            *reinterpret_cast<uint4*>(a.dym + gr0 * GD + c00) = pa;
+            *reinterpret_cast<uint4*>(a.dym + gr0 * GD + c00 + 8) = pb;
+        }
+#define GS_QV_DST(k) (&QKV[((tid + 512 * (k)) / 96) * LDQ + 8 * ((tid + 512 * (k)) % 96)])
+        *reinterpret_cast<uint4*>(GS_QV_DST(0)) = qv0; *reinterpret_cast<uint4*>(GS_QV_DST(1)) = qv1;
+        *reinterpret_cast<uint4*>(GS_QV_DST(2)) = qv2; *reinterpret_cast<uint4*>(GS_QV_DST(3)) = qv3;
+        *reinterpret_cast<uint4*>(GS_QV_DST(4)) = qv4; *reinterpret_cast<uint4*>(GS_QV_DST(5)) = qv5;
+#undef GS_QV_DST
+    }
+    lds_barrier();                                       // B0
+
+    // ---- phase 1: dh = dym . W2 (hidden column blocks 2 w, 2 w + 1), gated by h -> dpre ---------------------------------------
+    {
+        floatx16 d0, d1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+        bf16x8 b = row_frag(A1, LDX, li, 0, 0, h2);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const bf16x8 bn = ks + 1 < 16 ? row_frag(A1, LDX, li, 0, ks + 1, h2) : b;
+            Frag8 w0, w1;
+            GS_TAKE(ws, 2 * ks + 0, w0);
+            GS_TAKE(ws, 2 * ks + 1, w1);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.v, b, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.v, b, d1, 0, 0, 0);
+            b = bn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            float t[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float hv[4];
+                unpack4(hq[jj][c], hv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)         // h > 0 <=> the unit passed the ReLU and was kept by the dropout
+                    t[4 * c + e] = hv[e] > 0.f ? (jj ? d1[4 * c + e] : d0[4 * c + e]) * inv_keep : 0.f;
+            }
+            stage_rows(HI, LDH, li, 64 * wave + 32 * jj, h2, t);
+        }
+    }
+    lds_barrier();                                       // B1: dpre of the tile
+    store_image(a.dpre + row0 * GF, GF, HI, LDH, 0, S, GF);
+
+    // ---- phase 2: dxn2 = dpre . W1 (column block w), LayerNorm 2 backward, + dx2 -> dx1 ------------------------------------------
+    float dx1v[16];
+    {
+        floatx16 ga;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ga[r] = 0.f;
+        bf16x8 b = row_frag(HI, LDH, li, 0, 0, h2);
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+            const bf16x8 bn = ks + 1 < 32 ? row_frag(HI, LDH, li, 0, ks + 1, h2) : b;
+            Frag8 w0;
+            GS_TAKE(ws, 32 + ks, w0);
+            ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.v, b, ga, 0, 0, 0);
+            b = bn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float g[16], xv[16], res[16], t1[16], t2[16], o[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = bf2f(f2bf(ga[r]));      // (the unfused path stores dxn2 as bf16 between the launches)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) unpack4(x1q[c], &xv[4 * c]);
+        load_rows(A0, LDX, li, qc, h2, res);                          // dx2 at this lane's positions
+        ln_bwd_rows(g, xv, mean2, rstd2, sg2, qc, h2, res, stat, wave, li, live, o, t1, t2);       // (barrier B2a inside)
+        // every wave is past B2a: the dxn2 products (readers of HI) and the dh products (readers of A1) are complete
+        stage_rows(DO, LDX, li, qc, h2, t1);
+        stage_rows(A1, LDX, li, qc, h2, t2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dx1v[r] = bf2f(f2bf(o[r]));
+        stage_rows(HI, LDX, li, qc, h2, dx1v);
+        float t[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float dm[8];
+            drop_mult8(dr1, (uint64_t)m * GD + qc + 8 * c, dm);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[4 * c + e] = dx1v[4 * c + e] * dm[4 * h2 + e];
+        }
+        stage_rows(A0, LDX, li, qc, h2, t);             // (this wave's own column block of A0: read above, by this wave only)
+    }
+    lds_barrier();                                       // B2b: dx1m, dx1 and the LN2 gradient addends of the tile
+    float* part = a.ln_part + (size_t)blockIdx.x * 1024;
+    col_sums(DO, A1, qc, lane, part);                    // dgamma2 | dbeta2, columns of block w
+    store_image(a.dx1m + row0 * GD, GD, A0, LDX, 0, S, GD);
+    if (a.dx1) store_image(a.dx1 + row0 * GD, GD, HI, LDX, 0, S, GD);
+
+    // ---- phase 3: dao = dx1m . Wo (the dims of head w) + attention backward of head w -----------------------------------------
+    {
+        floatx16 oa;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oa[r] = 0.f;
+        bf16x8 b = row_frag(A0, LDX, li, 0, 0, h2);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const bf16x8 bn = ks + 1 < 16 ? row_frag(A0, LDX, li, 0, ks + 1, h2) : b;
+            Frag8 w0;
+            GS_TAKE(ws, 64 + ks, w0);
+            oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.v, b, oa, 0, 0, 0);
+            b = bn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = oa[r];
+        // (column block w of DO: its LN2 addends were consumed by this wave's own col_sums above)
+        stage_rows(DO, LDX, li, qc, h2, t);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        // body of attention_mfma.hip's backward kernel (MODE 2), q|k|v in QKV, dO in DO, everything of head `wave`
+        const uint32_t qm = (uint32_t)(((1ull << Smax) - 1ull) << my_start);
+        const uint32_t km = (kmask_raw << my_start) & qm;
+        const uint64_t hbase = ((uint64_t)my_seq * GH + wave) * Smax - my_start;
+        floatx16 acc, acc2;
+        float p[16], g[16];
+        // pass A: lane = (query li, half h2), registers over keys
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+        for (int step = 0; step < 2; ++step) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(QKV, LDQ, li, kc, step, h2), row_frag(QKV, LDQ, li, qc, step, h2),
+                                                          acc, 0, 0, 0);       // K Q^T
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(QKV, LDQ, li, vc, step, h2), row_frag(DO, LDX, li, qc, step, h2),
+                                                           acc2, 0, 0, 0);     // V dO^T
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = ((km >> rowmap(r, h2)) & 1u) ? acc[r] * a.scale : -INFINITY;
+            mx = fmaxf(mx, p[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = (p[r] == -INFINITY) ? 0.f : __expf(p[r] - mx);
+            l += p[r];
+        }
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.f / l;
+        const float lse = mx + __logf(l);
+        float D = 0.f;
+        const uint32_t hrow = attn_drop_row(dp, hbase + li, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] *= inv;                                                                    // P[q][key]
+            g[r] = acc2[r] * attn_drop_key(dp, hrow, (uint32_t)(rowmap(r, h2) - my_start));  // dP[q][key]
+            D = fmaf(p[r], g[r], D);
+        }
+        D += __shfl_xor(D, 32, 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = live ? p[r] * (g[r] - D) * a.scale : 0.f;       // scale * dS[q][key]
+        if (h2 == 0) { my_stat[li * 3 + 0] = lse; my_stat[li * 3 + 1] = D; my_stat[li * 3 + 2] = __uint_as_float(hrow); }
+        floatx16 dq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(QKV, LDQ, kc, ks, lane), pack_regs(g, ks), dq, 0, 0, 0);
+        uint32_t dq_pk[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dq_pk[c] = f2bf_pk(dq[2 * c], dq[2 * c + 1]);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (my_stat written above is read below by other lanes of this wave)
+
+        // pass B: lane = (key li, half h2), registers over queries
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+        for (int step = 0; step < 2; ++step) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(QKV, LDQ, li, qc, step, h2), row_frag(QKV, LDQ, li, kc, step, h2),
+                                                          acc, 0, 0, 0);       // Q K^T
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(DO, LDX, li, qc, step, h2), row_frag(QKV, LDQ, li, vc, step, h2),
+                                                           acc2, 0, 0, 0);     // dO V^T
+        }
+        const bool kvalid = live && (bool)((km >> li) & 1u);
+        uint32_t pp[8], gp[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float pv[2], gv[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * c + e;
+                const int q = rowmap(r, h2);
+                const float lse_q = my_stat[q * 3 + 0], D_q = my_stat[q * 3 + 1];
+                const bool ok = kvalid && q < S && ((qm >> q) & 1u);
+                const float pr = ok ? __expf(acc[r] * a.scale - lse_q) : 0.f;                // P[q][key = li]
+                const float mult = attn_drop_key(dp, __float_as_uint(my_stat[q * 3 + 2]), (uint32_t)(li - my_start));
+                pv[e] = pr * mult;                                                           // P~ (as used by O = P~ V)
+                gv[e] = ok ? pr * (acc2[r] * mult - D_q) * a.scale : 0.f;                    // scale * dS[q][key]
+            }
+            pp[c] = f2bf_pk(pv[0], pv[1]);
+            gp[c] = f2bf_pk(gv[0], gv[1]);
+        }
+        floatx16 dk, dv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag8 fg, fp;
+            fg.u = make_uint4(gp[4 * ks], gp[4 * ks + 1], gp[4 * ks + 2], gp[4 * ks + 3]);
+            fp.u = make_uint4(pp[4 * ks], pp[4 * ks + 1], pp[4 * ks + 2], pp[4 * ks + 3]);
+            dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(QKV, LDQ, qc, ks, lane), fg.v, dk, 0, 0, 0);
+            dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(DO, LDX, qc, ks, lane), fp.v, dv, 0, 0, 0);
+        }
+        // every operand read of this head's slabs is done (same wave, in-order LDS): stage dq | dk | dv over q | k | v
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<uint2*>(&QKV[li * LDQ + qc + 8 * c + 4 * h2]) = make_uint2(dq_pk[2 * c], dq_pk[2 * c + 1]);
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = dk[r];
+        stage_rows(QKV, LDQ, li, kc, h2, t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = dv[r];
+        stage_rows(QKV, LDQ, li, vc, h2, t);
+    }
+    lds_barrier();                                       // B3: dq | dk | dv of all heads
+    store_image(a.dqkv + row0 * (3 * GD), 3 * GD, QKV, LDQ, 0, S, 3 * GD);
+
+    // ---- phase 4: dxn1 = dqkv . Win (column block w), LayerNorm 1 backward, + dx1 -> dx ---------------------------------------------
+    {
+        floatx16 ga;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ga[r] = 0.f;
+        bf16x8 b = row_frag(QKV, LDQ, li, 0, 0, h2);
+#pragma unroll
+        for (int ks = 0; ks < 48; ++ks) {
+            const bf16x8 bn = ks + 1 < 48 ? row_frag(QKV, LDQ, li, 0, ks + 1, h2) : b;
+            Frag8 w0;
+            GS_TAKE(ws, 80 + ks, w0);
+            ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.v, b, ga, 0, 0, 0);
+            b = bn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float g[16], xv[16], t1[16], t2[16], o[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = bf2f(f2bf(ga[r]));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) unpack4(xq[c], &xv[4 * c]);
+        ln_bwd_rows(g, xv, mean1, rstd1, sg1, qc, h2, dx1v, stat, wave, li, live, o, t1, t2);      // (barrier B4a inside)
+        // every wave is past B4a: A0 (dao product), A1 / DO (col_sums, attention) and HI (dx1 stores) are free
+        stage_rows(A0, LDX, li, qc, h2, t1);
+        stage_rows(A1, LDX, li, qc, h2, t2);
+        stage_rows(HI, LDX, li, qc, h2, o);
+    }
+    lds_barrier();                                       // B4b
+    col_sums(A0, A1, qc, lane, part + 512);              // dgamma1 | dbeta1
+    store_image(a.dx + row0 * GD, GD, HI, LDX, 0, S, GD);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int64_t dsvg_gs_pack_bytes(int32_t n_layers) { return (int64_t)n_layers * GH * GS_FRAGS * FRAG; }
+
+extern "C" int dsvg_gs_pack(const float* flat_f32, const int64_t* offs, int32_t n_layers, int32_t d_model, int32_t d_ff,
+                            int32_t n_heads, void* packed_fwd, void* packed_bwd, void* stream) {
+    DSVG_CHECK_ARG(flat_f32 && offs && packed_fwd && packed_bwd, "gs_pack: null pointer");
+    DSVG_CHECK_ARG(d_model == GD && d_ff == GF && n_heads == GH,
+                   "gs_pack: the fused group-stage kernels are built for d_model 256 / dim_ff 512 / 8 heads");
+    DSVG_CHECK_ARG(n_layers > 0, "gs_pack: bad layer count");
+    const long long n = (long long)n_layers * 2 * GH * GS_FRAGS * 64;
+    hipLaunchKernelGGL(gs_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat_f32, offs,
+                       n_layers, (bf16_t*)packed_fwd, (bf16_t*)packed_bwd);
+    DSVG_LAUNCH_CHECK("gs_pack");
+    return 0;
+}
+
+extern "C" int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, const float* in_bias, const float* out_bias,
+                                 const float* b1, const float* b2, const float* gamma1, const float* beta1,
+                                 const float* gamma2, const float* beta2, const uint64_t* key_mask, const void* seq_add,
+                                 int64_t n_seq, int32_t S, void* x2, float* mean1, float* rstd1, void* xn1, void* qkv,
+                                 void* ao, void* x1, float* mean2, float* rstd2, void* xn2, void* h, float eps,
+                                 float scale, float drop_p, uint32_t site0, const void* seed, void* stream) {
+    DSVG_CHECK_ARG(x && packed_fwd_layer && in_bias && out_bias && b1 && b2 && gamma1 && beta1 && gamma2 && beta2 && x2,
+                   "gs_layer_fwd: null pointer");
+    DSVG_CHECK_ARG(S >= 1 && S <= 32 && (32 % S) == 0, "gs_layer_fwd: sequence length must divide 32 (got %d)", S);
+    DSVG_CHECK_ARG(n_seq > 0 && n_seq * S < (1ll << 31), "gs_layer_fwd: bad sizes");
+    DSVG_CHECK_ARG(!(drop_p > 0.f) || seed, "gs_layer_fwd: dropout needs a seed");
+    const bool train = xn1 != nullptr;
+    DSVG_CHECK_ARG(!train || (mean1 && rstd1 && qkv && ao && x1 && mean2 && rstd2 && xn2 && h),
+                   "gs_layer_fwd: the training outputs come together");
+    DSVG_CHECK_ARG((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)packed_fwd_layer | (uintptr_t)xn1 | (uintptr_t)qkv |
+                     (uintptr_t)ao | (uintptr_t)x1 | (uintptr_t)xn2 | (uintptr_t)h | (uintptr_t)seq_add) & 15) == 0,
+                   "gs_layer_fwd: operands must be 16-byte aligned");
+    GsFwdArgs a;
+    a.x = (const bf16_t*)x; a.img = (const bf16_t*)packed_fwd_layer;
+    a.in_bias = in_bias; a.out_bias = out_bias; a.b1 = b1; a.b2 = b2;
+    a.g1 = gamma1; a.be1 = beta1; a.g2 = gamma2; a.be2 = beta2;
+    a.key_mask = key_mask; a.gadd = (const bf16_t*)seq_add; a.seed = (const uint64_t*)seed;
+    a.x2 = (bf16_t*)x2; a.mean1 = mean1; a.rstd1 = rstd1; a.xn1 = (bf16_t*)xn1; a.qkv = (bf16_t*)qkv; a.ao = (bf16_t*)ao;
+    a.x1 = (bf16_t*)x1; a.mean2 = mean2; a.rstd2 = rstd2; a.xn2 = (bf16_t*)xn2; a.h = (bf16_t*)h;
+    a.n_seq = (int)n_seq; a.S = S; a.eps = eps; a.scale = scale; a.drop_p = drop_p; a.site0 = site0;
+    const int per = 32 / S;
+    const int nb = (int)((n_seq + per - 1) / per);
+    hipStream_t st = (hipStream_t)stream;
+    if (train) {
+        DSVG_ENSURE_LDS(gs_layer_fwd_kernel<true>, F_LDS);
+        hipLaunchKernelGGL(gs_layer_fwd_kernel<true>, dim3(nb), dim3(512), F_LDS, st, a);
+    } else {
+        DSVG_ENSURE_LDS(gs_layer_fwd_kernel<false>, F_LDS);
+        hipLaunchKernelGGL(gs_layer_fwd_kernel<false>, dim3(nb), dim3(512), F_LDS, st, a);
+    }
+    DSVG_LAUNCH_CHECK("gs_layer_fwd");
+    return 0;
+}
+
+extern "C" int64_t dsvg_gs_bwd_workspace_bytes(int64_t n_seq, int32_t S) {
+    const int per = 32 / (S > 0 ? S : 1);
+    return ((n_seq + per - 1) / per) * 1024 * (int64_t)sizeof(float);
+}
+
+extern "C" int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, const void* x, const float* mean1,
+                                 const float* rstd1, const void* qkv, const void* x1, const float* mean2,
+                                 const float* rstd2, const void* h, const float* gamma1, const float* gamma2,
+                                 const uint64_t* key_mask, int64_t n_seq, int32_t S, void* dx, void* dx1, void* dym,
+                                 void* dpre, void* dx1m, void* dqkv, float* dgamma2, float* dbeta2, float* dgamma1,
+                                 float* dbeta1, float scale, float drop_p, uint32_t site0, const void* seed,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+    DSVG_CHECK_ARG(dx2 && packed_bwd_layer && x && mean1 && rstd1 && qkv && x1 && mean2 && rstd2 && h && gamma1 && gamma2,
+                   "gs_layer_bwd: null input pointer");
+    DSVG_CHECK_ARG(dx && dym && dpre && dx1m && dqkv && dgamma2 && dbeta2 && dgamma1 && dbeta1 && workspace,
+                   "gs_layer_bwd: null output pointer");
+    DSVG_CHECK_ARG(S >= 1 && S <= 32 && (32 % S) == 0, "gs_layer_bwd: sequence length must divide 32 (got %d)", S);
+    DSVG_CHECK_ARG(n_seq > 0 && n_seq * S < (1ll << 31), "gs_layer_bwd: bad sizes");
+    DSVG_CHECK_ARG(!(drop_p > 0.f) || seed, "gs_layer_bwd: dropout needs a seed");
+    DSVG_CHECK_ARG(workspace_bytes >= dsvg_gs_bwd_workspace_bytes(n_seq, S), "gs_layer_bwd: workspace too small");
+    DSVG_CHECK_ARG((((uintptr_t)dx2 | (uintptr_t)x | (uintptr_t)qkv | (uintptr_t)x1 | (uintptr_t)h | (uintptr_t)dx |
+                     (uintptr_t)dx1 | (uintptr_t)dym | (uintptr_t)dpre | (uintptr_t)dx1m | (uintptr_t)dqkv |
+                     (uintptr_t)packed_bwd_layer | (uintptr_t)workspace) & 15) == 0,
+                   "gs_layer_bwd: operands must be 16-byte aligned");
+    GsBwdArgs a;
+    a.dx2 = (const bf16_t*)dx2; a.img = (const bf16_t*)packed_bwd_layer;
+    a.x = (const bf16_t*)x; a.mean1 = mean1; a.rstd1 = rstd1; a.qkv = (const bf16_t*)qkv;
+    a.x1 = (const bf16_t*)x1; a.mean2 = mean2; a.rstd2 = rstd2; a.h = (const bf16_t*)h;
+    a.g1 = gamma1; a.g2 = gamma2; a.key_mask = key_mask; a.seed = (const uint64_t*)seed;
+    a.dx = (bf16_t*)dx; a.dx1 = (bf16_t*)dx1; a.dym = (bf16_t*)dym; a.dpre = (bf16_t*)dpre; a.dx1m = (bf16_t*)dx1m;
+    a.dqkv = (bf16_t*)dqkv; a.ln_part = (float*)workspace;
+    a.n_seq = (int)n_seq; a.S = S; a.scale = scale; a.drop_p = drop_p; a.site0 = site0;
+    const int per = 32 / S;
+    const int nb = (int)((n_seq + per - 1) / per);
+    hipStream_t st = (hipStream_t)stream;
+    DSVG_ENSURE_LDS(gs_layer_bwd_kernel, B_LDS);
+    hipLaunchKernelGGL(gs_layer_bwd_kernel, dim3(nb), dim3(512), B_LDS, st, a);
+    DSVG_LAUNCH_CHECK("gs_layer_bwd");
+    // the four LayerNorm parameter gradients: fixed-order sums of the per-tile partials (queued while a deferral scope is
+    // open on this stream, like every other parameter-gradient reduction)
+    float* outs[4] = {dgamma2, dbeta2, dgamma1, dbeta1};
+    for (int k = 0; k < 4; ++k) {
+        const int rc = dsvg_reduce_partials_strided((const float*)workspace + 256 * k, nb, 1024, 256, outs[k], 0, st);
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -162,7 +162,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.act == ops.RELU:
             # y = drop(relu(pre)): (y > 0) <=> relu passed and the element was kept
             assert not ctx.has_res, "relu with a fused residual cannot be differentiated from the saved output"
-            scale = 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0
+            scale = ops.keep_scale(ctx.p)
             dy_eff, a_drop_p_eff, a_site = ops.gate_mul(dy.contiguous(), y, scale), 0.0, 0
         else:
             dy_eff, a_drop_p_eff, a_site = dy, ctx.p, ctx.site
@@ -424,6 +424,30 @@ class LayerFn(torch.autograd.Function):
         d = x.shape[1]
         scale = float(d // n_heads) ** -0.5
         want_bwd = any(ctx.needs_input_grad)         # (grad mode itself is off inside Function.forward)
+        ctx.gs = False
+        gs = None
+        if (rt.store is not None and x.dtype == torch.bfloat16 and not causal and seq_off is None and l is None
+                and n_heads == 8 and d == 256 and 32 % S == 0 and x.shape[0] == n_seq * S
+                and x.shape[0] < min(ATTN_MIN_ROWS, FFN_MIN_ROWS) and live is None
+                and (key_mask is None or key_mask.dtype == torch.int64)):
+            gs = rt.store.gs(win)
+        if gs is not None:
+            # the short-sequence ("group") stages: the whole block in ONE launch (csrc/group_stage.hip); with a backward pass
+            # ahead it stores exactly what the unfused launches below would have saved
+            g = ops.gemm(z, rt.w(wg), bias=bg.detach()) if z is not None else None
+            with ops.tag("gs"):
+                res = ops.gs_layer_fwd(x, gs[0], bin_.detach(), bo.detach(), b1.detach(), b2.detach(), n1w.detach(),
+                                       n1b.detach(), n2w.detach(), n2b.detach(), key_mask, n_seq, S, scale, 1e-5, p, site0,
+                                       rt.seed, seq_add=g, train=want_bwd)
+            if want_bwd:
+                x2, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h = res
+            else:
+                x2, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h = (res,) + (None,) * 10
+            ctx.gs, ctx.ffn_fused, ctx.tiles, ctx.causal, ctx.live = True, False, None, False, None
+            ctx.rt, ctx.n_seq, ctx.S, ctx.n_heads, ctx.p, ctx.site0, ctx.scale = rt, n_seq, S, n_heads, p, site0, scale
+            ctx.save_for_backward(x, key_mask, z, l, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h,
+                                  n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off)
+            return x2
         att = None
         if (rt.store is not None and x.dtype == torch.bfloat16 and x.shape[0] >= ATTN_MIN_ROWS and S <= 32 and not causal
                 and n_heads == 8 and d == 256 and (seq_off is None or tiles is not None)
@@ -501,8 +525,31 @@ class LayerFn(torch.autograd.Function):
             n_seq, R = live
             (dx2, x, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h) = (
                 (t[:R] if t is not None else None) for t in (dx2, x, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h))
-        inv_keep = 1.0 / (1.0 - p) if p > 0 else 1.0
+        inv_keep = ops.keep_scale(p)
         dx1m = None
+        if ctx.gs:
+            # one launch for the whole input-gradient chain of the block (csrc/group_stage.hip); it hands over the token-major
+            # operands of the four weight-gradient GEMMs and the LayerNorm parameter gradients
+            gs = rt.store.gs(win)
+            with rt.deferring(), ops.tag("gs"):
+                (dx, dx1, dym, dpre, dx1m, dqkv, dn2w, dn2b, dn1w, dn1b) = ops.gs_layer_bwd(
+                    dx2, gs[1], x, mean1, rstd1, qkv, x1, mean2, rstd2, h, n1w.detach(), n2w.detach(), key_mask, n_seq, S,
+                    ctx.scale, p, s0, rt.seed, want_dx1=z is not None, dgamma2=rt.grad_out(n2w), dbeta2=rt.grad_out(n2b),
+                    dgamma1=rt.grad_out(n1w), dbeta1=rt.grad_out(n1b))
+            with ops.tag("ffn"):
+                dw2, db2 = _wbgrad(rt, w2, b2, dym, h)
+                dw1, db1 = _wbgrad(rt, w1, b1, dpre, xn2)
+            dz = dwg = dbg = None
+            if z is not None:
+                dg = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed)
+                dwg, dbg = _wbgrad(rt, wg, bg, dg, z)
+                if ctx.needs_input_grad[3]:
+                    dz = ops.gemm(dg, rt.w(wg), b_kc=False)
+            dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao)
+            dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1)
+            return (None, dx, None, dz, None, None, None, None, None, None,
+                    dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, None, None, None, None, None,
+                    None)
         if ctx.ffn_fused:
             pb, b1f, w2p = rt.store.ffn(w1)[1:]
             T = x1.shape[0]

@@ -310,6 +310,7 @@ class ParamStore:
         self._in_flight = set()
         self._ffn_setup(device)
         self._attn_setup(device)
+        self._gs_setup(device)
         for h in self._hooks:
             h.remove()
         # a slot of the flat gradient buffer is free again once AccumulateGrad has consumed it (see grad_view)
@@ -370,6 +371,49 @@ class ParamStore:
         self._attn = dict(n=n, index=index, offs=torch.tensor(rows, dtype=torch.int64, device=device),
                           img=torch.empty(n * ops.ATTN_LAYER_ELEMS, dtype=torch.bfloat16, device=device))
 
+    def _gs_setup(self, device):
+        """layers of the short-sequence ("group") stacks - hierarchical_encoder / hierarchical_decoder, model.py:153-161,
+        246-254 - that fit the fused per-layer kernels (d_model 256, dim_ff 512, 8 heads; csrc/group_stage.hip): offsets of
+        (in_proj_weight, out_proj.weight, linear1.weight, linear2.weight) in the flat buffer and the buffers of the packed
+        forward / backward weight images (filled by ensure() on every forward)"""
+        self._gs = None
+        if os.environ.get("DSVG_GS_FUSED", "1") == "0":
+            return
+        rows, index = [], {}
+        for name, stack in self.module.named_modules():
+            if not (isinstance(stack, _Stack) and name.rsplit(".", 1)[-1].startswith("hierarchical_")):
+                continue
+            for m in stack.layers:
+                sa = getattr(m, "self_attn", None)
+                ps = (getattr(sa, "in_proj_weight", None), getattr(getattr(sa, "out_proj", None), "weight", None),
+                      m.linear1.weight, m.linear2.weight)
+                if any(p is None or id(p) not in self.index for p in ps):
+                    continue
+                if [tuple(p.shape) for p in ps] != [(768, 256), (256, 256), (512, 256), (256, 512)]:
+                    continue
+                if hasattr(m, "linear_global2"):        # label-conditioned layers keep the unfused launches
+                    continue
+                index[id(ps[0])] = len(rows)
+                rows.append([self.index[id(p)][0] for p in ps])
+        if not rows:
+            return
+        n = len(rows)
+        self._gs = dict(n=n, index=index, offs=torch.tensor(rows, dtype=torch.int64, device=device),
+                        fwd=torch.empty(n * ops.GS_LAYER_ELEMS, dtype=torch.bfloat16, device=device),
+                        bwd=torch.empty(n * ops.GS_LAYER_ELEMS, dtype=torch.bfloat16, device=device))
+
+    def gs(self, w_in):
+        """(packed forward image, packed backward image) of the group-stage layer whose in_proj_weight is w_in, or None when
+        that layer does not run on the fused per-layer kernels"""
+        g = self._gs
+        if g is None or self.flat_lp is None or self.flat_lp.dtype != torch.bfloat16:
+            return None
+        i = g["index"].get(id(w_in))
+        if i is None:
+            return None
+        sl = slice(i * ops.GS_LAYER_ELEMS, (i + 1) * ops.GS_LAYER_ELEMS)
+        return g["fwd"][sl], g["bwd"][sl]
+
     def attn(self, w_in):
         """packed in_proj / out_proj image of the layer whose in_proj_weight is w_in, or None when that layer does not run
         on the fused attention kernel"""
@@ -421,6 +465,9 @@ class ParamStore:
             if dtype == torch.bfloat16 and self._attn is not None:
                 a = self._attn
                 ops.attn_pack(self.flat, a["offs"], a["n"], a["img"])
+            if dtype == torch.bfloat16 and self._gs is not None:
+                g = self._gs
+                ops.gs_pack(self.flat, g["offs"], g["n"], g["fwd"], g["bwd"])
 
     def lp(self, param):
         v = self._lp_views.get(id(param))

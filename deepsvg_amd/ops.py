@@ -1047,6 +1047,103 @@ def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_
     return x1
 
 
+# ------------------------------------------------------------------------------------------------
+# fused layer of the short-sequence ("group") stages (csrc/group_stage.hip)
+# ------------------------------------------------------------------------------------------------
+GS_LAYER_ELEMS = 8 * 128 * 512      # bf16 elements of one layer's packed image (1 MiB), forward and backward each
+
+
+def gs_pack(flat, offs, n_layers, packed_fwd=None, packed_bwd=None):
+    """wave-major bf16 MFMA-fragment images of (in_proj_weight, out_proj.weight, linear1.weight, linear2.weight) of n_layers
+    layers for the forward and the backward kernel, from the fp32 master buffer (include/dsvg.h).  offs: int64 device tensor
+    [n_layers, 4] of element offsets.  -> (packed_fwd, packed_bwd)"""
+    _chk(flat, offs, packed_fwd, packed_bwd)
+    assert flat.dtype == torch.float32 and offs.dtype == torch.int64 and tuple(offs.shape) == (n_layers, 4)
+    assert offs.is_contiguous()
+    if packed_fwd is None:
+        packed_fwd = torch.empty(n_layers * GS_LAYER_ELEMS, dtype=torch.bfloat16, device=flat.device)
+    if packed_bwd is None:
+        packed_bwd = torch.empty(n_layers * GS_LAYER_ELEMS, dtype=torch.bfloat16, device=flat.device)
+    assert packed_fwd.numel() == n_layers * GS_LAYER_ELEMS and packed_bwd.numel() == n_layers * GS_LAYER_ELEMS
+    _l.check(_l.load().dsvg_gs_pack(flat.data_ptr(), offs.data_ptr(), n_layers, 256, 512, 8, packed_fwd.data_ptr(),
+                                    packed_bwd.data_ptr(), _stream()), "dsvg_gs_pack")
+    return packed_fwd, packed_bwd
+
+
+def gs_layer_fwd(x, packed_fwd_layer, in_bias, out_bias, b1, b2, gamma1, beta1, gamma2, beta2, key_mask, n_seq, S, scale,
+                 eps=1e-5, drop_p=0.0, site0=0, seed=None, seq_add=None, train=False):
+    """one pre-LN transformer block in one launch (x bf16 [n_seq * S, 256], 32 % S == 0; include/dsvg.h).
+    train=False -> x2;  train=True -> (x2, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h): the tensors the unfused
+    launches of the same block save for the backward pass, in the same layouts."""
+    _chk(x, packed_fwd_layer, in_bias, out_bias, b1, b2, gamma1, beta1, gamma2, beta2, key_mask, seed, seq_add)
+    rows = n_seq * S
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(x.shape) == (rows, 256) and 32 % S == 0
+    assert packed_fwd_layer.numel() == GS_LAYER_ELEMS and packed_fwd_layer.is_contiguous()
+    for t, n in ((in_bias, 768), (out_bias, 256), (b1, 512), (b2, 256), (gamma1, 256), (beta1, 256), (gamma2, 256), (beta2, 256)):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
+    assert key_mask is None or (key_mask.dtype == torch.int64 and key_mask.numel() >= n_seq)
+    if seq_add is not None:
+        assert seq_add.dtype == x.dtype and seq_add.is_contiguous() and tuple(seq_add.shape) == (n_seq, 256)
+    dev = x.device
+    x2 = torch.empty_like(x)
+    sv = [None] * 10
+    if train:
+        f32 = lambda: torch.empty(rows, dtype=torch.float32, device=dev)
+        sv = [f32(), f32(), torch.empty_like(x), torch.empty((rows, 768), dtype=x.dtype, device=dev), torch.empty_like(x),
+              torch.empty_like(x), f32(), f32(), torch.empty_like(x), torch.empty((rows, 512), dtype=x.dtype, device=dev)]
+    ev = _prof_begin()
+    _l.check(_l.load().dsvg_gs_layer_fwd(x.data_ptr(), packed_fwd_layer.data_ptr(), in_bias.data_ptr(), out_bias.data_ptr(),
+                                         b1.data_ptr(), b2.data_ptr(), gamma1.data_ptr(), beta1.data_ptr(),
+                                         gamma2.data_ptr(), beta2.data_ptr(), _p(key_mask), _p(seq_add), n_seq, S,
+                                         x2.data_ptr(), *[_p(t) for t in sv], float(eps), float(scale), float(drop_p),
+                                         int(site0), _p(seed) if drop_p > 0 else None, _stream()), "dsvg_gs_layer_fwd")
+    # algorithmic FLOPs of the block: in_proj + out_proj + attention (2 x 2 S 32 per head and row) + the two FFN products
+    _prof_end(ev, 2.0 * rows * 256 * (768 + 256 + 1024) + 4.0 * rows * S * 256, 1024.0 * rows,
+              dict(op="gs_layer_fwd", rows=rows, train=bool(train), ffn_flops=4.0 * 256 * 512 * rows))
+    if train:
+        return (x2, *sv)
+    return x2
+
+
+def gs_layer_bwd(dx2, packed_bwd_layer, x, mean1, rstd1, qkv, x1, mean2, rstd2, h, gamma1, gamma2, key_mask, n_seq, S,
+                 scale, drop_p=0.0, site0=0, seed=None, want_dx1=False, dgamma2=None, dbeta2=None, dgamma1=None,
+                 dbeta1=None):
+    """backward of gs_layer_fwd with respect to x (include/dsvg.h) -> (dx, dx1 or None, dym, dpre, dx1m, dqkv, dgamma2,
+    dbeta2, dgamma1, dbeta1): dym / dpre / dx1m / dqkv are the token-major operands of the four weight-gradient GEMMs."""
+    _chk(dx2, packed_bwd_layer, x, mean1, rstd1, qkv, x1, mean2, rstd2, h, gamma1, gamma2, key_mask, seed)
+    rows = n_seq * S
+    assert dx2.dtype == torch.bfloat16 and dx2.is_contiguous() and tuple(dx2.shape) == (rows, 256) and 32 % S == 0
+    assert packed_bwd_layer.numel() == GS_LAYER_ELEMS and packed_bwd_layer.is_contiguous()
+    for t, shape in ((x, (rows, 256)), (x1, (rows, 256)), (qkv, (rows, 768)), (h, (rows, 512))):
+        assert t.dtype == torch.bfloat16 and t.is_contiguous() and tuple(t.shape) == shape
+    for t in (mean1, rstd1, mean2, rstd2):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == rows
+    dev = dx2.device
+    dx, dym, dx1m = torch.empty_like(dx2), torch.empty_like(dx2), torch.empty_like(dx2)
+    dx1 = torch.empty_like(dx2) if want_dx1 else None
+    dpre = torch.empty((rows, 512), dtype=dx2.dtype, device=dev)
+    dqkv = torch.empty((rows, 768), dtype=dx2.dtype, device=dev)
+    outs = []
+    for t in (dgamma2, dbeta2, dgamma1, dbeta1):
+        if t is None:
+            t = torch.empty(256, dtype=torch.float32, device=dev)
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == 256
+        outs.append(t)
+    L = _l.load()
+    ws = _ws(L.dsvg_gs_bwd_workspace_bytes(n_seq, S), dev)
+    ev = _prof_begin()
+    _l.check(L.dsvg_gs_layer_bwd(dx2.data_ptr(), packed_bwd_layer.data_ptr(), x.data_ptr(), mean1.data_ptr(),
+                                 rstd1.data_ptr(), qkv.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(),
+                                 h.data_ptr(), gamma1.data_ptr(), gamma2.data_ptr(), _p(key_mask), n_seq, S, dx.data_ptr(),
+                                 _p(dx1), dym.data_ptr(), dpre.data_ptr(), dx1m.data_ptr(), dqkv.data_ptr(),
+                                 *[t.data_ptr() for t in outs], float(scale), float(drop_p), int(site0),
+                                 _p(seed) if drop_p > 0 else None, ws.data_ptr(), ws.numel() * 4, _stream()),
+             "dsvg_gs_layer_bwd")
+    _prof_end(ev, 2.0 * rows * 256 * (768 + 256 + 1024) + 8.0 * rows * S * 256, 1536.0 * rows,
+              dict(op="gs_layer_bwd", rows=rows, ffn_flops=4.0 * 256 * 512 * rows))
+    return (dx, dx1, dym, dpre, dx1m, dqkv, *outs)
+
+
 def _prof_begin():
     if not (PROFILE_ON and _TAG is not None):
         return None
@@ -1061,6 +1158,15 @@ def _prof_end(ev0, flops, alg_bytes, spec):
     ev1 = _event()
     ev1.record()
     PROFILE.append((_TAG, ev0, ev1, float(flops), float(alg_bytes), spec))
+
+
+def keep_scale(p):
+    """the factor the kernels scale kept elements by at dropout probability p: 65536 / (65536 - round(65536 p)) - the
+    thresholds are 16-bit (csrc/dsvg_common.h drop_make), so this is the exact gradient scale of a dropped activation"""
+    if p <= 0:
+        return 1.0
+    t = min(int(p * 65536.0 + 0.5), 65535)
+    return 65536.0 / (65536 - t)
 
 
 def gate_mul(dy, y, scale=1.0):

@@ -444,6 +444,47 @@ int dsvg_attn_block_fwd(const void* x, const void* packed_layer, const float* in
                         void* qkv_out, void* ao_out, float* mean_out, float* rstd_out, float eps, float scale,
                         float drop_p, uint32_t site_probs, uint32_t site_res, const void* seed,
                         const void* seq_add, uint32_t site_seq_add, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * One launch per layer and direction for the short-sequence ("group") stages: the whole pre-LN block
+ *     x1 = x  + drop( out_proj( MHA( LayerNorm1(x) ) ) ) [+ drop( seq_add[sequence] )]
+ *     x2 = x1 + drop( linear2( drop( relu( linear1( LayerNorm2(x1) ) ) ) ) )
+ * of deepsvg/model/layers/improved_transformer.py:42-54 and :126-141 as used by hierarchical_encoder (model/model.py:153-161)
+ * and hierarchical_decoder (:246-254): d_model 256, dim_ff 512, 8 heads, bf16, dense sequences of S tokens with 32 % S == 0,
+ * rows = n_seq * S.  They replace ~15 (forward) / ~25 (backward) launches of 5-12 us each; what they read and write is
+ * exactly what those launches read and write, with the same dropout draws (sites site0 + 0 probabilities, + 1 attention
+ * residual, + 2 per-sequence term, + 3 hidden, + 4 FFN residual), so fused and unfused launches can be mixed freely.
+ * dsvg_gs_pack: bf16 MFMA-fragment images (dsvg_gs_pack_bytes(n_layers) bytes = 1 MiB per layer, each) of the layer's four
+ *   weight matrices for the forward and for the backward kernel, straight from the fp32 master buffer; offs = int64
+ *   [n_layers][4] element offsets of (in_proj_weight, out_proj.weight, linear1.weight, linear2.weight).  Re-pack after
+ *   every optimiser step.
+ * dsvg_gs_layer_fwd: x bf16 [rows,256] -> x2.  key_mask (optional): bit j of key_mask[b] = key j of sequence b visible.
+ *   seq_add (optional): bf16 [n_seq,256] (the decoder's linear_global(z) term, drawn like dsvg_bcast_add_fwd).
+ *   Training outputs (all NULL for inference, all set otherwise) = what the backward pass reads, in the layouts of the
+ *   unfused launches: mean1 / rstd1 / mean2 / rstd2 fp32 [rows], xn1 = LayerNorm1(x), ao (head outputs), x1,
+ *   xn2 = LayerNorm2(x1) bf16 [rows,256], qkv bf16 [rows,768], h bf16 [rows,512] (after ReLU and dropout).
+ * dsvg_gs_layer_bwd: dx2 = dL/dx2 bf16 [rows,256] and the saved tensors -> dx = dL/dx, plus the token-major operands of
+ *   the four weight-gradient GEMMs the caller runs afterwards - dym = dx2 * mask(site0+4) (with h: linear2), dpre (with
+ *   xn2: linear1), dx1m = dx1 * mask(site0+1) (with ao: out_proj), dqkv (with xn1: in_proj); their column sums are the bias
+ *   gradients - dx1 (optional, for dsvg_bcast_add_bwd of the per-sequence term) and the four LayerNorm parameter
+ *   gradients (fp32 [256] each; reduced from per-tile partials in `workspace`, dsvg_gs_bwd_workspace_bytes(n_seq, S)
+ *   bytes, through the deferred-reduction queue when a scope is open on the stream).
+ * ------------------------------------------------------------------------------------------ */
+int64_t dsvg_gs_pack_bytes(int32_t n_layers);
+int dsvg_gs_pack(const float* flat_f32, const int64_t* offs, int32_t n_layers, int32_t d_model, int32_t d_ff,
+                 int32_t n_heads, void* packed_fwd, void* packed_bwd, void* stream);
+int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, const float* in_bias, const float* out_bias,
+                      const float* b1, const float* b2, const float* gamma1, const float* beta1, const float* gamma2,
+                      const float* beta2, const uint64_t* key_mask, const void* seq_add, int64_t n_seq, int32_t S,
+                      void* x2, float* mean1, float* rstd1, void* xn1, void* qkv, void* ao, void* x1, float* mean2,
+                      float* rstd2, void* xn2, void* h, float eps, float scale, float drop_p, uint32_t site0,
+                      const void* seed, void* stream);
+int64_t dsvg_gs_bwd_workspace_bytes(int64_t n_seq, int32_t S);
+int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, const void* x, const float* mean1, const float* rstd1,
+                      const void* qkv, const void* x1, const float* mean2, const float* rstd2, const void* h,
+                      const float* gamma1, const float* gamma2, const uint64_t* key_mask, int64_t n_seq, int32_t S,
+                      void* dx, void* dx1, void* dym, void* dpre, void* dx1m, void* dqkv, float* dgamma2, float* dbeta2,
+                      float* dgamma1, float* dbeta1, float scale, float drop_p, uint32_t site0, const void* seed,
+                      void* workspace, int64_t workspace_bytes, void* stream);
 /* test hook: raw ds_read_b64_tr_b16 on a 4 KiB LDS image img[i]=i, lane l reads at byte offset off[l] */
 int dsvg_probe_trread(const int* off, short* out, void* stream);
 

@@ -1,0 +1,250 @@
+"""The fused per-layer kernels of the short-sequence ("group") stages (csrc/group_stage.hip) against
+  * the fp32 torch restatement of the same block (tests/torch_ops_ref.py: the unfused reference ops composed, with the bf16
+    rounding points of the unfused launches), tensor by tensor - every saved tensor of the forward pass, every operand the
+    backward pass hands to the weight-gradient GEMMs, the LayerNorm parameter gradients;
+  * the unfused HIP launches they replace (same dropout draws: fused forward + unfused backward and the reverse must agree).
+Each check collects ALL mismatching tensors of a case before failing, so that one GPU run localises a defect to a phase."""
+import pytest
+import torch
+
+from deepsvg_amd import ops
+from tests import torch_ops_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+N_W = 196608 + 65536 + 131072 + 131072       # in_proj | out_proj | linear1 | linear2
+
+
+def _seed_tensor(v=0x1234567887654321):
+    return torch.tensor([v if v < (1 << 63) else v - (1 << 64)], dtype=torch.int64, device=DEV)
+
+
+def _setup(n_seq, S, seed=0, n_layers=2, masked=False, with_add=False):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    flat = torch.zeros(8 + n_layers * N_W)
+    offs = []
+    for i in range(n_layers):
+        o = 8 + i * N_W
+        ent = [o, o + 196608, o + 262144, o + 393216]
+        flat[o:o + N_W] = torch.randn(N_W, generator=g) * 0.06
+        offs.append(ent)
+    rows = n_seq * S
+    p = dict(
+        in_bias=0.2 * torch.randn(768, generator=g), out_bias=0.2 * torch.randn(256, generator=g),
+        b1=0.3 * torch.randn(512, generator=g), b2=0.3 * torch.randn(256, generator=g),
+        gamma1=1 + 0.2 * torch.randn(256, generator=g), beta1=0.2 * torch.randn(256, generator=g),
+        gamma2=1 + 0.2 * torch.randn(256, generator=g), beta2=0.2 * torch.randn(256, generator=g))
+    p = {k: v.to(DEV) for k, v in p.items()}
+    x = (torch.randn(rows, 256, generator=g) * 1.5 + 0.3).to(DEV).to(torch.bfloat16)
+    key_mask = None
+    if masked:      # arbitrary visibility masks with at least one visible key per sequence
+        bits = torch.randint(0, 2, (n_seq, S), generator=g)
+        bits[torch.arange(n_seq), torch.randint(0, S, (n_seq,), generator=g)] = 1
+        key_mask = (bits.to(torch.int64) << torch.arange(S, dtype=torch.int64)).sum(1).to(DEV)
+    seq_add = (torch.randn(n_seq, 256, generator=g) * 0.5).to(DEV).to(torch.bfloat16) if with_add else None
+    dx2 = (torch.randn(rows, 256, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    return flat.to(DEV), torch.tensor(offs, dtype=torch.int64, device=DEV), p, x, key_mask, seq_add, dx2
+
+
+def _diff(name, got, want, tol, bad, mean_tol=None):
+    got, want = got.float(), want.float()
+    if got.shape != want.shape:
+        bad.append(f"{name}: shape {tuple(got.shape)} vs {tuple(want.shape)}")
+        return
+    if not torch.isfinite(got).all():
+        bad.append(f"{name}: {int((~torch.isfinite(got)).sum())} non-finite values")
+        return
+    scale = want.abs().max().item() + 1e-12
+    err = (got - want).abs()
+    if err.max().item() > tol * scale:
+        i = int(err.argmax())
+        r, c = (i // got.shape[-1], i % got.shape[-1]) if got.dim() == 2 else (i, 0)
+        frac = (err > tol * scale).float().mean().item()
+        bad.append(f"{name}: max err {err.max().item():.3e} at (row {r}, col {c}) vs scale {scale:.3e} (tol {tol:.0e}); "
+                   f"{100 * frac:.2f} % of the elements out of tolerance")
+    elif mean_tol is not None and err.mean().item() > mean_tol * want.abs().mean().item():
+        bad.append(f"{name}: mean err {err.mean().item():.3e} vs mean |want| {want.abs().mean().item():.3e}")
+
+
+FWD_NAMES = ("x2", "mean1", "rstd1", "xn1", "qkv", "ao", "x1", "mean2", "rstd2", "xn2", "h")
+BWD_NAMES = ("dx", "dx1", "dym", "dpre", "dx1m", "dqkv", "dgamma2", "dbeta2", "dgamma1", "dbeta1")
+
+
+def _params(p):
+    return (p["in_bias"], p["out_bias"], p["b1"], p["b2"], p["gamma1"], p["beta1"], p["gamma2"], p["beta2"])
+
+
+def test_gs_pack_layout(gpu_device):
+    """every fragment of both images against the index formulas in the header of csrc/group_stage.hip"""
+    flat, offs, *_ = _setup(4, 8, seed=3)
+    pf, pb = ops.gs_pack(flat, offs, 2)
+    pf = pf.view(2, 8, 128, 64, 8).cpu().float()
+    pb = pb.view(2, 8, 128, 64, 8).cpu().float()
+    lane = torch.arange(64)
+    row, half = (lane & 31).view(64, 1), (lane >> 5).view(64, 1)
+    e = torch.arange(8).view(1, 8)
+    for layer in range(2):
+        oi, oo, o1, o2 = (int(v) for v in offs[layer])
+        bf = lambda t: t.to(torch.bfloat16).float().cpu()
+        Win, Wo = bf(flat[oi:oi + 196608].view(768, 256)), bf(flat[oo:oo + 65536].view(256, 256))
+        W1, W2 = bf(flat[o1:o1 + 131072].view(512, 256)), bf(flat[o2:o2 + 131072].view(256, 512))
+        for w in range(8):
+            for i in range(128):
+                k = lambda ks: 16 * ks + 8 * half + e
+                if i < 48:
+                    want = Win[256 * (i % 3) + 32 * w + row, k(i // 3)]
+                elif i < 64:
+                    want = Wo[32 * w + row, k(i - 48)]
+                elif i < 96:
+                    want = W1[64 * w + 32 * (i & 1) + row, k((i - 64) >> 1)]
+                else:
+                    want = W2[32 * w + row, k(i - 96)]
+                assert torch.equal(pf[layer, w, i], want), f"forward image: layer {layer} wave {w} fragment {i}"
+                if i < 32:
+                    want = W2[k(i >> 1), 64 * w + 32 * (i & 1) + row]
+                elif i < 64:
+                    want = W1[k(i - 32), 32 * w + row]
+                elif i < 80:
+                    want = Wo[k(i - 64), 32 * w + row]
+                else:
+                    want = Win[k(i - 80), 32 * w + row]
+                assert torch.equal(pb[layer, w, i], want), f"backward image: layer {layer} wave {w} fragment {i}"
+
+
+CASES = [  # n_seq, S, key masks, per-sequence add, dropout
+    (512, 8, True, False, 0.1),      # encoder group stage at the benchmark size
+    (512, 8, False, True, 0.1),      # decoder group stage
+    (37, 8, True, True, 0.0),        # ragged last tile (one sequence in it), no dropout
+    (5, 32, False, False, 0.1),      # one sequence per tile
+    (9, 16, True, True, 0.1),        # two per tile, ragged
+    (3, 4, False, True, 0.0),        # a single partly filled tile
+]
+
+
+@pytest.mark.parametrize("n_seq,S,masked,with_add,drop_p", CASES)
+def test_gs_layer_fwd_matches_reference(gpu_device, n_seq, S, masked, with_add, drop_p):
+    flat, offs, p, x, key_mask, seq_add, _ = _setup(n_seq, S, seed=n_seq + S, masked=masked, with_add=with_add)
+    pf, _pb = ops.gs_pack(flat, offs, 2)
+    ef, _eb = R.gs_pack(flat, offs, 2)
+    seed = _seed_tensor(0x0123456789ABCDEF)
+    scale = 32 ** -0.5
+    bad = []
+    for layer in (0, 1):
+        sl = slice(layer * ops.GS_LAYER_ELEMS, (layer + 1) * ops.GS_LAYER_ELEMS)
+        got = ops.gs_layer_fwd(x, pf[sl], *_params(p), key_mask, n_seq, S, scale, 1e-5, drop_p, 300 + 8 * layer, seed,
+                               seq_add=seq_add, train=True)
+        want = R.gs_layer_fwd(x, ef[sl], *_params(p), key_mask, n_seq, S, scale, 1e-5, drop_p, 300 + 8 * layer, seed,
+                              seq_add=seq_add, train=True)
+        torch.cuda.synchronize()
+        for name, a, b in zip(FWD_NAMES, got, want):
+            if name == "h":     # ReLU gates within rounding of zero may differ (other summation order): compare where both agree
+                same = (a != 0) == (b != 0)
+                if (~same).float().mean().item() > 3e-3:
+                    bad.append(f"layer {layer} h: {100 * (~same).float().mean().item():.2f} % of the gates differ")
+                a, b = torch.where(same, a, torch.zeros_like(a)), torch.where(same, b, torch.zeros_like(b))
+            tol = 1e-4 if name.startswith(("mean", "rstd")) else 2e-2
+            _diff(f"layer {layer} {name}", a, b, tol, bad, mean_tol=None if name.startswith(("mean", "rstd")) else 4e-3)
+        # the inference call: the same x2, nothing else written
+        y = ops.gs_layer_fwd(x, pf[sl], *_params(p), key_mask, n_seq, S, scale, 1e-5, drop_p, 300 + 8 * layer, seed,
+                             seq_add=seq_add)
+        if not torch.equal(y, got[0]):
+            bad.append(f"layer {layer}: inference x2 differs from the training call's x2")
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("n_seq,S,masked,with_add,drop_p", CASES)
+def test_gs_layer_bwd_matches_reference(gpu_device, n_seq, S, masked, with_add, drop_p):
+    flat, offs, p, x, key_mask, seq_add, dx2 = _setup(n_seq, S, seed=100 + n_seq + S, masked=masked, with_add=with_add)
+    _pf, pb = ops.gs_pack(flat, offs, 2)
+    ef, eb = R.gs_pack(flat, offs, 2)
+    seed = _seed_tensor(0x00C0FFEE12345678)
+    scale = 32 ** -0.5
+    bad = []
+    for layer in (0, 1):
+        sl = slice(layer * ops.GS_LAYER_ELEMS, (layer + 1) * ops.GS_LAYER_ELEMS)
+        # inputs of the backward pass from the REFERENCE forward: this test does not depend on the fused forward kernel
+        (_x2, mean1, rstd1, _xn1, qkv, _ao, x1, mean2, rstd2, _xn2, h) = R.gs_layer_fwd(
+            x, ef[sl], *_params(p), key_mask, n_seq, S, scale, 1e-5, drop_p, 300 + 8 * layer, seed, seq_add=seq_add, train=True)
+        args = (x, mean1, rstd1, qkv, x1, mean2, rstd2, h, p["gamma1"], p["gamma2"], key_mask, n_seq, S, scale, drop_p,
+                300 + 8 * layer, seed)
+        got = ops.gs_layer_bwd(dx2, pb[sl], *args, want_dx1=True)
+        want = R.gs_layer_bwd(dx2, eb[sl], *args, want_dx1=True)
+        torch.cuda.synchronize()
+        for name, a, b in zip(BWD_NAMES, got, want):
+            _diff(f"layer {layer} {name}", a, b, 2e-2 if not name.startswith(("dgamma", "dbeta")) else 1e-2, bad,
+                  mean_tol=5e-3 if not name.startswith(("dgamma", "dbeta")) else None)
+    assert not bad, "\n".join(bad)
+
+
+def _unfused_fwd(x, W, p, key_mask, n_seq, S, scale, drop_p, s0, seed, seq_add):
+    """the launches LayerFn.forward issues for a small stage (functional.py), same order"""
+    win, wo, w1, w2 = W
+    xn1, mean1, rstd1 = ops.layernorm_fwd(x, p["gamma1"], p["beta1"])
+    qkv = ops.gemm(xn1, win, bias=p["in_bias"])
+    ao = ops.attention_fwd(qkv, key_mask, n_seq, S, 8, scale, drop_p, s0, seed)
+    x1 = ops.gemm(ao, wo, bias=p["out_bias"], res=x, drop_p=drop_p, drop_site=s0 + 1, seed=seed)
+    if seq_add is not None:
+        ops.bcast_add_fwd_(x1, seq_add, n_seq, S, drop_p, s0 + 2, seed)
+    xn2, mean2, rstd2 = ops.layernorm_fwd(x1, p["gamma2"], p["beta2"])
+    h = ops.gemm(xn2, w1, bias=p["b1"], act=ops.RELU, drop_p=drop_p, drop_site=s0 + 3, seed=seed)
+    x2 = ops.gemm(h, w2, bias=p["b2"], res=x1, drop_p=drop_p, drop_site=s0 + 4, seed=seed)
+    return x2, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h
+
+
+def _unfused_bwd(dx2, W, p, sv, key_mask, n_seq, S, scale, drop_p, s0, seed):
+    """the input-gradient chain of LayerFn.backward's unfused branch"""
+    win, wo, w1, w2 = W
+    (_x2, mean1, rstd1, _xn1, qkv, _ao, x1, mean2, rstd2, _xn2, h), x = sv
+    inv_keep = ops.keep_scale(drop_p)
+    dym = ops.drop_apply(dx2, drop_p, s0 + 4, seed)
+    dpre = ops.gemm(dym, w2, b_kc=False, gate=h, gate_scale=inv_keep)
+    dxn2 = ops.gemm(dpre, w1, b_kc=False)
+    dx1, dg2, db2 = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, p["gamma2"], res=dx2)
+    dx1m = ops.drop_apply(dx1, drop_p, s0 + 1, seed)
+    dao = ops.gemm(dx1m, wo, b_kc=False)
+    dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, 8, scale, drop_p, s0, seed)
+    dxn1 = ops.gemm(dqkv, win, b_kc=False)
+    dx, dg1, db1 = ops.layernorm_bwd(dxn1, x, mean1, rstd1, p["gamma1"], res=dx1)
+    return dx, dx1, dym, dpre, dx1m, dqkv, dg2, db2, dg1, db1
+
+
+@pytest.mark.parametrize("n_seq,S,masked,with_add", [(512, 8, True, False), (130, 8, False, True), (6, 32, False, True)])
+def test_gs_layer_is_interchangeable_with_the_unfused_launches(gpu_device, n_seq, S, masked, with_add):
+    """dropout 0.1 at all five sites: the fused kernels draw the same masks as the launches they replace, so every tensor
+    of (fused forward, fused backward) agrees with (unfused forward, unfused backward), and a fused backward pass fed with
+    the UNFUSED forward's saved tensors (and the reverse) reproduces the same input gradient"""
+    drop_p = 0.1
+    flat, offs, p, x, key_mask, seq_add, dx2 = _setup(n_seq, S, seed=7 + n_seq, n_layers=1, masked=masked, with_add=with_add)
+    pf, pb = ops.gs_pack(flat, offs, 1)
+    oi, oo, o1, o2 = (int(v) for v in offs[0])
+    bf = lambda t: t.to(torch.bfloat16).contiguous()
+    W = (bf(flat[oi:oi + 196608].view(768, 256)), bf(flat[oo:oo + 65536].view(256, 256)),
+         bf(flat[o1:o1 + 131072].view(512, 256)), bf(flat[o2:o2 + 131072].view(256, 512)))
+    seed = _seed_tensor(0x0F1E2D3C4B5A6978)
+    scale, s0 = 32 ** -0.5, 208
+    bad = []
+    fu = ops.gs_layer_fwd(x, pf, *_params(p), key_mask, n_seq, S, scale, 1e-5, drop_p, s0, seed, seq_add=seq_add, train=True)
+    un = _unfused_fwd(x, W, p, key_mask, n_seq, S, scale, drop_p, s0, seed, seq_add)
+    for name, a, b in zip(FWD_NAMES, fu, un):
+        if name == "h":
+            same = (a != 0) == (b != 0)
+            if (~same).float().mean().item() > 3e-3:
+                bad.append(f"h: {100 * (~same).float().mean().item():.2f} % of the gates differ between fused and unfused")
+            a, b = torch.where(same, a, torch.zeros_like(a)), torch.where(same, b, torch.zeros_like(b))
+        _diff(f"forward {name} (fused vs unfused)", a, b, 1e-4 if name.startswith(("mean", "rstd")) else 2e-2, bad)
+
+    def fused_bwd(sv):
+        (_x2, mean1, rstd1, _xn1, qkv, _ao, x1, mean2, rstd2, _xn2, h) = sv
+        return ops.gs_layer_bwd(dx2, pb, x, mean1, rstd1, qkv, x1, mean2, rstd2, h, p["gamma1"], p["gamma2"], key_mask, n_seq,
+                                S, scale, drop_p, s0, seed, want_dx1=True)
+    ff = fused_bwd(fu)                                               # fused forward -> fused backward
+    uf = fused_bwd(un)                                               # unfused forward -> fused backward
+    uu = _unfused_bwd(dx2, W, p, (un, x), key_mask, n_seq, S, scale, drop_p, s0, seed)      # unfused -> unfused
+    fu_un = _unfused_bwd(dx2, W, p, (fu, x), key_mask, n_seq, S, scale, drop_p, s0, seed)   # fused forward -> unfused backward
+    torch.cuda.synchronize()
+    for name, a, b, c, d in zip(BWD_NAMES, ff, uf, uu, fu_un):
+        tol = 2.5e-2 if not name.startswith(("dgamma", "dbeta")) else 1e-2
+        _diff(f"backward {name} (unfused fwd + fused bwd vs all unfused)", b, c, tol, bad)
+        _diff(f"backward {name} (all fused vs all unfused)", a, c, tol, bad)
+        _diff(f"backward {name} (fused fwd + unfused bwd vs all unfused)", d, c, tol, bad)
+    assert not bad, "\n".join(bad)

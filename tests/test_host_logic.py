@@ -479,3 +479,55 @@ def test_fused_attention_path_matches_unfused_with_emulated_ops(emulated_ops):
     assert res[True][0] == res[False][0]
     for n in res[True][1]:
         assert torch.equal(res[True][1][n], res[False][1][n]), n
+
+
+def test_fused_group_stage_path_matches_unfused_with_emulated_ops(emulated_ops):
+    """bf16 compute: the layers of the two short-sequence stacks (hierarchical_encoder with its visibility key masks,
+    hierarchical_decoder with the per-icon conditioning row) run through gs_pack / gs_layer_fwd / gs_layer_bwd.  With the
+    emulated ops the fused calls are the composition of the unfused ones, so loss and gradients must be IDENTICAL - this
+    pins the wiring: saved tensors, dropout sites, key masks, the conditioning row and its gradient, which operand pairs
+    reach the four weight-gradient GEMMs, the LayerNorm parameter gradients"""
+    from deepsvg_amd.synthetic import make_batch
+    from deepsvg_amd import ops
+    cfg = H.build_cfg("hier")
+    cfg.n_layers = cfg.n_layers_decode = 2
+    cfg.dropout = 0.1
+    c, a = make_batch(6, seed=5)
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 8)
+    res, calls = {}, {}
+    saved = (ops.gs_layer_fwd, ops.gs_layer_bwd)
+    try:
+        for fused in (True, False):
+            n_calls = [0, 0]
+
+            def counted_f(*args, _f=saved[0], **kw):
+                n_calls[0] += 1
+                return _f(*args, **kw)
+
+            def counted_b(*args, _f=saved[1], **kw):
+                n_calls[1] += 1
+                return _f(*args, **kw)
+            ops.gs_layer_fwd, ops.gs_layer_bwd = counted_f, counted_b
+            torch.manual_seed(3)
+            model = deepsvg_amd.SVGTransformer(cfg).train()
+            model.load_state_dict(sd)
+            model.set_compute_dtype(torch.bfloat16)
+            if not fused:
+                model.store._gs_setup = lambda device: setattr(model.store, "_gs", None)
+            out = model(c, a, c, a, params={})
+            assert (model.store._gs is not None) == fused
+            ld = deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
+            ld["loss"].backward()
+            res[fused] = (float(ld["loss"]), {n: p.grad.clone() for n, p in model.named_parameters()})
+            calls[fused] = tuple(n_calls)
+    finally:
+        ops.gs_layer_fwd, ops.gs_layer_bwd = saved
+    assert calls[True] == (4, 4) and calls[False] == (0, 0)        # 2 group stacks x 2 layers, forward and backward
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    assert all(g is not None for g in res[True][1].values())
+    for n in res[True][1]:
+        assert torch.equal(res[True][1][n], res[False][1][n]), n
+    # inference call: one launch per layer as well, nothing saved
+    model.eval()
+    with torch.no_grad():
+        model(c, a, c, a, params={})

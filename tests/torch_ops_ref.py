@@ -835,6 +835,73 @@ def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_
     return x1
 
 
+# ------------------------------------------------------------------------------------------------
+# fused group-stage layer (csrc/group_stage.hip).  The emulated images carry in_proj | out_proj | linear1 | linear2 in bf16;
+# the restatement is the composition of the unfused launches in their own order.
+# ------------------------------------------------------------------------------------------------
+GS_LAYER_ELEMS = 8 * 128 * 512
+
+
+def gs_pack(flat, offs, n_layers, packed_fwd=None, packed_bwd=None):
+    dev = flat.device
+    if packed_fwd is None:
+        packed_fwd = torch.empty(n_layers * GS_LAYER_ELEMS, dtype=torch.bfloat16, device=dev)
+    if packed_bwd is None:
+        packed_bwd = torch.empty(n_layers * GS_LAYER_ELEMS, dtype=torch.bfloat16, device=dev)
+    for i in range(n_layers):
+        oi, oo, o1, o2 = (int(v) for v in offs[i])
+        w = torch.cat([flat[oi:oi + 196608], flat[oo:oo + 65536], flat[o1:o1 + 131072], flat[o2:o2 + 131072]]).to(torch.bfloat16)
+        packed_fwd[i * GS_LAYER_ELEMS:(i + 1) * GS_LAYER_ELEMS] = w
+        packed_bwd[i * GS_LAYER_ELEMS:(i + 1) * GS_LAYER_ELEMS] = w
+    return packed_fwd, packed_bwd
+
+
+def _gs_weights(img):
+    return (img[:196608].view(768, 256), img[196608:262144].view(256, 256), img[262144:393216].view(512, 256),
+            img[393216:524288].view(256, 512))
+
+
+def gs_layer_fwd(x, packed_fwd_layer, in_bias, out_bias, b1, b2, gamma1, beta1, gamma2, beta2, key_mask, n_seq, S, scale,
+                 eps=1e-5, drop_p=0.0, site0=0, seed=None, seq_add=None, train=False):
+    win, wo, w1, w2 = _gs_weights(packed_fwd_layer)
+    xn1, mean1, rstd1 = layernorm_fwd(x, gamma1, beta1, eps)
+    qkv = gemm(xn1, win, bias=in_bias)
+    ao = attention_fwd(qkv, key_mask, n_seq, S, 8, scale, drop_p, site0, seed)
+    x1 = gemm(ao, wo, bias=out_bias, res=x, drop_p=drop_p, drop_site=site0 + 1, seed=seed)
+    if seq_add is not None:
+        bcast_add_fwd_(x1, seq_add, n_seq, S, drop_p, site0 + 2, seed)
+    xn2, mean2, rstd2 = layernorm_fwd(x1, gamma2, beta2, eps)
+    h = gemm(xn2, w1, bias=b1, act=RELU, drop_p=drop_p, drop_site=site0 + 3, seed=seed)
+    x2 = gemm(h, w2, bias=b2, res=x1, drop_p=drop_p, drop_site=site0 + 4, seed=seed)
+    if train:
+        return x2, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h
+    return x2
+
+
+def gs_layer_bwd(dx2, packed_bwd_layer, x, mean1, rstd1, qkv, x1, mean2, rstd2, h, gamma1, gamma2, key_mask, n_seq, S,
+                 scale, drop_p=0.0, site0=0, seed=None, want_dx1=False, dgamma2=None, dbeta2=None, dgamma1=None,
+                 dbeta1=None):
+    win, wo, w1, w2 = _gs_weights(packed_bwd_layer)
+    inv_keep = keep_scale(drop_p)
+    dym = drop_apply(dx2, drop_p, site0 + 4, seed)
+    dpre = gemm(dym, w2, b_kc=False, gate=h, gate_scale=inv_keep)
+    dxn2 = gemm(dpre, w1, b_kc=False)
+    dx1, dg2, db2 = layernorm_bwd(dxn2, x1, mean2, rstd2, gamma2, res=dx2, dgamma=dgamma2, dbeta=dbeta2)
+    dx1m = drop_apply(dx1, drop_p, site0 + 1, seed)
+    dao = gemm(dx1m, wo, b_kc=False)
+    dqkv = attention_bwd(qkv, key_mask, dao, n_seq, S, 8, scale, drop_p, site0, seed)
+    dxn1 = gemm(dqkv, win, b_kc=False)
+    dx, dg1, db1 = layernorm_bwd(dxn1, x, mean1, rstd1, gamma1, res=dx1, dgamma=dgamma1, dbeta=dbeta1)
+    return dx, (dx1 if want_dx1 else None), dym, dpre, dx1m, dqkv, dg2, db2, dg1, db1
+
+
+def keep_scale(p):
+    if p <= 0:
+        return 1.0
+    t = min(int(p * 65536.0 + 0.5), 65535)
+    return 65536.0 / (65536 - t)
+
+
 def gate_mul(dy, y, scale=1.0):
     return torch.where(_f(y) > 0, _f(dy) * scale, torch.zeros_like(_f(dy))).to(dy.dtype)
 
