@@ -9,15 +9,15 @@ on N MI355X (one process per GPU, RCCL gradient all-reduce).
 
 Rank 0 prints ONE JSON line (contract in the task statement).  The timed loop rotates 8 distinct device-resident batches
 (different layout buckets included; `graphs` reports how many hipGraphs that took).  Extra objects:
-  roofline     the FFN sub-block of the 16 layers (fused forward kernel on the large stages, linear1 / linear2 GEMMs on
-               the small ones, the backward launches: dropout replay, gated dX GEMM, fused dx + LayerNorm-backward
-               kernel, the two weight-gradient GEMMs, the finishing kernel, and its share of the batched gradient
-               reductions), timed live with HIP events IN THE LAUNCH MODE `value` IS TIMED IN: for a hipGraph step the
-               events are event-record nodes of a second capture of the same step (hipEventRecordExternal), read back
-               after each replay; no ballast, same deferred reductions.  bound = "mfma": `frac` = ALGORITHMIC FLOPs the
-               launches executed (524,288 FLOP per token-layer forward, x3 trained; skipped padding
-               and recomputation are not counted) / that time / 2.5 PFLOP/s.  `fused_fwd_kernel` is the dominant
-               kernel alone; `traffic` is a committed rocprofv3 --pmc measurement (labelled `traffic_source`).
+  roofline     the FFN sub-block of the 16 layers (fused forward kernel on the large stages, its share of the fused per-layer
+               kernels on the 4096-row stages, the backward launches: dropout replay, gated dX GEMM, fused dx + LayerNorm-
+               backward kernel, the weight-gradient GEMMs, the finishing kernel, and its share of the batched gradient
+               reductions), timed live with HIP events around the launches of the timed step's own sequence (issued eagerly
+               behind a short queue of GPU work: events cannot be recorded inside a replayed hipGraph on this runtime; the
+               graph-mode durations of the same kernels are the committed rocprofv3 trace, `graph_mode_check`).  bound =
+               "mfma": `frac` = ALGORITHMIC FLOPs the launches executed (524,288 FLOP per token-layer
+               forward, x3 trained; skipped padding and recomputation are not counted) / that time / 2.5 PFLOP/s.
+               `fused_fwd_kernel` is the dominant kernel alone; `traffic` is a committed rocprofv3 --pmc measurement.
   fp32         the parity path (fp32 storage, exact-fp32 MFMA): ms/step and icons/s of the same step, same batch
   torch_rocm_reference   the reference's step as stock PyTorch ops (the oracle module: aten / rocBLAS / MIOpen kernels,
                fp32, dropout on) on the SAME MI355X and batch: what the hand-written kernels buy over aten on this chip
@@ -365,63 +365,41 @@ def main():
 
     roofline = None
     if rank == 0 and not a.no_roofline and not emulate:
-        # Per-launch times of the FFN sub-block, live, in the launch mode `value` was timed in.
-        #   hipGraph: a second TrainStep captures the same step (same model, same batch, same deferred reductions) with an
-        #   event-record node in front of and behind every tagged launch (torch.cuda.Event(external=True) =
-        #   hipEventRecordExternal); after each replay the node pairs give the launch durations inside the replayed graph.
-        #   eager (or no external events on this runtime): events around the eager launches, behind a short queue of other
-        #   GPU work so that the host has enqueued the step before the GPU reaches it (intervals = kernel time only).
+        # Per-launch times of the FFN sub-block, live: HIP events (torch.cuda.Event on the launch stream) around every tagged
+        # launch of the SAME launch sequence the timed step replays - same kernels, same order, deferred + batched gradient
+        # reductions - issued eagerly behind a short queue of other GPU work, so that the host has enqueued the step before
+        # the GPU reaches it and an interval is kernel time, not launch latency.  Events cannot be recorded INSIDE the
+        # replayed hipGraph on this runtime (torch: "External events are disallowed in rocm"; hipEventRecordWithFlags(...,
+        # hipEventRecordExternal) during a capture breaks the next launch - scripts/graph_event_probe.py): the graph-mode
+        # durations of the same kernels come from rocprofv3 --kernel-trace of the timed command, committed under profiles/
+        # and cross-checked below (`graph_mode_check`).
         ts_prof = None
         if world == 1:
-            ts_prof = TrainStep(model, loss_fn, lr=0.0, grad_clip=1.0, use_graph=use_graph)
+            ts_prof = TrainStep(model, loss_fn, lr=0.0, grad_clip=1.0, use_graph=False)
             ts_prof.inputs_resident = True
         prof_mode = None
         if ts_prof is not None:
             n_prof = 3
-            recs = None
-            if use_graph:
-                try:
-                    ops.PROFILE_EXTERNAL, ops.PROFILE_KEEP_DEFER, ops.PROFILE_ON = True, True, True
-                    ts_prof.on_capture_begin = ops.PROFILE.clear       # (drop the records of the capture's warm-up runs)
-                    ts_prof.step(commands, args)                       # capture + first replay
-                    ops.PROFILE_ON = False
-                    prof = list(ops.PROFILE)
-                    acc = [0.0] * len(prof)
-                    for it in range(n_prof):
-                        if it:
-                            ts_prof.step(commands, args)
-                        sync()
-                        for i, r in enumerate(prof):
-                            acc[i] += r[1].elapsed_time(r[2])
-                    recs = [(r[0], acc[i] / n_prof, r[3], r[4], r[5]) for i, r in enumerate(prof)]
-                    prof_mode = "hipGraph replay: event-record nodes inside a capture of the timed step"
-                except Exception as e:
-                    log(f"graph-captured events unavailable ({type(e).__name__}: {e}); profiling eager launches")
-                    recs = None
-                finally:
-                    ops.PROFILE_EXTERNAL, ops.PROFILE_KEEP_DEFER, ops.PROFILE_ON = False, False, False
-                    ops.PROFILE.clear()
-            if recs is None:
-                ts_prof = TrainStep(model, loss_fn, lr=0.0, grad_clip=1.0, use_graph=False)
-                ts_prof.step(commands, args)
-                ops.PROFILE.clear()
-                ops.PROFILE_KEEP_DEFER, ops.PROFILE_ON = True, True
-                queue = torch.randn(8192, 8192, device=device)
-                for _ in range(n_prof):
-                    sync()
-                    for _b in range(3):
-                        queue @ queue
-                    ts_prof.step(commands, args)
+            ts_prof.step(commands, args)
+            ops.PROFILE.clear()
+            ops.PROFILE_KEEP_DEFER, ops.PROFILE_ON = True, True
+            queue = torch.randn(8192, 8192, device=device)
+            for _ in range(n_prof):
                 sync()
-                del queue
-                ops.PROFILE_KEEP_DEFER, ops.PROFILE_ON = False, False
-                per = len(ops.PROFILE) // n_prof
-                recs = []
-                for i in range(per):
-                    rs = [ops.PROFILE[i + j * per] for j in range(n_prof)]
-                    recs.append((rs[0][0], sum(r[1].elapsed_time(r[2]) for r in rs) / n_prof, rs[0][3], rs[0][4], rs[0][5]))
-                ops.PROFILE.clear()
-                prof_mode = "eager launches behind a short queue of other GPU work"
+                for _b in range(3):
+                    queue @ queue
+                ts_prof.step(commands, args)
+            sync()
+            del queue
+            ops.PROFILE_KEEP_DEFER, ops.PROFILE_ON = False, False
+            per = len(ops.PROFILE) // n_prof
+            recs = []
+            for i in range(per):
+                rs = [ops.PROFILE[i + j * per] for j in range(n_prof)]
+                recs.append((rs[0][0], sum(r[1].elapsed_time(r[2]) for r in rs) / n_prof, rs[0][3], rs[0][4], rs[0][5]))
+            ops.PROFILE.clear()
+            prof_mode = ("HIP events around the launches of the timed step's sequence (deferred reductions included), "
+                         "issued eagerly behind a short queue of other GPU work; mean of 3 steps")
             # recs: (tag, ms, flops, algorithmic bytes, spec) per launch of ONE step
             n_prof = 1
             red = [r for r in recs if r[0] == "reduce"]
@@ -554,6 +532,17 @@ def main():
                     roofline["traffic"] = t["MB_per_launch"]
                     roofline["traffic_source"] = "committed: " + t["source"]
                     roofline["traffic_over_fused_algorithmic"] = t.get("over_fused_algorithmic")
+            gcsv = os.path.join(ROOT, "profiles", "r03_graph_kernel_stats.csv")
+            if os.path.exists(gcsv) and fused_fwd is not None:
+                for line in open(gcsv):
+                    if "ffn_fwd_kernel" in line:
+                        f = line.strip().split(",")
+                        roofline["graph_mode_check"] = {
+                            "kernel": "ffn_fwd_kernel", "source": "committed: profiles/r03_graph_kernel_stats.csv (rocprofv3 "
+                            "--kernel-trace of `bench.py --graph 1`, scripts/gpu_prof_graph.sh)",
+                            "graph_replay_avg_us": float(f[3]), "launches_profiled": int(f[1]),
+                            "live_event_avg_us": round(fk_ms * 1e3 / max(len(fk), 1), 1)}
+                        break
             if a.ffn_replay > 0:
                 specs = [r[5] for r in ffn[:n_ffn] if "a" in r[5]]
                 replay_ffn(specs, a.ffn_replay, device)

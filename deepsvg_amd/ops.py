@@ -15,17 +15,12 @@ RELU = 1
 # optional per-launch timing of tagged GEMMs (bench.py roofline leg): HIP events on the launch stream
 PROFILE_ON = False
 PROFILE = []          # (tag, start_event, end_event, flops of the launch, algorithmic bytes of the launch, spec)
-# events recorded while a hipGraph is being captured become event-record NODES of that graph (hipEventRecordExternal), so
-# the launches of the very graph whose replays are timed can be timed one by one after a replay
-PROFILE_EXTERNAL = False
 # keep the deferred reductions of the train step on while profiling (the profiled sequence = the timed one)
 PROFILE_KEEP_DEFER = False
 _TAG = None
 
 
 def _event():
-    if PROFILE_EXTERNAL:
-        return torch.cuda.Event(enable_timing=True, external=True)
     return torch.cuda.Event(enable_timing=True)
 
 

@@ -63,7 +63,6 @@ class TrainStep:
         self._pending = None
         self._pool = None
         self._gradless_known, self._gradless_slots = False, []
-        self.on_capture_begin = None    # optional callback right before a graph capture starts (bench.py's profiled graph)
         self.row_bucket, self.seq_bucket = 1024, 64
         self.defer_reductions = os.environ.get("DSVG_DEFER_REDUCE", "1") != "0"
         model._own_seed = False          # the trainer advances the dropout seed once per step
@@ -366,8 +365,6 @@ class TrainStep:
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()     # graphs replay one at a time: one shared pool
             g = torch.cuda.CUDAGraph()
-            if self.on_capture_begin is not None:
-                self.on_capture_begin()
             # thread-local capture mode: other threads of the process keep calling the runtime while this one captures -
             # with an initialised process group the RCCL watchdog thread polls its work events (hipEventQuery), which the
             # default global mode answers by invalidating the capture and the watchdog by aborting the process

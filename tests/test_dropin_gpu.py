@@ -83,8 +83,12 @@ def test_reference_training_sequence_drives_the_hip_kernels(gpu_device, monkeypa
     assert list(sd1) == list(sd0), "state_dict keys / order must be the reference's"
     for k, v in leaves.items():
         if v.requires_grad:
-            # Adam's first updates are lr * g / |g|: elements whose gradient is fp32 noise may flip sign -> lr-scaled atol
-            assert torch.allclose(sd1[k], v.detach(), rtol=1e-3, atol=0.5 * lr), k
+            # Adam's first updates are lr * g / |g| per element whatever |g| is: an element whose gradient is fp32 summation
+            # noise may move the other way (2 lr apart per step), every other element agrees to gradient accuracy
+            d = (sd1[k] - v.detach()).abs()
+            assert d.max().item() <= 2.05 * lr * 2, (k, d.max().item())
+            close = d <= 1e-3 * v.detach().abs() + 0.05 * lr
+            assert close.float().mean().item() >= 0.99, (k, close.float().mean().item())
 
     # ---- checkpoint round trip (train_utils.py:147-152: load_state_dict(strict=False)) into a fresh model ------------------
     fresh = deepsvg_amd.SVGTransformer(cfg)
