@@ -355,6 +355,12 @@ def main():
     loss_val = float(ld["loss"])
     assert loss_val == loss_val and abs(loss_val) < 1e4, f"loss diverged: {loss_val}"
     log(f"timed {a.steps} steps in {elapsed:.3f}s, loss {loss_val:.4f}")
+    if ts.host_trace:       # DSVG_TRACE_STEP=1: where the host spends a step (ms): plan + its one read, copies + graph launch
+        tr = ts.host_trace[-a.steps:]
+        plan_ms = sum(t[1] - t[0] for t in tr) / len(tr) * 1e3
+        launch_ms = sum(t[2] - t[1] for t in tr) / len(tr) * 1e3
+        period_ms = (tr[-1][0] - tr[0][0]) / max(len(tr) - 1, 1) * 1e3
+        log(f"host trace: plan + read {plan_ms:.3f} ms, copies + graph launch {launch_ms:.3f} ms, step period {period_ms:.3f} ms")
     ms_per_step = elapsed / a.steps * 1e3
     icons_per_s = a.batch * world / (elapsed / a.steps)
     graphs = {"launch_mode": "hipGraph replay" if use_graph else "eager", "batches_rotated": n_b,

@@ -728,10 +728,14 @@ __global__ void bcast_add_fwd_kernel(T* __restrict__ x, const T* __restrict__ g,
     }
 }
 template <typename T>
-__global__ void bcast_add_bwd_kernel(const T* __restrict__ dx, T* __restrict__ dg, int S, int d, float drop_p,
-                                     uint32_t site, const uint64_t* seed) {
-    const DropCtx dc = drop_make(drop_p, seed, site);
+__global__ void bcast_add_bwd_kernel(const T* __restrict__ dx, T* __restrict__ dg, long long n_seq, int S, int d,
+                                     float drop_p, uint32_t site, const uint64_t* seed) {
     const long long b = blockIdx.x;
+    if (b >= n_seq) {           // sequences past the live prefix: zero gradient
+        for (int c = threadIdx.x; c < d; c += blockDim.x) Elem<T>::st(dg + b * d + c, 0.f);
+        return;
+    }
+    const DropCtx dc = drop_make(drop_p, seed, site);
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
         float s = 0.f;
         const T* px = dx + b * S * d + c;
@@ -754,17 +758,17 @@ extern "C" int dsvg_bcast_add_fwd(int32_t dtype, void* x, const void* g, int64_t
     DSVG_LAUNCH_CHECK("bcast_add_fwd");
     return 0;
 }
-extern "C" int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64_t n_seq, int32_t S, int32_t d,
-                                  float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream) {
-    DSVG_CHECK_ARG(dx && dg && n_seq > 0 && S > 0 && d > 0, "bcast_add_bwd: bad args");
+extern "C" int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64_t n_seq, int64_t n_seq_out, int32_t S,
+                                  int32_t d, float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream) {
+    DSVG_CHECK_ARG(dx && dg && n_seq > 0 && n_seq_out >= n_seq && S > 0 && d > 0, "bcast_add_bwd: bad args");
     DSVG_CHECK_ARG(drop_p <= 0.f || seed, "bcast_add_bwd: dropout needs a seed pointer");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DSVG_F32)
-        hipLaunchKernelGGL(bcast_add_bwd_kernel<float>, dim3((unsigned)n_seq), dim3(256), 0, st, (const float*)dx,
-                           (float*)dg, S, d, drop_p, drop_site, seed);
+        hipLaunchKernelGGL(bcast_add_bwd_kernel<float>, dim3((unsigned)n_seq_out), dim3(256), 0, st, (const float*)dx,
+                           (float*)dg, (long long)n_seq, S, d, drop_p, drop_site, seed);
     else if (dtype == DSVG_BF16)
-        hipLaunchKernelGGL(bcast_add_bwd_kernel<bf16_t>, dim3((unsigned)n_seq), dim3(256), 0, st, (const bf16_t*)dx,
-                           (bf16_t*)dg, S, d, drop_p, drop_site, seed);
+        hipLaunchKernelGGL(bcast_add_bwd_kernel<bf16_t>, dim3((unsigned)n_seq_out), dim3(256), 0, st, (const bf16_t*)dx,
+                           (bf16_t*)dg, (long long)n_seq, S, d, drop_p, drop_site, seed);
     else { dsvg_set_error("bcast_add_bwd: bad dtype"); return -1; }
     DSVG_LAUNCH_CHECK("bcast_add_bwd");
     return 0;

@@ -158,6 +158,67 @@ extern "C" int dsvg_advance_step(int64_t* counter, uint64_t* seed, void* stream)
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Up to 32 device-to-device copies in ONE launch: the descriptor table travels in the kernel arguments (hipGraph-capturable,
+// no staging buffer).  A hipGraph step reads its inputs and its layout plan from static tensors; refreshing them took ~20
+// copy launches of 2-6 us each on the main stream between two replays.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int COPY_MAX = 32;
+constexpr int COPY_CHUNK = 256 * 16 * 4;        // bytes per workgroup: 256 threads x 4 pieces of 16 bytes
+struct CopyTable {
+    const char* src[COPY_MAX];
+    char* dst[COPY_MAX];
+    long long bytes[COPY_MAX];
+    int first_block[COPY_MAX + 1];
+    int n;
+};
+static_assert(sizeof(CopyTable) <= 3600, "the copy table must fit the kernel-argument segment");
+
+__global__ __launch_bounds__(256) void copy_many_kernel(const CopyTable t) {
+    int s = 0;
+    while (s + 1 < t.n && (int)blockIdx.x >= t.first_block[s + 1]) ++s;
+    const long long off = (long long)((int)blockIdx.x - t.first_block[s]) * COPY_CHUNK;
+    const long long left = t.bytes[s] - off;
+    const char* src = t.src[s] + off;
+    char* dst = t.dst[s] + off;
+    const long long n = left < COPY_CHUNK ? left : COPY_CHUNK;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const long long n16 = n >> 4;
+        for (long long i = threadIdx.x; i < n16; i += 256)
+            reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+        for (long long i = (n16 << 4) + threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    } else {
+        for (long long i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    }
+}
+}  // namespace
+
+extern "C" int dsvg_copy_many(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream) {
+    DSVG_CHECK_ARG(n >= 0 && (n == 0 || (src && dst && bytes)), "copy_many: bad arguments");
+    int at = 0;
+    while (at < n) {
+        CopyTable t;
+        int blocks = 0, k = 0;
+        for (; k < COPY_MAX && at < n; ++at) {
+            if (bytes[at] <= 0) continue;
+            DSVG_CHECK_ARG(src[at] && dst[at], "copy_many: null pointer in entry %d", at);
+            t.src[k] = (const char*)src[at];
+            t.dst[k] = (char*)dst[at];
+            t.bytes[k] = bytes[at];
+            t.first_block[k] = blocks;
+            blocks += (int)((bytes[at] + COPY_CHUNK - 1) / COPY_CHUNK);
+            ++k;
+        }
+        t.n = k;
+        t.first_block[k] = blocks;
+        if (k > 0) hipLaunchKernelGGL(copy_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+    }
+    DSVG_LAUNCH_CHECK("copy_many");
+    return 0;
+}
+
 template <typename T>
 __global__ void gate_mul_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ out, long long n,
                                 float scale) {

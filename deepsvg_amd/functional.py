@@ -636,9 +636,8 @@ class LayerFn(torch.autograd.Function):
             if ctx.needs_input_grad[4]:
                 dl = ops.gemm(dg2, rt.w(wg2), b_kc=False)
         if z is not None:
-            dg = ops.bcast_add_bwd(dx1[:n_seq * S], n_seq, S, p, s0 + 2, rt.seed)
-            if n_seq < n_seq_full:      # sequences past the live prefix: zero gradient
-                dg = torch.cat([dg, dg.new_zeros((n_seq_full - n_seq, dg.shape[1]))])
+            # (sequences past the live prefix: zero gradient rows, written by the same launch)
+            dg = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed, n_seq_out=n_seq_full)
             dwg, dbg = _wbgrad(rt, wg, bg, dg, z)
             if ctx.needs_input_grad[3]:
                 dz = ops.gemm(dg, rt.w(wg), b_kc=False)

@@ -640,12 +640,15 @@ def bcast_add_fwd_(x, g, n_seq, S, drop_p=0.0, drop_site=0, seed=None):
     return x
 
 
-def bcast_add_bwd(dx, n_seq, S, drop_p=0.0, drop_site=0, seed=None):
+def bcast_add_bwd(dx, n_seq, S, drop_p=0.0, drop_site=0, seed=None, n_seq_out=None):
+    """dg[b] = mask[b] * sum_s dx[b * S + s] for b < n_seq; with n_seq_out > n_seq the result has n_seq_out rows, the extra
+    ones zero (sequences past a live prefix)"""
     _chk(dx, seed)
     assert dx.is_contiguous()
     d = dx.shape[1]
-    dg = torch.empty((n_seq, d), dtype=dx.dtype, device=dx.device)
-    _l.check(_l.load().dsvg_bcast_add_bwd(_dt(dx), dx.data_ptr(), dg.data_ptr(), n_seq, S, d, float(drop_p),
+    n_out = n_seq if n_seq_out is None else int(n_seq_out)
+    dg = torch.empty((n_out, d), dtype=dx.dtype, device=dx.device)
+    _l.check(_l.load().dsvg_bcast_add_bwd(_dt(dx), dx.data_ptr(), dg.data_ptr(), n_seq, n_out, S, d, float(drop_p),
                                           int(drop_site), _p(seed) if drop_p > 0 else None, _stream()),
              "dsvg_bcast_add_bwd")
     return dg
@@ -1194,6 +1197,22 @@ def add(a, b):
     out = torch.empty_like(a)
     _l.check(_l.load().dsvg_add(_dt(a), a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "dsvg_add")
     return out
+
+
+def copy_many(pairs):
+    """dst.copy_(src) for every (dst, src) pair of same-sized contiguous device tensors, in one launch per 32 pairs"""
+    pairs = [(d, s) for d, s in pairs if d.numel() > 0]
+    if not pairs:
+        return
+    n = len(pairs)
+    for d, s in pairs:
+        _chk(d, s)
+        assert d.is_contiguous() and s.is_contiguous() and d.dtype == s.dtype and d.numel() == s.numel(), \
+            (d.shape, s.shape, d.dtype, s.dtype)
+    src = (C.c_void_p * n)(*[s.data_ptr() for _, s in pairs])
+    dst = (C.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+    nb = (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in pairs])
+    _l.check(_l.load().dsvg_copy_many(src, dst, nb, n, _stream()), "dsvg_copy_many")
 
 
 def advance_step_(counter, seed):

@@ -18,6 +18,7 @@ flat buffers, one process per GPU.
 """
 import collections
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -63,6 +64,8 @@ class TrainStep:
         self._pending = None
         self._pool = None
         self._gradless_known, self._gradless_slots = False, []
+        # DSVG_TRACE_STEP=1: host-side time stamps of every step (entry, plan read done, graph launched) in `host_trace`
+        self.host_trace = [] if os.environ.get("DSVG_TRACE_STEP") == "1" else None
         self.row_bucket, self.seq_bucket = 1024, 64
         self.defer_reductions = os.environ.get("DSVG_DEFER_REDUCE", "1") != "0"
         model._own_seed = False          # the trainer advances the dropout seed once per step
@@ -210,6 +213,7 @@ class TrainStep:
         if self._plan_stream is None:
             self._plan_stream = torch.cuda.Stream(device=commands.device)
         ps = self._plan_stream
+        t_trace = [time.perf_counter()] if self.host_trace is not None else None
         if not self.inputs_resident:
             ps.wait_stream(main)
         counts = None
@@ -220,6 +224,8 @@ class TrainStep:
                 # previous step's graph); its result is copied into the graph's static tensor right before the replay
                 counts = self._global_counts(dec[0] if dec else commands, dec[1] if dec else args, plan)
         main.wait_stream(ps)
+        if t_trace is not None:
+            t_trace.append(time.perf_counter())
         if counts is not None:
             counts.record_stream(main)
         for part in ("enc", "dec", "loss"):        # allocated on the plan stream, read by launches on the main stream
@@ -247,24 +253,30 @@ class TrainStep:
         key = key + (label is not None, dec is not None)
         entry, fresh = self._graph_entry(key, lambda: self._capture(key, commands, args, plan, label, dec))
         if not fresh:
+            # refresh the graph's static inputs and static layout plan: ONE launch for all of them (dsvg_copy_many)
             graph, (sc, sa, sl, sdec), splan, res = entry
-            sc.copy_(commands)
-            sa.copy_(args)
+            pairs = [(sc, commands), (sa, args)]
             if sl is not None:
-                sl.copy_(label)
+                pairs.append((sl, label))
             if sdec is not None:
-                sdec[0].copy_(dec[0])
-                sdec[1].copy_(dec[1])
+                pairs += [(sdec[0], dec[0]), (sdec[1], dec[1])]
             for part in ("enc", "dec", "loss"):
                 if splan[part] is not None:
                     for k, v in splan[part].items():
                         if torch.is_tensor(v):
-                            v.copy_(plan[part][k])
+                            pairs.append((v, plan[part][k]))
                         elif isinstance(v, tuple):
-                            for dst, src in zip(v, plan[part][k]):
-                                dst.copy_(src)
+                            pairs += list(zip(v, plan[part][k]))
+            if commands.is_cuda and all(d.is_contiguous() and s_.is_contiguous() and d.dtype == s_.dtype for d, s_ in pairs):
+                ops.copy_many(pairs)
+            else:
+                for d, s_ in pairs:
+                    d.copy_(s_)
         self._note_layout(plan, commands)
         entry[0].replay()
+        if t_trace is not None:
+            t_trace.append(time.perf_counter())
+            self.host_trace.append(tuple(t_trace))
         if self.ddp:
             self._step_back()
         return entry[3]

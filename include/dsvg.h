@@ -220,11 +220,12 @@ int dsvg_masked_mean_bwd(int32_t dtype, const void* dout, const uint64_t* mask, 
  * x[t,:] += drop(g)[t / S, :]      "implicit broadcast" add of linear_global(z)
  * (deepsvg/model/layers/improved_transformer.py:131-136): the dropout acts on the per-sequence row BEFORE the
  * broadcast, as in the reference, so one mask element (id b*d + c) covers every position of sequence b.
- * bwd: dg[b,:] = mask[b,:] * sum_s dx[b*S+s,:]
+ * bwd: dg[b,:] = mask[b,:] * sum_s dx[b*S+s,:] for b < n_seq; rows n_seq <= b < n_seq_out of dg are written as zeros (a
+ *      backward pass restricted to a live prefix of the sequences: the others have zero gradient)
  * ------------------------------------------------------------------------------------------ */
 int dsvg_bcast_add_fwd(int32_t dtype, void* x, const void* g, int64_t n_seq, int32_t S, int32_t d,
                        float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream);
-int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64_t n_seq, int32_t S, int32_t d,
+int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64_t n_seq, int64_t n_seq_out, int32_t S, int32_t d,
                        float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -279,6 +280,10 @@ int dsvg_cast_weights(int32_t dtype, const float* src, void* dst, void* dst_t, i
                       int64_t cols, void* stream);
 /* *counter += 1 ; *seed = hash(*seed)  — per-step dropout seed advance, graph-capturable */
 int dsvg_advance_step(int64_t* counter, uint64_t* seed, void* stream);
+/* n device-to-device copies dst[i][0 .. bytes[i]) = src[i][...] in one launch per 32 entries (the table travels in the kernel
+ * arguments: capturable, no staging).  deepsvg_amd/trainer.py refreshes the static inputs and the layout plan of a hipGraph
+ * step with it between two replays (they were ~20 separate copy launches). */
+int dsvg_copy_many(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream);
 /* out[i] = y[i] > 0 ? dy[i]*scale : 0 — backward of ReLU (basic_blocks.py:47-57) from the saved output */
 int dsvg_gate_mul(int32_t dtype, const void* dy, const void* y, void* out, int64_t n, float scale, void* stream);
 /* y[i] = x[i] * dropmask(seed, site, i): replay of an nn.Dropout mask on a gradient (n % 8 == 0) */

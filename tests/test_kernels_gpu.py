@@ -1183,3 +1183,29 @@ def test_attn_block_fwd_equals_unfused_kernels(gpu_device, kind, p):
                                  1e-5, p, 7, 8, seed, train=False, seq_add=g, site_seq_add=9)
         _close(x1g, want_g, 2e-2, "x1 with the per-sequence add")
         assert not torch.equal(x1g, x1)
+
+
+def test_copy_many_and_bcast_add_bwd_tail(gpu_device):
+    """dsvg_copy_many: 40 copies (two launches of the 32-entry table) of mixed dtypes, sizes from 1 element to several
+    chunks, some of them at addresses that are not 16-byte aligned; dsvg_bcast_add_bwd with zero rows behind a live prefix"""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    pairs, want = [], []
+    for i in range(40):
+        n = [1, 3, 7, 64, 1000, 4099, 70001, 300000][i % 8]
+        dt = [torch.float32, torch.int32, torch.int64, torch.bfloat16, torch.uint8][i % 5]
+        src = (torch.randn(n + 3, generator=g) * 100).to(DEV).to(dt)
+        dst = torch.zeros(n + 3, dtype=dt, device=DEV)
+        o = i % 3                                   # views that start 0, 1 or 2 elements into the buffer
+        pairs.append((dst[o:o + n], src[o:o + n]))
+        want.append((dst, src, o, n))
+    ops.copy_many(pairs)
+    torch.cuda.synchronize()
+    for dst, src, o, n in want:
+        assert torch.equal(dst[o:o + n], src[o:o + n])
+        assert (dst[:o] == 0).all() and (dst[o + n:] == 0).all(), "wrote outside the destination range"
+    dx = _rand(24 * 8, 256, dtype=torch.bfloat16, seed=9)
+    seed = _seed_tensor(77)
+    full = ops.bcast_add_bwd(dx, 24, 8, 0.1, 5, seed)
+    part = ops.bcast_add_bwd(dx, 10, 8, 0.1, 5, seed, n_seq_out=24)
+    assert torch.equal(part[:10], full[:10]) and (part[10:] == 0).all() and tuple(part.shape) == (24, 256)
+    _close(full, R.bcast_add_bwd(dx, 24, 8, 0.1, 5, seed), 1e-2, "bcast_add_bwd")
