@@ -8,6 +8,7 @@
 #include "dsvg_common.h"
 #include "../../include/dsvg.h"
 #include "gemm_common.h"
+int dsvg_gemm_group_flush(hipStream_t st);       // gemm_bf16_glds.hip
 #include <map>
 #include <mutex>
 #include <vector>
@@ -457,6 +458,8 @@ __global__ __launch_bounds__(256) void reduce_deferred_kernel(const DeferTable t
 }
 
 int defer_flush_locked(DeferQueue& d, hipStream_t st) {
+    // weight-gradient GEMMs still waiting in a group on this stream produce partials queued here: they go first
+    if (int rc = dsvg_gemm_group_flush(st)) return rc;
     size_t at = 0;
     while (at < d.q.size()) {
         DeferTable t;
@@ -528,6 +531,7 @@ int dsvg_reduce_partials_mixed(const float* part, int64_t P, int64_t stride, int
             }
         }
     }
+    if (int rc = dsvg_gemm_group_flush(st)) return rc;      // (an immediate reduction must not overtake a still-queued producer)
     if (n_bf16 > 0 && !vec) { dsvg_set_error("reduce_partials: bf16 partials need 16-byte aligned, 4-column-multiple data"); return -1; }
     const long long cols = vec ? n / 4 : n;
     // few columns + many partial rows (bias / LayerNorm gradients): 16 slices over the partial index per block;

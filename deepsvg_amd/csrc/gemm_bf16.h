@@ -17,3 +17,5 @@ enum {
 // part_is_bf16 (split-K only, may be NULL): set to 1 when the slices were written as packed bf16 (see the kernel)
 bool dsvg_gemm_bf16_glds_try(const dsvg_gemm_desc& d, int epi, dim3 grid, int tiles_n, int nwg, int k_chunk,
                              float* part, float* rs_part, int mode, hipStream_t st, int* part_is_bf16);
+// launch the weight-gradient GEMMs queued on this stream under dsvg_gemm_group_scope (gemm_bf16_glds.hip); 0 if none
+int dsvg_gemm_group_flush(hipStream_t st);

@@ -15,6 +15,9 @@
 //   * out-of-range rows are clamped on the load side (their results are never stored): no exec-mask branches.
 // Eligibility is decided on the host (dsvg_gemm_bf16_glds_try); everything else runs on gemm_bf16.hip.
 #include "gemm_bf16.h"
+#include <map>
+#include <mutex>
+#include <vector>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short shortx4 __attribute__((ext_vector_type(4)));
@@ -89,16 +92,16 @@ __device__ __forceinline__ void dma_step8(const char* a0, const char* a1, const 
 // one workgroup per CU, where nothing else on the CU hides the ~1.4 us of a DMA round trip per K step); OCC: waves per SIMD the register allocation is held to (4 -> 128 VGPRs, no
 // spills; 5 -> 96 VGPRs, a few epilogue values spill, but all five 32-KiB workgroups a CU's LDS can hold are resident:
 // the packed / live-prefix GEMMs launch ~1.25 x 1024 workgroups, which then run as one wave of workgroups, not two)
-template <bool AKC, bool BKC, int EPI, int NST, int OCC>
-__global__ __launch_bounds__(256, NST == 1 ? OCC : 2) void gemm_bf16_glds_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
-                                                                              int k_chunk, float* part, float* rs_part,
-                                                                              int mode, int part_bf16) {
+// the whole kernel as a function of (block index x, block index y): the plain kernel passes blockIdx, the grouped
+// weight-gradient kernel its position inside the problem it belongs to
+template <bool AKC, bool BKC, int EPI, int NST>
+__device__ __forceinline__ void glds_body(const dsvg_gemm_desc& p, int tiles_n, int nwg_mn, int k_chunk, float* part,
+                                          float* rs_part, int mode, int part_bf16, int bid, int bid_y) {
     __shared__ __attribute__((aligned(1024))) bf16_t smem_static[NST <= 2 ? NST * 2 * IMG : 8];
     extern __shared__ __attribute__((aligned(1024))) bf16_t smem_dynamic[];
     bf16_t* const smem = NST <= 2 ? smem_static : smem_dynamic;
 
     // tile schedule: identical to gemm_bf16.hip modes 0 and 1 (workgroup b runs on XCD b % 8)
-    const int bid = blockIdx.x;
     const int xcd = bid % 8, local = bid / 8;
     int wgid, kz;
     if (mode == 1) {
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256, NST == 1 ? OCC : 2) void gemm_bf16_glds_kernel
     } else {
         const int q8 = nwg_mn / 8, r8 = nwg_mn % 8;
         wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
-        kz = blockIdx.y;
+        kz = bid_y;
     }
     const int tile_m = wgid / tiles_n, tile_n = wgid % tiles_n;
     const int m0 = tile_m * GBM, n0 = tile_n * GBN;
@@ -435,6 +438,74 @@ __global__ __launch_bounds__(256, NST == 1 ? OCC : 2) void gemm_bf16_glds_kernel
     row_block(acc01, acc11, 1);
 }
 
+template <bool AKC, bool BKC, int EPI, int NST, int OCC>
+__global__ __launch_bounds__(256, NST == 1 ? OCC : 2) void gemm_bf16_glds_kernel(dsvg_gemm_desc p, int tiles_n, int nwg_mn,
+                                                                              int k_chunk, float* part, float* rs_part,
+                                                                              int mode, int part_bf16) {
+    glds_body<AKC, BKC, EPI, NST>(p, tiles_n, nwg_mn, k_chunk, part, rs_part, mode, part_bf16, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Grouped launch of split-K weight-gradient GEMMs (both operands token-major, 4-stage variant): the dW GEMMs of a layer of
+// the 4096-row stages are 5-8 us launches of 64-256 workgroups each, back to back and independent of each other; queued
+// under dsvg_gemm_group_scope they run as ONE launch whose workgroups look their problem up in a table that travels in the
+// kernel arguments (capturable).  Each problem keeps the grid, slices and workspace it would have had on its own, so the
+// results are bit-identical to separate launches.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int GROUP_MAX = 16;
+struct WgItem {
+    const void* A; const void* B; float* part; float* rs_part;
+    int M, N, K, tiles_n, nwg_mn, k_chunk, mode, part_bf16, first_block, grid_x;
+    long long lda, ldb;
+};
+struct WgTable { WgItem it[GROUP_MAX]; int n; };
+static_assert(sizeof(WgTable) <= 3600, "the problem table must fit the kernel-argument segment");
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_wgrad_group_kernel(const WgTable t) {
+    int g = 0;
+    while (g + 1 < t.n && (int)blockIdx.x >= t.it[g + 1].first_block) ++g;
+    const WgItem& w = t.it[g];
+    dsvg_gemm_desc p;
+    p.A = w.A; p.B = w.B; p.M = w.M; p.N = w.N; p.K = w.K; p.lda = w.lda; p.ldb = w.ldb;
+    const int local = (int)blockIdx.x - w.first_block;
+    glds_body<false, false, EPI_PARTIAL, 4>(p, w.tiles_n, w.nwg_mn, w.k_chunk, w.part, w.rs_part, w.mode, w.part_bf16,
+                                            local % w.grid_x, local / w.grid_x);
+}
+
+struct GroupQueue {
+    int scope = 0;
+    std::vector<WgItem> q;
+};
+struct GroupQueues {
+    std::mutex mu;
+    std::map<hipStream_t, GroupQueue> by_stream;
+};
+GroupQueues& group_queues() { static GroupQueues g; return g; }
+
+int group_launch_locked(GroupQueue& gq, hipStream_t st) {
+    size_t at = 0;
+    while (at < gq.q.size()) {
+        WgTable t;
+        int blocks = 0, k = 0;
+        for (; k < GROUP_MAX && at < gq.q.size(); ++k, ++at) {
+            t.it[k] = gq.q[at];
+            t.it[k].first_block = blocks;
+            blocks += gq.q[at].first_block;         // (queued with its block count in this field)
+        }
+        t.n = k;
+        const size_t lds = (size_t)4 * 2 * IMG * sizeof(bf16_t);
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            once = true;
+        }
+        hipLaunchKernelGGL(gemm_bf16_wgrad_group_kernel, dim3(blocks), dim3(256), lds, st, t);
+    }
+    gq.q.clear();
+    return 0;
+}
+
 template <bool AKC, bool BKC, int EPI>
 void launch(const dsvg_gemm_desc& d, dim3 grid, int tiles_n, int nwg, int k_chunk, float* part, float* rs_part, int mode,
             int nst, hipStream_t st, int pbf = 0) {
@@ -488,6 +559,21 @@ bool dsvg_gemm_bf16_glds_try(const dsvg_gemm_desc& d, int epi, dim3 grid, int ti
         if (((uintptr_t)part & 15) || (d.N & 3)) return false;
         if (!d.a_kc && !d.b_kc) {
             const int pbf = (pbf_on && part_is_bf16 && !(d.N & 7)) ? 1 : 0;
+            if (nst == 4 && grid.z == 1) {      // an open group scope on this stream: queue instead of launching
+                GroupQueues& G = group_queues();
+                std::lock_guard<std::mutex> lk(G.mu);
+                auto it = G.by_stream.find(st);
+                if (it != G.by_stream.end() && it->second.scope) {
+                    WgItem w;
+                    w.A = d.A; w.B = d.B; w.part = part; w.rs_part = rs_part;
+                    w.M = d.M; w.N = d.N; w.K = d.K; w.tiles_n = tiles_n; w.nwg_mn = nwg; w.k_chunk = k_chunk; w.mode = mode;
+                    w.part_bf16 = pbf; w.first_block = (int)(grid.x * grid.y); w.grid_x = (int)grid.x;
+                    w.lda = d.lda; w.ldb = d.ldb;
+                    it->second.q.push_back(w);
+                    if (part_is_bf16) *part_is_bf16 = pbf;
+                    return true;
+                }
+            }
             launch<false, false, EPI_PARTIAL>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, nst, st, pbf);
             if (part_is_bf16) *part_is_bf16 = pbf;
             return true;
@@ -509,4 +595,37 @@ bool dsvg_gemm_bf16_glds_try(const dsvg_gemm_desc& d, int epi, dim3 grid, int ti
         return true;
     }
     return false;
+}
+
+// launch what is queued on `st` (no-op without a queue); called when a group scope closes and, from gemm.hip, before any
+// deferred reduction of that stream runs (a reduction must never overtake the GEMM that produces its partials)
+int dsvg_gemm_group_flush(hipStream_t st) {
+    GroupQueues& G = group_queues();
+    std::lock_guard<std::mutex> lk(G.mu);
+    auto it = G.by_stream.find(st);
+    if (it == G.by_stream.end() || it->second.q.empty()) return 0;
+    const int rc = group_launch_locked(it->second, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { dsvg_set_error("gemm group: launch failed: %s", hipGetErrorString(e)); return -2; }
+    return rc;
+}
+
+extern "C" int dsvg_gemm_group_scope(int32_t on, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    {
+        GroupQueues& G = group_queues();
+        std::lock_guard<std::mutex> lk(G.mu);
+        if (on) { G.by_stream[st].scope = 1; return 0; }
+        auto it = G.by_stream.find(st);
+        if (it == G.by_stream.end()) return 0;
+        it->second.scope = 0;
+    }
+    const int rc = dsvg_gemm_group_flush(st);
+    {
+        GroupQueues& G = group_queues();
+        std::lock_guard<std::mutex> lk(G.mu);
+        auto it = G.by_stream.find(st);
+        if (it != G.by_stream.end() && it->second.q.empty() && !it->second.scope) G.by_stream.erase(it);
+    }
+    return rc;
 }

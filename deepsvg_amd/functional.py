@@ -36,6 +36,9 @@ FFN_BWD_ORDER = os.environ.get("DSVG_FFN_BWD_ORDER", "1") != "0"
 FFN_BWD_MASKED = os.environ.get("DSVG_FFN_BWD_MASKED", "0") != "0"
 
 
+# the weight-gradient GEMMs of a layer of the 4096-row stages as one grouped launch (DSVG_GROUP_WGRAD=0: one by one)
+GROUP_WGRAD = os.environ.get("DSVG_GROUP_WGRAD", "1") != "0"
+
 _NULL_CTX = contextlib.nullcontext()
 
 
@@ -54,6 +57,10 @@ class Runtime:
     def deferring(self):
         """context manager around launches whose reductions write parameter gradients"""
         return ops.DEFER if self.defer else _NULL_CTX
+
+    def grouping(self):
+        """context manager around a run of independent weight-gradient GEMMs: one launch for all of them (ops.GROUP)"""
+        return ops.GROUP if GROUP_WGRAD else _NULL_CTX
 
     def p(self, rate):
         """effective dropout probability"""
@@ -536,17 +543,20 @@ class LayerFn(torch.autograd.Function):
                     dx2, gs[1], x, mean1, rstd1, qkv, x1, mean2, rstd2, h, n1w.detach(), n2w.detach(), key_mask, n_seq, S,
                     ctx.scale, p, s0, rt.seed, want_dx1=z is not None, dgamma2=rt.grad_out(n2w), dbeta2=rt.grad_out(n2b),
                     dgamma1=rt.grad_out(n1w), dbeta1=rt.grad_out(n1b))
-            with ops.tag("ffn"):
-                dw2, db2 = _wbgrad(rt, w2, b2, dym, h)
-                dw1, db1 = _wbgrad(rt, w1, b1, dpre, xn2)
-            dz = dwg = dbg = None
+            dz = dwg = dbg = dg = None
             if z is not None:
                 dg = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed)
-                dwg, dbg = _wbgrad(rt, wg, bg, dg, z)
                 if ctx.needs_input_grad[3]:
                     dz = ops.gemm(dg, rt.w(wg), b_kc=False)
-            dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao)
-            dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1)
+            # the layer's weight-gradient GEMMs: independent of each other, 64-256 workgroups each - one grouped launch
+            with rt.grouping():
+                with ops.tag("ffn"):
+                    dw2, db2 = _wbgrad(rt, w2, b2, dym, h)
+                    dw1, db1 = _wbgrad(rt, w1, b1, dpre, xn2)
+                if z is not None:
+                    dwg, dbg = _wbgrad(rt, wg, bg, dg, z)
+                dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao)
+                dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1)
             return (None, dx, None, dz, None, None, None, None, None, None,
                     dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, None, None, None, None, None,
                     None)

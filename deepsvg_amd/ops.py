@@ -188,6 +188,25 @@ def flush_deferred():
         _DEFER.state.pop(key, None)
 
 
+class _GroupScope:
+    """`with ops.GROUP:` - the split-K weight-gradient GEMMs launched inside on the current stream run as ONE launch when
+    the block is left (include/dsvg.h: dsvg_gemm_group_scope).  Their operands must stay alive until then - they do when
+    they are locals of the code inside the block."""
+
+    def __enter__(self):
+        self._key = _stream_key()
+        if torch.cuda.is_available():
+            _l.check(_l.load().dsvg_gemm_group_scope(1, self._key), "dsvg_gemm_group_scope")
+
+    def __exit__(self, *exc):
+        if torch.cuda.is_available():
+            _l.check(_l.load().dsvg_gemm_group_scope(0, self._key), "dsvg_gemm_group_scope")
+        return False
+
+
+GROUP = _GroupScope()
+
+
 def _rowmajor(t):
     assert t.dim() == 2 and t.stride(1) == 1, f"need a row-major 2-D tensor, got strides {t.stride()}"
     return t

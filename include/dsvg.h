@@ -91,6 +91,13 @@ int dsvg_reduce_partials(const float* partial, int64_t P, int64_t n, float* out,
  * dsvg_defer_scope returns the number of reductions currently queued on that stream. */
 int dsvg_defer_scope(int32_t on, void* stream);
 int dsvg_flush_deferred(void* stream);
+/* Grouped weight-gradient launches.  While a group scope is open on a stream (dsvg_gemm_group_scope(1, s) ... (0, s)) every
+ * split-K weight-gradient dsvg_gemm on that stream that would take the 4-stage LDS-DMA kernel (bf16, both operands
+ * token-major, at most 256 workgroups) is queued, and closing the scope runs all of them as ONE launch (problem table in
+ * the kernel arguments; each problem keeps its own grid, slices and workspace: bit-identical results).  The operands and
+ * workspaces must stay alive and unchanged until the scope is closed; the split-K reductions of queued problems never run
+ * before them (a flush of the deferred reductions, or an immediate reduction, launches the queued group first). */
+int dsvg_gemm_group_scope(int32_t on, void* stream);
 
 /* out[n] (+)= sum_m drop(A[m*lda+n])  — bias gradients (autograd of the `+ b` in every nn.Linear).
  * workspace: at least dsvg_colsum_workspace_bytes(M,N) bytes. */

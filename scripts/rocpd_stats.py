@@ -29,17 +29,19 @@ def main(db_path, out_csv=None, skip_calls=0):
         sel = [d for d in durs if lo <= d < hi]
         lines.append(f"HIST {lo:g}-{hi:g} us,{len(sel)},{sum(sel) / 1e3:.3f},,,,{100 * sum(sel) * 1e3 / tot:.1f},,,")
     # timeline of the LAST step (between the last two adamw launches): launch order, duration and the idle gap before it
-    tl = c.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id order by d.start").fetchall()
+    cols = [r[1] for r in c.execute(f"pragma table_info({kd})")]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+    tl = c.execute(f"select s.kernel_name, d.start, d.end, d.{qcol} from {kd} d join {ks} s on d.kernel_id=s.id order by d.start").fetchall()
     marks = [i for i, r in enumerate(tl) if "adamw" in r[0]]
     if len(marks) >= 2 and out_csv:
         seg = tl[marks[-2] + 1:marks[-1] + 1]
         with open(out_csv.replace(".csv", "_timeline.csv"), "w") as f:
-            f.write("idx,kernel,start_us,dur_us,gap_before_us\n")
+            f.write("idx,kernel,start_us,dur_us,gap_before_us,queue\n")
             prev_end = seg[0][1]
-            for i, (nm, st, en) in enumerate(seg):
+            for i, (nm, st, en, qu) in enumerate(seg):
                 nm = re.sub(r"\(.*", "", nm).replace(",", ";")
                 nm = re.sub(r"_ZN12_GLOBAL__N_1\d+|void |\(anonymous namespace\)::", "", nm)[:60]
-                f.write(f"{i},{nm},{(st - seg[0][1]) / 1e3:.1f},{(en - st) / 1e3:.1f},{(st - prev_end) / 1e3:.1f}\n")
+                f.write(f"{i},{nm},{(st - seg[0][1]) / 1e3:.1f},{(en - st) / 1e3:.1f},{(st - prev_end) / 1e3:.1f},{qu}\n")
                 prev_end = max(prev_end, en)
     txt = "\n".join(lines) + "\n"
     if out_csv:

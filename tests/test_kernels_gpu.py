@@ -1209,3 +1209,41 @@ def test_copy_many_and_bcast_add_bwd_tail(gpu_device):
     part = ops.bcast_add_bwd(dx, 10, 8, 0.1, 5, seed, n_seq_out=24)
     assert torch.equal(part[:10], full[:10]) and (part[10:] == 0).all() and tuple(part.shape) == (24, 256)
     _close(full, R.bcast_add_bwd(dx, 24, 8, 0.1, 5, seed), 1e-2, "bcast_add_bwd")
+
+
+def test_grouped_weight_gradient_launch_is_bit_identical(gpu_device):
+    """ops.GROUP: the split-K weight-gradient GEMMs of a group-stage layer (4096 tokens; in_proj, out_proj, linear1, linear2
+    and the 512-row conditioning projection) queued and run as one launch - with the reductions deferred (one launch for the
+    GEMMs, one for the reductions) and with immediate reductions (each reduction first flushes the queued producers) - must
+    reproduce the separate launches bit for bit, bias gradients (fused row sums) included"""
+    T = 4096
+    shapes = [(768, 256, T), (256, 256, T), (512, 256, T), (256, 512, T), (256, 256, 512)]
+    ops_in = [(_rand(k, n_out, dtype=torch.bfloat16, seed=700 + i), _rand(k, k_in, dtype=torch.bfloat16, seed=710 + i))
+              for i, (n_out, k_in, k) in enumerate(shapes)]
+
+    def run(group, defer):
+        outs = []
+        ctxs = ([ops.DEFER] if defer else []) + ([ops.GROUP] if group else [])
+        import contextlib
+        with contextlib.ExitStack() as st:
+            for c in ctxs:
+                st.enter_context(c)
+            for (dy, x), (n_out, k_in, k) in zip(ops_in, shapes):
+                flat = torch.empty(n_out * k_in + n_out, device=DEV, dtype=torch.float32)
+                dw, db = flat[:n_out * k_in].view(n_out, k_in), flat[n_out * k_in:]
+                ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw, split_k=ops.split_k_for(n_out, k_in, k), rowsum=db)
+                outs.append(flat)
+        ops.flush_deferred()
+        torch.cuda.synchronize()
+        return outs
+    want = run(False, False)
+    for group, defer in ((True, True), (True, False), (False, True)):
+        got = run(group, defer)
+        for i, (a, b) in enumerate(zip(got, want)):
+            if defer:       # the deferred reduction sums the slices in another (fixed) order
+                _close(a, b, 2e-6, f"grouped={group} deferred: problem {i}")
+            else:
+                assert torch.equal(a, b), f"grouped={group} immediate reductions: problem {i}"
+    a, b = run(True, True), run(False, True)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), f"grouped vs separate launches (both deferred): problem {i}"
