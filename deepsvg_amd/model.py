@@ -582,6 +582,10 @@ class SVGTransformer(nn.Module):
         self.last_assignment = None  # self-matching configs: (N, Gp) int32 assignment of the last training forward
         self._forced_plan = None
         self._decoder_grads_ready = None    # callback of a data-parallel trainer (TrainStep), see forward()
+        # a trainer that runs the backward pass in two parts (decoder side, then encoder side: TrainStep's split hipGraph)
+        # asks forward() to keep the bottleneck output and its gradient
+        self._keep_bottleneck = False
+        self._bottleneck_out = None
         # queue the parameter-gradient reductions of the backward pass (ops.DEFER): only a trainer that calls
         # ops.flush_deferred() before anything reads a gradient may set it (TrainStep)
         self._defer_wgrad = False
@@ -938,6 +942,12 @@ class SVGTransformer(nn.Module):
         if z is None:
             zz = self._encode(rt, commands_enc, args_enc, plan, label)
             zz, mu, logsigma = self._bottleneck(rt, zz)
+            if self._keep_bottleneck and zz.requires_grad:
+                # two-part backward (TrainStep's split hipGraph): the decoder consumes a LEAF copy of the bottleneck output;
+                # the first backward call stops there (leaf.grad), the second one continues from it into the encoder
+                leaf = zz.detach().requires_grad_()
+                self._bottleneck_out = (zz, leaf)
+                zz = leaf
             if self._decoder_grads_ready is not None and zz.requires_grad:
                 # data-parallel trainer: the gradient of the bottleneck output is final exactly when every decoder
                 # parameter gradient is (the decoder is the only consumer of zz) -> its bucket can be all-reduced

@@ -61,6 +61,14 @@ class TrainStep:
         self.inputs_resident = False    # see step(): set by callers whose input tensors are complete well before step()
         # gradient all-reduce in two buckets, the decoder's overlapped with the encoder's backward (eager launches only)
         self.overlap_allreduce = os.environ.get("DSVG_DDP_OVERLAP", "1") != "0"
+        # hipGraph + DDP: capture the step as TWO graphs - [forward, loss, decoder-side backward] and [encoder-side backward] -
+        # so that the decoder half of the gradient is all-reduced while the second graph runs, as the eager path does with
+        # its hook.  The cut is the bottleneck output (the decoder's only input): configs where the loss reaches the
+        # encoder by another path too (the VAE's KL term on mu / logsigma) keep the single graph.
+        self.split_graph = (self.ddp and self.overlap_allreduce and not getattr(model.cfg, "use_vae", False)
+                            and getattr(model.cfg, "encode_stages", 0) > 0
+                            and os.environ.get("DSVG_DDP_SPLIT_GRAPH", "1") != "0")
+        self._zb = None
         self._pending = None
         self._pool = None
         self._gradless_known, self._gradless_slots = False, []
@@ -175,6 +183,46 @@ class TrainStep:
                     v.zero_()
         return {k: v.detach() for k, v in ld.items()}
 
+    def _front_a(self, commands, args, label=None, dec=None):
+        """first part of a split step: forward, loss, backward of everything BEHIND the bottleneck output (decoder, heads);
+        afterwards the decoder's range of the flat gradient buffer is final and the bottleneck output holds its gradient"""
+        model = self.model
+        cd, ad = dec if dec is not None else (commands, args)
+        ops.advance_step_(self.step_count, self.seed)
+        for p in model.store.params:
+            p.grad = None
+        for v in self._gradless_slots:
+            v.zero_()
+        model._defer_wgrad = self.defer_reductions
+        model._keep_bottleneck = True
+        try:
+            out = model(commands, args, cd, ad, label=label, params={})
+            ld = self.loss_fn(out, label, weights=self.weights)
+            zb = model._bottleneck_out          # (graph tensor, leaf copy the decoder consumed)
+            ld["loss"].backward()               # stops at the leaf: decoder-side gradients + leaf.grad
+        finally:
+            model._keep_bottleneck = False
+            model._bottleneck_out = None
+            model._defer_wgrad = False
+            ops.flush_deferred()
+        self._zb = zb
+        return {k: v.detach() for k, v in ld.items()}
+
+    def _front_b(self):
+        """second part: the encoder-side backward from the gradient the first part left on the bottleneck output"""
+        model = self.model
+        (zb, leaf), self._zb = self._zb, None
+        try:        # (the Functions of the forward pass carry their Runtime, deferral setting included)
+            zb.backward(leaf.grad)
+        finally:
+            ops.flush_deferred()
+        if not self._gradless_known:
+            self._gradless_known = True
+            slots = [model.store._grad_view(p, 0) for p in model.store.params if p.grad is None and p.requires_grad]
+            self._gradless_slots = [v for v in slots if v is not None]
+            for v in self._gradless_slots:
+                v.zero_()
+
     def _step_back(self):
         """gradient all-reduce (data parallel), global-norm clip and AdamW on the flat buffers (train.py:99-106)"""
         model = self.model
@@ -273,7 +321,16 @@ class TrainStep:
                 for d, s_ in pairs:
                     d.copy_(s_)
         self._note_layout(plan, commands)
-        entry[0].replay()
+        if isinstance(entry[0], tuple):
+            # split step: [forward, loss, decoder-side backward] -> the decoder's bucket goes out (asynchronously, on RCCL's
+            # stream) -> [encoder-side backward] runs beside it -> the rest of the gradient, clip + AdamW
+            entry[0][0].replay()
+            lo, hi = model.decoder_param_range()
+            self._pending = (lo, dist.all_reduce(model.store.grad_buffer(0)[lo:hi], group=self.pg, async_op=True))
+            entry[0][1].replay()
+        else:
+            self._pending = None
+            entry[0].replay()
         if t_trace is not None:
             t_trace.append(time.perf_counter())
             self.host_trace.append(tuple(t_trace))
@@ -362,6 +419,7 @@ class TrainStep:
         # the warm-up steps (allocator pools, lazy buffers) must not train the model.  Data parallel: the captured part
         # (and its warm-up) is forward + backward only - no collective, see step()
         body = self._step_front if self.ddp else self._step_body
+        split = self.ddp and self.split_graph
         state = [model.store.flat, self.m, self.v, self.step_count, self.seed]
         saved = [t.clone() for t in state]
         try:
@@ -369,22 +427,36 @@ class TrainStep:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    body(sc, sa, sl, sdec)
+                    if split:
+                        self._front_a(sc, sa, sl, sdec)
+                        self._front_b()
+                    else:
+                        body(sc, sa, sl, sdec)
                 for t, s0 in zip(state, saved):
                     t.copy_(s0)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()     # graphs replay one at a time: one shared pool
-            g = torch.cuda.CUDAGraph()
             # thread-local capture mode: other threads of the process keep calling the runtime while this one captures -
             # with an initialised process group the RCCL watchdog thread polls its work events (hipEventQuery), which the
             # default global mode answers by invalidating the capture and the watchdog by aborting the process
-            with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
-                res = body(sc, sa, sl, sdec)
+            if split:
+                # two graphs from ONE autograd graph: the second capture runs the encoder-side backward of the forward pass
+                # the first one recorded (its saved tensors live in the shared pool and are replayed in the same order)
+                g = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
+                with torch.cuda.graph(g[0], pool=self._pool, capture_error_mode="thread_local"):
+                    res = self._front_a(sc, sa, sl, sdec)
+                with torch.cuda.graph(g[1], pool=self._pool, capture_error_mode="thread_local"):
+                    self._front_b()
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
+                    res = body(sc, sa, sl, sdec)
         finally:
             model._forced_plan = None
             self._in_own_step = False
+            self._zb = None
         return (g, (sc, sa, sl, sdec), splan, res)
 
     def grad_norm(self):

@@ -467,16 +467,25 @@ def test_data_parallel_step_over_rccl_one_rank(gpu_device):
         batches = [tuple(t.to(DEV) for t in make_batch(64, seed=s_)) for s_ in (5, 6, 5)]
         runs = {}
         for name, kw in (("plain", dict(use_graph=True)), ("ddp_graph", dict(use_graph=True, force_ddp=True)),
+                         ("ddp_graph_one", dict(use_graph=True, force_ddp=True)),
                          ("ddp_eager", dict(use_graph=False, force_ddp=True))):
             torch.manual_seed(7)
             model = _hip_model(cfg, sd, torch.bfloat16).train()
             ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=1e-3, **kw)
             assert ts.ddp == ("force_ddp" in kw)
+            if name == "ddp_graph_one":
+                ts.split_graph = False          # the whole forward + backward as one graph, one all-reduce behind it
             losses = [float(ts.step(c, a)["loss"]) for c, a in batches]
             torch.cuda.synchronize()
             runs[name] = (losses, model.store.flat.detach().clone(), ts.grad_norm())
-            if name == "ddp_graph":
+            if name.startswith("ddp_graph"):
                 assert len(ts._graphs) >= 1 and ts._counts is not None
+                # default: two graphs per bucket (decoder side | encoder-side backward), the decoder bucket's all-reduce
+                # between them
+                assert all(isinstance(e[0], tuple) == (name == "ddp_graph") for e in ts._graphs.values())
+        # the split step issues the same kernels on the same data in the same order: identical to the one-graph step
+        assert runs["ddp_graph"][0] == runs["ddp_graph_one"][0]
+        assert torch.equal(runs["ddp_graph"][1], runs["ddp_graph_one"][1])
         for name in ("ddp_graph", "ddp_eager"):
             for a, b in zip(runs[name][0], runs["plain"][0]):
                 assert abs(a - b) <= 2e-2 * abs(b), (name, runs[name][0], runs["plain"][0])
