@@ -101,12 +101,13 @@ def _wgrad(rt, param, dy, x, *, a_drop_p=0.0, a_drop_site=0):
     return out
 
 
-def _wbgrad(rt, weight, bias, dy, x):
+def _wbgrad(rt, weight, bias, dy, x, blocks=None):
     """(dW, db) of y = x W^T + b from dy: db[n] = sum_t dy[t, n] is the row sum of the GEMM's A operand, so it
     rides on the weight-gradient GEMM (an extra MFMA against ones in a few workgroups) whenever that GEMM is
-    split over tokens; otherwise a separate column-sum launch."""
+    split over tokens; otherwise a separate column-sum launch.  blocks: target workgroup count of this GEMM (default: a
+    launch of its own, one workgroup per CU; members of a grouped launch share the chip)."""
     n_out, k_in = weight.shape
-    split = ops.split_k_for(n_out, k_in, dy.shape[0])
+    split = ops.split_k_for(n_out, k_in, dy.shape[0], target_blocks=blocks)
     dw = rt.grad_out(weight)
     db = rt.grad_out(bias)
     with rt.deferring(), _wgrad_tag():
@@ -549,14 +550,16 @@ class LayerFn(torch.autograd.Function):
                 if ctx.needs_input_grad[3]:
                     dz = ops.gemm(dg, rt.w(wg), b_kc=False)
             # the layer's weight-gradient GEMMs: independent of each other, 64-256 workgroups each - one grouped launch
+            # (32 - 36 output tiles of 128 x 128 between them: 8 token slices each fill the chip once, together)
+            gb = (lambda w_: 8 * -(-w_.shape[0] // 128) * -(-w_.shape[1] // 128)) if GROUP_WGRAD else (lambda w_: None)
             with rt.grouping():
                 with ops.tag("ffn"):
-                    dw2, db2 = _wbgrad(rt, w2, b2, dym, h)
-                    dw1, db1 = _wbgrad(rt, w1, b1, dpre, xn2)
+                    dw2, db2 = _wbgrad(rt, w2, b2, dym, h, gb(w2))
+                    dw1, db1 = _wbgrad(rt, w1, b1, dpre, xn2, gb(w1))
                 if z is not None:
-                    dwg, dbg = _wbgrad(rt, wg, bg, dg, z)
-                dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao)
-                dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1)
+                    dwg, dbg = _wbgrad(rt, wg, bg, dg, z, gb(wg))
+                dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao, gb(wo))
+                dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1, gb(win))
             return (None, dx, None, dz, None, None, None, None, None, None,
                     dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, None, None, None, None, None,
                     None)
