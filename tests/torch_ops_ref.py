@@ -130,11 +130,11 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
     return out
 
 
-def split_k_for(M, N, K, target_blocks=256):
+def split_k_for(M, N, K, target_blocks=None):
     """same policy as deepsvg_amd.ops.split_k_for (the emulated gemm ignores the value, but the host logic that
     decides whether the bias gradient can ride on the weight-gradient GEMM depends on it)"""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    s = max(1, target_blocks // tiles)
+    s = max(1, (target_blocks or 256) // tiles)
     s = min(s, max(1, K // 128))
     if s >= 8:
         s = s // 8 * 8
