@@ -387,7 +387,7 @@ int dsvg_reduce_partials_strided(const float* part, int64_t P, int64_t stride, i
 namespace {
 struct DeferSeg {
     const float* part; float* out; long long stride;
-    int n, n_bf16, P, first_block, accumulate, pad;
+    int n, n_bf16, P, first_block, accumulate, wide;
 };
 constexpr int DEFER_MAX = 64;
 struct DeferTable { DeferSeg s[DEFER_MAX]; int n_seg; };
@@ -409,6 +409,31 @@ DeferTableOfQueues& defer_queues() { static DeferTableOfQueues d; return d; }
 
 constexpr int DF_TX = 32, DF_TY = 8;       // 32 float4 column lanes x 8 groups over the partial index per block
 
+// "wide" segments (split-K slices of a weight gradient: >= 2048 columns, <= 64 slices): a thread owns 8 consecutive columns
+// and walks the slices itself, 8 loads of 16 bytes in flight - a wave reads 1 KiB runs of one slice per instruction.  The
+// other segments (LayerNorm / bias partials: few columns, up to thousands of partial rows) keep the 32 x 8 layout with a
+// tree over 8 groups of partial rows.  Both orders are fixed (bit-reproducible).
+constexpr int DF_WIDE_COLS = 256 * 8;
+
+__device__ __forceinline__ void defer_ld8(const float* part, long long stride, int q, int j, int n_bf16, float (&v)[8]) {
+    const float* row = part + q * stride;
+    if (j + 8 <= n_bf16) {
+        const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(row) + j);
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+    } else if (j >= n_bf16) {
+        const float4 a = *reinterpret_cast<const float4*>(row + j), b = *reinterpret_cast<const float4*>(row + j + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {        // the boundary group: 4 bf16 columns, then 4 fp32 columns
+        const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(row) + j);
+        const float4 b = *reinterpret_cast<const float4*>(row + j + 4);
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_deferred_kernel(const DeferTable t) {
     __shared__ float4 red[DF_TY][DF_TX];
     int s = 0;
@@ -416,6 +441,56 @@ __global__ __launch_bounds__(256) void reduce_deferred_kernel(const DeferTable t
     const float* __restrict__ part = t.s[s].part;
     const long long stride = t.s[s].stride;
     const int n = t.s[s].n, n_bf16 = t.s[s].n_bf16, P = t.s[s].P;
+    if (t.s[s].wide) {          // (uniform over the workgroup)
+        const int j = (((int)blockIdx.x - t.s[s].first_block) * 256 + (int)threadIdx.x) * 8;
+        if (j >= n) return;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        if (j + 8 <= n) {
+            int q = 0;
+            for (; q + 8 <= P; q += 8) {
+                float v[8][8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) defer_ld8(part, stride, q + u, j, n_bf16, v[u]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += v[u][e];
+            }
+            for (; q < P; ++q) {
+                float v[8];
+                defer_ld8(part, stride, q, j, n_bf16, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            }
+            float4* o = reinterpret_cast<float4*>(t.s[s].out + j);
+            float4 r0 = make_float4(acc[0], acc[1], acc[2], acc[3]), r1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            if (t.s[s].accumulate) {
+                const float4 a = o[0], b = o[1];
+                r0.x += a.x; r0.y += a.y; r0.z += a.z; r0.w += a.w; r1.x += b.x; r1.y += b.y; r1.z += b.z; r1.w += b.w;
+            }
+            o[0] = r0;
+            o[1] = r1;
+        } else {                // the last 4 columns of a segment whose width is 4 mod 8 (fp32 or bf16 alike)
+            const bool bf = j < n_bf16;
+            for (int q = 0; q < P; ++q) {
+                if (bf) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(part + q * stride) + j);
+                    acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xffff0000u);
+                    acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xffff0000u);
+                } else {
+                    const float4 v = *reinterpret_cast<const float4*>(part + q * stride + j);
+                    acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+                }
+            }
+            float4* o = reinterpret_cast<float4*>(t.s[s].out + j);
+            float4 r0 = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if (t.s[s].accumulate) { const float4 a = o[0]; r0.x += a.x; r0.y += a.y; r0.z += a.z; r0.w += a.w; }
+            o[0] = r0;
+        }
+        return;
+    }
     const int tx = threadIdx.x % DF_TX, ty = threadIdx.x / DF_TX;
     const int j = (((int)blockIdx.x - t.s[s].first_block) * DF_TX + tx) * 4;
     float4 acc[4];
@@ -467,7 +542,11 @@ int defer_flush_locked(DeferQueue& d, hipStream_t st) {
         for (; k < DEFER_MAX && at < d.q.size(); ++k, ++at) {
             t.s[k] = d.q[at];
             t.s[k].first_block = blocks;
-            blocks += dsvg_cdiv(t.s[k].n, DF_TX * 4);
+            // wide layout: 16-byte accesses of 8 columns (slices and destination 16-byte aligned, the bf16 / fp32 boundary on a
+            // group boundary); few slices, many columns
+            t.s[k].wide = (t.s[k].n >= DF_WIDE_COLS && t.s[k].P <= 64 && !(t.s[k].stride & 3) &&
+                           !((uintptr_t)t.s[k].part & 15) && !((uintptr_t)t.s[k].out & 15) && !(t.s[k].n_bf16 & 7)) ? 1 : 0;
+            blocks += t.s[k].wide ? dsvg_cdiv(t.s[k].n, DF_WIDE_COLS) : dsvg_cdiv(t.s[k].n, DF_TX * 4);
         }
         t.n_seg = k;
         hipLaunchKernelGGL(reduce_deferred_kernel, dim3(blocks), dim3(256), 0, st, t);
