@@ -406,3 +406,56 @@ extern "C" int dsvg_scatter_rows(int32_t dtype, const void* src, const int32_t* 
     DSVG_LAUNCH_CHECK("scatter_rows");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// loss terms and their weighted total from the (sum, count) pairs of up to 4 cross-entropies, and the backward of that:
+//     out[1 + i] = sum_i / count_i,   out[0] = sum_i w_i * out[1 + i]              (deepsvg/model/loss.py:43-57)
+//     dsc[i] = { dout0 * w_i + dterm_i, 0 }   (the masked-CE backward divides by the count itself)
+// One launch each instead of a dozen scalar elementwise launches of 5 us.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LossCombineArgs {
+    const float* sc[4];
+    const float* dterm[4];
+    float w[4];
+    int n;
+};
+__global__ void loss_combine_fwd_kernel(const LossCombineArgs a, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float total = 0.f;
+    for (int i = 0; i < a.n; ++i) {
+        const float l = a.sc[i][0] / a.sc[i][1];
+        out[1 + i] = l;
+        total += a.w[i] * l;
+    }
+    out[0] = total;
+}
+__global__ void loss_combine_bwd_kernel(const LossCombineArgs a, const float* __restrict__ dtotal, float* __restrict__ dsc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float g = dtotal ? *dtotal : 0.f;
+    for (int i = 0; i < a.n; ++i) {
+        dsc[2 * i] = g * a.w[i] + (a.dterm[i] ? *a.dterm[i] : 0.f);
+        dsc[2 * i + 1] = 0.f;
+    }
+}
+
+extern "C" int dsvg_loss_combine_fwd(const float* const* sum_count, const float* weights, int32_t n, float* out, void* stream) {
+    DSVG_CHECK_ARG(sum_count && weights && out && n >= 1 && n <= 4, "loss_combine_fwd: bad args");
+    LossCombineArgs a;
+    a.n = n;
+    for (int i = 0; i < 4; ++i) { a.sc[i] = i < n ? sum_count[i] : nullptr; a.dterm[i] = nullptr; a.w[i] = i < n ? weights[i] : 0.f; }
+    for (int i = 0; i < n; ++i) DSVG_CHECK_ARG(a.sc[i], "loss_combine_fwd: null (sum, count) pair %d", i);
+    hipLaunchKernelGGL(loss_combine_fwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, out);
+    DSVG_LAUNCH_CHECK("loss_combine_fwd");
+    return 0;
+}
+
+extern "C" int dsvg_loss_combine_bwd(const float* dtotal, const float* const* dterms, const float* weights, int32_t n,
+                                     float* dsum_count, void* stream) {
+    DSVG_CHECK_ARG(weights && dsum_count && n >= 1 && n <= 4, "loss_combine_bwd: bad args");
+    LossCombineArgs a;
+    a.n = n;
+    for (int i = 0; i < 4; ++i) { a.sc[i] = nullptr; a.dterm[i] = (dterms && i < n) ? dterms[i] : nullptr; a.w[i] = i < n ? weights[i] : 0.f; }
+    hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, dtotal, dsum_count);
+    DSVG_LAUNCH_CHECK("loss_combine_bwd");
+    return 0;
+}

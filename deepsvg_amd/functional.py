@@ -683,7 +683,8 @@ class LayerFn(torch.autograd.Function):
 
 # --------------------------------------------------------------------------------------------------
 class MaskedCEFn(torch.autograd.Function):
-    """mean over rows with w != 0 of CE(logits[row], target[row]); logits2d: [n_tok, group*C] row-major view."""
+    """(sum, count) of CE(logits[row], target[row]) over the rows with w != 0 (fp32 [2]; the mean and the weighted total are
+    taken by LossCombineFn); logits2d: [n_tok, group*C] row-major view."""
 
     @staticmethod
     def forward(ctx, logits2d, target, w, C_, group, count_fn):
@@ -694,20 +695,39 @@ class MaskedCEFn(torch.autograd.Function):
             sc = torch.stack([sc[0], count_fn(sc[1].clone()).to(sc.dtype).reshape(())])
         ctx.C_, ctx.group = C_, group
         ctx.save_for_backward(logits2d, target, w, lse, sc)
-        loss = sc[0] / sc[1]
-        return loss, sc
+        return sc
 
     @staticmethod
-    def backward(ctx, dloss, _dsc):
+    def backward(ctx, dsc):
+        """dsc[0] = dL / d(mean CE) (LossCombineFn): the kernel divides by the count itself"""
         logits2d, target, w, lse, sc = ctx.saved_tensors
-        g = dloss.reshape(1).to(torch.float32).contiguous()
+        g = dsc[0:1].to(torch.float32).contiguous()
         mult = 4 if logits2d.dtype == torch.float32 else 8
         dlogits = ops.masked_ce_bwd(logits2d, target, w, lse, sc, g, 1.0, ctx.C_, ctx.group, pad_to=mult)
         return dlogits, None, None, None, None, None
 
 
+class LossCombineFn(torch.autograd.Function):
+    """(total, term_0, term_1, ...) with term_i = sum_i / count_i and total = sum_i weights[i] * term_i from the (sum, count)
+    pairs of the cross-entropies (deepsvg/model/loss.py:43-57): one launch forward, one backward, instead of a dozen scalar
+    elementwise launches each way."""
+
+    @staticmethod
+    def forward(ctx, weights, *scs):
+        out = ops.loss_combine_fwd([sc.contiguous() for sc in scs], weights)
+        ctx.weights, ctx.device = tuple(float(w) for w in weights), out.device
+        ctx.set_materialize_grads(False)
+        return tuple(out.unbind(0))
+
+    @staticmethod
+    def backward(ctx, dtotal, *dterms):
+        f32 = lambda t: None if t is None else t.reshape(1).to(torch.float32).contiguous()
+        dsc = ops.loss_combine_bwd(f32(dtotal), [f32(t) for t in dterms], ctx.weights, ctx.device)
+        return (None,) + tuple(dsc.unbind(0))
+
+
 class ArgsHeadLossFn(torch.autograd.Function):
-    """loss_args = masked CE over the argument logits, with the argument head (args_fcn, deepsvg/model/model.py:228-246)
+    """(sum, count) of the masked CE over the argument logits (-> loss_args by LossCombineFn), with the argument head (args_fcn, deepsvg/model/model.py:228-246)
     folded in: forward AND backward run on the tokens that carry argument loss only.  Every other token's logits do
     not enter the loss and their dlogits are exact zeros (loss.py:51-54), so logits, dX, dW and db come from a compact
     [n_live, 2827] problem instead of the dense [T, 2827] one (about 30 % of the decoder tokens on the synthetic
@@ -737,13 +757,13 @@ class ArgsHeadLossFn(torch.autograd.Function):
             sc = torch.stack([sc[0], count_fn(sc[1].clone()).to(sc.dtype).reshape(())])
         ctx.rt, ctx.C_, ctx.group, ctx.rows_full, ctx.rows_used = rt, C_, group, x.shape[0], (r0, r1)
         ctx.save_for_backward(xc, weight, bias, logits_c, target, w, lse, sc, idx)
-        return sc[0] / sc[1], sc
+        return sc
 
     @staticmethod
-    def backward(ctx, dloss, _dsc):
+    def backward(ctx, dsc):
         rt = ctx.rt
         xc, weight, bias, logits_c, target, w, lse, sc, idx = ctx.saved_tensors
-        g = dloss.reshape(1).to(torch.float32).contiguous()
+        g = dsc[0:1].to(torch.float32).contiguous()
         mult = 4 if logits_c.dtype == torch.float32 else 8
         dl = ops.masked_ce_bwd(logits_c, target, w, lse, sc, g, 1.0, ctx.C_, ctx.group, pad_to=mult, tok_idx=idx,
                                logits_compact=True)

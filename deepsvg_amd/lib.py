@@ -85,6 +85,8 @@ SIGNATURES = {
     "dsvg_cast_weights": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i64, vp]),
     "dsvg_advance_step": (c_i32, [vp, vp, vp]),
     "dsvg_copy_many": (c_i32, [vp, vp, vp, c_i32, vp]),
+    "dsvg_loss_combine_fwd": (c_i32, [vp, vp, c_i32, vp, vp]),
+    "dsvg_loss_combine_bwd": (c_i32, [vp, vp, vp, c_i32, vp, vp]),
     "dsvg_gate_mul": (c_i32, [c_i32, vp, vp, vp, c_i64, c_f32, vp]),
     "dsvg_add": (c_i32, [c_i32, vp, vp, vp, c_i64, vp]),
     "dsvg_drop_apply": (c_i32, [c_i32, vp, vp, c_i64, c_f32, c_u32, vp, vp]),

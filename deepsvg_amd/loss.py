@@ -73,15 +73,18 @@ class SVGLoss(nn.Module):
             local = torch.stack([torch.full((), float(N * G), device=device),
                                  (cmd_w != 0).sum().float(), (arg_w != 0).sum().float()])
             cnt = red(local)
+        scs, ws, names = [], [], []
         if cfg.decode_stages == 2:
             vl = output["visibility_logits"].reshape(N * G, 2)
-            loss_visibility, sc_v = Fn.MaskedCEFn.apply(vl, vis_tgt, None, 2, 1, (lambda c: cnt[0]) if red else None)
-            loss = loss + weights["loss_visibility_weight"] * loss_visibility
-            res["loss_visibility"] = loss_visibility
+            scs.append(Fn.MaskedCEFn.apply(vl, vis_tgt, None, 2, 1, (lambda c: cnt[0]) if red else None))
+            ws.append(weights["loss_visibility_weight"])
+            names.append("loss_visibility")
 
         cl = command_logits.reshape(N * G * S, cfg.n_commands)
-        loss_cmd, sc_c = Fn.MaskedCEFn.apply(cl, cmd_tgt.view(-1), cmd_w.view(-1), cfg.n_commands, 1,
-                                             (lambda c: cnt[1]) if red else None)
+        scs.append(Fn.MaskedCEFn.apply(cl, cmd_tgt.view(-1), cmd_w.view(-1), cfg.n_commands, 1,
+                                       (lambda c: cnt[1]) if red else None))
+        ws.append(weights["loss_cmd_weight"])
+        names.append("loss_cmd")
         if head is not None:
             # fused argument head + loss on the loss-carrying tokens (forward and backward); the dense args_logits of
             # the result dict stays unmaterialised
@@ -91,13 +94,17 @@ class SVGLoss(nn.Module):
                 a_t, a_w, slots = tr[0], tr[1], (lo, hi)
             else:
                 a_t, a_w, slots = arg_tgt.view(-1), arg_w.view(-1), (0, n_args)
-            loss_args, sc_a = Fn.ArgsHeadLossFn.apply(head["rt"], head["x"], head["weight"], head["bias"], a_t, a_w,
-                                                      self.args_dim, slots[1] - slots[0],
-                                                      (lambda c: cnt[2]) if red else None, head["live"], slots[0])
+            sc_a = Fn.ArgsHeadLossFn.apply(head["rt"], head["x"], head["weight"], head["bias"], a_t, a_w, self.args_dim,
+                                           slots[1] - slots[0], (lambda c: cnt[2]) if red else None, head["live"], slots[0])
         else:
             al = output["args_logits"].reshape(N * G * S, n_args * self.args_dim)
-            loss_args, sc_a = Fn.MaskedCEFn.apply(al, arg_tgt.view(-1), arg_w.view(-1), self.args_dim, n_args,
-                                                  (lambda c: cnt[2]) if red else None)
-        loss = loss + weights["loss_cmd_weight"] * loss_cmd + weights["loss_args_weight"] * loss_args
-        res.update({"loss": loss, "loss_cmd": loss_cmd, "loss_args": loss_args})
+            sc_a = Fn.MaskedCEFn.apply(al, arg_tgt.view(-1), arg_w.view(-1), self.args_dim, n_args,
+                                       (lambda c: cnt[2]) if red else None)
+        scs.append(sc_a)
+        ws.append(weights["loss_args_weight"])
+        names.append("loss_args")
+        # the three means and their weighted sum (loss.py:43-57) in one launch (one more in the backward pass)
+        total, *terms = Fn.LossCombineFn.apply(tuple(ws), *scs)
+        res.update(dict(zip(names, terms)))
+        res["loss"] = total if not cfg.use_vae else loss + total
         return res

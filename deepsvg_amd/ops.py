@@ -744,6 +744,31 @@ def masked_ce_bwd(logits2d, target, w, lse, sum_count, gscale, coef, C_, group=1
     return buf[:, :width]
 
 
+def loss_combine_fwd(scs, weights):
+    """scs: fp32 [2] (sum, count) device tensors of n <= 4 cross-entropies -> fp32 [1 + n]: weighted total, then the terms"""
+    _chk(*scs)
+    n = len(scs)
+    assert 1 <= n <= 4 and len(weights) == n and all(t.dtype == torch.float32 and t.numel() == 2 and t.is_contiguous() for t in scs)
+    out = torch.empty(1 + n, dtype=torch.float32, device=scs[0].device)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in scs])
+    w = (C.c_float * n)(*[float(x) for x in weights])
+    _l.check(_l.load().dsvg_loss_combine_fwd(ptrs, w, n, out.data_ptr(), _stream()), "dsvg_loss_combine_fwd")
+    return out
+
+
+def loss_combine_bwd(dtotal, dterms, weights, device):
+    """-> fp32 [n, 2]: row i = (dtotal * weights[i] + dterms[i], 0); dtotal / dterms[i]: fp32 scalar device tensors or None"""
+    n = len(weights)
+    _chk(dtotal, *[t for t in dterms if t is not None])
+    for t in [dtotal] + list(dterms):
+        assert t is None or (t.dtype == torch.float32 and t.numel() == 1)
+    dsc = torch.empty((n, 2), dtype=torch.float32, device=device)
+    ptrs = (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in dterms])
+    w = (C.c_float * n)(*[float(x) for x in weights])
+    _l.check(_l.load().dsvg_loss_combine_bwd(_p(dtotal), ptrs, w, n, dsc.data_ptr(), _stream()), "dsvg_loss_combine_bwd")
+    return dsc
+
+
 def live_rows(w, group):
     """w float32 [n_tok * group] -> (live int32 [n_tok]: ascending tokens with any non-zero weight, -1 padded;
     count int32 [1])"""

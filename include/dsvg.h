@@ -259,6 +259,13 @@ int dsvg_masked_ce_bwd(int32_t dtype, const void* logits, int64_t ld, int32_t gr
                        const float* w, const float* lse, const float* sum_count, const float* gscale,
                        float coef, void* dlogits, int64_t ld_d, int64_t rows, int32_t C,
                        const int32_t* tok_idx, int32_t logits_compact, void* stream);
+/* The loss terms and their weighted total from the (sum, count) pairs of n <= 4 cross-entropies in one launch (host arrays
+ * of device pointers / host weights): out[1 + i] = sum_i / count_i, out[0] = sum_i weights[i] * out[1 + i]
+ * (deepsvg/model/loss.py:43-57), and its backward: dsum_count[2 i] = *dtotal * weights[i] + *dterms[i] (NULL pointers
+ * count as zero), dsum_count[2 i + 1] = 0 - the value dsvg_masked_ce_bwd takes as `gscale`. */
+int dsvg_loss_combine_fwd(const float* const* sum_count, const float* weights, int32_t n, float* out, void* stream);
+int dsvg_loss_combine_bwd(const float* dtotal, const float* const* dterms, const float* weights, int32_t n,
+                          float* dsum_count, void* stream);
 /* tok_idx (optional): compact token list, output token i = source token tok_idx[i] (negative -> zero row / zero
  * weight), `rows` = listed tokens * group; targets and weights are always indexed by the source token.
  * fwd with tok_idx: `logits` and `lse` are compact (row i = listed token i): the loss of the argument head is

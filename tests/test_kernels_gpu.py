@@ -1247,3 +1247,15 @@ def test_grouped_weight_gradient_launch_is_bit_identical(gpu_device):
     a, b = run(True, True), run(False, True)
     for i, (x, y) in enumerate(zip(a, b)):
         assert torch.equal(x, y), f"grouped vs separate launches (both deferred): problem {i}"
+
+
+def test_loss_combine(gpu_device):
+    scs = [torch.tensor([3.5, 7.0], device=DEV), torch.tensor([10.0, 4.0], device=DEV), torch.tensor([1.0, 8.0], device=DEV)]
+    w = (1.0, 2.0, 0.5)
+    out = ops.loss_combine_fwd(scs, w)
+    want = R.loss_combine_fwd(scs, w)
+    assert torch.allclose(out, want, rtol=1e-6, atol=0) and out.numel() == 4
+    dt, d1 = torch.tensor([0.25], device=DEV), torch.tensor([3.0], device=DEV)
+    got = ops.loss_combine_bwd(dt, [None, d1, None], w, torch.device(DEV))
+    assert torch.allclose(got, R.loss_combine_bwd(dt, [None, d1, None], w, torch.device(DEV))) and tuple(got.shape) == (3, 2)
+    assert torch.equal(ops.loss_combine_bwd(None, [None] * 3, w, torch.device(DEV)), torch.zeros(3, 2, device=DEV))

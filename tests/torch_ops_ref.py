@@ -515,6 +515,24 @@ def masked_ce_fwd(logits2d, target, w, C_, group=1, tok_idx=None):
     return lse, sc
 
 
+def loss_combine_fwd(scs, weights):
+    terms = [sc[0] / sc[1] for sc in scs]
+    total = sum(float(w) * t for w, t in zip(weights, terms))
+    return torch.stack([total] + terms).to(torch.float32)
+
+
+def loss_combine_bwd(dtotal, dterms, weights, device):
+    rows = []
+    for w, dt in zip(weights, dterms):
+        g = torch.zeros((), dtype=torch.float32, device=device)
+        if dtotal is not None:
+            g = g + dtotal.reshape(()).to(torch.float32) * float(w)
+        if dt is not None:
+            g = g + dt.reshape(()).to(torch.float32)
+        rows.append(torch.stack([g, torch.zeros_like(g)]))
+    return torch.stack(rows)
+
+
 def live_rows(w, group):
     live_tok = (w.reshape(-1, group) != 0).any(1)
     idx = live_tok.nonzero().squeeze(1).to(torch.int32)
