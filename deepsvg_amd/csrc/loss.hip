@@ -375,8 +375,8 @@ extern "C" int dsvg_live_rows(const float* w, int64_t n_tok, int32_t group, int3
     return 0;
 }
 
-// dst[idx[i], :] = src[i, :] for idx[i] >= 0 (rows of dst not named by idx keep their content)
-template <typename T>
+// dst[idx[i], :] (+)= src[i, :] for idx[i] >= 0 (rows of dst not named by idx keep their content; idx has no duplicates)
+template <typename T, bool ACC>
 __global__ void scatter_rows_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx, T* __restrict__ dst,
                                     long long n_rows, int width) {
     typedef typename Elem<T>::raw4 raw4;
@@ -387,22 +387,31 @@ __global__ void scatter_rows_kernel(const T* __restrict__ src, const int32_t* __
         const long long row = i / cpr;
         const int c = (int)(i - row * cpr);
         const int t = idx[row];
-        if (t >= 0) reinterpret_cast<raw4*>(dst + (long long)t * width)[c] = reinterpret_cast<const raw4*>(src + row * width)[c];
+        if (t < 0) continue;
+        if (ACC) {
+            float a[4], b[4];
+            Elem<T>::ld4(src + row * width + 4 * c, a);
+            Elem<T>::ld4(dst + (long long)t * width + 4 * c, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += b[e];
+            Elem<T>::st4(dst + (long long)t * width + 4 * c, a);
+        } else {
+            reinterpret_cast<raw4*>(dst + (long long)t * width)[c] = reinterpret_cast<const raw4*>(src + row * width)[c];
+        }
     }
 }
 extern "C" int dsvg_scatter_rows(int32_t dtype, const void* src, const int32_t* idx, void* dst, int64_t n_rows,
-                                 int32_t width, void* stream) {
+                                 int32_t width, int32_t accumulate, void* stream) {
     DSVG_CHECK_ARG(src && idx && dst && n_rows > 0 && width > 0 && (width % 4) == 0, "scatter_rows: bad args");
     const long long total = n_rows * (long long)(width / 4);
     const int nb = (int)min((long long)dsvg_cdiv(total, 256), 8192LL);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DSVG_F32)
-        hipLaunchKernelGGL(scatter_rows_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)src, idx, (float*)dst,
-                           (long long)n_rows, width);
-    else if (dtype == DSVG_BF16)
-        hipLaunchKernelGGL(scatter_rows_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)src, idx,
-                           (bf16_t*)dst, (long long)n_rows, width);
+#define DSVG_SR(T, A) hipLaunchKernelGGL((scatter_rows_kernel<T, A>), dim3(nb), dim3(256), 0, st, (const T*)src, idx, (T*)dst, \
+                                         (long long)n_rows, width)
+    if (dtype == DSVG_F32) { if (accumulate) DSVG_SR(float, true); else DSVG_SR(float, false); }
+    else if (dtype == DSVG_BF16) { if (accumulate) DSVG_SR(bf16_t, true); else DSVG_SR(bf16_t, false); }
     else { dsvg_set_error("scatter_rows: bad dtype"); return -1; }
+#undef DSVG_SR
     DSVG_LAUNCH_CHECK("scatter_rows");
     return 0;
 }

@@ -416,6 +416,39 @@ class PackedEmbedFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------------
+class GlobalCondFn(torch.autograd.Function):
+    """The conditioning rows of a whole decoder stack at once: g_l = linear_global_l(z) for every layer l
+    (layers/improved_transformer.py:131-132; z does not change between the layers).  Hoisted out of the layers so that the
+    gradient of z is accumulated by the input-gradient GEMMs themselves (no separate sums of per-layer contributions) and
+    the layers' weight-gradient GEMMs run as one grouped launch."""
+
+    @staticmethod
+    def forward(ctx, rt, z, *wb):
+        pairs = list(zip(wb[0::2], wb[1::2]))
+        ctx.rt, ctx.n = rt, len(pairs)
+        ctx.save_for_backward(z, *wb)
+        return tuple(ops.gemm(z, rt.w(w), bias=b.detach()) for w, b in pairs)
+
+    @staticmethod
+    def backward(ctx, *dgs):
+        rt = ctx.rt
+        z, *wb = ctx.saved_tensors
+        pairs = list(zip(wb[0::2], wb[1::2]))
+        dgs = [dg.contiguous() for dg in dgs]
+        grads = []
+        small = z.shape[0] < FFN_MIN_ROWS
+        with (rt.grouping() if small else _NULL_CTX):
+            for (w, b), dg in zip(pairs, dgs):
+                blocks = (8 * -(-w.shape[0] // 128) * -(-w.shape[1] // 128)) if (small and GROUP_WGRAD) else None
+                grads += list(_wbgrad(rt, w, b, dg, z, blocks))
+        dz = None
+        if ctx.needs_input_grad[1]:
+            dz = torch.empty_like(z)
+            for i, ((w, _b), dg) in enumerate(zip(pairs, dgs)):
+                ops.gemm(dg, rt.w(w), b_kc=False, out=dz, accumulate=i > 0)
+        return (None, dz, *grads)
+
+
 class LayerFn(torch.autograd.Function):
     """One pre-LN transformer block.  With z: the 'global' decoder block (x += linear_global(z) broadcast over
     the sequence); with l: the label-conditioned variant (x += linear_global2(l)).
@@ -442,7 +475,8 @@ class LayerFn(torch.autograd.Function):
         if gs is not None:
             # the short-sequence ("group") stages: the whole block in ONE launch (csrc/group_stage.hip); with a backward pass
             # ahead it stores exactly what the unfused launches below would have saved
-            g = ops.gemm(z, rt.w(wg), bias=bg.detach()) if z is not None else None
+            # (wg None: `z` already is the projected conditioning row linear_global(z), see GlobalCondFn)
+            g = (z if wg is None else ops.gemm(z, rt.w(wg), bias=bg.detach())) if z is not None else None
             with ops.tag("gs"):
                 res = ops.gs_layer_fwd(x, gs[0], bin_.detach(), bo.detach(), b1.detach(), b2.detach(), n1w.detach(),
                                        n1b.detach(), n2w.detach(), n2b.detach(), key_mask, n_seq, S, scale, 1e-5, p, site0,
@@ -468,7 +502,7 @@ class LayerFn(torch.autograd.Function):
             # backward pass ahead it also stores LN(x), q|k|v, the head outputs and the row statistics
             g = None
             if z is not None and seq_off is None and x.shape[0] == n_seq * S:
-                g = ops.gemm(z, rt.w(wg), bias=bg.detach())
+                g = z if wg is None else ops.gemm(z, rt.w(wg), bias=bg.detach())
                 z_fused = True
             with ops.tag("attn"):
                 res = ops.attn_block_fwd(x, att, bin_.detach(), bo.detach(), n1w.detach(), n1b.detach(), key_mask, n_seq,
@@ -489,7 +523,7 @@ class LayerFn(torch.autograd.Function):
             x1 = ops.gemm(ao, rt.w(wo), bias=bo.detach(), res=x, drop_p=p, drop_site=site0 + 1, seed=rt.seed)
         ctx.tiles, ctx.causal = tiles, causal
         if z is not None and not z_fused:
-            g = ops.gemm(z, rt.w(wg), bias=bg.detach())
+            g = z if wg is None else ops.gemm(z, rt.w(wg), bias=bg.detach())
             ops.bcast_add_fwd_(x1, g, n_seq, S, p, site0 + 2, rt.seed)
         if l is not None:
             g2 = ops.gemm(l, rt.w(wg2), bias=bg2.detach())
@@ -547,7 +581,9 @@ class LayerFn(torch.autograd.Function):
             dz = dwg = dbg = dg = None
             if z is not None:
                 dg = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed)
-                if ctx.needs_input_grad[3]:
+                if wg is None:
+                    dz = dg                 # `z` was the projected row itself: its gradient goes to GlobalCondFn
+                elif ctx.needs_input_grad[3]:
                     dz = ops.gemm(dg, rt.w(wg), b_kc=False)
             # the layer's weight-gradient GEMMs: independent of each other, 64-256 workgroups each - one grouped launch
             # (32 - 36 output tiles of 128 x 128 between them: 8 token slices each fill the chip once, together)
@@ -556,7 +592,7 @@ class LayerFn(torch.autograd.Function):
                 with ops.tag("ffn"):
                     dw2, db2 = _wbgrad(rt, w2, b2, dym, h, gb(w2))
                     dw1, db1 = _wbgrad(rt, w1, b1, dpre, xn2, gb(w1))
-                if z is not None:
+                if z is not None and wg is not None:
                     dwg, dbg = _wbgrad(rt, wg, bg, dg, z, gb(wg))
                 dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao, gb(wo))
                 dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1, gb(win))
@@ -651,9 +687,12 @@ class LayerFn(torch.autograd.Function):
         if z is not None:
             # (sequences past the live prefix: zero gradient rows, written by the same launch)
             dg = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed, n_seq_out=n_seq_full)
-            dwg, dbg = _wbgrad(rt, wg, bg, dg, z)
-            if ctx.needs_input_grad[3]:
-                dz = ops.gemm(dg, rt.w(wg), b_kc=False)
+            if wg is None:
+                dz = dg                     # `z` was the projected row itself: its gradient goes to GlobalCondFn
+            else:
+                dwg, dbg = _wbgrad(rt, wg, bg, dg, z)
+                if ctx.needs_input_grad[3]:
+                    dz = ops.gemm(dg, rt.w(wg), b_kc=False)
         # ---- attention: x1 = x + drop1(ao Wo^T + bo) ----
         if dx1m is None:
             dx1m = ops.drop_apply(dx1, p, s0 + 1, rt.seed)
@@ -735,9 +774,14 @@ class ArgsHeadLossFn(torch.autograd.Function):
     `live` = (token list int32 padded with -1, number of rows to process >= number of listed tokens)."""
 
     @staticmethod
-    def forward(ctx, rt, x, weight, bias, target, w, C_, group, count_fn, live, slot_lo=0):
+    def forward(ctx, rt, x, weight, bias, target, w, C_, group, count_fn, live, slot_lo=0, cmd_logits=None,
+                cmd_weight=None, cmd_bias=None, cmd_target=None, cmd_w=None, cmd_count_fn=None):
         """target / w: [n_tok * group] for the `group` argument slots slot_lo .. slot_lo + group - 1 (the slots that
-        carry loss in this batch: the head's other output rows get exact zero gradients)"""
+        carry loss in this batch: the head's other output rows get exact zero gradients).
+        cmd_logits [n_tok, n_cmd] (detached: the model computed them from the same x) with command_fcn's weight / bias, the
+        command targets / weights and their count_fn: the command head's cross-entropy joins this node - both heads read
+        the same x, so ONE backward node writes dX once (the command head's product, the argument head's rows added into
+        it) instead of two nodes + a zero-filled scatter target + autograd's sum.  -> sc_args, or (sc_cmd, sc_args)"""
         R = min(int(live[1]), x.shape[0])
         idx = live[0][:R]
         xc = ops.gather_groups(x, idx, R, 1)                       # rows of list padding read token 0 (weight 0)
@@ -756,13 +800,37 @@ class ArgsHeadLossFn(torch.autograd.Function):
         if count_fn is not None:
             sc = torch.stack([sc[0], count_fn(sc[1].clone()).to(sc.dtype).reshape(())])
         ctx.rt, ctx.C_, ctx.group, ctx.rows_full, ctx.rows_used = rt, C_, group, x.shape[0], (r0, r1)
-        ctx.save_for_backward(xc, weight, bias, logits_c, target, w, lse, sc, idx)
-        return sc
+        ctx.has_cmd = cmd_logits is not None
+        if cmd_logits is None:
+            ctx.save_for_backward(xc, weight, bias, logits_c, target, w, lse, sc, idx)
+            return sc
+        cl, cw, cb, ctgt, cwt, ccount = cmd_logits, cmd_weight, cmd_bias, cmd_target, cmd_w, cmd_count_fn
+        ctx.n_cmd = cl.shape[1]
+        clse, csc = ops.masked_ce_fwd(cl, ctgt, cwt, ctx.n_cmd, 1)
+        if ccount is not None:
+            csc = torch.stack([csc[0], ccount(csc[1].clone()).to(csc.dtype).reshape(())])
+        ctx.save_for_backward(xc, weight, bias, logits_c, target, w, lse, sc, idx, x, cl, cw, cb, ctgt, cwt, clse, csc)
+        ctx.set_materialize_grads(False)
+        return csc, sc
 
     @staticmethod
-    def backward(ctx, dsc):
+    def backward(ctx, *dscs):
         rt = ctx.rt
-        xc, weight, bias, logits_c, target, w, lse, sc, idx = ctx.saved_tensors
+        dx = dwc = dbc = None
+        if ctx.has_cmd:
+            (xc, weight, bias, logits_c, target, w, lse, sc, idx, x, cl, cw, cb, ctgt, cwt, clse, csc) = ctx.saved_tensors
+            dcsc, dsc = dscs
+            zero1 = lambda: torch.zeros(1, dtype=torch.float32, device=xc.device)
+            gc = dcsc[0:1].to(torch.float32).contiguous() if dcsc is not None else zero1()
+            if dsc is None:
+                dsc = torch.zeros(2, dtype=torch.float32, device=xc.device)
+            mult = 4 if cl.dtype == torch.float32 else 8
+            dcl = ops.masked_ce_bwd(cl, ctgt, cwt, clse, csc, gc, 1.0, ctx.n_cmd, 1, pad_to=mult)
+            dwc, dbc = _wbgrad(rt, cw, cb, dcl, x)
+            dx = ops.gemm(dcl, rt.w(cw), b_kc=False)       # dense [rows, d_model]: the argument head's rows join it below
+        else:
+            xc, weight, bias, logits_c, target, w, lse, sc, idx = ctx.saved_tensors
+            dsc, = dscs
         g = dsc[0:1].to(torch.float32).contiguous()
         mult = 4 if logits_c.dtype == torch.float32 else 8
         dl = ops.masked_ce_bwd(logits_c, target, w, lse, sc, g, 1.0, ctx.C_, ctx.group, pad_to=mult, tok_idx=idx,
@@ -783,6 +851,9 @@ class ArgsHeadLossFn(torch.autograd.Function):
                     ops.gemm(dl, xc, a_kc=False, b_kc=False, out=dw[r0:r1])
                     ops.colsum(dl, out=db[r0:r1])
             dxc = ops.gemm(dl, rt.w(weight)[r0:r1], b_kc=False)
-        dx = torch.zeros((ctx.rows_full, xc.shape[1]), dtype=xc.dtype, device=xc.device)
-        ops.scatter_rows(dxc, idx, dx)
-        return None, dx, dw, db, None, None, None, None, None, None, None
+        if dx is None:
+            dx = torch.zeros((ctx.rows_full, xc.shape[1]), dtype=xc.dtype, device=xc.device)
+            ops.scatter_rows(dxc, idx, dx)
+        else:
+            ops.scatter_rows(dxc, idx, dx, accumulate=True)
+        return (None, dx, dw, db, None, None, None, None, None, None, None, None, dwc, dbc, None, None, None)

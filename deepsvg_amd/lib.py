@@ -78,7 +78,7 @@ SIGNATURES = {
     "dsvg_masked_ce_bwd": (c_i32, [c_i32, vp, c_i64, c_i32, vp, vp, vp, vp, vp, c_f32, vp, c_i64, c_i64, c_i32, vp, c_i32, vp]),
     "dsvg_live_rows": (c_i32, [vp, c_i64, c_i32, vp, vp, vp, c_i64, vp]),
     "dsvg_live_rows_workspace_bytes": (c_i64, [c_i64]),
-    "dsvg_scatter_rows": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, vp]),
+    "dsvg_scatter_rows": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, vp]),
     "dsvg_sumsq": (c_i32, [vp, c_i64, vp, vp, c_i64, vp]),
     "dsvg_sumsq_workspace_bytes": (c_i64, [c_i64]),
     "dsvg_adamw_step": (c_i32, [vp, vp, vp, vp, c_i64, vp, c_f32, c_f32, c_f32, c_f32, vp, vp, c_f32, c_f32, vp]),

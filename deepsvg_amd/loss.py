@@ -5,6 +5,8 @@ The three cross-entropies run in the masked-CE HIP kernels (no boolean-mask gath
 shapes -> hipGraph-capturable).  Mask semantics: the `extended` padding mask uses the non-aliased reading of
 deepsvg/model/utils.py:25-28 (mask | mask shifted by 3), see DESIGN.md "loss_cmd mask".
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -23,6 +25,8 @@ class SVGLoss(nn.Module):
         # data-parallel hook (deepsvg_amd/trainer.py): count_reducer(float32 [3] local counts of the visibility / command /
         # argument cross-entropies) -> global counts / world, ONE collective per step
         self.count_reducer = None
+        # the command head's cross-entropy inside the argument head's autograd node (functional.ArgsHeadLossFn)
+        self.joint_heads = os.environ.get("DSVG_JOINT_HEADS", "1") != "0"
 
     def _cam(self, device):
         if self._cam_f32 is None or self._cam_f32.device != device:
@@ -81,10 +85,12 @@ class SVGLoss(nn.Module):
             names.append("loss_visibility")
 
         cl = command_logits.reshape(N * G * S, cfg.n_commands)
-        scs.append(Fn.MaskedCEFn.apply(cl, cmd_tgt.view(-1), cmd_w.view(-1), cfg.n_commands, 1,
-                                       (lambda c: cnt[1]) if red else None))
-        ws.append(weights["loss_cmd_weight"])
-        names.append("loss_cmd")
+        joint = head is not None and head.get("cmd_weight") is not None and self.joint_heads
+        if not joint:
+            scs.append(Fn.MaskedCEFn.apply(cl, cmd_tgt.view(-1), cmd_w.view(-1), cfg.n_commands, 1,
+                                           (lambda c: cnt[1]) if red else None))
+            ws.append(weights["loss_cmd_weight"])
+            names.append("loss_cmd")
         if head is not None:
             # fused argument head + loss on the loss-carrying tokens (forward and backward); the dense args_logits of
             # the result dict stays unmaterialised
@@ -94,8 +100,20 @@ class SVGLoss(nn.Module):
                 a_t, a_w, slots = tr[0], tr[1], (lo, hi)
             else:
                 a_t, a_w, slots = arg_tgt.view(-1), arg_w.view(-1), (0, n_args)
-            sc_a = Fn.ArgsHeadLossFn.apply(head["rt"], head["x"], head["weight"], head["bias"], a_t, a_w, self.args_dim,
-                                           slots[1] - slots[0], (lambda c: cnt[2]) if red else None, head["live"], slots[0])
+            if joint:
+                # ... together with the command head's cross-entropy: one backward node for both heads (their input's
+                # gradient is written once: the command head's product, the argument head's rows added into it)
+                sc_c, sc_a = Fn.ArgsHeadLossFn.apply(
+                    head["rt"], head["x"], head["weight"], head["bias"], a_t, a_w, self.args_dim, slots[1] - slots[0],
+                    (lambda c: cnt[2]) if red else None, head["live"], slots[0], cl.detach(), head["cmd_weight"],
+                    head["cmd_bias"], cmd_tgt.view(-1), cmd_w.view(-1), (lambda c: cnt[1]) if red else None)
+                scs.append(sc_c)
+                ws.append(weights["loss_cmd_weight"])
+                names.append("loss_cmd")
+            else:
+                sc_a = Fn.ArgsHeadLossFn.apply(head["rt"], head["x"], head["weight"], head["bias"], a_t, a_w, self.args_dim,
+                                               slots[1] - slots[0], (lambda c: cnt[2]) if red else None, head["live"],
+                                               slots[0])
         else:
             al = output["args_logits"].reshape(N * G * S, n_args * self.args_dim)
             sc_a = Fn.MaskedCEFn.apply(al, arg_tgt.view(-1), arg_w.view(-1), self.args_dim, n_args,

@@ -577,6 +577,8 @@ class SVGTransformer(nn.Module):
         self.compact_head_backward = os.environ.get("DSVG_COMPACT_HEAD", "1") != "0"
         # argument head + loss on the argument slots that carry loss in the batch only (see _plan)
         self.head_slot_range = os.environ.get("DSVG_HEAD_SLOT_RANGE", "1") != "0"
+        # the decoder stacks' conditioning rows linear_global_l(z) computed for all layers up front (functional.GlobalCondFn)
+        self.hoist_global = os.environ.get("DSVG_HOIST_GLOBAL", "1") != "0"
         self.last_head_rows = None
         self.kv_cache = True         # autoregressive sampling: incremental decoding over a per-layer q|k|v cache
         self.last_assignment = None  # self-matching configs: (N, Gp) int32 assignment of the last training forward
@@ -632,16 +634,23 @@ class SVGTransformer(nn.Module):
         """l: label embedding rows [n_seq, dim_label] of a label-conditioned config (memory2 of the reference layers,
         layers/improved_transformer.py:47-49,134-136)"""
         cfg = self.cfg
+        # the decoder's conditioning rows linear_global_l(z) of all layers up front (z is the same for every layer)
+        gl = None
+        if z is not None and all(hasattr(L, "linear_global") for L in stack.layers) and self.hoist_global:
+            wb = [t for L in stack.layers for t in (L.linear_global.weight, L.linear_global.bias)]
+            gl = Fn.GlobalCondFn.apply(rt, z, *wb)
         for i, L in enumerate(stack.layers):
             has_g = hasattr(L, "linear_global")
             has_l = l is not None and hasattr(L, "linear_global2")
+            hoisted = gl is not None
             x = Fn.LayerFn.apply(
-                rt, x, key_mask, z if has_g else None, l if has_l else None, n_seq, S, cfg.n_heads, cfg.dropout,
-                site + 8 * i,
+                rt, x, key_mask, (gl[i] if hoisted else z) if has_g else None, l if has_l else None, n_seq, S, cfg.n_heads,
+                cfg.dropout, site + 8 * i,
                 L.norm1.weight, L.norm1.bias, L.self_attn.in_proj_weight, L.self_attn.in_proj_bias,
                 L.self_attn.out_proj.weight, L.self_attn.out_proj.bias, L.norm2.weight, L.norm2.bias,
                 L.linear1.weight, L.linear1.bias, L.linear2.weight, L.linear2.bias,
-                L.linear_global.weight if has_g else None, L.linear_global.bias if has_g else None,
+                L.linear_global.weight if (has_g and not hoisted) else None,
+                L.linear_global.bias if (has_g and not hoisted) else None,
                 L.linear_global2.weight if has_l else None, L.linear_global2.bias if has_l else None,
                 seq_off, live, tiles, causal)
         return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps, live)
@@ -1015,7 +1024,9 @@ class SVGTransformer(nn.Module):
                 T_dec = self._head_in.shape[0]
                 n_rows = min(max((pl["n_live"] + 127) // 128 * 128, int(pl.get("rows", 0))), T_dec)
                 fcn = self.decoder.fcn.args_fcn
+                cf = self.decoder.fcn.command_fcn
                 res["_dsvg_head"] = dict(rt=rt, x=self._head_in, weight=fcn.weight, bias=fcn.bias,
+                                         cmd_weight=cf.weight, cmd_bias=cf.bias,
                                          targets=pl["targets"], live=(pl["live"], n_rows),
                                          tgt_commands=commands_dec, tgt_args=args_dec,
                                          slots=(pl.get("slot_lo", 0), pl.get("slot_hi", args_dec.shape[-1])),

@@ -784,13 +784,13 @@ def live_rows(w, group):
     return live, count
 
 
-def scatter_rows(src, idx, dst):
-    """dst[idx[i]] = src[i] for idx[i] >= 0"""
+def scatter_rows(src, idx, dst, accumulate=False):
+    """dst[idx[i]] = src[i] (accumulate: +=) for idx[i] >= 0"""
     _chk(src, idx, dst)
     assert src.is_contiguous() and dst.is_contiguous() and idx.dtype == torch.int32 and src.dtype == dst.dtype
     assert src.shape[1] == dst.shape[1] and idx.numel() >= src.shape[0]
     _l.check(_l.load().dsvg_scatter_rows(_dt(src), src.data_ptr(), idx.data_ptr(), dst.data_ptr(), src.shape[0],
-                                         src.shape[1], _stream()), "dsvg_scatter_rows")
+                                         src.shape[1], int(bool(accumulate)), _stream()), "dsvg_scatter_rows")
     return dst
 
 

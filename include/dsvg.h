@@ -275,9 +275,10 @@ int dsvg_loss_combine_bwd(const float* dtotal, const float* const* dterms, const
 int dsvg_live_rows(const float* w, int64_t n_tok, int32_t group, int32_t* live, int32_t* count,
                    int32_t* workspace, int64_t workspace_bytes, void* stream);
 int64_t dsvg_live_rows_workspace_bytes(int64_t n_tok);
-/* dst[idx[i], :] = src[i, :] for idx[i] >= 0 (width % 4 == 0); other rows of dst are left untouched */
+/* dst[idx[i], :] = src[i, :] (accumulate: +=) for idx[i] >= 0 (width % 4 == 0, idx without duplicates); other rows of dst are
+ * left untouched */
 int dsvg_scatter_rows(int32_t dtype, const void* src, const int32_t* idx, void* dst, int64_t n_rows,
-                      int32_t width, void* stream);
+                      int32_t width, int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Flat-buffer optimizer step: clip_grad_norm_ (deepsvg/train.py:100) + AdamW

@@ -541,10 +541,13 @@ def live_rows(w, group):
     return live, torch.tensor([idx.numel()], dtype=torch.int32, device=w.device)
 
 
-def scatter_rows(src, idx, dst):
+def scatter_rows(src, idx, dst, accumulate=False):
     sel = idx[:src.shape[0]].long()
     ok = sel >= 0
-    dst[sel[ok]] = src[ok]
+    if accumulate:
+        dst[sel[ok]] = (_f(dst[sel[ok]]) + _f(src[ok])).to(dst.dtype)
+    else:
+        dst[sel[ok]] = src[ok]
     return dst
 
 
