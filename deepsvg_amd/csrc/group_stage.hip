@@ -35,7 +35,7 @@ constexpr int LDX = GD + 8;             // row stride (elements) of a [32][256] 
 constexpr int LDQ = 3 * GD + 8;         // q|k|v image: 1552 B = 97 x 16 B
 constexpr int LDH = GF + 8;             // hidden image: 1040 B = 65 x 16 B
 constexpr int GS_FRAGS = 128;           // weight fragments per wave and layer (both directions)
-constexpr int PF = 12;                  // prefetch distance of the weight stream (fragments = KiB in flight per wave)
+constexpr int GS_PF_DEFAULT = 12;       // prefetch distance of the weight stream (fragments = KiB in flight per wave)
 
 __host__ __device__ inline int rowmap(int r, int h2) { return (r & 3) + 8 * (r >> 2) + 4 * h2; }
 
@@ -173,9 +173,12 @@ __device__ __forceinline__ DropCtx drop_make_v(float p, bool has_seed, uint64_t 
 }
 
 // the per-wave weight stream: fragment i of the layer is `ring[i % PF]` once `take(i)` has been called in order
+// PF: prefetch distance of the weight stream (fragments = KiB in flight per wave)
+template <int PF>
 struct WStream {
     const char* base;       // this lane's 16 bytes of fragment 0
     uint4 ring[PF];
+    static constexpr int DEPTH = PF;
     __device__ __forceinline__ void start(const bf16_t* img, int wave, int lane) {
         base = reinterpret_cast<const char*>(img) + ((size_t)wave * GS_FRAGS) * FRAG + lane * 16;
 #pragma unroll
@@ -187,7 +190,7 @@ struct WStream {
     do {                                                                                                         \
         (dst).u = (ws).ring[(I) % PF];                                                                           \
         if ((I) + PF < GS_FRAGS) (ws).ring[(I) % PF] = *reinterpret_cast<const uint4*>((ws).base + (size_t)((I) + PF) * FRAG); \
-    } while (0)
+    } while (0)        /* (PF: the enclosing kernel's template parameter) */
 
 struct GsFwdArgs {
     const bf16_t* x; const bf16_t* img;
@@ -222,7 +225,7 @@ __device__ __forceinline__ float row_total(float part, float* stat, int wave, in
     return t;
 }
 
-template <bool TRAIN>
+template <bool TRAIN, int PF>
 __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     bf16_t* XN = reinterpret_cast<bf16_t*>(smem + F_XN);
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         sbo[tid] = a.out_bias[tid]; sb2[tid] = a.b2[tid];
         sg1[tid] = a.g1[tid]; sbe1[tid] = a.be1[tid]; sg2[tid] = a.g2[tid]; sbe2[tid] = a.be2[tid];
     }
-    WStream ws;
+    WStream<PF> ws;
     ws.start(a.img, wave, lane);
 
     // ---- phase 0: LayerNorm 1, 16 lanes per row (wave w: rows 4 w .. 4 w + 3), 16 columns per lane -----------------------
@@ -637,6 +640,7 @@ __device__ __forceinline__ void unpack4(const uint2 t, float* v) {
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
 
+template <int PF>
 __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     bf16_t* A0 = reinterpret_cast<bf16_t*>(smem + B_A0);
@@ -694,7 +698,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a)
     const int qi = min(li / Smax, n_in - 1);
     const int my_seq = s_first + qi, my_start = qi * Smax;
     const uint32_t kmask_raw = a.key_mask ? (uint32_t)a.key_mask[my_seq] : ~0u;
-    WStream ws;
+    WStream<PF> ws;
     ws.start(a.img, wave, lane);
 
     const DropCtx dp = drop_make_v(a.drop_p, has_seed, seedv, a.site0);
@@ -1026,13 +1030,15 @@ extern "C" int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, co
     const int per = 32 / S;
     const int nb = (int)((n_seq + per - 1) / per);
     hipStream_t st = (hipStream_t)stream;
-    if (train) {
-        DSVG_ENSURE_LDS(gs_layer_fwd_kernel<true>, F_LDS);
-        hipLaunchKernelGGL(gs_layer_fwd_kernel<true>, dim3(nb), dim3(512), F_LDS, st, a);
-    } else {
-        DSVG_ENSURE_LDS(gs_layer_fwd_kernel<false>, F_LDS);
-        hipLaunchKernelGGL(gs_layer_fwd_kernel<false>, dim3(nb), dim3(512), F_LDS, st, a);
-    }
+    static const int pf = getenv("DSVG_GS_PF") ? atoi(getenv("DSVG_GS_PF")) : GS_PF_DEFAULT;       // tuning knob
+#define DSVG_GS_FWD(TR, P)                                                                       \
+    do {                                                                                         \
+        DSVG_ENSURE_LDS((gs_layer_fwd_kernel<TR, P>), F_LDS);                                    \
+        hipLaunchKernelGGL((gs_layer_fwd_kernel<TR, P>), dim3(nb), dim3(512), F_LDS, st, a);     \
+    } while (0)
+    if (train) { if (pf == 8) DSVG_GS_FWD(true, 8); else if (pf == 24) DSVG_GS_FWD(true, 24); else if (pf == 16) DSVG_GS_FWD(true, 16); else DSVG_GS_FWD(true, 12); }
+    else { if (pf == 8) DSVG_GS_FWD(false, 8); else if (pf == 24) DSVG_GS_FWD(false, 24); else if (pf == 16) DSVG_GS_FWD(false, 16); else DSVG_GS_FWD(false, 12); }
+#undef DSVG_GS_FWD
     DSVG_LAUNCH_CHECK("gs_layer_fwd");
     return 0;
 }
@@ -1072,8 +1078,14 @@ extern "C" int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, 
     const int per = 32 / S;
     const int nb = (int)((n_seq + per - 1) / per);
     hipStream_t st = (hipStream_t)stream;
-    DSVG_ENSURE_LDS(gs_layer_bwd_kernel, B_LDS);
-    hipLaunchKernelGGL(gs_layer_bwd_kernel, dim3(nb), dim3(512), B_LDS, st, a);
+    static const int pf = getenv("DSVG_GS_PF") ? atoi(getenv("DSVG_GS_PF")) : GS_PF_DEFAULT;       // tuning knob
+#define DSVG_GS_BWD(P)                                                                       \
+    do {                                                                                     \
+        DSVG_ENSURE_LDS((gs_layer_bwd_kernel<P>), B_LDS);                                    \
+        hipLaunchKernelGGL((gs_layer_bwd_kernel<P>), dim3(nb), dim3(512), B_LDS, st, a);     \
+    } while (0)
+    if (pf == 8) DSVG_GS_BWD(8); else if (pf == 16) DSVG_GS_BWD(16); else DSVG_GS_BWD(12);
+#undef DSVG_GS_BWD
     DSVG_LAUNCH_CHECK("gs_layer_bwd");
     // the four LayerNorm parameter gradients: fixed-order sums of the per-tile partials (queued while a deferral scope is
     // open on this stream, like every other parameter-gradient reduction)
