@@ -172,6 +172,22 @@ __device__ __forceinline__ DropCtx drop_make_v(float p, bool has_seed, uint64_t 
     return c;
 }
 
+// multipliers of the 4 elements idx8 + 4 h2 .. + 3 of an aligned group of 8 (the half of drop_mult8's group this lane owns in
+// a transposed result tile: words 2 h2 and 2 h2 + 1 of the group - the other two are the partner lane's)
+__device__ __forceinline__ void drop_mult4(const DropCtx& c, uint64_t idx8, int h2, float (&m)[4]) {
+    if (!c.on) {
+        m[0] = m[1] = m[2] = m[3] = 1.f;
+        return;
+    }
+    const uint32_t h = drop_group(c, idx8 >> 3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t w = drop_word(h, 2 * h2 + i);
+        m[2 * i] = (w & 0xffffu) < c.thresh ? 0.f : c.scale;
+        m[2 * i + 1] = (w >> 16) < c.thresh ? 0.f : c.scale;
+    }
+}
+
 // the per-wave weight stream: fragment i of the layer is `ring[i % PF]` once `take(i)` has been called in order
 // PF: prefetch distance of the weight stream (fragments = KiB in flight per wave)
 template <int PF>
@@ -438,18 +454,18 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             // columns qc + 8 c + 4 h2 .. + 3: half of the aligned group of 8 the standard draws are made for
-            float dm[8], gm[8];
-            drop_mult8(dr1, (uint64_t)m * GD + qc + 8 * c, dm);
-            if (a.gadd) drop_mult8(dg, (uint64_t)my_seq * GD + qc + 8 * c, gm);
+            float dm[4], gm[4];
+            drop_mult4(dr1, (uint64_t)m * GD + qc + 8 * c, h2, dm);
+            if (a.gadd) drop_mult4(dg, (uint64_t)my_seq * GD + qc + 8 * c, h2, gm);
             const float xv[4] = {__uint_as_float(xr[c].x << 16), __uint_as_float(xr[c].x & 0xffff0000u),
                                  __uint_as_float(xr[c].y << 16), __uint_as_float(xr[c].y & 0xffff0000u)};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = (ya[4 * c + e] + sbo[qc + 8 * c + 4 * h2 + e]) * dm[4 * h2 + e] + xv[e];
+                float v = (ya[4 * c + e] + sbo[qc + 8 * c + 4 * h2 + e]) * dm[e] + xv[e];
                 if (a.gadd) {
                     const uint32_t gw = e < 2 ? gr4[c].x : gr4[c].y;
                     const float gv = (e & 1) ? __uint_as_float(gw & 0xffff0000u) : __uint_as_float(gw << 16);
-                    v += gv * gm[4 * h2 + e];
+                    v += gv * gm[e];
                 }
                 // (the value every later stage sees is the stored bf16 one, as on the unfused path)
                 x1v[4 * c + e] = bf2f(f2bf(v));
@@ -507,12 +523,12 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
             float t[16];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float dm[8];
-                drop_mult8(dh, (uint64_t)m * GF + hc + 8 * c, dm);
+                float dm[4];
+                drop_mult4(dh, (uint64_t)m * GF + hc + 8 * c, h2, dm);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float pre = (jj ? h1[4 * c + e] : h0[4 * c + e]) + sb1[hc + 8 * c + 4 * h2 + e];
-                    t[4 * c + e] = fmaxf(pre, 0.f) * dm[4 * h2 + e];
+                    t[4 * c + e] = fmaxf(pre, 0.f) * dm[e];
                 }
             }
             stage_rows(HI, LDH, li, hc, h2, t);
@@ -539,11 +555,11 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         float t[16];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float dm[8];
-            drop_mult8(dr2, (uint64_t)m * GD + qc + 8 * c, dm);
+            float dm[4];
+            drop_mult4(dr2, (uint64_t)m * GD + qc + 8 * c, h2, dm);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                t[4 * c + e] = (ya[4 * c + e] + sb2[qc + 8 * c + 4 * h2 + e]) * dm[4 * h2 + e] + x1v[4 * c + e];
+                t[4 * c + e] = (ya[4 * c + e] + sb2[qc + 8 * c + 4 * h2 + e]) * dm[e] + x1v[4 * c + e];
         }
         // every wave is past B3: nobody reads XN (linear1) any more
         stage_rows(XN, LDX, li, qc, h2, t);
@@ -801,10 +817,10 @@ __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a)
         float t[16];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float dm[8];
-            drop_mult8(dr1, (uint64_t)m * GD + qc + 8 * c, dm);
+            float dm[4];
+            drop_mult4(dr1, (uint64_t)m * GD + qc + 8 * c, h2, dm);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[4 * c + e] = dx1v[4 * c + e] * dm[4 * h2 + e];
+            for (int e = 0; e < 4; ++e) t[4 * c + e] = dx1v[4 * c + e] * dm[e];
         }
         stage_rows(A0, LDX, li, qc, h2, t);             // (this wave's own column block of A0: read above, by this wave only)
     }
