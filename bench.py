@@ -417,6 +417,12 @@ def main():
             red_total = float(sum(red_by.values())) or 1.0
             ffn_red_ms = red_ms * red_by.get("ffn", 0) / red_total
             wg_red_ms = red_ms * (red_by.get("ffn", 0) + red_by.get("wgrad", 0)) / red_total
+            # grouped weight-gradient launches of the 4096-row stages: one record per launch, members' FLOPs / bytes by tag
+            grp = [r for r in recs if r[0] == "group"]
+            grp_ms = sum(r[1] for r in grp)
+            grp_ffn_ms = sum(r[1] * r[4]["by_tag"].get("ffn", 0.0) / max(r[2], 1.0) for r in grp)
+            grp_ffn_flop = sum(r[4]["by_tag"].get("ffn", 0.0) for r in grp)
+            grp_bytes = sum(r[3] for r in grp)
 
             class _Ms:              # stands in for the (start event, end event) pair of a record: the averaged duration
                 def __init__(self, ms):
@@ -433,11 +439,11 @@ def main():
             gs_ffn_ms = sum(r[1].elapsed_time(r[2]) * r[5]["ffn_flops"] / r[3] for r in gsr)
             gs_ffn_flop = sum(r[5]["ffn_flops"] for r in gsr)
             # the FFN sub-block's time = its launches + its share (by queued workspace bytes) of the batched reductions
-            ffn_ms = sum(r[1].elapsed_time(r[2]) for r in ffn) + ffn_red_ms + gs_ffn_ms
-            n_ffn += len(gsr)
+            ffn_ms = sum(r[1].elapsed_time(r[2]) for r in ffn) + ffn_red_ms + gs_ffn_ms + grp_ffn_ms
+            n_ffn += len(gsr) + len(grp)
             # algorithmic FLOPs of the FFN sub-block = linear1 + linear2 forward, dX and dW; recomputed or
             # auxiliary launches (dropout replay, reductions, finishing kernel) carry 0 FLOPs but their time counts
-            flop_exec = sum(r[3] for r in ffn) / n_prof + gs_ffn_flop
+            flop_exec = sum(r[3] for r in ffn) / n_prof + gs_ffn_flop + grp_ffn_flop
             flop_padded = a.batch * FFN_FLOP_PER_ICON_TRAIN         # the reference's padded layout
             tf = flop_exec / (ffn_ms * 1e-3) / 1e12
             peak_tf = PEAK_TFLOPS[a.dtype]
@@ -493,10 +499,10 @@ def main():
             wg = [r for r in allr if len(r[5]) and r[5].get("split_k", 1) > 1 and r[0] in ("wgrad", "ffn")]
             wgrad = None
             if wg:
-                wg_ms = sum(r[1].elapsed_time(r[2]) for r in wg) / n_prof + wg_red_ms
-                wg_bytes = sum(r[4] for r in wg) / n_prof
+                wg_ms = sum(r[1].elapsed_time(r[2]) for r in wg) / n_prof + wg_red_ms + grp_ms
+                wg_bytes = sum(r[4] for r in wg) / n_prof + grp_bytes
                 wgrad = {"kernel": "weight-gradient GEMMs (dW = dY^T X over all tokens, split-K) incl. their reductions",
-                         "bound": "hbm", "launches_per_step": len(wg) // n_prof, "ms_per_step": round(wg_ms, 3),
+                         "bound": "hbm", "launches_per_step": len(wg) // n_prof + len(grp), "ms_per_step": round(wg_ms, 3),
                          "algorithmic_GB_per_step": round(wg_bytes / 1e9, 3),
                          "achieved_GBps": round(wg_bytes / (wg_ms * 1e-3) / 1e9, 1), "peak_GBps": 8000.0,
                          "frac": round(wg_bytes / (wg_ms * 1e-3) / 1e9 / 8000.0, 4)}

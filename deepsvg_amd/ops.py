@@ -192,15 +192,32 @@ class _GroupScope:
     """`with ops.GROUP:` - the split-K weight-gradient GEMMs launched inside on the current stream run as ONE launch when
     the block is left (include/dsvg.h: dsvg_gemm_group_scope).  Their operands must stay alive until then - they do when
     they are locals of the code inside the block."""
+    active = None       # profiling only: {tag: [flops, bytes]} of the members queued in the open scope
 
     def __enter__(self):
         self._key = _stream_key()
         if torch.cuda.is_available():
             _l.check(_l.load().dsvg_gemm_group_scope(1, self._key), "dsvg_gemm_group_scope")
+        if PROFILE_ON:
+            _GroupScope.active = {}
 
     def __exit__(self, *exc):
+        members, _GroupScope.active = _GroupScope.active, None
+        ev = None
+        if PROFILE_ON and members:
+            ev = _event()
+            ev.record()
         if torch.cuda.is_available():
             _l.check(_l.load().dsvg_gemm_group_scope(0, self._key), "dsvg_gemm_group_scope")
+        if ev is not None:
+            # one record for the grouped launch; `by_tag` = FLOPs each tag queued (the share of the launch a sub-block is
+            # charged with), the members' own records carry no time
+            ev1 = _event()
+            ev1.record()
+            PROFILE.append(("group", ev, ev1, float(sum(v[0] for v in members.values())),
+                            float(sum(v[1] for v in members.values())),
+                            dict(op="wgrad_group", by_tag={k: v[0] for k, v in members.items()},
+                                 bytes_by_tag={k: v[1] for k, v in members.items()})))
         return False
 
 
@@ -303,12 +320,19 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     L = _l.load()
     if PROFILE_ON and _TAG is not None:
+        esz = 2 if a.dtype == torch.bfloat16 else 4
+        extra = (esz * d.M * d.N if (res is not None or gate is not None) else 0)    # residual / gate operand
+        if _GroupScope.active is not None and split_k > 1 and not a_kc and not b_kc:
+            # queued in an open group: it runs with the group's one launch (timed at the end of the scope)
+            _l.check(L.dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
+            m = _GroupScope.active.setdefault(_TAG, [0.0, 0.0])
+            m[0] += 2.0 * d.M * d.N * d.K
+            m[1] += float(esz * (d.M * d.K + d.N * d.K) + out.element_size() * d.M * d.N)
+            return out
         ev0, ev1 = _event(), _event()
         ev0.record()
         _l.check(L.dsvg_gemm(C.byref(d), _stream()), "dsvg_gemm")
         ev1.record()
-        esz = 2 if a.dtype == torch.bfloat16 else 4
-        extra = (esz * d.M * d.N if (res is not None or gate is not None) else 0)    # residual / gate operand
         spec = dict(a=tuple(a.shape), b=tuple(b.shape), a_kc=a_kc, b_kc=b_kc, bias=bias is not None, res=res is not None,
                     act=act, gate=gate is not None, gate_scale=gate_scale, drop_p=drop_p, split_k=split_k,
                     rowsum=rowsum is not None, out_f32=out.dtype == torch.float32, dtype=str(a.dtype))
