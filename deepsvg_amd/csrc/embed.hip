@@ -126,35 +126,40 @@ extern "C" int dsvg_visible_first(const int32_t* visible, int64_t n, int32_t* ne
 }
 
 // dst[g * S + s, :] = src[max(idx[g], 0) * S + s, :] for g < n_groups  (whole-sequence row gather; 16-byte pieces;
-// a negative index marks list padding and reads group 0)
+// a negative index marks list padding and reads group 0; an index >= n_src - a group the source does not hold - gives a
+// zero row)
 template <typename T>
 __global__ void gather_groups_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx, T* __restrict__ dst,
-                                     long long n_groups, int S, int width) {
+                                     long long n_groups, int S, int width, long long n_src) {
     typedef typename Elem<T>::raw4 raw4;
     const int cpr = width / 4;
     const long long total = n_groups * S * cpr;
+    raw4 zero;
+    __builtin_memset(&zero, 0, sizeof(zero));
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const long long row = i / cpr;
         const int c = (int)(i - row * cpr);
         const long long g = row / S;
         const int sidx = (int)(row - g * S);
+        const long long sg = max(idx[g], 0);
         reinterpret_cast<raw4*>(dst + row * width)[c] =
-            reinterpret_cast<const raw4*>(src + ((long long)max(idx[g], 0) * S + sidx) * width)[c];
+            sg < n_src ? reinterpret_cast<const raw4*>(src + (sg * S + sidx) * width)[c] : zero;
     }
 }
 extern "C" int dsvg_gather_groups(int32_t dtype, const void* src, const int32_t* idx, void* dst, int64_t n_groups,
-                                  int32_t S, int32_t width, void* stream) {
+                                  int32_t S, int32_t width, int64_t n_src, void* stream) {
     DSVG_CHECK_ARG(src && idx && dst && n_groups > 0 && S > 0 && width > 0 && (width % 4) == 0, "gather_groups: bad args");
+    DSVG_CHECK_ARG(n_src > 0, "gather_groups: n_src = number of groups in src (> 0)");
     const long long total = n_groups * S * (long long)(width / 4);
     const int nb = (int)min((long long)dsvg_cdiv(total, 256), 8192LL);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DSVG_F32)
         hipLaunchKernelGGL(gather_groups_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)src, idx, (float*)dst,
-                           (long long)n_groups, S, width);
+                           (long long)n_groups, S, width, (long long)n_src);
     else if (dtype == DSVG_BF16)
         hipLaunchKernelGGL(gather_groups_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)src, idx,
-                           (bf16_t*)dst, (long long)n_groups, S, width);
+                           (bf16_t*)dst, (long long)n_groups, S, width, (long long)n_src);
     else { dsvg_set_error("gather_groups: bad dtype"); return -1; }
     DSVG_LAUNCH_CHECK("gather_groups");
     return 0;

@@ -339,26 +339,30 @@ class EmbedFn(torch.autograd.Function):
 
 
 class GatherGroupsFn(torch.autograd.Function):
-    """y[g*S + s] = x[idx[g]*S + s] (whole sequences); inv = inverse permutation.  With `live` = (n_live, rows): the
-    upstream gradient of the sequences inv[g >= n_live] is known to be zero, so backward gathers only the sequences
-    that cover the first `rows` rows (the exact zeros included) and leaves the rest of dx unwritten (never read)."""
+    """y[g*S + s] = x[idx[g]*S + s] (whole sequences), g < n_groups; inv = inverse permutation.  x may hold FEWER sequences
+    than the permutation has (a stage that ran on the leading sequences only): the others come out as zero rows; and
+    n_groups may be smaller than the permutation (only its leading sequences are wanted): the gradient of the sequences
+    of x that nobody read is zero.  With `live` = (n_live, rows): the upstream gradient of the sequences inv[g >= n_live]
+    is known to be zero, so backward gathers only the sequences that cover the first `rows` rows (the exact zeros
+    included) and leaves the rest of dx unwritten (never read)."""
 
     @staticmethod
     def forward(ctx, x, idx, inv, n_groups, S, live=None):
         ctx.n_groups, ctx.S, ctx.live = n_groups, S, _live_rows(live, n_groups * S)
+        ctx.n_src = x.shape[0] // S
         ctx.save_for_backward(inv)
-        return ops.gather_groups(x.contiguous(), idx, n_groups, S)
+        return ops.gather_groups(x.contiguous(), idx, n_groups, S, n_src=ctx.n_src)
 
     @staticmethod
     def backward(ctx, dy):
         inv, = ctx.saved_tensors
         dy = dy.contiguous()
         live = _armed(ctx.live)
-        if live is None:
-            return ops.gather_groups(dy, inv, ctx.n_groups, ctx.S), None, None, None, None, None
-        n_cover = min(ctx.n_groups, -(-live[1] // ctx.S))
-        dx = torch.empty_like(dy)
-        ops.gather_groups(dy, inv, n_cover, ctx.S, out=dx)
+        n_back = ctx.n_src
+        if live is not None:
+            n_back = min(n_back, -(-live[1] // ctx.S))
+        dx = torch.empty((ctx.n_src * ctx.S, dy.shape[1]), dtype=dy.dtype, device=dy.device)
+        ops.gather_groups(dy, inv, n_back, ctx.S, out=dx, n_src=ctx.n_groups)
         return dx, None, None, None, None, None
 
 

@@ -58,7 +58,7 @@ SIGNATURES = {
     "dsvg_attention_tiles": (c_i32, [vp, c_i64, c_i32, vp, vp, vp]),
     "dsvg_pack_tokens": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, vp]),
     "dsvg_visible_first": (c_i32, [vp, c_i64, vp, vp, vp, vp]),
-    "dsvg_gather_groups": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, vp]),
+    "dsvg_gather_groups": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, c_i64, vp]),
     "dsvg_build_masks": (c_i32, [vp, c_i64, c_i32, c_i32, c_i32, vp, vp, vp, vp]),
     "dsvg_embed_gather": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, vp]),
     "dsvg_embed_scatter": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32,

@@ -46,8 +46,6 @@ class SVGLoss(nn.Module):
             res["loss_kl"] = loss_kl
 
         tgt_commands, tgt_args = output["tgt_commands"], output["tgt_args"]
-        command_logits = output["command_logits"]       # ("args_logits" may be lazy: only read when it is needed)
-        device = command_logits.device
         N, G, S1 = tgt_commands.shape
         n_args = tgt_args.shape[-1]
         S = S1 - 1
@@ -62,6 +60,13 @@ class SVGLoss(nn.Module):
         if head is not None and not (head["tgt_commands"] is tgt_commands and head["tgt_args"] is tgt_args
                                      and torch.is_grad_enabled()):
             head = None
+        # the dense logit tensors may be LAZY entries of the model's result (only read when they are needed): a training
+        # forward that ran the visible groups only hands over the command logits of those groups - every row with a loss
+        # term is among them
+        command_logits = head.get("cmd_logits") if head is not None else None
+        if command_logits is None:
+            command_logits = output["command_logits"]
+        device = command_logits.device
         if head is not None:
             cmd_tgt, cmd_w, arg_tgt, arg_w, vis_tgt = head["targets"]
         else:

@@ -572,6 +572,9 @@ class SVGTransformer(nn.Module):
         self.last_packing = None
         # backward of the second decoder stage only over the sequences of visible target groups (exact under SVGLoss)
         self.skip_invisible_backward = os.environ.get("DSVG_SKIP_INVISIBLE", "1") != "0"
+        # ... and the same sequences' forward pass in a training call (their logits stay available: lazy result entries)
+        self.skip_invisible_forward = os.environ.get("DSVG_SKIP_INVISIBLE_FWD", "1") != "0"
+        self._cmd_logits_live = None
         self.last_live = None
         # backward of the argument head only over the tokens that carry argument loss (exact under SVGLoss)
         self.compact_head_backward = os.environ.get("DSVG_COMPACT_HEAD", "1") != "0"
@@ -858,18 +861,43 @@ class SVGTransformer(nn.Module):
         S = dec.embedding.seq_len
         pd = plan["dec"] if (plan is not None and cfg.decode_stages == 2) else None
         live = None
+        n_run = n_seq               # sequences the stage runs forward
         if pd is not None and max(pd["n_visible"], pd.get("n_live", 0)) < n_seq:
             # visible-first order: sequence `new` of the stage is group old_of_new[new]; backward covers the prefix
             # (any prefix that contains every visible sequence is exact; a graph bucket rounds it up)
             nv = max(pd["n_visible"], pd.get("n_live", 0))
             live = Fn.LivePrefix((nv, min((nv * S + 127) // 128 * 128, n_seq * S)))
-            z = Fn.GatherGroupsFn.apply(z, pd["old_of_new"], pd["new_of_old"], n_seq, 1, None)
+            if self.skip_invisible_forward and match is None and l_seq is None:
+                # ... and so does the forward pass: SVGLoss reads no logit of an invisible target group (loss.py:36,51-54)
+                # and the sequences are independent, so the training step runs the whole sequences that cover that prefix.
+                # The other groups' logits are LAZY entries of the result (see `complete` below)
+                n_run = min(n_seq, -(-live[1] // S))
+            z_all = z
+            z = Fn.GatherGroupsFn.apply(z, pd["old_of_new"], pd["new_of_old"], n_run, 1, None)
         self.last_live = (live[0], n_seq) if live is not None else None
         self._live = live
-        src = Fn.AddPosFn.apply(rt, None, dec.embedding.PE.pos_embed.weight, n_seq, S, PE_DROPOUT, 4, live)
-        out = self._run_stack(rt, dec.decoder, src, None, z, n_seq, S, 400, live=live, l=l_seq)
-        if live is not None:        # back to the caller's group order before the heads
+        src = Fn.AddPosFn.apply(rt, None, dec.embedding.PE.pos_embed.weight, n_run, S, PE_DROPOUT, 4, live)
+        out = self._run_stack(rt, dec.decoder, src, None, z, n_run, S, 400, live=live, l=l_seq)
+        if live is not None:        # back to the caller's group order before the heads (sequences that did not run: zeros)
             out = Fn.GatherGroupsFn.apply(out, pd["new_of_old"], pd["old_of_new"], n_seq, S, live)
+        complete = None
+        if n_run < n_seq:
+            done = []
+
+            def complete():
+                """the stage's output with the rows of EVERY group: runs the sequences the training pass left out (first
+                read of a dense logit tensor by anything but deepsvg_amd.SVGLoss: the reference's SVGLoss, a metric, a
+                test).  Differentiable; off the hot path, so the row bookkeeping is plain torch.  Dropout: those rows
+                draw from their own sites."""
+                if not done:
+                    rest = pd["old_of_new"][n_run:].long()
+                    n_rest = n_seq - n_run
+                    z_r = z_all.index_select(0, rest)
+                    src_r = Fn.AddPosFn.apply(rt, None, dec.embedding.PE.pos_embed.weight, n_rest, S, PE_DROPOUT, 6, None)
+                    out_r = self._run_stack(rt, dec.decoder, src_r, None, z_r, n_rest, S, 464)
+                    full = out.view(n_seq, -1).index_copy(0, rest, out_r.view(n_rest, -1))
+                    done.append(full.view(n_seq * S, -1))
+                return done[0]
         if match is not None:
             # Hungarian self-matching (model.py:384-395): cost of every (target group, predicted group) pair from the
             # dense logits (no gradient), exact assignment, then output slot j takes predicted group assign[j].  The
@@ -888,16 +916,21 @@ class SVGTransformer(nn.Module):
             self.last_assignment = assign
             out = Fn.GatherGroupsFn.apply(out, idx, inv, n_seq, S, None)
             vis_logits = vis_logits.index_select(0, idx.long())         # (N*G, 2): a tiny gather, left to torch
-        cmd_logits = Fn.LinearFn.apply(rt, out, dec.fcn.command_fcn.weight, dec.fcn.command_fcn.bias, 0, None, 0.0, 0,
-                                       None)
+        cf = dec.fcn.command_fcn
+        cmd_logits = Fn.LinearFn.apply(rt, out, cf.weight, cf.bias, 0, None, 0.0, 0, None).view(N, G, S, cfg.n_commands)
         n_args, args_dim, fcn = cfg.n_args, self.args_dim, dec.fcn.args_fcn
 
         def make_args_logits():
-            al = Fn.LinearFn.apply(rt, out, fcn.weight, fcn.bias, 0, None, 0.0, 0, None)
+            al = Fn.LinearFn.apply(rt, out if complete is None else complete(), fcn.weight, fcn.bias, 0, None, 0.0, 0, None)
             return al.view(N, G, S, n_args, args_dim)
         args_logits = make_args_logits if lazy_args else make_args_logits()
         self._head_in = out         # input of the heads (for the fused argument head + loss)
-        cmd_logits = cmd_logits.view(N, G, S, cfg.n_commands)
+        self._cmd_logits_live = None
+        if complete is not None:
+            # valid on the groups that ran (every loss-carrying row is among them): what deepsvg_amd.SVGLoss reads
+            self._cmd_logits_live = cmd_logits
+            cmd_logits = lambda: Fn.LinearFn.apply(rt, complete(), cf.weight, cf.bias, 0, None, 0.0, 0, None) \
+                .view(N, G, S, cfg.n_commands)
         if vis_logits is not None:
             vis_logits = vis_logits.view(N, G, 1, 2)
         return cmd_logits, args_logits, vis_logits
@@ -1007,7 +1040,11 @@ class SVGTransformer(nn.Module):
             prefix = (commands_dec[..., :-1], args_dec[..., :-1, :]) if return_tgt else (commands_dec, args_dec)
         cmd_logits, args_logits, vis_logits = self._decode(rt, zz, plan, lazy_args=lazy_args, label=label,
                                                            hierarch_logits=hl, match=match, prefix=prefix)
-        res = ModelOutput({"command_logits": cmd_logits})
+        res = ModelOutput()
+        if callable(cmd_logits):        # (the training pass ran the visible groups only, see _decode)
+            res.set_lazy("command_logits", cmd_logits)
+        else:
+            res["command_logits"] = cmd_logits
         if lazy_args:
             res.set_lazy("args_logits", args_logits)
         else:
@@ -1026,7 +1063,7 @@ class SVGTransformer(nn.Module):
                 fcn = self.decoder.fcn.args_fcn
                 cf = self.decoder.fcn.command_fcn
                 res["_dsvg_head"] = dict(rt=rt, x=self._head_in, weight=fcn.weight, bias=fcn.bias,
-                                         cmd_weight=cf.weight, cmd_bias=cf.bias,
+                                         cmd_weight=cf.weight, cmd_bias=cf.bias, cmd_logits=self._cmd_logits_live,
                                          targets=pl["targets"], live=(pl["live"], n_rows),
                                          tgt_commands=commands_dec, tgt_args=args_dec,
                                          slots=(pl.get("slot_lo", 0), pl.get("slot_hi", args_dec.shape[-1])),
@@ -1040,6 +1077,7 @@ class SVGTransformer(nn.Module):
                 res["mu"] = mu.view(mu.shape[0], 1, 1, -1)
                 res["logsigma"] = logsigma.view(logsigma.shape[0], 1, 1, -1)
         self._head_in = None
+        self._cmd_logits_live = None
         self._live = None
         return res
 

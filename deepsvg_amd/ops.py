@@ -642,15 +642,20 @@ def visible_first(visible):
     return new_of_old, old_of_new, nvis
 
 
-def gather_groups(src, idx, n_groups, S, out=None):
-    """out[g*S + s] = src[idx[g]*S + s] for g < n_groups (rows past n_groups*S of `out` are left untouched)"""
+def gather_groups(src, idx, n_groups, S, out=None, n_src=None):
+    """out[g*S + s] = src[idx[g]*S + s] for g < n_groups (rows past n_groups*S of `out` are left untouched); n_src: `src`
+    holds that many groups and an index beyond them gives a zero sequence (default: every index is taken to be valid)"""
     _chk(src, idx, out)
     assert src.is_contiguous() and idx.dtype == torch.int32 and src.dim() == 2
+    if n_src is None:
+        n_src = 1 << 40
+    else:
+        assert 0 < n_src * S <= src.shape[0]
     if out is None:
         out = torch.empty((n_groups * S, src.shape[1]), dtype=src.dtype, device=src.device)
     assert out.is_contiguous() and out.shape[0] >= n_groups * S and out.shape[1] == src.shape[1] and out.dtype == src.dtype
     _l.check(_l.load().dsvg_gather_groups(_dt(src), src.data_ptr(), idx.data_ptr(), out.data_ptr(), n_groups, S,
-                                          src.shape[1], _stream()), "dsvg_gather_groups")
+                                          src.shape[1], n_src, _stream()), "dsvg_gather_groups")
     return out
 
 

@@ -187,9 +187,11 @@ int dsvg_group_index(const float* commands, int64_t n_seq, int32_t S, int32_t m_
  * kernels run on a row prefix.  new_of_old / old_of_new: stable partition and its inverse. */
 int dsvg_visible_first(const int32_t* visible, int64_t n, int32_t* new_of_old, int32_t* old_of_new,
                        int32_t* n_visible, void* stream);
-/* dst[g*S + s, :] = src[idx[g]*S + s, :], g < n_groups: whole-sequence row gather (width % 4 == 0) */
+/* dst[g*S + s, :] = src[idx[g]*S + s, :], g < n_groups: whole-sequence row gather (width % 4 == 0).  src holds n_src
+ * groups: idx[g] >= n_src gives a zero sequence (the second decoder stage's forward runs on the visible sequences only;
+ * the output rows of the others are zeros until somebody reads their logits), idx[g] < 0 (list padding) reads group 0 */
 int dsvg_gather_groups(int32_t dtype, const void* src, const int32_t* idx, void* dst, int64_t n_groups,
-                       int32_t S, int32_t width, void* stream);
+                       int32_t S, int32_t width, int64_t n_src, void* stream);
 /* Packed token layout of the first encoder stage: only keys are masked there (layers/functional.py:234-239)
  * and padded query rows are dropped by the mean-pool (model/model.py:137), so the encoder can run on the
  * valid tokens only, bit-for-bit safe.  seq_off[b] = exclusive scan of popcount(key_mask) (n_seq+1 entries,

@@ -114,6 +114,36 @@ def test_packed_encoder_equals_padded_encoder(emulated_ops):
         assert H.rel_l2(res[True][2][n], res[False][2][n]) < 1e-4, n
 
 
+def test_invisible_groups_run_forward_only_when_their_logits_are_read(emulated_ops):
+    """training call + deepsvg_amd.SVGLoss: the second decoder stage runs the visible groups' sequences only (forward and
+    backward) and both dense logit tensors stay lazy; loss and gradients are those of the dense computation, and a later
+    read of the logits gives the dense tensors"""
+    from deepsvg_amd.synthetic import make_batch
+    cfg = H.build_cfg("hier")
+    cfg.n_layers = cfg.n_layers_decode = 2
+    c, a = make_batch(12, seed=5)
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 7)
+    res = {}
+    for skip in (True, False):
+        model = deepsvg_amd.SVGTransformer(cfg).eval()
+        model.load_state_dict(sd)
+        model.skip_invisible_forward = skip
+        out = model(c, a, c, a, params={})
+        assert out.is_pending("command_logits") == skip and out.is_pending("args_logits")
+        ld = deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
+        ld["loss"].backward()
+        assert out.is_pending("command_logits") == skip, "the loss materialised the dense command logits"
+        res[skip] = (ld["loss"].item(), {n: p.grad.clone() for n, p in model.named_parameters()},
+                     out["command_logits"].detach().float(), out["args_logits"].detach().float())
+        assert not out.is_pending("command_logits")
+    assert model.last_live is not None and model.last_live[0] < model.last_live[1], "the batch has no invisible group"
+    assert abs(res[True][0] - res[False][0]) < 1e-6
+    for n in res[True][1]:
+        assert H.rel_l2(res[True][1][n], res[False][1][n]) < 1e-5, n
+    assert torch.allclose(res[True][2], res[False][2], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(res[True][3], res[False][3], rtol=1e-5, atol=1e-6)
+
+
 def test_args_logits_is_lazy_with_the_fused_head_loss(emulated_ops):
     """training forward + deepsvg_amd.SVGLoss: the dense args_logits is never built (the fused argument head + loss
     works on the loss-carrying tokens); reading it later still gives the reference's tensor"""

@@ -448,6 +448,15 @@ def test_visible_first_and_gather_groups(gpu_device):
             y = ops.gather_groups(x, got[1], n, 3)
             assert torch.equal(y, R.gather_groups(x, got[1], n, 3))
             assert torch.equal(ops.gather_groups(y, got[0], n, 3), x)       # the inverse permutation restores x
+            # a source that holds the leading groups only: the others come out as zero sequences; and the leading
+            # groups of the permutation only (the two halves of a stage that ran on a prefix of its sequences)
+            m = (n + 1) // 2
+            part = ops.gather_groups(x, got[1], m, 3)
+            assert torch.equal(part, y[:m * 3])
+            back = ops.gather_groups(part, got[0], n, 3, n_src=m)
+            assert torch.equal(back, R.gather_groups(part, got[0], n, 3, n_src=m))
+            keep = (got[0].long() < m).repeat_interleave(3).unsqueeze(1).to(x.dtype)
+            assert torch.equal(back, x * keep)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

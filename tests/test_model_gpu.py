@@ -177,7 +177,9 @@ def test_fp32_model_matches_oracle_at_benchmark_size_512(gpu_device):
         finally:
             ops.PROFILE_ON = False
             Fn.FFN_MIN_ROWS, Fn.ATTN_MIN_ROWS = saved
-        assert (n_fused == 16) if fused else (n_fused == 0), n_fused     # 8 large layers x (FFN, attention)
+        # 8 large layers x (FFN, attention), + the second decoder stage's 4 layers once more: the training pass ran the
+        # visible groups' sequences, the others run when this test reads the dense logits
+        assert (n_fused == 24) if fused else (n_fused == 0), n_fused
         e_c = (b_out["command_logits"].float() - o_out["command_logits"]).abs().max().item()
         e_a = (b_out["args_logits"].float() - o_out["args_logits"]).abs().max().item()
         agree = (b_out["command_logits"].argmax(-1) == o_out["command_logits"].argmax(-1)).float().mean().item()

@@ -361,11 +361,14 @@ def visible_first(visible):
     return new_of_old, old_of_new, v.sum().to(torch.int32).reshape(1)
 
 
-def gather_groups(src, idx, n_groups, S, out=None):
-    rows = (idx[:n_groups].long().clamp(min=0).unsqueeze(1) * S + torch.arange(S, device=src.device)).reshape(-1)
+def gather_groups(src, idx, n_groups, S, out=None, n_src=None):
+    g = idx[:n_groups].long().clamp(min=0)
+    ok = torch.ones_like(g, dtype=torch.bool) if n_src is None else g < n_src
+    rows = (torch.where(ok, g, torch.zeros_like(g)).unsqueeze(1) * S + torch.arange(S, device=src.device)).reshape(-1)
+    val = src[rows] * ok.repeat_interleave(S).unsqueeze(1).to(src.dtype)
     if out is None:
-        return src[rows].clone()
-    out[:n_groups * S] = src[rows]
+        return val.clone()
+    out[:n_groups * S] = val
     return out
 
 
