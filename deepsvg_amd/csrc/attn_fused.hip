@@ -36,7 +36,8 @@ constexpr int SLOT = 32 * FRAG;         // ring slot = the largest chunk
 constexpr int N_CHUNK = 20;             // 8 x (qk, v) + 4 x out_proj
 constexpr int IMG_FRAGS = 512;          // 384 in_proj + 128 out_proj fragments per layer
 constexpr int TILES_PER_WG = 8;
-constexpr int VLD = 40;                 // row stride (elements) of the per-wave staging tile [32 tokens][32 dims]
+constexpr int VLD = 32;                 // row stride (elements) of the per-wave staging tile [32 tokens][32 dims]: 64 B,
+                                        // swizzled (stg_swz)
 constexpr int SMALL_LDS = (768 + 256 + 256 + 256) * 4;      // in_proj bias | out_proj bias | gamma | beta
 constexpr int STAGE_LDS = TILES_PER_WG * 32 * VLD * 2;
 
@@ -86,6 +87,30 @@ __device__ __forceinline__ bf16x8 col_frag(const bf16_t* img, int ld, int col0, 
     union { bf16x8 v; shortx4 h[2]; } f;
     f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(&img[row * ld + col]));
     f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(&img[(row + 8) * ld + col]));
+    return f.v;
+}
+
+// The staging tile's swizzle: 64-byte rows, the eight 8-byte granules of row r stored at granule ^ stg_swz(r).
+//   * writes (ds_write_b64, 16-lane groups = 16 consecutive rows, 32 banks): rows of equal parity share a 16-bank half and
+//     get 8 different granule positions (stg_swz is a bijection of (r >> 1) & 7);
+//   * row reads (ds_read_b64 pairs, 32-lane groups = 8 rows x 4 granules of one parity, 64 banks): rows r and r + 4 share a
+//     quarter of the banks and read granules of opposite parity (bit 0 of stg_swz = bit 2 of r);
+//   * transposed reads (32-lane groups = 4 consecutive rows x 8 granules): all 64 banks whatever the order inside a row.
+// (Round 2's 80-byte rows put rows r, r + 16 - and r, r + 4 of a read group - on the same banks: 23 % of the LDS cycles of
+// the training variant were bank conflicts, profiles/r02_attn_pmc_summary.txt.)
+__device__ __forceinline__ int stg_swz(int row) {
+    const int m = row >> 1;
+    return ((m >> 1) & 1) | ((m & 1) << 1) | (m & 4);
+}
+__device__ __forceinline__ bf16x8 col_frag_swz(const bf16_t* img, int ks, int lane) {
+    const int g = lane >> 4, q16 = lane & 15;
+    const int row = 16 * ks + 4 * (g >> 1) + (q16 >> 2);
+    const int gran = 4 * (g & 1) + (q16 & 3);                      // 8-byte granule of the row
+    const int off = row * VLD + 4 * (gran ^ stg_swz(row));
+    const int off8 = (row + 8) * VLD + 4 * (gran ^ stg_swz(row + 8));
+    union { bf16x8 v; shortx4 h[2]; } f;
+    f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(&img[off]));
+    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((shortx4 __attribute__((address_space(3)))*)(&img[off8]));
     return f.v;
 }
 
@@ -283,16 +308,26 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
     // the packed 32 x 32 tile (lane: token li, dims 8 g + 4 h2 + 0..3 as piece g) -> staging tile [token][dim]
     auto stage_put = [&](const Frag8 (&f)[2]) {
         asm volatile("" ::: "memory");      // (one wave, in-order LDS: only the compiler must keep put / take / col_frag in order)
-        *reinterpret_cast<uint2*>(&stg[li * VLD + 0 + 4 * h2]) = make_uint2(f[0].u.x, f[0].u.y);
-        *reinterpret_cast<uint2*>(&stg[li * VLD + 8 + 4 * h2]) = make_uint2(f[0].u.z, f[0].u.w);
-        *reinterpret_cast<uint2*>(&stg[li * VLD + 16 + 4 * h2]) = make_uint2(f[1].u.x, f[1].u.y);
-        *reinterpret_cast<uint2*>(&stg[li * VLD + 24 + 4 * h2]) = make_uint2(f[1].u.z, f[1].u.w);
+        const int sw = stg_swz(li);
+        *reinterpret_cast<uint2*>(&stg[li * VLD + 4 * ((0 + h2) ^ sw)]) = make_uint2(f[0].u.x, f[0].u.y);
+        *reinterpret_cast<uint2*>(&stg[li * VLD + 4 * ((2 + h2) ^ sw)]) = make_uint2(f[0].u.z, f[0].u.w);
+        *reinterpret_cast<uint2*>(&stg[li * VLD + 4 * ((4 + h2) ^ sw)]) = make_uint2(f[1].u.x, f[1].u.y);
+        *reinterpret_cast<uint2*>(&stg[li * VLD + 4 * ((6 + h2) ^ sw)]) = make_uint2(f[1].u.z, f[1].u.w);
         asm volatile("" ::: "memory");
     };
-    // staging tile -> two pending 16-byte row pieces per lane: token (lane + 64 j) >> 2, dims 8 ((lane + 64 j) & 3) ..
+    // staging tile -> two pending 16-byte row pieces per lane: token (lane + 64 j) >> 2, dims 8 ((lane + 64 j) & 3) .. (rows 16
+    // apart share the swizzle); each piece as its two granules
+    const int tk_lo = (lane >> 2) * VLD + 4 * ((2 * (lane & 3)) ^ stg_swz(lane >> 2));
+    const int tk_hi = (lane >> 2) * VLD + 4 * ((2 * (lane & 3) + 1) ^ stg_swz(lane >> 2));
+    // (the far rows' offsets are made opaque: near + 1 KiB would be merged into ds_read2st64_b64, which is banked in 16-lane
+    // groups over 32 banks and runs at half the rate of two ds_read_b64)
+    int tk_lo_far = tk_lo + 16 * VLD, tk_hi_far = tk_hi + 16 * VLD;
+    asm volatile("" : "+v"(tk_lo_far), "+v"(tk_hi_far));
     auto stage_take = [&](uint4& near, uint4& far) {
-        near = *reinterpret_cast<const uint4*>(&stg[(lane >> 2) * VLD + 8 * (lane & 3)]);
-        far = *reinterpret_cast<const uint4*>(&stg[((lane >> 2) + 16) * VLD + 8 * (lane & 3)]);
+        const uint2 n0 = *reinterpret_cast<const uint2*>(&stg[tk_lo]), n1 = *reinterpret_cast<const uint2*>(&stg[tk_hi]);
+        const uint2 f0 = *reinterpret_cast<const uint2*>(&stg[tk_lo_far]), f1 = *reinterpret_cast<const uint2*>(&stg[tk_hi_far]);
+        near = make_uint4(n0.x, n0.y, n1.x, n1.y);
+        far = make_uint4(f0.x, f0.y, f1.x, f1.y);
     };
 
     bf16x8 aof[16];         // the out_proj operand queue: every head shifts it by two fragments and appends its own
@@ -419,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
                 Frag8 pf;
                 pf.u = make_uint4(f2bf_pk(p[8 * ks + 0], p[8 * ks + 1]), f2bf_pk(p[8 * ks + 2], p[8 * ks + 3]),
                                   f2bf_pk(p[8 * ks + 4], p[8 * ks + 5]), f2bf_pk(p[8 * ks + 6], p[8 * ks + 7]));
-                ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(stg, VLD, 0, ks, lane), pf.v, ot, 0, 0, 0);
+                ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag_swz(stg, ks, lane), pf.v, ot, 0, 0, 0);
             }
             // ot[r] = O[token li][dim rowmap(r, h2)] -> packed, appended to the out_proj operand queue (oldest head first)
             Frag8 of[2];

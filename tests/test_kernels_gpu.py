@@ -1140,6 +1140,40 @@ def _attn_case(kind, seed):
     raise KeyError(kind)
 
 
+@pytest.mark.parametrize("kind", ["packed", "dense31", "dense32_masked", "dense8_masked_tail", "packed_extremes"])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attn_block_fwd_against_fp32_torch(gpu_device, kind, p):
+    """the fused attention block DIRECTLY against the plain-torch fp32 restatement (tests/torch_ops_ref.py: LayerNorm,
+    in_proj, per-head masked softmax with the replayed dropout draws, out_proj, dropout, residual) run on fp32 copies of the
+    same bf16 inputs and weights - no HIP kernel and no bf16 rounding between the steps on the reference side.  Bounds:
+    the kernel rounds LN(x), q|k|v, the probabilities and the head outputs to bf16 (2^-9 relative each); worst element
+    against the tensor's largest magnitude, mean error against its mean magnitude."""
+    flat, offs, prm = _attn_setup(seed=12)
+    rows, n_seq, S, km, seq_off, tiles, real = _attn_case(kind, seed=22)
+    x = (_rand(rows, 256, seed=32) * 1.5 + 0.3).to(torch.bfloat16)
+    img = ops.attn_pack(flat, offs, 2)
+    layer = 0
+    packed = img[layer * ops.ATTN_LAYER_ELEMS:(layer + 1) * ops.ATTN_LAYER_ELEMS]
+    oi, oo = (int(v) for v in offs[layer])
+    w32 = torch.cat([flat[oi:oi + 196608], flat[oo:oo + 65536]]).to(torch.bfloat16).float()   # the values the kernel multiplies by
+    seed = _seed_tensor(0x0BADC0FFEE123459)
+    scale = 32 ** -0.5
+    want = R.attn_block_fwd(x.float(), w32, prm["in_bias"], prm["out_bias"], prm["gamma"], prm["beta"], km, n_seq, S, scale,
+                            1e-5, p, 7, 8, seed, seq_off=seq_off, tiles=tiles, train=True)
+    got = ops.attn_block_fwd(x, packed, prm["in_bias"], prm["out_bias"], prm["gamma"], prm["beta"], km, n_seq, S, scale,
+                             1e-5, p, 7, 8, seed, seq_off=seq_off, tiles=tiles, train=True)
+    torch.cuda.synchronize()
+    assert all(w.dtype == torch.float32 for w in want)
+    r = slice(0, real)
+    for (g, w, tol, mean_tol, what) in zip(got, want, (1.5e-2, 8e-3, 8e-3, 1.5e-2, 1e-5, 1e-5),
+                                           (1e-2, 4e-3, 1e-2, 1e-2, 1e-6, 1e-6),
+                                           ("x1", "LN(x)", "q|k|v", "head outputs", "mean", "rstd")):
+        _close(g[r], w[r], tol, what)
+        err = (g[r].float() - w[r]).abs().mean().item()
+        ref = w[r].abs().mean().item()
+        assert err <= mean_tol * ref + 1e-12, f"{what}: mean abs error {err:.3e} = {err / ref:.2e} of the mean magnitude"
+
+
 @pytest.mark.parametrize("kind", ["packed", "dense31", "dense32_masked", "dense8_masked_tail", "dense10", "tiny_dense5",
                                   "one_sequence_32", "packed_extremes"])
 @pytest.mark.parametrize("p", [0.0, 0.1])
