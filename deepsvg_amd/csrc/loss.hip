@@ -239,6 +239,68 @@ __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const T* __restrict_
     }
 }
 
+// The same for bf16 rows whose `group` slots lie back to back in 16-byte-aligned token rows (the argument head: 6 - 11 slots of
+// 257 logits): a wave per TOKEN, a lane per 16-byte piece - the per-(token, slot) rows of the kernel above start at odd
+// 2-byte offsets (514 B apart), so its accesses are 2 bytes per lane (1.4 TB/s measured on the compact argument logits).
+// A piece of 8 columns touches at most two slots (C >= 8); the slots' lse / target / weight sit in lanes 0 .. group - 1.
+__global__ __launch_bounds__(256) void masked_ce_bwd_tok_kernel(const bf16_t* __restrict__ logits, long long ld, int group,
+                                                                const int* __restrict__ target, const float* __restrict__ w,
+                                                                const float* __restrict__ lse,
+                                                                const float* __restrict__ sum_count,
+                                                                const float* __restrict__ gscale, float coef,
+                                                                bf16_t* __restrict__ dlogits, long long ld_d, long long n_tok,
+                                                                int C, const int32_t* __restrict__ tok_idx,
+                                                                int logits_compact) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float g = coef * (gscale ? *gscale : 1.f) / sum_count[1];
+    const int width = group * C;
+    for (long long tok_o = (long long)blockIdx.x * 4 + wave; tok_o < n_tok; tok_o += (long long)gridDim.x * 4) {
+        const long long tok = tok_idx ? (long long)tok_idx[tok_o] : tok_o;
+        float my_w = 0.f, my_l = 0.f;
+        int my_t = 0;
+        if (lane < group && tok >= 0) {
+            const long long r = tok * group + lane;
+            my_w = w ? w[r] : 1.f;
+            my_l = lse[logits_compact ? tok_o * group + lane : r];
+            my_t = min(max(target[r], 0), C - 1) + lane * C;        // column of the token row
+        }
+        const bf16_t* p = logits + (logits_compact ? tok_o : max(tok, 0LL)) * ld;
+        bf16_t* q = dlogits + tok_o * ld_d;
+        for (int base = 0; base < ld_d; base += 512) {      // (wave-uniform trip count: the shuffles read lanes < group)
+            const int c0 = base + 8 * lane;
+            const int s0 = min(c0 / C, group - 1), s1 = min(s0 + 1, group - 1);
+            const int edge = (s0 + 1) * C;                          // first column of the next slot
+            const float w0 = __shfl(my_w, s0, 64), w1 = __shfl(my_w, s1, 64);
+            const float l0 = __shfl(my_l, s0, 64), l1 = __shfl(my_l, s1, 64);
+            const int t0 = __shfl(my_t, s0, 64), t1 = __shfl(my_t, s1, 64);
+            float v[8];
+            if (c0 < width && (w0 != 0.f || w1 != 0.f)) {
+                const uint4 raw = *reinterpret_cast<const uint4*>(p + min(c0, (int)ld - 8));
+                const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] = __uint_as_float(rw[e] << 16);
+                    v[2 * e + 1] = __uint_as_float(rw[e] & 0xffff0000u);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = c0 + e;
+                    const bool hi = c >= edge;
+                    const float wr = hi ? w1 : w0;
+                    const float sm = __expf(v[e] - (hi ? l1 : l0)) - (c == (hi ? t1 : t0) ? 1.f : 0.f);
+                    v[e] = (c < width && wr != 0.f) ? wr * g * sm : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            if (c0 < ld_d)
+                *reinterpret_cast<uint4*>(q + c0) =
+                    make_uint4(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]), f2bf_pk(v[4], v[5]), f2bf_pk(v[6], v[7]));
+        }
+    }
+}
+
 static int ce_grid(long long rows) {
     long long nb = (rows + 3) / 4;
     return (int)(nb < CE_MAX_BLOCKS ? nb : CE_MAX_BLOCKS);
@@ -284,6 +346,15 @@ extern "C" int dsvg_masked_ce_bwd(int32_t dtype, const void* logits, int64_t ld,
                    "masked_ce_bwd: bad args");
     DSVG_CHECK_ARG(ld_d >= (int64_t)group * C, "masked_ce_bwd: ld_d too small");
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSVG_BF16 && C >= 8 && group > 1 && group <= 64 && (ld % 8) == 0 && (ld_d % 8) == 0 && ld >= (int64_t)group * C
+        && ld >= 8 && (rows % group) == 0 && (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0 && ld_d < (1 << 30)) {
+        const long long n_tok = rows / group;
+        hipLaunchKernelGGL(masked_ce_bwd_tok_kernel, dim3(ce_grid(n_tok)), dim3(256), 0, st, (const bf16_t*)logits,
+                           (long long)ld, group, target, w, lse, sum_count, gscale, coef, (bf16_t*)dlogits, (long long)ld_d,
+                           n_tok, C, tok_idx, logits_compact);
+        DSVG_LAUNCH_CHECK("masked_ce_bwd (token rows)");
+        return 0;
+    }
     const int nb = ce_grid(rows);
     if (dtype == DSVG_F32)
         hipLaunchKernelGGL(masked_ce_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)logits, (long long)ld,

@@ -582,10 +582,12 @@ def test_loss_targets_and_masked_ce(gpu_device, dtype):
         _close(d, dr, 2e-6 if dtype == torch.float32 else 1e-2, "dlogits")
 
 
+@pytest.mark.parametrize("group", [11, 6])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_compact_ce_backward_live_rows_scatter(gpu_device, dtype):
-    """argument-head backward on the loss-carrying tokens only: token list, compact dlogits, row scatter"""
-    n_tok, group, C_ = 700, 11, 257
+def test_compact_ce_backward_live_rows_scatter(gpu_device, dtype, group):
+    """argument-head backward on the loss-carrying tokens only: token list, compact dlogits, row scatter (bf16 rows of
+    16-byte-aligned stride: the wave-per-token kernel; group 6 = the slot range that carries loss without arcs)"""
+    n_tok, C_ = 700, 257
     g = torch.Generator().manual_seed(4)
     w = (torch.rand(n_tok, group, generator=g) < 0.15).float()
     w[torch.rand(n_tok, generator=g) < 0.6] = 0.0            # most tokens carry no loss at all
@@ -595,7 +597,7 @@ def test_compact_ce_backward_live_rows_scatter(gpu_device, dtype):
     assert torch.equal(live, elive) and torch.equal(count, ecount)
     n_live = int(count)
     assert 0 < n_live < n_tok
-    ld = 2832
+    ld = (group * C_ + 7) // 8 * 8
     buf = _rand(n_tok, ld, dtype=dtype, seed=90)
     logits = buf[:, :group * C_]
     target = torch.randint(0, C_, (n_tok * group,), generator=g).to(torch.int32).to(DEV)
