@@ -58,6 +58,12 @@ SIGNATURES = {
     "dsvg_attention_tiles": (c_i32, [vp, c_i64, c_i32, vp, vp, vp]),
     "dsvg_pack_tokens": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, vp]),
     "dsvg_visible_first": (c_i32, [vp, c_i64, vp, vp, vp, vp]),
+    "dsvg_head_pack_elems": (c_i64, [c_i32]),
+    "dsvg_head_pack": (c_i32, [vp, c_i32, vp, vp]),
+    "dsvg_head_argmax": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, vp, vp]),
+    "dsvg_head_lse_workspace_bytes": (c_i64, [c_i64]),
+    "dsvg_head_lse": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, vp, vp, c_i64, vp]),
+    "dsvg_head_dlogits": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, vp, vp, c_f32, vp, c_i64, vp]),
     "dsvg_gather_groups": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, c_i64, vp]),
     "dsvg_build_masks": (c_i32, [vp, c_i64, c_i32, c_i32, c_i32, vp, vp, vp, vp]),
     "dsvg_embed_gather": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, vp]),

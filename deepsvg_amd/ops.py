@@ -860,6 +860,64 @@ def argmax_rows(logits2d, C, group=1):
     return out
 
 
+# ---- the argument head fused with its consumers (csrc/head_fused.hip) -------------------------------------------------------
+def head_pack(weight_lp):
+    """bf16 [n_out, 256] rows of the head in use (contiguous) -> packed MFMA fragment image for the three head_* kernels"""
+    _chk(weight_lp)
+    assert weight_lp.dtype == torch.bfloat16 and weight_lp.dim() == 2 and weight_lp.shape[1] == 256 and weight_lp.is_contiguous()
+    L = _l.load()
+    img = torch.empty(L.dsvg_head_pack_elems(weight_lp.shape[0]), dtype=torch.bfloat16, device=weight_lp.device)
+    _l.check(L.dsvg_head_pack(weight_lp.data_ptr(), weight_lp.shape[0], img.data_ptr(), _stream()), "dsvg_head_pack")
+    return img
+
+
+def _head_args(x, packed, bias, n_out, C):
+    _chk(x, packed, bias)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
+    assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == n_out and n_out % C == 0
+
+
+def head_argmax(x, packed, bias, n_out, C):
+    """-> int32 [rows * (n_out // C)]: arg-max of every C-wide slot of x @ W^T + bias, the logits never stored"""
+    _head_args(x, packed, bias, n_out, C)
+    out = torch.empty(x.shape[0] * (n_out // C), dtype=torch.int32, device=x.device)
+    _l.check(_l.load().dsvg_head_argmax(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), x.shape[0], n_out, C,
+                                        out.data_ptr(), _stream()), "dsvg_head_argmax")
+    return out
+
+
+def head_lse(x, packed, bias, n_out, C, target, w, tok_idx=None):
+    """masked CE forward on x @ W^T + bias without the logits -> (lse [rows * group], (sum, count) [2]); target / w / tok_idx
+    as masked_ce_fwd takes them (compact logits: row i of x is token tok_idx[i])"""
+    _head_args(x, packed, bias, n_out, C)
+    _chk(target, w, tok_idx)
+    rows, group = x.shape[0], n_out // C
+    assert target.dtype == torch.int32 and (w is None or w.dtype == torch.float32)
+    L = _l.load()
+    lse = torch.empty(rows * group, dtype=torch.float32, device=x.device)
+    sc = torch.empty(2, dtype=torch.float32, device=x.device)
+    nb = L.dsvg_head_lse_workspace_bytes(rows)
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
+    _l.check(L.dsvg_head_lse(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), rows, n_out, C, target.data_ptr(),
+                             w.data_ptr() if w is not None else None, tok_idx.data_ptr() if tok_idx is not None else None,
+                             lse.data_ptr(), sc.data_ptr(), ws.data_ptr(), nb, _stream()), "dsvg_head_lse")
+    return lse, sc
+
+
+def head_dlogits(x, packed, bias, n_out, C, target, w, lse, sum_count, gscale, coef, tok_idx=None):
+    """-> bf16 [rows, n_out rounded up to 8] (view of its first n_out columns): w g (softmax - onehot), logits recomputed"""
+    _head_args(x, packed, bias, n_out, C)
+    _chk(target, w, tok_idx, lse, sum_count, gscale)
+    ld = (n_out + 7) // 8 * 8
+    buf = torch.empty((x.shape[0], ld), dtype=torch.bfloat16, device=x.device)
+    _l.check(_l.load().dsvg_head_dlogits(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), x.shape[0], n_out, C,
+                                         target.data_ptr(), w.data_ptr() if w is not None else None,
+                                         tok_idx.data_ptr() if tok_idx is not None else None, lse.data_ptr(),
+                                         sum_count.data_ptr(), gscale.data_ptr() if gscale is not None else None,
+                                         float(coef), buf.data_ptr(), ld, _stream()), "dsvg_head_dlogits")
+    return buf[:, :n_out]
+
+
 def match_assign(cost, vis):
     """cost f32 [N, G, Gp], visible int32 [N, G] -> assign [N, Gp], idx [N*Gp], inv [N*Gp] (all int32)"""
     _chk(cost, vis)

@@ -369,6 +369,34 @@ int dsvg_argmax_rows(int32_t dtype, const void* logits, int64_t ld, int32_t grou
                      int32_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The argument head fused with its consumers (csrc/head_fused.hip): args_fcn = Linear(256 -> n_args *
+ * args_dim) of deepsvg/model/model.py:228-246 evaluated tile by tile on chip - the [tokens, group * C] logits never reach
+ * memory.  bf16 x [rows, 256]; `packed` = dsvg_head_pack of the head's weight rows in use ([n_out, 256] bf16, row-major,
+ * n_out = group * C with slots of C >= 64 consecutive outputs, n_out <= 3008); bias fp32 [n_out].
+ *   dsvg_head_argmax   out_idx[row * group + slot] = argmax_c logits(row, slot, c), ties -> lowest class: the temperature
+ *                      -> 0 limit of _sample_categorical (deepsvg/model/utils.py:75-80) without the logits (replaces
+ *                      the head GEMM + dsvg_argmax_rows in greedy_sample(temperature=0)).
+ *   dsvg_head_lse      the masked cross-entropy forward of SVGLoss (deepsvg/model/loss.py:51-57) on the compact token list:
+ *                      lse[row * group + slot] (0 where the weight is 0) and sum_count = (sum of w (lse - logit[target]),
+ *                      sum of w).  target / w are indexed tok * group + slot with tok = tok_idx ? tok_idx[row] : row
+ *                      (tok < 0: list padding, weight 0) exactly as dsvg_masked_ce_fwd takes them (replaces head GEMM +
+ *                      dsvg_masked_ce_fwd).  workspace: dsvg_head_lse_workspace_bytes(rows).
+ *   dsvg_head_dlogits  its backward: dlogits[row, c] = w g (softmax - onehot), g = coef * (gscale ? *gscale : 1) /
+ *                      sum_count[1], bf16 [rows, ld_d], ld_d = n_out rounded up to a multiple of 8, padding columns zero
+ *                      (replaces a second head GEMM + dsvg_masked_ce_bwd; the logits are recomputed on chip). */
+int64_t dsvg_head_pack_elems(int32_t n_out);
+int dsvg_head_pack(const void* weight_bf16, int32_t n_out, void* packed, void* stream);
+int dsvg_head_argmax(const void* x, const void* packed, const float* bias, int64_t rows, int32_t n_out, int32_t C,
+                     int32_t* out_idx, void* stream);
+int64_t dsvg_head_lse_workspace_bytes(int64_t rows);
+int dsvg_head_lse(const void* x, const void* packed, const float* bias, int64_t rows, int32_t n_out, int32_t C,
+                  const int32_t* target, const float* w, const int32_t* tok_idx, float* lse, float* sum_count,
+                  float* workspace, int64_t workspace_bytes, void* stream);
+int dsvg_head_dlogits(const void* x, const void* packed, const float* bias, int64_t rows, int32_t n_out, int32_t C,
+                      const int32_t* target, const float* w, const int32_t* tok_idx, const float* lse,
+                      const float* sum_count, const float* gscale, float coef, void* dlogits, int64_t ld_d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Device-side batch assembly.  Replaces, for a whole batch, the per-item chain of
  * SVGTensorDataset.get_data (deepsvg/svgtensor_dataset.py:164-205): SVGTensor.from_data(...).add_eos().add_sos()
  * .pad(seq_len) (deepsvg/difflib/tensor.py:85-88,108-116,125-143), .cmds()/.args()/.get_relative_args()

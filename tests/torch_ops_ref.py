@@ -852,6 +852,34 @@ def attn_pack(flat, offs, n_layers, packed=None):
     return packed
 
 
+# ------------------------------------------------------------------------------------------------
+# the argument head fused with its consumers (csrc/head_fused.hip).  The emulated image is the bf16 weight itself; the
+# restatement is head GEMM (fp32 accumulation, logits NOT rounded to bf16 - they never leave the chip) + the masked-CE math.
+# ------------------------------------------------------------------------------------------------
+def head_pack(weight_lp):
+    return weight_lp.clone()
+
+
+def _head_logits(x, packed, bias, n_out):
+    return x.float() @ packed[:n_out].float().t() + bias.float()
+
+
+def head_argmax(x, packed, bias, n_out, C):
+    lg = _head_logits(x, packed, bias, n_out).view(x.shape[0], n_out // C, C)
+    return lg.argmax(-1).to(torch.int32).reshape(-1)
+
+
+def head_lse(x, packed, bias, n_out, C, target, w, tok_idx=None):
+    return masked_ce_fwd(_head_logits(x, packed, bias, n_out), target, w, C, n_out // C, tok_idx=tok_idx)
+
+
+def head_dlogits(x, packed, bias, n_out, C, target, w, lse, sum_count, gscale, coef, tok_idx=None):
+    lg = _head_logits(x, packed, bias, n_out)
+    d = masked_ce_bwd(lg, target, w, lse, sum_count, gscale, coef, C, n_out // C, pad_to=8, tok_idx=tok_idx,
+                      logits_compact=tok_idx is not None)
+    return d.to(torch.bfloat16)
+
+
 def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_seq, S, scale, eps=1e-5, drop_p=0.0,
                    site_probs=0, site_res=0, seed=None, seq_off=None, tiles=None, train=False, seq_add=None, site_seq_add=0):
     """the unfused launches, composed (LayerNorm -> in_proj -> attention -> out_proj + dropout + residual [-> bcast add])"""
