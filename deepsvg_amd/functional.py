@@ -38,6 +38,11 @@ FFN_BWD_MASKED = os.environ.get("DSVG_FFN_BWD_MASKED", "0") != "0"
 
 # the weight-gradient GEMMs of a layer of the 4096-row stages as one grouped launch (DSVG_GROUP_WGRAD=0: one by one)
 GROUP_WGRAD = os.environ.get("DSVG_GROUP_WGRAD", "1") != "0"
+# argument head + masked CE with the logit tile on chip, forward and backward (csrc/head_fused.hip) instead of head GEMM ->
+# stored compact logits -> masked-CE kernels.  Opt-in: on the compact token list the stored logits are only ~120 MB, and
+# recomputing the tile in the backward pass costs as much as reading them - measured 7.02 vs 6.99 ms/step (same box, three
+# alternating runs).  Decoding (greedy_sample at temperature 0) always uses the fused head + arg-max kernel.
+HEAD_FUSED = os.environ.get("DSVG_HEAD_FUSED", "0") != "0"
 
 _NULL_CTX = contextlib.nullcontext()
 
@@ -795,12 +800,21 @@ class ArgsHeadLossFn(torch.autograd.Function):
         b_used = bias.detach()[r0:r1]
         if b_used.data_ptr() % 16:
             b_used = b_used.clone()                                # (the GEMM epilogue reads the bias in 16-byte pieces)
-        mult = 4 if xc.dtype == torch.float32 else 8
-        ld = (n_out + mult - 1) // mult * mult
-        buf = torch.empty((R, ld), dtype=xc.dtype, device=xc.device)
-        logits_c = buf[:, :n_out]
-        ops.gemm(xc, w_used, bias=b_used, out=logits_c)
-        lse, sc = ops.masked_ce_fwd(logits_c, target, w, C_, group, tok_idx=idx)
+        ctx.head_img = None
+        if HEAD_FUSED and xc.dtype == torch.bfloat16 and xc.shape[1] == 256 and C_ >= 64 and n_out <= 3008:
+            # the logit tile stays on chip (csrc/head_fused.hip): log-sum-exp, target logit and the loss sums in one launch;
+            # backward recomputes the tile and emits dlogits directly - the [R, n_out] logits are never stored
+            ctx.head_img = ops.head_pack(w_used if w_used.is_contiguous() else w_used.contiguous())
+            logits_c = None
+            lse, sc = ops.head_lse(xc, ctx.head_img, b_used, n_out, C_, target, w, tok_idx=idx)
+        else:
+            mult = 4 if xc.dtype == torch.float32 else 8
+            ld = (n_out + mult - 1) // mult * mult
+            buf = torch.empty((R, ld), dtype=xc.dtype, device=xc.device)
+            logits_c = buf[:, :n_out]
+            ops.gemm(xc, w_used, bias=b_used, out=logits_c)
+            lse, sc = ops.masked_ce_fwd(logits_c, target, w, C_, group, tok_idx=idx)
+        ctx.b_used = b_used
         if count_fn is not None:
             sc = torch.stack([sc[0], count_fn(sc[1].clone()).to(sc.dtype).reshape(())])
         ctx.rt, ctx.C_, ctx.group, ctx.rows_full, ctx.rows_used = rt, C_, group, x.shape[0], (r0, r1)
@@ -836,10 +850,13 @@ class ArgsHeadLossFn(torch.autograd.Function):
             xc, weight, bias, logits_c, target, w, lse, sc, idx = ctx.saved_tensors
             dsc, = dscs
         g = dsc[0:1].to(torch.float32).contiguous()
-        mult = 4 if logits_c.dtype == torch.float32 else 8
-        dl = ops.masked_ce_bwd(logits_c, target, w, lse, sc, g, 1.0, ctx.C_, ctx.group, pad_to=mult, tok_idx=idx,
-                               logits_compact=True)
         r0, r1 = ctx.rows_used
+        if ctx.head_img is not None:
+            dl = ops.head_dlogits(xc, ctx.head_img, ctx.b_used, r1 - r0, ctx.C_, target, w, lse, sc, g, 1.0, tok_idx=idx)
+        else:
+            mult = 4 if logits_c.dtype == torch.float32 else 8
+            dl = ops.masked_ce_bwd(logits_c, target, w, lse, sc, g, 1.0, ctx.C_, ctx.group, pad_to=mult, tok_idx=idx,
+                                   logits_compact=True)
         if (r0, r1) == (0, weight.shape[0]):
             dw, db = _wbgrad(rt, weight, bias, dl, xc)
             dxc = ops.gemm(dl, rt.w(weight), b_kc=False)

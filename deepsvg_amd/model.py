@@ -925,6 +925,16 @@ class SVGTransformer(nn.Module):
             return al.view(N, G, S, n_args, args_dim)
         args_logits = make_args_logits if lazy_args else make_args_logits()
         self._head_in = out         # input of the heads (for the fused argument head + loss)
+        self._head_argmax = None
+        if out.dtype == torch.bfloat16 and out.shape[1] == 256 and args_dim >= 64 and n_args * args_dim <= 3008:
+            # decoding at temperature 0: arg-max per (token, argument slot) with the head's logit tile on chip
+            # (csrc/head_fused.hip) instead of the dense (N, G, S, n_args, args_dim) logits + an arg-max pass over them
+            def head_argmax():
+                src = out if complete is None else complete()
+                img = ops.head_pack(rt.w(fcn.weight))
+                return ops.head_argmax(src.detach().contiguous(), img, fcn.bias.detach().float().contiguous(),
+                                       n_args * args_dim, args_dim).view(N, G, S, n_args)
+            self._head_argmax = head_argmax
         self._cmd_logits_live = None
         if complete is not None:
             # valid on the groups that ran (every loss-carrying row is among them): what deepsvg_amd.SVGLoss reads
@@ -1027,6 +1037,10 @@ class SVGTransformer(nn.Module):
             return (vis.to(torch.float32).view(N, G, 2).permute(1, 0, 2).unsqueeze(0),
                     zg.to(torch.float32).view(N, G, -1).permute(1, 0, 2).unsqueeze(0))
         lazy_args = bool(return_tgt and plan is not None and plan.get("loss") is not None)
+        # a sampling call (greedy_sample): the dense argument logits are only built if somebody reads them - at temperature 0
+        # the arg-max comes from the fused head kernel
+        sampling = not return_tgt and not torch.is_grad_enabled() and cfg.pred_mode != "autoregressive" and not cfg.self_match
+        lazy_args = lazy_args or sampling
         match = None
         if cfg.self_match and return_tgt and commands_dec is not None:      # train-mode call (model.py:384)
             if cfg.decode_stages != 2:
@@ -1051,6 +1065,9 @@ class SVGTransformer(nn.Module):
             res["args_logits"] = args_logits
         if cfg.decode_stages == 2:
             res["visibility_logits"] = vis_logits
+        if sampling and getattr(self, "_head_argmax", None) is not None:
+            res["_dsvg_head_argmax"] = dict(fn=self._head_argmax)
+        self._head_argmax = None
         if return_tgt:
             res["tgt_commands"] = commands_dec
             res["tgt_args"] = args_dec
@@ -1091,7 +1108,11 @@ class SVGTransformer(nn.Module):
         else:
             res = self.forward(commands_enc, args_enc, commands_dec, args_dec, label=label, z=z,
                                hierarch_logits=hierarch_logits, return_tgt=False)
-            commands_y, args_y = self._sample(res["command_logits"], res["args_logits"], temperature)
+            arg_src = None
+            if temperature == 0 and res.is_pending("args_logits"):
+                arg_src = (dict.get(res, "_dsvg_head_argmax") or {}).get("fn")    # fused head + arg-max of this forward
+            commands_y, args_y = self._sample(res["command_logits"], arg_src if arg_src is not None else res["args_logits"],
+                                              temperature)
             args_y -= 1   # shift due to -1 PAD_VAL
             visibility_y = None
             if self.cfg.decode_stages == 2:
@@ -1111,6 +1132,12 @@ class SVGTransformer(nn.Module):
         """_sample_categorical (deepsvg/model/utils.py:75-80): a draw from softmax(logits / temperature) per slot.
         temperature == 0 (an extension: the reference would divide by zero) takes the limit exactly - the arg-max
         kernel reads the logits in their storage dtype, no fp32 copy / softmax / multinomial over the 2827-wide rows."""
+        if temperature == 0 and callable(args_logits):
+            # (N, G, S, n_args) arg-max straight from the head's input: the logit tile never leaves the chip
+            cs = command_logits.shape
+            cl = command_logits.reshape(-1, cs[-1])
+            cmd = ops.argmax_rows(cl if cl.stride(-1) == 1 else cl.contiguous(), cs[-1]).long().view(cs[:-1])
+            return cmd, args_logits().long().view(*cs[:-1], -1)
         if temperature == 0:
             cs, as_ = command_logits.shape, args_logits.shape
             cl = command_logits.reshape(-1, cs[-1])

@@ -83,8 +83,18 @@ def main():
     def one_shot_argmax():
         return [model.greedy_sample(z=z[i:i + 1024], concat_groups=False, temperature=0) for i in range(0, N, 1024)]
     sec = timed(one_shot_argmax, 2)
-    print(f"C5a' same with temperature = 0 (arg-max kernel on the bf16 logits instead of the categorical draw): "
+    print(f"C5a' same with temperature = 0 (argument head + arg-max in one kernel, the logits never stored): "
           f"{sec * 1e3:.0f} ms, {N / sec:,.0f} icons/s")
+    def one_shot_argmax_unfused():      # round 2's temperature-0 path: dense bf16 argument logits + an arg-max pass over them
+        out = []
+        with torch.no_grad():
+            for i in range(0, N, 1024):
+                res = model.forward(None, None, None, None, z=z[i:i + 1024], return_tgt=False)
+                out.append(model._sample(res["command_logits"], res["args_logits"], 0))
+        return out
+    sec_u = timed(one_shot_argmax_unfused, 2)
+    print(f"C5a'' forward + dense bf16 argument logits + arg-max kernel over them (round 2's temperature-0 path, without the "
+          f"validity fix-ups of greedy_sample): {sec_u * 1e3:.0f} ms")
     del model
 
     # ---- C5b -------------------------------------------------------------------------------------------------

@@ -561,3 +561,72 @@ def test_fused_group_stage_path_matches_unfused_with_emulated_ops(emulated_ops):
     model.eval()
     with torch.no_grad():
         model(c, a, c, a, params={})
+
+
+def test_fused_argument_head_path_with_emulated_ops(emulated_ops):
+    """bf16 compute: SVGLoss takes loss_args from head_lse / head_dlogits (the logit tile never stored) and
+    greedy_sample(temperature=0) its arguments from head_argmax.  With the emulated ops the only difference to the unfused
+    pair is that the logits are not rounded to bf16 in between: loss and gradients agree to that rounding, the decoded
+    arguments to logit ties."""
+    from deepsvg_amd.synthetic import make_batch
+    from deepsvg_amd import ops
+    import deepsvg_amd.functional as Fn
+    cfg = H.build_cfg("hier")
+    cfg.n_layers = cfg.n_layers_decode = 1
+    c, a = make_batch(6, seed=11)
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 9)
+    res, calls = {}, {}
+    saved = (ops.head_lse, ops.head_dlogits, Fn.HEAD_FUSED)
+    try:
+        for fused in (True, False):
+            n_calls = [0, 0]
+
+            def counted_f(*args, _f=saved[0], **kw):
+                n_calls[0] += 1
+                return _f(*args, **kw)
+
+            def counted_b(*args, _f=saved[1], **kw):
+                n_calls[1] += 1
+                return _f(*args, **kw)
+            ops.head_lse, ops.head_dlogits, Fn.HEAD_FUSED = counted_f, counted_b, fused
+            model = deepsvg_amd.SVGTransformer(cfg).eval()
+            model.load_state_dict(sd)
+            model.set_compute_dtype(torch.bfloat16)
+            out = model(c, a, c, a, params={})
+            ld = deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
+            ld["loss"].backward()
+            assert out.is_pending("args_logits")
+            res[fused] = ({k: float(v) for k, v in ld.items()}, {n: p.grad.clone() for n, p in model.named_parameters()})
+            calls[fused] = tuple(n_calls)
+    finally:
+        ops.head_lse, ops.head_dlogits, Fn.HEAD_FUSED = saved
+    assert calls[True] == (1, 1) and calls[False] == (0, 0)
+    assert abs(res[True][0]["loss_args"] - res[False][0]["loss_args"]) <= 3e-3 * abs(res[False][0]["loss_args"])
+    assert res[True][0]["loss_cmd"] == res[False][0]["loss_cmd"]
+    for n in res[True][1]:
+        assert H.rel_l2(res[True][1][n], res[False][1][n]) < 2e-2, n
+    # decoding
+    model = deepsvg_amd.SVGTransformer(cfg).eval()
+    model.load_state_dict(sd)
+    model.set_compute_dtype(torch.bfloat16)
+    n_arg = [0]
+    saved_am = ops.head_argmax
+
+    def counted_am(*args, **kw):
+        n_arg[0] += 1
+        return saved_am(*args, **kw)
+    ops.head_argmax = counted_am
+    try:
+        cy, ay = model.greedy_sample(c, a, temperature=0, concat_groups=False)
+    finally:
+        ops.head_argmax = saved_am
+    assert n_arg[0] == 1
+    with torch.no_grad():
+        out = model(c, a, None, None, return_tgt=False)
+        assert out.is_pending("args_logits")
+        cy2, ay2 = model._sample(out["command_logits"], out["args_logits"], 0)
+        ay2 = ay2 - 1
+        vis = (torch.softmax(out["visibility_logits"].float(), dim=-1)[..., 1] > 0.7).squeeze(-1)
+        cy2, ay2 = model._make_valid(cy2, ay2, vis)
+    assert torch.equal(cy, cy2)
+    assert (ay != ay2).float().mean().item() < 5e-3
