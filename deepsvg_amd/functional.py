@@ -38,6 +38,7 @@ FFN_BWD_MASKED = os.environ.get("DSVG_FFN_BWD_MASKED", "0") != "0"
 
 # the weight-gradient GEMMs of a layer of the 4096-row stages as one grouped launch (DSVG_GROUP_WGRAD=0: one by one)
 GROUP_WGRAD = os.environ.get("DSVG_GROUP_WGRAD", "1") != "0"
+GROUP_LARGE = os.environ.get("DSVG_GROUP_LARGE", "0") != "0"
 # argument head + masked CE with the logit tile on chip, forward and backward (csrc/head_fused.hip) instead of head GEMM ->
 # stored compact logits -> masked-CE kernels.  Opt-in: on the compact token list the stored logits are only ~120 MB, and
 # recomputing the tile in the backward pass costs as much as reading them - measured 7.02 vs 6.99 ms/step (same box, three
@@ -608,6 +609,12 @@ class LayerFn(torch.autograd.Function):
             return (None, dx, None, dz, None, None, None, None, None, None,
                     dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, None, None, None, None, None,
                     None)
+        # DSVG_GROUP_LARGE: the layer's four token-reducing weight-gradient GEMMs as ONE grouped launch at the end of its
+        # backward pass (their operands are kept alive until then) instead of four launches right behind their producers
+        keep = []
+        group = contextlib.ExitStack()
+        if GROUP_LARGE and x.dtype == torch.bfloat16:
+            group.enter_context(rt.grouping())
         if ctx.ffn_fused:
             pb, b1f, w2p = rt.store.ffn(w1)[1:]
             T = x1.shape[0]
@@ -672,6 +679,7 @@ class LayerFn(torch.autograd.Function):
                     ops.defer_post(finish)      # reads the queued reductions' outputs: runs right after the flush
                 else:
                     finish()
+            keep += [hp, dpre, xh, dym]
             del hp, dpre, xh, dym
         else:
             # ---- FFN: x2 = x1 + drop4(h W2^T + b2),  h = drop3(relu(xn2 W1^T + b1)) ----
@@ -685,6 +693,7 @@ class LayerFn(torch.autograd.Function):
                 with rt.deferring():
                     dx1, dn2w, dn2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w.detach(), res=dx2,
                                                         dgamma=rt.grad_out(n2w), dbeta=rt.grad_out(n2b))
+            keep += [dx2m, dh]
             del dx2m
         # ---- conditioning adds ----
         dz = dl = dwg = dbg = dwg2 = dbg2 = None
@@ -707,6 +716,7 @@ class LayerFn(torch.autograd.Function):
             dx1m = ops.drop_apply(dx1, p, s0 + 1, rt.seed)
         dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao)
         dao = ops.gemm(dx1m, rt.w(wo), b_kc=False)
+        keep.append(dx1m)
         del dx1m
         if ctx.causal:
             dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed, causal=True)
@@ -724,6 +734,8 @@ class LayerFn(torch.autograd.Function):
                                                dgamma=rt.grad_out(n1w), dbeta=rt.grad_out(n1b))
         if live is not None:
             dx = dx_full
+        group.close()           # (the grouped launch, if any; `keep` and the locals above held its operands)
+        del keep
         return (None, dx, None, dz, dl, None, None, None, None, None,
                 dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, dwg2, dbg2, None, None, None,
                 None)

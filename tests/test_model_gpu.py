@@ -451,6 +451,33 @@ def test_head_on_the_loss_carrying_slot_range_is_exact(gpu_device, dtype):
     assert torch.count_nonzero(gw[:5 * 257]) == 0 and torch.count_nonzero(gw[5 * 257:]) > 0
 
 
+def test_fused_argument_head_and_loss_in_the_model(gpu_device):
+    """bf16 training step with the argument head + masked CE on the fused kernels (csrc/head_fused.hip: logits never stored,
+    recomputed in the backward pass) against the default head GEMM -> bf16 logits -> masked-CE kernels: the two differ by
+    the bf16 rounding of the stored logits only.  With and without the slot-range restriction (6 / 11 slots)."""
+    import deepsvg_amd.functional as Fn
+    cfg = H.build_cfg("hier")
+    commands, args = make_batch(24, seed=33)
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 18)
+    saved = Fn.HEAD_FUSED
+    try:
+        for slot_range in (True, False):
+            res = {}
+            for fused in (True, False):
+                Fn.HEAD_FUSED = fused
+                model = _hip_model(cfg, sd, torch.bfloat16).eval()
+                model.head_slot_range = slot_range
+                ops.PROFILE.clear()
+                out, ld, grads = _fwd_bwd(model, cfg, commands, args)
+                res[fused] = (ld, grads)
+            for k in res[True][0]:
+                assert abs(res[True][0][k] - res[False][0][k]) <= 2e-3 * max(1.0, abs(res[False][0][k])), k
+            worst, name = max((H.rel_l2(res[True][1][n], res[False][1][n]), n) for n in res[True][1])
+            assert worst < 3e-2, (worst, name)
+    finally:
+        Fn.HEAD_FUSED = saved
+
+
 def test_data_parallel_step_over_rccl_one_rank(gpu_device):
     """The data-parallel TrainStep on a ONE-rank RCCL group (force_ddp): eager (count all-reduce inside the loss, two
     overlapped gradient buckets) and hipGraph mode (count all-reduce before the graph, graph = forward + backward, gradient
