@@ -140,6 +140,18 @@ __device__ __forceinline__ void store_image(bf16_t* dst, long long ld_dst, const
         *reinterpret_cast<uint4*>(dst + (long long)r * ld_dst + 8 * c) = *reinterpret_cast<const uint4*>(img + r * ld + col0 + 8 * c);
     }
 }
+// hidden image [S][512] -> global rows with fragment-ordered columns (position p holds unit (p & ~12) | ((p & 4) << 1) |
+// ((p & 8) >> 1), csrc/ffn_fused.hip frag_pos): the 16-byte piece q of a row = the 8-byte granules at columns
+// 16 (q >> 1) + 4 (q & 1) and + 8
+__device__ __forceinline__ void store_image_frag512(bf16_t* dst, const bf16_t* img, int ld, int S) {
+    for (int idx = threadIdx.x; idx < S * 64; idx += 512) {
+        const int r = idx >> 6, q = idx & 63;
+        const int c0 = 16 * (q >> 1) + 4 * (q & 1);
+        const uint2 lo = *reinterpret_cast<const uint2*>(img + r * ld + c0);
+        const uint2 hi = *reinterpret_cast<const uint2*>(img + r * ld + c0 + 8);
+        *reinterpret_cast<uint4*>(dst + (long long)r * GF + 8 * q) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+}
 // global rows -> image (rows >= S: a copy of row S - 1, finite values that are computed on but never stored)
 __device__ __forceinline__ void load_image(bf16_t* img, int ld, int col0, const bf16_t* src, long long ld_src, int S, int cols) {
     const int cpr = cols / 8;
@@ -219,6 +231,10 @@ struct GsFwdArgs {
     int n_seq, S;
     float eps, scale, drop_p;
     uint32_t site0;
+    long long seq_base;     // the launch covers sequences seq_base .. seq_base + n_seq - 1 of a longer buffer: the pointers are
+                            // those of its first row, the dropout draws are indexed from the buffer's first row / sequence
+    int ffn_format;         // training outputs of the FFN half as csrc/ffn_fused.hip's backward reads them: xn2 = the
+                            // affine-free (x1 - mean2) rstd2, h with fragment-ordered columns (frag_pos)
 };
 
 // LDS layout of the forward kernel (bytes)
@@ -248,6 +264,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
     bf16_t* AO = reinterpret_cast<bf16_t*>(smem + F_AO);
     bf16_t* QKV = reinterpret_cast<bf16_t*>(smem + F_QKV);
     bf16_t* HI = QKV;
+    bf16_t* XH = QKV + (32 * LDQ - 32 * GD);            // [32][256] behind the hidden image (32 * LDH elements), ffn_format only
     float* sbin = reinterpret_cast<float*>(smem + F_SMALL);
     float* sbo = sbin + 768;
     float* sb1 = sbo + 256;
@@ -341,6 +358,8 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
     const DropCtx dh = drop_make_v(a.drop_p, has_seed, seedv, a.site0 + 3);
     const DropCtx dr2 = drop_make_v(a.drop_p, has_seed, seedv, a.site0 + 4);
     const long long m = row0 + li;                      // this lane's row (result tiles: lane = row li)
+    const uint64_t dseq = (uint64_t)(my_seq + a.seq_base);              // ... and their indices for the dropout draws
+    const uint64_t drow = (uint64_t)(m + a.seq_base * Smax);
     const bool live = li < S;
     const long long mrow = row0 + min(li, S - 1);
     const int qc = wave * 32, kc = GD + wave * 32, vc = 2 * GD + wave * 32;
@@ -404,7 +423,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.f / l;
         // dropout row of (sequence s, head h, query i) = (s H + h) Smax + i; query and key counted inside the sequence
-        const uint32_t hrow = attn_drop_row(dp, ((uint64_t)my_seq * GH + wave) * Smax + (li - my_start), 0);
+        const uint32_t hrow = attn_drop_row(dp, (dseq * GH + wave) * Smax + (li - my_start), 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) p[r] = p[r] * inv * attn_drop_key(dp, hrow, (uint32_t)(rowmap(r, h2) - my_start));
         if (!live) {
@@ -455,8 +474,8 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         for (int c = 0; c < 4; ++c) {
             // columns qc + 8 c + 4 h2 .. + 3: half of the aligned group of 8 the standard draws are made for
             float dm[4], gm[4];
-            drop_mult4(dr1, (uint64_t)m * GD + qc + 8 * c, h2, dm);
-            if (a.gadd) drop_mult4(dg, (uint64_t)my_seq * GD + qc + 8 * c, h2, gm);
+            drop_mult4(dr1, drow * GD + qc + 8 * c, h2, dm);
+            if (a.gadd) drop_mult4(dg, dseq * GD + qc + 8 * c, h2, gm);
             const float xv[4] = {__uint_as_float(xr[c].x << 16), __uint_as_float(xr[c].x & 0xffff0000u),
                                  __uint_as_float(xr[c].y << 16), __uint_as_float(xr[c].y & 0xffff0000u)};
 #pragma unroll
@@ -491,10 +510,18 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         // every wave is past B2a: nobody reads XN (in_proj) or AO (out_proj) any more
         stage_rows(XN, LDX, li, qc, h2, t);
         if (TRAIN) stage_rows(AO, LDX, li, qc, h2, x1v);
+        if (TRAIN && a.ffn_format) {
+            // the affine-free rows for the fused FFN backward, staged behind the hidden image's extent in the (dead) q|k|v
+            // region: [32][256], unpadded - written once, its bank conflicts do not matter
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = (x1v[r] - mean2) * rstd2;
+            stage_rows(XH, GD, li, qc, h2, t);
+        }
     }
     lds_barrier();                                       // B2c: LN2(x1) (and x1) complete
     if (TRAIN) {
-        store_image(a.xn2 + row0 * GD, GD, XN, LDX, 0, S, GD);
+        if (a.ffn_format) store_image(a.xn2 + row0 * GD, GD, XH, GD, 0, S, GD);
+        else store_image(a.xn2 + row0 * GD, GD, XN, LDX, 0, S, GD);
         store_image(a.x1 + row0 * GD, GD, AO, LDX, 0, S, GD);
         if (wave == 0 && h2 == 0 && live) { a.mean2[m] = mean2; a.rstd2[m] = rstd2; }
     }
@@ -524,7 +551,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float dm[4];
-                drop_mult4(dh, (uint64_t)m * GF + hc + 8 * c, h2, dm);
+                drop_mult4(dh, drow * GF + hc + 8 * c, h2, dm);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float pre = (jj ? h1[4 * c + e] : h0[4 * c + e]) + sb1[hc + 8 * c + 4 * h2 + e];
@@ -535,7 +562,10 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         }
     }
     lds_barrier();                                       // B3: the hidden activations of the tile are in LDS
-    if (TRAIN) store_image(a.h + row0 * GF, GF, HI, LDH, 0, S, GF);
+    if (TRAIN) {
+        if (a.ffn_format) store_image_frag512(a.h + row0 * GF, HI, LDH, S);
+        else store_image(a.h + row0 * GF, GF, HI, LDH, 0, S, GF);
+    }
 
     // ---- phase 4: linear2 column block `wave`, bias, dropout, residual -> x2 ----------------------------------------------------
     {
@@ -556,7 +586,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float dm[4];
-            drop_mult4(dr2, (uint64_t)m * GD + qc + 8 * c, h2, dm);
+            drop_mult4(dr2, drow * GD + qc + 8 * c, h2, dm);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 t[4 * c + e] = (ya[4 * c + e] + sb2[qc + 8 * c + 4 * h2 + e]) * dm[e] + x1v[4 * c + e];
@@ -1023,10 +1053,12 @@ extern "C" int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, co
                                  const float* gamma2, const float* beta2, const uint64_t* key_mask, const void* seq_add,
                                  int64_t n_seq, int32_t S, void* x2, float* mean1, float* rstd1, void* xn1, void* qkv,
                                  void* ao, void* x1, float* mean2, float* rstd2, void* xn2, void* h, float eps,
-                                 float scale, float drop_p, uint32_t site0, const void* seed, void* stream) {
+                                 float scale, float drop_p, uint32_t site0, const void* seed, int64_t seq_base,
+                                 int32_t ffn_format, void* stream) {
     DSVG_CHECK_ARG(x && packed_fwd_layer && in_bias && out_bias && b1 && b2 && gamma1 && beta1 && gamma2 && beta2 && x2,
                    "gs_layer_fwd: null pointer");
-    DSVG_CHECK_ARG(S >= 1 && S <= 32 && (32 % S) == 0, "gs_layer_fwd: sequence length must divide 32 (got %d)", S);
+    DSVG_CHECK_ARG(S >= 1 && S <= 32, "gs_layer_fwd: sequences of 1 .. 32 rows (got %d)", S);
+    DSVG_CHECK_ARG(seq_base >= 0 && (seq_base + n_seq) * S < (1ll << 31), "gs_layer_fwd: bad sequence offset");
     DSVG_CHECK_ARG(n_seq > 0 && n_seq * S < (1ll << 31), "gs_layer_fwd: bad sizes");
     DSVG_CHECK_ARG(!(drop_p > 0.f) || seed, "gs_layer_fwd: dropout needs a seed");
     const bool train = xn1 != nullptr;
@@ -1043,6 +1075,7 @@ extern "C" int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, co
     a.x2 = (bf16_t*)x2; a.mean1 = mean1; a.rstd1 = rstd1; a.xn1 = (bf16_t*)xn1; a.qkv = (bf16_t*)qkv; a.ao = (bf16_t*)ao;
     a.x1 = (bf16_t*)x1; a.mean2 = mean2; a.rstd2 = rstd2; a.xn2 = (bf16_t*)xn2; a.h = (bf16_t*)h;
     a.n_seq = (int)n_seq; a.S = S; a.eps = eps; a.scale = scale; a.drop_p = drop_p; a.site0 = site0;
+    a.seq_base = seq_base; a.ffn_format = ffn_format;
     const int per = 32 / S;
     const int nb = (int)((n_seq + per - 1) / per);
     hipStream_t st = (hipStream_t)stream;

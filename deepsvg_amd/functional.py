@@ -39,6 +39,10 @@ FFN_BWD_MASKED = os.environ.get("DSVG_FFN_BWD_MASKED", "0") != "0"
 # the weight-gradient GEMMs of a layer of the 4096-row stages as one grouped launch (DSVG_GROUP_WGRAD=0: one by one)
 GROUP_WGRAD = os.environ.get("DSVG_GROUP_WGRAD", "1") != "0"
 GROUP_LARGE = os.environ.get("DSVG_GROUP_LARGE", "0") != "0"
+# training forward of a large dense stage: sequences beyond a multiple of SEQ_ROUND (one round of the chip for the fused
+# attention kernel: 256 CUs x 8 sequences) run on the group-stage layer kernel when there are at most this many (0: never)
+GS_REMAINDER = int(os.environ.get("DSVG_GS_REMAINDER", "512"))
+SEQ_ROUND = 2048
 # argument head + masked CE with the logit tile on chip, forward and backward (csrc/head_fused.hip) instead of head GEMM ->
 # stored compact logits -> masked-CE kernels.  Opt-in: on the compact token list the stored logits are only ~120 MB, and
 # recomputing the tile in the backward pass costs as much as reading them - measured 7.02 vs 6.99 ms/step (same box, three
@@ -506,7 +510,43 @@ class LayerFn(torch.autograd.Function):
                 and (key_mask is None or key_mask.dtype == torch.int64)):
             att = rt.store.attn(win)
         z_fused = False
-        if att is not None:
+        split = 0
+        if (att is not None and want_bwd and GS_REMAINDER > 0 and seq_off is None and key_mask is None and l is None
+                and x.shape[0] == n_seq * S and x.shape[0] >= FFN_MIN_ROWS and n_seq > SEQ_ROUND):
+            # The fused kernels of the large stages own a CU per workgroup (8 sequences / 256 rows each): a launch of 2048 k + r
+            # sequences pays k + 1 full rounds of the chip for any r > 0.  The training forward therefore runs the first
+            # 2048 k sequences on them and the remainder on the one-tile-per-workgroup layer kernel of the group stages
+            # (csrc/group_stage.hip, one launch for the whole block), both writing row slices of the same saved tensors.
+            rem = n_seq % SEQ_ROUND
+            if 0 < rem <= GS_REMAINDER and rt.store.gs(win) is not None and rt.store.ffn(w1) is not None:
+                split = n_seq - rem
+        if split:
+            gsr, ffn = rt.store.gs(win), rt.store.ffn(w1)
+            T, R0 = x.shape[0], split * S
+            bf = lambda w_: torch.empty((T, w_), dtype=x.dtype, device=x.device)
+            f32 = lambda n_: torch.empty(n_, dtype=torch.float32, device=x.device)
+            x1, xn1, qkv, ao, mean1, rstd1 = bf(256), bf(256), bf(768), bf(256), f32(T), f32(T)
+            x2, h, xn2 = bf(256), bf(512), bf(256)
+            g = None
+            if z is not None:
+                g = z if wg is None else ops.gemm(z, rt.w(wg), bias=bg.detach())
+                z_fused = True
+            with ops.tag("attn"):
+                ops.attn_block_fwd(x[:R0], att, bin_.detach(), bo.detach(), n1w.detach(), n1b.detach(), None, split, S, scale,
+                                   1e-5, p, site0, site0 + 1, rt.seed, train=True, seq_add=None if g is None else g[:split],
+                                   site_seq_add=site0 + 2,
+                                   into=(x1[:R0], xn1[:R0], qkv[:R0], ao[:R0], mean1[:R0], rstd1[:R0]))
+            with ops.tag("ffn"):
+                ops.ffn_fwd(x1[:R0], ffn[0], ffn[2], b2.detach(), 1e-5, p, site0 + 3, site0 + 4, rt.seed, out=x2[:R0],
+                            train=True, into=(h[:R0], xn2[:R0]))
+            with ops.tag("gs"):
+                ops.gs_layer_fwd(x[R0:], gsr[0], bin_.detach(), bo.detach(), b1.detach(), b2.detach(), n1w.detach(),
+                                 n1b.detach(), n2w.detach(), n2b.detach(), None, n_seq - split, S, scale, 1e-5, p, site0,
+                                 rt.seed, seq_add=None if g is None else g[split:], train=True, seq_base=split, ffn_format=True,
+                                 into=(x2[R0:], mean1[R0:], rstd1[R0:], xn1[R0:], qkv[R0:], ao[R0:], x1[R0:], f32(T - R0),
+                                       f32(T - R0), xn2[R0:], h[R0:]))
+            mean2 = rstd2 = None
+        elif att is not None:
             # one launch: LayerNorm, in_proj, the 8 heads, out_proj, dropout, residual (csrc/attn_fused.hip) - and the
             # decoder's per-sequence conditioning add when the layout is dense and every row belongs to a sequence.  With a
             # backward pass ahead it also stores LN(x), q|k|v, the head outputs and the row statistics
@@ -540,7 +580,9 @@ class LayerFn(torch.autograd.Function):
             ops.bcast_add_fwd_(x1, g2, n_seq, S, p, site0 + 5, rt.seed)
         ffn = rt.store.ffn(w1) if (rt.store is not None and x.dtype == torch.bfloat16 and x.shape[0] >= FFN_MIN_ROWS) else None
         ctx.ffn_fused = ffn is not None
-        if ffn is not None:
+        if split:
+            pass                    # (x2, h, xn2 are there already)
+        elif ffn is not None:
             # one launch: LayerNorm (folded into the packed linear1), linear1, ReLU, dropout, linear2, dropout, residual
             # (csrc/ffn_fused.hip).  With a backward pass ahead it also stores h (fragment-ordered columns) and the
             # normalised rows xh; the inference call stores nothing but the result.

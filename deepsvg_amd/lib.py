@@ -123,7 +123,7 @@ SIGNATURES = {
                                     c_f32, c_f32, c_f32, c_u32, c_u32, vp, vp, c_u32, vp]),
     "dsvg_gs_pack_bytes": (c_i64, [c_i32]),
     "dsvg_gs_pack": (c_i32, [vp, vp, c_i32, c_i32, c_i32, c_i32, vp, vp, vp]),
-    "dsvg_gs_layer_fwd": (c_i32, [vp] * 12 + [c_i64, c_i32] + [vp] * 11 + [c_f32, c_f32, c_f32, c_u32, vp, vp]),
+    "dsvg_gs_layer_fwd": (c_i32, [vp] * 12 + [c_i64, c_i32] + [vp] * 11 + [c_f32, c_f32, c_f32, c_u32, vp, c_i64, c_i32, vp]),
     "dsvg_gs_bwd_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "dsvg_gs_layer_bwd": (c_i32, [vp] * 13 + [c_i64, c_i32] + [vp] * 10 + [c_f32, c_f32, c_u32, vp, vp, c_i64, vp]),
 }

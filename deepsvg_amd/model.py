@@ -381,7 +381,9 @@ class ParamStore:
             return
         rows, index = [], {}
         for name, stack in self.module.named_modules():
-            if not (isinstance(stack, _Stack) and name.rsplit(".", 1)[-1].startswith("hierarchical_")):
+            # (... and the second decoder stage: the remainder sequences of its training forward, functional.LayerFn)
+            if not (isinstance(stack, _Stack) and (name.rsplit(".", 1)[-1].startswith("hierarchical_")
+                                                   or name == "decoder.decoder")):
                 continue
             for m in stack.layers:
                 sa = getattr(m, "self_attn", None)

@@ -1029,7 +1029,7 @@ def ffn_pack(flat, offs, n_layers, packed_fwd=None, packed_bwd=None, b1f=None, w
 
 
 def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, site_res=0, seed=None, out=None,
-            train=False):
+            train=False, into=None):
     """y = x + drop_r(linear2(drop_h(relu(linear1(LayerNorm(x))))))  (x bf16 [rows, 256]; the LayerNorm's gamma / beta
     are inside packed_fwd_layer / b1f, see ffn_pack).  train: -> (y, h, xh, rstd) with h bf16 [rows, 512] in fragment
     order, xh = (x - mean) * rstd bf16, rstd fp32 [rows] (what the backward pass needs)"""
@@ -1042,8 +1042,12 @@ def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, s
         out = torch.empty_like(x)
     h = xh = rstd = None
     if train:
-        h = torch.empty((rows, 512), dtype=x.dtype, device=x.device)
-        xh = torch.empty_like(x)
+        if into is not None:    # (h, xh) given: row slices of longer buffers
+            h, xh = into
+            assert h.is_contiguous() and xh.is_contiguous() and tuple(h.shape) == (rows, 512) and xh.shape == x.shape
+        else:
+            h = torch.empty((rows, 512), dtype=x.dtype, device=x.device)
+            xh = torch.empty_like(x)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     ev = _prof_begin()
     _l.check(_l.load().dsvg_ffn_fwd(x.data_ptr(), packed_fwd_layer.data_ptr(), b1f.data_ptr(), b2.data_ptr(),
@@ -1140,7 +1144,8 @@ def attn_pack(flat, offs, n_layers, packed=None):
 
 
 def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_seq, S, scale, eps=1e-5, drop_p=0.0,
-                   site_probs=0, site_res=0, seed=None, seq_off=None, tiles=None, train=False, seq_add=None, site_seq_add=0):
+                   site_probs=0, site_res=0, seed=None, seq_off=None, tiles=None, train=False, seq_add=None, site_seq_add=0,
+                   into=None):
     """x1 = x + drop_r(out_proj(MHA(LayerNorm(x)))) [+ drop(seq_add[sequence])]  (x bf16 [rows, 256], 8 heads, S <= 32)
     in one launch.  seq_add (bf16 [n_seq, 256], dense layouts): the decoder's per-sequence conditioning term.
     train=False -> x1;  train=True -> (x1, xn, qkv, ao, mean, rstd): what the unfused backward reads."""
@@ -1154,9 +1159,13 @@ def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_
     if seq_add is not None:
         _chk(seq_add)
         assert seq_off is None and seq_add.dtype == x.dtype and seq_add.is_contiguous() and tuple(seq_add.shape) == (n_seq, 256)
-    x1 = torch.empty_like(x)
     xn = qkv = ao = mean = rstd = None
-    if train:
+    if into is not None:        # (x1, xn, qkv, ao, mean, rstd) given: row slices of longer buffers
+        assert train and len(into) == 6 and all(t.is_contiguous() and t.shape[0] == rows for t in into)
+        x1, xn, qkv, ao, mean, rstd = into
+    else:
+        x1 = torch.empty_like(x)
+    if train and into is None:
         xn = torch.empty_like(x)
         qkv = torch.empty((rows, 768), dtype=x.dtype, device=x.device)
         ao = torch.empty_like(x)
@@ -1200,13 +1209,16 @@ def gs_pack(flat, offs, n_layers, packed_fwd=None, packed_bwd=None):
 
 
 def gs_layer_fwd(x, packed_fwd_layer, in_bias, out_bias, b1, b2, gamma1, beta1, gamma2, beta2, key_mask, n_seq, S, scale,
-                 eps=1e-5, drop_p=0.0, site0=0, seed=None, seq_add=None, train=False):
-    """one pre-LN transformer block in one launch (x bf16 [n_seq * S, 256], 32 % S == 0; include/dsvg.h).
+                 eps=1e-5, drop_p=0.0, site0=0, seed=None, seq_add=None, train=False, seq_base=0, ffn_format=False, into=None):
+    """one pre-LN transformer block in one launch (x bf16 [n_seq * S, 256], S <= 32; include/dsvg.h).
     train=False -> x2;  train=True -> (x2, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h): the tensors the unfused
-    launches of the same block save for the backward pass, in the same layouts."""
+    launches of the same block save for the backward pass, in the same layouts.
+    seq_base: x (key_mask, seq_add, the outputs) are the rows of the sequences seq_base .. of a longer buffer - dropout draws
+    are indexed from that buffer's first row.  ffn_format: xn2 / h as ffn_fwd(train=True) hands them over (affine-free rows,
+    fragment-ordered hidden columns).  into: the 11 output tensors (row slices of longer buffers) instead of fresh ones."""
     _chk(x, packed_fwd_layer, in_bias, out_bias, b1, b2, gamma1, beta1, gamma2, beta2, key_mask, seed, seq_add)
     rows = n_seq * S
-    assert x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(x.shape) == (rows, 256) and 32 % S == 0
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(x.shape) == (rows, 256) and 1 <= S <= 32
     assert packed_fwd_layer.numel() == GS_LAYER_ELEMS and packed_fwd_layer.is_contiguous()
     for t, n in ((in_bias, 768), (out_bias, 256), (b1, 512), (b2, 256), (gamma1, 256), (beta1, 256), (gamma2, 256), (beta2, 256)):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
@@ -1214,18 +1226,26 @@ def gs_layer_fwd(x, packed_fwd_layer, in_bias, out_bias, b1, b2, gamma1, beta1, 
     if seq_add is not None:
         assert seq_add.dtype == x.dtype and seq_add.is_contiguous() and tuple(seq_add.shape) == (n_seq, 256)
     dev = x.device
-    x2 = torch.empty_like(x)
-    sv = [None] * 10
-    if train:
-        f32 = lambda: torch.empty(rows, dtype=torch.float32, device=dev)
-        sv = [f32(), f32(), torch.empty_like(x), torch.empty((rows, 768), dtype=x.dtype, device=dev), torch.empty_like(x),
-              torch.empty_like(x), f32(), f32(), torch.empty_like(x), torch.empty((rows, 512), dtype=x.dtype, device=dev)]
+    if into is not None:
+        assert train and len(into) == 11
+        for t, w_ in zip(into, (256, None, None, 256, 768, 256, 256, None, None, 256, 512)):
+            assert t.is_contiguous() and t.shape[0] == rows and (t.dtype == torch.float32 if w_ is None else
+                                                                 (t.dtype == x.dtype and t.shape[1] == w_))
+        x2, sv = into[0], list(into[1:])
+    else:
+        x2 = torch.empty_like(x)
+        sv = [None] * 10
+        if train:
+            f32 = lambda: torch.empty(rows, dtype=torch.float32, device=dev)
+            sv = [f32(), f32(), torch.empty_like(x), torch.empty((rows, 768), dtype=x.dtype, device=dev), torch.empty_like(x),
+                  torch.empty_like(x), f32(), f32(), torch.empty_like(x), torch.empty((rows, 512), dtype=x.dtype, device=dev)]
     ev = _prof_begin()
     _l.check(_l.load().dsvg_gs_layer_fwd(x.data_ptr(), packed_fwd_layer.data_ptr(), in_bias.data_ptr(), out_bias.data_ptr(),
                                          b1.data_ptr(), b2.data_ptr(), gamma1.data_ptr(), beta1.data_ptr(),
                                          gamma2.data_ptr(), beta2.data_ptr(), _p(key_mask), _p(seq_add), n_seq, S,
                                          x2.data_ptr(), *[_p(t) for t in sv], float(eps), float(scale), float(drop_p),
-                                         int(site0), _p(seed) if drop_p > 0 else None, _stream()), "dsvg_gs_layer_fwd")
+                                         int(site0), _p(seed) if drop_p > 0 else None, int(seq_base), int(bool(ffn_format)),
+                                         _stream()), "dsvg_gs_layer_fwd")
     # algorithmic FLOPs of the block: in_proj + out_proj + attention (2 x 2 S 32 per head and row) + the two FFN products
     _prof_end(ev, 2.0 * rows * 256 * (768 + 256 + 1024) + 4.0 * rows * S * 256, 1024.0 * rows,
               dict(op="gs_layer_fwd", rows=rows, train=bool(train), ffn_flops=4.0 * 256 * 512 * rows))

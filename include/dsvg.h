@@ -512,6 +512,12 @@ int dsvg_attn_block_fwd(const void* x, const void* packed_layer, const float* in
  *   Training outputs (all NULL for inference, all set otherwise) = what the backward pass reads, in the layouts of the
  *   unfused launches: mean1 / rstd1 / mean2 / rstd2 fp32 [rows], xn1 = LayerNorm1(x), ao (head outputs), x1,
  *   xn2 = LayerNorm2(x1) bf16 [rows,256], qkv bf16 [rows,768], h bf16 [rows,512] (after ReLU and dropout).
+ *   The forward call also takes sequences of any length 1 .. 32 (32 / S whole sequences per tile) and a sequence offset:
+ *   seq_base > 0 = the launch covers sequences seq_base .. seq_base + n_seq - 1 of a longer buffer (all pointers at their
+ *   first row; dropout draws indexed from the buffer's first row), ffn_format != 0 = xn2 and h come out as the fused FFN
+ *   kernels' backward reads them (xn2 without gamma / beta, h with fragment-ordered columns, dsvg_ffn_fwd).  Together: the
+ *   training forward of a large dense stage runs the sequences that fill whole rounds of the chip on dsvg_attn_block_fwd +
+ *   dsvg_ffn_fwd and the remainder on this kernel, into the same saved tensors.
  * dsvg_gs_layer_bwd: dx2 = dL/dx2 bf16 [rows,256] and the saved tensors -> dx = dL/dx, plus the token-major operands of
  *   the four weight-gradient GEMMs the caller runs afterwards - dym = dx2 * mask(site0+4) (with h: linear2), dpre (with
  *   xn2: linear1), dx1m = dx1 * mask(site0+1) (with ao: out_proj), dqkv (with xn1: in_proj); their column sums are the bias
@@ -527,7 +533,7 @@ int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, const float* 
                       const float* beta2, const uint64_t* key_mask, const void* seq_add, int64_t n_seq, int32_t S,
                       void* x2, float* mean1, float* rstd1, void* xn1, void* qkv, void* ao, void* x1, float* mean2,
                       float* rstd2, void* xn2, void* h, float eps, float scale, float drop_p, uint32_t site0,
-                      const void* seed, void* stream);
+                      const void* seed, int64_t seq_base, int32_t ffn_format, void* stream);
 int64_t dsvg_gs_bwd_workspace_bytes(int64_t n_seq, int32_t S);
 int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, const void* x, const float* mean1, const float* rstd1,
                       const void* qkv, const void* x1, const float* mean2, const float* rstd2, const void* h,

@@ -153,6 +153,64 @@ def test_gs_layer_fwd_matches_reference(gpu_device, n_seq, S, masked, with_add, 
     assert not bad, "\n".join(bad)
 
 
+@pytest.mark.parametrize("n_total,n_tail,S,with_add,drop_p", [(300, 257, 31, True, 0.1), (40, 13, 31, False, 0.0),
+                                                              (90, 33, 10, True, 0.1), (64, 64, 31, True, 0.1)])
+def test_gs_layer_fwd_on_the_tail_sequences_of_a_longer_buffer(gpu_device, n_total, n_tail, S, with_add, drop_p):
+    """the forward kernel on sequences of any length <= 32 (here 31: one sequence and one padding row per tile) and on the
+    LAST n_tail sequences of a longer buffer (seq_base = n_total - n_tail: pointers at their first row, dropout draws
+    indexed from the buffer's first row) - against the restatement run on the whole buffer; then with the FFN half's
+    training outputs in the fused FFN kernels' format (affine-free LayerNorm rows, fragment-ordered hidden columns), written
+    into row slices of preallocated buffers"""
+    flat, offs, p, x, _km, seq_add, _ = _setup(n_total, S, seed=n_total + S, with_add=with_add)
+    pf, _pb = ops.gs_pack(flat, offs, 2)
+    ef, _eb = R.gs_pack(flat, offs, 2)
+    seed = _seed_tensor(0x0123456789ABCDE1)
+    scale = 32 ** -0.5
+    base = n_total - n_tail
+    r0 = base * S
+    sl = slice(0, ops.GS_LAYER_ELEMS)
+    want = R.gs_layer_fwd(x, ef[sl], *_params(p), None, n_total, S, scale, 1e-5, drop_p, 400, seed, seq_add=seq_add, train=True)
+    sa = seq_add[base:].contiguous() if seq_add is not None else None
+    got = ops.gs_layer_fwd(x[r0:], pf[sl], *_params(p), None, n_tail, S, scale, 1e-5, drop_p, 400, seed, seq_add=sa,
+                           train=True, seq_base=base)
+    torch.cuda.synchronize()
+    bad = []
+
+    def check(got_t, what):
+        for name, a, b in zip(FWD_NAMES, got_t, want):
+            b = b[r0:]
+            if name == "h":
+                same = (a != 0) == (b != 0)
+                if (~same).float().mean().item() > 3e-3:
+                    bad.append(f"{what} h: {100 * (~same).float().mean().item():.2f} % of the gates differ")
+                a, b = torch.where(same, a, torch.zeros_like(a)), torch.where(same, b, torch.zeros_like(b))
+            tol = 1e-4 if name in ("mean1", "rstd1") else (4e-3 if name in ("mean2", "rstd2") else 2e-2)
+            _diff(f"{what} {name}", a, b, tol, bad, mean_tol=None if name.startswith(("mean", "rstd")) else 4e-3)
+    check(got, "tail")
+    if base:        # the draws really are those of the longer buffer: the same call with seq_base = 0 gives other masks
+        other = ops.gs_layer_fwd(x[r0:], pf[sl], *_params(p), None, n_tail, S, scale, 1e-5, drop_p, 400, seed, seq_add=sa,
+                                 train=True)
+        assert (drop_p == 0) == torch.equal(other[0], got[0])
+    # fused-FFN format, into row slices of buffers that cover the whole batch
+    rows = n_total * S
+    bf = lambda w_: torch.full((rows, w_), 7.0, dtype=torch.bfloat16, device=DEV)
+    f32 = lambda: torch.full((rows,), 7.0, dtype=torch.float32, device=DEV)
+    full = [bf(256), f32(), f32(), bf(256), bf(768), bf(256), bf(256), f32(), f32(), bf(256), bf(512)]
+    res = ops.gs_layer_fwd(x[r0:], pf[sl], *_params(p), None, n_tail, S, scale, 1e-5, drop_p, 400, seed, seq_add=sa,
+                           train=True, seq_base=base, ffn_format=True, into=tuple(t[r0:] for t in full))
+    torch.cuda.synchronize()
+    for t in full:
+        assert bool((t[:r0] == 7.0).all()), "rows in front of the slice were written"
+    for i, name in enumerate(FWD_NAMES):
+        if name not in ("xn2", "h"):
+            assert torch.equal(res[i], got[i]), name
+    xh = ((got[6].float() - got[7].unsqueeze(1)) * got[8].unsqueeze(1))
+    _diff("ffn_format xn2 = (x1 - mean2) rstd2", res[9], xh, 8e-3, bad)
+    perm = R._ffn_frag_perm(DEV)
+    assert torch.equal(res[10][:, perm], got[10]), "h is not the fragment-order permutation of the natural-order h"
+    assert not bad, "\n".join(bad)
+
+
 @pytest.mark.parametrize("n_seq,S,masked,with_add,drop_p", CASES)
 def test_gs_layer_bwd_matches_reference(gpu_device, n_seq, S, masked, with_add, drop_p):
     flat, offs, p, x, key_mask, seq_add, dx2 = _setup(n_seq, S, seed=100 + n_seq + S, masked=masked, with_add=with_add)

@@ -630,3 +630,49 @@ def test_fused_argument_head_path_with_emulated_ops(emulated_ops):
         cy2, ay2 = model._make_valid(cy2, ay2, vis)
     assert torch.equal(cy, cy2)
     assert (ay != ay2).float().mean().item() < 5e-3
+
+
+def test_remainder_sequences_on_the_group_stage_kernel_with_emulated_ops(emulated_ops, monkeypatch):
+    """bf16 training forward of the second decoder stage: the sequences beyond a multiple of SEQ_ROUND run on gs_layer_fwd
+    (seq_base, fused-FFN output format, written into row slices of the saved tensors), the others on attn_block_fwd +
+    ffn_fwd; the backward pass reads the joint buffers.  Shrunk thresholds so that a 6-icon batch takes the path.  Against
+    the unsplit run: same loss and gradients up to the bf16 rounding differences of the two formulations."""
+    from deepsvg_amd.synthetic import make_batch
+    from deepsvg_amd import ops
+    import deepsvg_amd.functional as Fn
+    cfg = H.build_cfg("hier")
+    cfg.n_layers = cfg.n_layers_decode = 2
+    cfg.dropout = 0.0           # (the two paths draw the hidden-site dropout masks differently: compare without)
+    c, a = make_batch(6, seed=21)
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 10)
+    monkeypatch.setattr(Fn, "FFN_MIN_ROWS", 64)
+    monkeypatch.setattr(Fn, "ATTN_MIN_ROWS", 64)
+    monkeypatch.setattr(Fn, "SEQ_ROUND", 8)
+    res, calls = {}, {}
+    saved = ops.gs_layer_fwd
+    try:
+        for rem_max in (7, 0):
+            n_calls = []
+
+            def counted(*args, _f=saved, **kw):
+                n_calls.append((kw.get("seq_base", 0), bool(kw.get("ffn_format", False))))
+                return _f(*args, **kw)
+            ops.gs_layer_fwd = counted
+            monkeypatch.setattr(Fn, "GS_REMAINDER", rem_max)
+            torch.manual_seed(3)
+            model = deepsvg_amd.SVGTransformer(cfg).train()
+            model.load_state_dict(sd)
+            model.set_compute_dtype(torch.bfloat16)
+            out = model(c, a, c, a, params={})
+            ld = deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
+            ld["loss"].backward()
+            res[rem_max] = (float(ld["loss"].detach()), {n: p.grad.clone() for n, p in model.named_parameters()})
+            calls[rem_max] = [cc for cc in n_calls if cc[1]]
+            n_run = model.last_live
+    finally:
+        ops.gs_layer_fwd = saved
+    assert len(calls[7]) == 2 and all(b > 0 and b % 8 == 0 for b, _ in calls[7]), calls     # the stage's two layers
+    assert calls[0] == []
+    assert abs(res[7][0] - res[0][0]) <= 2e-3 * abs(res[0][0])
+    for n in res[7][1]:
+        assert H.rel_l2(res[7][1][n], res[0][1][n]) < 3e-2, n

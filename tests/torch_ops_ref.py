@@ -768,7 +768,7 @@ def _ffn_hidden(xn, W1, b1, drop_p, site_hidden, seed):
 
 
 def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, site_res=0, seed=None, out=None,
-            train=False):
+            train=False, into=None):
     W1, W2 = _ffn_weights(packed_fwd_layer)
     xh, _, rstd = _ffn_normalise(x, eps)
     h, _, _ = _ffn_hidden(xh, W1, b1f, drop_p, site_hidden, seed)
@@ -782,6 +782,10 @@ def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, s
         return y
     hp = torch.empty_like(h)
     hp[:, _ffn_frag_perm(x.device)] = h
+    if into is not None:
+        into[0].copy_(hp)
+        into[1].copy_(xh)
+        hp, xh = into
     return y, hp, xh, rstd
 
 
@@ -881,7 +885,8 @@ def head_dlogits(x, packed, bias, n_out, C, target, w, lse, sum_count, gscale, c
 
 
 def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_seq, S, scale, eps=1e-5, drop_p=0.0,
-                   site_probs=0, site_res=0, seed=None, seq_off=None, tiles=None, train=False, seq_add=None, site_seq_add=0):
+                   site_probs=0, site_res=0, seed=None, seq_off=None, tiles=None, train=False, seq_add=None, site_seq_add=0,
+                   into=None):
     """the unfused launches, composed (LayerNorm -> in_proj -> attention -> out_proj + dropout + residual [-> bcast add])"""
     win, wo = packed_layer[:196608].view(768, 256), packed_layer[196608:].view(256, 256)
     xn, mean, rstd = layernorm_fwd(x, gamma, beta, eps)
@@ -891,7 +896,12 @@ def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_
     if seq_add is not None:
         bcast_add_fwd_(x1, seq_add, n_seq, S, drop_p, site_seq_add, seed)
     if train:
-        return x1, xn, qkv, ao, mean, rstd
+        res = (x1, xn, qkv, ao, mean, rstd)
+        if into is not None:
+            for dst, src in zip(into, res):
+                dst.copy_(src)
+            res = tuple(into)
+        return res
     return x1
 
 
@@ -922,7 +932,30 @@ def _gs_weights(img):
 
 
 def gs_layer_fwd(x, packed_fwd_layer, in_bias, out_bias, b1, b2, gamma1, beta1, gamma2, beta2, key_mask, n_seq, S, scale,
-                 eps=1e-5, drop_p=0.0, site0=0, seed=None, seq_add=None, train=False):
+                 eps=1e-5, drop_p=0.0, site0=0, seed=None, seq_add=None, train=False, seq_base=0, ffn_format=False, into=None):
+    if seq_base or ffn_format or into is not None:
+        # the sequences seq_base .. of a longer buffer: the draws are indexed from that buffer's first row, so the restatement
+        # runs on a buffer of that length (zeros in front) and keeps its tail
+        pad = lambda t, w_: None if t is None else torch.cat([torch.zeros((seq_base * w_,) + tuple(t.shape[1:]), dtype=t.dtype,
+                                                                               device=t.device), t])
+        km = None if key_mask is None else torch.cat([torch.ones(seq_base, dtype=key_mask.dtype, device=key_mask.device),
+                                                      key_mask[:n_seq]])
+        res = gs_layer_fwd(pad(x, S), packed_fwd_layer, in_bias, out_bias, b1, b2, gamma1, beta1, gamma2, beta2, km,
+                           seq_base + n_seq, S, scale, eps, drop_p, site0, seed, seq_add=pad(seq_add, 1), train=train)
+        if not train:
+            return res[seq_base * S:]
+        res = [t[seq_base * S:] for t in res]
+        if ffn_format:
+            x1f = _f(res[6])
+            res[9] = ((x1f - res[7].unsqueeze(-1)) * res[8].unsqueeze(-1)).to(x.dtype)
+            hp = torch.empty_like(res[10])
+            hp[:, _ffn_frag_perm(x.device)] = res[10]
+            res[10] = hp
+        if into is not None:
+            for dst, src in zip(into, res):
+                dst.copy_(src)
+            res = list(into)
+        return tuple(res)
     win, wo, w1, w2 = _gs_weights(packed_fwd_layer)
     xn1, mean1, rstd1 = layernorm_fwd(x, gamma1, beta1, eps)
     qkv = gemm(xn1, win, bias=in_bias)
