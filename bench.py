@@ -535,7 +535,7 @@ def main():
                                      "definition": "SURVEY.md 8(d) fused byte count: 1024 B per token-layer forward; "
                                                    "1536 B per token-layer backward (dy, x in; dx out)"}}
             # HBM traffic of the dominant kernel, measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (scripts/
-            # gpu_ffn_pmc.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte streaming reads on
+            # gpu_step_pmc.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte streaming reads on
             # gfx950): a COMMITTED measurement (profiles/ffn_traffic.json), not taken in this run
             tj = os.path.join(ROOT, "profiles", "ffn_traffic.json")
             if os.path.exists(tj):
