@@ -16,11 +16,15 @@
 __global__ void loss_targets_kernel(const float* __restrict__ tc, const float* __restrict__ ta,
                                     const float* __restrict__ cam, long long n_seq, int S1, int n_args, int n_cmd,
                                     int eos, int* __restrict__ cmd_tgt, float* __restrict__ cmd_w,
-                                    int* __restrict__ arg_tgt, float* __restrict__ arg_w, int* __restrict__ vis_tgt) {
+                                    int* __restrict__ arg_tgt, float* __restrict__ arg_w, int* __restrict__ vis_tgt,
+                                    const int32_t* __restrict__ seq_perm) {
+    // seq_perm != null: output sequence b is source sequence seq_perm[b] (the visible-first order of the second decoder
+    // stage: the heads then read their targets in the order the stage's rows are in); vis_tgt stays in source order
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_seq) return;
+    const long long src = seq_perm ? seq_perm[b] : b;
     const int S = S1 - 1;
-    const float* row = tc + b * S1;
+    const float* row = tc + src * S1;
     // padding mask = positions before the first EOS (utils.py:20-24), `extended` by the mask shifted 3 positions
     // (utils.py:25-30, canonical non-aliased reading): position t is on iff t < fe or (t >= 3 and t - 3 < fe)
     int n_eos = 0, fe = S1;
@@ -30,7 +34,7 @@ __global__ void loss_targets_kernel(const float* __restrict__ tc, const float* _
         if (e) fe = s;
     }
     const int vis = (n_eos < S1 - 1) ? 1 : 0;
-    vis_tgt[b] = vis;
+    vis_tgt[src] = vis;
     for (int s = 0; s < S; ++s) {
         int c = (int)row[s + 1];
         c = min(max(c, 0), n_cmd - 1);
@@ -39,7 +43,7 @@ __global__ void loss_targets_kernel(const float* __restrict__ tc, const float* _
         const bool ext = t < fe || (t >= 3 && t - 3 < fe);
         cmd_w[b * S + s] = (ext && vis) ? 1.f : 0.f;
         for (int a = 0; a < n_args; ++a) {
-            arg_tgt[(b * S + s) * n_args + a] = (int)ta[(b * S1 + s + 1) * n_args + a] + 1;
+            arg_tgt[(b * S + s) * n_args + a] = (int)ta[(src * S1 + s + 1) * n_args + a] + 1;
             arg_w[(b * S + s) * n_args + a] = cam[c * n_args + a];
         }
     }
@@ -48,13 +52,13 @@ __global__ void loss_targets_kernel(const float* __restrict__ tc, const float* _
 extern "C" int dsvg_loss_targets(const float* tgt_commands, const float* tgt_args, const float* cmd_args_mask,
                                  int64_t n_seq, int32_t S1, int32_t n_args, int32_t n_cmd, int32_t eos_id,
                                  int32_t* cmd_tgt, float* cmd_w, int32_t* arg_tgt, float* arg_w, int32_t* vis_tgt,
-                                 void* stream) {
+                                 const int32_t* seq_perm, void* stream) {
     DSVG_CHECK_ARG(tgt_commands && tgt_args && cmd_args_mask && cmd_tgt && cmd_w && arg_tgt && arg_w && vis_tgt,
                    "loss_targets: null pointer");
     DSVG_CHECK_ARG(n_seq > 0 && S1 > 1 && S1 <= 4096, "loss_targets: bad shape (S1=%d)", S1);
     hipLaunchKernelGGL(loss_targets_kernel, dim3(dsvg_cdiv(n_seq, 64)), dim3(64), 0, (hipStream_t)stream, tgt_commands,
                        tgt_args, cmd_args_mask, (long long)n_seq, S1, n_args, n_cmd, eos_id, cmd_tgt, cmd_w, arg_tgt,
-                       arg_w, vis_tgt);
+                       arg_w, vis_tgt, seq_perm);
     DSVG_LAUNCH_CHECK("loss_targets");
     return 0;
 }

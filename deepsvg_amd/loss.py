@@ -89,10 +89,11 @@ class SVGLoss(nn.Module):
             ws.append(weights["loss_visibility_weight"])
             names.append("loss_visibility")
 
-        cl = command_logits.reshape(N * G * S, cfg.n_commands)
+        cl = command_logits.reshape(-1, cfg.n_commands)      # (the head input's rows: all N G S, or the sequences that ran)
+        cmd_t, cmd_wt = cmd_tgt.view(-1)[:cl.shape[0]], cmd_w.view(-1)[:cl.shape[0]]
         joint = head is not None and head.get("cmd_weight") is not None and self.joint_heads
         if not joint:
-            scs.append(Fn.MaskedCEFn.apply(cl, cmd_tgt.view(-1), cmd_w.view(-1), cfg.n_commands, 1,
+            scs.append(Fn.MaskedCEFn.apply(cl, cmd_t, cmd_wt, cfg.n_commands, 1,
                                            (lambda c: cnt[1]) if red else None))
             ws.append(weights["loss_cmd_weight"])
             names.append("loss_cmd")
@@ -111,7 +112,7 @@ class SVGLoss(nn.Module):
                 sc_c, sc_a = Fn.ArgsHeadLossFn.apply(
                     head["rt"], head["x"], head["weight"], head["bias"], a_t, a_w, self.args_dim, slots[1] - slots[0],
                     (lambda c: cnt[2]) if red else None, head["live"], slots[0], cl.detach(), head["cmd_weight"],
-                    head["cmd_bias"], cmd_tgt.view(-1), cmd_w.view(-1), (lambda c: cnt[1]) if red else None)
+                    head["cmd_bias"], cmd_t, cmd_wt, (lambda c: cnt[1]) if red else None)
                 scs.append(sc_c)
                 ws.append(weights["loss_cmd_weight"])
                 names.append("loss_cmd")

@@ -576,6 +576,8 @@ class SVGTransformer(nn.Module):
         self.skip_invisible_backward = os.environ.get("DSVG_SKIP_INVISIBLE", "1") != "0"
         # ... and the same sequences' forward pass in a training call (their logits stay available: lazy result entries)
         self.skip_invisible_forward = os.environ.get("DSVG_SKIP_INVISIBLE_FWD", "1") != "0"
+        # ... with the heads and the loss reading that stage's rows in its own (visible-first) order
+        self.heads_visible_first = os.environ.get("DSVG_HEADS_VF", "1") != "0"
         self._cmd_logits_live = None
         self.last_live = None
         # backward of the argument head only over the tokens that carry argument loss (exact under SVGLoss)
@@ -712,10 +714,14 @@ class SVGTransformer(nn.Module):
             tc = commands_dec.to(torch.float32).contiguous().view(N * G, S1)
             ta = args_dec.to(torch.float32).contiguous().view(N * G, S1, -1)
             cam = self.cmd_args_mask.to(device=tc.device, dtype=torch.float32).contiguous()
-            targets = ops.loss_targets(tc, ta, cam, EOS_ID)
+            # with the visible-first order of the second decoder stage known, the heads read that stage's rows where they
+            # are: command / argument targets, weights and the token list in THAT order (no gather back to the caller's
+            # group order in the training step; the visibility targets - first-stage rows - stay in the caller's order)
+            vf = plan["dec"] is not None and self.skip_invisible_forward and self.heads_visible_first
+            targets = ops.loss_targets(tc, ta, cam, EOS_ID, seq_perm=plan["dec"]["old_of_new"] if vf else None)
             n_args = ta.shape[-1]
             live, n_live = ops.live_rows(targets[3].view(-1), n_args)
-            plan["loss"] = dict(targets=targets, live=live)
+            plan["loss"] = dict(targets=targets, live=live, vf=vf)
             counts.append(n_live)
             # which argument slots carry loss anywhere in this batch (CMD_ARGS_MASK columns of the commands present: real
             # DeepSVG data has no arcs, so slots 0-4 never do): the head then runs on that slot range only
@@ -864,10 +870,11 @@ class SVGTransformer(nn.Module):
         pd = plan["dec"] if (plan is not None and cfg.decode_stages == 2) else None
         live = None
         n_run = n_seq               # sequences the stage runs forward
-        if pd is not None and max(pd["n_visible"], pd.get("n_live", 0)) < n_seq:
+        vf_plan = bool(pd is not None and plan.get("loss") and plan["loss"].get("vf"))     # head targets in that order
+        if pd is not None and (max(pd["n_visible"], pd.get("n_live", 0)) < n_seq or vf_plan):
             # visible-first order: sequence `new` of the stage is group old_of_new[new]; backward covers the prefix
             # (any prefix that contains every visible sequence is exact; a graph bucket rounds it up)
-            nv = max(pd["n_visible"], pd.get("n_live", 0))
+            nv = min(max(pd["n_visible"], pd.get("n_live", 0)), n_seq)
             live = Fn.LivePrefix((nv, min((nv * S + 127) // 128 * 128, n_seq * S)))
             if self.skip_invisible_forward and match is None and l_seq is None:
                 # ... and so does the forward pass: SVGLoss reads no logit of an invisible target group (loss.py:36,51-54)
@@ -880,26 +887,36 @@ class SVGTransformer(nn.Module):
         self._live = live
         src = Fn.AddPosFn.apply(rt, None, dec.embedding.PE.pos_embed.weight, n_run, S, PE_DROPOUT, 4, live)
         out = self._run_stack(rt, dec.decoder, src, None, z, n_run, S, 400, live=live, l=l_seq)
-        if live is not None:        # back to the caller's group order before the heads (sequences that did not run: zeros)
-            out = Fn.GatherGroupsFn.apply(out, pd["new_of_old"], pd["old_of_new"], n_seq, S, live)
+        # the heads read the stage's rows in visible-first order when the loss plan's targets are in that order (_plan): the
+        # training step then never gathers back to the caller's group order; anything else that reads a dense logit tensor
+        # gets it through `complete` (lazy)
+        vf_heads = bool(live is not None and plan is not None and plan.get("loss") and plan["loss"].get("vf")
+                        and match is None and lazy_args)
         complete = None
-        if n_run < n_seq:
+        if live is not None and (n_run < n_seq or vf_heads):
+            out_vf = out
             done = []
 
             def complete():
-                """the stage's output with the rows of EVERY group: runs the sequences the training pass left out (first
-                read of a dense logit tensor by anything but deepsvg_amd.SVGLoss: the reference's SVGLoss, a metric, a
-                test).  Differentiable; off the hot path, so the row bookkeeping is plain torch.  Dropout: those rows
-                draw from their own sites."""
+                """the stage's output with the rows of EVERY group, in the caller's group order: runs the sequences the
+                training pass left out (first read of a dense logit tensor by anything but deepsvg_amd.SVGLoss: the
+                reference's SVGLoss, a metric, a test).  Differentiable; off the hot path, so the row bookkeeping is
+                plain torch.  Dropout: those rows draw from their own sites."""
                 if not done:
-                    rest = pd["old_of_new"][n_run:].long()
-                    n_rest = n_seq - n_run
-                    z_r = z_all.index_select(0, rest)
-                    src_r = Fn.AddPosFn.apply(rt, None, dec.embedding.PE.pos_embed.weight, n_rest, S, PE_DROPOUT, 6, None)
-                    out_r = self._run_stack(rt, dec.decoder, src_r, None, z_r, n_rest, S, 464)
-                    full = out.view(n_seq, -1).index_copy(0, rest, out_r.view(n_rest, -1))
-                    done.append(full.view(n_seq * S, -1))
+                    full = out_vf
+                    if n_run < n_seq:
+                        rest = pd["old_of_new"][n_run:].long()
+                        n_rest = n_seq - n_run
+                        z_r = z_all.index_select(0, rest)
+                        src_r = Fn.AddPosFn.apply(rt, None, dec.embedding.PE.pos_embed.weight, n_rest, S, PE_DROPOUT, 6, None)
+                        out_r = self._run_stack(rt, dec.decoder, src_r, None, z_r, n_rest, S, 464)
+                        full = torch.cat([out_vf, out_r])
+                    done.append(Fn.GatherGroupsFn.apply(full, pd["new_of_old"], pd["old_of_new"], n_seq, S, None))
                 return done[0]
+            if not vf_heads:        # (heads on caller-order rows: zeros for the sequences that did not run)
+                out = Fn.GatherGroupsFn.apply(out, pd["new_of_old"], pd["old_of_new"], n_seq, S, live)
+        elif live is not None:
+            out = Fn.GatherGroupsFn.apply(out, pd["new_of_old"], pd["old_of_new"], n_seq, S, live)
         if match is not None:
             # Hungarian self-matching (model.py:384-395): cost of every (target group, predicted group) pair from the
             # dense logits (no gradient), exact assignment, then output slot j takes predicted group assign[j].  The
@@ -919,7 +936,9 @@ class SVGTransformer(nn.Module):
             out = Fn.GatherGroupsFn.apply(out, idx, inv, n_seq, S, None)
             vis_logits = vis_logits.index_select(0, idx.long())         # (N*G, 2): a tiny gather, left to torch
         cf = dec.fcn.command_fcn
-        cmd_logits = Fn.LinearFn.apply(rt, out, cf.weight, cf.bias, 0, None, 0.0, 0, None).view(N, G, S, cfg.n_commands)
+        cmd_logits = Fn.LinearFn.apply(rt, out, cf.weight, cf.bias, 0, None, 0.0, 0, None)
+        if complete is None:
+            cmd_logits = cmd_logits.view(N, G, S, cfg.n_commands)
         n_args, args_dim, fcn = cfg.n_args, self.args_dim, dec.fcn.args_fcn
 
         def make_args_logits():
@@ -939,7 +958,8 @@ class SVGTransformer(nn.Module):
             self._head_argmax = head_argmax
         self._cmd_logits_live = None
         if complete is not None:
-            # valid on the groups that ran (every loss-carrying row is among them): what deepsvg_amd.SVGLoss reads
+            # valid on the groups that ran (every loss-carrying row is among them), [rows of the head input, n_commands] in
+            # the head input's row order: what deepsvg_amd.SVGLoss reads
             self._cmd_logits_live = cmd_logits
             cmd_logits = lambda: Fn.LinearFn.apply(rt, complete(), cf.weight, cf.bias, 0, None, 0.0, 0, None) \
                 .view(N, G, S, cfg.n_commands)

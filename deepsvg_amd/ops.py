@@ -705,9 +705,12 @@ def bcast_add_bwd(dx, n_seq, S, drop_p=0.0, drop_site=0, seed=None, n_seq_out=No
 # ------------------------------------------------------------------------------------------------
 # loss
 # ------------------------------------------------------------------------------------------------
-def loss_targets(tgt_commands, tgt_args, cmd_args_mask, eos_id=4):
-    """tgt_commands float32 [n_seq, S1], tgt_args float32 [n_seq, S1, n_args], cmd_args_mask float32 [n_cmd,n_args]"""
-    _chk(tgt_commands, tgt_args, cmd_args_mask)
+def loss_targets(tgt_commands, tgt_args, cmd_args_mask, eos_id=4, seq_perm=None):
+    """tgt_commands float32 [n_seq, S1], tgt_args float32 [n_seq, S1, n_args], cmd_args_mask float32 [n_cmd,n_args].
+    seq_perm (int32 [n_seq]): the token-level results of sequence b are those of source sequence seq_perm[b]; vis_tgt stays in
+    source order"""
+    _chk(tgt_commands, tgt_args, cmd_args_mask, seq_perm)
+    assert seq_perm is None or (seq_perm.dtype == torch.int32 and seq_perm.numel() >= tgt_commands.shape[0])
     assert tgt_commands.is_contiguous() and tgt_args.is_contiguous() and cmd_args_mask.is_contiguous()
     assert tgt_commands.dtype == torch.float32 and tgt_args.dtype == torch.float32
     assert cmd_args_mask.dtype == torch.float32
@@ -723,7 +726,7 @@ def loss_targets(tgt_commands, tgt_args, cmd_args_mask, eos_id=4):
     vis_tgt = torch.empty(n_seq, dtype=torch.int32, device=dev)
     _l.check(_l.load().dsvg_loss_targets(tgt_commands.data_ptr(), tgt_args.data_ptr(), cmd_args_mask.data_ptr(),
                                          n_seq, S1, n_args, n_cmd, eos_id, cmd_tgt.data_ptr(), cmd_w.data_ptr(),
-                                         arg_tgt.data_ptr(), arg_w.data_ptr(), vis_tgt.data_ptr(), _stream()),
+                                         arg_tgt.data_ptr(), arg_w.data_ptr(), vis_tgt.data_ptr(), _p(seq_perm), _stream()),
              "dsvg_loss_targets")
     return cmd_tgt, cmd_w, arg_tgt, arg_w, vis_tgt
 

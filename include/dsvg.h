@@ -241,7 +241,9 @@ int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64_t n_seq, i
  * SVGLoss (deepsvg/model/loss.py:19-65).
  *  targets: from tgt_commands [n_seq,S1] / tgt_args [n_seq,S1,n_args] (float32, S1=S+1 incl. SOS)
  *    cmd_tgt[n_seq,S], cmd_w[n_seq,S] (extended padding mask x visibility, loss.py:35-36,49),
- *    arg_tgt[n_seq,S,n_args] (=arg+1), arg_w = CMD_ARGS_MASK[cmd] (loss.py:51), vis_tgt[n_seq]
+ *    arg_tgt[n_seq,S,n_args] (=arg+1), arg_w = CMD_ARGS_MASK[cmd] (loss.py:51), vis_tgt[n_seq];
+ *    seq_perm (optional, int32 [n_seq]): the token-level outputs of sequence b are those of source sequence seq_perm[b]
+ *    (the second decoder stage's visible-first order), vis_tgt stays in source order
  *  masked CE: logical row r of the [rows, C] matrix lives at logits + (r/group)*ld + (r%group)*C
  *    (group = n_args for args_logits, whose 11x257 slots are contiguous per token; 1 otherwise);
  *    lse per row, sum_count = {sum_r w_r*(lse_r - logit[r,target_r]), sum_r w_r}; rows with w==0
@@ -252,7 +254,7 @@ int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64_t n_seq, i
 int dsvg_loss_targets(const float* tgt_commands, const float* tgt_args, const float* cmd_args_mask,
                       int64_t n_seq, int32_t S1, int32_t n_args, int32_t n_cmd, int32_t eos_id,
                       int32_t* cmd_tgt, float* cmd_w, int32_t* arg_tgt, float* arg_w, int32_t* vis_tgt,
-                      void* stream);
+                      const int32_t* seq_perm, void* stream);
 int dsvg_masked_ce_fwd(int32_t dtype, const void* logits, int64_t ld, int32_t group, const int32_t* target,
                        const float* w, int64_t rows, int32_t C, float* lse, float* sum_count,
                        float* workspace, int64_t workspace_bytes, const int32_t* tok_idx, void* stream);

@@ -474,7 +474,13 @@ def copy_many(pairs):
         dst.copy_(src)
 
 
-def loss_targets(tgt_commands, tgt_args, cmd_args_mask, eos_id=4):
+def loss_targets(tgt_commands, tgt_args, cmd_args_mask, eos_id=4, seq_perm=None):
+    if seq_perm is not None:
+        perm = seq_perm[:tgt_commands.shape[0]].long()
+        res = loss_targets(tgt_commands[perm], tgt_args[perm], cmd_args_mask, eos_id)
+        vis = torch.empty_like(res[4])
+        vis[perm] = res[4]
+        return res[0], res[1], res[2], res[3], vis
     n_seq, S1 = tgt_commands.shape
     c = tgt_commands.long()
     is_eos = c == eos_id
