@@ -305,6 +305,33 @@ __global__ __launch_bounds__(256) void masked_ce_bwd_tok_kernel(const bf16_t* __
     }
 }
 
+// ... and for the narrow heads (command head: 7 classes, visibility head: 2; one slot per token, bf16 rows padded to 8
+// columns in dlogits): a THREAD per row - the wave-per-row kernel above spends a wave on 7 elements (34 us for 127 k rows)
+__global__ __launch_bounds__(256) void masked_ce_bwd_narrow_kernel(const bf16_t* __restrict__ logits, long long ld,
+                                                                   const int* __restrict__ target, const float* __restrict__ w,
+                                                                   const float* __restrict__ lse,
+                                                                   const float* __restrict__ sum_count,
+                                                                   const float* __restrict__ gscale, float coef,
+                                                                   bf16_t* __restrict__ dlogits, long long rows, int C) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float g = coef * (gscale ? *gscale : 1.f) / sum_count[1];
+    const float wr = w ? w[r] : 1.f;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = 0.f;
+    if (wr != 0.f) {
+        const float l = lse[r];
+        const int t = min(max(target[r], 0), C - 1);
+        const bf16_t* p = logits + r * ld;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < C) v[c] = wr * g * (__expf(bf2f(p[c]) - l) - (c == t ? 1.f : 0.f));
+    }
+    *reinterpret_cast<uint4*>(dlogits + r * 8) =
+        make_uint4(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]), f2bf_pk(v[4], v[5]), f2bf_pk(v[6], v[7]));
+}
+
 static int ce_grid(long long rows) {
     long long nb = (rows + 3) / 4;
     return (int)(nb < CE_MAX_BLOCKS ? nb : CE_MAX_BLOCKS);
@@ -357,6 +384,13 @@ extern "C" int dsvg_masked_ce_bwd(int32_t dtype, const void* logits, int64_t ld,
                            (long long)ld, group, target, w, lse, sum_count, gscale, coef, (bf16_t*)dlogits, (long long)ld_d,
                            n_tok, C, tok_idx, logits_compact);
         DSVG_LAUNCH_CHECK("masked_ce_bwd (token rows)");
+        return 0;
+    }
+    if (dtype == DSVG_BF16 && group == 1 && C <= 8 && ld_d == 8 && !tok_idx && ((uintptr_t)dlogits & 15) == 0) {
+        hipLaunchKernelGGL(masked_ce_bwd_narrow_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st,
+                           (const bf16_t*)logits, (long long)ld, target, w, lse, sum_count, gscale, coef, (bf16_t*)dlogits,
+                           (long long)rows, C);
+        DSVG_LAUNCH_CHECK("masked_ce_bwd (narrow rows)");
         return 0;
     }
     const int nb = ce_grid(rows);

@@ -565,6 +565,14 @@ def test_loss_targets_and_masked_ce(gpu_device, dtype):
     refs = R.loss_targets(tc, ta, cam)
     for o, r, nm in zip(outs, refs, ["cmd_tgt", "cmd_w", "arg_tgt", "arg_w", "vis_tgt"]):
         assert torch.equal(o.cpu(), r.cpu().to(o.dtype)), nm
+    # the same in a permuted sequence order (the second decoder stage's visible-first order): token-level outputs follow the
+    # permutation, the visibility targets stay where they were
+    perm = torch.randperm(tc.shape[0], generator=torch.Generator().manual_seed(3)).to(torch.int32).to(DEV)
+    outs_p = ops.loss_targets(tc, ta, cam, seq_perm=perm)
+    refs_p = R.loss_targets(tc, ta, cam, seq_perm=perm)
+    for o, r, nm in zip(outs_p, refs_p, ["cmd_tgt", "cmd_w", "arg_tgt", "arg_w", "vis_tgt"]):
+        assert torch.equal(o.cpu(), r.cpu().to(o.dtype)), "permuted " + nm
+    assert torch.equal(outs_p[0], outs[0][perm.long()]) and torch.equal(outs_p[4], outs[4])
     cmd_tgt, cmd_w, arg_tgt, arg_w, vis_tgt = outs
     n_tok = cmd_tgt.numel()
     for (logits, tgt, w, C_, group) in [
