@@ -619,8 +619,12 @@ int dsvg_reduce_partials_mixed(const float* part, int64_t P, int64_t stride, int
 #define DSVG_RP(V, X, B) hipLaunchKernelGGL((reduce_partials_strided_kernel<V, X, B>), dim3(dsvg_cdiv(cols, X)), dim3(256), 0, \
                                             st, part, (long long)P, (long long)stride, (long long)n, out, accumulate,      \
                                             (long long)n_bf16)
+    // a handful of columns (the loss sums: n = 2 from up to 2048 partial rows): 64 slices over the partial index - with 16
+    // of them two threads per slice summed 128 rows each, a 10 us chain of dependent loads
+    const bool narrow = !vec && n_bf16 == 0 && cols <= 4 && P > 64;
     if (n_bf16 > 0) { if (wide) DSVG_RP(4, 64, true); else DSVG_RP(4, 16, true); }
     else if (vec) { if (wide) DSVG_RP(4, 64, false); else DSVG_RP(4, 16, false); }
+    else if (narrow) DSVG_RP(1, 4, false);
     else     { if (wide) DSVG_RP(1, 64, false); else DSVG_RP(1, 16, false); }
 #undef DSVG_RP
     DSVG_LAUNCH_CHECK("reduce_partials");

@@ -140,6 +140,12 @@ class TrainStep:
         self._step_back()
         return ld
 
+    def _seed_grad(self, loss):
+        g = getattr(self, "_one", None)
+        if g is None or g.device != loss.device or g.dtype != loss.dtype:
+            g = self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        return g
+
     def _step_front(self, commands, args, label=None, dec=None):
         """forward, loss, backward: everything up to the (local) gradient in the flat buffer.
         dec = (commands_dec, args_dec) when the decoder side takes other tensors than the encoder side (relative
@@ -165,7 +171,7 @@ class TrainStep:
         try:
             out = model(commands, args, cd, ad, label=label, params={})
             ld = self.loss_fn(out, label, weights=self.weights)
-            ld["loss"].backward()
+            ld["loss"].backward(self._seed_grad(ld["loss"]))      # (a static 1: autograd would launch a fill for its own)
         finally:
             model._decoder_grads_ready = None
             model._defer_wgrad = False
@@ -199,7 +205,7 @@ class TrainStep:
             out = model(commands, args, cd, ad, label=label, params={})
             ld = self.loss_fn(out, label, weights=self.weights)
             zb = model._bottleneck_out          # (graph tensor, leaf copy the decoder consumed)
-            ld["loss"].backward()               # stops at the leaf: decoder-side gradients + leaf.grad
+            ld["loss"].backward(self._seed_grad(ld["loss"]))      # stops at the leaf: decoder-side gradients + leaf.grad
         finally:
             model._keep_bottleneck = False
             model._bottleneck_out = None
