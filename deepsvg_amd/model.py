@@ -1076,6 +1076,14 @@ class SVGTransformer(nn.Module):
             prefix = (commands_dec[..., :-1], args_dec[..., :-1, :]) if return_tgt else (commands_dec, args_dec)
         cmd_logits, args_logits, vis_logits = self._decode(rt, zz, plan, lazy_args=lazy_args, label=label,
                                                            hierarch_logits=hl, match=match, prefix=prefix)
+        if sampling and callable(args_logits):
+            # (a sampling call's lazy tensors are built without an autograd graph, whatever the grad mode at read time)
+            def _no_grad(fn):
+                def run():
+                    with torch.no_grad():
+                        return fn()
+                return run
+            args_logits = _no_grad(args_logits)
         res = ModelOutput()
         if callable(cmd_logits):        # (the training pass ran the visible groups only, see _decode)
             res.set_lazy("command_logits", cmd_logits)
