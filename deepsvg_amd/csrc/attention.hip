@@ -19,7 +19,8 @@ int dsvg_attention_fwd_mfma(const void* qkv, const uint64_t* key_mask, const int
 int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
                             const int32_t* tile_first, const void* dout, void* dqkv, int64_t n_seq, int32_t S,
                             int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
-                            hipStream_t st);
+                            hipStream_t st, const void* wo_packed_bwd = nullptr);
+int dsvg_attn_pack_bwd_launch(const float* flat, const int64_t* offs, int n_layers, void* img, hipStream_t st);
 
 template <typename T, int SP, int HG>
 struct AttnCfg {
@@ -490,6 +491,31 @@ extern "C" int dsvg_attention_bwd(int32_t dtype, const void* qkv, const uint64_t
     }
     dsvg_set_error("attention_bwd: unsupported dtype/shape (dtype=%d S=%d H=%d)", dtype, S, n_heads);
     return -1;
+}
+
+// The same with the out_proj backward inside (8 heads of 32, sequences of 17 .. 32 rows or the packed tile layout): dx1m is the
+// gradient of the block's projected output with the residual dropout mask on it, wo_packed_bwd one layer of dsvg_attn_pack_bwd
+extern "C" int dsvg_attention_bwd_outproj(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off,
+                                          int64_t total_rows, const int32_t* tile_first, const void* dx1m,
+                                          const void* wo_packed_bwd, void* dqkv, int64_t n_seq, int32_t S, float scale,
+                                          float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream) {
+    DSVG_CHECK_ARG(qkv && dx1m && wo_packed_bwd && dqkv && n_seq > 0, "attention_bwd_outproj: bad args");
+    DSVG_CHECK_ARG(drop_p <= 0.f || seed, "attention_bwd_outproj: dropout needs a seed pointer");
+    DSVG_CHECK_ARG(!seq_off || (!key_mask && total_rows > 0 && tile_first), "attention_bwd_outproj: the packed layout takes its tile list, no key mask");
+    DSVG_CHECK_ARG(seq_off || (S > 16 && S <= 32), "attention_bwd_outproj: dense sequences of 17 .. 32 rows");
+    DSVG_CHECK_ARG(dsvg_attention_mfma_ok(DSVG_BF16, S, 8), "attention_bwd_outproj: the MFMA attention kernels are switched off");
+    DSVG_CHECK_ARG(seq_off || total_rows == 0 || total_rows >= n_seq * S, "attention_bwd_outproj: total_rows < n_seq * S");
+    DSVG_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)dx1m | (uintptr_t)wo_packed_bwd | (uintptr_t)dqkv) & 15) == 0,
+                   "attention_bwd_outproj: operands must be 16-byte aligned");
+    if (!seq_off && total_rows <= n_seq * S) total_rows = 0;
+    return dsvg_attention_bwd_mfma(qkv, key_mask, seq_off, total_rows, seq_off ? tile_first : nullptr, dx1m, dqkv, n_seq, S,
+                                   8, scale, drop_p, drop_site, seed, (hipStream_t)stream, wo_packed_bwd);
+}
+
+extern "C" int64_t dsvg_attn_pack_bwd_elems(int32_t n_layers) { return (int64_t)n_layers * 128 * 512; }
+extern "C" int dsvg_attn_pack_bwd(const float* flat_f32, const int64_t* offs, int32_t n_layers, void* packed_bwd, void* stream) {
+    DSVG_CHECK_ARG(flat_f32 && offs && packed_bwd && n_layers > 0 && ((uintptr_t)packed_bwd & 15) == 0, "attn_pack_bwd: bad args");
+    return dsvg_attn_pack_bwd_launch(flat_f32, offs, n_layers, packed_bwd, (hipStream_t)stream);
 }
 
 extern "C" int dsvg_attention_causal_bwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const void* dout,

@@ -233,14 +233,19 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const bf16_t* __rest
     store_slab(out + (size_t)row0 * d + (size_t)hg * W, (long long)d, tile, LD, S, W);
 }
 
-template <int MODE>
+// FO (8 heads, d_model 256): `dout` is the gradient of the attention block's OUTPUT PROJECTION result with the residual
+// dropout mask already on it (dx1m [rows, 256]) and wo_img the packed out_proj weight (dsvg_attn_pack_bwd: A fragments of
+// Wo^T per head): the head-output gradient dO = dx1m . Wo is formed per tile on chip - each wave 16 MFMAs for its head's 32
+// columns, B operand = the staged dx1m rows - instead of by a separate GEMM launch that writes and re-reads it.
+template <int MODE, bool FO>
 __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                             const uint64_t* __restrict__ key_mask,
                                                             const int32_t* __restrict__ seq_off, long long total_rows,
                                                             const int32_t* __restrict__ tile_first, int n_seq,
                                                             const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                             int Smax, int H, float scale, float drop_p,
-                                                            uint32_t drop_site, const uint64_t* seed) {
+                                                            uint32_t drop_site, const uint64_t* seed,
+                                                            const bf16_t* __restrict__ wo_img) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);          // [32][LD]   q|k|v
     bf16_t* dtile = tile + 32 * LD;                              // [32][LDO]  dO
@@ -281,12 +286,36 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
     }
 
     const bf16_t* src = qkv + (size_t)row0 * 3 * d + (size_t)hg * W;
+    // FO: the first half of this head's Wo^T fragments, issued ahead of the tile loads (L2-resident: 8 KiB per head)
+    F8 wa[8];
+    const uint4* wp = FO ? reinterpret_cast<const uint4*>(wo_img) + (size_t)(hh * 16) * 64 + lane : nullptr;
+    if (FO) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) wa[ks].u = wp[ks * 64];
+    }
     {
         const SlabSrc sl[4] = {{src, 3LL * d, tile, LD}, {src + d, 3LL * d, tile + W, LD}, {src + 2 * d, 3LL * d, tile + 2 * W, LD},
                                {dout + (size_t)row0 * d + (size_t)hg * W, (long long)d, dtile, LDO}};
         load_slabs<4>(sl, S);
     }
     __syncthreads();
+    if (FO) {
+        // dO^T of this head: lane (token li, half h2) ends up with dO[li][32 hh + rowmap(r, h2)], the layout stage_rows takes
+        floatx16 da;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) da[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks].v, row_frag(dtile, LDO, li, 0, ks, h2), da, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) wa[ks].u = wp[(8 + ks) * 64];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks].v, row_frag(dtile, LDO, li, 0, 8 + ks, h2), da, 0, 0, 0);
+        __syncthreads();                        // every wave has read the whole dx1m tile: it may be overwritten
+        stage_rows(dtile, LDO, li, hh * 32, h2, da);
+        __builtin_amdgcn_wave_barrier();        // (the head's dO slab is written and read by this wave only: in-order LDS)
+    }
     // this lane's row (query in pass A, key in pass B): its sequence, first row of that sequence in the tile, length
     int my_seq = b, my_start = 0, my_len = S;
     if (TILED) {
@@ -446,17 +475,49 @@ int dsvg_attention_fwd_mfma(const void* qkv, const uint64_t* key_mask, const int
 int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
                             const int32_t* tile_first, const void* dout, void* dqkv, int64_t n_seq, int32_t S,
                             int32_t n_heads, float scale, float drop_p, uint32_t drop_site, const uint64_t* seed,
-                            hipStream_t st) {
+                            hipStream_t st, const void* wo_packed_bwd) {
     const size_t lds = (size_t)32 * (LD + LDO) * sizeof(bf16_t) + (size_t)HG * 96 * sizeof(float) + 34 * sizeof(int);
     const bool multi = !tile_first && !seq_off && S <= 16;
-    auto kern = tile_first ? attn_bwd_mfma_kernel<1> : (multi ? attn_bwd_mfma_kernel<2> : attn_bwd_mfma_kernel<0>);
-    DSVG_ENSURE_LDS(attn_bwd_mfma_kernel<0>, lds);
-    DSVG_ENSURE_LDS(attn_bwd_mfma_kernel<1>, lds);
-    DSVG_ENSURE_LDS(attn_bwd_mfma_kernel<2>, lds);
+    const bool fo = wo_packed_bwd != nullptr;       // (the caller checked: 8 heads, not the multi-sequence mode)
+    auto kern = fo ? (tile_first ? attn_bwd_mfma_kernel<1, true> : attn_bwd_mfma_kernel<0, true>)
+                   : (tile_first ? attn_bwd_mfma_kernel<1, false>
+                                 : (multi ? attn_bwd_mfma_kernel<2, false> : attn_bwd_mfma_kernel<0, false>));
+    DSVG_ENSURE_LDS((attn_bwd_mfma_kernel<0, false>), lds);
+    DSVG_ENSURE_LDS((attn_bwd_mfma_kernel<1, false>), lds);
+    DSVG_ENSURE_LDS((attn_bwd_mfma_kernel<2, false>), lds);
+    DSVG_ENSURE_LDS((attn_bwd_mfma_kernel<0, true>), lds);
+    DSVG_ENSURE_LDS((attn_bwd_mfma_kernel<1, true>), lds);
     const int64_t n_wg = multi ? (n_seq + 32 / S - 1) / (32 / S) : n_seq;
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg + (total_rows > 0 ? 1u : 0u), n_heads / HG), dim3(512), lds, st,
                        (const bf16_t*)qkv, key_mask, seq_off, (long long)total_rows, tile_first, (int)n_seq,
-                       (const bf16_t*)dout, (bf16_t*)dqkv, S, n_heads, scale, drop_p, drop_site, seed);
+                       (const bf16_t*)dout, (bf16_t*)dqkv, S, n_heads, scale, drop_p, drop_site, seed,
+                       (const bf16_t*)wo_packed_bwd);
     DSVG_LAUNCH_CHECK("attention_bwd_mfma");
+    return 0;
+}
+
+// packed_bwd[layer][head 8][K step 16][lane l][e] = Wo[16 ks + 8 (l >> 5) + e][32 head + (l & 31)]: the A fragments of
+// dO^T = Wo^T-columns x dx1m^T per head (offs[layer][1] = element offset of out_proj.weight [256, 256] in `flat`)
+__global__ __launch_bounds__(256) void attn_pack_bwd_kernel(const float* __restrict__ flat, const int64_t* __restrict__ offs,
+                                                            int n_layers, bf16_t* __restrict__ img) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;       // one thread per 16-byte lane slot
+    if (gid >= (long long)n_layers * 128 * 64) return;
+    const int layer = (int)(gid / (128 * 64));
+    const int s = (int)(gid % (128 * 64));
+    const int l = s & 63, f = s >> 6, hh = f >> 4, ks = f & 15;
+    const float* Wo = flat + offs[layer * 2 + 1];
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 16 * ks + 8 * (l >> 5) + 2 * e;
+        w[e] = f2bf_pk(Wo[(size_t)k * 256 + 32 * hh + (l & 31)], Wo[(size_t)(k + 1) * 256 + 32 * hh + (l & 31)]);
+    }
+    *reinterpret_cast<uint4*>(img + gid * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+int dsvg_attn_pack_bwd_launch(const float* flat, const int64_t* offs, int n_layers, void* img, hipStream_t st) {
+    const long long n = (long long)n_layers * 128 * 64;
+    hipLaunchKernelGGL(attn_pack_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat, offs, n_layers,
+                       (bf16_t*)img);
+    DSVG_LAUNCH_CHECK("attn_pack_bwd");
     return 0;
 }

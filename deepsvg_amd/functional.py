@@ -39,6 +39,8 @@ FFN_BWD_MASKED = os.environ.get("DSVG_FFN_BWD_MASKED", "0") != "0"
 # the weight-gradient GEMMs of a layer of the 4096-row stages as one grouped launch (DSVG_GROUP_WGRAD=0: one by one)
 GROUP_WGRAD = os.environ.get("DSVG_GROUP_WGRAD", "1") != "0"
 GROUP_LARGE = os.environ.get("DSVG_GROUP_LARGE", "0") != "0"
+# attention backward of the large stages with the out_proj backward inside (no `dao = dx1m @ Wo` GEMM launch)
+ATTN_BWD_OUTPROJ = os.environ.get("DSVG_ATTN_BWD_OUTPROJ", "1") != "0"
 # training forward of a large dense stage: sequences beyond a multiple of SEQ_ROUND (one round of the chip for the fused
 # attention kernel: 256 CUs x 8 sequences) run on the group-stage layer kernel when there are at most this many (0: never)
 GS_REMAINDER = int(os.environ.get("DSVG_GS_REMAINDER", "512"))
@@ -757,14 +759,24 @@ class LayerFn(torch.autograd.Function):
         if dx1m is None:
             dx1m = ops.drop_apply(dx1, p, s0 + 1, rt.seed)
         dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao)
-        dao = ops.gemm(dx1m, rt.w(wo), b_kc=False)
+        wob = None
+        if (ATTN_BWD_OUTPROJ and rt.store is not None and x.dtype == torch.bfloat16 and H == 8 and x.shape[1] == 256
+                and not ctx.causal and x.shape[0] >= ATTN_MIN_ROWS and (key_mask is None or key_mask.dtype == torch.int64)
+                and ((seq_off is None and 16 < S <= 32 and x.shape[0] >= n_seq * S) or (seq_off is not None and ctx.tiles is not None))):
+            wob = rt.store.attn_bwd(win)
+        if wob is not None:
+            # the head-output gradient dx1m @ Wo is formed tile by tile inside the attention backward kernel
+            dqkv = ops.attention_bwd_outproj(qkv, key_mask, dx1m, wob, n_seq, S, ctx.scale, p, s0, rt.seed, seq_off=seq_off,
+                                             tiles=ctx.tiles)
+        else:
+            dao = ops.gemm(dx1m, rt.w(wo), b_kc=False)
+            if ctx.causal:
+                dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed, causal=True)
+            else:
+                dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed, seq_off=seq_off,
+                                         tiles=ctx.tiles)
         keep.append(dx1m)
         del dx1m
-        if ctx.causal:
-            dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed, causal=True)
-        else:
-            dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed, seq_off=seq_off,
-                                     tiles=ctx.tiles)
         dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1)
         dxn1 = ops.gemm(dqkv, rt.w(win), b_kc=False)
         dx_out = None

@@ -369,7 +369,8 @@ class ParamStore:
             return
         n = len(rows)
         self._attn = dict(n=n, index=index, offs=torch.tensor(rows, dtype=torch.int64, device=device),
-                          img=torch.empty(n * ops.ATTN_LAYER_ELEMS, dtype=torch.bfloat16, device=device))
+                          img=torch.empty(n * ops.ATTN_LAYER_ELEMS, dtype=torch.bfloat16, device=device),
+                          bwd=torch.empty(n * ops.ATTN_BWD_LAYER_ELEMS, dtype=torch.bfloat16, device=device))
 
     def _gs_setup(self, device):
         """layers of the short-sequence ("group") stacks - hierarchical_encoder / hierarchical_decoder, model.py:153-161,
@@ -427,6 +428,17 @@ class ParamStore:
             return None
         return a["img"][i * ops.ATTN_LAYER_ELEMS:(i + 1) * ops.ATTN_LAYER_ELEMS]
 
+    def attn_bwd(self, w_in):
+        """packed out_proj^T image (attention backward with the out_proj backward inside) of the layer whose in_proj_weight
+        is w_in, or None"""
+        a = self._attn
+        if a is None or self.flat_lp is None or self.flat_lp.dtype != torch.bfloat16:
+            return None
+        i = a["index"].get(id(w_in))
+        if i is None:
+            return None
+        return a["bwd"][i * ops.ATTN_BWD_LAYER_ELEMS:(i + 1) * ops.ATTN_BWD_LAYER_ELEMS]
+
     def ffn(self, w1):
         """(packed forward image, packed backward image, folded linear1 bias, linear2.weight with fragment-ordered
         columns) of the layer whose linear1.weight is w1, or None when that layer does not run on the fused FFN kernels"""
@@ -467,6 +479,8 @@ class ParamStore:
             if dtype == torch.bfloat16 and self._attn is not None:
                 a = self._attn
                 ops.attn_pack(self.flat, a["offs"], a["n"], a["img"])
+                if torch.is_grad_enabled():     # (only a backward pass reads it)
+                    ops.attn_pack_bwd(self.flat, a["offs"], a["n"], a["bwd"])
             if dtype == torch.bfloat16 and self._gs is not None:
                 g = self._gs
                 ops.gs_pack(self.flat, g["offs"], g["n"], g["fwd"], g["bwd"])

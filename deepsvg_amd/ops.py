@@ -493,6 +493,40 @@ def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, dro
     return dqkv
 
 
+ATTN_BWD_LAYER_ELEMS = 128 * 512    # bf16 elements of one layer's packed out_proj^T image (attn_pack_bwd)
+
+
+def attn_pack_bwd(flat, offs, n_layers, packed=None):
+    """fp32 flat parameters + the [n_layers, 2] offset table of attn_pack -> per layer the A fragments of Wo^T per head, for
+    attention_bwd_outproj"""
+    _chk(flat, offs, packed)
+    assert flat.dtype == torch.float32 and offs.dtype == torch.int64 and offs.is_contiguous() and tuple(offs.shape) == (n_layers, 2)
+    if packed is None:
+        packed = torch.empty(n_layers * ATTN_BWD_LAYER_ELEMS, dtype=torch.bfloat16, device=flat.device)
+    assert packed.numel() == n_layers * ATTN_BWD_LAYER_ELEMS and packed.dtype == torch.bfloat16
+    _l.check(_l.load().dsvg_attn_pack_bwd(flat.data_ptr(), offs.data_ptr(), n_layers, packed.data_ptr(), _stream()),
+             "dsvg_attn_pack_bwd")
+    return packed
+
+
+def attention_bwd_outproj(qkv, key_mask, dx1m, wo_packed_bwd, n_seq, S, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None,
+                          tiles=None):
+    """attention_bwd of 8 heads of 32 with the out_proj backward inside: dx1m [rows, 256] is the gradient of the projected
+    output (residual dropout mask applied), the head-output gradient dx1m @ Wo never leaves the chip -> dqkv"""
+    _chk(qkv, key_mask, dx1m, wo_packed_bwd, seed, seq_off, tiles)
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and qkv.shape[1] == 768
+    assert dx1m.dtype == qkv.dtype and dx1m.is_contiguous() and tuple(dx1m.shape) == (qkv.shape[0], 256)
+    assert wo_packed_bwd.numel() == ATTN_BWD_LAYER_ELEMS and wo_packed_bwd.is_contiguous()
+    assert (seq_off is None) == (tiles is None) and (seq_off is None or (key_mask is None and seq_off.numel() == n_seq + 1))
+    dqkv = torch.empty_like(qkv)
+    _l.check(_l.load().dsvg_attention_bwd_outproj(qkv.data_ptr(), _p(key_mask), _p(seq_off), qkv.shape[0], _p(tiles),
+                                                  dx1m.data_ptr(), wo_packed_bwd.data_ptr(), dqkv.data_ptr(), n_seq, S,
+                                                  float(scale), float(drop_p), int(drop_site),
+                                                  _p(seed) if drop_p > 0 else None, _stream()),
+             "dsvg_attention_bwd_outproj")
+    return dqkv
+
+
 # ------------------------------------------------------------------------------------------------
 # masks / embedding / positional / pooling
 # ------------------------------------------------------------------------------------------------

@@ -316,6 +316,19 @@ int dsvg_add(int32_t dtype, const void* a, const void* b, void* out, int64_t n, 
 int dsvg_attention_causal_fwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, void* out, int64_t n_seq,
                               int32_t S, int32_t n_heads, float scale, float drop_p, uint32_t drop_site,
                               const uint64_t* seed, void* stream);
+/* dsvg_attention_bwd with the out_proj backward inside (bf16, 8 heads of 32; dense sequences of 17 .. 32 rows, or the packed
+ * tile layout): dx1m = gradient of the block's projected output with the residual dropout mask on it [rows, 256] (what
+ * dsvg_drop_apply / dsvg_ffn_bwd_dx hand over), wo_packed_bwd = one layer of dsvg_attn_pack_bwd.  The head-output gradient
+ * dO = dx1m . Wo is formed per tile on chip: replaces the `dao = dx1m @ out_proj.weight` GEMM launch (its 512 B / token
+ * written and re-read) in front of dsvg_attention_bwd (autograd of layers/functional.py:248-249 + :197-247).
+ * dsvg_attn_pack_bwd: offs[layer][1] = element offset of out_proj.weight in flat_f32 (the offs table of dsvg_attn_pack);
+ * packed_bwd: dsvg_attn_pack_bwd_elems(n_layers) bf16 elements. */
+int dsvg_attention_bwd_outproj(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
+                               const int32_t* tile_first, const void* dx1m, const void* wo_packed_bwd, void* dqkv,
+                               int64_t n_seq, int32_t S, float scale, float drop_p, uint32_t drop_site,
+                               const uint64_t* seed, void* stream);
+int64_t dsvg_attn_pack_bwd_elems(int32_t n_layers);
+int dsvg_attn_pack_bwd(const float* flat_f32, const int64_t* offs, int32_t n_layers, void* packed_bwd, void* stream);
 int dsvg_attention_causal_bwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const void* dout, void* dqkv,
                               int64_t n_seq, int32_t S, int32_t n_heads, float scale, float drop_p,
                               uint32_t drop_site, const uint64_t* seed, void* stream);

@@ -1150,6 +1150,42 @@ def _attn_case(kind, seed):
     raise KeyError(kind)
 
 
+@pytest.mark.parametrize("kind", ["packed", "dense31", "dense32_masked", "packed_extremes", "one_sequence_32"])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_bwd_with_the_out_proj_backward_inside(gpu_device, kind, p):
+    """dsvg_attention_bwd_outproj (dO = dx1m . Wo formed per tile on chip) against the two launches it replaces - the
+    `dao = dx1m @ Wo` GEMM and dsvg_attention_bwd - and against their fp32 torch restatement"""
+    flat, offs, prm = _attn_setup(seed=13)
+    rows, n_seq, S, km, seq_off, tiles, real = _attn_case(kind, seed=23)
+    qkv = (_rand(rows, 768, seed=33) * 0.8).to(torch.bfloat16)
+    dx1m = (_rand(rows, 256, seed=34) * 0.6).to(torch.bfloat16)
+    if real < rows:
+        dx1m[real:] = 0            # (rows behind the last sequence carry no gradient)
+    layer = 1
+    oo = int(offs[layer][1])
+    wo = flat[oo:oo + 65536].view(256, 256).to(torch.bfloat16)
+    img = ops.attn_pack_bwd(flat, offs, 2)
+    wob = img[layer * ops.ATTN_BWD_LAYER_ELEMS:(layer + 1) * ops.ATTN_BWD_LAYER_ELEMS]
+    eimg = R.attn_pack_bwd(flat, offs, 2)
+    assert torch.equal(eimg[layer * R.ATTN_BWD_LAYER_ELEMS:(layer + 1) * R.ATTN_BWD_LAYER_ELEMS].view(256, 256), wo)
+    seed = _seed_tensor(0x0BADC0FFEE12345B)
+    scale = 32 ** -0.5
+    got = ops.attention_bwd_outproj(qkv, km, dx1m, wob, n_seq, S, scale, p, 7, seed, seq_off=seq_off, tiles=tiles)
+    dao = ops.gemm(dx1m, wo, b_kc=False)
+    want = ops.attention_bwd(qkv, km, dao, n_seq, S, 8, scale, p, 7, seed, seq_off=seq_off, tiles=tiles)
+    ref = R.attention_bwd_outproj(qkv.float(), km, dx1m.float(), wo.float().reshape(-1), n_seq, S, scale, p, 7, seed,
+                                  seq_off=seq_off, tiles=tiles)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    r = slice(0, real)
+    # the unfused pair rounds dao to bf16 before the attention backward reads it, the fused kernel does too (its staging tile)
+    _close(got[r], want[r], 1.5e-2, "dqkv vs GEMM + attention_bwd")
+    _close(got[r], ref[r], 2e-2, "dqkv vs fp32 torch")
+    assert ((got[r].float() - ref[r].float()).abs().mean() <= 4e-3 * ref[r].float().abs().mean()).item()
+    if real < rows:
+        assert torch.count_nonzero(got[real:]) == 0
+
+
 @pytest.mark.parametrize("kind", ["packed", "dense31", "dense32_masked", "dense8_masked_tail", "packed_extremes"])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_attn_block_fwd_against_fp32_torch(gpu_device, kind, p):

@@ -862,6 +862,26 @@ def attn_pack(flat, offs, n_layers, packed=None):
     return packed
 
 
+ATTN_BWD_LAYER_ELEMS = 128 * 512
+
+
+def attn_pack_bwd(flat, offs, n_layers, packed=None):
+    """emulated image of a layer: out_proj.weight itself (bf16, row-major [256, 256])"""
+    if packed is None:
+        packed = torch.empty(n_layers * ATTN_BWD_LAYER_ELEMS, dtype=torch.bfloat16, device=flat.device)
+    for i in range(n_layers):
+        oo = int(offs[i][1])
+        packed[i * ATTN_BWD_LAYER_ELEMS:(i + 1) * ATTN_BWD_LAYER_ELEMS] = flat[oo:oo + 65536].to(torch.bfloat16)
+    return packed
+
+
+def attention_bwd_outproj(qkv, key_mask, dx1m, wo_packed_bwd, n_seq, S, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None,
+                          tiles=None):
+    """the two launches it replaces: dao = dx1m @ Wo (rounded to the storage dtype), then attention_bwd"""
+    dao = (_f(dx1m) @ _f(wo_packed_bwd.view(256, 256))).to(qkv.dtype)
+    return attention_bwd(qkv, key_mask, dao, n_seq, S, 8, scale, drop_p, drop_site, seed, seq_off=seq_off, tiles=tiles)
+
+
 # ------------------------------------------------------------------------------------------------
 # the argument head fused with its consumers (csrc/head_fused.hip).  The emulated image is the bf16 weight itself; the
 # restatement is head GEMM (fp32 accumulation, logits NOT rounded to bf16 - they never leave the chip) + the masked-CE math.
