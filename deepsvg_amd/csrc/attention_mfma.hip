@@ -293,13 +293,36 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) wa[ks].u = wp[ks * 64];
     }
-    {
+    if (!FO) {
         const SlabSrc sl[4] = {{src, 3LL * d, tile, LD}, {src + d, 3LL * d, tile + W, LD}, {src + 2 * d, 3LL * d, tile + 2 * W, LD},
                                {dout + (size_t)row0 * d + (size_t)hg * W, (long long)d, dtile, LDO}};
         load_slabs<4>(sl, S);
-    }
-    __syncthreads();
-    if (FO) {
+        __syncthreads();
+    } else {
+        // the dx1m tile first, then the q | k | v slabs: their loads are in flight (registers) while the tile's dO^T = Wo^T-
+        // columns x dx1m^T runs - loads return in order, so the wait for the dx1m pieces leaves the six later ones pending
+        constexpr int CPR = W / 8;
+        const int rmax = S > 0 ? S - 1 : 0;
+        uint4 vd[2], vq[3][2];
+        const bf16_t* dsrc = dout + (size_t)row0 * d + (size_t)hg * W;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = threadIdx.x + 512 * k, r = idx / CPR, c = idx % CPR;
+            vd[k] = *reinterpret_cast<const uint4*>(dsrc + (long long)min(r, rmax) * d + 8 * c);
+        }
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = threadIdx.x + 512 * k, r = idx / CPR, c = idx % CPR;
+                vq[n][k] = *reinterpret_cast<const uint4*>(src + (size_t)n * d + (long long)min(r, rmax) * 3 * d + 8 * c);
+            }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = threadIdx.x + 512 * k, r = idx / CPR, c = idx % CPR;
+            *reinterpret_cast<uint4*>(dtile + r * LDO + 8 * c) = r < S ? vd[k] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
         // dO^T of this head: lane (token li, half h2) ends up with dO[li][32 hh + rowmap(r, h2)], the layout stage_rows takes
         floatx16 da;
 #pragma unroll
@@ -312,7 +335,14 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_mfma_kernel(const bf16_t* __r
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
             da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks].v, row_frag(dtile, LDO, li, 0, 8 + ks, h2), da, 0, 0, 0);
-        __syncthreads();                        // every wave has read the whole dx1m tile: it may be overwritten
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = threadIdx.x + 512 * k, r = idx / CPR, c = idx % CPR;
+                *reinterpret_cast<uint4*>(tile + n * W + r * LD + 8 * c) = r < S ? vq[n][k] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        __syncthreads();                        // every wave has read the whole dx1m tile; q | k | v are staged
         stage_rows(dtile, LDO, li, hh * 32, h2, da);
         __builtin_amdgcn_wave_barrier();        // (the head's dO slab is written and read by this wave only: in-order LDS)
     }
