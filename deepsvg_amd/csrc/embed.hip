@@ -748,6 +748,55 @@ __global__ void bcast_add_bwd_kernel(const T* __restrict__ dx, T* __restrict__ d
         Elem<T>::st(dg + b * d + c, s * drop_mult(dc, (uint64_t)b * d + c));
     }
 }
+// bf16 rows of d % 8 == 0 columns: a thread owns 8 columns of one sequence (16-byte loads, 8 rows in flight), a workgroup
+// 256 / (d / 8) sequences - the kernel above reads 2 bytes per lane (19 us for 71 k rows of 256 columns)
+__global__ __launch_bounds__(256) void bcast_add_bwd8_kernel(const bf16_t* __restrict__ dx, bf16_t* __restrict__ dg,
+                                                             long long n_seq, long long n_seq_out, int S, int d,
+                                                             float drop_p, uint32_t site, const uint64_t* seed) {
+    const int cpr = d / 8;
+    const long long b = (long long)blockIdx.x * (256 / cpr) + threadIdx.x / cpr;
+    const int c8 = (threadIdx.x % cpr) * 8;
+    if (threadIdx.x >= (256 / cpr) * cpr || b >= n_seq_out) return;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (b < n_seq) {
+        const DropCtx dc = drop_make(drop_p, seed, site);
+        const bf16_t* px = dx + (b * S) * d + c8;
+        int i = 0;
+        for (; i + 8 <= S; i += 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(px + (long long)(i + u) * d);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[2 * e] += __uint_as_float(w[e] << 16);
+                    s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+                }
+            }
+        }
+        for (; i < S; ++i) {
+            const uint4 t = *reinterpret_cast<const uint4*>(px + (long long)i * d);
+            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[2 * e] += __uint_as_float(w[e] << 16);
+                s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+            }
+        }
+        if (dc.on) {
+            float dm[8];
+            drop_mult8(dc, (uint64_t)b * d + c8, dm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] *= dm[e];
+        }
+    }
+    *reinterpret_cast<uint4*>(dg + b * d + c8) =
+        make_uint4(f2bf_pk(s[0], s[1]), f2bf_pk(s[2], s[3]), f2bf_pk(s[4], s[5]), f2bf_pk(s[6], s[7]));
+}
 extern "C" int dsvg_bcast_add_fwd(int32_t dtype, void* x, const void* g, int64_t n_seq, int32_t S, int32_t d,
                                   float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream) {
     DSVG_CHECK_ARG(x && g && n_seq > 0 && S > 0 && d > 0, "bcast_add_fwd: bad args");
@@ -771,7 +820,12 @@ extern "C" int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64
     if (dtype == DSVG_F32)
         hipLaunchKernelGGL(bcast_add_bwd_kernel<float>, dim3((unsigned)n_seq_out), dim3(256), 0, st, (const float*)dx,
                            (float*)dg, (long long)n_seq, S, d, drop_p, drop_site, seed);
-    else if (dtype == DSVG_BF16)
+    else if (dtype == DSVG_BF16 && (d % 8) == 0 && d <= 2048 && (((uintptr_t)dx | (uintptr_t)dg) & 15) == 0) {
+        const int per = 256 / (d / 8);
+        hipLaunchKernelGGL(bcast_add_bwd8_kernel, dim3((unsigned)((n_seq_out + per - 1) / per)), dim3(256), 0, st,
+                           (const bf16_t*)dx, (bf16_t*)dg, (long long)n_seq, (long long)n_seq_out, S, d, drop_p, drop_site,
+                           seed);
+    } else if (dtype == DSVG_BF16)
         hipLaunchKernelGGL(bcast_add_bwd_kernel<bf16_t>, dim3((unsigned)n_seq_out), dim3(256), 0, st, (const bf16_t*)dx,
                            (bf16_t*)dg, (long long)n_seq, S, d, drop_p, drop_site, seed);
     else { dsvg_set_error("bcast_add_bwd: bad dtype"); return -1; }
