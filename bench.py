@@ -31,6 +31,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")     # before the HIP runtime comes up (see deepsvg_amd/__init__.py)
+
 import torch
 import torch.distributed as dist
 
@@ -360,7 +362,9 @@ def main():
         plan_ms = sum(t[1] - t[0] for t in tr) / len(tr) * 1e3
         launch_ms = sum(t[2] - t[1] for t in tr) / len(tr) * 1e3
         period_ms = (tr[-1][0] - tr[0][0]) / max(len(tr) - 1, 1) * 1e3
-        log(f"host trace: plan + read {plan_ms:.3f} ms, copies + graph launch {launch_ms:.3f} ms, step period {period_ms:.3f} ms")
+        only_plan_ms = sum(t[3] - t[0] for t in tr) / len(tr) * 1e3 if len(tr[0]) > 3 else float("nan")
+        log(f"host trace: plan + read {plan_ms:.3f} ms (of which the layout plan and its read {only_plan_ms:.3f}), copies + graph "
+            f"launch {launch_ms:.3f} ms, step period {period_ms:.3f} ms")
     ms_per_step = elapsed / a.steps * 1e3
     icons_per_s = a.batch * world / (elapsed / a.steps)
     graphs = {"launch_mode": "hipGraph replay" if use_graph else "eager", "batches_rotated": n_b,

@@ -65,15 +65,20 @@ class TrainStep:
         # so that the decoder half of the gradient is all-reduced while the second graph runs, as the eager path does with
         # its hook.  The cut is the bottleneck output (the decoder's only input): configs where the loss reaches the
         # encoder by another path too (the VAE's KL term on mu / logsigma) keep the single graph.
+        # Opt-in (DSVG_DDP_SPLIT_GRAPH=1 / split_graph=True): it could only be measured over a ONE-rank RCCL group, where it
+        # costs 0.05 ms/step (6.90 against 6.85 for the single graph) and, with GPU_MAX_HW_QUEUES=8, fell into a 15 ms/step
+        # pathology (deepsvg_amd/__init__.py) - the expected gain at 8 ranks (~60 % of a ~0.4 ms all-reduce hidden) does not
+        # justify that risk unmeasured.
         self.split_graph = (self.ddp and self.overlap_allreduce and not getattr(model.cfg, "use_vae", False)
                             and getattr(model.cfg, "encode_stages", 0) > 0
-                            and os.environ.get("DSVG_DDP_SPLIT_GRAPH", "1") != "0")
+                            and os.environ.get("DSVG_DDP_SPLIT_GRAPH", "0") != "0")
         self._zb = None
         self._pending = None
         self._pool = None
         self._gradless_known, self._gradless_slots = False, []
         # DSVG_TRACE_STEP=1: host-side time stamps of every step (entry, plan read done, graph launched) in `host_trace`
         self.host_trace = [] if os.environ.get("DSVG_TRACE_STEP") == "1" else None
+        self._count_stream = None
         self.row_bucket, self.seq_bucket = 1024, 64
         self.defer_reductions = os.environ.get("DSVG_DEFER_REDUCE", "1") != "0"
         model._own_seed = False          # the trainer advances the dropout seed once per step
@@ -273,10 +278,24 @@ class TrainStep:
         counts = None
         with torch.cuda.stream(ps):
             plan = model.make_plan(commands, args, dec[0] if dec else commands, True, dec[1] if dec else args)
-            if self.ddp and self.use_graph:
-                # data parallel + hipGraph: the 3-element count all-reduce rides on the plan stream too (under the
-                # previous step's graph); its result is copied into the graph's static tensor right before the replay
+        t_plan = time.perf_counter() if self.host_trace is not None else None
+        if self.ddp and self.use_graph:
+            # data parallel + hipGraph: the 3-element count all-reduce goes out before the replay, its result is copied into
+            # the graph's static tensor.  It runs on a stream of its OWN: RCCL executes a communicator's collectives in
+            # issue order, so this one sits behind the previous step's gradient all-reduce - on the plan stream its wait
+            # would hold back the NEXT step's plan kernels, the host's read of their result would block until the
+            # previous step has finished, and the host could never run ahead of the GPU (measured on a one-rank group:
+            # plan + read 6.7 ms instead of 0.45 ms, every graph launch exposed: 7.27 ms/step against 6.74 single-GPU)
+            if self._count_stream is None:
+                self._count_stream = torch.cuda.Stream(device=commands.device)
+            cs = self._count_stream
+            cs.wait_stream(ps)
+            with torch.cuda.stream(cs):
                 counts = self._global_counts(dec[0] if dec else commands, dec[1] if dec else args, plan)
+            if plan["loss"] is not None:
+                for t in plan["loss"]["targets"]:
+                    t.record_stream(cs)
+            main.wait_stream(cs)
         main.wait_stream(ps)
         if t_trace is not None:
             t_trace.append(time.perf_counter())
@@ -339,6 +358,7 @@ class TrainStep:
             entry[0].replay()
         if t_trace is not None:
             t_trace.append(time.perf_counter())
+            t_trace.append(t_plan)
             self.host_trace.append(tuple(t_trace))
         if self.ddp:
             self._step_back()

@@ -502,15 +502,14 @@ def test_data_parallel_step_over_rccl_one_rank(gpu_device):
             model = _hip_model(cfg, sd, torch.bfloat16).train()
             ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=1e-3, **kw)
             assert ts.ddp == ("force_ddp" in kw)
-            if name == "ddp_graph_one":
-                ts.split_graph = False          # the whole forward + backward as one graph, one all-reduce behind it
+            # (split_graph is opt-in: DSVG_DDP_SPLIT_GRAPH=1) two graphs per bucket with the decoder bucket's all-reduce between
+            # them, against the whole forward + backward as one graph with one all-reduce behind it
+            ts.split_graph = name == "ddp_graph"
             losses = [float(ts.step(c, a)["loss"]) for c, a in batches]
             torch.cuda.synchronize()
             runs[name] = (losses, model.store.flat.detach().clone(), ts.grad_norm())
             if name.startswith("ddp_graph"):
                 assert len(ts._graphs) >= 1 and ts._counts is not None
-                # default: two graphs per bucket (decoder side | encoder-side backward), the decoder bucket's all-reduce
-                # between them
                 assert all(isinstance(e[0], tuple) == (name == "ddp_graph") for e in ts._graphs.values())
         # the split step issues the same kernels on the same data in the same order: identical to the one-graph step
         assert runs["ddp_graph"][0] == runs["ddp_graph_one"][0]
