@@ -816,15 +816,15 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
 //     dgamma[k] = sum_j W1[j][k] G1p[p(j)][k],                  dbeta[k] = sum_j W1[j][k] db1p[p(j)]
 // One workgroup per 4 columns k (and 4 rows o of dW2); fixed summation order (deterministic).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ffn_wgrad_finish_kernel(const float* __restrict__ G1p, const float* __restrict__ db1p,
-                                                               const float* __restrict__ G2p, const float* __restrict__ W1,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               float* __restrict__ dW1, float* __restrict__ db1,
-                                                               float* __restrict__ dW2, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta) {
+__device__ __forceinline__ void ffn_wgrad_finish_body(const float* __restrict__ G1p, const float* __restrict__ db1p,
+                                                      const float* __restrict__ G2p, const float* __restrict__ W1,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ dW1, float* __restrict__ db1,
+                                                      float* __restrict__ dW2, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, int block) {
     __shared__ float red[2][4][256];
     const int t = threadIdx.x;
-    const int k0 = blockIdx.x * 4;
+    const int k0 = block * 4;
     const float4 ga = *reinterpret_cast<const float4*>(gamma + k0);
     const float4 be = *reinterpret_cast<const float4*>(beta + k0);
     float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
@@ -838,8 +838,8 @@ __global__ __launch_bounds__(256) void ffn_wgrad_finish_kernel(const float* __re
             make_float4(ga.x * g.x + be.x * b, ga.y * g.y + be.y * b, ga.z * g.z + be.z * b, ga.w * g.w + be.w * b);
         dg[0] += w.x * g.x; dg[1] += w.y * g.y; dg[2] += w.z * g.z; dg[3] += w.w * g.w;
         db[0] += w.x * b; db[1] += w.y * b; db[2] += w.z * b; db[3] += w.w * b;
-        if (blockIdx.x == 0) db1[j] = b;
-        // rows o = k0 .. k0 + 3 of dW2 (blockIdx.x < 64 covers all 256 rows)
+        if (block == 0) db1[j] = b;
+        // rows o = k0 .. k0 + 3 of dW2 (block < 64 covers all 256 rows)
 #pragma unroll
         for (int oo = 0; oo < 4; ++oo) dW2[(size_t)(k0 + oo) * FF + j] = G2p[(size_t)(k0 + oo) * FF + pj];
     }
@@ -852,6 +852,23 @@ __global__ __launch_bounds__(256) void ffn_wgrad_finish_kernel(const float* __re
         for (int i = 0; i < 256; ++i) a += r[i];
         if (t < 4) dgamma[k0 + t] = a; else dbeta[k0 + t - 4] = a;
     }
+}
+__global__ __launch_bounds__(256) void ffn_wgrad_finish_kernel(const float* __restrict__ G1p, const float* __restrict__ db1p,
+                                                               const float* __restrict__ G2p, const float* __restrict__ W1,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ dW1, float* __restrict__ db1,
+                                                               float* __restrict__ dW2, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+    ffn_wgrad_finish_body(G1p, db1p, G2p, W1, gamma, beta, dW1, db1, dW2, dgamma, dbeta, (int)blockIdx.x);
+}
+// the same for up to 16 layers in one launch (the table travels in the kernel arguments): a backward pass finishes all of
+// its fused-FFN layers behind the one batched reduction launch
+constexpr int FINISH_MAX = 16;
+struct FinishTable { const float* in[FINISH_MAX][6]; float* out[FINISH_MAX][5]; };
+__global__ __launch_bounds__(256) void ffn_wgrad_finish_many_kernel(const FinishTable t) {
+    const int layer = blockIdx.x / (FD / 4), block = blockIdx.x % (FD / 4);
+    ffn_wgrad_finish_body(t.in[layer][0], t.in[layer][1], t.in[layer][2], t.in[layer][3], t.in[layer][4], t.in[layer][5],
+                          t.out[layer][0], t.out[layer][1], t.out[layer][2], t.out[layer][3], t.out[layer][4], block);
 }
 
 }  // namespace
@@ -964,5 +981,22 @@ extern "C" int dsvg_ffn_wgrad_finish(const float* g1p, const float* db1p, const 
     hipLaunchKernelGGL(ffn_wgrad_finish_kernel, dim3(FD / 4), dim3(256), 0, (hipStream_t)stream, g1p, db1p, g2p, w1, gamma,
                        beta, dw1, db1, dw2, dgamma, dbeta);
     DSVG_LAUNCH_CHECK("ffn_wgrad_finish");
+    return 0;
+}
+
+extern "C" int dsvg_ffn_wgrad_finish_many(const void* const* ptrs, int32_t n_layers, void* stream) {
+    DSVG_CHECK_ARG(ptrs && n_layers > 0, "ffn_wgrad_finish_many: bad arguments");
+    for (int base = 0; base < n_layers; base += FINISH_MAX) {
+        const int n = n_layers - base < FINISH_MAX ? n_layers - base : FINISH_MAX;
+        FinishTable t{};
+        for (int i = 0; i < n; ++i) {
+            const void* const* p = ptrs + (size_t)(base + i) * 11;
+            for (int k = 0; k < 11; ++k) DSVG_CHECK_ARG(p[k], "ffn_wgrad_finish_many: null pointer");
+            for (int k = 0; k < 6; ++k) t.in[i][k] = (const float*)p[k];
+            for (int k = 0; k < 5; ++k) t.out[i][k] = (float*)const_cast<void*>(p[6 + k]);
+        }
+        hipLaunchKernelGGL(ffn_wgrad_finish_many_kernel, dim3(n * (FD / 4)), dim3(256), 0, (hipStream_t)stream, t);
+        DSVG_LAUNCH_CHECK("ffn_wgrad_finish_many");
+    }
     return 0;
 }

@@ -716,13 +716,12 @@ class LayerFn(torch.autograd.Function):
                 dn2w, dn2b = rt.grad_out(n2w), rt.grad_out(n2b)
                 # (aliases of the gradient tensors: AccumulateGrad adopts a returned gradient only while nobody else
                 # holds a reference to that tensor object, otherwise it clones it - here before it is even written)
-                finish = functools.partial(ops.ffn_wgrad_finish, g1p, db1p, g2p, w1.detach(), n2w.detach(),
-                                           n2b.detach(), dw1.detach(), db1.detach(), dw2.detach(), dn2w.detach(),
-                                           dn2b.detach())
+                fin = (g1p, db1p, g2p, w1.detach(), n2w.detach(), n2b.detach(), dw1.detach(), db1.detach(), dw2.detach(),
+                       dn2w.detach(), dn2b.detach())
                 if rt.defer:
-                    ops.defer_post(finish)      # reads the queued reductions' outputs: runs right after the flush
-                else:
-                    finish()
+                    ops.ffn_wgrad_finish_deferred(*fin)     # reads the queued reductions' outputs: runs right after the
+                else:                                       # flush, one launch for all the layers of the backward pass
+                    ops.ffn_wgrad_finish(*fin)
             keep += [hp, dpre, xh, dym]
             del hp, dpre, xh, dym
         else:

@@ -100,10 +100,10 @@ def _stream_key():
 
 
 class _DeferState:
-    __slots__ = ("depth", "keep", "post", "bytes_by_tag")
+    __slots__ = ("depth", "keep", "post", "bytes_by_tag", "finish")
 
     def __init__(self):
-        self.depth, self.keep, self.post, self.bytes_by_tag = 0, [], [], {}
+        self.depth, self.keep, self.post, self.bytes_by_tag, self.finish = 0, [], [], {}, []
 
 
 class _DeferScope:
@@ -158,7 +158,7 @@ def flush_deferred():
     """perform every reduction queued on the current stream (one launch per 64), then the work registered with defer_post"""
     key = _stream_key()
     st = _DEFER.state.get(key)
-    if st is None or not (st.keep or st.post):
+    if st is None or not (st.keep or st.post or st.finish):
         if st is not None and st.depth == 0:
             _DEFER.state.pop(key, None)
         return
@@ -176,6 +176,10 @@ def flush_deferred():
             PROFILE.append(("reduce", ev, ev1, 0.0, float(sum(st.bytes_by_tag.values())),
                             dict(op="reduce_deferred", by_tag=dict(st.bytes_by_tag))))
     st.bytes_by_tag = {}
+    if st.finish:           # the fused-FFN layers' gradient finishes queued behind the reductions: one launch for all of them
+        fin, st.finish = st.finish, []
+        with tag("ffn"):
+            ffn_wgrad_finish_many(fin)
     post, st.post = st.post, []
     for fn, t in post:
         if t is None:
@@ -1158,6 +1162,29 @@ def ffn_wgrad_finish(g1p, db1p, g2p, w1, gamma, beta, dw1, db1, dw2, dgamma, dbe
     ev = _prof_begin()
     _l.check(_l.load().dsvg_ffn_wgrad_finish(*(t.data_ptr() for t in ts), _stream()), "dsvg_ffn_wgrad_finish")
     _prof_end(ev, 0.0, 0.0, dict(op="ffn_wgrad_finish"))
+
+
+def ffn_wgrad_finish_many(layers):
+    """ffn_wgrad_finish for a list of layers (each the 11 tensors of ffn_wgrad_finish) in one launch per 16"""
+    if not layers:
+        return
+    flat = [t for ts in layers for t in ts]
+    _chk(*flat)
+    assert all(len(ts) == 11 for ts in layers) and all(t.dtype == torch.float32 and t.is_contiguous() for t in flat)
+    ptrs = (C.c_void_p * len(flat))(*[t.data_ptr() for t in flat])
+    ev = _prof_begin()
+    _l.check(_l.load().dsvg_ffn_wgrad_finish_many(ptrs, len(layers), _stream()), "dsvg_ffn_wgrad_finish_many")
+    _prof_end(ev, 0.0, 0.0, dict(op="ffn_wgrad_finish"))
+
+
+def ffn_wgrad_finish_deferred(*ts):
+    """ffn_wgrad_finish behind the queued reductions of the current stream's open deferral scope (all such layers of a
+    backward pass in ONE launch at the flush); without an open scope: now"""
+    st = _DEFER.state.get(_stream_key())
+    if st is None:
+        ffn_wgrad_finish(*ts)
+    else:
+        st.finish.append(ts)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -479,6 +479,9 @@ int dsvg_ffn_bwd_dx(const void* dpre, const void* x, const void* dy, const void*
 int dsvg_ffn_wgrad_finish(const float* g1p, const float* db1p, const float* g2p, const float* w1, const float* gamma,
                           const float* beta, float* dw1, float* db1, float* dw2, float* dgamma, float* dbeta,
                           void* stream);
+/* the same for n_layers layers in one launch per 16: ptrs = n_layers x 11 pointers in the argument order of
+ * dsvg_ffn_wgrad_finish (g1p, db1p, g2p, w1, gamma, beta, dw1, db1, dw2, dgamma, dbeta), a host array */
+int dsvg_ffn_wgrad_finish_many(const void* const* ptrs, int32_t n_layers, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused attention sub-block (d_model 256, 8 heads of 32, sequences of at most 32 tokens, bf16):

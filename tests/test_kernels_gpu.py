@@ -1016,6 +1016,18 @@ def test_ffn_wgrad_finish_and_full_gradients(gpu_device):
     R.ffn_wgrad_finish(g1p, db1p, g2p, W1.detach(), gamma.detach(), beta.detach(), *eouts)
     for a, b in zip(outs, eouts):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4)
+    # the batched launch (all fused-FFN layers of a backward pass at once; 19 layers: two launches of 16 + 3): bit-identical
+    layers = []
+    for i in range(19):
+        o_i = [torch.full_like(t, float("nan")) for t in outs]
+        layers.append((g1p * (i + 1), db1p * (i + 1), g2p * (i + 1), W1.detach().contiguous(), gamma.detach().contiguous(),
+                       beta.detach().contiguous(), *o_i))
+    ops.ffn_wgrad_finish_many(layers)
+    for i in (0, 7, 16, 18):
+        single = [torch.empty_like(t) for t in outs]
+        ops.ffn_wgrad_finish(*layers[i][:6], *single)
+        for a, b in zip(layers[i][6:], single):
+            assert torch.equal(a, b), f"batched finish differs from the single launch (layer {i})"
     checks = [("dx", dx.float(), xf.grad), ("dW1", dw1.view(512, 256), W1.grad), ("db1", db1, b1.grad),
               ("dW2", dw2.view(256, 512), W2.grad), ("db2", db2, dy.float().sum(0)), ("dgamma", dgamma, gamma.grad),
               ("dbeta", dbeta, beta.grad)]

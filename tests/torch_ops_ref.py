@@ -795,6 +795,11 @@ def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, s
     return y, hp, xh, rstd
 
 
+def ffn_wgrad_finish_many(layers):
+    for ts in layers:
+        ffn_wgrad_finish(*ts)
+
+
 def _ffn_frag_perm(device):
     """position p(j) of hidden unit j in the fragment-ordered h / dpre matrices: bits 2 and 3 of j swapped"""
     j = torch.arange(512, device=device)
