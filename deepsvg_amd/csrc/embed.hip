@@ -376,6 +376,111 @@ __global__ __launch_bounds__(256) void embed_scatter_arg_kernel(const float* __r
     for (int i = threadIdx.x; i < tab; i += 256) dst[i] = acc[i];
 }
 
+// The same table gradient as ONE-HOT MATRIX PRODUCTS on the matrix cores (bf16 gradients, E = 64): per argument slot a,
+//     dTable^T[e][v] += sum_t dA[t][a][e] * [arg(t, a) + 1 == v]
+// i.e. A = a hardware-transposed 32-token x 32-column block of the staged gradient rows (ds_read_b64_tr_b16), B = the
+// one-hot of the same 32 tokens' indices against this wave's 32 table rows, built in registers from the staged indices.
+// A workgroup of 8 waves owns ES_TOK_PER_BLOCK tokens; wave w accumulates table rows 32 w .. 32 w + 31 (wave 0 also the
+// rows from 256 on), both 32-column halves: fp32 accumulation in a FIXED order - unlike the LDS float atomics of the
+// kernel above, which also run at a fraction of a lane per clock (93 us for 41 k tokens; this one is bound by reading dA).
+typedef __bf16 es_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short es_shortx4 __attribute__((ext_vector_type(4)));
+typedef float es_floatx16 __attribute__((ext_vector_type(16)));
+constexpr int ESM_LD = 11 * 64 + 8;         // row stride (elements) of the staged gradient rows: 1424 B = 89 x 16 B
+__device__ __forceinline__ int es_rowmap(int r, int h2) { return (r & 3) + 8 * (r >> 2) + 4 * h2; }
+__global__ __launch_bounds__(512) void embed_scatter_arg_mfma_kernel(const float* __restrict__ args,
+                                                                     const bf16_t* __restrict__ dA, float* __restrict__ part,
+                                                                     long long T_tok, int n_args, int n_argvals) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char es_smem[];
+    bf16_t* img = reinterpret_cast<bf16_t*>(es_smem);                   // [32 tokens][ESM_LD]
+    int* sidx = reinterpret_cast<int*>(es_smem + 32 * ESM_LD * 2);      // [32 tokens][16]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h2 = lane >> 5;
+    const int width = n_args * 64, cpr = width / 8;
+    const long long t0 = (long long)blockIdx.x * ES_TOK_PER_BLOCK;
+    const long long t1 = min(T_tok, t0 + ES_TOK_PER_BLOCK);
+    const int n_vt = wave == 0 && n_argvals > 256 ? 2 : 1;             // value tiles of this wave: w (and 8 for wave 0)
+    es_floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (long long tb = t0; tb < t1; tb += 32) {
+        const int nt = (int)min(32LL, t1 - tb);
+        // stage the chunk: gradient rows (rows past the end: zeros) and the +1-shifted, clamped indices
+        for (int idx = threadIdx.x; idx < 32 * cpr; idx += 512) {
+            const int r = idx / cpr, c = idx % cpr;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (r < nt) v = *reinterpret_cast<const uint4*>(dA + (tb + r) * width + 8 * c);
+            *reinterpret_cast<uint4*>(img + r * ESM_LD + 8 * c) = v;
+        }
+        if (threadIdx.x < 32 * 16) {
+            const int r = threadIdx.x >> 4, a = threadIdx.x & 15;
+            int iv = -1;                                                // (no table row: padding tokens / slots)
+            if (r < nt && a < n_args) iv = min(max((int)args[(tb + r) * n_args + a] + 1, 0), n_argvals - 1);
+            sidx[r * 16 + a] = iv;
+        }
+        __syncthreads();
+        for (int a = 0; a < n_args; ++a) {
+            // the one-hot B fragments of this slot: lane (table row li of the tile, half h2), K slot e of step ks = token
+            // row es_rowmap(8 ks + e, h2) - the K order of the transposed reads below
+            es_bf16x8 oh[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                int tok_idx[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tok_idx[e] = sidx[es_rowmap(8 * ks + e, h2) * 16 + a];
+#pragma unroll
+                for (int vt = 0; vt < 2; ++vt) {
+                    if (vt >= n_vt) break;      // (wave-uniform)
+                    const int v = (vt == 0 ? 32 * wave : 256) + li;
+                    uint32_t w[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        w[e] = (tok_idx[2 * e] == v ? 0x3f80u : 0u) | (tok_idx[2 * e + 1] == v ? 0x3f800000u : 0u);
+                    union { es_bf16x8 v8; uint4 u; } f;
+                    f.u = make_uint4(w[0], w[1], w[2], w[3]);
+                    oh[vt][ks] = f.v8;
+                }
+            }
+#pragma unroll
+            for (int ntile = 0; ntile < 2; ++ntile) {
+                const int col0 = a * 64 + 32 * ntile;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    // A[i = column col0 + (lane & 31)][K slot e] = img[row es_rowmap(8 ks + e, lane >> 5)][col0 + i]
+                    const int g = lane >> 4, q16 = lane & 15;
+                    const int row = 16 * ks + 4 * (g >> 1) + (q16 >> 2);
+                    const int col = col0 + 16 * (g & 1) + 4 * (q16 & 3);
+                    union { es_bf16x8 v8; es_shortx4 h[2]; } fa;
+                    fa.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (es_shortx4 __attribute__((address_space(3)))*)(&img[row * ESM_LD + col]));
+                    fa.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (es_shortx4 __attribute__((address_space(3)))*)(&img[(row + 8) * ESM_LD + col]));
+                    acc[0][ntile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v8, oh[0][ks], acc[0][ntile], 0, 0, 0);
+                    if (n_vt == 2)
+                        acc[1][ntile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v8, oh[1][ks], acc[1][ntile], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // acc[vt][ntile][r] = dTable[v = tile base + li][e = 32 ntile + es_rowmap(r, h2)]
+    float* dst = part + (size_t)blockIdx.x * n_argvals * 64;
+#pragma unroll
+    for (int vt = 0; vt < 2; ++vt) {
+        if (vt >= n_vt) break;
+        const int v = (vt == 0 ? 32 * wave : 256) + li;
+        if (v >= n_argvals) continue;
+#pragma unroll
+        for (int ntile = 0; ntile < 2; ++ntile)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(size_t)v * 64 + 32 * ntile + es_rowmap(r, h2)] = acc[vt][ntile][r];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void embed_scatter_row_kernel(const float* __restrict__ commands,
                                                                 const int* __restrict__ groups,
@@ -468,6 +573,14 @@ extern "C" int dsvg_embed_scatter(int32_t dtype, const float* commands, const fl
         auto kr = embed_scatter_row_kernel<bf16_t>;
         DSVG_ENSURE_LDS(ka, lds_a);
         DSVG_ENSURE_LDS(kr, lds_r);
+        static const bool mfma_off = getenv("DSVG_EMBED_SCATTER_MFMA") && atoi(getenv("DSVG_EMBED_SCATTER_MFMA")) == 0;
+        if (!mfma_off && E == 64 && n_args == 11 && n_argvals > 224 && n_argvals <= 288 && ((uintptr_t)dA & 15) == 0) {
+            // (table rows 32 w .. of wave w; rows >= 256: wave 0's second tile - the tiles cover 288 rows)
+            const size_t lds_m = (size_t)32 * ESM_LD * 2 + 32 * 16 * sizeof(int);
+            DSVG_ENSURE_LDS(embed_scatter_arg_mfma_kernel, lds_m);
+            hipLaunchKernelGGL(embed_scatter_arg_mfma_kernel, dim3(nb), dim3(512), lds_m, st, args, (const bf16_t*)dA, part_arg,
+                               (long long)T_tok, n_args, n_argvals);
+        } else
         hipLaunchKernelGGL(ka, dim3(nb), dim3(256), lds_a, st, args, (const bf16_t*)dA, part_arg, (long long)T_tok, n_args, E, n_argvals);
         for (int g_lo = 0; g_lo == 0 || g_lo < n_groups; g_lo += g_cap) {
             const int win = n_groups - g_lo < g_cap ? n_groups - g_lo : g_cap;
