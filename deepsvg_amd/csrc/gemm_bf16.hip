@@ -443,10 +443,13 @@ int dsvg_gemm_bf16_launch(const dsvg_gemm_desc& d, int k_chunk, int nsplit, floa
         if (d.gate && !d.res && !d.bias && d.act == 0 && d.drop_p <= 0.f) return EPI_GATE;
         return EPI_GENERIC;
     };
-    const bool vec_base = !part && !d.c_f32 && !d.accumulate && !d.res_pre && !(d.ldc & 7) &&
-                          !((uintptr_t)d.C & 15) && (!d.res || (!(d.ldres & 7) && !((uintptr_t)d.res & 15))) &&
-                          (!d.gate || (!(d.ldgate & 7) && !((uintptr_t)d.gate & 15)));
-    const int epi_dma = classify(vec_base);
+    // (res_pre - the residual inside the dropout, the embedding's `drop(fcn(...) + command + position)` - is a run-time
+    // switch of the LDS-DMA kernel's residual epilogue; this file's compile-time variants have the residual outside)
+    const bool vec_dma = !part && !d.c_f32 && !d.accumulate && !(d.ldc & 7) &&
+                         !((uintptr_t)d.C & 15) && (!d.res || (!(d.ldres & 7) && !((uintptr_t)d.res & 15))) &&
+                         (!d.gate || (!(d.ldgate & 7) && !((uintptr_t)d.gate & 15)));
+    const bool vec_base = vec_dma && !d.res_pre;
+    const int epi_dma = classify(vec_dma);
     const int epi = classify(vec_base && !(d.N & 7));
     if (epi_dma != EPI_GENERIC && dsvg_gemm_bf16_glds_try(d, epi_dma, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, st, nullptr)) {
         DSVG_LAUNCH_CHECK("gemm_bf16_glds");

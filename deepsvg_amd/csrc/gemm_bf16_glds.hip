@@ -390,6 +390,19 @@ __device__ __forceinline__ void glds_body(const dsvg_gemm_desc& p, int tiles_n, 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = gv[e] > 0.f ? v[e] * p.gate_scale : 0.f;
             }
+            float rv[8];
+            if (has_res) {
+                const bf16_t* rp = (const bf16_t*)p.res + (size_t)m * p.ldres + nb;
+                if (nv == 8) unpack8(*reinterpret_cast<const uint4*>(rp), rv);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rv[e] = e < nv ? bf2f(rp[e]) : 0.f;
+                }
+                if (p.res_pre) {        // (run-time: the residual inside the dropout)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                }
+            }
             if (may_drop && dc.on) {
                 float dm[8];
                 if (n_aligned) {
@@ -401,14 +414,7 @@ __device__ __forceinline__ void glds_body(const dsvg_gemm_desc& p, int tiles_n, 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= dm[e];
             }
-            if (has_res) {
-                float rv[8];
-                const bf16_t* rp = (const bf16_t*)p.res + (size_t)m * p.ldres + nb;
-                if (nv == 8) unpack8(*reinterpret_cast<const uint4*>(rp), rv);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) rv[e] = e < nv ? bf2f(rp[e]) : 0.f;
-                }
+            if (has_res && !p.res_pre) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += rv[e];
             }

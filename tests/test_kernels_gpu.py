@@ -96,6 +96,8 @@ def test_gemm_epilogues(gpu_device, dtype):
     tol = _tol(dtype, K)
     for kw in [dict(bias=bias, act=R.RELU), dict(bias=bias, res=res), dict(bias=bias, res=res, res_pre=True, act=R.RELU),
                dict(gate=gate, gate_scale=1.25), dict(bias=bias, res=res, drop_p=0.1, drop_site=7, seed=seed),
+               # the embedding's epilogue: residual INSIDE the dropout (a run-time switch of the LDS-DMA kernel's epilogue)
+               dict(bias=bias, res=res, res_pre=True, drop_p=0.1, drop_site=7, seed=seed), dict(bias=bias, res=res, res_pre=True),
                dict(bias=bias, act=R.RELU, drop_p=0.3, drop_site=9, seed=seed),
                dict(a_drop_p=0.1, a_drop_site=11, seed=seed)]:
         out = ops.gemm(a, b, **kw)
