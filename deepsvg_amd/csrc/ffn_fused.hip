@@ -198,8 +198,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
     const char* my_src = reinterpret_cast<const char*>(img) + wave * 4096 + lane * 16;
     const uint32_t my_dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);
     auto issue = [&](int c) { dma4(my_src + (size_t)c * FWD_CHUNK, my_dst + (uint32_t)(c % NBUF) * FWD_CHUNK); };
-    // DMA distance: DIST = NBUF - 1 chunks ahead of the compute (NBUF = 3: 2, NBUF = 4: 3; TRAIN: always 2, see above)
-    constexpr int DIST = TRAIN ? 2 : NBUF - 1;
+    // DMA distance: DIST = NBUF - 1 chunks ahead of the compute (NBUF = 3: 2, NBUF = 4: 3)
+    constexpr int DIST = NBUF - 1;
 #pragma unroll
     for (int c = 0; c < DIST; ++c)
         if (c < n_chunks) issue(c);
@@ -293,7 +293,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
         }
     };
     auto sync = [&](int k) {
-        if (!TRAIN && DIST == 3 && k + 2 < n_chunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // (TRAIN: the h stores behind each sync are in flight too.  Loads return in order, so "at most 4 outstanding" still
+        // means chunk k + 1 - older than the 4 DMA loads of chunk k + 2 - has landed; with the 3-slot ring there is no
+        // younger load to count on and every sync has to drain the stores as well)
+        if (DIST == 3 && k + 2 < n_chunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (k + DIST < n_chunks) issue(k + DIST);
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
     // Both wave groups run the SAME straight-line code G1 E1 G2 per chunk; only the position of their one barrier per
     // chunk differs (before G1 for waves 0-3, before G2 for waves 4-7), which holds waves 4-7 one stage (G1 + E1) ahead.
     if (n_chunks > 0) {
-        if (!TRAIN && DIST == 3 && n_chunks > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (DIST == 3 && n_chunks > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // chunks 0 and 1 are in LDS
         {
@@ -912,7 +915,10 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
     const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
     hipStream_t st = (hipStream_t)stream;
     if (stages == 0) stages = 4;
-    if (train) stages = 3;
+    // training variant: 4 slots (chunk k + 2's DMA in flight across the syncs, counted waits) or 3 (every sync drains the
+    // wave's h stores too); DSVG_FFN_TRAIN_STAGES for the A/B
+    static const int train_stages = getenv("DSVG_FFN_TRAIN_STAGES") ? atoi(getenv("DSVG_FFN_TRAIN_STAGES")) : 4;
+    if (train) stages = train_stages == 3 ? 3 : 4;
     // timing probe only (results are wrong below 16): number of hidden chunks actually processed
     static const int dbg_chunks = getenv("DSVG_FFN_DBG_CHUNKS") ? atoi(getenv("DSVG_FFN_DBG_CHUNKS")) : NCH;
 #define DSVG_FFN_FWD(NB, TR)                                                                                          \
@@ -923,7 +929,8 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
                            (const bf16_t*)packed_fwd_layer, b1_folded, b2, (bf16_t*)y, (bf16_t*)h_out, (bf16_t*)xh_out,\
                            rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res, dbg_chunks); \
     } while (0)
-    if (train) DSVG_FFN_FWD(3, true);
+    if (train && stages == 3) DSVG_FFN_FWD(3, true);
+    else if (train) DSVG_FFN_FWD(4, true);
     else if (stages == 3) DSVG_FFN_FWD(3, false);
     else if (stages == 4) DSVG_FFN_FWD(4, false);
     else { dsvg_set_error("ffn_fwd: stages must be 3 or 4"); return -1; }
