@@ -176,6 +176,13 @@ __device__ __forceinline__ void drop2_mult8(const DropCtx& c, uint32_t h, int hi
 //     counts stores too, out of order with respect to loads, so the only safe DMA wait is vmcnt(0); the h stores of a
 //     chunk are therefore held back in 8 registers and issued right BEHIND the next sync point, which gives them (and
 //     the DMA) a whole iteration to drain before the next wait.
+// development probe (dsvg_ffn_debug_clock): when set, wave `w` of every workgroup stores s_memtime at four points - kernel
+// start, LayerNorm done (first chunk sync ahead), chunk loop done, last store issued - into dbg[(block * 8 + w) * 4 ..]
+__device__ __forceinline__ void ffn_stamp(unsigned long long* d, int slot) {
+    if (d && (threadIdx.x & 63) == 0)
+        d[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + slot] = __builtin_amdgcn_s_memtime();
+}
+
 template <int NBUF, bool TRAIN>
 __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ img,
                                                          const float* __restrict__ b1, const float* __restrict__ b2,
@@ -183,8 +190,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
                                                          bf16_t* __restrict__ xh_out, float* __restrict__ rstd_out,
                                                          int M, float eps, float drop_p,
                                                          const uint64_t* __restrict__ seed, uint32_t site_h,
-                                                         uint32_t site_r, int n_chunks) {
+                                                         uint32_t site_r, int n_chunks, unsigned long long* dbg) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // [NBUF chunk slots | b1 (2 KiB) | b2 (1 KiB)]
+    ffn_stamp(dbg, 0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -361,6 +369,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
     // ---- the chunk loop ---------------------------------------------------------------------------------------------------
     // Both wave groups run the SAME straight-line code G1 E1 G2 per chunk; only the position of their one barrier per
     // chunk differs (before G1 for waves 0-3, before G2 for waves 4-7), which holds waves 4-7 one stage (G1 + E1) ahead.
+    ffn_stamp(dbg, 1);
     if (n_chunks > 0) {
         if (DIST == 3 && n_chunks > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -381,6 +390,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
         }
         flush();
     }
+    ffn_stamp(dbg, 2);
 
     // ---- epilogue: + b2, dropout, + residual, bf16 rows ---------------------------------------------------------------
     const int m = row0 + tok;
@@ -426,6 +436,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
             *reinterpret_cast<uint4*>(yrow + n16 * 2 + 16) = pk[1];
         }
     }
+    ffn_stamp(dbg, 3);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -902,6 +913,8 @@ extern "C" int dsvg_ffn_pack(const float* flat_f32, const int64_t* offs, int32_t
     return 0;
 }
 
+static unsigned long long* g_ffn_dbg_host = nullptr;      // development probe, see dsvg_ffn_debug_clock
+
 extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const float* b1_folded, const float* b2, void* y,
                             void* h_out, void* xh_out, float* rstd_out, int64_t rows, float eps, float drop_p,
                             uint32_t site_hidden, uint32_t site_res, const void* seed, int32_t stages, void* stream) {
@@ -927,7 +940,8 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
         DSVG_ENSURE_LDS((ffn_fwd_kernel<NB, TR>), lds);                                                               \
         hipLaunchKernelGGL((ffn_fwd_kernel<NB, TR>), dim3(nb), dim3(512), lds, st, (const bf16_t*)x,                   \
                            (const bf16_t*)packed_fwd_layer, b1_folded, b2, (bf16_t*)y, (bf16_t*)h_out, (bf16_t*)xh_out,\
-                           rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res, dbg_chunks); \
+                           rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res, dbg_chunks,    \
+                           g_ffn_dbg_host);                                                                           \
     } while (0)
     if (train && stages == 3) DSVG_FFN_FWD(3, true);
     else if (train) DSVG_FFN_FWD(4, true);
@@ -936,6 +950,12 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
     else { dsvg_set_error("ffn_fwd: stages must be 3 or 4"); return -1; }
 #undef DSVG_FFN_FWD
     DSVG_LAUNCH_CHECK("ffn_fwd");
+    return 0;
+}
+
+/* development probe: buf = device buffer of (workgroups * 8 * 4) uint64 or NULL (off); see ffn_stamp */
+extern "C" int dsvg_ffn_debug_clock(void* buf) {
+    g_ffn_dbg_host = (unsigned long long*)buf;
     return 0;
 }
 

@@ -482,6 +482,9 @@ int dsvg_ffn_wgrad_finish(const float* g1p, const float* db1p, const float* g2p,
 /* the same for n_layers layers in one launch per 16: ptrs = n_layers x 11 pointers in the argument order of
  * dsvg_ffn_wgrad_finish (g1p, db1p, g2p, w1, gamma, beta, dw1, db1, dw2, dgamma, dbeta), a host array */
 int dsvg_ffn_wgrad_finish_many(const void* const* ptrs, int32_t n_layers, void* stream);
+/* development probe of dsvg_ffn_fwd: buf = device buffer of (workgroups x 8 waves x 4) uint64 time stamps (kernel start,
+ * LayerNorm done, chunk loop done, stores issued) or NULL to switch it off (scripts/ffn_phase_probe.py) */
+int dsvg_ffn_debug_clock(void* buf);
 
 /* ------------------------------------------------------------------------------------------
  * Fused attention sub-block (d_model 256, 8 heads of 32, sequences of at most 32 tokens, bf16):
