@@ -220,30 +220,11 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
         uint4 raw[16];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) raw[ks] = *reinterpret_cast<const uint4*>(xr + 32 * ks);
-        float s = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            float v[8];
-            unpack8(raw[ks], v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += v[e];
-        }
-        s += __shfl_xor(s, 32, 64);
-        const float mean = s * (1.f / AD);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
-        float ss = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            float v[8];
-            unpack8(raw[ks], v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; ss += d * d; }
-        }
-        ss += __shfl_xor(ss, 32, 64);
-        const float rstd = rsqrtf(ss * (1.f / AD) + eps);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
+        // (statistics from the packed words: ln_stats_packed, fused_common.h)
+        float s, q, mean, rstd;
+        ln_stats_packed(raw, s, q);
+        ln_mean_rstd256(s, q, eps, mean, rstd);
+        const float shift = -mean * rstd;
         char* xo = TRAIN ? reinterpret_cast<char*>(xn_out) + (size_t)my_row * (AD * 2) + h2 * 16 : nullptr;
         const bool st = TRAIN && row_live;
         if (st && h2 == 0) { mean_out[my_row] = mean; rstd_out[my_row] = rstd; }
@@ -259,10 +240,10 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
             const float4 g1 = *reinterpret_cast<const float4*>(sga + 16 * ks + zoff + 4);
             const float4 b0 = *reinterpret_cast<const float4*>(sbe + 16 * ks + zoff);
             const float4 b1 = *reinterpret_cast<const float4*>(sbe + 16 * ks + zoff + 4);
-            v[0] = (v[0] - mean) * rstd * g0.x + b0.x; v[1] = (v[1] - mean) * rstd * g0.y + b0.y;
-            v[2] = (v[2] - mean) * rstd * g0.z + b0.z; v[3] = (v[3] - mean) * rstd * g0.w + b0.w;
-            v[4] = (v[4] - mean) * rstd * g1.x + b1.x; v[5] = (v[5] - mean) * rstd * g1.y + b1.y;
-            v[6] = (v[6] - mean) * rstd * g1.z + b1.z; v[7] = (v[7] - mean) * rstd * g1.w + b1.w;
+            v[0] = fmaf(fmaf(v[0], rstd, shift), g0.x, b0.x); v[1] = fmaf(fmaf(v[1], rstd, shift), g0.y, b0.y);
+            v[2] = fmaf(fmaf(v[2], rstd, shift), g0.z, b0.z); v[3] = fmaf(fmaf(v[3], rstd, shift), g0.w, b0.w);
+            v[4] = fmaf(fmaf(v[4], rstd, shift), g1.x, b1.x); v[5] = fmaf(fmaf(v[5], rstd, shift), g1.y, b1.y);
+            v[6] = fmaf(fmaf(v[6], rstd, shift), g1.z, b1.z); v[7] = fmaf(fmaf(v[7], rstd, shift), g1.w, b1.w);
             Frag8 f;
             f.u = pack8(v);
             xf[ks] = f.v;

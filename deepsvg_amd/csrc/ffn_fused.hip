@@ -183,6 +183,38 @@ __device__ __forceinline__ void ffn_stamp(unsigned long long* d, int slot) {
         d[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + slot] = __builtin_amdgcn_s_memtime();
 }
 
+// The wave's 32 rows, one row per lane pair (lane half h owns the columns 16 ks + 8 h .. + 7 of every K step): LayerNorm
+// without the affine part (folded into W1' / b1') -> the 16 B-operand fragments xf; TRAIN also stores xh and rstd.
+// The statistics come from the packed words (ln_stats_packed, fused_common.h: the prologue is instruction-issue-bound).
+// Called between the row loads and the first use of b1 / b2 (__syncthreads).
+template <bool TRAIN, bool SYNC = true>
+__device__ __forceinline__ void ffn_ln_rows(const bf16_t* __restrict__ x, int my_row, int half, bool st,
+                                            bf16_t* __restrict__ xh_out, float* __restrict__ rstd_out, float eps,
+                                            bf16x8 (&xf)[16]) {
+    const char* xr = reinterpret_cast<const char*>(x) + (size_t)my_row * (FD * 2) + half * 16;
+    uint4 raw[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) raw[ks] = *reinterpret_cast<const uint4*>(xr + 32 * ks);
+    if (SYNC) __syncthreads();  // b1 / b2 staged (the row loads above are in flight meanwhile)
+    float s, q, mean, rstd;
+    ln_stats_packed(raw, s, q);
+    ln_mean_rstd256(s, q, eps, mean, rstd);
+    const float shift = -mean * rstd;
+    char* xo = TRAIN ? reinterpret_cast<char*>(xh_out) + (size_t)my_row * (FD * 2) + half * 16 : nullptr;
+    if (TRAIN && st && half == 0 && rstd_out) rstd_out[my_row] = rstd;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {       // (gamma / beta live in the packed W1' / b1', see ffn_pack_kernel)
+        float v[8];
+        unpack8(raw[ks], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], rstd, shift);
+        Frag8 f;
+        f.u = pack8(v);
+        xf[ks] = f.v;
+        if (TRAIN && st) *reinterpret_cast<uint4*>(xo + 32 * ks) = f.u;
+    }
+}
+
 template <int NBUF, bool TRAIN>
 __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ img,
                                                          const float* __restrict__ b1, const float* __restrict__ b2,
@@ -219,53 +251,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
     const int row0 = blockIdx.x * TOK_PER_WG + wave * 32;
     const int my_row = min(row0 + tok, M - 1);          // rows past M are computed on a clamped copy, never stored
     bf16x8 xf[16];
-    {
-        const char* xr = reinterpret_cast<const char*>(x) + (size_t)my_row * (FD * 2) + half * 16;
-        uint4 raw[16];
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) raw[ks] = *reinterpret_cast<const uint4*>(xr + 32 * ks);
-        __syncthreads();            // b1 / b2 staged (the row loads above are in flight meanwhile)
-        float s = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            float v[8];
-            unpack8(raw[ks], v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += v[e];
-        }
-        s += __shfl_xor(s, 32, 64);
-        const float mean = s * (1.f / FD);
-        // the three passes re-unpack the packed row: without the opaque copies hipcc keeps all 128 unpacked floats alive
-        // from the first pass to the last (CSE), which together with the 64 result registers spills the prologue
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
-        float ss = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            float v[8];
-            unpack8(raw[ks], v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; ss += d * d; }
-        }
-        ss += __shfl_xor(ss, 32, 64);
-        const float rstd = rsqrtf(ss * (1.f / FD) + eps);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
-        char* xo = TRAIN ? reinterpret_cast<char*>(xh_out) + (size_t)my_row * (FD * 2) + half * 16 : nullptr;
-        const bool st = TRAIN && row0 + tok < M;
-        if (st && half == 0) rstd_out[my_row] = rstd;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {       // (gamma / beta live in the packed W1' / b1', see ffn_pack_kernel)
-            float v[8];
-            unpack8(raw[ks], v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd;
-            Frag8 f;
-            f.u = pack8(v);
-            xf[ks] = f.v;
-            if (st) *reinterpret_cast<uint4*>(xo + 32 * ks) = f.u;
-        }
-    }
+    ffn_ln_rows<TRAIN>(x, my_row, half, TRAIN && row0 + tok < M, xh_out, rstd_out, eps, xf);
     __builtin_amdgcn_sched_barrier(0);      // (the 128 accumulator zeroes below must not be hoisted above the LayerNorm)
 
     const DropCtx dh = drop_make(drop_p, seed, site_h);
@@ -440,6 +426,236 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// forward, half-size workgroups: the same per-wave program (32 rows: LayerNorm -> G1 E1 G2 per chunk -> epilogue, results
+// bit-identical to ffn_fwd_kernel) in workgroups of 4 waves = 128 rows with a ring of four 16 KiB HALF chunks (the W1 part /
+// the W2 part of a chunk; 67 KiB of LDS), so that two workgroups fit on a CU.  Used for launches of at most 32,768 rows:
+// 256 of these workgroups put ONE wave on every SIMD of the chip where 128 of the 256-row workgroups put two waves on
+// every SIMD of half the CUs (1,000 rows: 30 us against 40; at full size the two kernels are equal, and delaying the second
+// workgroup of a CU so that its prologue runs beside its partner's chunk loop gained nothing: prologue and epilogue are
+// latency- / VALU-bound per wave, not HBM-bound).
+//   sync(hc) in front of every G: half chunk hc + 1 has landed (the A ring runs on into it), half chunk hc + 3 is issued
+//   into the slot half chunk hc - 1 has left; hc + 2 stays in flight across the barrier (counted wait: 4 pieces per wave).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int HSLOT = 16 * FRAG;        // half chunk: 16 fragments = 16 KiB
+constexpr int HNBUF = 4;
+constexpr int CU_TURNS = 4096;
+__device__ unsigned int g_cu_turn[CU_TURNS];
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256, 2) void ffn_fwd_half_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ img,
+                                                              const float* __restrict__ b1, const float* __restrict__ b2,
+                                                              bf16_t* __restrict__ y, bf16_t* __restrict__ h_out,
+                                                              bf16_t* __restrict__ xh_out, float* __restrict__ rstd_out,
+                                                              int M, float eps, float drop_p,
+                                                              const uint64_t* __restrict__ seed, uint32_t site_h,
+                                                              uint32_t site_r, int n_chunks, int stagger, int delay,
+                                                              unsigned long long* dbg) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [4 half-chunk slots | b1 (2 KiB) | b2 (1 KiB)]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (dbg && lane == 0) dbg[((size_t)blockIdx.x * 4 + wave) * 4 + 0] = __builtin_amdgcn_s_memtime();
+    const int tok = lane & 31, half = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)DSVG_LDS_PTR(smem);
+    float* sb1 = reinterpret_cast<float*>(smem + HNBUF * HSLOT);
+    float* sb2 = sb1 + FF;
+    const int n_half = 2 * n_chunks;
+
+    // ---- weight stream: this wave moves pieces 4 wave .. 4 wave + 3 of every half chunk ------------------------------
+    const char* my_src = reinterpret_cast<const char*>(img) + wave * 4096 + lane * 16;
+    const uint32_t my_dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);
+    auto issue = [&](int hc) { dma4(my_src + (size_t)hc * HSLOT, my_dst + (uint32_t)(hc % HNBUF) * HSLOT); };
+#pragma unroll
+    for (int hc = 0; hc < 3; ++hc)
+        if (hc < n_half) issue(hc);
+
+    sb1[tid] = b1[tid];
+    sb1[tid + 256] = b1[tid + 256];
+    sb2[tid] = b2[tid];
+
+    // ---- experiment (off by default, see the header): the second workgroup to arrive on a CU starts `delay` ticks late ----
+    if (stagger) {
+        unsigned int* turn = reinterpret_cast<unsigned int*>(smem + HNBUF * HSLOT + 3072);
+        if (tid == 0) {
+            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID
+            const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+            const uint32_t cu = ((hw >> 8) & 0xffu) | ((xcc & 15u) << 8);        // cu [11:8], sh [12], se [15:13] | xcc
+            *turn = atomicAdd(&g_cu_turn[cu & (CU_TURNS - 1)], 1u);
+            if (dbg) dbg[(size_t)gridDim.x * 16 + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
+        }
+        __syncthreads();
+        if (*turn & 1u) {
+            const uint64_t t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)delay) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+
+    // ---- the wave's 32 rows: LayerNorm in registers -> 16 B-operand fragments (as in ffn_fwd_kernel) -----------------
+    const int row0 = blockIdx.x * 128 + wave * 32;
+    const int my_row = min(row0 + tok, M - 1);
+    bf16x8 xf[16];
+    ffn_ln_rows<TRAIN>(x, my_row, half, TRAIN && row0 + tok < M, xh_out, rstd_out, eps, xf);
+    __builtin_amdgcn_sched_barrier(0);
+
+    const DropCtx dh = drop_make(drop_p, seed, site_h);
+    const DropCtx dr = drop_make(drop_p, seed, site_r);
+
+    floatx16 yacc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[t][r] = 0.f;
+    floatx16 hid;
+    bf16x8 hf[2];
+    uint4 ring[4];
+
+    const char* lbase = smem + lane * 16;
+    auto slot_of = [&](int hc) -> const char* { return lbase + (hc % HNBUF) * HSLOT; };
+    auto ld = [&](const char* p) -> uint4 { return *reinterpret_cast<const uint4*>(p); };
+
+    uint4 stash[2];
+    int stash_c = -1;
+    char* hrow = TRAIN ? reinterpret_cast<char*>(h_out) + (size_t)my_row * (FF * 2) + half * 16 : nullptr;
+    const bool hst = TRAIN && row0 + tok < M;
+    auto flush = [&]() {
+        if (TRAIN && stash_c >= 0) {
+            if (hst) {
+                *reinterpret_cast<uint4*>(hrow + (CH * stash_c) * 2) = stash[0];
+                *reinterpret_cast<uint4*>(hrow + (CH * stash_c + 16) * 2) = stash[1];
+            }
+            stash_c = -1;
+        }
+    };
+    auto sync = [&](int hc) {
+        // loads return in order: "at most 4 outstanding" means half chunk hc + 1 - older than the 4 pieces of hc + 2 - has
+        // landed; the h stores behind a sync can only make the wait stricter
+        if (hc + 2 < n_half) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (hc + 3 < n_half) issue(hc + 3);
+        flush();
+    };
+    auto G1 = [&](const char* w1, const char* cont) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hid[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            Frag8 a;
+            a.u = ring[ks & 3];
+            hid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, xf[ks], hid, 0, 0, 0);
+            if (ks + 4 < 16) ring[ks & 3] = ld(w1 + (ks + 4) * FRAG);
+            else if (cont) ring[ks & 3] = ld(cont + (ks + 4 - 16) * FRAG);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto E1 = [&](int c) {
+        const uint64_t id0 = (uint64_t)(row0 + tok) * FF + (uint32_t)(CH * c + 16 * half);
+        const uint32_t hh = dh.on ? drop2_group(dh, id0 >> 4) : 0u;
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            float v[8];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * ks2 + qq;
+                const float4 bb = *reinterpret_cast<const float4*>(sb1 + CH * c + 8 * q + 4 * half);
+                v[4 * qq + 0] = fmaxf(hid[4 * q + 0] + bb.x, 0.f);
+                v[4 * qq + 1] = fmaxf(hid[4 * q + 1] + bb.y, 0.f);
+                v[4 * qq + 2] = fmaxf(hid[4 * q + 2] + bb.z, 0.f);
+                v[4 * qq + 3] = fmaxf(hid[4 * q + 3] + bb.w, 0.f);
+            }
+            if (dh.on) {
+                float m[8];
+                drop2_mult8(dh, hh, ks2, m);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= m[e];
+            }
+            Frag8 f;
+            f.u = pack8(v);
+            hf[ks2] = f.v;
+            if (TRAIN) stash[ks2] = f.u;
+        }
+        if (TRAIN) stash_c = c;
+    };
+    auto G2 = [&](const char* w2, const char* cont) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            Frag8 a;
+            a.u = ring[n & 3];
+            yacc[n >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, hf[n & 1], yacc[n >> 1], 0, 0, 0);
+            if (n + 4 < 16) ring[n & 3] = ld(w2 + (n + 4) * FRAG);
+            else if (cont) ring[n & 3] = ld(cont + (n + 4 - 16) * FRAG);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (dbg && lane == 0) dbg[((size_t)blockIdx.x * 4 + wave) * 4 + 1] = __builtin_amdgcn_s_memtime();
+    if (n_chunks > 0) {
+        // half chunk 0 has to be readable before the ring is primed: everything but the newest 4 operations (the last
+        // xh stores when training, else the pieces of half chunk 2) done, and the other waves' pieces behind the barrier
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const char* s0 = slot_of(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ring[i] = ld(s0 + i * FRAG);
+        }
+        for (int c = 0; c < n_chunks; ++c) {
+            sync(2 * c);
+            G1(slot_of(2 * c), slot_of(2 * c + 1));
+            E1(c);
+            sync(2 * c + 1);
+            G2(slot_of(2 * c + 1), (c + 1 < n_chunks) ? slot_of(2 * c + 2) : nullptr);
+        }
+        flush();
+    }
+    if (dbg && lane == 0) dbg[((size_t)blockIdx.x * 4 + wave) * 4 + 2] = __builtin_amdgcn_s_memtime();
+
+    // ---- epilogue: + b2, dropout, + residual, bf16 rows (as in ffn_fwd_kernel) ---------------------------------------
+    const int m = row0 + tok;
+    const bool live = m < M;
+    const char* xres = reinterpret_cast<const char*>(x) + (size_t)my_row * (FD * 2);
+    char* yrow = reinterpret_cast<char*>(y) + (size_t)my_row * (FD * 2);
+    uint4 res[16];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        res[2 * t] = *reinterpret_cast<const uint4*>(xres + (32 * t + 16 * half) * 2);
+        res[2 * t + 1] = *reinterpret_cast<const uint4*>(xres + (32 * t + 16 * half + 8) * 2);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        uint32_t xc[4][4];
+        tile_to_cols16(yacc[t], xc);
+        const int n16 = 32 * t + 16 * half;
+        uint4 pk[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            float v[8], rv[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(xc[2 * cb][e]); v[4 + e] = __uint_as_float(xc[2 * cb + 1][e]); }
+            const float4 b0 = *reinterpret_cast<const float4*>(sb2 + n16 + 8 * cb);
+            const float4 b1v = *reinterpret_cast<const float4*>(sb2 + n16 + 8 * cb + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+            v[4] += b1v.x; v[5] += b1v.y; v[6] += b1v.z; v[7] += b1v.w;
+            if (dr.on) {
+                float dm[8];
+                drop_mult8(dr, (uint64_t)m * FD + n16 + 8 * cb, dm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dm[e];
+            }
+            unpack8(res[2 * t + cb], rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            pk[cb] = pack8(v);
+        }
+        if (live) {
+            *reinterpret_cast<uint4*>(yrow + n16 * 2) = pk[0];
+            *reinterpret_cast<uint4*>(yrow + n16 * 2 + 16) = pk[1];
+        }
+    }
+    if (dbg && lane == 0) dbg[((size_t)blockIdx.x * 4 + wave) * 4 + 3] = __builtin_amdgcn_s_memtime();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // backward, kernel 1 of 2: the hidden tile.  Per 32-token wave and hidden chunk c:
 //     pre  = W1'[chunk] . xh            (recomputed: the forward pass stores nothing but x)
 //     dh   = W2[:, chunk]^T . dym       (dym = dy * residual-dropout mask, replayed)
@@ -483,50 +699,10 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_hidden_kernel(const bf16_t* __
     const DropCtx dh_ctx = drop_make(drop_p, seed, site_h);
     const DropCtx dr_ctx = drop_make(drop_p, seed, site_r);
 
-    // ---- xh fragments (LayerNorm without the affine part) and their copy for the weight-gradient GEMM ---------------------
+    // ---- xh fragments (LayerNorm without the affine part, bit-identical to the forward kernel's) and their copy for the
+    // weight-gradient GEMM ----
     bf16x8 xf[16];
-    {
-        const char* xr = reinterpret_cast<const char*>(x) + (size_t)my_row * (FD * 2) + half * 16;
-        uint4 raw[16];
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) raw[ks] = *reinterpret_cast<const uint4*>(xr + 32 * ks);
-        float s = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            float v[8];
-            unpack8(raw[ks], v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += v[e];
-        }
-        s += __shfl_xor(s, 32, 64);
-        const float mean = s * (1.f / FD);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
-        float ss = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            float v[8];
-            unpack8(raw[ks], v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; ss += d * d; }
-        }
-        ss += __shfl_xor(ss, 32, 64);
-        const float rstd = rsqrtf(ss * (1.f / FD) + eps);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
-        char* xo = reinterpret_cast<char*>(xh_out) + (size_t)my_row * (FD * 2) + half * 16;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            float v[8];
-            unpack8(raw[ks], v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd;
-            Frag8 f;
-            f.u = pack8(v);
-            xf[ks] = f.v;
-            if (live) *reinterpret_cast<uint4*>(xo + 32 * ks) = f.u;
-        }
-    }
+    ffn_ln_rows<true, false>(x, my_row, half, live, xh_out, nullptr, eps, xf);
     // ---- dym fragments: dy with the residual dropout replayed (ids m * 256 + column, standard draws) ----------------------
     bf16x8 df[16];
     {
@@ -718,31 +894,10 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[t][4 * q + e] = __uint_as_float(xc[q][e]);      // column 4 q + e of the 16
     }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        float v[8];
-        unpack8(xr[i], v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += v[e];
-    }
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.f / FD);
-    // (opaque copies between the passes: hipcc would otherwise keep the 128 unpacked floats alive next to the 128 accumulators)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(xr[i].x), "+v"(xr[i].y), "+v"(xr[i].z), "+v"(xr[i].w));
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        float v[8];
-        unpack8(xr[i], v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; ss += d * d; }
-    }
-    ss += __shfl_xor(ss, 32, 64);
-    const float rstd = rsqrtf(ss * (1.f / FD) + eps);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(xr[i].x), "+v"(xr[i].y), "+v"(xr[i].z), "+v"(xr[i].w));
+    float s, q, mean, rstd;
+    ln_stats_packed(xr, s, q);
+    ln_mean_rstd256(s, q, eps, mean, rstd);
+    const float shift = -mean * rstd;       // xh = x * rstd + shift
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -754,7 +909,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
             for (int e = 0; e < 8; ++e) {
                 const float g = acc[t][8 * cb + e];
                 c1 += g;
-                c2 += g * ((v[e] - mean) * rstd);
+                c2 += g * fmaf(v[e], rstd, shift);
             }
         }
     c1 += __shfl_xor(c1, 32, 64);
@@ -771,7 +926,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
             float v[8];
             unpack8(xr[2 * t + cb], v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[t][8 * cb + e] = rstd * (acc[t][8 * cb + e] - c1 - (v[e] - mean) * rstd * c2);
+            for (int e = 0; e < 8; ++e) acc[t][8 * cb + e] = rstd * (acc[t][8 * cb + e] - c1 - fmaf(v[e], rstd, shift) * c2);
         }
     // (the dy loads below must not be hoisted above the pass that frees the x registers: an address offset that is
     // opaque to the compiler - always 0 - and ordered behind the last value of that pass pins them here)
@@ -927,7 +1082,8 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
                    "ffn_fwd: operands must be 16-byte aligned");
     const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
     hipStream_t st = (hipStream_t)stream;
-    if (stages == 0) stages = 4;
+    const int stages_arg = stages;       // 0 default, 2 half-size workgroups, 3 / 4 ring slots of the 256-row kernel
+    if (stages == 0 || stages == 2) stages = 4;
     // training variant: 4 slots (chunk k + 2's DMA in flight across the syncs, counted waits) or 3 (every sync drains the
     // wave's h stores too); DSVG_FFN_TRAIN_STAGES for the A/B
     static const int train_stages = getenv("DSVG_FFN_TRAIN_STAGES") ? atoi(getenv("DSVG_FFN_TRAIN_STAGES")) : 4;
@@ -943,11 +1099,33 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
                            rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res, dbg_chunks,    \
                            g_ffn_dbg_host);                                                                           \
     } while (0)
+    // half-size workgroups (stages 2, or by default up to 32,768 rows; DSVG_FFN_HALF=0 / 1 forces the choice)
+    static const int half_env = getenv("DSVG_FFN_HALF") ? atoi(getenv("DSVG_FFN_HALF")) : -1;
+    const bool half_on = stages_arg == 2 || (stages_arg == 0 && (half_env >= 0 ? half_env != 0 : rows <= 32768));
+    if (half_on) {
+        const int nbh = (int)((rows + 127) / 128);
+        const size_t lds = (size_t)HNBUF * HSLOT + 3072 + 16;
+        static const int half_stagger = getenv("DSVG_FFN_HALF_STAGGER") ? atoi(getenv("DSVG_FFN_HALF_STAGGER")) : 0;
+        static const int half_delay = getenv("DSVG_FFN_HALF_DELAY") ? atoi(getenv("DSVG_FFN_HALF_DELAY")) : 24000;
+#define DSVG_FFN_FWD_HALF(TR)                                                                                         \
+    do {                                                                                                              \
+        DSVG_ENSURE_LDS((ffn_fwd_half_kernel<TR>), lds);                                                              \
+        hipLaunchKernelGGL((ffn_fwd_half_kernel<TR>), dim3(nbh), dim3(256), lds, st, (const bf16_t*)x,                 \
+                           (const bf16_t*)packed_fwd_layer, b1_folded, b2, (bf16_t*)y, (bf16_t*)h_out, (bf16_t*)xh_out,\
+                           rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res, dbg_chunks,    \
+                           half_stagger, half_delay, g_ffn_dbg_host);                                                 \
+    } while (0)
+        if (train) DSVG_FFN_FWD_HALF(true);
+        else DSVG_FFN_FWD_HALF(false);
+#undef DSVG_FFN_FWD_HALF
+        DSVG_LAUNCH_CHECK("ffn_fwd (half-size workgroups)");
+        return 0;
+    }
     if (train && stages == 3) DSVG_FFN_FWD(3, true);
     else if (train) DSVG_FFN_FWD(4, true);
     else if (stages == 3) DSVG_FFN_FWD(3, false);
     else if (stages == 4) DSVG_FFN_FWD(4, false);
-    else { dsvg_set_error("ffn_fwd: stages must be 3 or 4"); return -1; }
+    else { dsvg_set_error("ffn_fwd: stages must be 0 (default), 2 (half-size workgroups), 3 or 4"); return -1; }
 #undef DSVG_FFN_FWD
     DSVG_LAUNCH_CHECK("ffn_fwd");
     return 0;

@@ -29,6 +29,37 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
     return make_uint4(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]), f2bf_pk(v[4], v[5]), f2bf_pk(v[6], v[7]));
 }
 
+// LayerNorm statistics of a row whose 256 bf16 values sit packed in the registers of a lane pair (16 x uint4 per lane): sum
+// and sum of squares straight from the packed words - v_dot2c_f32_bf16 with (1, 1) and with the word itself, one instruction
+// per element, no unpack.  The prologues / epilogues of the token-stationary kernels are instruction-issue-bound (a wave issues
+// one VALU instruction every ~5 cycles with at most two waves per SIMD and no MFMA beside them, scripts/probes/
+// valu_rate_probe.hip): the two-pass form cost 5 instructions per element.  var = E[x^2] - mean^2 in fp32: the inputs are
+// bf16, whose own rounding (2^-9 relative) is coarser than the cancellation error of that form for any |mean| / sigma the
+// format can represent.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ln_stats_packed(const uint4 (&raw)[16], float& s, float& q) {
+    const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+    s = 0.f;
+    q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bf16x2_t a = __builtin_bit_cast(bf16x2_t, w[e]);
+            s = __builtin_amdgcn_fdot2_f32_bf16(a, ones, s, false);
+            q = __builtin_amdgcn_fdot2_f32_bf16(a, a, q, false);
+        }
+    }
+}
+// mean and rstd of a 256-column row from the two lane halves' partial sums
+__device__ __forceinline__ void ln_mean_rstd256(float s, float q, float eps, float& mean, float& rstd) {
+    s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 32, 64);
+    mean = s * (1.f / 256.f);
+    rstd = rsqrtf(fmaxf(q * (1.f / 256.f) - mean * mean, 0.f) + eps);
+}
+
 
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -1070,10 +1070,12 @@ def ffn_pack(flat, offs, n_layers, packed_fwd=None, packed_bwd=None, b1f=None, w
 
 
 def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, site_res=0, seed=None, out=None,
-            train=False, into=None):
+            train=False, into=None, stages=None):
     """y = x + drop_r(linear2(drop_h(relu(linear1(LayerNorm(x))))))  (x bf16 [rows, 256]; the LayerNorm's gamma / beta
     are inside packed_fwd_layer / b1f, see ffn_pack).  train: -> (y, h, xh, rstd) with h bf16 [rows, 512] in fragment
-    order, xh = (x - mean) * rstd bf16, rstd fp32 [rows] (what the backward pass needs)"""
+    order, xh = (x - mean) * rstd bf16, rstd fp32 [rows] (what the backward pass needs).
+    stages: None = the library's choice (half-size workgroups up to 32,768 rows), 2 = half-size workgroups, 3 / 4 = the
+    256-row workgroups with that many weight-ring slots (all bit-identical; tests and probes)"""
     _chk(x, packed_fwd_layer, b1f, b2, seed, out)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
     assert packed_fwd_layer.numel() == FFN_FWD_LAYER_ELEMS and packed_fwd_layer.is_contiguous()
@@ -1093,8 +1095,8 @@ def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, s
     ev = _prof_begin()
     _l.check(_l.load().dsvg_ffn_fwd(x.data_ptr(), packed_fwd_layer.data_ptr(), b1f.data_ptr(), b2.data_ptr(),
                                     out.data_ptr(), _p(h), _p(xh), _p(rstd), rows, float(eps), float(drop_p),
-                                    int(site_hidden), int(site_res), _p(seed) if drop_p > 0 else None, _FFN_STAGES,
-                                    _stream()), "dsvg_ffn_fwd")
+                                    int(site_hidden), int(site_res), _p(seed) if drop_p > 0 else None,
+                                    _FFN_STAGES if stages is None else int(stages), _stream()), "dsvg_ffn_fwd")
     # 2 GEMMs of 2 * 256 * 512 FLOP per row; algorithmic bytes: the row in, the row out, plus - in
     # training - h and xh for the backward pass
     _prof_end(ev, 4.0 * 256 * 512 * rows, (2.0 * 512 + (1536.0 if train else 0.0)) * rows, dict(op="ffn_fwd", rows=rows))

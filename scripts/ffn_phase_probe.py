@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepsvg_amd import ops, lib  # noqa: E402
 
 DEV = "cuda"
+STAGES = int(os.environ.get("PROBE_STAGES", "0")) or None      # 2: the half-size workgroups (4 waves each)
 
 
 def main():
@@ -32,12 +33,13 @@ def main():
         nwg = (rows + 255) // 256
         for train in (False, True):
             for _ in range(3):
-                ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 3, 4, seed, train=train)
-            buf = torch.zeros(nwg * 8 * 4, dtype=torch.int64, device=DEV)
+                ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 3, 4, seed, train=train, stages=STAGES)
+            buf = torch.zeros(nwg * 8 * 4 + 2 * nwg, dtype=torch.int64, device=DEV)   # (+ the hardware ids of the half-size workgroups)
+            hwbuf, buf = buf[nwg * 32:], buf[:nwg * 32]
             lib.check(L_.dsvg_ffn_debug_clock(buf.data_ptr()), "dbg")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 3, 4, seed, train=train)
+            ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 3, 4, seed, train=train, stages=STAGES)
             e1.record()
             torch.cuda.synchronize()
             lib.check(L_.dsvg_ffn_debug_clock(None), "dbg")
@@ -51,12 +53,31 @@ def main():
             us = e0.elapsed_time(e1) * 1e3
             if nwg <= 256 and not train:        # one round: a workgroup's life ~ the launch -> ticks per microsecond
                 main.tick = total.median().item() / us
+            if os.environ.get("PROBE_TICK"):        # ticks per microsecond measured by an earlier run of the 256-row kernel
+                main.tick = float(os.environ["PROBE_TICK"])
             k = 1.0 / getattr(main, "tick", 1.0)
             med = ph.median(0).values * k
             p90 = ph.quantile(0.9, 0) * k
             print(f"rows {rows:6d} ({nwg} workgroups) {'train' if train else 'infer'}: launch {us:6.1f} us | per wave, median "
                   f"(90th pct): prologue {med[0]:5.1f} ({p90[0]:5.1f}) us, chunk loop {med[1]:5.1f} ({p90[1]:5.1f}) us, epilogue "
                   f"{med[2]:5.1f} ({p90[2]:5.1f}) us, total {total.median().item() * k:5.1f} us")
+            if os.environ.get("PROBE_HW") and STAGES == 2:
+                # DSVG_FFN_HALF_STAGGER=1: which CU did every workgroup run on, and was exactly one of a CU's two delayed?
+                hw = hwbuf.cpu()
+                key = ((hw >> 32) & 15) * 65536 + (hw & 0xff00)
+                pro = (t[:, 0, 1] - t[:, 0, 0]).view(-1, 4)[:, 0] * k          # wave 0's prologue (incl. the delay)
+                late = pro > pro.median()
+                uniq, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
+                n_late = torch.zeros_like(cnt).scatter_add_(0, inv, late.long())
+                print(f"        {uniq.numel()} distinct (xcc, se, sh, cu) ids; workgroups per id: "
+                      f"{dict(zip(*[v.tolist() for v in torch.unique(cnt, return_counts=True)]))}; ids with 2 workgroups and "
+                      f"exactly one late: {int(((cnt == 2) & (n_late == 1)).sum())}; xcc values {sorted(set(((hw >> 32) & 15).tolist()))}; "
+                      f"sample hw ids {[hex(v & 0xffffffff) for v in hw[:4].tolist()]}")
+            if os.environ.get("PROBE_SPLIT"):       # the two populations of a staggered launch: by the length of the prologue
+                order = torch.argsort(ph[:, 0])
+                for name, idx in (("early half", order[:order.numel() // 2]), ("late half ", order[order.numel() // 2:])):
+                    m = ph[idx].median(0).values * k
+                    print(f"        {name}: prologue {m[0]:5.1f} us, chunk loop {m[1]:5.1f} us, epilogue {m[2]:5.1f} us")
 
 
 if __name__ == "__main__":

@@ -922,6 +922,27 @@ def test_ffn_fwd_matches_reference(gpu_device, rows, drop_p):
         assert torch.equal(y1, y2) and not torch.equal(y1, y3)
 
 
+@pytest.mark.parametrize("rows", [100, 4096 + 37, 40000])
+def test_ffn_fwd_workgroup_variants_agree(gpu_device, rows):
+    """the 256-row workgroups (3- and 4-slot weight rings) and the half-size workgroups (128 rows, the default up to
+    32,768 rows) run the same per-wave program: every output is bit-identical, inference and training variants"""
+    flat, offs, x, b2 = _ffn_setup(rows, seed=rows + 1)
+    pf, _, b1f = ops.ffn_pack(flat, offs, 2)
+    pl = pf[:ops.FFN_FWD_LAYER_ELEMS]
+    seed = _seed_tensor(0x1122334455667788)
+    for train in (False, True):
+        outs = {}
+        for stages in (2, 3, 4):
+            r = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 403, 404, seed, train=train, stages=stages)
+            outs[stages] = r if train else (r,)
+        for stages in (3, 4):
+            for a, b in zip(outs[2], outs[stages]):
+                assert torch.equal(a, b), (rows, train, stages)
+        dflt = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 403, 404, seed, train=train)
+        for a, b in zip(outs[2], dflt if train else (dflt,)):
+            assert torch.equal(a, b)
+
+
 def test_ffn_fwd_equals_unfused_kernels(gpu_device):
     """eval mode: the fused kernel against the three launches it replaces (layernorm_fwd + 2 GEMMs on the bf16 weights);
     the fused path rounds W1 diag(gamma) and the un-scaled normalised rows to bf16 instead of W1 and the scaled rows"""
