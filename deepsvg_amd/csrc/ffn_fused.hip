@@ -168,6 +168,9 @@ __device__ __forceinline__ void drop2_mult8(const DropCtx& c, uint32_t h, int hi
 //        waves 4-7:  sync(c) | G2(c)   G1(c + 1) E1(c + 1)         (same code, their barrier sits before G2)
 //     so every VALU stage of one wave sits beside an MFMA stage of its partner instead of beside the partner's VALU
 //     stage (waves that leave a barrier together otherwise stay in lockstep and the matrix pipe idles during E1).
+//     (tried in round 3, both without effect on the 52 us of a 65,536-row inference launch: the barrier of waves 4-7 between
+//     the two halves of E1 - half a period apart instead of a stage - and two accumulator chains in G1, which cost 16
+//     registers and with them in-loop spills: 60 us)
 //   * A fragments go through a 4-deep register ring that is refilled right behind each MFMA (prefetch distance 4 MFMAs,
 //     continuous across stages and chunks): ds_read latency is covered by the wave's own MFMAs, not only by its partner.
 //   * TRAIN: the kernel also hands the unfused backward what it needs - h (bf16 [T, 512], hidden columns in FRAGMENT
@@ -297,6 +300,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
         flush();
     };
     // G1: hid[unit][token] = sum_k W1[32 c + unit][k] xn[token][k]; the ring runs on into `cont` (4 more fragments)
+    auto g2frag = [](int p) -> int { return 2 * (p & 7) + (p >> 3); };      // G2 position -> fragment of the W2 chunk
     auto G1 = [&](const char* w1, const char* cont) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) hid[r] = 0.f;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
             a.u = ring[ks & 3];
             hid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, xf[ks], hid, 0, 0, 0);
             if (ks + 4 < 16) ring[ks & 3] = ld(w1 + (ks + 4) * FRAG);
-            else if (cont) ring[ks & 3] = ld(cont + (ks + 4 - 16) * FRAG);
+            else if (cont) ring[ks & 3] = ld(cont + g2frag(ks + 4 - 16) * FRAG);
             __builtin_amdgcn_sched_barrier(0);      // keep "MFMA n, refill slot n" order: hipcc otherwise sinks every read
         }                                           // to just before its MFMA (prefetch distance 0)
     };
@@ -341,12 +345,14 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
     };
     // G2: y[out][token] += sum_unit W2[out][32 c + unit] hid[unit][token]; the ring runs on into `cont`
     auto G2 = [&](const char* w2, const char* cont) {
+        // position n: output tile n & 7, K step n >> 3 (fragment 2 (n & 7) + (n >> 3) of the packed chunk): the two MFMAs of
+        // an accumulator are 8 apart instead of adjacent with a ring refill between them
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
             Frag8 a;
             a.u = ring[n & 3];
-            yacc[n >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, hf[n & 1], yacc[n >> 1], 0, 0, 0);
-            if (n + 4 < 16) ring[n & 3] = ld(w2 + (n + 4) * FRAG);
+            yacc[n & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, hf[n >> 3], yacc[n & 7], 0, 0, 0);
+            if (n + 4 < 16) ring[n & 3] = ld(w2 + g2frag(n + 4) * FRAG);
             else if (cont) ring[n & 3] = ld(cont + (n + 4 - 16) * FRAG);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -535,6 +541,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_half_kernel(const bf16_t* __re
         if (hc + 3 < n_half) issue(hc + 3);
         flush();
     };
+    auto g2frag = [](int p) -> int { return 2 * (p & 7) + (p >> 3); };      // G2 position -> fragment of the W2 chunk
     auto G1 = [&](const char* w1, const char* cont) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) hid[r] = 0.f;
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_half_kernel(const bf16_t* __re
             a.u = ring[ks & 3];
             hid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, xf[ks], hid, 0, 0, 0);
             if (ks + 4 < 16) ring[ks & 3] = ld(w1 + (ks + 4) * FRAG);
-            else if (cont) ring[ks & 3] = ld(cont + (ks + 4 - 16) * FRAG);
+            else if (cont) ring[ks & 3] = ld(cont + g2frag(ks + 4 - 16) * FRAG);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -577,12 +584,14 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_half_kernel(const bf16_t* __re
         if (TRAIN) stash_c = c;
     };
     auto G2 = [&](const char* w2, const char* cont) {
+        // position n: output tile n & 7, K step n >> 3 (fragment 2 (n & 7) + (n >> 3) of the packed chunk): the two MFMAs of
+        // an accumulator are 8 apart instead of adjacent with a ring refill between them
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
             Frag8 a;
             a.u = ring[n & 3];
-            yacc[n >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, hf[n & 1], yacc[n >> 1], 0, 0, 0);
-            if (n + 4 < 16) ring[n & 3] = ld(w2 + (n + 4) * FRAG);
+            yacc[n & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, hf[n >> 3], yacc[n & 7], 0, 0, 0);
+            if (n + 4 < 16) ring[n & 3] = ld(w2 + g2frag(n + 4) * FRAG);
             else if (cont) ring[n & 3] = ld(cont + (n + 4 - 16) * FRAG);
             __builtin_amdgcn_sched_barrier(0);
         }
