@@ -53,6 +53,59 @@ HEAD_FUSED = os.environ.get("DSVG_HEAD_FUSED", "0") != "0"
 
 _NULL_CTX = contextlib.nullcontext()
 
+# Weight-gradient GEMMs of the second decoder stage on a second stream beside the group stages' layer kernels: a group-stage
+# launch is 128 workgroups bound by the weight stream per CU - half of the CUs and most of the HBM bandwidth idle for ~40 us
+# per layer - and the backward pass runs 8 of them right behind the four large decoder layers, whose 16 token-reducing
+# weight-gradient GEMMs (one workgroup per CU, HBM-bound) depend on nothing that follows.  Beside the token-stationary
+# kernels of the large stages the same GEMMs only compete (scripts/overlap_wgrad_probe.py), so they are QUEUED during those
+# layers and launched when the first group-stage layer's backward begins (scripts/overlap_gs_wgrad_probe.py: 4 layer
+# launches + 6 GEMMs 352 -> 275 us inside one hipGraph).  OFF by default: in the full step's graph the forked branch costs more
+# than it hides on this ROCm - 6.46 -> 6.72 / 6.65 / 6.49 ms with 1 / 2 / 4 layers queued (GPU_MAX_HW_QUEUES 6), 6.6 with 4
+# queues, 10.6 ms with 8 (the same pathology as the two-graph data-parallel step) - results are bit-identical either way
+# (tests/test_model_gpu.py::test_side_stream_weight_gradients_equal_inline_ones).
+SIDE_WGRAD = int(os.environ.get("DSVG_SIDE_WGRAD", "0"))       # number of layers (from the stage's first) that queue theirs
+
+
+class SideWgrad:
+    """queue of weight-gradient launches (closures over their operands) and the stream they run on.  push() during the
+    large layers' backward, launch() when a group stage begins (fork: the side stream waits for everything issued so far),
+    join() before anything reads a parameter gradient (the side stream's deferred reductions, then the main stream waits).
+    The operands stay referenced until join(): a block freed earlier could be handed to a later launch of the main stream
+    that no dependency orders behind the side stream's reads."""
+
+    def __init__(self):
+        self.stream = None
+        self.pending = []
+        self.running = []
+
+    def push(self, fn):
+        self.pending.append((fn, ops._TAG))
+
+    def launch(self):
+        if not self.pending:
+            return
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            for fn, t in self.pending:
+                with (ops.tag(t) if t is not None else _NULL_CTX):
+                    fn()
+        self.running += self.pending
+        self.pending = []
+
+    def join(self):
+        for fn, t in self.pending:          # never reached a group stage: on the calling stream, now
+            with (ops.tag(t) if t is not None else _NULL_CTX):
+                fn()
+        self.pending = []
+        if self.running:
+            with torch.cuda.stream(self.stream):
+                ops.flush_deferred()
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.running = []
+
+
 
 class Runtime:
     """Per-forward execution context shared by the Functions."""
@@ -65,6 +118,7 @@ class Runtime:
         self.seed = seed          # int64[1] device tensor holding the dropout seed of this step
         self.store = store        # ParamStore or None
         self.training = training
+        self.side = None          # SideWgrad of this pass (model.py) or None
 
     def deferring(self):
         """context manager around launches whose reductions write parameter gradients"""
@@ -113,7 +167,7 @@ def _wgrad(rt, param, dy, x, *, a_drop_p=0.0, a_drop_site=0):
     return out
 
 
-def _wbgrad(rt, weight, bias, dy, x, blocks=None):
+def _wbgrad(rt, weight, bias, dy, x, blocks=None, late=False):
     """(dW, db) of y = x W^T + b from dy: db[n] = sum_t dy[t, n] is the row sum of the GEMM's A operand, so it
     rides on the weight-gradient GEMM (an extra MFMA against ones in a few workgroups) whenever that GEMM is
     split over tokens; otherwise a separate column-sum launch.  blocks: target workgroup count of this GEMM (default: a
@@ -122,12 +176,19 @@ def _wbgrad(rt, weight, bias, dy, x, blocks=None):
     split = ops.split_k_for(n_out, k_in, dy.shape[0], target_blocks=blocks)
     dw = rt.grad_out(weight)
     db = rt.grad_out(bias)
-    with rt.deferring(), _wgrad_tag():
-        if split > 1:
-            ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in), split_k=split, rowsum=db)
-        else:
-            ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in))
-            ops.colsum(dy, out=db)
+
+    def run():
+        with rt.deferring(), _wgrad_tag():
+            if split > 1:
+                ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in), split_k=split, rowsum=db)
+            else:
+                ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in))
+                ops.colsum(dy, out=db)
+
+    if late:
+        rt.side.push(run)       # (SideWgrad: launched beside the next group stage)
+    else:
+        run()
     return dw, db
 
 
@@ -476,9 +537,10 @@ class LayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rt, x, key_mask, z, l, n_seq, S, n_heads, drop_rate, site0,
                 n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off=None, live=None,
-                tiles=None, causal=False):
+                tiles=None, causal=False, side=False):
         p = rt.p(drop_rate)
         d = x.shape[1]
+        ctx.side = bool(side)      # its weight-gradient GEMMs may wait for the next group stage (SideWgrad)
         scale = float(d // n_heads) ** -0.5
         want_bwd = any(ctx.needs_input_grad)         # (grad mode itself is off inside Function.forward)
         ctx.gs = False
@@ -624,6 +686,8 @@ class LayerFn(torch.autograd.Function):
         inv_keep = ops.keep_scale(p)
         dx1m = None
         if ctx.gs:
+            if rt.side is not None:
+                rt.side.launch()        # the queued weight-gradient GEMMs of the large layers run beside this stage
             # one launch for the whole input-gradient chain of the block (csrc/group_stage.hip); it hands over the token-major
             # operands of the four weight-gradient GEMMs and the LayerNorm parameter gradients
             gs = rt.store.gs(win)
@@ -652,9 +716,10 @@ class LayerFn(torch.autograd.Function):
                 dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1, gb(win))
             return (None, dx, None, dz, None, None, None, None, None, None,
                     dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, None, None, None, None, None,
-                    None)
+                    None, None)
         # DSVG_GROUP_LARGE: the layer's four token-reducing weight-gradient GEMMs as ONE grouped launch at the end of its
         # backward pass (their operands are kept alive until then) instead of four launches right behind their producers
+        late = ctx.side and rt.side is not None and rt.defer and not GROUP_LARGE
         keep = []
         group = contextlib.ExitStack()
         if GROUP_LARGE and x.dtype == torch.bfloat16:
@@ -689,8 +754,12 @@ class LayerFn(torch.autograd.Function):
                     # fully fused variant (opt-in, DSVG_FFN_BWD_FUSED=1): hidden tile recomputed from x1, both dropout
                     # masks replayed in the kernel; measured slower than the default below (it writes h, dpre, xh AND dym)
                     dx1, hp, dpre, xh, dym = ops.ffn_bwd(x1, dx2, pb, b1f, 1e-5, p, s0 + 3, s0 + 4, rt.seed)
-                    wgrad2(dym, hp)
-                    wgrad1(dpre, xh)
+                    if late:
+                        rt.side.push(lambda a=dym, b=hp: wgrad2(a, b))
+                        rt.side.push(lambda a=dpre, b=xh: wgrad1(a, b))
+                    else:
+                        wgrad2(dym, hp)
+                        wgrad1(dpre, xh)
                 else:
                     # default: the forward kernel stored h (fragment order) and xh.  dym = residual mask replayed once;
                     # dpre = (dym . W2p) gated by h (h > 0 <=> ReLU passed AND kept) in one GEMM; dx by the fused kernel
@@ -699,17 +768,21 @@ class LayerFn(torch.autograd.Function):
                     # partly in the memory-side cache) instead of at the end
                     hp, xh = h, xn2
                     dym = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
-                    if FFN_BWD_ORDER:
+                    if late:
+                        rt.side.push(lambda a=dym, b=hp: wgrad2(a, b))
+                    elif FFN_BWD_ORDER:
                         wgrad2(dym, hp)
                     dpre = ops.gemm(dym, w2p, b_kc=False, gate=hp, gate_scale=inv_keep)
-                    if FFN_BWD_ORDER:
+                    if late:
+                        rt.side.push(lambda a=dpre, b=xh: wgrad1(a, b))
+                    elif FFN_BWD_ORDER:
                         wgrad1(dpre, xh)
                     # (the same launch also hands over dx1 with the attention residual's dropout mask replayed on it)
                     if FFN_BWD_MASKED:
                         dx1, dx1m = ops.ffn_bwd_dx(dpre, x1, dx2, pb, masked=(p, s0 + 1, rt.seed))
                     else:
                         dx1 = ops.ffn_bwd_dx(dpre, x1, dx2, pb)
-                    if not FFN_BWD_ORDER:
+                    if not FFN_BWD_ORDER and not late:
                         wgrad2(dym, hp)
                         wgrad1(dpre, xh)
                 dw1, db1, dw2 = rt.grad_out(w1), rt.grad_out(b1), rt.grad_out(w2)
@@ -729,9 +802,9 @@ class LayerFn(torch.autograd.Function):
             # the mask of the residual dropout is replayed ONCE into dx2m; the three consumers read plain data
             with ops.tag("ffn"):
                 dx2m = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
-                dw2, db2 = _wbgrad(rt, w2, b2, dx2m, h)
+                dw2, db2 = _wbgrad(rt, w2, b2, dx2m, h, late=late)
                 dh = ops.gemm(dx2m, rt.w(w2), b_kc=False, gate=h, gate_scale=inv_keep)   # (h > 0) <=> relu passed AND kept
-                dw1, db1 = _wbgrad(rt, w1, b1, dh, xn2)
+                dw1, db1 = _wbgrad(rt, w1, b1, dh, xn2, late=late)
                 dxn2 = ops.gemm(dh, rt.w(w1), b_kc=False)
                 with rt.deferring():
                     dx1, dn2w, dn2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w.detach(), res=dx2,
@@ -757,7 +830,7 @@ class LayerFn(torch.autograd.Function):
         # ---- attention: x1 = x + drop1(ao Wo^T + bo) ----
         if dx1m is None:
             dx1m = ops.drop_apply(dx1, p, s0 + 1, rt.seed)
-        dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao)
+        dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao, late=late)
         wob = None
         if (ATTN_BWD_OUTPROJ and rt.store is not None and x.dtype == torch.bfloat16 and H == 8 and x.shape[1] == 256
                 and not ctx.causal and x.shape[0] >= ATTN_MIN_ROWS and (key_mask is None or key_mask.dtype == torch.int64)
@@ -776,7 +849,7 @@ class LayerFn(torch.autograd.Function):
                                          tiles=ctx.tiles)
         keep.append(dx1m)
         del dx1m
-        dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1)
+        dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1, late=late)
         dxn1 = ops.gemm(dqkv, rt.w(win), b_kc=False)
         dx_out = None
         if live is not None:
@@ -791,7 +864,7 @@ class LayerFn(torch.autograd.Function):
         del keep
         return (None, dx, None, dz, dl, None, None, None, None, None,
                 dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, dwg2, dbg2, None, None, None,
-                None)
+                None, None)
 
 
 # --------------------------------------------------------------------------------------------------

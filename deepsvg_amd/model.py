@@ -613,6 +613,7 @@ class SVGTransformer(nn.Module):
         # ops.flush_deferred() before anything reads a gradient may set it (TrainStep)
         self._defer_wgrad = False
         self._rt = None
+        self._side = None           # Fn.SideWgrad (DSVG_SIDE_WGRAD=1), created with the first deferred training pass
         self._live = None
 
     # ---- runtime plumbing ------------------------------------------------------------------------
@@ -647,11 +648,21 @@ class SVGTransformer(nn.Module):
             ops.advance_step_(None, seed)
         self._rt = Fn.Runtime(self.compute_dtype, seed, self._store, training,
                               defer=self._defer_wgrad and (not ops.PROFILE_ON or ops.PROFILE_KEEP_DEFER))
+        if Fn.SIDE_WGRAD and training and self._rt.defer and device.type == "cuda" and not ops.PROFILE_ON:
+            if self._side is None:
+                self._side = Fn.SideWgrad()
+            self._rt.side = self._side
         return self._rt
+
+    def side_join(self):
+        """the owner of a deferred backward pass (TrainStep) calls this before it flushes: queued / side-stream weight
+        gradients (Fn.SideWgrad) are finished and ordered in front of the calling stream"""
+        if self._side is not None:
+            self._side.join()
 
     # ---- blocks ----------------------------------------------------------------------------------
     def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site, seq_off=None, live=None, tiles=None, l=None,
-                   causal=False):
+                   causal=False, side=False):
         """l: label embedding rows [n_seq, dim_label] of a label-conditioned config (memory2 of the reference layers,
         layers/improved_transformer.py:47-49,134-136)"""
         cfg = self.cfg
@@ -673,7 +684,7 @@ class SVGTransformer(nn.Module):
                 L.linear_global.weight if (has_g and not hoisted) else None,
                 L.linear_global.bias if (has_g and not hoisted) else None,
                 L.linear_global2.weight if has_l else None, L.linear_global2.bias if has_l else None,
-                seq_off, live, tiles, causal)
+                seq_off, live, tiles, causal, side and i < int(Fn.SIDE_WGRAD))
         return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps, live)
 
     def make_plan(self, commands_enc, args_enc, commands_dec, want_grad=True, args_dec=None):
@@ -900,7 +911,8 @@ class SVGTransformer(nn.Module):
         self.last_live = (live[0], n_seq) if live is not None else None
         self._live = live
         src = Fn.AddPosFn.apply(rt, None, dec.embedding.PE.pos_embed.weight, n_run, S, PE_DROPOUT, 4, live)
-        out = self._run_stack(rt, dec.decoder, src, None, z, n_run, S, 400, live=live, l=l_seq)
+        # (side: in the backward pass this stage's weight-gradient GEMMs wait for the group stage that follows, Fn.SideWgrad)
+        out = self._run_stack(rt, dec.decoder, src, None, z, n_run, S, 400, live=live, l=l_seq, side=True)
         # the heads read the stage's rows in visible-first order when the loss plan's targets are in that order (_plan): the
         # training step then never gathers back to the caller's group order; anything else that reads a dense logit tensor
         # gets it through `complete` (lazy)

@@ -109,6 +109,7 @@ class TrainStep:
     def _launch_decoder_bucket(self):
         """called from the backward pass when every decoder gradient is final (model.forward registers the hook)"""
         lo, hi = self.model.decoder_param_range()
+        self.model.side_join()
         ops.flush_deferred()                # the queued split-K / LayerNorm reductions of the decoder's gradients
         flat_g = self.model.store.grad_buffer(0)
         self._pending = (lo, dist.all_reduce(flat_g[lo:hi], group=self.pg, async_op=True))
@@ -180,6 +181,7 @@ class TrainStep:
         finally:
             model._decoder_grads_ready = None
             model._defer_wgrad = False
+            model.side_join()
             ops.flush_deferred()
         if not self._gradless_known:
             # first step: find the parameters without a gradient (torch's AdamW skips them) and zero their slots now, once,
@@ -215,6 +217,7 @@ class TrainStep:
             model._keep_bottleneck = False
             model._bottleneck_out = None
             model._defer_wgrad = False
+            model.side_join()
             ops.flush_deferred()
         self._zb = zb
         return {k: v.detach() for k, v in ld.items()}

@@ -561,6 +561,36 @@ def test_deferred_gradient_reductions_equal_immediate_ones(gpu_device, dtype, us
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
+def test_side_stream_weight_gradients_equal_inline_ones(gpu_device, use_graph, monkeypatch):
+    """DSVG_SIDE_WGRAD: the weight-gradient GEMMs of the second decoder stage are queued during that stage's backward and run
+    on a second stream beside the group stages' layer kernels (functional.SideWgrad).  Same launches on the same operands,
+    the same reduction order: loss and flat gradient are bit-identical to the inline order, eagerly and in a replayed
+    hipGraph, over two different batches (a stale or racing gradient would show)."""
+    from deepsvg_amd import functional as Fn
+    from deepsvg_amd.trainer import TrainStep
+    cfg = H.build_cfg("hier")
+    cfg.dropout = 0.1
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 78)
+    batches = [tuple(t.to(DEV) for t in make_batch(640, seed=sd_)) for sd_ in (31, 32, 31)]
+    runs = {}
+    for side in (False, True):
+        monkeypatch.setattr(Fn, "SIDE_WGRAD", 4 if side else 0)
+        torch.manual_seed(98)
+        model = _hip_model(cfg, sd, torch.bfloat16).train()
+        ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=0.0, use_graph=use_graph)
+        grads = []
+        for c, a in batches:
+            ld = ts.step(c, a)
+            torch.cuda.synchronize()
+            grads.append((float(ld["loss"]), model.store.grad_buffer(0).detach().clone()))
+        assert (model._side is not None) == side
+        runs[side] = grads
+    for (l0, g0), (l1, g1) in zip(runs[False], runs[True]):
+        assert l0 == l1
+        assert g0.abs().max().item() > 0 and torch.equal(g0, g1)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
 def test_self_matching_training_step(gpu_device, use_graph):
     """HierarchicalSelfMatching through TrainStep (costs + exhaustive assignment + row permutation have no host round
     trip, so the step is capturable): finite losses, and the assignment is a permutation per icon"""
