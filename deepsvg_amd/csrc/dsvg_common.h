@@ -136,12 +136,15 @@ __device__ __forceinline__ void row32_store(bf16_t* p, const float (&v)[32]) {
 // Counter-based dropout RNG.  The mask is a pure function of (seed, site, element id) so the backward
 // pass regenerates the forward mask instead of storing it; `seed` lives in device memory so that a
 // captured hipGraph sees a new value on every replay.
-//   group g = id >> 3 :  h  = hash32(hash32(lo(g) ^ s0) + hi(g)*C + s1)           (once per 8 elements)
-//   word  i = 0..3    :  w  = hash32(h + (i+1)*0x9e3779b9)                         (two 16-bit draws each)
+//   group g = id >> 3 :  h  = (hash32(lo(g) ^ s0) ^ s1) + hi(g)*C                  (once per 8 elements)
+//   word  i = 0..3    :  w  = mix(h + (i+1)*0x9e3779b9),  mix(w): w ^= w >> 16; w *= 0x7feb352d; w ^= w >> 15
+//                                                                                  (two 16-bit draws each)
 //   element slot = id & 7 uses the low (even slot) / high (odd slot) half of word slot>>1 and is dropped
 //   when draw16 < round(p * 65536); survivors are scaled by 65536 / (65536 - thresh16).
-// Kernels that own an aligned run of 8 elements pay 6 hash rounds per 8 elements (drop_mult8); scalar
-// users pay 3 per element (drop_mult).  Restated bit-for-bit with int64 torch ops in tests/torch_ops_ref.py.
+// One full hash round per group and a one-multiply finaliser per word (round 3; before: two rounds per group and a full
+// round per word, 59 instructions per 8 elements - in the kernels whose epilogues are instruction-issue-bound the draws
+// were up to 2/3 of the epilogue, 40 % of the group-stage layer kernel).  Restated bit-for-bit with int64 torch ops in
+// tests/torch_ops_ref.py.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t dsvg_hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -169,10 +172,14 @@ __device__ __forceinline__ DropCtx drop_make(float p, const uint64_t* seed_ptr, 
     return c;
 }
 __device__ __forceinline__ uint32_t drop_group(const DropCtx& c, uint64_t g) {
-    uint32_t h = dsvg_hash32((uint32_t)g ^ c.s0);
-    return dsvg_hash32(h + (uint32_t)(g >> 32) * 0x9e3779b1u + c.s1);
+    const uint32_t h = dsvg_hash32((uint32_t)g ^ c.s0);
+    return (h ^ c.s1) + (uint32_t)(g >> 32) * 0x9e3779b1u;
 }
-__device__ __forceinline__ uint32_t drop_word(uint32_t h, uint32_t i) { return dsvg_hash32(h + (i + 1u) * 0x9e3779b9u); }
+__device__ __forceinline__ uint32_t drop_word(uint32_t h, uint32_t i) {
+    uint32_t w = h + (i + 1u) * 0x9e3779b9u;
+    w ^= w >> 16; w *= 0x7feb352du; w ^= w >> 15;
+    return w;
+}
 // multiplier (0 or scale) for element idx
 __device__ __forceinline__ float drop_mult(const DropCtx& c, uint64_t idx) {
     if (!c.on) return 1.f;

@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void ffn_fold_bias_kernel(const float* __restr
 // dropout draws, scheme v2 (see the header): group of 16 consecutive ids, word i = two 16-bit draws (slots 2 i, 2 i + 1)
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t drop2_group(const DropCtx& c, uint64_t g16) {
-    uint32_t h = dsvg_hash32((uint32_t)g16 ^ c.s0);
-    return dsvg_hash32(h + (uint32_t)(g16 >> 32) * 0x9e3779b1u + c.s1);
+    const uint32_t h = dsvg_hash32((uint32_t)g16 ^ c.s0);
+    return (h ^ c.s1) + (uint32_t)(g16 >> 32) * 0x9e3779b1u;
 }
 __device__ __forceinline__ uint32_t drop2_word(uint32_t h, uint32_t i) {
     uint32_t w = h + (i + 1u) * 0x9e3779b9u;

@@ -53,8 +53,11 @@ def drop_mult(p, seed, site, idx):
     slot = idx & 7
     lo, hi = g & M32, (g >> 32) & M32
     h = _hash32_t(lo ^ s0)
-    h = _hash32_t((h + hi * 0x9E3779B1 + s1) & M32)
-    w = _hash32_t((h + ((slot >> 1) + 1) * 0x9E3779B9) & M32)
+    h = ((h ^ s1) + hi * 0x9E3779B1) & M32
+    w = (h + ((slot >> 1) + 1) * 0x9E3779B9) & M32
+    w = w ^ (w >> 16)
+    w = (w * 0x7FEB352D) & M32
+    w = w ^ (w >> 15)
     draw = torch.where((slot & 1) == 1, w >> 16, w & 0xFFFF)
     return torch.where(draw < thresh, torch.zeros((), dtype=torch.float32, device=idx.device),
                        torch.full((), scale, dtype=torch.float32, device=idx.device))
@@ -75,7 +78,7 @@ def drop2_mult(p, seed, site, idx):
     slot = idx & 15
     lo, hi = g & M32, (g >> 32) & M32
     h = _hash32_t(lo ^ s0)
-    h = _hash32_t((h + hi * 0x9E3779B1 + s1) & M32)
+    h = ((h ^ s1) + hi * 0x9E3779B1) & M32
     w = (h + ((slot >> 1) + 1) * 0x9E3779B9) & M32
     w = w ^ (w >> 16)
     w = (w * 0x7FEB352D) & M32
