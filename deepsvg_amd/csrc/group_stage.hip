@@ -235,7 +235,15 @@ struct GsFwdArgs {
                             // those of its first row, the dropout draws are indexed from the buffer's first row / sequence
     int ffn_format;         // training outputs of the FFN half as csrc/ffn_fused.hip's backward reads them: xn2 = the
                             // affine-free (x1 - mean2) rstd2, h with fragment-ordered columns (frag_pos)
+    unsigned long long* dbg;    // development probe (dsvg_gs_debug_clock): 8 s_memtime stamps per wave, or nullptr
 };
+
+// stamp `slot` of this wave: kernel start, LayerNorm 1 done, B1 (in_proj + attention), B2c (out_proj + LayerNorm 2), B3
+// (linear1), B4 (linear2), stores issued
+__device__ __forceinline__ void gs_stamp(unsigned long long* d, int slot) {
+    if (d && (threadIdx.x & 63) == 0)
+        d[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + slot] = __builtin_amdgcn_s_memtime();
+}
 
 // LDS layout of the forward kernel (bytes)
 constexpr int F_XN = 0;                                 // [32][LDX]  LN1(x); later LN2(x1); at the end x2
@@ -260,6 +268,7 @@ __device__ __forceinline__ float row_total(float part, float* stat, int wave, in
 template <bool TRAIN, int PF>
 __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
+    gs_stamp(a.dbg, 0);
     bf16_t* XN = reinterpret_cast<bf16_t*>(smem + F_XN);
     bf16_t* AO = reinterpret_cast<bf16_t*>(smem + F_AO);
     bf16_t* QKV = reinterpret_cast<bf16_t*>(smem + F_QKV);
@@ -346,6 +355,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         }
     }
     lds_barrier();
+    gs_stamp(a.dbg, 1);
 
     // ---- the lane's attention row: its sequence, the first row of that sequence inside the tile, visible keys -------------
     const int qi = min(li / Smax, n_in - 1);
@@ -442,6 +452,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         stage_rows(AO, LDX, li, qc, h2, t);             // ot[r] = O[row li][dim rowmap(r, h2)] of head `wave`
     }
     lds_barrier();                                       // B1: q|k|v and the head outputs of all heads are in LDS
+    gs_stamp(a.dbg, 2);
     if (TRAIN) {
         store_image(a.qkv + row0 * (3 * GD), 3 * GD, QKV, LDQ, 0, S, 3 * GD);
         store_image(a.ao + row0 * GD, GD, AO, LDX, 0, S, GD);
@@ -519,6 +530,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         }
     }
     lds_barrier();                                       // B2c: LN2(x1) (and x1) complete
+    gs_stamp(a.dbg, 3);
     if (TRAIN) {
         if (a.ffn_format) store_image(a.xn2 + row0 * GD, GD, XH, GD, 0, S, GD);
         else store_image(a.xn2 + row0 * GD, GD, XN, LDX, 0, S, GD);
@@ -562,6 +574,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         }
     }
     lds_barrier();                                       // B3: the hidden activations of the tile are in LDS
+    gs_stamp(a.dbg, 4);
     if (TRAIN) {
         if (a.ffn_format) store_image_frag512(a.h + row0 * GF, HI, LDH, S);
         else store_image(a.h + row0 * GF, GF, HI, LDH, 0, S, GF);
@@ -595,7 +608,9 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         stage_rows(XN, LDX, li, qc, h2, t);
     }
     lds_barrier();                                       // B4
+    gs_stamp(a.dbg, 5);
     store_image(a.x2 + row0 * GD, GD, XN, LDX, 0, S, GD);
+    gs_stamp(a.dbg, 6);
 }
 
 
@@ -1048,6 +1063,13 @@ extern "C" int dsvg_gs_pack(const float* flat_f32, const int64_t* offs, int32_t 
     return 0;
 }
 
+static unsigned long long* g_gs_dbg_host = nullptr;
+/* development probe: buf = device buffer of (workgroups * 8 waves * 8) uint64 or NULL (off); see gs_stamp */
+extern "C" int dsvg_gs_debug_clock(void* buf) {
+    g_gs_dbg_host = (unsigned long long*)buf;
+    return 0;
+}
+
 extern "C" int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, const float* in_bias, const float* out_bias,
                                  const float* b1, const float* b2, const float* gamma1, const float* beta1,
                                  const float* gamma2, const float* beta2, const uint64_t* key_mask, const void* seq_add,
@@ -1075,7 +1097,7 @@ extern "C" int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, co
     a.x2 = (bf16_t*)x2; a.mean1 = mean1; a.rstd1 = rstd1; a.xn1 = (bf16_t*)xn1; a.qkv = (bf16_t*)qkv; a.ao = (bf16_t*)ao;
     a.x1 = (bf16_t*)x1; a.mean2 = mean2; a.rstd2 = rstd2; a.xn2 = (bf16_t*)xn2; a.h = (bf16_t*)h;
     a.n_seq = (int)n_seq; a.S = S; a.eps = eps; a.scale = scale; a.drop_p = drop_p; a.site0 = site0;
-    a.seq_base = seq_base; a.ffn_format = ffn_format;
+    a.seq_base = seq_base; a.ffn_format = ffn_format; a.dbg = g_gs_dbg_host;
     const int per = 32 / S;
     const int nb = (int)((n_seq + per - 1) / per);
     hipStream_t st = (hipStream_t)stream;

@@ -69,6 +69,7 @@ SIGNATURES = {
     "dsvg_attn_pack_bwd": (c_i32, [vp, vp, c_i32, vp, vp]),
     "dsvg_ffn_wgrad_finish_many": (c_i32, [vp, c_i32, vp]),
     "dsvg_ffn_debug_clock": (c_i32, [vp]),
+    "dsvg_gs_debug_clock": (c_i32, [vp]),
     "dsvg_gather_groups": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i32, c_i32, c_i64, vp]),
     "dsvg_build_masks": (c_i32, [vp, c_i64, c_i32, c_i32, c_i32, vp, vp, vp, vp]),
     "dsvg_embed_gather": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, vp]),

@@ -486,6 +486,9 @@ int dsvg_ffn_wgrad_finish_many(const void* const* ptrs, int32_t n_layers, void* 
 /* development probe of dsvg_ffn_fwd: buf = device buffer of (workgroups x 8 waves x 4) uint64 time stamps (kernel start,
  * LayerNorm done, chunk loop done, stores issued) or NULL to switch it off (scripts/ffn_phase_probe.py) */
 int dsvg_ffn_debug_clock(void* buf);
+/* the same for dsvg_gs_layer_fwd: (workgroups * 8 * 8) uint64 - kernel start, LayerNorm 1, in_proj + attention, out_proj +
+ * LayerNorm 2, linear1, linear2, stores issued (scripts/gs_phase_probe.py) */
+int dsvg_gs_debug_clock(void* buf);
 
 /* ------------------------------------------------------------------------------------------
  * Fused attention sub-block (d_model 256, 8 heads of 32, sequences of at most 32 tokens, bf16):
