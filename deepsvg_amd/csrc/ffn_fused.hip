@@ -436,16 +436,15 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
 // bit-identical to ffn_fwd_kernel) in workgroups of 4 waves = 128 rows with a ring of four 16 KiB HALF chunks (the W1 part /
 // the W2 part of a chunk; 67 KiB of LDS), so that two workgroups fit on a CU.  Used for launches of at most 32,768 rows:
 // 256 of these workgroups put ONE wave on every SIMD of the chip where 128 of the 256-row workgroups put two waves on
-// every SIMD of half the CUs (1,000 rows: 30 us against 40; at full size the two kernels are equal, and delaying the second
-// workgroup of a CU so that its prologue runs beside its partner's chunk loop gained nothing: prologue and epilogue are
-// latency- / VALU-bound per wave, not HBM-bound).
+// every SIMD of half the CUs (1,000 rows: 28 us against 39; at full size the two kernels are equal, and delaying the second
+// workgroup of a CU so that its prologue runs beside its partner's chunk loop - tried with a per-CU turn counter keyed by
+// HW_ID / XCC_ID, removed again - gained nothing: two 128-row workgroups stream the weights twice, which saturates the
+// L2 -> LDS path).
 //   sync(hc) in front of every G: half chunk hc + 1 has landed (the A ring runs on into it), half chunk hc + 3 is issued
 //   into the slot half chunk hc - 1 has left; hc + 2 stays in flight across the barrier (counted wait: 4 pieces per wave).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int HSLOT = 16 * FRAG;        // half chunk: 16 fragments = 16 KiB
 constexpr int HNBUF = 4;
-constexpr int CU_TURNS = 4096;
-__device__ unsigned int g_cu_turn[CU_TURNS];
 
 template <bool TRAIN>
 __global__ __launch_bounds__(256, 2) void ffn_fwd_half_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ img,
@@ -454,8 +453,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_half_kernel(const bf16_t* __re
                                                               bf16_t* __restrict__ xh_out, float* __restrict__ rstd_out,
                                                               int M, float eps, float drop_p,
                                                               const uint64_t* __restrict__ seed, uint32_t site_h,
-                                                              uint32_t site_r, int n_chunks, int stagger, int delay,
-                                                              unsigned long long* dbg) {
+                                                              uint32_t site_r, int n_chunks, unsigned long long* dbg) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // [4 half-chunk slots | b1 (2 KiB) | b2 (1 KiB)]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -478,23 +476,6 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_half_kernel(const bf16_t* __re
     sb1[tid] = b1[tid];
     sb1[tid + 256] = b1[tid + 256];
     sb2[tid] = b2[tid];
-
-    // ---- experiment (off by default, see the header): the second workgroup to arrive on a CU starts `delay` ticks late ----
-    if (stagger) {
-        unsigned int* turn = reinterpret_cast<unsigned int*>(smem + HNBUF * HSLOT + 3072);
-        if (tid == 0) {
-            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID
-            const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
-            const uint32_t cu = ((hw >> 8) & 0xffu) | ((xcc & 15u) << 8);        // cu [11:8], sh [12], se [15:13] | xcc
-            *turn = atomicAdd(&g_cu_turn[cu & (CU_TURNS - 1)], 1u);
-            if (dbg) dbg[(size_t)gridDim.x * 16 + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
-        }
-        __syncthreads();
-        if (*turn & 1u) {
-            const uint64_t t0 = __builtin_amdgcn_s_memtime();
-            while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)delay) __builtin_amdgcn_s_sleep(64);
-        }
-    }
 
     // ---- the wave's 32 rows: LayerNorm in registers -> 16 B-operand fragments (as in ffn_fwd_kernel) -----------------
     const int row0 = blockIdx.x * 128 + wave * 32;
@@ -1113,16 +1094,14 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
     const bool half_on = stages_arg == 2 || (stages_arg == 0 && (half_env >= 0 ? half_env != 0 : rows <= 32768));
     if (half_on) {
         const int nbh = (int)((rows + 127) / 128);
-        const size_t lds = (size_t)HNBUF * HSLOT + 3072 + 16;
-        static const int half_stagger = getenv("DSVG_FFN_HALF_STAGGER") ? atoi(getenv("DSVG_FFN_HALF_STAGGER")) : 0;
-        static const int half_delay = getenv("DSVG_FFN_HALF_DELAY") ? atoi(getenv("DSVG_FFN_HALF_DELAY")) : 24000;
+        const size_t lds = (size_t)HNBUF * HSLOT + 3072;
 #define DSVG_FFN_FWD_HALF(TR)                                                                                         \
     do {                                                                                                              \
         DSVG_ENSURE_LDS((ffn_fwd_half_kernel<TR>), lds);                                                              \
         hipLaunchKernelGGL((ffn_fwd_half_kernel<TR>), dim3(nbh), dim3(256), lds, st, (const bf16_t*)x,                 \
                            (const bf16_t*)packed_fwd_layer, b1_folded, b2, (bf16_t*)y, (bf16_t*)h_out, (bf16_t*)xh_out,\
                            rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res, dbg_chunks,    \
-                           half_stagger, half_delay, g_ffn_dbg_host);                                                 \
+                           g_ffn_dbg_host);                                                                           \
     } while (0)
         if (train) DSVG_FFN_FWD_HALF(true);
         else DSVG_FFN_FWD_HALF(false);

@@ -34,8 +34,7 @@ def main():
         for train in (False, True):
             for _ in range(3):
                 ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 3, 4, seed, train=train, stages=STAGES)
-            buf = torch.zeros(nwg * 8 * 4 + 2 * nwg, dtype=torch.int64, device=DEV)   # (+ the hardware ids of the half-size workgroups)
-            hwbuf, buf = buf[nwg * 32:], buf[:nwg * 32]
+            buf = torch.zeros(nwg * 8 * 4, dtype=torch.int64, device=DEV)
             lib.check(L_.dsvg_ffn_debug_clock(buf.data_ptr()), "dbg")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -61,19 +60,7 @@ def main():
             print(f"rows {rows:6d} ({nwg} workgroups) {'train' if train else 'infer'}: launch {us:6.1f} us | per wave, median "
                   f"(90th pct): prologue {med[0]:5.1f} ({p90[0]:5.1f}) us, chunk loop {med[1]:5.1f} ({p90[1]:5.1f}) us, epilogue "
                   f"{med[2]:5.1f} ({p90[2]:5.1f}) us, total {total.median().item() * k:5.1f} us")
-            if os.environ.get("PROBE_HW") and STAGES == 2:
-                # DSVG_FFN_HALF_STAGGER=1: which CU did every workgroup run on, and was exactly one of a CU's two delayed?
-                hw = hwbuf.cpu()
-                key = ((hw >> 32) & 15) * 65536 + (hw & 0xff00)
-                pro = (t[:, 0, 1] - t[:, 0, 0]).view(-1, 4)[:, 0] * k          # wave 0's prologue (incl. the delay)
-                late = pro > pro.median()
-                uniq, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
-                n_late = torch.zeros_like(cnt).scatter_add_(0, inv, late.long())
-                print(f"        {uniq.numel()} distinct (xcc, se, sh, cu) ids; workgroups per id: "
-                      f"{dict(zip(*[v.tolist() for v in torch.unique(cnt, return_counts=True)]))}; ids with 2 workgroups and "
-                      f"exactly one late: {int(((cnt == 2) & (n_late == 1)).sum())}; xcc values {sorted(set(((hw >> 32) & 15).tolist()))}; "
-                      f"sample hw ids {[hex(v & 0xffffffff) for v in hw[:4].tolist()]}")
-            if os.environ.get("PROBE_SPLIT"):       # the two populations of a staggered launch: by the length of the prologue
+            if os.environ.get("PROBE_SPLIT"):       # the faster and the slower half of the waves, by the length of the prologue
                 order = torch.argsort(ph[:, 0])
                 for name, idx in (("early half", order[:order.numel() // 2]), ("late half ", order[order.numel() // 2:])):
                     m = ph[idx].median(0).values * k
