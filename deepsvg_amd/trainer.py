@@ -32,6 +32,22 @@ DEFAULT_WEIGHTS = {   # configs/deepsvg/default_icons.py:65-73 at step 0
 }
 
 
+_SHARED_STREAMS = {}
+
+
+def _shared_stream(role, device):
+    """the plan / count stream of a device: ONE per process and role, shared by every TrainStep.  ROCm maps HIP streams onto
+    GPU_MAX_HW_QUEUES hardware queues in creation order; a trainer created later in the process (a second model, a
+    validation trainer) would otherwise draw streams further down torch's pool, and a plan stream that lands on the main
+    stream's hardware queue serialises the plan behind the previous step - the host can no longer run ahead of the GPU
+    (scripts/secondary_bench.py: the second TrainStep of the process ran 29.3 -> 36.8 ms/step)."""
+    key = (role, torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())
+    st = _SHARED_STREAMS.get(key)
+    if st is None:
+        st = _SHARED_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class TrainStep:
     def __init__(self, model, loss_fn, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_clip=1.0,
                  weights=None, process_group=None, use_graph=False, exact_global_mean=True, force_ddp=False):
@@ -273,7 +289,7 @@ class TrainStep:
         # Safe by default (the plan stream first waits for everything enqueued so far, i.e. for the inputs);
         # `inputs_resident = True` (inputs were complete before the previous step was enqueued) skips that wait.
         if self._plan_stream is None:
-            self._plan_stream = torch.cuda.Stream(device=commands.device)
+            self._plan_stream = _shared_stream("plan", commands.device)
         ps = self._plan_stream
         t_trace = [time.perf_counter()] if self.host_trace is not None else None
         if not self.inputs_resident:
@@ -290,7 +306,7 @@ class TrainStep:
             # previous step has finished, and the host could never run ahead of the GPU (measured on a one-rank group:
             # plan + read 6.7 ms instead of 0.45 ms, every graph launch exposed: 7.27 ms/step against 6.74 single-GPU)
             if self._count_stream is None:
-                self._count_stream = torch.cuda.Stream(device=commands.device)
+                self._count_stream = _shared_stream("count", commands.device)
             cs = self._count_stream
             cs.wait_stream(ps)
             with torch.cuda.stream(cs):

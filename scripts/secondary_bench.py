@@ -36,7 +36,25 @@ def model_for(cfg, seed=1):
     return m.to(DEV).set_compute_dtype(torch.bfloat16)
 
 
+def leg_c4p():
+    """C4 at the reference's default length"""
+    cfg = C.OneStageOneShot()
+    cfg.use_vae = False                         # max_total_len = 240: 242-token encoder / 241-token decoder sequences
+    model = model_for(cfg).train()
+    commands, args = make_batch_onestage(256, total_len=240, seed=1)
+    commands, args = commands.to(DEV), args.to(DEV)
+    step = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=1e-3, use_graph=True)
+    for _ in range(3):
+        step.step(commands, args)
+    sec = timed(lambda: step.step(commands, args), 10)
+    print(f"C4' one-stage train step at max_total_len = 240 (256 icons x 242 tokens, bf16, hipGraph, streaming attention): "
+          f"{sec * 1e3:.2f} ms/step, {256 / sec:,.0f} icons/s, {256 * 242 / sec:,.0f} tokens/s")
+
+
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None          # "c4p": the 242-token training leg alone (A/B of knobs)
+    if only == "c4p":
+        return leg_c4p()
     # ---- C4 --------------------------------------------------------------------------------------------------
     cfg = C.OneStageOneShot()
     cfg.max_total_len = 50
@@ -52,19 +70,7 @@ def main():
           f"{512 / sec:,.0f} icons/s")
     del step, model
 
-    # ---- C4 at the reference's default length ------------------------------------------------------------------
-    cfg = C.OneStageOneShot()
-    cfg.use_vae = False                         # max_total_len = 240: 242-token encoder / 241-token decoder sequences
-    model = model_for(cfg).train()
-    commands, args = make_batch_onestage(256, total_len=240, seed=1)
-    commands, args = commands.to(DEV), args.to(DEV)
-    step = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=1e-3, use_graph=True)
-    for _ in range(3):
-        step.step(commands, args)
-    sec = timed(lambda: step.step(commands, args), 10)
-    print(f"C4' one-stage train step at max_total_len = 240 (256 icons x 242 tokens, bf16, hipGraph, streaming attention): "
-          f"{sec * 1e3:.2f} ms/step, {256 / sec:,.0f} icons/s, {256 * 242 / sec:,.0f} tokens/s")
-    del step, model
+    leg_c4p()
 
     # ---- C5a -------------------------------------------------------------------------------------------------
     cfg = C.HierarchicalOrdered()
