@@ -861,45 +861,70 @@ __global__ void bcast_add_bwd_kernel(const T* __restrict__ dx, T* __restrict__ d
         Elem<T>::st(dg + b * d + c, s * drop_mult(dc, (uint64_t)b * d + c));
     }
 }
-// bf16 rows of d % 8 == 0 columns: a thread owns 8 columns of one sequence (16-byte loads, 8 rows in flight), a workgroup
-// 256 / (d / 8) sequences - the kernel above reads 2 bytes per lane (19 us for 71 k rows of 256 columns)
+// bf16 rows of d % 8 == 0 columns: 16-byte loads, 8 columns of one sequence per thread and BA_SPLIT threads per such piece
+// (thread q takes the rows q, q + BA_SPLIT, ..: 2,304 sequences of 31 rows are 18 k pieces of 31 dependent-free loads - one
+// thread per piece left the chip at one wave per SIMD and the launch at 9.4 us, bound by issue and latency); the partial
+// sums meet in LDS in a fixed order.
+// dxm (optional): the rows themselves with the mask of ANOTHER dropout site replayed on them (what dsvg_drop_apply(dx, site_m)
+// writes) - the large decoder layers' backward needs both of dx1, and this kernel already reads every element of it once
+constexpr int BA_SPLIT = 4;
 __global__ __launch_bounds__(256) void bcast_add_bwd8_kernel(const bf16_t* __restrict__ dx, bf16_t* __restrict__ dg,
                                                              long long n_seq, long long n_seq_out, int S, int d,
-                                                             float drop_p, uint32_t site, const uint64_t* seed) {
-    const int cpr = d / 8;
-    const long long b = (long long)blockIdx.x * (256 / cpr) + threadIdx.x / cpr;
-    const int c8 = (threadIdx.x % cpr) * 8;
-    if (threadIdx.x >= (256 / cpr) * cpr || b >= n_seq_out) return;
+                                                             float drop_p, uint32_t site, const uint64_t* seed,
+                                                             bf16_t* __restrict__ dxm, uint32_t site_m) {
+    __shared__ float part[256][8];
+    const int cpr = d / 8;                                  // pieces per row
+    const int per = 256 / (cpr * BA_SPLIT);                 // sequences per workgroup (>= 1: d <= 512; see the host side)
+    const int t = threadIdx.x;
+    const int piece = t % cpr, q = (t / cpr) % BA_SPLIT, sl = t / (cpr * BA_SPLIT);
+    const long long b = (long long)blockIdx.x * per + sl;
+    const int c8 = piece * 8;
+    const bool mine = sl < per && b < n_seq_out;
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
-    if (b < n_seq) {
-        const DropCtx dc = drop_make(drop_p, seed, site);
+    if (mine && b < n_seq) {
+        const DropCtx dm_ctx = drop_make(dxm ? drop_p : 0.f, seed, site_m);
         const bf16_t* px = dx + (b * S) * d + c8;
-        int i = 0;
-        for (; i + 8 <= S; i += 8) {
-            uint4 v[8];
+        // the masked copy of one row piece: ids (row * d + c8) .. + 7 are one aligned group of the standard draws
+        auto put_masked = [&](long long row, const uint32_t (&w)[4]) {
+            if (!dxm) return;
+            float v[8], m[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(px + (long long)(i + u) * d);
+            for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+            drop_mult8(dm_ctx, (uint64_t)row * d + c8, m);
+            *reinterpret_cast<uint4*>(dxm + row * d + c8) =
+                make_uint4(f2bf_pk(v[0] * m[0], v[1] * m[1]), f2bf_pk(v[2] * m[2], v[3] * m[3]),
+                           f2bf_pk(v[4] * m[4], v[5] * m[5]), f2bf_pk(v[6] * m[6], v[7] * m[7]));
+        };
+        for (int i = q; i < S; i += 4 * BA_SPLIT) {          // 4 rows of this thread in flight
+            uint4 v[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 4; ++u)
+                if (i + u * BA_SPLIT < S) v[u] = *reinterpret_cast<const uint4*>(px + (long long)(i + u * BA_SPLIT) * d);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i + u * BA_SPLIT >= S) break;
                 const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     s[2 * e] += __uint_as_float(w[e] << 16);
                     s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
                 }
+                put_masked(b * S + i + u * BA_SPLIT, w);
             }
         }
-        for (; i < S; ++i) {
-            const uint4 t = *reinterpret_cast<const uint4*>(px + (long long)i * d);
-            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+    }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s[2 * e] += __uint_as_float(w[e] << 16);
-                s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
-            }
-        }
+    for (int e = 0; e < 8; ++e) part[t][e] = s[e];
+    __syncthreads();
+    if (!mine || q != 0) return;
+#pragma unroll
+    for (int k = 1; k < BA_SPLIT; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += part[t + k * cpr][e];
+    if (b < n_seq) {
+        const DropCtx dc = drop_make(drop_p, seed, site);
         if (dc.on) {
             float dm[8];
             drop_mult8(dc, (uint64_t)b * d + c8, dm);
@@ -933,15 +958,30 @@ extern "C" int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64
     if (dtype == DSVG_F32)
         hipLaunchKernelGGL(bcast_add_bwd_kernel<float>, dim3((unsigned)n_seq_out), dim3(256), 0, st, (const float*)dx,
                            (float*)dg, (long long)n_seq, S, d, drop_p, drop_site, seed);
-    else if (dtype == DSVG_BF16 && (d % 8) == 0 && d <= 2048 && (((uintptr_t)dx | (uintptr_t)dg) & 15) == 0) {
-        const int per = 256 / (d / 8);
+    else if (dtype == DSVG_BF16 && (d % 8) == 0 && d <= 512 && (((uintptr_t)dx | (uintptr_t)dg) & 15) == 0) {
+        const int per = 256 / ((d / 8) * BA_SPLIT);
         hipLaunchKernelGGL(bcast_add_bwd8_kernel, dim3((unsigned)((n_seq_out + per - 1) / per)), dim3(256), 0, st,
                            (const bf16_t*)dx, (bf16_t*)dg, (long long)n_seq, (long long)n_seq_out, S, d, drop_p, drop_site,
-                           seed);
+                           seed, (bf16_t*)nullptr, 0u);
     } else if (dtype == DSVG_BF16)
         hipLaunchKernelGGL(bcast_add_bwd_kernel<bf16_t>, dim3((unsigned)n_seq_out), dim3(256), 0, st, (const bf16_t*)dx,
                            (bf16_t*)dg, (long long)n_seq, S, d, drop_p, drop_site, seed);
     else { dsvg_set_error("bcast_add_bwd: bad dtype"); return -1; }
     DSVG_LAUNCH_CHECK("bcast_add_bwd");
+    return 0;
+}
+
+extern "C" int dsvg_bcast_add_bwd_masked(const void* dx, void* dg, void* dx_masked, int64_t n_seq, int64_t n_seq_out, int32_t S,
+                                         int32_t d, float drop_p, uint32_t drop_site, uint32_t mask_site, const uint64_t* seed,
+                                         void* stream) {
+    DSVG_CHECK_ARG(dx && dg && dx_masked && n_seq > 0 && n_seq_out >= n_seq && S > 0 && d > 0, "bcast_add_bwd_masked: bad args");
+    DSVG_CHECK_ARG(drop_p > 0.f && seed, "bcast_add_bwd_masked: needs dropout and a seed pointer (use dsvg_bcast_add_bwd otherwise)");
+    DSVG_CHECK_ARG((d % 8) == 0 && d <= 512 && (((uintptr_t)dx | (uintptr_t)dg | (uintptr_t)dx_masked) & 15) == 0,
+                   "bcast_add_bwd_masked: bf16 rows of d % 8 == 0 <= 512 columns, 16-byte aligned");
+    const int per = 256 / ((d / 8) * BA_SPLIT);
+    hipLaunchKernelGGL(bcast_add_bwd8_kernel, dim3((unsigned)((n_seq_out + per - 1) / per)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dx, (bf16_t*)dg, (long long)n_seq, (long long)n_seq_out, S, d, drop_p, drop_site, seed,
+                       (bf16_t*)dx_masked, mask_site);
+    DSVG_LAUNCH_CHECK("bcast_add_bwd_masked");
     return 0;
 }

@@ -39,6 +39,8 @@ FFN_BWD_MASKED = os.environ.get("DSVG_FFN_BWD_MASKED", "0") != "0"
 # the weight-gradient GEMMs of a layer of the 4096-row stages as one grouped launch (DSVG_GROUP_WGRAD=0: one by one)
 GROUP_WGRAD = os.environ.get("DSVG_GROUP_WGRAD", "1") != "0"
 GROUP_LARGE = os.environ.get("DSVG_GROUP_LARGE", "0") != "0"
+# the decoder layers' bcast_add_bwd also writes the masked copy of dx1 the attention half needs (one read of dx1, no drop_apply launch)
+BCAST_MASKED = os.environ.get("DSVG_BCAST_MASKED", "1") != "0"
 # attention backward of the large stages with the out_proj backward inside (no `dao = dx1m @ Wo` GEMM launch)
 ATTN_BWD_OUTPROJ = os.environ.get("DSVG_ATTN_BWD_OUTPROJ", "1") != "0"
 # training forward of a large dense stage: sequences beyond a multiple of SEQ_ROUND (one round of the chip for the fused
@@ -819,8 +821,13 @@ class LayerFn(torch.autograd.Function):
             if ctx.needs_input_grad[4]:
                 dl = ops.gemm(dg2, rt.w(wg2), b_kc=False)
         if z is not None:
-            # (sequences past the live prefix: zero gradient rows, written by the same launch)
-            dg = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed, n_seq_out=n_seq_full)
+            # (sequences past the live prefix: zero gradient rows, written by the same launch; and with dropout on, the launch
+            # that reads every element of dx1 anyway also writes dx1m = drop1's mask replayed on dx1 for the attention half)
+            if (BCAST_MASKED and dx1m is None and p > 0 and dx1.dtype == torch.bfloat16 and dx1.shape[0] == n_seq * S
+                    and dx1.shape[1] % 8 == 0 and dx1.is_contiguous()):
+                dg, dx1m = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed, n_seq_out=n_seq_full, mask_site=s0 + 1)
+            else:
+                dg = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed, n_seq_out=n_seq_full)
             if wg is None:
                 dz = dg                     # `z` was the projected row itself: its gradient goes to GlobalCondFn
             else:

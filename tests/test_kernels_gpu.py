@@ -853,6 +853,22 @@ def _ffn_params(flat, offs, layer):
             flat[og:og + 256], flat[ob:ob + 256])
 
 
+def test_bcast_add_bwd_with_the_masked_copy(gpu_device):
+    """dsvg_bcast_add_bwd_masked: the per-sequence sum AND drop_apply(dx, mask_site) from one read of dx - both bit-identical to
+    the two separate launches, incl. a sequence count that does not fill the last workgroup and zero rows past the live prefix"""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    seed = _seed_tensor(0x5151515151)
+    for n_seq, S, n_out in ((37, 31, 37), (64, 8, 80), (5, 3, 5)):
+        dx = torch.randn(n_seq * S, 256, generator=g).to(DEV).to(torch.bfloat16)
+        dg0 = ops.bcast_add_bwd(dx, n_seq, S, 0.1, 402, seed, n_seq_out=n_out)
+        dm0 = ops.drop_apply(dx, 0.1, 401, seed)
+        dg1, dm1 = ops.bcast_add_bwd(dx, n_seq, S, 0.1, 402, seed, n_seq_out=n_out, mask_site=401)
+        assert torch.equal(dg0, dg1) and torch.equal(dm0, dm1)
+        eg, em = R.bcast_add_bwd(dx, n_seq, S, 0.1, 402, seed, n_seq_out=n_out, mask_site=401)
+        assert torch.equal(dm1, em)
+        _close(dg1, eg, 1e-2, "bcast_add_bwd (masked variant) dg")
+
+
 def test_ffn_pack_layouts(gpu_device):
     """every fragment of the packed images against the index formulas of csrc/ffn_fused.hip (lane l = (i, half), 8
     elements e): forward [W1' chunk | W2 chunk], backward [W1' chunk | W2^T chunk | W1'^T chunk], W1' = W1 diag(gamma)
