@@ -871,7 +871,9 @@ constexpr int BA_SPLIT = 4;
 __global__ __launch_bounds__(256) void bcast_add_bwd8_kernel(const bf16_t* __restrict__ dx, bf16_t* __restrict__ dg,
                                                              long long n_seq, long long n_seq_out, int S, int d,
                                                              float drop_p, uint32_t site, const uint64_t* seed,
-                                                             bf16_t* __restrict__ dxm, uint32_t site_m) {
+                                                             bf16_t* __restrict__ dxm, uint32_t site_m, long long rows_m) {
+    // rows_m (with dxm): dx / dxm have rows_m >= n_seq * S rows (a live row prefix rounded up): the rows past the summed
+    // sequences are masked too, by the workgroups of the sequences they would belong to
     __shared__ float part[256][8];
     const int cpr = d / 8;                                  // pieces per row
     const int per = 256 / (cpr * BA_SPLIT);                 // sequences per workgroup (>= 1: d <= 512; see the host side)
@@ -883,7 +885,8 @@ __global__ __launch_bounds__(256) void bcast_add_bwd8_kernel(const bf16_t* __res
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
-    if (mine && b < n_seq) {
+    const bool summing = b < n_seq;
+    if (mine && (summing || (dxm && b * S < rows_m))) {
         const DropCtx dm_ctx = drop_make(dxm ? drop_p : 0.f, seed, site_m);
         const bf16_t* px = dx + (b * S) * d + c8;
         // the masked copy of one row piece: ids (row * d + c8) .. + 7 are one aligned group of the standard draws
@@ -897,19 +900,23 @@ __global__ __launch_bounds__(256) void bcast_add_bwd8_kernel(const bf16_t* __res
                 make_uint4(f2bf_pk(v[0] * m[0], v[1] * m[1]), f2bf_pk(v[2] * m[2], v[3] * m[3]),
                            f2bf_pk(v[4] * m[4], v[5] * m[5]), f2bf_pk(v[6] * m[6], v[7] * m[7]));
         };
-        for (int i = q; i < S; i += 4 * BA_SPLIT) {          // 4 rows of this thread in flight
+        // rows of this sequence that exist: all S of a summed sequence, those below rows_m of a masked-only one
+        const int S_here = summing ? S : (int)min((long long)S, rows_m - b * S);
+        for (int i = q; i < S_here; i += 4 * BA_SPLIT) {     // 4 rows of this thread in flight
             uint4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (i + u * BA_SPLIT < S) v[u] = *reinterpret_cast<const uint4*>(px + (long long)(i + u * BA_SPLIT) * d);
+                if (i + u * BA_SPLIT < S_here) v[u] = *reinterpret_cast<const uint4*>(px + (long long)(i + u * BA_SPLIT) * d);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (i + u * BA_SPLIT >= S) break;
+                if (i + u * BA_SPLIT >= S_here) break;
                 const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                if (summing) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s[2 * e] += __uint_as_float(w[e] << 16);
-                    s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+                    for (int e = 0; e < 4; ++e) {
+                        s[2 * e] += __uint_as_float(w[e] << 16);
+                        s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+                    }
                 }
                 put_masked(b * S + i + u * BA_SPLIT, w);
             }
@@ -962,7 +969,7 @@ extern "C" int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64
         const int per = 256 / ((d / 8) * BA_SPLIT);
         hipLaunchKernelGGL(bcast_add_bwd8_kernel, dim3((unsigned)((n_seq_out + per - 1) / per)), dim3(256), 0, st,
                            (const bf16_t*)dx, (bf16_t*)dg, (long long)n_seq, (long long)n_seq_out, S, d, drop_p, drop_site,
-                           seed, (bf16_t*)nullptr, 0u);
+                           seed, (bf16_t*)nullptr, 0u, 0ll);
     } else if (dtype == DSVG_BF16)
         hipLaunchKernelGGL(bcast_add_bwd_kernel<bf16_t>, dim3((unsigned)n_seq_out), dim3(256), 0, st, (const bf16_t*)dx,
                            (bf16_t*)dg, (long long)n_seq, S, d, drop_p, drop_site, seed);
@@ -972,16 +979,17 @@ extern "C" int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64
 }
 
 extern "C" int dsvg_bcast_add_bwd_masked(const void* dx, void* dg, void* dx_masked, int64_t n_seq, int64_t n_seq_out, int32_t S,
-                                         int32_t d, float drop_p, uint32_t drop_site, uint32_t mask_site, const uint64_t* seed,
-                                         void* stream) {
+                                         int32_t d, int64_t rows, float drop_p, uint32_t drop_site, uint32_t mask_site,
+                                         const uint64_t* seed, void* stream) {
     DSVG_CHECK_ARG(dx && dg && dx_masked && n_seq > 0 && n_seq_out >= n_seq && S > 0 && d > 0, "bcast_add_bwd_masked: bad args");
+    DSVG_CHECK_ARG(rows >= n_seq * S && rows <= n_seq_out * S, "bcast_add_bwd_masked: rows must lie in [n_seq * S, n_seq_out * S]");
     DSVG_CHECK_ARG(drop_p > 0.f && seed, "bcast_add_bwd_masked: needs dropout and a seed pointer (use dsvg_bcast_add_bwd otherwise)");
     DSVG_CHECK_ARG((d % 8) == 0 && d <= 512 && (((uintptr_t)dx | (uintptr_t)dg | (uintptr_t)dx_masked) & 15) == 0,
                    "bcast_add_bwd_masked: bf16 rows of d % 8 == 0 <= 512 columns, 16-byte aligned");
     const int per = 256 / ((d / 8) * BA_SPLIT);
     hipLaunchKernelGGL(bcast_add_bwd8_kernel, dim3((unsigned)((n_seq_out + per - 1) / per)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dx, (bf16_t*)dg, (long long)n_seq, (long long)n_seq_out, S, d, drop_p, drop_site, seed,
-                       (bf16_t*)dx_masked, mask_site);
+                       (bf16_t*)dx_masked, mask_site, (long long)rows);
     DSVG_LAUNCH_CHECK("bcast_add_bwd_masked");
     return 0;
 }

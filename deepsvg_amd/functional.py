@@ -823,8 +823,8 @@ class LayerFn(torch.autograd.Function):
         if z is not None:
             # (sequences past the live prefix: zero gradient rows, written by the same launch; and with dropout on, the launch
             # that reads every element of dx1 anyway also writes dx1m = drop1's mask replayed on dx1 for the attention half)
-            if (BCAST_MASKED and dx1m is None and p > 0 and dx1.dtype == torch.bfloat16 and dx1.shape[0] == n_seq * S
-                    and dx1.shape[1] % 8 == 0 and dx1.is_contiguous()):
+            if (BCAST_MASKED and dx1m is None and p > 0 and dx1.dtype == torch.bfloat16 and dx1.is_contiguous()
+                    and n_seq * S <= dx1.shape[0] <= n_seq_full * S and dx1.shape[1] % 8 == 0 and dx1.shape[1] <= 512):
                 dg, dx1m = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed, n_seq_out=n_seq_full, mask_site=s0 + 1)
             else:
                 dg = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed, n_seq_out=n_seq_full)

@@ -84,7 +84,7 @@ SIGNATURES = {
     "dsvg_masked_mean_bwd": (c_i32, [c_i32, vp, vp, vp, c_i64, vp, c_i64, c_i32, c_i32, vp]),
     "dsvg_bcast_add_fwd": (c_i32, [c_i32, vp, vp, c_i64, c_i32, c_i32, c_f32, c_u32, vp, vp]),
     "dsvg_bcast_add_bwd": (c_i32, [c_i32, vp, vp, c_i64, c_i64, c_i32, c_i32, c_f32, c_u32, vp, vp]),
-    "dsvg_bcast_add_bwd_masked": (c_i32, [vp, vp, vp, c_i64, c_i64, c_i32, c_i32, c_f32, c_u32, c_u32, vp, vp]),
+    "dsvg_bcast_add_bwd_masked": (c_i32, [vp, vp, vp, c_i64, c_i64, c_i32, c_i32, c_i64, c_f32, c_u32, c_u32, vp, vp]),
     "dsvg_loss_targets": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, vp, vp]),
     "dsvg_masked_ce_fwd": (c_i32, [c_i32, vp, c_i64, c_i32, vp, vp, c_i64, c_i32, vp, vp, vp, c_i64, vp, vp]),
     "dsvg_masked_ce_workspace_bytes": (c_i64, [c_i64]),

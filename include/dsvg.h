@@ -236,10 +236,12 @@ int dsvg_bcast_add_fwd(int32_t dtype, void* x, const void* g, int64_t n_seq, int
                        float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream);
 int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64_t n_seq, int64_t n_seq_out, int32_t S, int32_t d,
                        float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream);
-/* bf16 only: dsvg_bcast_add_bwd AND dx_masked = dsvg_drop_apply(dx, drop_p, mask_site) over the n_seq * S rows, from ONE read
- * of dx (the large decoder layers' backward needs both; d % 8 == 0, d <= 512, 16-byte aligned buffers, drop_p > 0) */
+/* bf16 only: dsvg_bcast_add_bwd AND dx_masked = dsvg_drop_apply(dx, drop_p, mask_site) over all `rows` rows of dx (n_seq * S <=
+ * rows <= n_seq_out * S: a live row prefix may be rounded up past the summed sequences), from ONE read of dx (the large decoder
+ * layers' backward needs both; d % 8 == 0, d <= 512, 16-byte aligned buffers, drop_p > 0) */
 int dsvg_bcast_add_bwd_masked(const void* dx, void* dg, void* dx_masked, int64_t n_seq, int64_t n_seq_out, int32_t S, int32_t d,
-                              float drop_p, uint32_t drop_site, uint32_t mask_site, const uint64_t* seed, void* stream);
+                              int64_t rows, float drop_p, uint32_t drop_site, uint32_t mask_site, const uint64_t* seed,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * SVGLoss (deepsvg/model/loss.py:19-65).

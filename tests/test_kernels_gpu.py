@@ -858,8 +858,9 @@ def test_bcast_add_bwd_with_the_masked_copy(gpu_device):
     the two separate launches, incl. a sequence count that does not fill the last workgroup and zero rows past the live prefix"""
     g = torch.Generator(device="cpu").manual_seed(5)
     seed = _seed_tensor(0x5151515151)
-    for n_seq, S, n_out in ((37, 31, 37), (64, 8, 80), (5, 3, 5)):
-        dx = torch.randn(n_seq * S, 256, generator=g).to(DEV).to(torch.bfloat16)
+    for n_seq, S, n_out, extra in ((37, 31, 37, 0), (64, 8, 80, 0), (5, 3, 5, 0), (37, 31, 64, 133), (3, 31, 5, 62)):
+        # (extra: rows past the summed sequences - a live row prefix rounded up - that are masked but not summed)
+        dx = torch.randn(n_seq * S + extra, 256, generator=g).to(DEV).to(torch.bfloat16)
         dg0 = ops.bcast_add_bwd(dx, n_seq, S, 0.1, 402, seed, n_seq_out=n_out)
         dm0 = ops.drop_apply(dx, 0.1, 401, seed)
         dg1, dm1 = ops.bcast_add_bwd(dx, n_seq, S, 0.1, 402, seed, n_seq_out=n_out, mask_site=401)
