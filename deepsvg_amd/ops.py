@@ -1085,7 +1085,8 @@ def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, s
     are inside packed_fwd_layer / b1f, see ffn_pack).  train: -> (y, h, xh, rstd) with h bf16 [rows, 512] in fragment
     order, xh = (x - mean) * rstd bf16, rstd fp32 [rows] (what the backward pass needs).
     stages: None = the library's choice (half-size workgroups up to 32,768 rows), 2 = half-size workgroups, 3 / 4 = the
-    256-row workgroups with that many weight-ring slots (all bit-identical; tests and probes)"""
+    256-row workgroups with that many weight-ring slots (all bit-identical; tests and probes), 5 = the experimental
+    software-pipelined chunk loop (opt-in: DSVG_FFN_STAGES=5; tests/test_kernels_gpu.py under DSVG_EXPERIMENTAL=1)"""
     _chk(x, packed_fwd_layer, b1f, b2, seed, out)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
     assert packed_fwd_layer.numel() == FFN_FWD_LAYER_ELEMS and packed_fwd_layer.is_contiguous()

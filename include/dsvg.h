@@ -453,7 +453,7 @@ int dsvg_assemble_batch(const int16_t* rows, int64_t n_rows, const int32_t* slot
  *   dsvg_ffn_fwd    x, y bf16 [rows, 256] (row stride 256); packed_fwd_layer / b1_folded = that layer's slices; b2 fp32;
  *                   dropout sites / seed as everywhere else (draw scheme "v2", private to the fused kernels);
  *                   stages: 0 = default (workgroups of 128 rows up to 32,768 rows, of 256 rows above), 2 = 128-row
- *                   workgroups, 3 / 4 = 256-row workgroups with that many weight-ring slots; all bit-identical.  Training calls pass h_out (bf16 [rows, 512], hidden columns in
+ *                   workgroups, 3 / 4 = 256-row workgroups with that many weight-ring slots; all bit-identical.  5 = EXPERIMENTAL (opt-in, not yet run on hardware): 256-row workgroups with a software-pipelined chunk loop (ffn_fwd_pipe_kernel), meant to be bit-identical too.  Training calls pass h_out (bf16 [rows, 512], hidden columns in
  *                   FRAGMENT ORDER: position p(j) = j with bits 2 and 3 swapped), xh_out = (x - mean) * rstd (bf16
  *                   [rows, 256]) and rstd_out (fp32 [rows]) for the backward pass; inference passes NULL for all three.
  * Buffers are caller-owned; all work is enqueued on `stream`. */

@@ -7,6 +7,7 @@ import torch
 
 from deepsvg_amd import ops
 from tests import torch_ops_ref as R
+from tests.conftest import experimental
 
 pytestmark = pytest.mark.gpu
 
@@ -958,6 +959,27 @@ def test_ffn_fwd_workgroup_variants_agree(gpu_device, rows):
         dflt = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 403, 404, seed, train=train)
         for a, b in zip(outs[2], dflt if train else (dflt,)):
             assert torch.equal(a, b)
+
+
+@experimental
+@pytest.mark.parametrize("rows", [100, 4096 + 37, 40000, 126976])
+def test_ffn_fwd_pipelined_variant_agrees(gpu_device, rows):
+    """stages = 5 (ffn_fwd_pipe_kernel: E1 of chunk k in the shadow of G2(k - 1)'s MFMAs, split W1 / W2 streams) performs the
+    same operations on every element in the same order as the 256-row kernel: every output is bit-identical, with and
+    without dropout, inference and training variants; the timing probe's shortened loop (>= 2 chunks) is not exercised"""
+    flat, offs, x, b2 = _ffn_setup(rows, seed=rows + 3)
+    pf, _, b1f = ops.ffn_pack(flat, offs, 2)
+    seed = _seed_tensor(0x1122334455667788)
+    for layer in (0, 1):
+        pl = pf[layer * ops.FFN_FWD_LAYER_ELEMS:(layer + 1) * ops.FFN_FWD_LAYER_ELEMS]
+        for p in (0.1, 0.0):
+            for train in (False, True):
+                want = ops.ffn_fwd(x, pl, b1f[layer], b2, 1e-5, p, 403, 404, seed, train=train, stages=4)
+                got = ops.ffn_fwd(x, pl, b1f[layer], b2, 1e-5, p, 403, 404, seed, train=train, stages=5)
+                names = ("y", "h", "xh", "rstd") if train else ("y",)
+                for name, a, b in zip(names, want if train else (want,), got if train else (got,)):
+                    assert torch.equal(a, b), (rows, layer, p, train, name,
+                                               (a.float() - b.float()).abs().max().item())
 
 
 def test_ffn_fwd_equals_unfused_kernels(gpu_device):
