@@ -469,7 +469,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_pipe_kernel(const bf16_t* __re
                                                               bf16_t* __restrict__ xh_out, float* __restrict__ rstd_out,
                                                               int M, float eps, float drop_p,
                                                               const uint64_t* __restrict__ seed, uint32_t site_h,
-                                                              uint32_t site_r, int n_chunks, unsigned long long* dbg) {
+                                                              uint32_t site_r, int n_chunks, unsigned long long* dbg,
+                                                              int flags) {
+    // flags (probes, DSVG_FFN_PIPE_FLAGS): 1 = no stage offset between the two waves of a SIMD (every wave's barrier in front
+    // of G1), 2 = s_setprio 1 for waves 4-7 (the later-dispatched half loses every issue arbitration at equal priority)
     constexpr int NBUF = 4;
     // [4 chunk slots | b1 (2 KiB) | b2 (1 KiB) | the last XL B-operand fragments of every wave's rows (8 KiB each)]
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -477,7 +480,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_pipe_kernel(const bf16_t* __re
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool late = wave >= 4;
+    const bool late = wave >= 4 && !(flags & 1);
+    if ((flags & 2) && wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int tok = lane & 31, half = lane >> 5;
     const uint32_t lds0 = (uint32_t)(uintptr_t)DSVG_LDS_PTR(smem);
     float* sb1 = reinterpret_cast<float*>(smem + NBUF * FWD_CHUNK);
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_pipe_kernel(const bf16_t* __re
     const char* my_src = reinterpret_cast<const char*>(img) + wave * 4096;
     const uint32_t lane16 = lane * 16;
     const uint32_t my_dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);
-    const int lag = late ? 1 : 0;
+    const int lag = wave >= 4 ? 1 : 0;
     auto issue = [&](int c) { dma4s(my_src + (size_t)c * FWD_CHUNK, lane16, my_dst + (uint32_t)(c % NBUF) * FWD_CHUNK); };
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -1427,13 +1431,14 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
         const size_t lds = (size_t)4 * FWD_CHUNK + 3072 + (size_t)XL * 8 * FRAG;
         const bool drop = drop_p > 0.f;
         const int pipe_chunks = dbg_chunks < 2 ? 2 : dbg_chunks;       // (the kernel's first iteration is peeled: >= 2 chunks)
+        static const int pipe_flags = getenv("DSVG_FFN_PIPE_FLAGS") ? atoi(getenv("DSVG_FFN_PIPE_FLAGS")) : 0;
 #define DSVG_FFN_FWD_PIPE(TR, DR)                                                                                     \
     do {                                                                                                              \
         DSVG_ENSURE_LDS((ffn_fwd_pipe_kernel<TR, DR, XL>), lds);                                                          \
         hipLaunchKernelGGL((ffn_fwd_pipe_kernel<TR, DR, XL>), dim3(nb), dim3(512), lds, st, (const bf16_t*)x,              \
                            (const bf16_t*)packed_fwd_layer, b1_folded, b2, (bf16_t*)y, (bf16_t*)h_out, (bf16_t*)xh_out,\
                            rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res, pipe_chunks,    \
-                           g_ffn_dbg_host);                                                                           \
+                           g_ffn_dbg_host, pipe_flags);                                                                           \
     } while (0)
         if (train && drop) DSVG_FFN_FWD_PIPE(true, true);
         else if (train) DSVG_FFN_FWD_PIPE(true, false);
