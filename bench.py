@@ -138,13 +138,24 @@ def cpu_baseline(cfg, sd, batch, dropout):
         except Exception as e:      # TimeoutExpired: not one step in the time box
             legs[str(more)] = {"value": None, "note": f"did not finish in 30 s ({type(e).__name__})"}
     v2, c2, n2, dt2 = _cpu_leg(cfg, sd, 2, t16, 4.0, dropout)
+    ref_c1 = None       # the same configuration through the reference's own train.py, measured where the reference is mounted
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_cpu_c1_reference_train.log")) as f:
+            for line in f:
+                if line.startswith("{"):
+                    ref_c1 = json.loads(line)
+                    ref_c1["source"] = ("committed: profiles/r03_cpu_c1_reference_train.log (scripts/cpu_c1_reference_train.py in "
+                                        "the build container; the port on that host and batch: 195.9 ms/step)")
+    except Exception:
+        pass
     return {"value": round(best[0], 2), "unit": "icons/s", "cores": best[1], "host_cores": ncores, "kind": "port",
             "dropout": dropout, "by_threads": legs,
             "c1_batch2": {"value": round(v2, 2), "unit": "icons/s", "cores": c2, "steps": n2,
                           "ms_per_step": round(dt2 * 1e3, 1),
-                          "note": "BASELINE configs[0] (batch 2): direct step loop of the port; the reference's own "
-                                  "deepsvg/train.py plumbing is driven by tests/test_reference_trainer.py in the build "
-                                  "container (/root/reference does not exist on the GPU box)"},
+                          "reference_train_py": ref_c1,
+                          "note": "BASELINE configs[0] (batch 2): direct step loop of the port on this host; "
+                                  "reference_train_py = the unmodified deepsvg/train.py on the build container's cores "
+                                  "(/root/reference does not exist on the GPU box)"},
             "sample": f"{best[2]} train step(s) of batch {batch} (fwd+SVGLoss+bwd+clip+AdamW, dropout {dropout}, fp32, "
                       f"oracle/svg_transformer_oracle.py = stock PyTorch CPU ops), {best[3] * 1e3:.0f} ms/step on "
                       f"{best[1]} threads"}
