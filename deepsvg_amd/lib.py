@@ -126,6 +126,7 @@ SIGNATURES = {
     "dsvg_probe_trread": (c_i32, [vp, vp, vp]),
     "dsvg_attn_pack_bytes": (c_i64, [c_i32]),
     "dsvg_attn_pack": (c_i32, [vp, vp, c_i32, c_i32, c_i32, vp, vp]),
+    "dsvg_attn_block_fwd_stages": (c_i32, [c_i32]),
     "dsvg_attn_block_fwd": (c_i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_i64, vp, vp, vp, vp, vp, vp,
                                     c_f32, c_f32, c_f32, c_u32, c_u32, vp, vp, c_u32, vp]),
     "dsvg_gs_pack_bytes": (c_i64, [c_i32]),

@@ -1220,6 +1220,12 @@ def attn_pack(flat, offs, n_layers, packed=None):
     return packed
 
 
+def attn_block_fwd_stages(stages):
+    """process-wide development switch: ring slots of attn_block_fwd's weight stream - 3 (default) or 4 (EXPERIMENTAL: DMA
+    three chunks ahead, counted waits; DSVG_ATTN_STAGES presets it; bit-identical results)"""
+    _l.check(_l.load().dsvg_attn_block_fwd_stages(int(stages)), "dsvg_attn_block_fwd_stages")
+
+
 def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_seq, S, scale, eps=1e-5, drop_p=0.0,
                    site_probs=0, site_res=0, seed=None, seq_off=None, tiles=None, train=False, seq_add=None, site_seq_add=0,
                    into=None):

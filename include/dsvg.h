@@ -519,6 +519,11 @@ int dsvg_gs_debug_clock(void* buf);
 int64_t dsvg_attn_pack_bytes(int32_t n_layers);
 int dsvg_attn_pack(const float* flat_f32, const int64_t* offs, int32_t n_layers, int32_t d_model, int32_t n_heads,
                    void* packed, void* stream);
+/* development switch: ring slots of dsvg_attn_block_fwd's weight stream, process-wide - 3 (default: every ring
+ * synchronisation drains the wave's memory operations) or 4 (EXPERIMENTAL, not yet run on hardware: DMA three chunks ahead,
+ * counted waits, the training stores stay in flight across the synchronisations; results are meant to be bit-identical).
+ * The environment variable DSVG_ATTN_STAGES presets it. */
+int dsvg_attn_block_fwd_stages(int32_t stages);
 int dsvg_attn_block_fwd(const void* x, const void* packed_layer, const float* in_bias, const float* out_bias,
                         const float* gamma, const float* beta, const uint64_t* key_mask, const int32_t* seq_off,
                         const int32_t* tile_first, int64_t n_seq, int32_t S, int64_t rows, void* x1, void* xn_out,

@@ -1294,6 +1294,42 @@ def test_attn_block_fwd_against_fp32_torch(gpu_device, kind, p):
         assert err <= mean_tol * ref + 1e-12, f"{what}: mean abs error {err:.3e} = {err / ref:.2e} of the mean magnitude"
 
 
+@experimental
+@pytest.mark.parametrize("kind", ["packed", "dense31", "dense32_masked", "dense8_masked_tail", "dense10", "tiny_dense5",
+                                  "one_sequence_32", "packed_extremes"])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attn_block_fwd_four_slot_variant_agrees(gpu_device, kind, p):
+    """dsvg_attn_block_fwd_stages(4): 4 ring slots, DMA three chunks ahead, counted waits (the training stores stay in
+    flight across the ring synchronisations), the out_proj rows stored behind both tiles' arithmetic - the same operations
+    on every element: every output bit-identical to the 3-slot kernel, inference and training, with the per-sequence add"""
+    flat, offs, prm = _attn_setup(seed=13)
+    rows, n_seq, S, km, seq_off, tiles, real = _attn_case(kind, seed=23)
+    x = (_rand(rows, 256, seed=33) * 1.5 + 0.3).to(torch.bfloat16)
+    img = ops.attn_pack(flat, offs, 2)
+    seed = _seed_tensor(0x0BADC0FFEE12345B)
+    scale = 32 ** -0.5
+    gadd = None if seq_off is not None else (_rand(n_seq, 256, seed=43) * 0.5).to(torch.bfloat16)
+    try:
+        for layer in (0, 1):
+            packed = img[layer * ops.ATTN_LAYER_ELEMS:(layer + 1) * ops.ATTN_LAYER_ELEMS]
+            for sa in ((None,) if gadd is None else (None, gadd)):
+                for train in (False, True):
+                    outs = {}
+                    for stages in (3, 4):
+                        ops.attn_block_fwd_stages(stages)
+                        r = ops.attn_block_fwd(x, packed, prm["in_bias"], prm["out_bias"], prm["gamma"], prm["beta"], km, n_seq,
+                                               S, scale, 1e-5, p, 7, 8, seed, seq_off=seq_off, tiles=tiles, train=train,
+                                               seq_add=sa, site_seq_add=9)
+                        torch.cuda.synchronize()
+                        outs[stages] = r if train else (r,)
+                    for i, (a, b) in enumerate(zip(outs[3], outs[4])):
+                        a, b = a[:real], b[:real]       # (the rows of the sequences; bucket padding behind them is not compared)
+                        assert torch.equal(a, b), (kind, p, layer, train, sa is not None, i,
+                                                   (a.float() - b.float()).abs().max().item())
+    finally:
+        ops.attn_block_fwd_stages(3)
+
+
 @pytest.mark.parametrize("kind", ["packed", "dense31", "dense32_masked", "dense8_masked_tail", "dense10", "tiny_dense5",
                                   "one_sequence_32", "packed_extremes"])
 @pytest.mark.parametrize("p", [0.0, 0.1])
