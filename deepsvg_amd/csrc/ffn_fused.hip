@@ -1284,6 +1284,302 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// backward of the sub-block's input path in ONE launch (EXPERIMENTAL, opt-in DSVG_FFN_BWD_ONE=1; written at the end of round 3
+// without a GPU at hand, first to be run in round 4):
+//     dym = drop_r-mask(dy);   dpre = (dym . W2) gated by the stored h (h > 0 <=> the unit passed the ReLU and was kept);
+//     dx  = dy + LayerNorm'( dpre . W1' )
+// - the mirror image of ffn_fwd_kernel (GEMM 1 over the 256 outputs with the W2^T chunk, a VALU stage on the 32 x 32 hidden
+// tile, GEMM 2 with the W1'^T chunk into 8 accumulators) with ffn_bwd_dx_kernel's epilogue.  It replaces three launches of
+// the default backward - dsvg_drop_apply (dym), the gated input-gradient GEMM (dpre) and dsvg_ffn_bwd_dx - which move 390 MB
+// per 63 k-row layer between them (dy twice, dym and dpre written and read back); this kernel moves 260 MB (dy, h, x in;
+// dym, dpre, dx out: the weight-gradient GEMMs still want dym and dpre in memory) and keeps the hidden tile on the chip.
+//   * weights: the last 32 KiB of every 48 KiB backward chunk [W2^T chunk | W1'^T chunk] through a 4-slot ring, DMA three
+//     chunks ahead, as in ffn_fwd_kernel; source = SGPR base + lane offset (dma4s).
+//   * the gate: a lane needs its 2 x 16 bytes of h per chunk (the pieces the forward kernel stored, fragment order) one
+//     VALU stage after GEMM 1.  They come by LDS-DMA too - two 1 KiB pieces per wave and chunk into a private two-slot
+//     staging area, two chunks ahead (a chunk is ~1.3-2.3 us of work per wave, an HBM load ~2 us) - so that EVERY load of
+//     the loop is issued from inline asm and every wait is a counted s_waitcnt of ours: a compiler-visible load in this
+//     loop would be waited for with a count that knows nothing of the DMA pieces around it, i.e. it would drain the
+//     weight stream every iteration.  Wait values: scripts/checks/ffn_bwd_one_protocol.py derives and checks them
+//     (sync(c): vmcnt(8), gate(c): vmcnt(10), stricter at both ends).  LDS: 128 KiB ring + 8 x 2 x 2 KiB = all 160 KiB.
+//   * dpre (bf16, fragment order - the B operand of GEMM 2 as it is) is stored like the forward kernel's h: held in 8
+//     registers and issued right behind the next ring synchronisation.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void ffn_bwd_one_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ h,
+                                                             const bf16_t* __restrict__ x, const bf16_t* __restrict__ img,
+                                                             bf16_t* __restrict__ dym_out, bf16_t* __restrict__ dpre_out,
+                                                             bf16_t* __restrict__ dx, bf16_t* __restrict__ dxm, int M,
+                                                             float eps, float gate_scale, float drop_p,
+                                                             const uint64_t* __restrict__ seed, uint32_t site_r,
+                                                             uint32_t site_m) {
+    constexpr int NBUF = 4;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [4 x 32 KiB ring | 8 waves x 2 slots x 2 KiB of h]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = wave >= 4;
+    const int tok = lane & 31, half = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)DSVG_LDS_PTR(smem);
+
+    // ---- weight stream: pieces 4 wave .. 4 wave + 3 of [W2^T chunk | W1'^T chunk] = bytes 16 KiB .. 48 KiB of a backward chunk
+    const char* w_src = reinterpret_cast<const char*>(img) + 16 * FRAG + wave * 4096;
+    const uint32_t lane16 = lane * 16;
+    const uint32_t w_dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);
+    auto issue_w = [&](int c) { dma4s(w_src + (size_t)c * BWD_CHUNK, lane16, w_dst + (uint32_t)(c % NBUF) * FWD_CHUNK); };
+    issue_w(0);
+    issue_w(1);
+    issue_w(2);
+
+    const int wg_row0 = blockIdx.x * TOK_PER_WG;
+    const int row0 = wg_row0 + wave * 32;
+    const int m = row0 + tok;
+    const bool live = m < M;
+    const int my_row = min(m, M - 1);
+    const DropCtx dr_ctx = drop_make(drop_p, seed, site_r);
+
+    // ---- dym fragments: dy with the residual dropout replayed (ids m * 256 + column, standard draws), as ffn_bwd_hidden_kernel
+    bf16x8 df[16];
+    {
+        const char* dr = reinterpret_cast<const char*>(dy) + (size_t)my_row * (FD * 2) + half * 16;
+        char* dm_o = reinterpret_cast<char*>(dym_out) + (size_t)my_row * (FD * 2) + half * 16;
+        uint4 raw[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) raw[ks] = *reinterpret_cast<const uint4*>(dr + 32 * ks);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            Frag8 f;
+            if (DROP) {
+                float v[8], mm[8];
+                unpack8(raw[ks], v);
+                drop_mult8(dr_ctx, (uint64_t)m * FD + 16 * ks + 8 * half, mm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= mm[e];
+                f.u = pack8(v);
+                if (live) *reinterpret_cast<uint4*>(dm_o + 32 * ks) = f.u;
+            } else {
+                // no dropout: dym == dy (the caller hands dy itself to the weight-gradient GEMM).  The empty asm "uses" the
+                // loaded registers HERE, so the compiler's wait for the rows sits in front of the DMA issues below and not
+                // in front of the first MFMAs (as s_waitcnt vmcnt(0): a drain of the weight and gate streams)
+                asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
+                f.u = raw[ks];
+            }
+            df[ks] = f.v;
+        }
+    }
+    // (every wave has read its dy rows by now: loads return in order, so its pieces of W(0 .. 2) have landed as well)
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- gate stream: the lane's two 16-byte pieces of h per chunk -> the wave's staging slot c & 1 -------------------------
+    // source = workgroup-uniform base (+ 64 c bytes) + 32-bit lane offset (rows past M read a clamped copy)
+    const char* h_src = reinterpret_cast<const char*>(h) + (size_t)wg_row0 * (FF * 2);
+    const uint32_t h_off = (uint32_t)(my_row - wg_row0) * (FF * 2) + half * 16;
+    const uint32_t h_dst = __builtin_amdgcn_readfirstlane(lds0 + NBUF * FWD_CHUNK + wave * 4096);
+    auto issue_h = [&](int c) { dma2_pair32(h_src + (size_t)(CH * c) * 2, h_off, h_dst + (uint32_t)(c & 1) * 2048); };
+    issue_h(0);
+    issue_h(1);
+    const char* hst = smem + NBUF * FWD_CHUNK + wave * 4096 + lane * 16;
+
+    floatx16 yacc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[t][r] = 0.f;
+    floatx16 hid;
+    bf16x8 hf[2];
+    uint4 ring[4];
+
+    const char* lbase = smem + lane * 16;
+    auto slot_of = [&](int c) -> const char* { return lbase + (c % NBUF) * FWD_CHUNK; };
+    auto ld = [&](const char* p) -> uint4 { return *reinterpret_cast<const uint4*>(p); };
+
+    // dpre rows: workgroup-uniform base + 32-bit lane offset (rows past M are never stored)
+    char* pbase = reinterpret_cast<char*>(dpre_out) + (size_t)wg_row0 * (FF * 2);
+    const uint32_t poff = (uint32_t)((wave * 32 + tok) * (FF * 2) + half * 16);
+    uint4 stash[2];
+    int stash_c = -1;
+    auto flush = [&]() {
+        if (stash_c >= 0) {
+            if (live) {
+                const uint32_t o = poff + (uint32_t)(CH * stash_c) * 2u;
+                *reinterpret_cast<uint4*>(pbase + o) = stash[0];
+                *reinterpret_cast<uint4*>(pbase + o + 32u) = stash[1];
+            }
+            stash_c = -1;
+        }
+    };
+    // sync(c): afterwards chunks <= c + 1 are readable, chunk c + 3 is on its way into the slot chunk c - 1 has left
+    auto sync = [&](int c) {
+        if (c + 2 < NCH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c + 3 < NCH) issue_w(c + 3);
+        flush();
+    };
+    auto g2frag = [](int p) -> int { return 2 * (p & 7) + (p >> 3); };
+    // G1: dh[unit][token] = sum_o W2[o][32 c + unit] dym[token][o]  (A = fragments 0 .. 15 of the slot); the ring runs on into G2
+    auto G1 = [&](const char* sc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hid[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            Frag8 a;
+            a.u = ring[ks & 3];
+            hid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, df[ks], hid, 0, 0, 0);
+            if (ks + 4 < 16) ring[ks & 3] = ld(sc + (ks + 4) * FRAG);
+            else ring[ks & 3] = ld(sc + (16 + g2frag(ks + 4 - 16)) * FRAG);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // E1: the gate.  Accumulator register 4 q + e holds unit 8 q + 4 half + e of the chunk = element 4 (q & 1) + e of the
+    // lane's piece q >> 1 of h (the layout ffn_fwd_kernel's E1 packed and stored); dpre = dh * gate_scale where h > 0
+    auto E1 = [&](int c) {
+        if (c < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (c + 3 < NCH) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const char* hs = hst + (c & 1) * 2048;
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            float g[8], v[8];
+            unpack8(ld(hs + ks2 * 1024), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = g[e] > 0.f ? hid[8 * ks2 + e] * gate_scale : 0.f;
+            Frag8 f;
+            f.u = pack8(v);
+            hf[ks2] = f.v;
+            stash[ks2] = f.u;
+        }
+        stash_c = c;
+        // the staging slot is free again (its two reads have returned: their values were just used): chunk c + 2 goes there
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (c + 2 < NCH) issue_h(c + 2);
+    };
+    // G2: dxh[d][token] += sum_unit W1'[32 c + unit][d] dpre[token][unit]  (A = fragments 16 .. 31 of the slot)
+    auto G2 = [&](const char* sc, const char* sn) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            Frag8 a;
+            a.u = ring[n & 3];
+            yacc[n & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, hf[n >> 3], yacc[n & 7], 0, 0, 0);
+            if (n + 4 < 16) ring[n & 3] = ld(sc + (16 + g2frag(n + 4)) * FRAG);
+            else if (sn) ring[n & 3] = ld(sn + (n + 4 - 16) * FRAG);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // W(0 .. 2) have landed (see above); the barrier makes every wave's pieces visible.  (The h pieces and the dym stores
+    // stay in flight.)
+    __builtin_amdgcn_s_barrier();
+    {
+        const char* s0 = slot_of(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ring[i] = ld(s0 + i * FRAG);
+    }
+    for (int c = 0; c < NCH; ++c) {
+        const char* sc = slot_of(c);
+        const char* sn = (c + 1 < NCH) ? slot_of(c + 1) : nullptr;
+        if (!late) sync(c);
+        G1(sc);
+        E1(c);
+        if (late) sync(c);
+        G2(sc, sn);
+    }
+    flush();
+
+    // ---- epilogue: LayerNorm backward on the rows in registers (ffn_bwd_dx_kernel's) ----------------------------------------
+    const char* xrow = reinterpret_cast<const char*>(x) + (size_t)my_row * (FD * 2);
+    uint4 xr[16];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        xr[2 * t] = *reinterpret_cast<const uint4*>(xrow + (32 * t + 16 * half) * 2);
+        xr[2 * t + 1] = *reinterpret_cast<const uint4*>(xrow + (32 * t + 16 * half + 8) * 2);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        uint32_t xc[4][4];
+        tile_to_cols16(yacc[t], xc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yacc[t][4 * q + e] = __uint_as_float(xc[q][e]);      // column 4 q + e of the 16
+    }
+    float s, q, mean, rstd;
+    ln_stats_packed(xr, s, q);
+    ln_mean_rstd256(s, q, eps, mean, rstd);
+    const float shift = -mean * rstd;       // xh = x * rstd + shift
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            float v[8];
+            unpack8(xr[2 * t + cb], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float g = yacc[t][8 * cb + e];
+                c1 += g;
+                c2 += g * fmaf(v[e], rstd, shift);
+            }
+        }
+    c1 += __shfl_xor(c1, 32, 64);
+    c2 += __shfl_xor(c2, 32, 64);
+    c1 *= (1.f / FD);
+    c2 *= (1.f / FD);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(xr[i].x), "+v"(xr[i].y), "+v"(xr[i].z), "+v"(xr[i].w));
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            float v[8];
+            unpack8(xr[2 * t + cb], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) yacc[t][8 * cb + e] = rstd * (yacc[t][8 * cb + e] - c1 - fmaf(v[e], rstd, shift) * c2);
+        }
+    uint32_t zoff = 0;
+    asm volatile("" : "+v"(zoff) : "v"(yacc[7][15]), "v"(yacc[0][0]));
+    const char* dyrow = reinterpret_cast<const char*>(dy) + (size_t)my_row * (FD * 2) + zoff;
+    char* orow = reinterpret_cast<char*>(dx) + (size_t)my_row * (FD * 2);
+    char* mrow = dxm ? reinterpret_cast<char*>(dxm) + (size_t)my_row * (FD * 2) : nullptr;
+    uint4 dr[16];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        dr[2 * t] = *reinterpret_cast<const uint4*>(dyrow + (32 * t + 16 * half) * 2);
+        dr[2 * t + 1] = *reinterpret_cast<const uint4*>(dyrow + (32 * t + 16 * half + 8) * 2);
+    }
+    if (m < M) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                float v[8];
+                unpack8(dr[2 * t + cb], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += yacc[t][8 * cb + e];
+                *reinterpret_cast<uint4*>(orow + (32 * t + 16 * half + 8 * cb) * 2) = pack8(v);
+            }
+    }
+    if (mrow && m < M) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t zo2 = 0;
+        asm volatile("" : "+v"(zo2));
+        const char* back = orow + zo2;
+        const DropCtx dcm = drop_make(drop_p, seed, site_m);
+#pragma unroll 2
+        for (int i = 0; i < 16; ++i) {
+            const int col = 32 * (i >> 1) + 16 * half + 8 * (i & 1);
+            const uint4 pk = *reinterpret_cast<const uint4*>(back + col * 2);
+            float w[8], mm[8];
+            unpack8(pk, w);
+            drop_mult8(dcm, (uint64_t)m * FD + col, mm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] *= mm[e];
+            *reinterpret_cast<uint4*>(mrow + col * 2) = pack8(w);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // weight gradients, last step.  The two split-K GEMMs deliver G1p = dpre^T xh [512 (fragment order), 256], its row sums
 // db1p [512 (fragment order)] and G2p = dym^T h [256, 512 (fragment order)]; this kernel undoes the fragment order
 // (position p(j): bits 2 and 3 of j swapped) and the LayerNorm fold (see ffn_pack_kernel):
@@ -1502,6 +1798,36 @@ extern "C" int dsvg_ffn_bwd_dx(const void* dpre, const void* x, const void* dy, 
                        (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps,
                        (bf16_t*)dx_masked, drop_p, (const uint64_t*)seed, drop_site);
     DSVG_LAUNCH_CHECK("ffn_bwd_dx");
+    return 0;
+}
+
+extern "C" int dsvg_ffn_bwd_one(const void* dy, const void* h, const void* x, const void* packed_bwd_layer, void* dym,
+                                void* dpre, void* dx, void* dx_masked, int64_t rows, float eps, float gate_scale,
+                                float drop_p, uint32_t site_res, uint32_t site_masked, const void* seed, void* stream) {
+    DSVG_CHECK_ARG(dy && h && x && packed_bwd_layer && dpre && dx, "ffn_bwd_one: null pointer");
+    DSVG_CHECK_ARG(rows > 0 && rows < (1ll << 31) - TOK_PER_WG, "ffn_bwd_one: bad row count");
+    DSVG_CHECK_ARG(!(drop_p > 0.f) || (seed && dym), "ffn_bwd_one: dropout needs a seed and the dym buffer");
+    DSVG_CHECK_ARG(!dx_masked || (drop_p > 0.f && seed), "ffn_bwd_one: the masked output needs dropout and a seed");
+    DSVG_CHECK_ARG((((uintptr_t)dy | (uintptr_t)h | (uintptr_t)x | (uintptr_t)packed_bwd_layer | (uintptr_t)dym |
+                     (uintptr_t)dpre | (uintptr_t)dx | (uintptr_t)dx_masked) & 15) == 0,
+                   "ffn_bwd_one: operands must be 16-byte aligned");
+    const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
+    const size_t lds = (size_t)4 * FWD_CHUNK + 8 * 4096;         // the whole 160 KiB: 4-slot weight ring + the gate staging
+    hipStream_t st = (hipStream_t)stream;
+    if (drop_p > 0.f) {
+        DSVG_ENSURE_LDS(ffn_bwd_one_kernel<true>, lds);
+        hipLaunchKernelGGL(ffn_bwd_one_kernel<true>, dim3(nb), dim3(512), lds, st, (const bf16_t*)dy, (const bf16_t*)h,
+                           (const bf16_t*)x, (const bf16_t*)packed_bwd_layer, (bf16_t*)dym, (bf16_t*)dpre, (bf16_t*)dx,
+                           (bf16_t*)dx_masked, (int)rows, eps, gate_scale, drop_p, (const uint64_t*)seed, site_res,
+                           site_masked);
+    } else {
+        DSVG_ENSURE_LDS(ffn_bwd_one_kernel<false>, lds);
+        hipLaunchKernelGGL(ffn_bwd_one_kernel<false>, dim3(nb), dim3(512), lds, st, (const bf16_t*)dy, (const bf16_t*)h,
+                           (const bf16_t*)x, (const bf16_t*)packed_bwd_layer, (bf16_t*)dym, (bf16_t*)dpre, (bf16_t*)dx,
+                           (bf16_t*)nullptr, (int)rows, eps, gate_scale, 0.f, (const uint64_t*)nullptr, site_res,
+                           site_masked);
+    }
+    DSVG_LAUNCH_CHECK("ffn_bwd_one");
     return 0;
 }
 

@@ -107,6 +107,23 @@ __device__ __forceinline__ void dma4s(const void* sbase, uint32_t voff, uint32_t
         : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
 
+// two 1 KiB pieces whose sources are 32 bytes apart per lane (the two K steps of a lane's 64-byte run): source = wave-uniform
+// base + 32-bit per-lane offset, destination lds and lds + 1024 (the instruction offset advances both addresses, so M0 makes
+// up for it on the LDS side)
+__device__ __forceinline__ void dma2_pair32(const void* sbase, uint32_t voff, uint32_t lds) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_add_u32 m0, m0, 0x3e0\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:32\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory", "scc");
+}
+
 // One transposed 32 x 32 accumulator tile (lane: token row lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the
 // tile) -> the lane's 16 consecutive tile columns 16 (lane >> 5) .. + 15 as x[q][e] = column 4 q + e.
 __device__ __forceinline__ void tile_to_cols16(const floatx16& c, uint32_t (&x)[4][4]) {

@@ -34,6 +34,9 @@ FFN_BWD_ORDER = os.environ.get("DSVG_FFN_BWD_ORDER", "1") != "0"
 # dx and its dropout-masked copy from one ffn_bwd_dx launch instead of a drop_apply launch: measured SLOWER (8.52 vs 8.43
 # ms/step: the extra pass sits on the tail of a one-workgroup-per-CU kernel), so it is opt-in
 FFN_BWD_MASKED = os.environ.get("DSVG_FFN_BWD_MASKED", "0") != "0"
+# EXPERIMENTAL (written without a GPU at the end of round 3, first to be run in round 4): drop_apply + gated GEMM + ffn_bwd_dx of
+# the fused-FFN backward as ONE launch (csrc/ffn_fused.hip ffn_bwd_one_kernel): 260 instead of 390 MB per 63 k-row layer
+FFN_BWD_ONE = os.environ.get("DSVG_FFN_BWD_ONE", "0") != "0"
 
 
 # the weight-gradient GEMMs of a layer of the 4096-row stages as one grouped launch (DSVG_GROUP_WGRAD=0: one by one)
@@ -769,24 +772,38 @@ class LayerFn(torch.autograd.Function):
                     # behind the launch that produced its token-major operand (dym, dpre: 65 / 130 MB that are then still
                     # partly in the memory-side cache) instead of at the end
                     hp, xh = h, xn2
-                    dym = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
-                    if late:
-                        rt.side.push(lambda a=dym, b=hp: wgrad2(a, b))
-                    elif FFN_BWD_ORDER:
-                        wgrad2(dym, hp)
-                    dpre = ops.gemm(dym, w2p, b_kc=False, gate=hp, gate_scale=inv_keep)
-                    if late:
-                        rt.side.push(lambda a=dpre, b=xh: wgrad1(a, b))
-                    elif FFN_BWD_ORDER:
-                        wgrad1(dpre, xh)
-                    # (the same launch also hands over dx1 with the attention residual's dropout mask replayed on it)
-                    if FFN_BWD_MASKED:
-                        dx1, dx1m = ops.ffn_bwd_dx(dpre, x1, dx2, pb, masked=(p, s0 + 1, rt.seed))
+                    if FFN_BWD_ONE:
+                        # EXPERIMENTAL (opt-in): dym, dpre and dx1 from ONE launch (the hidden tile stays on the chip); the two
+                        # weight-gradient GEMMs follow behind it
+                        r = ops.ffn_bwd_one(dx2, hp, x1, pb, inv_keep, 1e-5, p, s0 + 4, rt.seed,
+                                            masked_site=(s0 + 1) if (FFN_BWD_MASKED and p > 0) else None)
+                        dx1, dpre, dym = r[0], r[1], r[2]
+                        if len(r) > 3:
+                            dx1m = r[3]
+                        for fn in ((lambda a=dym, b=hp: wgrad2(a, b)), (lambda a=dpre, b=xh: wgrad1(a, b))):
+                            if late:
+                                rt.side.push(fn)
+                            else:
+                                fn()
                     else:
-                        dx1 = ops.ffn_bwd_dx(dpre, x1, dx2, pb)
-                    if not FFN_BWD_ORDER and not late:
-                        wgrad2(dym, hp)
-                        wgrad1(dpre, xh)
+                        dym = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
+                        if late:
+                            rt.side.push(lambda a=dym, b=hp: wgrad2(a, b))
+                        elif FFN_BWD_ORDER:
+                            wgrad2(dym, hp)
+                        dpre = ops.gemm(dym, w2p, b_kc=False, gate=hp, gate_scale=inv_keep)
+                        if late:
+                            rt.side.push(lambda a=dpre, b=xh: wgrad1(a, b))
+                        elif FFN_BWD_ORDER:
+                            wgrad1(dpre, xh)
+                        # (the same launch also hands over dx1 with the attention residual's dropout mask replayed on it)
+                        if FFN_BWD_MASKED:
+                            dx1, dx1m = ops.ffn_bwd_dx(dpre, x1, dx2, pb, masked=(p, s0 + 1, rt.seed))
+                        else:
+                            dx1 = ops.ffn_bwd_dx(dpre, x1, dx2, pb)
+                        if not FFN_BWD_ORDER and not late:
+                            wgrad2(dym, hp)
+                            wgrad1(dpre, xh)
                 dw1, db1, dw2 = rt.grad_out(w1), rt.grad_out(b1), rt.grad_out(w2)
                 dn2w, dn2b = rt.grad_out(n2w), rt.grad_out(n2b)
                 # (aliases of the gradient tensors: AccumulateGrad adopts a returned gradient only while nobody else

@@ -483,6 +483,15 @@ int dsvg_ffn_bwd(const void* x, const void* dy, const void* packed_bwd_layer, co
 int dsvg_ffn_bwd_dx(const void* dpre, const void* x, const void* dy, const void* packed_bwd_layer, void* dx,
                     int64_t rows, float eps, void* dx_masked, float drop_p, uint32_t drop_site, const void* seed,
                     void* stream);
+/* EXPERIMENTAL (opt-in, written without a GPU at the end of round 3): dsvg_drop_apply + the gated input-gradient GEMM +
+ * dsvg_ffn_bwd_dx of the default backward as ONE launch.  dy = dL/dy bf16 [rows,256]; h = the forward kernel's h_out (bf16
+ * [rows,512], fragment order); x = the sub-block's input rows; gate_scale = 1 / keep probability as the forward pass applied
+ * it (dsvg_keep_scale); outputs: dym = dy with the residual site's dropout mask replayed (NULL without dropout: dym is dy),
+ * dpre (bf16 [rows,512], fragment order), dx = dy + LayerNorm'(dpre . W1'), dx_masked (optional) = dx with the mask of
+ * site_masked replayed.  The weight-gradient GEMMs (dW2 from dym and h, dW1' from dpre and xh) follow as before. */
+int dsvg_ffn_bwd_one(const void* dy, const void* h, const void* x, const void* packed_bwd_layer, void* dym, void* dpre,
+                     void* dx, void* dx_masked, int64_t rows, float eps, float gate_scale, float drop_p, uint32_t site_res,
+                     uint32_t site_masked, const void* seed, void* stream);
 int dsvg_ffn_wgrad_finish(const float* g1p, const float* db1p, const float* g2p, const float* w1, const float* gamma,
                           const float* beta, float* dw1, float* db1, float* dw2, float* dgamma, float* dbeta,
                           void* stream);

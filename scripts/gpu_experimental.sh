@@ -1,6 +1,7 @@
 #!/bin/bash
 # First contact of the kernels written without a GPU at the end of round 3 (opt-in in the library, tests skipped by default):
-#   1. their gated tests (DSVG_EXPERIMENTAL=1: ffn_fwd stages = 5, attn_block_fwd with 4 ring slots), each under its own
+#   1. their gated tests (DSVG_EXPERIMENTAL=1: ffn_fwd stages = 5, attn_block_fwd with 4 ring slots,
+#      ffn_bwd_one), each under its own
 #      timeout - a kernel that hangs must not take the box along;
 #   2. bit-equality + launch times of the ffn_fwd variants, the phase probe of the pipelined one;
 #   3. if (1) passed: the train step with the variant switched on against the default, same box (scripts/ab.sh).
@@ -16,6 +17,11 @@ echo "experimental tests (ffn_fwd stages 5) rc=$rc"; tail -n 30 gpurun_out/exper
     > gpurun_out/experimental_tests_attn.log 2>&1
 rca=$?
 echo "experimental tests (attn_block_fwd 4 slots) rc=$rca"; tail -n 30 gpurun_out/experimental_tests_attn.log | cut -c1-300
+( time DSVG_EXPERIMENTAL=1 timeout 300 python -m pytest tests -q -p no:cacheprovider --timeout 120 -m gpu -k "one_launch" ) \
+    > gpurun_out/experimental_tests_bwd_one.log 2>&1
+rcb=$?
+echo "experimental tests (ffn_bwd_one) rc=$rcb"; tail -n 30 gpurun_out/experimental_tests_bwd_one.log | cut -c1-300
+timeout 300 python scripts/ffn_bwd_one_probe.py 2>&1 | tee gpurun_out/experimental_ffn_bwd_one.log | cut -c1-300
 for st in 3 4; do
   echo "--- attn_block_fwd, DSVG_ATTN_STAGES=$st"
   DSVG_ATTN_STAGES=$st timeout 300 python scripts/attn_bench.py 2>&1 | tee -a gpurun_out/experimental_attn_bench.log | cut -c1-300
@@ -33,7 +39,8 @@ done
 cfgs=("DSVG_FFN_STAGES=0")
 [ $rc -eq 0 ] && cfgs+=("DSVG_FFN_STAGES=5" "DSVG_FFN_STAGES=5 DSVG_FFN_PIPE_FLAGS=2")
 [ $rca -eq 0 ] && cfgs+=("DSVG_ATTN_STAGES=4")
-[ $rc -eq 0 ] && [ $rca -eq 0 ] && cfgs+=("DSVG_FFN_STAGES=5 DSVG_ATTN_STAGES=4")
+[ $rcb -eq 0 ] && cfgs+=("DSVG_FFN_BWD_ONE=1")
+[ $rc -eq 0 ] && [ $rca -eq 0 ] && [ $rcb -eq 0 ] && cfgs+=("DSVG_FFN_STAGES=5 DSVG_ATTN_STAGES=4 DSVG_FFN_BWD_ONE=1")
 if [ ${#cfgs[@]} -gt 1 ]; then
   bash scripts/ab.sh "${cfgs[@]}" 2>&1 | tee gpurun_out/experimental_ab.log
 fi

@@ -1138,6 +1138,45 @@ def test_ffn_training_path_matches_reference(gpu_device, drop_p):
     _close(dx_f, dx, 2e-2, "fused vs training-path dx")
 
 
+@experimental
+@pytest.mark.parametrize("rows", [100, 2000, 4096 + 37, 40000])
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_ffn_bwd_one_launch_matches_the_three_launch_path(gpu_device, rows, drop_p):
+    """dsvg_ffn_bwd_one (dym, gated dpre and dx from one launch, the hidden tile on chip) against the default backward's three
+    launches on the same inputs - drop_apply -> gated GEMM on W2p -> ffn_bwd_dx: dym bit for bit (the same draws on the same
+    values), dpre and dx up to the summation order of the two products, the gate's zero pattern exactly; and the optional
+    masked copy of dx against drop_apply of the first output"""
+    flat, offs, x, b2 = _ffn_setup(rows, seed=rows + 5)
+    w2p = torch.empty((2, 256, 512), dtype=torch.bfloat16, device=DEV)
+    pf, pb, b1f = ops.ffn_pack(flat, offs, 2, w2p=w2p)
+    g = torch.Generator(device="cpu").manual_seed(rows)
+    dy = torch.randn(rows, 256, generator=g).to(DEV).to(torch.bfloat16)
+    seed = _seed_tensor(0x0123456789ABCDE1)
+    inv_keep = ops.keep_scale(drop_p)
+    for layer in (0, 1):
+        pl = pf[layer * ops.FFN_FWD_LAYER_ELEMS:(layer + 1) * ops.FFN_FWD_LAYER_ELEMS]
+        pbl = pb[layer * ops.FFN_BWD_LAYER_ELEMS:(layer + 1) * ops.FFN_BWD_LAYER_ELEMS]
+        y, h, xh, rstd = ops.ffn_fwd(x, pl, b1f[layer], b2, 1e-5, drop_p, 403, 404, seed, train=True)
+        dym0 = ops.drop_apply(dy, drop_p, 404, seed)
+        dpre0 = ops.gemm(dym0, w2p[layer], b_kc=False, gate=h, gate_scale=inv_keep)
+        dx0 = ops.ffn_bwd_dx(dpre0, x, dy, pbl)
+        dx, dpre, dym = ops.ffn_bwd_one(dy, h, x, pbl, inv_keep, 1e-5, drop_p, 404, seed)
+        torch.cuda.synchronize()
+        if drop_p > 0:
+            assert torch.equal(dym, dym0), (rows, layer)
+        else:
+            assert dym is dy
+        assert torch.isfinite(dpre.float()).all() and torch.isfinite(dx.float()).all()
+        assert torch.equal(dpre == 0, dpre0 == 0) or ((dpre == 0) != (dpre0 == 0)).float().mean().item() < 1e-4
+        assert torch.count_nonzero(dpre[h <= 0]) == 0                    # a closed gate passes nothing
+        _close(dpre, dpre0, 1.5e-2, f"dpre (rows {rows}, layer {layer})")
+        _close(dx, dx0, 2e-2, f"dx (rows {rows}, layer {layer})")
+        if drop_p > 0:
+            dx_b, dpre_b, dym_b, dxm = ops.ffn_bwd_one(dy, h, x, pbl, inv_keep, 1e-5, drop_p, 404, seed, masked_site=77)
+            assert torch.equal(dx_b, dx) and torch.equal(dpre_b, dpre) and torch.equal(dym_b, dym)
+            assert torch.equal(dxm, ops.drop_apply(dx, drop_p, 77, seed))
+
+
 # ----------------------------------------------------------------------------------------------------
 # fused attention sub-block (csrc/attn_fused.hip)
 # ----------------------------------------------------------------------------------------------------

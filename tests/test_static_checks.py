@@ -39,6 +39,13 @@ def test_attn_four_slot_counted_waits_cover_the_next_chunk():
     assert m.check() > 0
 
 
+def test_ffn_bwd_one_counted_waits_cover_their_loads():
+    m = _load(os.path.join(ROOT, "scripts", "checks", "ffn_bwd_one_protocol.py"))
+    assert m.check() == 0
+    m.gate_wait = lambda c: 12
+    assert m.check() > 0
+
+
 def test_ffn_pipe_sliced_e1_equals_the_original():
     m = _load(os.path.join(ROOT, "scripts", "checks", "ffn_pipe_e1_equiv.py"))
     with pytest.raises(SystemExit) as e:
