@@ -1301,11 +1301,13 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
 //     the loop is issued from inline asm and every wait is a counted s_waitcnt of ours: a compiler-visible load in this
 //     loop would be waited for with a count that knows nothing of the DMA pieces around it, i.e. it would drain the
 //     weight stream every iteration.  Wait values: scripts/checks/ffn_bwd_one_protocol.py derives and checks them
-//     (sync(c): vmcnt(8), gate(c): vmcnt(10), stricter at both ends).  LDS: 128 KiB ring + 8 x 2 x 2 KiB = all 160 KiB.
+//     (sync(c): vmcnt(8), gate(c): vmcnt(10), stricter at both ends).  LDS: 128 KiB ring + 8 x 2 x 2 KiB = all 160 KiB;
+//     DSVG_FFN_BWD_ONE_SLOTS=3 selects a 3-slot ring (128 KiB in all, the weight DMA two chunks ahead: the two gate pieces
+//     behind W(c + 1) still allow a counted wait, vmcnt(2)).
 //   * dpre (bf16, fragment order - the B operand of GEMM 2 as it is) is stored like the forward kernel's h: held in 8
 //     registers and issued right behind the next ring synchronisation.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool DROP>
+template <bool DROP, int NBUF>
 __global__ __launch_bounds__(512, 2) void ffn_bwd_one_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ h,
                                                              const bf16_t* __restrict__ x, const bf16_t* __restrict__ img,
                                                              bf16_t* __restrict__ dym_out, bf16_t* __restrict__ dpre_out,
@@ -1313,8 +1315,9 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_one_kernel(const bf16_t* __res
                                                              float eps, float gate_scale, float drop_p,
                                                              const uint64_t* __restrict__ seed, uint32_t site_r,
                                                              uint32_t site_m) {
-    constexpr int NBUF = 4;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [4 x 32 KiB ring | 8 waves x 2 slots x 2 KiB of h]
+    // NBUF ring slots (4: all 160 KiB of LDS with the staging area; 3: 128 KiB), the weight DMA DIST chunks ahead
+    constexpr int DIST = NBUF - 1;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [NBUF x 32 KiB ring | 8 waves x 2 slots x 2 KiB of h]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1329,7 +1332,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_one_kernel(const bf16_t* __res
     auto issue_w = [&](int c) { dma4s(w_src + (size_t)c * BWD_CHUNK, lane16, w_dst + (uint32_t)(c % NBUF) * FWD_CHUNK); };
     issue_w(0);
     issue_w(1);
-    issue_w(2);
+    if (DIST == 3) issue_w(2);
 
     const int wg_row0 = blockIdx.x * TOK_PER_WG;
     const int row0 = wg_row0 + wave * 32;
@@ -1408,12 +1411,18 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_one_kernel(const bf16_t* __res
             stash_c = -1;
         }
     };
-    // sync(c): afterwards chunks <= c + 1 are readable, chunk c + 3 is on its way into the slot chunk c - 1 has left
+    // sync(c): afterwards chunks <= c + 1 are readable, chunk c + DIST is on its way into the slot chunk c - 1 has left.
+    // Loads behind the last piece of W(c + 1) at this point (scripts/checks/ffn_bwd_one_protocol.py): 4 slots - two gate
+    // chunks and W(c + 2): 8; 3 slots - one gate chunk: 2
     auto sync = [&](int c) {
-        if (c + 2 < NCH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (c + 2 < NCH) {
+            if (DIST == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        if (c + 3 < NCH) issue_w(c + 3);
+        if (c + DIST < NCH) issue_w(c + DIST);
         flush();
     };
     auto g2frag = [](int p) -> int { return 2 * (p & 7) + (p >> 3); };
@@ -1435,7 +1444,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_one_kernel(const bf16_t* __res
     // lane's piece q >> 1 of h (the layout ffn_fwd_kernel's E1 packed and stored); dpre = dh * gate_scale where h > 0
     auto E1 = [&](int c) {
         if (c < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (c + 3 < NCH) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (c + DIST < NCH) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const char* hs = hst + (c & 1) * 2048;
 #pragma unroll
@@ -1812,21 +1821,22 @@ extern "C" int dsvg_ffn_bwd_one(const void* dy, const void* h, const void* x, co
                      (uintptr_t)dpre | (uintptr_t)dx | (uintptr_t)dx_masked) & 15) == 0,
                    "ffn_bwd_one: operands must be 16-byte aligned");
     const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
-    const size_t lds = (size_t)4 * FWD_CHUNK + 8 * 4096;         // the whole 160 KiB: 4-slot weight ring + the gate staging
+    // ring slots: 4 (default: all 160 KiB of LDS together with the gate staging) or 3 (128 KiB; DSVG_FFN_BWD_ONE_SLOTS=3)
+    static const int slots = getenv("DSVG_FFN_BWD_ONE_SLOTS") ? atoi(getenv("DSVG_FFN_BWD_ONE_SLOTS")) : 4;
     hipStream_t st = (hipStream_t)stream;
-    if (drop_p > 0.f) {
-        DSVG_ENSURE_LDS(ffn_bwd_one_kernel<true>, lds);
-        hipLaunchKernelGGL(ffn_bwd_one_kernel<true>, dim3(nb), dim3(512), lds, st, (const bf16_t*)dy, (const bf16_t*)h,
-                           (const bf16_t*)x, (const bf16_t*)packed_bwd_layer, (bf16_t*)dym, (bf16_t*)dpre, (bf16_t*)dx,
-                           (bf16_t*)dx_masked, (int)rows, eps, gate_scale, drop_p, (const uint64_t*)seed, site_res,
-                           site_masked);
-    } else {
-        DSVG_ENSURE_LDS(ffn_bwd_one_kernel<false>, lds);
-        hipLaunchKernelGGL(ffn_bwd_one_kernel<false>, dim3(nb), dim3(512), lds, st, (const bf16_t*)dy, (const bf16_t*)h,
-                           (const bf16_t*)x, (const bf16_t*)packed_bwd_layer, (bf16_t*)dym, (bf16_t*)dpre, (bf16_t*)dx,
-                           (bf16_t*)nullptr, (int)rows, eps, gate_scale, 0.f, (const uint64_t*)nullptr, site_res,
-                           site_masked);
-    }
+    const bool drop = drop_p > 0.f;
+#define DSVG_FFN_BWD_ONE(DR, NB)                                                                                       \
+    do {                                                                                                               \
+        const size_t lds = (size_t)NB * FWD_CHUNK + 8 * 4096;                                                          \
+        DSVG_ENSURE_LDS((ffn_bwd_one_kernel<DR, NB>), lds);                                                            \
+        hipLaunchKernelGGL((ffn_bwd_one_kernel<DR, NB>), dim3(nb), dim3(512), lds, st, (const bf16_t*)dy,              \
+                           (const bf16_t*)h, (const bf16_t*)x, (const bf16_t*)packed_bwd_layer, (bf16_t*)dym,          \
+                           (bf16_t*)dpre, (bf16_t*)dx, (bf16_t*)(DR ? dx_masked : nullptr), (int)rows, eps, gate_scale, \
+                           DR ? drop_p : 0.f, (const uint64_t*)(DR ? seed : nullptr), site_res, site_masked);          \
+    } while (0)
+    if (slots == 3) { if (drop) DSVG_FFN_BWD_ONE(true, 3); else DSVG_FFN_BWD_ONE(false, 3); }
+    else { if (drop) DSVG_FFN_BWD_ONE(true, 4); else DSVG_FFN_BWD_ONE(false, 4); }
+#undef DSVG_FFN_BWD_ONE
     DSVG_LAUNCH_CHECK("ffn_bwd_one");
     return 0;
 }

@@ -6,31 +6,41 @@ wave into the wave's private staging slot c & 1) - together with the two wait po
 Loads return in order, so `s_waitcnt vmcnt(N)` certainly covers a load iff more than N loads sit at or behind it in program
 order at the wait (stores in flight only make the wait stricter).  The script prints, for early (sync in front of G1) and
 late (sync in front of G2) waves, the largest admissible N per iteration and checks the constants the kernel uses:
-    sync(c): vmcnt(8) while c + 2 < NCH, else vmcnt(0);     gate(c): vmcnt(2) for c < 2, vmcnt(10) while c + 3 < NCH, else vmcnt(0)
+    4 slots:  sync(c): vmcnt(8) while c + 2 < NCH, else vmcnt(0);   gate(c): vmcnt(2) for c < 2, vmcnt(10) while c + 3 < NCH, else 0
+    3 slots:  sync(c): vmcnt(2) while c + 2 < NCH, else vmcnt(0);   gate(c): vmcnt(2) for c < 2, vmcnt(10) while c + 2 < NCH, else 0
 and the reuse of the staging slots (h(c + 2) is issued behind gate(c)'s reads) and ring slots (W(c + 3) behind barrier c)."""
 import sys
 
 NCH = 16
+NBUF = 4                    # ring slots: the weight DMA runs DIST = NBUF - 1 chunks ahead
 
 
 def sync_wait(c):
-    return 8 if c + 2 < NCH else 0
+    if NBUF == 4:
+        return 8 if c + 2 < NCH else 0
+    return 2 if c + 2 < NCH else 0          # 3 slots: only the two gate pieces of chunk c + 1 / c + 2 sit behind W(c + 1)
 
 
 def gate_wait(c):
     if c < 2:
         return 2            # (the first two gate pieces sit right behind the prologue: few loads behind them yet)
-    return 10 if c + 3 < NCH else 0
+    if NBUF == 4:
+        return 10 if c + 3 < NCH else 0
+    return 10 if c + 2 < NCH else 0
 
 
 def program(late):
-    ev = [("W", 0)] * 4 + [("W", 1)] * 4 + [("W", 2)] * 4 + [("drain_loads",)] + [("h", 0)] * 2 + [("h", 1)] * 2
+    dist = NBUF - 1
+    ev = []
+    for c in range(dist):
+        ev += [("W", c)] * 4
+    ev += [("drain_loads",)] + [("h", 0)] * 2 + [("h", 1)] * 2
     ev.append(("pre",))
 
     def sync(c):
         out = [("sync", c)]
-        if c + 3 < NCH:
-            out += [("W", c + 3)] * 4
+        if c + dist < NCH:
+            out += [("W", c + dist)] * 4
         return out
     for c in range(NCH):
         if not late:
@@ -74,6 +84,9 @@ def check():
 
 
 if __name__ == "__main__":
-    b = check()
+    b = 0
+    for NBUF in (4, 3):
+        print(f"--- {NBUF} ring slots")
+        b += check()
     print("violations:", b)
     sys.exit(1 if b else 0)

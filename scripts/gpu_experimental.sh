@@ -20,8 +20,15 @@ echo "experimental tests (attn_block_fwd 4 slots) rc=$rca"; tail -n 30 gpurun_ou
 ( time DSVG_EXPERIMENTAL=1 timeout 300 python -m pytest tests -q -p no:cacheprovider --timeout 120 -m gpu -k "one_launch" ) \
     > gpurun_out/experimental_tests_bwd_one.log 2>&1
 rcb=$?
-echo "experimental tests (ffn_bwd_one) rc=$rcb"; tail -n 30 gpurun_out/experimental_tests_bwd_one.log | cut -c1-300
-timeout 300 python scripts/ffn_bwd_one_probe.py 2>&1 | tee gpurun_out/experimental_ffn_bwd_one.log | cut -c1-300
+echo "experimental tests (ffn_bwd_one, 4 ring slots = all 160 KiB of LDS) rc=$rcb"; tail -n 30 gpurun_out/experimental_tests_bwd_one.log | cut -c1-300
+( time DSVG_FFN_BWD_ONE_SLOTS=3 DSVG_EXPERIMENTAL=1 timeout 300 python -m pytest tests -q -p no:cacheprovider --timeout 120 -m gpu -k "one_launch" ) \
+    > gpurun_out/experimental_tests_bwd_one_3slots.log 2>&1
+rcb3=$?
+echo "experimental tests (ffn_bwd_one, 3 ring slots) rc=$rcb3"; tail -n 12 gpurun_out/experimental_tests_bwd_one_3slots.log | cut -c1-300
+for sl in 4 3; do
+  echo "--- ffn_bwd_one, $sl ring slots"
+  DSVG_FFN_BWD_ONE_SLOTS=$sl timeout 300 python scripts/ffn_bwd_one_probe.py 2>&1 | tee -a gpurun_out/experimental_ffn_bwd_one.log | cut -c1-300
+done
 for st in 3 4; do
   echo "--- attn_block_fwd, DSVG_ATTN_STAGES=$st"
   DSVG_ATTN_STAGES=$st timeout 300 python scripts/attn_bench.py 2>&1 | tee -a gpurun_out/experimental_attn_bench.log | cut -c1-300
@@ -40,6 +47,7 @@ cfgs=("DSVG_FFN_STAGES=0")
 [ $rc -eq 0 ] && cfgs+=("DSVG_FFN_STAGES=5" "DSVG_FFN_STAGES=5 DSVG_FFN_PIPE_FLAGS=2")
 [ $rca -eq 0 ] && cfgs+=("DSVG_ATTN_STAGES=4")
 [ $rcb -eq 0 ] && cfgs+=("DSVG_FFN_BWD_ONE=1")
+[ $rcb -ne 0 ] && [ $rcb3 -eq 0 ] && cfgs+=("DSVG_FFN_BWD_ONE=1 DSVG_FFN_BWD_ONE_SLOTS=3")
 [ $rc -eq 0 ] && [ $rca -eq 0 ] && [ $rcb -eq 0 ] && cfgs+=("DSVG_FFN_STAGES=5 DSVG_ATTN_STAGES=4 DSVG_FFN_BWD_ONE=1")
 if [ ${#cfgs[@]} -gt 1 ]; then
   bash scripts/ab.sh "${cfgs[@]}" 2>&1 | tee gpurun_out/experimental_ab.log
