@@ -108,20 +108,21 @@ __device__ __forceinline__ void dma4s(const void* sbase, uint32_t voff, uint32_t
 }
 
 // two 1 KiB pieces whose sources are 32 bytes apart per lane (the two K steps of a lane's 64-byte run): source = wave-uniform
-// base + 32-bit per-lane offset, destination lds and lds + 1024 (the instruction offset advances both addresses, so M0 makes
-// up for it on the LDS side)
+// base (+ 32 for the second piece: a second SGPR pair, so that M0 stays on 1 KiB boundaries and no instruction offset is
+// involved) + 32-bit per-lane offset, destination lds and lds + 1024
 __device__ __forceinline__ void dma2_pair32(const void* sbase, uint32_t voff, uint32_t lds) {
     uint32_t keep;
+    const char* sbase1 = reinterpret_cast<const char*>(sbase) + 32;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
+        "s_mov_b32 m0, %4\n\t"
         "s_nop 0\n\t"
         "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_add_u32 m0, m0, 0x3e0\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:32\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
         "s_mov_b32 m0, %0"
-        : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory", "scc");
+        : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(sbase1), "s"(lds) : "memory", "scc");
 }
 
 // One transposed 32 x 32 accumulator tile (lane: token row lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the
