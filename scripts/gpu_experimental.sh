@@ -47,6 +47,9 @@ if [ $rc -eq 0 ]; then
     PROBE_STAGES=$st timeout 200 python scripts/ffn_phase_probe.py 2>&1 | tee -a gpurun_out/experimental_ffn_phase.log | cut -c1-300
   done
 fi
+( time DSVG_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_model_gpu.py -q -p no:cacheprovider --timeout 300 -m gpu -k "experimental_kernels" ) \
+    > gpurun_out/experimental_tests_model.log 2>&1
+echo "experimental kernels inside the train step rc=$?"; tail -n 20 gpurun_out/experimental_tests_model.log | cut -c1-300
 cfgs=("DSVG_FFN_STAGES=0")
 [ $rc -eq 0 ] && cfgs+=("DSVG_FFN_STAGES=5" "DSVG_FFN_STAGES=5 DSVG_FFN_PIPE_FLAGS=2")
 [ $rca -eq 0 ] && cfgs+=("DSVG_ATTN_STAGES=4")

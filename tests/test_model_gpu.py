@@ -12,6 +12,8 @@ from deepsvg_amd.synthetic import make_batch
 from oracle import svg_transformer_oracle as O
 from tests import helpers as H
 
+from tests.conftest import experimental
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
@@ -588,6 +590,46 @@ def test_side_stream_weight_gradients_equal_inline_ones(gpu_device, use_graph, m
     for (l0, g0), (l1, g1) in zip(runs[False], runs[True]):
         assert l0 == l1
         assert g0.abs().max().item() > 0 and torch.equal(g0, g1)
+
+
+@experimental
+@pytest.mark.parametrize("which", ["ffn_fwd_stages5", "attn_4_slots", "ffn_bwd_one", "all"])
+def test_experimental_kernels_in_the_train_step(gpu_device, which, monkeypatch):
+    """the opt-in kernels of the end of round 3 inside the real training step (bf16, dropout 0.1, 640 icons: the large stages
+    run the fused kernels), eagerly and over two batches: ffn_fwd stages = 5 and attn_block_fwd with 4 ring slots are
+    bit-identical to the default kernels - loss and flat gradient must be EQUAL -, ffn_bwd_one changes the summation order of
+    two products - loss equal (the forward pass is untouched), gradient within bf16 rounding"""
+    from deepsvg_amd import functional as Fn, ops
+    from deepsvg_amd.trainer import TrainStep
+    cfg = H.build_cfg("hier")
+    cfg.dropout = 0.1
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 79)
+    batches = [tuple(t.to(DEV) for t in make_batch(640, seed=sd_)) for sd_ in (41, 42)]
+    runs = {}
+    try:
+        for on in (False, True):
+            monkeypatch.setattr(ops, "_FFN_STAGES", 5 if (on and which in ("ffn_fwd_stages5", "all")) else 0)
+            ops.attn_block_fwd_stages(4 if (on and which in ("attn_4_slots", "all")) else 3)
+            monkeypatch.setattr(Fn, "FFN_BWD_ONE", on and which in ("ffn_bwd_one", "all"))
+            torch.manual_seed(99)
+            model = _hip_model(cfg, sd, torch.bfloat16).train()
+            ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=0.0, use_graph=False)
+            grads = []
+            for c, a in batches:
+                ld = ts.step(c, a)
+                torch.cuda.synchronize()
+                grads.append((float(ld["loss"]), model.store.grad_buffer(0).detach().clone()))
+            runs[on] = grads
+    finally:
+        ops.attn_block_fwd_stages(3)
+    for (l0, g0), (l1, g1) in zip(runs[False], runs[True]):
+        assert l0 == l1, (which, l0, l1)
+        assert g0.abs().max().item() > 0 and torch.isfinite(g1).all()
+        if which in ("ffn_fwd_stages5", "attn_4_slots"):
+            assert torch.equal(g0, g1), (which, (g0 - g1).abs().max().item())
+        else:
+            rel = ((g0 - g1).norm() / g0.norm()).item()
+            assert rel < 2e-2, (which, rel)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
