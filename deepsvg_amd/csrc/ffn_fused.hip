@@ -472,7 +472,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_pipe_kernel(const bf16_t* __re
                                                               uint32_t site_r, int n_chunks, unsigned long long* dbg,
                                                               int flags) {
     // flags (probes, DSVG_FFN_PIPE_FLAGS): 1 = no stage offset between the two waves of a SIMD (every wave's barrier in front
-    // of G1), 2 = s_setprio 1 for waves 4-7 (the later-dispatched half loses every issue arbitration at equal priority)
+    // of G1), 2 = s_setprio 1 for waves 4-7 (the later-dispatched half loses every issue arbitration at equal priority);
+    // debugging: 8 = every ring wait is s_waitcnt vmcnt(0) (no counted waits)
     constexpr int NBUF = 4;
     // [4 chunk slots | b1 (2 KiB) | b2 (1 KiB) | the last XL B-operand fragments of every wave's rows (8 KiB each)]
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_pipe_kernel(const bf16_t* __re
     // of chunk k - 1 leave right behind the barrier (a whole iteration to drain before the next counted wait; stores can
     // only make that wait stricter, see ffn_fwd_kernel)
     auto sync = [&](int k) {
-        if (k + 2 < n_chunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (k + 2 < n_chunks && !(flags & 8)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int nc = k + 3 - lag;
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_pipe_kernel(const bf16_t* __re
     ffn_stamp(dbg, 1);
     __builtin_assume(n_chunks >= 2);        // (the host's contract: chunk 0 is peeled, the loop below runs at least once)
     {
-        if (n_chunks > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (n_chunks > 2 && !(flags & 8)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // W1(0), W1(1), W2(0) are in LDS
         {
@@ -1314,7 +1315,8 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_one_kernel(const bf16_t* __res
                                                              bf16_t* __restrict__ dx, bf16_t* __restrict__ dxm, int M,
                                                              float eps, float gate_scale, float drop_p,
                                                              const uint64_t* __restrict__ seed, uint32_t site_r,
-                                                             uint32_t site_m) {
+                                                             uint32_t site_m, int flags) {
+    // flags (debugging, DSVG_FFN_BWD_ONE_FLAGS): 1 = every wait of the loop is s_waitcnt vmcnt(0) (no counted waits)
     // NBUF ring slots (4: all 160 KiB of LDS with the staging area; 3: 128 KiB), the weight DMA DIST chunks ahead
     constexpr int DIST = NBUF - 1;
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // [NBUF x 32 KiB ring | 8 waves x 2 slots x 2 KiB of h]
@@ -1415,7 +1417,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_one_kernel(const bf16_t* __res
     // Loads behind the last piece of W(c + 1) at this point (scripts/checks/ffn_bwd_one_protocol.py): 4 slots - two gate
     // chunks and W(c + 2): 8; 3 slots - one gate chunk: 2
     auto sync = [&](int c) {
-        if (c + 2 < NCH) {
+        if (c + 2 < NCH && !(flags & 1)) {
             if (DIST == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
@@ -1443,7 +1445,8 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_one_kernel(const bf16_t* __res
     // E1: the gate.  Accumulator register 4 q + e holds unit 8 q + 4 half + e of the chunk = element 4 (q & 1) + e of the
     // lane's piece q >> 1 of h (the layout ffn_fwd_kernel's E1 packed and stored); dpre = dh * gate_scale where h > 0
     auto E1 = [&](int c) {
-        if (c < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (flags & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (c < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else if (c + DIST < NCH) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const char* hs = hst + (c & 1) * 2048;
@@ -1823,6 +1826,7 @@ extern "C" int dsvg_ffn_bwd_one(const void* dy, const void* h, const void* x, co
     const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
     // ring slots: 4 (default: all 160 KiB of LDS together with the gate staging) or 3 (128 KiB; DSVG_FFN_BWD_ONE_SLOTS=3)
     static const int slots = getenv("DSVG_FFN_BWD_ONE_SLOTS") ? atoi(getenv("DSVG_FFN_BWD_ONE_SLOTS")) : 4;
+    static const int one_flags = getenv("DSVG_FFN_BWD_ONE_FLAGS") ? atoi(getenv("DSVG_FFN_BWD_ONE_FLAGS")) : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool drop = drop_p > 0.f;
 #define DSVG_FFN_BWD_ONE(DR, NB)                                                                                       \
@@ -1832,7 +1836,8 @@ extern "C" int dsvg_ffn_bwd_one(const void* dy, const void* h, const void* x, co
         hipLaunchKernelGGL((ffn_bwd_one_kernel<DR, NB>), dim3(nb), dim3(512), lds, st, (const bf16_t*)dy,              \
                            (const bf16_t*)h, (const bf16_t*)x, (const bf16_t*)packed_bwd_layer, (bf16_t*)dym,          \
                            (bf16_t*)dpre, (bf16_t*)dx, (bf16_t*)(DR ? dx_masked : nullptr), (int)rows, eps, gate_scale, \
-                           DR ? drop_p : 0.f, (const uint64_t*)(DR ? seed : nullptr), site_res, site_masked);          \
+                           DR ? drop_p : 0.f, (const uint64_t*)(DR ? seed : nullptr), site_res, site_masked,           \
+                           one_flags);                                                                                 \
     } while (0)
     if (slots == 3) { if (drop) DSVG_FFN_BWD_ONE(true, 3); else DSVG_FFN_BWD_ONE(false, 3); }
     else { if (drop) DSVG_FFN_BWD_ONE(true, 4); else DSVG_FFN_BWD_ONE(false, 4); }
