@@ -623,7 +623,11 @@ def main():
                        "parallelism": f"dp{world}", "hip_graph": use_graph, "loss": round(loss_val, 4),
                        "encoder_layout": ("packed (valid tokens only, exact)" if model.last_packing else "padded"),
                        "encoder_valid_token_frac": (round(model.last_packing[0] / model.last_packing[1], 4)
-                                                    if model.last_packing else 1.0)},
+                                                    if model.last_packing else 1.0),
+                       # every DSVG_* environment switch that was set for this run (A/B knobs, opt-in kernels): a record taken
+                       # with a non-default kernel selection says so
+                       "env_overrides": {k: v for k, v in sorted(os.environ.items())
+                                         if k.startswith("DSVG_") and not k.startswith("DSVG_BENCH_")}},
             "graphs": graphs, "rccl_ranks": rccl_ranks,
             "roofline": roofline, "fp32": fp32, "torch_rocm_reference": torch_ref, "cpu_baseline": cpu,
         }
