@@ -181,9 +181,15 @@ __device__ __forceinline__ void drop2_mult8(const DropCtx& c, uint32_t h, int hi
 //     the DMA) a whole iteration to drain before the next wait.
 // development probe (dsvg_ffn_debug_clock): when set, wave `w` of every workgroup stores s_memtime at four points - kernel
 // start, LayerNorm done (first chunk sync ahead), chunk loop done, last store issued - into dbg[(block * 8 + w) * 4 ..]
+// (bit 0 of the buffer address set: s_memrealtime - the constant 100 MHz reference counter, ONE time base for the whole chip, so
+// that start / end stamps of different workgroups can be compared: dispatch ramp and tail of a launch - instead of s_memtime,
+// the shader clock (one counter per XCD: only differences inside a wave mean anything))
 __device__ __forceinline__ void ffn_stamp(unsigned long long* d, int slot) {
-    if (d && (threadIdx.x & 63) == 0)
-        d[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + slot] = __builtin_amdgcn_s_memtime();
+    if (d && (threadIdx.x & 63) == 0) {
+        const bool real = (reinterpret_cast<uintptr_t>(d) & 1) != 0;
+        unsigned long long* b = reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(d) & ~(uintptr_t)1);
+        b[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + slot] = real ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+    }
 }
 
 // The wave's 32 rows, one row per lane pair (lane half h owns the columns 16 ks + 8 h .. + 7 of every K step): LayerNorm
