@@ -31,7 +31,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")     # before the HIP runtime comes up (see deepsvg_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")     # before the HIP runtime comes up (deepsvg_amd/trainer.py HW_QUEUES_NOTE)
 
 import torch
 import torch.distributed as dist

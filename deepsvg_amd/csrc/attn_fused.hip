@@ -117,7 +117,10 @@ __device__ __forceinline__ bf16x8 col_frag_swz(const bf16_t* img, int ks, int la
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NBUF, bool TRAIN, bool TILED>
+constexpr int NBUF = 3;         // ring slots of the weight stream
+constexpr int DIST = NBUF - 1;  // chunks the DMA runs ahead
+
+template <bool TRAIN, bool TILED>
 __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
         const bf16_t* __restrict__ x, const bf16_t* __restrict__ img, const float* __restrict__ in_bias,
         const float* __restrict__ out_bias, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -147,12 +150,11 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
         if (c < 16 && (c & 1)) dma2(src + wave * 2048, __builtin_amdgcn_readfirstlane(slot + wave * 2048));
         else dma4(src + wave * 4096, __builtin_amdgcn_readfirstlane(slot + wave * 4096));
     };
-    // NBUF = 3: DMA two chunks ahead, every sync drains the wave's memory operations (vmcnt(0)).  NBUF = 4 (EXPERIMENTAL,
-    // dsvg_attn_block_fwd_stages(4) / DSVG_ATTN_STAGES=4): three chunks ahead with counted waits, see sync()
-    constexpr int DIST = NBUF - 1;
+    // 3 ring slots, the DMA two chunks ahead; every sync drains the wave's memory operations (vmcnt(0)).  (Round 4 measured a
+    // 4-slot ring with counted waits - the training stores no longer drained at the 20 syncs - on MI355X: bit-identical, but 2 %
+    // SLOWER per launch (176 vs 173 us at 127 k rows) and no change of the step; removed.  profiles/r04_experimental_attn_bench.log)
     issue(0);
     issue(1);
-    if (DIST == 3) issue(2);
 
     for (int i = tid; i < 768; i += 512) sbin[i] = in_bias[i];
     if (tid < 256) { sbo[tid] = out_bias[tid]; sga[tid] = gamma[tid]; sbe[tid] = beta[tid]; }
@@ -275,22 +277,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
     // sits beside the VALU-bound softmax stage of the other.  Behind the barrier go the stores of the stage the wave has
     // just finished: the q | k tiles (chunk 2 h) or the v and head-output tiles (chunk 2 h + 1) of head h.
     auto sync = [&](int k) {
-        if (DIST == 3) {
-            // counted wait (the 4-slot ring): chunk k + 2 - issued at sync(k - 1), the wave's youngest DMA - stays in flight
-            // across the barrier together with the training stores issued behind it.  Loads return in order, so "at most
-            // pieces(k + 2) operations outstanding" means every piece of chunk k + 1 has landed (one outstanding piece of
-            // it would leave all of chunk k + 2's outstanding as well); stores in flight only make the wait stricter.
-            // pieces(c): 2 for the 16-fragment v chunks (odd c < 16), 4 otherwise (issue()).  With 3 slots every sync
-            // drains the stores of the previous stage too: ~2 us of HBM write latency, 20 times per workgroup.
-            // The last two syncs (k = 18, 19: no chunk k + 2) need chunk 19 - issued at sync(16) - landed: at least two
-            // out_proj iterations' residual-row loads (>= 4 each, unconditional) are younger than its pieces, so "at most 4
-            // outstanding" implies it there too, and the 4 row stores issued right in front of the sync stay in flight.
-            const int nx = k + 2;
-            if (nx < 16 && (nx & 1)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (k + DIST < N_CHUNK) issue(k + DIST);
         const int done = late ? k : k - 1;         // chunk whose stage this wave finished last
@@ -511,10 +498,6 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
             if (n + 4 < 32) ring[n & 3] = ld(sl + (16 * ((n + 4) & 1) + ((n + 4) >> 1)) * FRAG);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // (NBUF = 4: the rows of both tiles leave behind the second tile's arithmetic - the stores sit in a branch, and a
-        // load result read behind a store that may or may not have been issued costs a full s_waitcnt vmcnt(0), i.e. the
-        // first tile's stores would be drained before the second tile can read its residual rows)
-        uint4 pkt[2][2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             uint32_t xc[4][4];
@@ -553,20 +536,9 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
                 }
                 pk[cb] = pack8(v);
             }
-            if (NBUF == 4) {
-                pkt[tt][0] = pk[0];
-                pkt[tt][1] = pk[1];
-            } else if (row_live) {
+            if (row_live) {
                 *reinterpret_cast<uint4*>(yrow + n16 * 2) = pk[0];
                 *reinterpret_cast<uint4*>(yrow + n16 * 2 + 16) = pk[1];
-            }
-        }
-        if (NBUF == 4 && row_live) {
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int n16 = 32 * (2 * u + tt) + 16 * h2;
-                *reinterpret_cast<uint4*>(yrow + n16 * 2) = pkt[tt][0];
-                *reinterpret_cast<uint4*>(yrow + n16 * 2 + 16) = pkt[tt][1];
             }
         }
         if (late) sync(16 + u);
@@ -589,15 +561,6 @@ extern "C" int dsvg_attn_pack(const float* flat_f32, const int64_t* offs, int32_
     hipLaunchKernelGGL(attn_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat_f32, offs,
                        n_layers, (bf16_t*)packed);
     DSVG_LAUNCH_CHECK("attn_pack");
-    return 0;
-}
-
-// ring slots of dsvg_attn_block_fwd: 3 (default) or 4 (experimental, see the kernel's sync()); DSVG_ATTN_STAGES presets it
-static int g_attn_stages = getenv("DSVG_ATTN_STAGES") ? atoi(getenv("DSVG_ATTN_STAGES")) : 3;
-
-extern "C" int dsvg_attn_block_fwd_stages(int32_t stages) {
-    DSVG_CHECK_ARG(stages == 3 || stages == 4, "attn_block_fwd_stages: 3 or 4 ring slots (got %d)", stages);
-    g_attn_stages = stages;
     return 0;
 }
 
@@ -632,23 +595,18 @@ extern "C" int dsvg_attn_block_fwd(const void* x, const void* packed_layer, cons
     }
     const int nb = (int)((waves + TILES_PER_WG - 1) / TILES_PER_WG);
     hipStream_t st = (hipStream_t)stream;
-#define DSVG_ATTN_FWD(NB, TR, TI)                                                                                      \
+#define DSVG_ATTN_FWD(TR, TI)                                                                                          \
     do {                                                                                                               \
-        const size_t lds = (size_t)NB * SLOT + SMALL_LDS + STAGE_LDS;                                                  \
-        DSVG_ENSURE_LDS((attn_block_fwd_kernel<NB, TR, TI>), lds);                                                     \
-        hipLaunchKernelGGL((attn_block_fwd_kernel<NB, TR, TI>), dim3(nb), dim3(512), lds, st, (const bf16_t*)x,        \
+        const size_t lds = (size_t)NBUF * SLOT + SMALL_LDS + STAGE_LDS;                                                \
+        DSVG_ENSURE_LDS((attn_block_fwd_kernel<TR, TI>), lds);                                                     \
+        hipLaunchKernelGGL((attn_block_fwd_kernel<TR, TI>), dim3(nb), dim3(512), lds, st, (const bf16_t*)x,        \
                            (const bf16_t*)packed_layer, in_bias, out_bias, gamma, beta, key_mask, seq_off, tile_first, \
                            (int)n_seq, (int)S, (long long)rows, (bf16_t*)x1, (bf16_t*)xn_out, (bf16_t*)qkv_out,        \
                            (bf16_t*)ao_out, mean_out, rstd_out, eps, scale, drop_p, (const uint64_t*)seed, site_probs, \
                            site_res, (const bf16_t*)seq_add, site_seq_add);                                            \
     } while (0)
-    if (g_attn_stages == 4) {       // EXPERIMENTAL: 4 ring slots, counted waits (bit-identical results)
-        if (train) { if (tiled) DSVG_ATTN_FWD(4, true, true); else DSVG_ATTN_FWD(4, true, false); }
-        else { if (tiled) DSVG_ATTN_FWD(4, false, true); else DSVG_ATTN_FWD(4, false, false); }
-    } else {
-        if (train) { if (tiled) DSVG_ATTN_FWD(3, true, true); else DSVG_ATTN_FWD(3, true, false); }
-        else { if (tiled) DSVG_ATTN_FWD(3, false, true); else DSVG_ATTN_FWD(3, false, false); }
-    }
+    if (train) { if (tiled) DSVG_ATTN_FWD(true, true); else DSVG_ATTN_FWD(true, false); }
+    else { if (tiled) DSVG_ATTN_FWD(false, true); else DSVG_ATTN_FWD(false, false); }
 #undef DSVG_ATTN_FWD
     DSVG_LAUNCH_CHECK("attn_block_fwd");
     return 0;

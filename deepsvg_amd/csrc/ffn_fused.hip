@@ -438,323 +438,6 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// forward, software-pipelined chunk loop (stages = 5; EXPERIMENTAL, opt-in with DSVG_FFN_STAGES=5 - written at the end of
-// round 3 without a GPU at hand, first to be run and timed in round 4; every output is meant to be bit-identical to
-// ffn_fwd_kernel's, tests/test_kernels_gpu.py::test_ffn_fwd_pipelined_variant_agrees).
-// Why: the phase probe (profiles/r03_ffn_phase_probe.log) has the chunk loop of ffn_fwd_kernel at 3,600 cycles per chunk
-// for the 2 x 1,024 matrix-pipe cycles of a SIMD's two waves, and ONE wave alone at 1,800: a wave's three stages G1 (16
-// MFMAs) - E1 (~165 VALU instructions, one issued per ~5 cycles and wave whatever the opcode: ~800 cycles with the matrix
-// pipe unused by this wave) - G2 (16 MFMAs) are serial, and two waves one stage apart pair G1 with G2 (matrix beside
-// matrix) for a third of the period.  Here E1 runs in the shadow of the wave's OWN MFMAs instead:
-//     chunk k:   G1(k)   |   X(k) = the 16 MFMAs of G2(k - 1), with E1(k) cut into 12 slices of ~13 VALU instructions,
-//                            one behind each of the first 12 MFMAs (an MFMA occupies the matrix pipe for 32 cycles, during
-//                            which the wave goes on issuing the independent VALU work behind it)
-// so a wave issues ~260 instructions per chunk (~1,300 cycles of its own issue time) around 32 MFMAs and the SIMD's matrix
-// pipe (2,048 cycles per chunk for both waves) becomes the bound.  The two waves of a SIMD still run one stage apart (the
-// barrier of waves 0-3 in front of G1, of waves 4-7 in front of X): a pure-MFMA stage beside a mixed one.
-//   * G2 trails by one chunk, so the W2 half of a ring slot lives one iteration longer than the W1 half: the two halves
-//     are two DMA streams - waves 0-3 move the W1 halves 3 chunks ahead, waves 4-7 the W2 halves 2 chunks ahead (the same
-//     lead over their consumer), 4 pieces per wave and sync as before, so the counted wait (vmcnt(4): everything but the
-//     wave's newest 4 pieces has landed) gives after barrier k: W1(<= k + 1) and W2(<= k) readable - what G1(k) / X(k) of
-//     the early waves and X(k) / G1(k + 1) of the late waves (and the A ring running 4 fragments ahead of them) read.
-//     Slot reuse: W1(k + 3) overwrites W1(k - 1) (last read by G1(k - 1)), W2(k + 2) overwrites W2(k - 2) (last read by
-//     G2(k - 2) inside X(k - 1)); every wave is past both when it arrives at barrier k.
-//   * registers (256 per wave, none to spare: a spill inside the loop is a scratch load + s_waitcnt vmcnt(0) behind the
-//     DMA issue, i.e. the whole L2 -> LDS latency exposed per chunk; scripts/isa_scan.py on the .s file is the check): X
-//     reads its A fragments 2 MFMAs ahead (two register quads instead of the 4-deep ring - the VALU slices between the
-//     MFMAs cover the LDS latency - and the last four MFMAs refill the ring for the pure-MFMA stage that follows); E1
-//     works in place in `hid` and the packed tile is single-buffered (see X); TRAIN stores h(k - 1) straight from hf
-//     behind barrier k (no stash registers); the DMA source and the h rows are addressed as SGPR base + 32-bit lane
-//     offset; the last B-operand fragment of the wave's normalised rows waits in LDS (XL = 1, 8 KiB of the 29 KiB free
-//     beside the ring) and is fetched 3 MFMAs ahead of its K step; the host passes >= 2 chunks (chunk 0 is peeled).
-// ---------------------------------------------------------------------------------------------------------------------
-template <bool TRAIN, bool DROP, int XL>
-__global__ __launch_bounds__(512, 2) void ffn_fwd_pipe_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ img,
-                                                              const float* __restrict__ b1, const float* __restrict__ b2,
-                                                              bf16_t* __restrict__ y, bf16_t* __restrict__ h_out,
-                                                              bf16_t* __restrict__ xh_out, float* __restrict__ rstd_out,
-                                                              int M, float eps, float drop_p,
-                                                              const uint64_t* __restrict__ seed, uint32_t site_h,
-                                                              uint32_t site_r, int n_chunks, unsigned long long* dbg,
-                                                              int flags) {
-    // flags (probes, DSVG_FFN_PIPE_FLAGS): 1 = no stage offset between the two waves of a SIMD (every wave's barrier in front
-    // of G1), 2 = s_setprio 1 for waves 4-7 (the later-dispatched half loses every issue arbitration at equal priority);
-    // debugging: 8 = every ring wait is s_waitcnt vmcnt(0) (no counted waits)
-    constexpr int NBUF = 4;
-    // [4 chunk slots | b1 (2 KiB) | b2 (1 KiB) | the last XL B-operand fragments of every wave's rows (8 KiB each)]
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    ffn_stamp(dbg, 0);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool late = wave >= 4 && !(flags & 1);
-    if ((flags & 2) && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    const int tok = lane & 31, half = lane >> 5;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)DSVG_LDS_PTR(smem);
-    float* sb1 = reinterpret_cast<float*>(smem + NBUF * FWD_CHUNK);
-    float* sb2 = sb1 + FF;
-
-    // ---- weight streams: waves 0-3 move the W1 half of a chunk (pieces 4 wave .. + 3), waves 4-7 the W2 half, one chunk
-    // behind (`lag`): chunk c's halves land in slot c % 4 at different times
-    // (source = wave-uniform base + lane * 16: one address register, none of them live across the loop as a 64-bit pair)
-    const char* my_src = reinterpret_cast<const char*>(img) + wave * 4096;
-    const uint32_t lane16 = lane * 16;
-    const uint32_t my_dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);
-    const int lag = wave >= 4 ? 1 : 0;
-    auto issue = [&](int c) { dma4s(my_src + (size_t)c * FWD_CHUNK, lane16, my_dst + (uint32_t)(c % NBUF) * FWD_CHUNK); };
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-        if (c + lag < 3 && c < n_chunks) issue(c);      // W1(0 .. 2) / W2(0 .. 1)
-
-    sb1[tid] = b1[tid];
-    if (tid < FD) sb2[tid] = b2[tid];
-
-    const int row0 = blockIdx.x * TOK_PER_WG + wave * 32;
-    const int my_row = min(row0 + tok, M - 1);
-    bf16x8 xf[16];
-    ffn_ln_rows<TRAIN>(x, my_row, half, TRAIN && row0 + tok < M, xh_out, rstd_out, eps, xf);
-    // the registers are the bound of this kernel (256 per wave): the last XL fragments of the normalised rows wait in LDS
-    // (29 KiB are free beside the ring) and are fetched 3 MFMAs ahead of their K step by every G1
-    char* xs = smem + NBUF * FWD_CHUNK + 3072 + (wave * XL) * FRAG + lane * 16;
-#pragma unroll
-    for (int j = 0; j < XL; ++j) {
-        Frag8 f;
-        f.v = xf[16 - XL + j];
-        *reinterpret_cast<uint4*>(xs + j * FRAG) = f.u;       // (read back by this wave only: in-order LDS, no barrier)
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    const DropCtx dh = drop_make(drop_p, seed, site_h);
-    const DropCtx dr = drop_make(drop_p, seed, site_r);
-    // the group index of the hidden site's draws for chunk c is (row * 32 + half) + 2 c (drop2_group's id >> 4): its low word
-    // without the chunk and the high word's contribution, once per lane
-    const uint32_t gl = ((uint32_t)(row0 + tok) << 5) | (uint32_t)half;
-    const uint32_t gh = ((uint32_t)(row0 + tok) >> 27) * 0x9e3779b1u;
-
-    floatx16 yacc[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) yacc[t][r] = 0.f;
-    floatx16 hid;
-    bf16x8 hf[2];                   // packed hidden tile of the previous chunk: B operands of G2, and (TRAIN) its h rows
-    uint4 ring[4];
-    float4 bq;                      // b1' of the quad the next E1 slice starts with
-
-    const char* lbase = smem + lane * 16;
-    auto slot_of = [&](int c) -> const char* { return lbase + (c % NBUF) * FWD_CHUNK; };
-    auto ld = [&](const char* p) -> uint4 { return *reinterpret_cast<const uint4*>(p); };
-    auto bias4 = [&](int c, int q) -> float4 { return *reinterpret_cast<const float4*>(sb1 + CH * c + 8 * q + 4 * half); };
-
-    // h rows: workgroup-uniform base + a 32-bit per-lane offset (rows past M are never stored, so no clamp is needed here)
-    char* hbase = TRAIN ? reinterpret_cast<char*>(h_out) + (size_t)blockIdx.x * ((size_t)TOK_PER_WG * FF * 2) : nullptr;
-    const uint32_t hoff = (uint32_t)((wave * 32 + tok) * (FF * 2) + half * 16);
-    const bool hst = TRAIN && row0 + tok < M;
-    auto store_h = [&](int c) {     // the h rows of chunk c from hf (fragment order: one aligned 16-byte piece per K step)
-        if (TRAIN && hst) {
-            Frag8 f0, f1;
-            f0.v = hf[0];
-            f1.v = hf[1];
-            const uint32_t o = hoff + (uint32_t)(CH * c) * 2u;
-            *reinterpret_cast<uint4*>(hbase + o) = f0.u;
-            *reinterpret_cast<uint4*>(hbase + o + 32u) = f1.u;
-        }
-    };
-    // sync(k): afterwards W1(<= k + 1) and W2(<= k) are readable; W1(k + 3) / W2(k + 2) are on their way; TRAIN: the h rows
-    // of chunk k - 1 leave right behind the barrier (a whole iteration to drain before the next counted wait; stores can
-    // only make that wait stricter, see ffn_fwd_kernel)
-    auto sync = [&](int k) {
-        if (k + 2 < n_chunks && !(flags & 8)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const int nc = k + 3 - lag;
-        if (nc < n_chunks) issue(nc);
-        if (k > 0) store_h(k - 1);
-    };
-    auto g2frag = [](int p) -> int { return 2 * (p & 7) + (p >> 3); };      // G2 position -> fragment of the W2 chunk
-    // G1: hid[unit][token] = sum_k W1[32 c + unit][k] xn[token][k]; the 4-deep ring runs on into the next MFMA stage
-    // (fragments cont + j * cstride, j < 4); bias_c >= 0: the first quad of b1' for chunk bias_c is fetched under the tail
-    auto G1 = [&](const char* w1, const char* cont, int cstride, int bias_c) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hid[r] = 0.f;
-        Frag8 xl[XL > 0 ? XL : 1];
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            Frag8 a;
-            a.u = ring[ks & 3];
-            const int jl = ks >= 16 - XL ? ks - (16 - XL) : 0;
-            hid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, ks < 16 - XL ? xf[ks] : xl[jl].v, hid, 0, 0, 0);
-            if (ks + 4 < 16) ring[ks & 3] = ld(w1 + (ks + 4) * FRAG);
-            else ring[ks & 3] = ld(cont + (ks + 4 - 16) * cstride);
-            if (XL > 0 && ks + 3 >= 16 - XL && ks + 3 < 16) xl[ks + 3 - (16 - XL)].u = ld(xs + (ks + 3 - (16 - XL)) * FRAG);
-            if (ks == 12 && bias_c >= 0) bq = bias4(bias_c, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // E1 of chunk 0, not interleaved with anything (as ffn_fwd_kernel's): bias, ReLU, dropout, bf16 -> hf
-    auto E1_first = [&]() {
-        const uint32_t hh = DROP ? (dsvg_hash32(gl ^ dh.s0) ^ dh.s1) + gh : 0u;
-#pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
-            float v[8];
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const int q = 2 * ks2 + qq;
-                const float4 bb = bias4(0, q);
-                v[4 * qq + 0] = fmaxf(hid[4 * q + 0] + bb.x, 0.f);
-                v[4 * qq + 1] = fmaxf(hid[4 * q + 1] + bb.y, 0.f);
-                v[4 * qq + 2] = fmaxf(hid[4 * q + 2] + bb.z, 0.f);
-                v[4 * qq + 3] = fmaxf(hid[4 * q + 3] + bb.w, 0.f);
-            }
-            if (DROP) {
-                float m[8];
-                drop2_mult8(dh, hh, ks2, m);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= m[e];
-            }
-            Frag8 f;
-            f.u = pack8(v);
-            hf[ks2] = f.v;
-        }
-    };
-    // X(c): y[out][token] += sum_unit W2[out][32 (c - 1) + unit] hid(c - 1)[unit][token] (the MFMAs of G2(c - 1), same
-    // order as ffn_fwd_kernel's G2: position n = output tile n & 7, K step n >> 3) with E1(c) behind the first 12 of them:
-    // slice 3 q + 0: (q = 0: the group hash of the chunk's 16 draws) bias + ReLU of quad q, fetch of the next quad's bias;
-    // slice 3 q + 1: the quad's two draw words; slice 3 q + 2: mask, scale, bf16 -> words 2 (q & 1), + 1 of hf_new[q >> 1].
-    // Fragments: positions 0-3 come from the ring (fetched under the previous stage's tail), position n + 2 is fetched
-    // behind MFMA n, the last four MFMAs refill the ring for the next stage (cont + j * cstride).
-    auto X = [&](int c, const char* w2, const char* cont, int cstride) {
-        uint32_t hh = 0u, wd0 = 0u, wd1 = 0u;
-        uint4 fr[2];
-#pragma unroll
-        for (int n = 0; n < 16; ++n) {
-            Frag8 a;
-            a.u = n < 4 ? ring[n & 3] : fr[n & 1];
-            yacc[n & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, hf[n >> 3], yacc[n & 7], 0, 0, 0);
-            if (n >= 2 && n <= 13) fr[n & 1] = ld(w2 + g2frag(n + 2) * FRAG);
-            if (n >= 12) ring[n - 12] = ld(cont + (n - 12) * cstride);
-            if (n < 12) {
-                const int q = n / 3, ph = n % 3;
-                if (ph == 0) {
-                    // id0 >> 4 of drop2_group = row * 32 + 2 c + half: the low 5 bits of row * 32 are free, no carry
-                    if (DROP && q == 0) hh = (dsvg_hash32((gl | (uint32_t)(2 * c)) ^ dh.s0) ^ dh.s1) + gh;
-                    hid[4 * q + 0] = fmaxf(hid[4 * q + 0] + bq.x, 0.f);
-                    hid[4 * q + 1] = fmaxf(hid[4 * q + 1] + bq.y, 0.f);
-                    hid[4 * q + 2] = fmaxf(hid[4 * q + 2] + bq.z, 0.f);
-                    hid[4 * q + 3] = fmaxf(hid[4 * q + 3] + bq.w, 0.f);
-                } else if (ph == 1) {
-                    if (DROP) {         // words 4 ks2 + 2 qq + {0, 1} = 2 q, 2 q + 1 of the group (drop2_mult8)
-                        wd0 = drop2_word(hh, 2 * q);
-                        wd1 = drop2_word(hh, 2 * q + 1);
-                    }
-                } else {
-                    if (DROP) {
-                        hid[4 * q + 0] *= (wd0 & 0xffffu) < dh.thresh ? 0.f : dh.scale;
-                        hid[4 * q + 1] *= (wd0 >> 16) < dh.thresh ? 0.f : dh.scale;
-                        hid[4 * q + 2] *= (wd1 & 0xffffu) < dh.thresh ? 0.f : dh.scale;
-                        hid[4 * q + 3] *= (wd1 >> 16) < dh.thresh ? 0.f : dh.scale;
-                    }
-                    if (q < 3) bq = bias4(c, q + 1);        // (behind the slice's temporaries, one MFMA ahead of its use)
-                }
-            }
-            if (n == 8) {       // hf[0] fed its last MFMA at position 7; quads 0 and 1 are final since slice 5
-                Frag8 f;
-                f.u = make_uint4(f2bf_pk(hid[0], hid[1]), f2bf_pk(hid[2], hid[3]), f2bf_pk(hid[4], hid[5]), f2bf_pk(hid[6], hid[7]));
-                hf[0] = f.v;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        Frag8 f;                // hf[1] fed position 15
-        f.u = make_uint4(f2bf_pk(hid[8], hid[9]), f2bf_pk(hid[10], hid[11]), f2bf_pk(hid[12], hid[13]), f2bf_pk(hid[14], hid[15]));
-        hf[1] = f.v;
-    };
-
-    ffn_stamp(dbg, 1);
-    __builtin_assume(n_chunks >= 2);        // (the host's contract: chunk 0 is peeled, the loop below runs at least once)
-    {
-        if (n_chunks > 2 && !(flags & 8)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();           // W1(0), W1(1), W2(0) are in LDS
-        {
-            const char* s0 = slot_of(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ring[i] = ld(s0 + i * FRAG);
-        }
-        {   // chunk 0: G1, E1 (the next MFMA stage is G1(1): the host passes n_chunks >= 2)
-            if (!late) sync(0);
-            G1(slot_of(0), slot_of(1), FRAG, -1);
-            if (late) sync(0);
-            E1_first();
-        }
-        for (int k = 1; k < n_chunks; ++k) {
-            const char* w2 = slot_of(k - 1) + 16 * FRAG;
-            if (!late) sync(k);
-            G1(slot_of(k), w2, 2 * FRAG, k);
-            if (late) sync(k);
-            const bool more = k + 1 < n_chunks;
-            X(k, w2, more ? slot_of(k + 1) : slot_of(k) + 16 * FRAG, more ? FRAG : 2 * FRAG);
-        }
-        {   // G2 of the last chunk, then its h rows
-            const char* w2 = slot_of(n_chunks - 1) + 16 * FRAG;
-#pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                Frag8 a;
-                a.u = ring[n & 3];
-                yacc[n & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, hf[n >> 3], yacc[n & 7], 0, 0, 0);
-                if (n + 4 < 16) ring[n & 3] = ld(w2 + g2frag(n + 4) * FRAG);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        store_h(n_chunks - 1);
-    }
-    ffn_stamp(dbg, 2);
-
-    // ---- epilogue: + b2, dropout, + residual, bf16 rows (as in ffn_fwd_kernel) ---------------------------------------
-    const int m = row0 + tok;
-    const bool live = m < M;
-    const char* xres = reinterpret_cast<const char*>(x) + (size_t)my_row * (FD * 2);
-    char* yrow = reinterpret_cast<char*>(y) + (size_t)my_row * (FD * 2);
-    uint4 res[16];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        res[2 * t] = *reinterpret_cast<const uint4*>(xres + (32 * t + 16 * half) * 2);
-        res[2 * t + 1] = *reinterpret_cast<const uint4*>(xres + (32 * t + 16 * half + 8) * 2);
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        uint32_t xc[4][4];
-        tile_to_cols16(yacc[t], xc);
-        const int n16 = 32 * t + 16 * half;
-        uint4 pk[2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            float v[8], rv[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(xc[2 * cb][e]); v[4 + e] = __uint_as_float(xc[2 * cb + 1][e]); }
-            const float4 b0 = *reinterpret_cast<const float4*>(sb2 + n16 + 8 * cb);
-            const float4 b1v = *reinterpret_cast<const float4*>(sb2 + n16 + 8 * cb + 4);
-            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-            v[4] += b1v.x; v[5] += b1v.y; v[6] += b1v.z; v[7] += b1v.w;
-            if (dr.on) {
-                float dm[8];
-                drop_mult8(dr, (uint64_t)m * FD + n16 + 8 * cb, dm);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= dm[e];
-            }
-            unpack8(res[2 * t + cb], rv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rv[e];
-            pk[cb] = pack8(v);
-        }
-        if (live) {
-            *reinterpret_cast<uint4*>(yrow + n16 * 2) = pk[0];
-            *reinterpret_cast<uint4*>(yrow + n16 * 2 + 16) = pk[1];
-        }
-    }
-    ffn_stamp(dbg, 3);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // forward, half-size workgroups: the same per-wave program (32 rows: LayerNorm -> G1 E1 G2 per chunk -> epilogue, results
 // bit-identical to ffn_fwd_kernel) in workgroups of 4 waves = 128 rows with a ring of four 16 KiB HALF chunks (the W1 part /
 // the W2 part of a chunk; 67 KiB of LDS), so that two workgroups fit on a CU.  Used for launches of at most 32,768 rows:
@@ -1291,313 +974,6 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// backward of the sub-block's input path in ONE launch (EXPERIMENTAL, opt-in DSVG_FFN_BWD_ONE=1; written at the end of round 3
-// without a GPU at hand, first to be run in round 4):
-//     dym = drop_r-mask(dy);   dpre = (dym . W2) gated by the stored h (h > 0 <=> the unit passed the ReLU and was kept);
-//     dx  = dy + LayerNorm'( dpre . W1' )
-// - the mirror image of ffn_fwd_kernel (GEMM 1 over the 256 outputs with the W2^T chunk, a VALU stage on the 32 x 32 hidden
-// tile, GEMM 2 with the W1'^T chunk into 8 accumulators) with ffn_bwd_dx_kernel's epilogue.  It replaces three launches of
-// the default backward - dsvg_drop_apply (dym), the gated input-gradient GEMM (dpre) and dsvg_ffn_bwd_dx - which move 390 MB
-// per 63 k-row layer between them (dy twice, dym and dpre written and read back); this kernel moves 260 MB (dy, h, x in;
-// dym, dpre, dx out: the weight-gradient GEMMs still want dym and dpre in memory) and keeps the hidden tile on the chip.
-//   * weights: the last 32 KiB of every 48 KiB backward chunk [W2^T chunk | W1'^T chunk] through a 4-slot ring, DMA three
-//     chunks ahead, as in ffn_fwd_kernel; source = SGPR base + lane offset (dma4s).
-//   * the gate: a lane needs its 2 x 16 bytes of h per chunk (the pieces the forward kernel stored, fragment order) one
-//     VALU stage after GEMM 1.  They come by LDS-DMA too - two 1 KiB pieces per wave and chunk into a private two-slot
-//     staging area, two chunks ahead (a chunk is ~1.3-2.3 us of work per wave, an HBM load ~2 us) - so that EVERY load of
-//     the loop is issued from inline asm and every wait is a counted s_waitcnt of ours: a compiler-visible load in this
-//     loop would be waited for with a count that knows nothing of the DMA pieces around it, i.e. it would drain the
-//     weight stream every iteration.  Wait values: scripts/checks/ffn_bwd_one_protocol.py derives and checks them
-//     (sync(c): vmcnt(8), gate(c): vmcnt(10), stricter at both ends).  LDS: 128 KiB ring + 8 x 2 x 2 KiB = all 160 KiB;
-//     DSVG_FFN_BWD_ONE_SLOTS=3 selects a 3-slot ring (128 KiB in all, the weight DMA two chunks ahead: the two gate pieces
-//     behind W(c + 1) still allow a counted wait, vmcnt(2)).
-//   * dpre (bf16, fragment order - the B operand of GEMM 2 as it is) is stored like the forward kernel's h: held in 8
-//     registers and issued right behind the next ring synchronisation.
-// ---------------------------------------------------------------------------------------------------------------------
-template <bool DROP, int NBUF>
-__global__ __launch_bounds__(512, 2) void ffn_bwd_one_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ h,
-                                                             const bf16_t* __restrict__ x, const bf16_t* __restrict__ img,
-                                                             bf16_t* __restrict__ dym_out, bf16_t* __restrict__ dpre_out,
-                                                             bf16_t* __restrict__ dx, bf16_t* __restrict__ dxm, int M,
-                                                             float eps, float gate_scale, float drop_p,
-                                                             const uint64_t* __restrict__ seed, uint32_t site_r,
-                                                             uint32_t site_m, int flags) {
-    // flags (debugging, DSVG_FFN_BWD_ONE_FLAGS): 1 = every wait of the loop is s_waitcnt vmcnt(0) (no counted waits)
-    // NBUF ring slots (4: all 160 KiB of LDS with the staging area; 3: 128 KiB), the weight DMA DIST chunks ahead
-    constexpr int DIST = NBUF - 1;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [NBUF x 32 KiB ring | 8 waves x 2 slots x 2 KiB of h]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool late = wave >= 4;
-    const int tok = lane & 31, half = lane >> 5;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)DSVG_LDS_PTR(smem);
-
-    // ---- weight stream: pieces 4 wave .. 4 wave + 3 of [W2^T chunk | W1'^T chunk] = bytes 16 KiB .. 48 KiB of a backward chunk
-    const char* w_src = reinterpret_cast<const char*>(img) + 16 * FRAG + wave * 4096;
-    const uint32_t lane16 = lane * 16;
-    const uint32_t w_dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);
-    auto issue_w = [&](int c) { dma4s(w_src + (size_t)c * BWD_CHUNK, lane16, w_dst + (uint32_t)(c % NBUF) * FWD_CHUNK); };
-    issue_w(0);
-    issue_w(1);
-    if (DIST == 3) issue_w(2);
-
-    const int wg_row0 = blockIdx.x * TOK_PER_WG;
-    const int row0 = wg_row0 + wave * 32;
-    const int m = row0 + tok;
-    const bool live = m < M;
-    const int my_row = min(m, M - 1);
-    const DropCtx dr_ctx = drop_make(drop_p, seed, site_r);
-
-    // ---- dym fragments: dy with the residual dropout replayed (ids m * 256 + column, standard draws), as ffn_bwd_hidden_kernel
-    bf16x8 df[16];
-    {
-        const char* dr = reinterpret_cast<const char*>(dy) + (size_t)my_row * (FD * 2) + half * 16;
-        char* dm_o = reinterpret_cast<char*>(dym_out) + (size_t)my_row * (FD * 2) + half * 16;
-        uint4 raw[16];
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) raw[ks] = *reinterpret_cast<const uint4*>(dr + 32 * ks);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            Frag8 f;
-            if (DROP) {
-                float v[8], mm[8];
-                unpack8(raw[ks], v);
-                drop_mult8(dr_ctx, (uint64_t)m * FD + 16 * ks + 8 * half, mm);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= mm[e];
-                f.u = pack8(v);
-                if (live) *reinterpret_cast<uint4*>(dm_o + 32 * ks) = f.u;
-            } else {
-                // no dropout: dym == dy (the caller hands dy itself to the weight-gradient GEMM).  The empty asm "uses" the
-                // loaded registers HERE, so the compiler's wait for the rows sits in front of the DMA issues below and not
-                // in front of the first MFMAs (as s_waitcnt vmcnt(0): a drain of the weight and gate streams)
-                asm volatile("" : "+v"(raw[ks].x), "+v"(raw[ks].y), "+v"(raw[ks].z), "+v"(raw[ks].w));
-                f.u = raw[ks];
-            }
-            df[ks] = f.v;
-        }
-    }
-    // (every wave has read its dy rows by now: loads return in order, so its pieces of W(0 .. 2) have landed as well)
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- gate stream: the lane's two 16-byte pieces of h per chunk -> the wave's staging slot c & 1 -------------------------
-    // source = workgroup-uniform base (+ 64 c bytes) + 32-bit lane offset (rows past M read a clamped copy)
-    const char* h_src = reinterpret_cast<const char*>(h) + (size_t)wg_row0 * (FF * 2);
-    const uint32_t h_off = (uint32_t)(my_row - wg_row0) * (FF * 2) + half * 16;
-    const uint32_t h_dst = __builtin_amdgcn_readfirstlane(lds0 + NBUF * FWD_CHUNK + wave * 4096);
-    auto issue_h = [&](int c) { dma2_pair32(h_src + (size_t)(CH * c) * 2, h_off, h_dst + (uint32_t)(c & 1) * 2048); };
-    issue_h(0);
-    issue_h(1);
-    const char* hst = smem + NBUF * FWD_CHUNK + wave * 4096 + lane * 16;
-
-    floatx16 yacc[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) yacc[t][r] = 0.f;
-    floatx16 hid;
-    bf16x8 hf[2];
-    uint4 ring[4];
-
-    const char* lbase = smem + lane * 16;
-    auto slot_of = [&](int c) -> const char* { return lbase + (c % NBUF) * FWD_CHUNK; };
-    auto ld = [&](const char* p) -> uint4 { return *reinterpret_cast<const uint4*>(p); };
-
-    // dpre rows: workgroup-uniform base + 32-bit lane offset (rows past M are never stored)
-    char* pbase = reinterpret_cast<char*>(dpre_out) + (size_t)wg_row0 * (FF * 2);
-    const uint32_t poff = (uint32_t)((wave * 32 + tok) * (FF * 2) + half * 16);
-    uint4 stash[2];
-    int stash_c = -1;
-    auto flush = [&]() {
-        if (stash_c >= 0) {
-            if (live) {
-                const uint32_t o = poff + (uint32_t)(CH * stash_c) * 2u;
-                *reinterpret_cast<uint4*>(pbase + o) = stash[0];
-                *reinterpret_cast<uint4*>(pbase + o + 32u) = stash[1];
-            }
-            stash_c = -1;
-        }
-    };
-    // sync(c): afterwards chunks <= c + 1 are readable, chunk c + DIST is on its way into the slot chunk c - 1 has left.
-    // Loads behind the last piece of W(c + 1) at this point (scripts/checks/ffn_bwd_one_protocol.py): 4 slots - two gate
-    // chunks and W(c + 2): 8; 3 slots - one gate chunk: 2
-    auto sync = [&](int c) {
-        if (c + 2 < NCH && !(flags & 1)) {
-            if (DIST == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        if (c + DIST < NCH) issue_w(c + DIST);
-        flush();
-    };
-    auto g2frag = [](int p) -> int { return 2 * (p & 7) + (p >> 3); };
-    // G1: dh[unit][token] = sum_o W2[o][32 c + unit] dym[token][o]  (A = fragments 0 .. 15 of the slot); the ring runs on into G2
-    auto G1 = [&](const char* sc) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hid[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            Frag8 a;
-            a.u = ring[ks & 3];
-            hid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, df[ks], hid, 0, 0, 0);
-            if (ks + 4 < 16) ring[ks & 3] = ld(sc + (ks + 4) * FRAG);
-            else ring[ks & 3] = ld(sc + (16 + g2frag(ks + 4 - 16)) * FRAG);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // E1: the gate.  Accumulator register 4 q + e holds unit 8 q + 4 half + e of the chunk = element 4 (q & 1) + e of the
-    // lane's piece q >> 1 of h (the layout ffn_fwd_kernel's E1 packed and stored); dpre = dh * gate_scale where h > 0
-    auto E1 = [&](int c) {
-        if (flags & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (c < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (c + DIST < NCH) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const char* hs = hst + (c & 1) * 2048;
-#pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
-            float g[8], v[8];
-            unpack8(ld(hs + ks2 * 1024), g);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = g[e] > 0.f ? hid[8 * ks2 + e] * gate_scale : 0.f;
-            Frag8 f;
-            f.u = pack8(v);
-            hf[ks2] = f.v;
-            stash[ks2] = f.u;
-        }
-        stash_c = c;
-        // the staging slot is free again (its two reads have returned: their values were just used): chunk c + 2 goes there
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (c + 2 < NCH) issue_h(c + 2);
-    };
-    // G2: dxh[d][token] += sum_unit W1'[32 c + unit][d] dpre[token][unit]  (A = fragments 16 .. 31 of the slot)
-    auto G2 = [&](const char* sc, const char* sn) {
-#pragma unroll
-        for (int n = 0; n < 16; ++n) {
-            Frag8 a;
-            a.u = ring[n & 3];
-            yacc[n & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, hf[n >> 3], yacc[n & 7], 0, 0, 0);
-            if (n + 4 < 16) ring[n & 3] = ld(sc + (16 + g2frag(n + 4)) * FRAG);
-            else if (sn) ring[n & 3] = ld(sn + (n + 4 - 16) * FRAG);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    // W(0 .. 2) have landed (see above); the barrier makes every wave's pieces visible.  (The h pieces and the dym stores
-    // stay in flight.)
-    __builtin_amdgcn_s_barrier();
-    {
-        const char* s0 = slot_of(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ring[i] = ld(s0 + i * FRAG);
-    }
-    for (int c = 0; c < NCH; ++c) {
-        const char* sc = slot_of(c);
-        const char* sn = (c + 1 < NCH) ? slot_of(c + 1) : nullptr;
-        if (!late) sync(c);
-        G1(sc);
-        E1(c);
-        if (late) sync(c);
-        G2(sc, sn);
-    }
-    flush();
-
-    // ---- epilogue: LayerNorm backward on the rows in registers (ffn_bwd_dx_kernel's) ----------------------------------------
-    const char* xrow = reinterpret_cast<const char*>(x) + (size_t)my_row * (FD * 2);
-    uint4 xr[16];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        xr[2 * t] = *reinterpret_cast<const uint4*>(xrow + (32 * t + 16 * half) * 2);
-        xr[2 * t + 1] = *reinterpret_cast<const uint4*>(xrow + (32 * t + 16 * half + 8) * 2);
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        uint32_t xc[4][4];
-        tile_to_cols16(yacc[t], xc);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) yacc[t][4 * q + e] = __uint_as_float(xc[q][e]);      // column 4 q + e of the 16
-    }
-    float s, q, mean, rstd;
-    ln_stats_packed(xr, s, q);
-    ln_mean_rstd256(s, q, eps, mean, rstd);
-    const float shift = -mean * rstd;       // xh = x * rstd + shift
-    float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            float v[8];
-            unpack8(xr[2 * t + cb], v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float g = yacc[t][8 * cb + e];
-                c1 += g;
-                c2 += g * fmaf(v[e], rstd, shift);
-            }
-        }
-    c1 += __shfl_xor(c1, 32, 64);
-    c2 += __shfl_xor(c2, 32, 64);
-    c1 *= (1.f / FD);
-    c2 *= (1.f / FD);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(xr[i].x), "+v"(xr[i].y), "+v"(xr[i].z), "+v"(xr[i].w));
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            float v[8];
-            unpack8(xr[2 * t + cb], v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) yacc[t][8 * cb + e] = rstd * (yacc[t][8 * cb + e] - c1 - fmaf(v[e], rstd, shift) * c2);
-        }
-    uint32_t zoff = 0;
-    asm volatile("" : "+v"(zoff) : "v"(yacc[7][15]), "v"(yacc[0][0]));
-    const char* dyrow = reinterpret_cast<const char*>(dy) + (size_t)my_row * (FD * 2) + zoff;
-    char* orow = reinterpret_cast<char*>(dx) + (size_t)my_row * (FD * 2);
-    char* mrow = dxm ? reinterpret_cast<char*>(dxm) + (size_t)my_row * (FD * 2) : nullptr;
-    uint4 dr[16];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        dr[2 * t] = *reinterpret_cast<const uint4*>(dyrow + (32 * t + 16 * half) * 2);
-        dr[2 * t + 1] = *reinterpret_cast<const uint4*>(dyrow + (32 * t + 16 * half + 8) * 2);
-    }
-    if (m < M) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                float v[8];
-                unpack8(dr[2 * t + cb], v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += yacc[t][8 * cb + e];
-                *reinterpret_cast<uint4*>(orow + (32 * t + 16 * half + 8 * cb) * 2) = pack8(v);
-            }
-    }
-    if (mrow && m < M) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t zo2 = 0;
-        asm volatile("" : "+v"(zo2));
-        const char* back = orow + zo2;
-        const DropCtx dcm = drop_make(drop_p, seed, site_m);
-#pragma unroll 2
-        for (int i = 0; i < 16; ++i) {
-            const int col = 32 * (i >> 1) + 16 * half + 8 * (i & 1);
-            const uint4 pk = *reinterpret_cast<const uint4*>(back + col * 2);
-            float w[8], mm[8];
-            unpack8(pk, w);
-            drop_mult8(dcm, (uint64_t)m * FD + col, mm);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] *= mm[e];
-            *reinterpret_cast<uint4*>(mrow + col * 2) = pack8(w);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // weight gradients, last step.  The two split-K GEMMs deliver G1p = dpre^T xh [512 (fragment order), 256], its row sums
 // db1p [512 (fragment order)] and G2p = dym^T h [256, 512 (fragment order)]; this kernel undoes the fragment order
 // (position p(j): bits 2 and 3 of j swapped) and the LayerNorm fold (see ffn_pack_kernel):
@@ -1739,34 +1115,11 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
         DSVG_LAUNCH_CHECK("ffn_fwd (half-size workgroups)");
         return 0;
     }
-    if (stages_arg == 5) {
-        // EXPERIMENTAL (see ffn_fwd_pipe_kernel): software-pipelined chunk loop, 256-row workgroups, 4 ring slots
-        constexpr int XL = 1;        // B-operand fragments parked in LDS (registers: see the kernel)
-        const size_t lds = (size_t)4 * FWD_CHUNK + 3072 + (size_t)XL * 8 * FRAG;
-        const bool drop = drop_p > 0.f;
-        const int pipe_chunks = dbg_chunks < 2 ? 2 : dbg_chunks;       // (the kernel's first iteration is peeled: >= 2 chunks)
-        static const int pipe_flags = getenv("DSVG_FFN_PIPE_FLAGS") ? atoi(getenv("DSVG_FFN_PIPE_FLAGS")) : 0;
-#define DSVG_FFN_FWD_PIPE(TR, DR)                                                                                     \
-    do {                                                                                                              \
-        DSVG_ENSURE_LDS((ffn_fwd_pipe_kernel<TR, DR, XL>), lds);                                                          \
-        hipLaunchKernelGGL((ffn_fwd_pipe_kernel<TR, DR, XL>), dim3(nb), dim3(512), lds, st, (const bf16_t*)x,              \
-                           (const bf16_t*)packed_fwd_layer, b1_folded, b2, (bf16_t*)y, (bf16_t*)h_out, (bf16_t*)xh_out,\
-                           rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res, pipe_chunks,    \
-                           g_ffn_dbg_host, pipe_flags);                                                                           \
-    } while (0)
-        if (train && drop) DSVG_FFN_FWD_PIPE(true, true);
-        else if (train) DSVG_FFN_FWD_PIPE(true, false);
-        else if (drop) DSVG_FFN_FWD_PIPE(false, true);
-        else DSVG_FFN_FWD_PIPE(false, false);
-#undef DSVG_FFN_FWD_PIPE
-        DSVG_LAUNCH_CHECK("ffn_fwd (pipelined chunk loop)");
-        return 0;
-    }
     if (train && stages == 3) DSVG_FFN_FWD(3, true);
     else if (train) DSVG_FFN_FWD(4, true);
     else if (stages == 3) DSVG_FFN_FWD(3, false);
     else if (stages == 4) DSVG_FFN_FWD(4, false);
-    else { dsvg_set_error("ffn_fwd: stages must be 0 (default), 2 (half-size workgroups), 3, 4 or 5 (experimental)"); return -1; }
+    else { dsvg_set_error("ffn_fwd: stages must be 0 (default), 2 (half-size workgroups), 3 or 4"); return -1; }
 #undef DSVG_FFN_FWD
     DSVG_LAUNCH_CHECK("ffn_fwd");
     return 0;
@@ -1816,39 +1169,6 @@ extern "C" int dsvg_ffn_bwd_dx(const void* dpre, const void* x, const void* dy, 
                        (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps,
                        (bf16_t*)dx_masked, drop_p, (const uint64_t*)seed, drop_site);
     DSVG_LAUNCH_CHECK("ffn_bwd_dx");
-    return 0;
-}
-
-extern "C" int dsvg_ffn_bwd_one(const void* dy, const void* h, const void* x, const void* packed_bwd_layer, void* dym,
-                                void* dpre, void* dx, void* dx_masked, int64_t rows, float eps, float gate_scale,
-                                float drop_p, uint32_t site_res, uint32_t site_masked, const void* seed, void* stream) {
-    DSVG_CHECK_ARG(dy && h && x && packed_bwd_layer && dpre && dx, "ffn_bwd_one: null pointer");
-    DSVG_CHECK_ARG(rows > 0 && rows < (1ll << 31) - TOK_PER_WG, "ffn_bwd_one: bad row count");
-    DSVG_CHECK_ARG(!(drop_p > 0.f) || (seed && dym), "ffn_bwd_one: dropout needs a seed and the dym buffer");
-    DSVG_CHECK_ARG(!dx_masked || (drop_p > 0.f && seed), "ffn_bwd_one: the masked output needs dropout and a seed");
-    DSVG_CHECK_ARG((((uintptr_t)dy | (uintptr_t)h | (uintptr_t)x | (uintptr_t)packed_bwd_layer | (uintptr_t)dym |
-                     (uintptr_t)dpre | (uintptr_t)dx | (uintptr_t)dx_masked) & 15) == 0,
-                   "ffn_bwd_one: operands must be 16-byte aligned");
-    const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
-    // ring slots: 4 (default: all 160 KiB of LDS together with the gate staging) or 3 (128 KiB; DSVG_FFN_BWD_ONE_SLOTS=3)
-    static const int slots = getenv("DSVG_FFN_BWD_ONE_SLOTS") ? atoi(getenv("DSVG_FFN_BWD_ONE_SLOTS")) : 4;
-    static const int one_flags = getenv("DSVG_FFN_BWD_ONE_FLAGS") ? atoi(getenv("DSVG_FFN_BWD_ONE_FLAGS")) : 0;
-    hipStream_t st = (hipStream_t)stream;
-    const bool drop = drop_p > 0.f;
-#define DSVG_FFN_BWD_ONE(DR, NB)                                                                                       \
-    do {                                                                                                               \
-        const size_t lds = (size_t)NB * FWD_CHUNK + 8 * 4096;                                                          \
-        DSVG_ENSURE_LDS((ffn_bwd_one_kernel<DR, NB>), lds);                                                            \
-        hipLaunchKernelGGL((ffn_bwd_one_kernel<DR, NB>), dim3(nb), dim3(512), lds, st, (const bf16_t*)dy,              \
-                           (const bf16_t*)h, (const bf16_t*)x, (const bf16_t*)packed_bwd_layer, (bf16_t*)dym,          \
-                           (bf16_t*)dpre, (bf16_t*)dx, (bf16_t*)(DR ? dx_masked : nullptr), (int)rows, eps, gate_scale, \
-                           DR ? drop_p : 0.f, (const uint64_t*)(DR ? seed : nullptr), site_res, site_masked,           \
-                           one_flags);                                                                                 \
-    } while (0)
-    if (slots == 3) { if (drop) DSVG_FFN_BWD_ONE(true, 3); else DSVG_FFN_BWD_ONE(false, 3); }
-    else { if (drop) DSVG_FFN_BWD_ONE(true, 4); else DSVG_FFN_BWD_ONE(false, 4); }
-#undef DSVG_FFN_BWD_ONE
-    DSVG_LAUNCH_CHECK("ffn_bwd_one");
     return 0;
 }
 

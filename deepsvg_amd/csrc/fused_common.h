@@ -92,39 +92,6 @@ __device__ __forceinline__ void dma4(const void* src, uint32_t lds) {
         : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
 }
 
-// the same with the source as (wave-uniform base in SGPRs) + (32-bit per-lane byte offset): one address VGPR instead of two
-__device__ __forceinline__ void dma4s(const void* sbase, uint32_t voff, uint32_t lds) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
-}
-
-// two 1 KiB pieces whose sources are 32 bytes apart per lane (the two K steps of a lane's 64-byte run): source = wave-uniform
-// base (+ 32 for the second piece: a second SGPR pair, so that M0 stays on 1 KiB boundaries and no instruction offset is
-// involved) + 32-bit per-lane offset, destination lds and lds + 1024
-__device__ __forceinline__ void dma2_pair32(const void* sbase, uint32_t voff, uint32_t lds) {
-    uint32_t keep;
-    const char* sbase1 = reinterpret_cast<const char*>(sbase) + 32;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %4\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(sbase1), "s"(lds) : "memory", "scc");
-}
-
 // One transposed 32 x 32 accumulator tile (lane: token row lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the
 // tile) -> the lane's 16 consecutive tile columns 16 (lane >> 5) .. + 15 as x[q][e] = column 4 q + e.
 __device__ __forceinline__ void tile_to_cols16(const floatx16& c, uint32_t (&x)[4][4]) {

@@ -273,4 +273,4 @@ void dsvg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* dsvg_last_error(void) { return g_err; }
-extern "C" int dsvg_version(void) { return 1; }
+extern "C" int dsvg_version(void) { return DSVG_ABI_VERSION; }

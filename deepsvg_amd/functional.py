@@ -34,18 +34,17 @@ FFN_BWD_ORDER = os.environ.get("DSVG_FFN_BWD_ORDER", "1") != "0"
 # dx and its dropout-masked copy from one ffn_bwd_dx launch instead of a drop_apply launch: measured SLOWER (8.52 vs 8.43
 # ms/step: the extra pass sits on the tail of a one-workgroup-per-CU kernel), so it is opt-in
 FFN_BWD_MASKED = os.environ.get("DSVG_FFN_BWD_MASKED", "0") != "0"
-# EXPERIMENTAL (written without a GPU at the end of round 3, first to be run in round 4): drop_apply + gated GEMM + ffn_bwd_dx of
-# the fused-FFN backward as ONE launch (csrc/ffn_fused.hip ffn_bwd_one_kernel): 260 instead of 390 MB per 63 k-row layer
-FFN_BWD_ONE = os.environ.get("DSVG_FFN_BWD_ONE", "0") != "0"
-
 
 # the weight-gradient GEMMs of a layer of the 4096-row stages as one grouped launch (DSVG_GROUP_WGRAD=0: one by one)
 GROUP_WGRAD = os.environ.get("DSVG_GROUP_WGRAD", "1") != "0"
-GROUP_LARGE = os.environ.get("DSVG_GROUP_LARGE", "0") != "0"
 # the decoder layers' bcast_add_bwd also writes the masked copy of dx1 the attention half needs (one read of dx1, no drop_apply launch)
 BCAST_MASKED = os.environ.get("DSVG_BCAST_MASKED", "1") != "0"
 # attention backward of the large stages with the out_proj backward inside (no `dao = dx1m @ Wo` GEMM launch)
 ATTN_BWD_OUTPROJ = os.environ.get("DSVG_ATTN_BWD_OUTPROJ", "1") != "0"
+# ... which only exists on the MFMA attention kernels: the library's A/B knobs that route attention to the VALU kernels
+# (dsvg_attention_mfma_ok, csrc/attention_mfma.hip) must switch it off too instead of failing the backward pass
+_ATTN_VALU = os.environ.get("DSVG_ATTN_VALU") is not None
+_ATTN_MFMA_MIN_S = int(os.environ.get("DSVG_ATTN_MFMA_MIN_S", "2"))
 # training forward of a large dense stage: sequences beyond a multiple of SEQ_ROUND (one round of the chip for the fused
 # attention kernel: 256 CUs x 8 sequences) run on the group-stage layer kernel when there are at most this many (0: never)
 GS_REMAINDER = int(os.environ.get("DSVG_GS_REMAINDER", "512"))
@@ -58,60 +57,6 @@ HEAD_FUSED = os.environ.get("DSVG_HEAD_FUSED", "0") != "0"
 
 _NULL_CTX = contextlib.nullcontext()
 
-# Weight-gradient GEMMs of the second decoder stage on a second stream beside the group stages' layer kernels: a group-stage
-# launch is 128 workgroups bound by the weight stream per CU - half of the CUs and most of the HBM bandwidth idle for ~40 us
-# per layer - and the backward pass runs 8 of them right behind the four large decoder layers, whose 16 token-reducing
-# weight-gradient GEMMs (one workgroup per CU, HBM-bound) depend on nothing that follows.  Beside the token-stationary
-# kernels of the large stages the same GEMMs only compete (scripts/overlap_wgrad_probe.py), so they are QUEUED during those
-# layers and launched when the first group-stage layer's backward begins (scripts/overlap_gs_wgrad_probe.py: 4 layer
-# launches + 6 GEMMs 352 -> 275 us inside one hipGraph).  OFF by default: in the full step's graph the forked branch costs more
-# than it hides on this ROCm - 6.46 -> 6.72 / 6.65 / 6.49 ms with 1 / 2 / 4 layers queued (GPU_MAX_HW_QUEUES 6), 6.6 with 4
-# queues, 10.6 ms with 8 (the same pathology as the two-graph data-parallel step) - results are bit-identical either way
-# (tests/test_model_gpu.py::test_side_stream_weight_gradients_equal_inline_ones).
-SIDE_WGRAD = int(os.environ.get("DSVG_SIDE_WGRAD", "0"))       # number of layers (from the stage's first) that queue theirs
-
-
-class SideWgrad:
-    """queue of weight-gradient launches (closures over their operands) and the stream they run on.  push() during the
-    large layers' backward, launch() when a group stage begins (fork: the side stream waits for everything issued so far),
-    join() before anything reads a parameter gradient (the side stream's deferred reductions, then the main stream waits).
-    The operands stay referenced until join(): a block freed earlier could be handed to a later launch of the main stream
-    that no dependency orders behind the side stream's reads."""
-
-    def __init__(self):
-        self.stream = None
-        self.pending = []
-        self.running = []
-
-    def push(self, fn):
-        self.pending.append((fn, ops._TAG))
-
-    def launch(self):
-        if not self.pending:
-            return
-        if self.stream is None:
-            self.stream = torch.cuda.Stream()
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            for fn, t in self.pending:
-                with (ops.tag(t) if t is not None else _NULL_CTX):
-                    fn()
-        self.running += self.pending
-        self.pending = []
-
-    def join(self):
-        for fn, t in self.pending:          # never reached a group stage: on the calling stream, now
-            with (ops.tag(t) if t is not None else _NULL_CTX):
-                fn()
-        self.pending = []
-        if self.running:
-            with torch.cuda.stream(self.stream):
-                ops.flush_deferred()
-            torch.cuda.current_stream().wait_stream(self.stream)
-            self.running = []
-
-
-
 class Runtime:
     """Per-forward execution context shared by the Functions."""
 
@@ -123,7 +68,6 @@ class Runtime:
         self.seed = seed          # int64[1] device tensor holding the dropout seed of this step
         self.store = store        # ParamStore or None
         self.training = training
-        self.side = None          # SideWgrad of this pass (model.py) or None
 
     def deferring(self):
         """context manager around launches whose reductions write parameter gradients"""
@@ -172,7 +116,7 @@ def _wgrad(rt, param, dy, x, *, a_drop_p=0.0, a_drop_site=0):
     return out
 
 
-def _wbgrad(rt, weight, bias, dy, x, blocks=None, late=False):
+def _wbgrad(rt, weight, bias, dy, x, blocks=None):
     """(dW, db) of y = x W^T + b from dy: db[n] = sum_t dy[t, n] is the row sum of the GEMM's A operand, so it
     rides on the weight-gradient GEMM (an extra MFMA against ones in a few workgroups) whenever that GEMM is
     split over tokens; otherwise a separate column-sum launch.  blocks: target workgroup count of this GEMM (default: a
@@ -182,18 +126,12 @@ def _wbgrad(rt, weight, bias, dy, x, blocks=None, late=False):
     dw = rt.grad_out(weight)
     db = rt.grad_out(bias)
 
-    def run():
-        with rt.deferring(), _wgrad_tag():
-            if split > 1:
-                ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in), split_k=split, rowsum=db)
-            else:
-                ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in))
-                ops.colsum(dy, out=db)
-
-    if late:
-        rt.side.push(run)       # (SideWgrad: launched beside the next group stage)
-    else:
-        run()
+    with rt.deferring(), _wgrad_tag():
+        if split > 1:
+            ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in), split_k=split, rowsum=db)
+        else:
+            ops.gemm(dy, x, a_kc=False, b_kc=False, out=dw.view(n_out, k_in))
+            ops.colsum(dy, out=db)
     return dw, db
 
 
@@ -542,10 +480,9 @@ class LayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rt, x, key_mask, z, l, n_seq, S, n_heads, drop_rate, site0,
                 n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off=None, live=None,
-                tiles=None, causal=False, side=False):
+                tiles=None, causal=False):
         p = rt.p(drop_rate)
         d = x.shape[1]
-        ctx.side = bool(side)      # its weight-gradient GEMMs may wait for the next group stage (SideWgrad)
         scale = float(d // n_heads) ** -0.5
         want_bwd = any(ctx.needs_input_grad)         # (grad mode itself is off inside Function.forward)
         ctx.gs = False
@@ -691,8 +628,6 @@ class LayerFn(torch.autograd.Function):
         inv_keep = ops.keep_scale(p)
         dx1m = None
         if ctx.gs:
-            if rt.side is not None:
-                rt.side.launch()        # the queued weight-gradient GEMMs of the large layers run beside this stage
             # one launch for the whole input-gradient chain of the block (csrc/group_stage.hip); it hands over the token-major
             # operands of the four weight-gradient GEMMs and the LayerNorm parameter gradients
             gs = rt.store.gs(win)
@@ -721,14 +656,10 @@ class LayerFn(torch.autograd.Function):
                 dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1, gb(win))
             return (None, dx, None, dz, None, None, None, None, None, None,
                     dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, None, None, None, None, None,
-                    None, None)
-        # DSVG_GROUP_LARGE: the layer's four token-reducing weight-gradient GEMMs as ONE grouped launch at the end of its
-        # backward pass (their operands are kept alive until then) instead of four launches right behind their producers
-        late = ctx.side and rt.side is not None and rt.defer and not GROUP_LARGE
-        keep = []
-        group = contextlib.ExitStack()
-        if GROUP_LARGE and x.dtype == torch.bfloat16:
-            group.enter_context(rt.grouping())
+                    None)
+        # (round 3 measured, round 4 removed: the layer's four token-reducing weight-gradient GEMMs as one grouped launch at the
+        # end of its backward pass - slower, each product right behind the launch that wrote its operand hits the memory-side
+        # cache - and the same GEMMs queued onto a second stream beside the group stages - slower inside the step's hipGraph)
         if ctx.ffn_fused:
             pb, b1f, w2p = rt.store.ffn(w1)[1:]
             T = x1.shape[0]
@@ -759,12 +690,8 @@ class LayerFn(torch.autograd.Function):
                     # fully fused variant (opt-in, DSVG_FFN_BWD_FUSED=1): hidden tile recomputed from x1, both dropout
                     # masks replayed in the kernel; measured slower than the default below (it writes h, dpre, xh AND dym)
                     dx1, hp, dpre, xh, dym = ops.ffn_bwd(x1, dx2, pb, b1f, 1e-5, p, s0 + 3, s0 + 4, rt.seed)
-                    if late:
-                        rt.side.push(lambda a=dym, b=hp: wgrad2(a, b))
-                        rt.side.push(lambda a=dpre, b=xh: wgrad1(a, b))
-                    else:
-                        wgrad2(dym, hp)
-                        wgrad1(dpre, xh)
+                    wgrad2(dym, hp)
+                    wgrad1(dpre, xh)
                 else:
                     # default: the forward kernel stored h (fragment order) and xh.  dym = residual mask replayed once;
                     # dpre = (dym . W2p) gated by h (h > 0 <=> ReLU passed AND kept) in one GEMM; dx by the fused kernel
@@ -772,38 +699,24 @@ class LayerFn(torch.autograd.Function):
                     # behind the launch that produced its token-major operand (dym, dpre: 65 / 130 MB that are then still
                     # partly in the memory-side cache) instead of at the end
                     hp, xh = h, xn2
-                    if FFN_BWD_ONE:
-                        # EXPERIMENTAL (opt-in): dym, dpre and dx1 from ONE launch (the hidden tile stays on the chip); the two
-                        # weight-gradient GEMMs follow behind it
-                        r = ops.ffn_bwd_one(dx2, hp, x1, pb, inv_keep, 1e-5, p, s0 + 4, rt.seed,
-                                            masked_site=(s0 + 1) if (FFN_BWD_MASKED and p > 0) else None)
-                        dx1, dpre, dym = r[0], r[1], r[2]
-                        if len(r) > 3:
-                            dx1m = r[3]
-                        for fn in ((lambda a=dym, b=hp: wgrad2(a, b)), (lambda a=dpre, b=xh: wgrad1(a, b))):
-                            if late:
-                                rt.side.push(fn)
-                            else:
-                                fn()
+                    # (round 4, MI355X: the three launches below as ONE kernel - dsvg_ffn_bwd_one, the mirror image of ffn_fwd -
+                    # were bit-identical and 13 % faster in isolation (93 -> 80 us at 63 k rows) but 0.4 % SLOWER inside the
+                    # step, where dym already comes from the masked bcast_add_bwd and dpre is read back from the memory-side
+                    # cache; removed.  profiles/r04_experimental_ffn_bwd_one.log, r04_experimental_ab.log)
+                    dym = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
+                    if FFN_BWD_ORDER:
+                        wgrad2(dym, hp)
+                    dpre = ops.gemm(dym, w2p, b_kc=False, gate=hp, gate_scale=inv_keep)
+                    if FFN_BWD_ORDER:
+                        wgrad1(dpre, xh)
+                    # (the same launch also hands over dx1 with the attention residual's dropout mask replayed on it)
+                    if FFN_BWD_MASKED:
+                        dx1, dx1m = ops.ffn_bwd_dx(dpre, x1, dx2, pb, masked=(p, s0 + 1, rt.seed))
                     else:
-                        dym = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
-                        if late:
-                            rt.side.push(lambda a=dym, b=hp: wgrad2(a, b))
-                        elif FFN_BWD_ORDER:
-                            wgrad2(dym, hp)
-                        dpre = ops.gemm(dym, w2p, b_kc=False, gate=hp, gate_scale=inv_keep)
-                        if late:
-                            rt.side.push(lambda a=dpre, b=xh: wgrad1(a, b))
-                        elif FFN_BWD_ORDER:
-                            wgrad1(dpre, xh)
-                        # (the same launch also hands over dx1 with the attention residual's dropout mask replayed on it)
-                        if FFN_BWD_MASKED:
-                            dx1, dx1m = ops.ffn_bwd_dx(dpre, x1, dx2, pb, masked=(p, s0 + 1, rt.seed))
-                        else:
-                            dx1 = ops.ffn_bwd_dx(dpre, x1, dx2, pb)
-                        if not FFN_BWD_ORDER and not late:
-                            wgrad2(dym, hp)
-                            wgrad1(dpre, xh)
+                        dx1 = ops.ffn_bwd_dx(dpre, x1, dx2, pb)
+                    if not FFN_BWD_ORDER:
+                        wgrad2(dym, hp)
+                        wgrad1(dpre, xh)
                 dw1, db1, dw2 = rt.grad_out(w1), rt.grad_out(b1), rt.grad_out(w2)
                 dn2w, dn2b = rt.grad_out(n2w), rt.grad_out(n2b)
                 # (aliases of the gradient tensors: AccumulateGrad adopts a returned gradient only while nobody else
@@ -814,21 +727,19 @@ class LayerFn(torch.autograd.Function):
                     ops.ffn_wgrad_finish_deferred(*fin)     # reads the queued reductions' outputs: runs right after the
                 else:                                       # flush, one launch for all the layers of the backward pass
                     ops.ffn_wgrad_finish(*fin)
-            keep += [hp, dpre, xh, dym]
             del hp, dpre, xh, dym
         else:
             # ---- FFN: x2 = x1 + drop4(h W2^T + b2),  h = drop3(relu(xn2 W1^T + b1)) ----
             # the mask of the residual dropout is replayed ONCE into dx2m; the three consumers read plain data
             with ops.tag("ffn"):
                 dx2m = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
-                dw2, db2 = _wbgrad(rt, w2, b2, dx2m, h, late=late)
+                dw2, db2 = _wbgrad(rt, w2, b2, dx2m, h)
                 dh = ops.gemm(dx2m, rt.w(w2), b_kc=False, gate=h, gate_scale=inv_keep)   # (h > 0) <=> relu passed AND kept
-                dw1, db1 = _wbgrad(rt, w1, b1, dh, xn2, late=late)
+                dw1, db1 = _wbgrad(rt, w1, b1, dh, xn2)
                 dxn2 = ops.gemm(dh, rt.w(w1), b_kc=False)
                 with rt.deferring():
                     dx1, dn2w, dn2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w.detach(), res=dx2,
                                                         dgamma=rt.grad_out(n2w), dbeta=rt.grad_out(n2b))
-            keep += [dx2m, dh]
             del dx2m
         # ---- conditioning adds ----
         dz = dl = dwg = dbg = dwg2 = dbg2 = None
@@ -854,9 +765,10 @@ class LayerFn(torch.autograd.Function):
         # ---- attention: x1 = x + drop1(ao Wo^T + bo) ----
         if dx1m is None:
             dx1m = ops.drop_apply(dx1, p, s0 + 1, rt.seed)
-        dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao, late=late)
+        dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao)
         wob = None
-        if (ATTN_BWD_OUTPROJ and rt.store is not None and x.dtype == torch.bfloat16 and H == 8 and x.shape[1] == 256
+        if (ATTN_BWD_OUTPROJ and not _ATTN_VALU and S >= _ATTN_MFMA_MIN_S
+                and rt.store is not None and x.dtype == torch.bfloat16 and H == 8 and x.shape[1] == 256
                 and not ctx.causal and x.shape[0] >= ATTN_MIN_ROWS and (key_mask is None or key_mask.dtype == torch.int64)
                 and ((seq_off is None and 16 < S <= 32 and x.shape[0] >= n_seq * S) or (seq_off is not None and ctx.tiles is not None))):
             wob = rt.store.attn_bwd(win)
@@ -871,9 +783,8 @@ class LayerFn(torch.autograd.Function):
             else:
                 dqkv = ops.attention_bwd(qkv, key_mask, dao, n_seq, S, H, ctx.scale, p, s0, rt.seed, seq_off=seq_off,
                                          tiles=ctx.tiles)
-        keep.append(dx1m)
         del dx1m
-        dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1, late=late)
+        dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1)
         dxn1 = ops.gemm(dqkv, rt.w(win), b_kc=False)
         dx_out = None
         if live is not None:
@@ -884,11 +795,9 @@ class LayerFn(torch.autograd.Function):
                                                dgamma=rt.grad_out(n1w), dbeta=rt.grad_out(n1b))
         if live is not None:
             dx = dx_full
-        group.close()           # (the grouped launch, if any; `keep` and the locals above held its operands)
-        del keep
         return (None, dx, None, dz, dl, None, None, None, None, None,
                 dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, dwg2, dbg2, None, None, None,
-                None, None)
+                None)
 
 
 # --------------------------------------------------------------------------------------------------

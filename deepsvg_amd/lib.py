@@ -12,6 +12,9 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libdsvg_hip.so")
 
 DSVG_F32 = 0
 DSVG_BF16 = 1
+# == DSVG_ABI_VERSION of include/dsvg.h at the time SIGNATURES below was written: load() refuses a library built from another
+# header (a stale .so with the old argument lists would otherwise be called with a stream where a size is expected)
+ABI_VERSION = 2
 
 c_i32, c_i64, c_u32, c_f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_float
 vp = C.c_void_p
@@ -122,12 +125,10 @@ SIGNATURES = {
     "dsvg_ffn_fwd": (c_i32, [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_f32, c_f32, c_u32, c_u32, vp, c_i32, vp]),
     "dsvg_ffn_bwd": (c_i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_f32, c_f32, c_u32, c_u32, vp, vp]),
     "dsvg_ffn_bwd_dx": (c_i32, [vp, vp, vp, vp, vp, c_i64, c_f32, vp, c_f32, c_u32, vp, vp]),
-    "dsvg_ffn_bwd_one": (c_i32, [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_f32, c_f32, c_f32, c_u32, c_u32, vp, vp]),
     "dsvg_ffn_wgrad_finish": (c_i32, [vp] * 12),
     "dsvg_probe_trread": (c_i32, [vp, vp, vp]),
     "dsvg_attn_pack_bytes": (c_i64, [c_i32]),
     "dsvg_attn_pack": (c_i32, [vp, vp, c_i32, c_i32, c_i32, vp, vp]),
-    "dsvg_attn_block_fwd_stages": (c_i32, [c_i32]),
     "dsvg_attn_block_fwd": (c_i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_i64, vp, vp, vp, vp, vp, vp,
                                     c_f32, c_f32, c_f32, c_u32, c_u32, vp, vp, c_u32, vp]),
     "dsvg_gs_pack_bytes": (c_i64, [c_i32]),
@@ -158,6 +159,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    built = lib.dsvg_version()
+    if built != ABI_VERSION:
+        raise DsvgError(f"{LIB_PATH} was built with DSVG_ABI_VERSION {built}, this binding expects {ABI_VERSION}: rebuild "
+                        f"the library (deepsvg_amd/csrc/build.sh)")
     _lib = lib
     return lib
 

@@ -90,6 +90,11 @@ class SVGLoss(nn.Module):
             names.append("loss_visibility")
 
         cl = command_logits.reshape(-1, cfg.n_commands)      # (the head input's rows: all N G S, or the sequences that ran)
+        if cl.shape[0] != cmd_tgt.numel():
+            # logits of a row prefix (the visible sequences that ran): only meaningful when the targets are in the SAME
+            # (visible-first) order as the head input's rows - the plan guarantees it, checked here rather than assumed
+            assert head is not None and head.get("vf") and head.get("x_vf"), \
+                "command logits cover a row prefix but the targets are not in the stage's visible-first order"
         cmd_t, cmd_wt = cmd_tgt.view(-1)[:cl.shape[0]], cmd_w.view(-1)[:cl.shape[0]]
         joint = head is not None and head.get("cmd_weight") is not None and self.joint_heads
         if not joint:

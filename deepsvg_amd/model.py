@@ -605,15 +605,10 @@ class SVGTransformer(nn.Module):
         self.last_assignment = None  # self-matching configs: (N, Gp) int32 assignment of the last training forward
         self._forced_plan = None
         self._decoder_grads_ready = None    # callback of a data-parallel trainer (TrainStep), see forward()
-        # a trainer that runs the backward pass in two parts (decoder side, then encoder side: TrainStep's split hipGraph)
-        # asks forward() to keep the bottleneck output and its gradient
-        self._keep_bottleneck = False
-        self._bottleneck_out = None
         # queue the parameter-gradient reductions of the backward pass (ops.DEFER): only a trainer that calls
         # ops.flush_deferred() before anything reads a gradient may set it (TrainStep)
         self._defer_wgrad = False
         self._rt = None
-        self._side = None           # Fn.SideWgrad (DSVG_SIDE_WGRAD=1), created with the first deferred training pass
         self._live = None
 
     # ---- runtime plumbing ------------------------------------------------------------------------
@@ -648,21 +643,11 @@ class SVGTransformer(nn.Module):
             ops.advance_step_(None, seed)
         self._rt = Fn.Runtime(self.compute_dtype, seed, self._store, training,
                               defer=self._defer_wgrad and (not ops.PROFILE_ON or ops.PROFILE_KEEP_DEFER))
-        if Fn.SIDE_WGRAD and training and self._rt.defer and device.type == "cuda" and not ops.PROFILE_ON:
-            if self._side is None:
-                self._side = Fn.SideWgrad()
-            self._rt.side = self._side
         return self._rt
-
-    def side_join(self):
-        """the owner of a deferred backward pass (TrainStep) calls this before it flushes: queued / side-stream weight
-        gradients (Fn.SideWgrad) are finished and ordered in front of the calling stream"""
-        if self._side is not None:
-            self._side.join()
 
     # ---- blocks ----------------------------------------------------------------------------------
     def _run_stack(self, rt, stack, x, key_mask, z, n_seq, S, site, seq_off=None, live=None, tiles=None, l=None,
-                   causal=False, side=False):
+                   causal=False):
         """l: label embedding rows [n_seq, dim_label] of a label-conditioned config (memory2 of the reference layers,
         layers/improved_transformer.py:47-49,134-136)"""
         cfg = self.cfg
@@ -684,7 +669,7 @@ class SVGTransformer(nn.Module):
                 L.linear_global.weight if (has_g and not hoisted) else None,
                 L.linear_global.bias if (has_g and not hoisted) else None,
                 L.linear_global2.weight if has_l else None, L.linear_global2.bias if has_l else None,
-                seq_off, live, tiles, causal, side and i < int(Fn.SIDE_WGRAD))
+                seq_off, live, tiles, causal)
         return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps, live)
 
     def make_plan(self, commands_enc, args_enc, commands_dec, want_grad=True, args_dec=None):
@@ -911,8 +896,7 @@ class SVGTransformer(nn.Module):
         self.last_live = (live[0], n_seq) if live is not None else None
         self._live = live
         src = Fn.AddPosFn.apply(rt, None, dec.embedding.PE.pos_embed.weight, n_run, S, PE_DROPOUT, 4, live)
-        # (side: in the backward pass this stage's weight-gradient GEMMs wait for the group stage that follows, Fn.SideWgrad)
-        out = self._run_stack(rt, dec.decoder, src, None, z, n_run, S, 400, live=live, l=l_seq, side=True)
+        out = self._run_stack(rt, dec.decoder, src, None, z, n_run, S, 400, live=live, l=l_seq)
         # the heads read the stage's rows in visible-first order when the loss plan's targets are in that order (_plan): the
         # training step then never gathers back to the caller's group order; anything else that reads a dense logit tensor
         # gets it through `complete` (lazy)
@@ -1042,12 +1026,6 @@ class SVGTransformer(nn.Module):
         if z is None:
             zz = self._encode(rt, commands_enc, args_enc, plan, label)
             zz, mu, logsigma = self._bottleneck(rt, zz)
-            if self._keep_bottleneck and zz.requires_grad:
-                # two-part backward (TrainStep's split hipGraph): the decoder consumes a LEAF copy of the bottleneck output;
-                # the first backward call stops there (leaf.grad), the second one continues from it into the encoder
-                leaf = zz.detach().requires_grad_()
-                self._bottleneck_out = (zz, leaf)
-                zz = leaf
             if self._decoder_grads_ready is not None and zz.requires_grad:
                 # data-parallel trainer: the gradient of the bottleneck output is final exactly when every decoder
                 # parameter gradient is (the decoder is the only consumer of zz) -> its bucket can be all-reduced
@@ -1140,7 +1118,10 @@ class SVGTransformer(nn.Module):
                                          targets=pl["targets"], live=(pl["live"], n_rows),
                                          tgt_commands=commands_dec, tgt_args=args_dec,
                                          slots=(pl.get("slot_lo", 0), pl.get("slot_hi", args_dec.shape[-1])),
-                                         targets_r=pl.get("targets_r"))
+                                         targets_r=pl.get("targets_r"),
+                                         # row order of `targets`: the stage's visible-first order (then `x` / `cmd_logits`
+                                         # may cover only the sequences that ran) or the caller's group order
+                                         vf=bool(pl.get("vf")), x_vf=self._cmd_logits_live is not None)
                 self.last_head_rows = (pl["n_live"], T_dec)
             if getattr(self, "_live", None) is not None:
                 # the live-prefix backward of the second decoder stage is exact under SVGLoss only: deepsvg_amd.SVGLoss

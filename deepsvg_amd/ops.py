@@ -1085,8 +1085,7 @@ def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, s
     are inside packed_fwd_layer / b1f, see ffn_pack).  train: -> (y, h, xh, rstd) with h bf16 [rows, 512] in fragment
     order, xh = (x - mean) * rstd bf16, rstd fp32 [rows] (what the backward pass needs).
     stages: None = the library's choice (half-size workgroups up to 32,768 rows), 2 = half-size workgroups, 3 / 4 = the
-    256-row workgroups with that many weight-ring slots (all bit-identical; tests and probes), 5 = the experimental
-    software-pipelined chunk loop (opt-in: DSVG_FFN_STAGES=5; tests/test_kernels_gpu.py under DSVG_EXPERIMENTAL=1)"""
+    256-row workgroups with that many weight-ring slots (all bit-identical; tests and probes)"""
     _chk(x, packed_fwd_layer, b1f, b2, seed, out)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
     assert packed_fwd_layer.numel() == FFN_FWD_LAYER_ELEMS and packed_fwd_layer.is_contiguous()
@@ -1163,34 +1162,6 @@ def ffn_bwd_dx(dpre, x, dy, packed_bwd_layer, eps=1e-5, masked=None):
     return dx
 
 
-def ffn_bwd_one(dy, h, x, packed_bwd_layer, gate_scale, eps=1e-5, drop_p=0.0, site_res=0, seed=None, masked_site=None):
-    """EXPERIMENTAL (opt-in, include/dsvg.h dsvg_ffn_bwd_one): the input path of the fused-FFN backward in one launch -
-    dym = drop-mask(dy), dpre = (dym . W2) gated by the stored h, dx = dy + LayerNorm'(dpre . W1') - instead of drop_apply +
-    the gated GEMM + ffn_bwd_dx.  h bf16 [rows, 512] in fragment order (ffn_fwd's training output), x = the sub-block's input
-    rows.  -> (dx, dpre, dym[, dxm]); dym is dy itself without dropout; masked_site: also return drop_apply(dx, drop_p,
-    masked_site, seed)"""
-    _chk(dy, h, x, packed_bwd_layer, seed)
-    rows = x.shape[0]
-    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
-    assert dy.dtype == x.dtype and dy.shape == x.shape and dy.is_contiguous()
-    assert h.dtype == x.dtype and tuple(h.shape) == (rows, 512) and h.is_contiguous()
-    assert packed_bwd_layer.numel() == FFN_BWD_LAYER_ELEMS and packed_bwd_layer.is_contiguous()
-    dx = torch.empty_like(x)
-    dpre = torch.empty_like(h)
-    drop = drop_p > 0
-    dym = torch.empty_like(x) if drop else dy
-    dxm = torch.empty_like(x) if (drop and masked_site is not None) else None
-    ev = _prof_begin()
-    _l.check(_l.load().dsvg_ffn_bwd_one(dy.data_ptr(), h.data_ptr(), x.data_ptr(), packed_bwd_layer.data_ptr(),
-                                        dym.data_ptr() if drop else None, dpre.data_ptr(), dx.data_ptr(), _p(dxm), rows,
-                                        float(eps), float(gate_scale), float(drop_p), int(site_res),
-                                        int(masked_site or 0), _p(seed) if drop else None, _stream()), "dsvg_ffn_bwd_one")
-    _prof_end(ev, 4.0 * 256 * 512 * rows, (3 * 512 + 2 * 1024 + (1024 if drop else 0)) * rows, dict(op="ffn_bwd_one", rows=rows))
-    if masked_site is not None:
-        return dx, dpre, dym, (dxm if dxm is not None else dx)
-    return dx, dpre, dym
-
-
 def ffn_wgrad_finish(g1p, db1p, g2p, w1, gamma, beta, dw1, db1, dw2, dgamma, dbeta):
     """(G1p = dpre^T xh, its row sums, G2p = dym^T h) in fragment order -> gradients of linear1.weight / bias,
     linear2.weight, norm.weight, norm.bias (include/dsvg.h)"""
@@ -1246,12 +1217,6 @@ def attn_pack(flat, offs, n_layers, packed=None):
     _l.check(_l.load().dsvg_attn_pack(flat.data_ptr(), offs.data_ptr(), n_layers, 256, 8, packed.data_ptr(), _stream()),
              "dsvg_attn_pack")
     return packed
-
-
-def attn_block_fwd_stages(stages):
-    """process-wide development switch: ring slots of attn_block_fwd's weight stream - 3 (default) or 4 (EXPERIMENTAL: DMA
-    three chunks ahead, counted waits; DSVG_ATTN_STAGES presets it; bit-identical results)"""
-    _l.check(_l.load().dsvg_attn_block_fwd_stages(int(stages)), "dsvg_attn_block_fwd_stages")
 
 
 def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_seq, S, scale, eps=1e-5, drop_p=0.0,

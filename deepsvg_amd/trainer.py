@@ -32,6 +32,16 @@ DEFAULT_WEIGHTS = {   # configs/deepsvg/default_icons.py:65-73 at step 0
 }
 
 
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and a stream that waits on an event
+# holds up every other stream of its queue.  The data-parallel hipGraph step uses five (main, layout plan, loss counts, RCCL's,
+# torch's copy stream): with four queues the plan stream ended up behind RCCL's wait for the previous step's graph, the host's
+# read of the plan blocked for a whole step and could never run ahead of the GPU (one-rank RCCL group: 7.19 ms/step, 6.85 with
+# six queues against 6.71 for the single-GPU step).  The variable only takes effect when it is set before the HIP runtime
+# initialises, so it is a LAUNCH setting of the training process (bench.py sets it; `GPU_MAX_HW_QUEUES=6 python train.py`),
+# not something this library changes behind the caller's back.
+HW_QUEUES_NOTE = ("data-parallel hipGraph step: set GPU_MAX_HW_QUEUES=6 in the environment before the process touches the GPU "
+                  "(with the default of 4 hardware queues the host cannot run ahead of the device, ~+7 % per step)")
+
 _SHARED_STREAMS = {}
 
 
@@ -60,6 +70,9 @@ class TrainStep:
         # development boxes exercise RCCL and the graph / collective / optimiser split below
         self.ddp = self.world > 1 or (force_ddp and dist.is_available() and dist.is_initialized())
         self.use_graph = use_graph
+        if self.ddp and use_graph and "GPU_MAX_HW_QUEUES" not in os.environ:
+            import warnings
+            warnings.warn(HW_QUEUES_NOTE)
         self.exact_global_mean = exact_global_mean and self.ddp
         self._counts = None             # graph + DDP: the global loss counts, filled before every replay
         self._in_own_step = False       # True only while this trainer's captured / replayed step is being enqueued
@@ -77,21 +90,13 @@ class TrainStep:
         self.inputs_resident = False    # see step(): set by callers whose input tensors are complete well before step()
         # gradient all-reduce in two buckets, the decoder's overlapped with the encoder's backward (eager launches only)
         self.overlap_allreduce = os.environ.get("DSVG_DDP_OVERLAP", "1") != "0"
-        # hipGraph + DDP: capture the step as TWO graphs - [forward, loss, decoder-side backward] and [encoder-side backward] -
-        # so that the decoder half of the gradient is all-reduced while the second graph runs, as the eager path does with
-        # its hook.  The cut is the bottleneck output (the decoder's only input): configs where the loss reaches the
-        # encoder by another path too (the VAE's KL term on mu / logsigma) keep the single graph.
-        # Opt-in (DSVG_DDP_SPLIT_GRAPH=1 / split_graph=True): it could only be measured over a ONE-rank RCCL group, where it
-        # costs 0.05 ms/step (6.90 against 6.85 for the single graph) and, with GPU_MAX_HW_QUEUES=8, fell into a 15 ms/step
-        # pathology (deepsvg_amd/__init__.py) - the expected gain at 8 ranks (~60 % of a ~0.4 ms all-reduce hidden) does not
-        # justify that risk unmeasured.
-        self.split_graph = (self.ddp and self.overlap_allreduce and not getattr(model.cfg, "use_vae", False)
-                            and getattr(model.cfg, "encode_stages", 0) > 0
-                            and os.environ.get("DSVG_DDP_SPLIT_GRAPH", "0") != "0")
-        self._zb = None
+        # (rounds 3-4: the step captured as TWO hipGraphs at the bottleneck, the decoder bucket's all-reduce in flight between
+        # them, was measurable on a one-rank RCCL group only - 6.90 against 6.85 ms/step for the single graph, a 15 ms/step
+        # pathology with GPU_MAX_HW_QUEUES=8 - and is removed: with hipGraph the gradient goes out in one all-reduce behind
+        # the graph; the eager path keeps the overlapped decoder bucket)
         self._pending = None
         self._pool = None
-        self._gradless_known, self._gradless_slots = False, []
+        self._gradless_slots, self._gradless_ids = [], set()
         # DSVG_TRACE_STEP=1: host-side time stamps of every step (entry, plan read done, graph launched) in `host_trace`
         self.host_trace = [] if os.environ.get("DSVG_TRACE_STEP") == "1" else None
         self._count_stream = None
@@ -125,7 +130,6 @@ class TrainStep:
     def _launch_decoder_bucket(self):
         """called from the backward pass when every decoder gradient is final (model.forward registers the hook)"""
         lo, hi = self.model.decoder_param_range()
-        self.model.side_join()
         ops.flush_deferred()                # the queued split-K / LayerNorm reductions of the decoder's gradients
         flat_g = self.model.store.grad_buffer(0)
         self._pending = (lo, dist.all_reduce(flat_g[lo:hi], group=self.pg, async_op=True))
@@ -197,61 +201,22 @@ class TrainStep:
         finally:
             model._decoder_grads_ready = None
             model._defer_wgrad = False
-            model.side_join()
             ops.flush_deferred()
-        if not self._gradless_known:
-            # first step: find the parameters without a gradient (torch's AdamW skips them) and zero their slots now, once,
-            # after everything that may be in flight over the buffer has been waited for
-            self._gradless_known = True
-            slots = [model.store._grad_view(p, 0) for p in model.store.params if p.grad is None and p.requires_grad]
-            self._gradless_slots = [v for v in slots if v is not None]
-            if self._gradless_slots:
-                if self._pending is not None:
-                    self._pending[1].wait()
-                for v in self._gradless_slots:
+        # parameters without a gradient in THIS call (torch's AdamW skips them; which ones can depend on the call shape - with /
+        # without label, relative targets): checked on every eager step and inside every capture (a replay runs no Python).
+        # Slots found for the first time are zeroed now, after everything that may be in flight over the buffer has been
+        # waited for, and from the next call on before backward (above)
+        new = [p for p in model.store.params if p.grad is None and p.requires_grad and id(p) not in self._gradless_ids]
+        if new:
+            if self._pending is not None:
+                self._pending[1].wait()
+            for p in new:
+                self._gradless_ids.add(id(p))
+                v = model.store._grad_view(p, 0)
+                if v is not None:
                     v.zero_()
+                    self._gradless_slots.append(v)
         return {k: v.detach() for k, v in ld.items()}
-
-    def _front_a(self, commands, args, label=None, dec=None):
-        """first part of a split step: forward, loss, backward of everything BEHIND the bottleneck output (decoder, heads);
-        afterwards the decoder's range of the flat gradient buffer is final and the bottleneck output holds its gradient"""
-        model = self.model
-        cd, ad = dec if dec is not None else (commands, args)
-        ops.advance_step_(self.step_count, self.seed)
-        for p in model.store.params:
-            p.grad = None
-        for v in self._gradless_slots:
-            v.zero_()
-        model._defer_wgrad = self.defer_reductions
-        model._keep_bottleneck = True
-        try:
-            out = model(commands, args, cd, ad, label=label, params={})
-            ld = self.loss_fn(out, label, weights=self.weights)
-            zb = model._bottleneck_out          # (graph tensor, leaf copy the decoder consumed)
-            ld["loss"].backward(self._seed_grad(ld["loss"]))      # stops at the leaf: decoder-side gradients + leaf.grad
-        finally:
-            model._keep_bottleneck = False
-            model._bottleneck_out = None
-            model._defer_wgrad = False
-            model.side_join()
-            ops.flush_deferred()
-        self._zb = zb
-        return {k: v.detach() for k, v in ld.items()}
-
-    def _front_b(self):
-        """second part: the encoder-side backward from the gradient the first part left on the bottleneck output"""
-        model = self.model
-        (zb, leaf), self._zb = self._zb, None
-        try:        # (the Functions of the forward pass carry their Runtime, deferral setting included)
-            zb.backward(leaf.grad)
-        finally:
-            ops.flush_deferred()
-        if not self._gradless_known:
-            self._gradless_known = True
-            slots = [model.store._grad_view(p, 0) for p in model.store.params if p.grad is None and p.requires_grad]
-            self._gradless_slots = [v for v in slots if v is not None]
-            for v in self._gradless_slots:
-                v.zero_()
 
     def _step_back(self):
         """gradient all-reduce (data parallel), global-norm clip and AdamW on the flat buffers (train.py:99-106)"""
@@ -365,16 +330,8 @@ class TrainStep:
                 for d, s_ in pairs:
                     d.copy_(s_)
         self._note_layout(plan, commands)
-        if isinstance(entry[0], tuple):
-            # split step: [forward, loss, decoder-side backward] -> the decoder's bucket goes out (asynchronously, on RCCL's
-            # stream) -> [encoder-side backward] runs beside it -> the rest of the gradient, clip + AdamW
-            entry[0][0].replay()
-            lo, hi = model.decoder_param_range()
-            self._pending = (lo, dist.all_reduce(model.store.grad_buffer(0)[lo:hi], group=self.pg, async_op=True))
-            entry[0][1].replay()
-        else:
-            self._pending = None
-            entry[0].replay()
+        self._pending = None
+        entry[0].replay()
         if t_trace is not None:
             t_trace.append(time.perf_counter())
             t_trace.append(t_plan)
@@ -405,7 +362,9 @@ class TrainStep:
         process group): bench.py reports it so that a scaling run can be checked to have used N ranks"""
         if not (dist.is_available() and dist.is_initialized()):
             return 1
-        dev = self.model.store.flat.device if self._ready else None
+        # (before the first step the flat buffers are not on the device yet: the NCCL backend needs a device tensor all the same)
+        dev = self.model.store.flat.device if self._ready else torch.device("cuda", torch.cuda.current_device()) \
+            if torch.cuda.is_available() else None
         one = torch.ones(1, dtype=torch.float32, device=dev)
         dist.all_reduce(one, group=self.pg)
         return int(round(one.item()))
@@ -464,7 +423,6 @@ class TrainStep:
         # the warm-up steps (allocator pools, lazy buffers) must not train the model.  Data parallel: the captured part
         # (and its warm-up) is forward + backward only - no collective, see step()
         body = self._step_front if self.ddp else self._step_body
-        split = self.ddp and self.split_graph
         state = [model.store.flat, self.m, self.v, self.step_count, self.seed]
         saved = [t.clone() for t in state]
         try:
@@ -472,11 +430,7 @@ class TrainStep:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    if split:
-                        self._front_a(sc, sa, sl, sdec)
-                        self._front_b()
-                    else:
-                        body(sc, sa, sl, sdec)
+                    body(sc, sa, sl, sdec)
                 for t, s0 in zip(state, saved):
                     t.copy_(s0)
             torch.cuda.current_stream().wait_stream(side)
@@ -486,22 +440,12 @@ class TrainStep:
             # thread-local capture mode: other threads of the process keep calling the runtime while this one captures -
             # with an initialised process group the RCCL watchdog thread polls its work events (hipEventQuery), which the
             # default global mode answers by invalidating the capture and the watchdog by aborting the process
-            if split:
-                # two graphs from ONE autograd graph: the second capture runs the encoder-side backward of the forward pass
-                # the first one recorded (its saved tensors live in the shared pool and are replayed in the same order)
-                g = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
-                with torch.cuda.graph(g[0], pool=self._pool, capture_error_mode="thread_local"):
-                    res = self._front_a(sc, sa, sl, sdec)
-                with torch.cuda.graph(g[1], pool=self._pool, capture_error_mode="thread_local"):
-                    self._front_b()
-            else:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
-                    res = body(sc, sa, sl, sdec)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
+                res = body(sc, sa, sl, sdec)
         finally:
             model._forced_plan = None
             self._in_own_step = False
-            self._zb = None
         return (g, (sc, sa, sl, sdec), splan, res)
 
     def grad_norm(self):

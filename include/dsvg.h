@@ -28,6 +28,12 @@ extern "C" {
 #define DSVG_F32 0
 #define DSVG_BF16 1
 
+/* ABI version: bumped on EVERY change of an exported signature (round 4: 2 - dsvg_ffn_bwd_one and
+ * dsvg_attn_block_fwd_stages removed, round 3's signature changes of dsvg_defer_scope / dsvg_gather_groups /
+ * dsvg_bcast_add_bwd / dsvg_loss_targets / dsvg_scatter_rows counted).  dsvg_version() returns the value the library was
+ * built with; a caller compiled against another header must refuse to run (deepsvg_amd/lib.py does). */
+#define DSVG_ABI_VERSION 2
+
 const char* dsvg_last_error(void);
 int dsvg_version(void);
 
@@ -453,7 +459,8 @@ int dsvg_assemble_batch(const int16_t* rows, int64_t n_rows, const int32_t* slot
  *   dsvg_ffn_fwd    x, y bf16 [rows, 256] (row stride 256); packed_fwd_layer / b1_folded = that layer's slices; b2 fp32;
  *                   dropout sites / seed as everywhere else (draw scheme "v2", private to the fused kernels);
  *                   stages: 0 = default (workgroups of 128 rows up to 32,768 rows, of 256 rows above), 2 = 128-row
- *                   workgroups, 3 / 4 = 256-row workgroups with that many weight-ring slots; all bit-identical.  5 = EXPERIMENTAL (opt-in, not yet run on hardware): 256-row workgroups with a software-pipelined chunk loop (ffn_fwd_pipe_kernel), meant to be bit-identical too.  Training calls pass h_out (bf16 [rows, 512], hidden columns in
+ *                   workgroups, 3 / 4 = 256-row workgroups with that many weight-ring slots; all bit-identical.
+ *                   Training calls pass h_out (bf16 [rows, 512], hidden columns in
  *                   FRAGMENT ORDER: position p(j) = j with bits 2 and 3 swapped), xh_out = (x - mean) * rstd (bf16
  *                   [rows, 256]) and rstd_out (fp32 [rows]) for the backward pass; inference passes NULL for all three.
  * Buffers are caller-owned; all work is enqueued on `stream`. */
@@ -483,15 +490,6 @@ int dsvg_ffn_bwd(const void* x, const void* dy, const void* packed_bwd_layer, co
 int dsvg_ffn_bwd_dx(const void* dpre, const void* x, const void* dy, const void* packed_bwd_layer, void* dx,
                     int64_t rows, float eps, void* dx_masked, float drop_p, uint32_t drop_site, const void* seed,
                     void* stream);
-/* EXPERIMENTAL (opt-in, written without a GPU at the end of round 3): dsvg_drop_apply + the gated input-gradient GEMM +
- * dsvg_ffn_bwd_dx of the default backward as ONE launch.  dy = dL/dy bf16 [rows,256]; h = the forward kernel's h_out (bf16
- * [rows,512], fragment order); x = the sub-block's input rows; gate_scale = 1 / keep probability as the forward pass applied
- * it (dsvg_keep_scale); outputs: dym = dy with the residual site's dropout mask replayed (NULL without dropout: dym is dy),
- * dpre (bf16 [rows,512], fragment order), dx = dy + LayerNorm'(dpre . W1'), dx_masked (optional) = dx with the mask of
- * site_masked replayed.  The weight-gradient GEMMs (dW2 from dym and h, dW1' from dpre and xh) follow as before. */
-int dsvg_ffn_bwd_one(const void* dy, const void* h, const void* x, const void* packed_bwd_layer, void* dym, void* dpre,
-                     void* dx, void* dx_masked, int64_t rows, float eps, float gate_scale, float drop_p, uint32_t site_res,
-                     uint32_t site_masked, const void* seed, void* stream);
 int dsvg_ffn_wgrad_finish(const float* g1p, const float* db1p, const float* g2p, const float* w1, const float* gamma,
                           const float* beta, float* dw1, float* db1, float* dw2, float* dgamma, float* dbeta,
                           void* stream);
@@ -528,11 +526,6 @@ int dsvg_gs_debug_clock(void* buf);
 int64_t dsvg_attn_pack_bytes(int32_t n_layers);
 int dsvg_attn_pack(const float* flat_f32, const int64_t* offs, int32_t n_layers, int32_t d_model, int32_t n_heads,
                    void* packed, void* stream);
-/* development switch: ring slots of dsvg_attn_block_fwd's weight stream, process-wide - 3 (default: every ring
- * synchronisation drains the wave's memory operations) or 4 (EXPERIMENTAL, not yet run on hardware: DMA three chunks ahead,
- * counted waits, the training stores stay in flight across the synchronisations; results are meant to be bit-identical).
- * The environment variable DSVG_ATTN_STAGES presets it. */
-int dsvg_attn_block_fwd_stages(int32_t stages);
 int dsvg_attn_block_fwd(const void* x, const void* packed_layer, const float* in_bias, const float* out_bias,
                         const float* gamma, const float* beta, const uint64_t* key_mask, const int32_t* seq_off,
                         const int32_t* tile_first, int64_t n_seq, int32_t S, int64_t rows, void* x1, void* xn_out,

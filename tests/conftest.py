@@ -16,13 +16,6 @@ def pytest_configure(config):
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
-# Kernels written without a GPU at hand (end of round 3) are opt-in in the library and their tests are opt-in here: they run
-# with DSVG_EXPERIMENTAL=1 (scripts/gpu_experimental.sh) and are skipped by the default `-m gpu` run until they have been
-# validated on a MI355X once.
-experimental = pytest.mark.skipif(os.environ.get("DSVG_EXPERIMENTAL", "0") == "0",
-                                  reason="unvalidated experimental kernel: set DSVG_EXPERIMENTAL=1")
-
-
 def install_emulated_ops():
     """Replace every function of deepsvg_amd.ops by its plain-torch restatement (CPU host-logic tests only)."""
     import deepsvg_amd.ops as ops

@@ -48,7 +48,8 @@ def test_gemm_desc_layout_matches_header():
 
 def test_error_reporting_without_gpu():
     L = lib.load()
-    assert L.dsvg_version() >= 1
+    hdr = open(os.path.join(ROOT, "include", "dsvg.h")).read()
+    assert L.dsvg_version() == lib.ABI_VERSION == int(re.search(r"#define DSVG_ABI_VERSION (\d+)", hdr).group(1))
     rc = L.dsvg_gemm(None, None)
     assert rc != 0 and b"null desc" in L.dsvg_last_error()
     with pytest.raises(lib.DsvgError):

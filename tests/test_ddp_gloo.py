@@ -192,36 +192,3 @@ def test_graph_cache_is_bounded_lru():
     assert ts._graph_entry(4, lambda: cap(4))[1] and list(ts._graphs) == [3, 1, 4]      # 2 (the oldest) is gone
     assert ts._graph_entry(2, lambda: cap(2))[1] and list(ts._graphs) == [1, 4, 2]      # re-captured, 3 evicted
     assert made == [1, 2, 3, 4, 2] and ts.graphs_captured == 5 and ts.graphs_evicted == 2
-
-
-def test_two_part_backward_equals_one_backward():
-    """The split hipGraph step of the data-parallel trainer runs the backward pass in two parts - everything behind the
-    bottleneck output (decoder, heads), then the encoder side from the gradient left on that tensor - so that the decoder's
-    half of the flat gradient can be all-reduced while the second part runs.  Same kernels in the same order: the flat
-    gradient must be IDENTICAL to the one-pass backward, and the decoder's range must be final after part one."""
-    from tests.conftest import install_emulated_ops, restore_ops
-    saved = install_emulated_ops()
-    try:
-        from deepsvg_amd.trainer import TrainStep
-        from deepsvg_amd.synthetic import make_batch
-        commands, args = make_batch(6, seed=9)
-        grads = {}
-        for split in (False, True):
-            cfg, model, loss_fn = _make("hier")
-            ts = TrainStep(model, loss_fn, lr=1e-2)
-            ts._setup(commands.device)
-            if split:
-                ld = ts._front_a(commands, args)
-                lo, hi = model.decoder_param_range()
-                after_a = model.store.grad_buffer(0).clone()
-                assert all(p.grad is None for n, p in model.named_parameters() if not n.startswith("decoder."))
-                ts._front_b()
-                assert torch.equal(after_a[lo:hi], model.store.grad_buffer(0)[lo:hi]), "part two touched the decoder's bucket"
-            else:
-                ld = ts._step_front(commands, args)
-            grads[split] = (model.store.grad_buffer(0).clone(), float(ld["loss"]))
-            assert all(p.grad is not None for p in model.parameters())
-        assert grads[True][1] == grads[False][1]
-        assert torch.equal(grads[True][0], grads[False][0])
-    finally:
-        restore_ops(saved)

@@ -467,42 +467,6 @@ def test_fused_ffn_path_matches_unfused_with_emulated_ops(emulated_ops):
     assert med < 0.05, med
 
 
-@pytest.mark.parametrize("masked", [False, True])
-def test_one_launch_ffn_backward_wiring_with_emulated_ops(emulated_ops, monkeypatch, masked):
-    """DSVG_FFN_BWD_ONE (experimental kernel, opt-in): the host wiring of the one-launch input path - argument order, the
-    dropout sites, the weight-gradient GEMMs behind it, the optional masked copy for the attention half - reproduces the
-    default three-launch path's loss and gradients with dropout on (same seed: the masks are functions of site and id)"""
-    from deepsvg_amd.synthetic import make_batch
-    import deepsvg_amd.functional as Fn
-    cfg = H.build_cfg("hier")
-    cfg.n_layers = cfg.n_layers_decode = 2
-    c, a = make_batch(5, seed=4)
-    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 5)
-    monkeypatch.setattr(Fn, "FFN_MIN_ROWS", 0)
-    monkeypatch.setattr(Fn, "FFN_BWD_MASKED", masked)
-    from deepsvg_amd import ops
-    res, calls = {}, []
-    real = ops.ffn_bwd_one
-    monkeypatch.setattr(ops, "ffn_bwd_one", lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1])
-    for one in (False, True):
-        monkeypatch.setattr(Fn, "FFN_BWD_ONE", one)
-        n_before = len(calls)
-        model = deepsvg_amd.SVGTransformer(cfg).train()
-        model.load_state_dict(sd)
-        model.set_compute_dtype(torch.bfloat16)
-        model.seed_tensor(torch.device("cpu")).fill_(1234567)
-        model._own_seed = False                      # (both runs draw the same masks)
-        out = model(c, a, c, a, params={})
-        assert model.store._ffn is not None
-        ld = deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
-        ld["loss"].backward()
-        res[one] = (float(ld["loss"].detach()), {n: p.grad.clone() for n, p in model.named_parameters()})
-        assert (len(calls) - n_before > 0) == one        # every fused-FFN layer's backward took the one-launch path, or none
-    assert res[True][0] == res[False][0]
-    worst, name = max((H.rel_l2(res[True][1][n], res[False][1][n]), n) for n in res[True][1])
-    assert worst < 2e-2, (worst, name)
-
-
 def test_fused_attention_path_matches_unfused_with_emulated_ops(emulated_ops):
     """bf16 compute, every layer's attention sub-block through attn_pack / attn_block_fwd (packed tiles of the first
     encoder stage, dense key-masked group stages, the live-prefix decoder stage): with the emulated ops the fused call is

@@ -7,7 +7,6 @@ import torch
 
 from deepsvg_amd import ops
 from tests import torch_ops_ref as R
-from tests.conftest import experimental
 
 pytestmark = pytest.mark.gpu
 
@@ -961,27 +960,6 @@ def test_ffn_fwd_workgroup_variants_agree(gpu_device, rows):
             assert torch.equal(a, b)
 
 
-@experimental
-@pytest.mark.parametrize("rows", [100, 4096 + 37, 40000, 126976])
-def test_ffn_fwd_pipelined_variant_agrees(gpu_device, rows):
-    """stages = 5 (ffn_fwd_pipe_kernel: E1 of chunk k in the shadow of G2(k - 1)'s MFMAs, split W1 / W2 streams) performs the
-    same operations on every element in the same order as the 256-row kernel: every output is bit-identical, with and
-    without dropout, inference and training variants; the timing probe's shortened loop (>= 2 chunks) is not exercised"""
-    flat, offs, x, b2 = _ffn_setup(rows, seed=rows + 3)
-    pf, _, b1f = ops.ffn_pack(flat, offs, 2)
-    seed = _seed_tensor(0x1122334455667788)
-    for layer in (0, 1):
-        pl = pf[layer * ops.FFN_FWD_LAYER_ELEMS:(layer + 1) * ops.FFN_FWD_LAYER_ELEMS]
-        for p in (0.1, 0.0):
-            for train in (False, True):
-                want = ops.ffn_fwd(x, pl, b1f[layer], b2, 1e-5, p, 403, 404, seed, train=train, stages=4)
-                got = ops.ffn_fwd(x, pl, b1f[layer], b2, 1e-5, p, 403, 404, seed, train=train, stages=5)
-                names = ("y", "h", "xh", "rstd") if train else ("y",)
-                for name, a, b in zip(names, want if train else (want,), got if train else (got,)):
-                    assert torch.equal(a, b), (rows, layer, p, train, name,
-                                               (a.float() - b.float()).abs().max().item())
-
-
 def test_ffn_fwd_equals_unfused_kernels(gpu_device):
     """eval mode: the fused kernel against the three launches it replaces (layernorm_fwd + 2 GEMMs on the bf16 weights);
     the fused path rounds W1 diag(gamma) and the un-scaled normalised rows to bf16 instead of W1 and the scaled rows"""
@@ -1138,48 +1116,6 @@ def test_ffn_training_path_matches_reference(gpu_device, drop_p):
     _close(dx_f, dx, 2e-2, "fused vs training-path dx")
 
 
-@experimental
-@pytest.mark.parametrize("rows", [100, 2000, 4096 + 37, 40000])
-@pytest.mark.parametrize("drop_p", [0.0, 0.1])
-def test_ffn_bwd_one_launch_matches_the_three_launch_path(gpu_device, rows, drop_p):
-    """dsvg_ffn_bwd_one (dym, gated dpre and dx from one launch, the hidden tile on chip) against the default backward's three
-    launches on the same inputs - drop_apply -> gated GEMM on W2p -> ffn_bwd_dx: dym bit for bit (the same draws on the same
-    values), dpre and dx up to the summation order of the two products, the gate's zero pattern exactly; and the optional
-    masked copy of dx against drop_apply of the first output"""
-    flat, offs, x, b2 = _ffn_setup(rows, seed=rows + 5)
-    w2p = torch.empty((2, 256, 512), dtype=torch.bfloat16, device=DEV)
-    pf, pb, b1f = ops.ffn_pack(flat, offs, 2, w2p=w2p)
-    g = torch.Generator(device="cpu").manual_seed(rows)
-    dy = torch.randn(rows, 256, generator=g).to(DEV).to(torch.bfloat16)
-    seed = _seed_tensor(0x0123456789ABCDE1)
-    inv_keep = ops.keep_scale(drop_p)
-    for layer in (0, 1):
-        pl = pf[layer * ops.FFN_FWD_LAYER_ELEMS:(layer + 1) * ops.FFN_FWD_LAYER_ELEMS]
-        pbl = pb[layer * ops.FFN_BWD_LAYER_ELEMS:(layer + 1) * ops.FFN_BWD_LAYER_ELEMS]
-        y, h, xh, rstd = ops.ffn_fwd(x, pl, b1f[layer], b2, 1e-5, drop_p, 403, 404, seed, train=True)
-        dym0 = ops.drop_apply(dy, drop_p, 404, seed)
-        dpre0 = ops.gemm(dym0, w2p[layer], b_kc=False, gate=h, gate_scale=inv_keep)
-        dx0 = ops.ffn_bwd_dx(dpre0, x, dy, pbl)
-        dx, dpre, dym = ops.ffn_bwd_one(dy, h, x, pbl, inv_keep, 1e-5, drop_p, 404, seed)
-        torch.cuda.synchronize()
-        if drop_p > 0:
-            assert torch.equal(dym, dym0), (rows, layer)
-        else:
-            assert dym is dy
-        assert torch.isfinite(dpre.float()).all() and torch.isfinite(dx.float()).all()
-        assert torch.equal(dpre == 0, dpre0 == 0) or ((dpre == 0) != (dpre0 == 0)).float().mean().item() < 1e-4
-        assert torch.count_nonzero(dpre[h <= 0]) == 0                    # a closed gate passes nothing
-        _close(dpre, dpre0, 1.5e-2, f"dpre (rows {rows}, layer {layer})")
-        _close(dx, dx0, 2e-2, f"dx (rows {rows}, layer {layer})")
-        if drop_p > 0:
-            dx_b, dpre_b, dym_b, dxm = ops.ffn_bwd_one(dy, h, x, pbl, inv_keep, 1e-5, drop_p, 404, seed, masked_site=77)
-            assert torch.equal(dx_b, dx) and torch.equal(dpre_b, dpre) and torch.equal(dym_b, dym)
-            assert torch.equal(dxm, ops.drop_apply(dx, drop_p, 77, seed))
-
-
-# ----------------------------------------------------------------------------------------------------
-# fused attention sub-block (csrc/attn_fused.hip)
-# ----------------------------------------------------------------------------------------------------
 def _attn_setup(seed=0, n_layers=2):
     """fp32 'master' buffer with n_layers x (in_proj_weight, out_proj.weight) and the offsets table dsvg_attn_pack takes;
     biases and the LayerNorm affine of the layer under test"""
@@ -1331,42 +1267,6 @@ def test_attn_block_fwd_against_fp32_torch(gpu_device, kind, p):
         err = (g[r].float() - w[r]).abs().mean().item()
         ref = w[r].abs().mean().item()
         assert err <= mean_tol * ref + 1e-12, f"{what}: mean abs error {err:.3e} = {err / ref:.2e} of the mean magnitude"
-
-
-@experimental
-@pytest.mark.parametrize("kind", ["packed", "dense31", "dense32_masked", "dense8_masked_tail", "dense10", "tiny_dense5",
-                                  "one_sequence_32", "packed_extremes"])
-@pytest.mark.parametrize("p", [0.0, 0.1])
-def test_attn_block_fwd_four_slot_variant_agrees(gpu_device, kind, p):
-    """dsvg_attn_block_fwd_stages(4): 4 ring slots, DMA three chunks ahead, counted waits (the training stores stay in
-    flight across the ring synchronisations), the out_proj rows stored behind both tiles' arithmetic - the same operations
-    on every element: every output bit-identical to the 3-slot kernel, inference and training, with the per-sequence add"""
-    flat, offs, prm = _attn_setup(seed=13)
-    rows, n_seq, S, km, seq_off, tiles, real = _attn_case(kind, seed=23)
-    x = (_rand(rows, 256, seed=33) * 1.5 + 0.3).to(torch.bfloat16)
-    img = ops.attn_pack(flat, offs, 2)
-    seed = _seed_tensor(0x0BADC0FFEE12345B)
-    scale = 32 ** -0.5
-    gadd = None if seq_off is not None else (_rand(n_seq, 256, seed=43) * 0.5).to(torch.bfloat16)
-    try:
-        for layer in (0, 1):
-            packed = img[layer * ops.ATTN_LAYER_ELEMS:(layer + 1) * ops.ATTN_LAYER_ELEMS]
-            for sa in ((None,) if gadd is None else (None, gadd)):
-                for train in (False, True):
-                    outs = {}
-                    for stages in (3, 4):
-                        ops.attn_block_fwd_stages(stages)
-                        r = ops.attn_block_fwd(x, packed, prm["in_bias"], prm["out_bias"], prm["gamma"], prm["beta"], km, n_seq,
-                                               S, scale, 1e-5, p, 7, 8, seed, seq_off=seq_off, tiles=tiles, train=train,
-                                               seq_add=sa, site_seq_add=9)
-                        torch.cuda.synchronize()
-                        outs[stages] = r if train else (r,)
-                    for i, (a, b) in enumerate(zip(outs[3], outs[4])):
-                        a, b = a[:real], b[:real]       # (the rows of the sequences; bucket padding behind them is not compared)
-                        assert torch.equal(a, b), (kind, p, layer, train, sa is not None, i,
-                                                   (a.float() - b.float()).abs().max().item())
-    finally:
-        ops.attn_block_fwd_stages(3)
 
 
 @pytest.mark.parametrize("kind", ["packed", "dense31", "dense32_masked", "dense8_masked_tail", "dense10", "tiny_dense5",

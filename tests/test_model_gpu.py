@@ -12,7 +12,6 @@ from deepsvg_amd.synthetic import make_batch
 from oracle import svg_transformer_oracle as O
 from tests import helpers as H
 
-from tests.conftest import experimental
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -498,24 +497,16 @@ def test_data_parallel_step_over_rccl_one_rank(gpu_device):
         batches = [tuple(t.to(DEV) for t in make_batch(64, seed=s_)) for s_ in (5, 6, 5)]
         runs = {}
         for name, kw in (("plain", dict(use_graph=True)), ("ddp_graph", dict(use_graph=True, force_ddp=True)),
-                         ("ddp_graph_one", dict(use_graph=True, force_ddp=True)),
                          ("ddp_eager", dict(use_graph=False, force_ddp=True))):
             torch.manual_seed(7)
             model = _hip_model(cfg, sd, torch.bfloat16).train()
             ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=1e-3, **kw)
             assert ts.ddp == ("force_ddp" in kw)
-            # (split_graph is opt-in: DSVG_DDP_SPLIT_GRAPH=1) two graphs per bucket with the decoder bucket's all-reduce between
-            # them, against the whole forward + backward as one graph with one all-reduce behind it
-            ts.split_graph = name == "ddp_graph"
             losses = [float(ts.step(c, a)["loss"]) for c, a in batches]
             torch.cuda.synchronize()
             runs[name] = (losses, model.store.flat.detach().clone(), ts.grad_norm())
             if name.startswith("ddp_graph"):
                 assert len(ts._graphs) >= 1 and ts._counts is not None
-                assert all(isinstance(e[0], tuple) == (name == "ddp_graph") for e in ts._graphs.values())
-        # the split step issues the same kernels on the same data in the same order: identical to the one-graph step
-        assert runs["ddp_graph"][0] == runs["ddp_graph_one"][0]
-        assert torch.equal(runs["ddp_graph"][1], runs["ddp_graph_one"][1])
         for name in ("ddp_graph", "ddp_eager"):
             for a, b in zip(runs[name][0], runs["plain"][0]):
                 assert abs(a - b) <= 2e-2 * abs(b), (name, runs[name][0], runs["plain"][0])
@@ -560,76 +551,6 @@ def test_deferred_gradient_reductions_equal_immediate_ones(gpu_device, dtype, us
     err = (g1 - g0).abs().max().item()
     assert err <= 3e-6 * g0.abs().max().item() + 1e-9, f"deferred vs immediate gradient: {err:.3e} (max |g| {g0.abs().max().item():.3e})"
     assert abs(runs[True][2] - runs[False][2]) <= 1e-5 * runs[False][2]
-
-
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_side_stream_weight_gradients_equal_inline_ones(gpu_device, use_graph, monkeypatch):
-    """DSVG_SIDE_WGRAD: the weight-gradient GEMMs of the second decoder stage are queued during that stage's backward and run
-    on a second stream beside the group stages' layer kernels (functional.SideWgrad).  Same launches on the same operands,
-    the same reduction order: loss and flat gradient are bit-identical to the inline order, eagerly and in a replayed
-    hipGraph, over two different batches (a stale or racing gradient would show)."""
-    from deepsvg_amd import functional as Fn
-    from deepsvg_amd.trainer import TrainStep
-    cfg = H.build_cfg("hier")
-    cfg.dropout = 0.1
-    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 78)
-    batches = [tuple(t.to(DEV) for t in make_batch(640, seed=sd_)) for sd_ in (31, 32, 31)]
-    runs = {}
-    for side in (False, True):
-        monkeypatch.setattr(Fn, "SIDE_WGRAD", 4 if side else 0)
-        torch.manual_seed(98)
-        model = _hip_model(cfg, sd, torch.bfloat16).train()
-        ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=0.0, use_graph=use_graph)
-        grads = []
-        for c, a in batches:
-            ld = ts.step(c, a)
-            torch.cuda.synchronize()
-            grads.append((float(ld["loss"]), model.store.grad_buffer(0).detach().clone()))
-        assert (model._side is not None) == side
-        runs[side] = grads
-    for (l0, g0), (l1, g1) in zip(runs[False], runs[True]):
-        assert l0 == l1
-        assert g0.abs().max().item() > 0 and torch.equal(g0, g1)
-
-
-@experimental
-@pytest.mark.parametrize("which", ["ffn_fwd_stages5", "attn_4_slots", "ffn_bwd_one", "all"])
-def test_experimental_kernels_in_the_train_step(gpu_device, which, monkeypatch):
-    """the opt-in kernels of the end of round 3 inside the real training step (bf16, dropout 0.1, 640 icons: the large stages
-    run the fused kernels), eagerly and over two batches: ffn_fwd stages = 5 and attn_block_fwd with 4 ring slots are
-    bit-identical to the default kernels - loss and flat gradient must be EQUAL -, ffn_bwd_one changes the summation order of
-    two products - loss equal (the forward pass is untouched), gradient within bf16 rounding"""
-    from deepsvg_amd import functional as Fn, ops
-    from deepsvg_amd.trainer import TrainStep
-    cfg = H.build_cfg("hier")
-    cfg.dropout = 0.1
-    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 79)
-    batches = [tuple(t.to(DEV) for t in make_batch(640, seed=sd_)) for sd_ in (41, 42)]
-    runs = {}
-    try:
-        for on in (False, True):
-            monkeypatch.setattr(ops, "_FFN_STAGES", 5 if (on and which in ("ffn_fwd_stages5", "all")) else 0)
-            ops.attn_block_fwd_stages(4 if (on and which in ("attn_4_slots", "all")) else 3)
-            monkeypatch.setattr(Fn, "FFN_BWD_ONE", on and which in ("ffn_bwd_one", "all"))
-            torch.manual_seed(99)
-            model = _hip_model(cfg, sd, torch.bfloat16).train()
-            ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=0.0, use_graph=False)
-            grads = []
-            for c, a in batches:
-                ld = ts.step(c, a)
-                torch.cuda.synchronize()
-                grads.append((float(ld["loss"]), model.store.grad_buffer(0).detach().clone()))
-            runs[on] = grads
-    finally:
-        ops.attn_block_fwd_stages(3)
-    for (l0, g0), (l1, g1) in zip(runs[False], runs[True]):
-        assert l0 == l1, (which, l0, l1)
-        assert g0.abs().max().item() > 0 and torch.isfinite(g1).all()
-        if which in ("ffn_fwd_stages5", "attn_4_slots"):
-            assert torch.equal(g0, g1), (which, (g0 - g1).abs().max().item())
-        else:
-            rel = ((g0 - g1).norm() / g0.norm()).item()
-            assert rel < 2e-2, (which, rel)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

@@ -844,21 +844,6 @@ def ffn_bwd_dx(dpre, x, dy, packed_bwd_layer, eps=1e-5, masked=None):
     return dx.to(x.dtype)
 
 
-def ffn_bwd_one(dy, h, x, packed_bwd_layer, gate_scale, eps=1e-5, drop_p=0.0, site_res=0, seed=None, masked_site=None):
-    """the one-launch input path of the fused-FFN backward (csrc/ffn_fused.hip ffn_bwd_one_kernel): dym, dpre gated by the
-    stored h (fragment order), dx"""
-    _, W2 = _ffn_weights(packed_bwd_layer)
-    dym = drop_apply(dy, drop_p, site_res, seed) if drop_p > 0 else dy
-    dh = _f(dym) @ _f(W2)                                       # [rows, 512], natural unit order
-    dhp = torch.empty_like(dh)
-    dhp[:, _ffn_frag_perm(x.device)] = dh                       # position p(j) holds unit j, like h
-    dpre = torch.where(_f(h) > 0, dhp * gate_scale, torch.zeros_like(dhp)).to(x.dtype)
-    dx = ffn_bwd_dx(dpre, x, dy, packed_bwd_layer, eps)
-    if masked_site is not None:
-        return dx, dpre, dym, (drop_apply(dx, drop_p, masked_site, seed) if drop_p > 0 else dx)
-    return dx, dpre, dym
-
-
 def ffn_wgrad_finish(g1p, db1p, g2p, w1, gamma, beta, dw1, db1, dw2, dgamma, dbeta):
     perm = _ffn_frag_perm(g1p.device)
     G1 = g1p.view(512, 256)[perm]                   # G1[j] = G1p[p(j)]
