@@ -19,6 +19,12 @@ Rank 0 prints ONE JSON line (contract in the task statement).  The timed loop ro
                forward, x3 trained; skipped padding and recomputation are not counted) / that time / 2.5 PFLOP/s.
                `fused_fwd_kernel` is the dominant kernel alone; `traffic` is a committed rocprofv3 --pmc measurement.
   fp32         the parity path (fp32 storage, exact-fp32 MFMA): ms/step and icons/s of the same step, same batch
+  dense_layout the same bf16 step with every exact work-skipping layout OFF (padded encoder, all decoder groups, dense head):
+               like for like with the padded work `torch_rocm_reference` does
+  secondary    BASELINE configs[3] / [4] as short legs: C4 one-stage train step, C5 one-shot and autoregressive decode of 8192
+  in_kernel_clock / config.clock_mhz   the shader clock: sysfs sclk sampled during the timed loop, and s_memtime ticks per
+               s_memrealtime microsecond inside ffn_fwd (the chip clocks to its power budget: `fused_fwd_kernel` also
+               carries its fraction of the MFMA peak at the clock it actually ran at)
   torch_rocm_reference   the reference's step as stock PyTorch ops (the oracle module: aten / rocBLAS / MIOpen kernels,
                fp32, dropout on) on the SAME MI355X and batch: what the hand-written kernels buy over aten on this chip
   cpu_baseline the CPU restatement of the reference step (oracle/, kind "port": /root/reference does not exist on the GPU
@@ -68,6 +74,7 @@ def parse():
     ap.add_argument("--batches", type=int, default=8, help="distinct device-resident batches rotated through the loop")
     ap.add_argument("--no-torch-ref", action="store_true", help="skip the stock-PyTorch-on-this-GPU sub-record")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-path sub-record")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the dense_layout / secondary / in-kernel clock legs")
     ap.add_argument("--cpu-leg", type=int, default=0, help="internal: run one CPU-baseline leg on this many threads and exit")
     return ap.parse_args()
 
@@ -187,6 +194,181 @@ def torch_rocm_reference(cfg, sd, batch, device, dropout, steps=5):
             "dtype": "fp32", "dropout": dropout, "loss": round(float(loss), 4),
             "what": "oracle/svg_transformer_oracle.py (line-by-line restatement of the reference model + SVGLoss, pinned to "
                     "it by tests/golden) with torch.optim.AdamW and clip_grad_norm_, stock aten kernels on this GPU"}
+
+
+def dense_layout_leg(cfg, sd_cpu, batches, device, steps=5):
+    """the same train step with every exact work-skipping layout switched OFF (padded encoder rows, all 8 groups of the
+    second decoder stage forward and backward, dense argument head): the like-for-like number against the reference's padded
+    work (`torch_rocm_reference` does exactly that work), hipGraph replay, same batches"""
+    import deepsvg_amd
+    from deepsvg_amd.trainer import TrainStep
+    m = deepsvg_amd.SVGTransformer(cfg)
+    m.load_state_dict(sd_cpu)
+    m.to(device).set_compute_dtype(torch.bfloat16)
+    m.pack_encoder = False
+    m.skip_invisible_backward = False
+    m.skip_invisible_forward = False
+    m.compact_head_backward = False
+    m.train()
+    ts = TrainStep(m, deepsvg_amd.SVGLoss(cfg).to(device), lr=1e-3, grad_clip=1.0, use_graph=True)
+    ts.inputs_resident = True
+    nb = min(len(batches), 4)
+    for i in range(nb + 2):
+        ts.step(*batches[i % nb])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ld = ts.step(*batches[i % nb])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n = batches[0][0].shape[0]
+    return {"ms_per_step": round(dt * 1e3, 3), "icons_per_s": round(n / dt, 1), "steps": steps, "loss": round(float(ld["loss"]), 4),
+            "switches": "pack_encoder=0 skip_invisible_backward=0 skip_invisible_forward=0 compact_head_backward=0 "
+                        "(= DSVG_PACK_ENCODER=0 DSVG_SKIP_INVISIBLE=0 DSVG_SKIP_INVISIBLE_FWD=0 DSVG_COMPACT_HEAD=0)",
+            "what": "every row of the reference's padded (N, G, S) layout is computed, forward and backward"}
+
+
+def secondary_legs(device):
+    """BASELINE configs[3] and [4] as short legs (scripts/secondary_bench.py has the long form): C4 one-stage train step
+    (OneStageOneShot, max_total_len 50, 512 icons), C5 decode-only of 8192 latents - one-shot arg-max (hierarchical_ordered)
+    and autoregressive command sampling over the q|k|v cache (Sketchformer, max_total_len 50)"""
+    import deepsvg_amd
+    from deepsvg_amd import config as C
+    from deepsvg_amd.synthetic import make_batch_onestage, det_state_dict
+    from deepsvg_amd.trainer import TrainStep
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def model_for(cfg):
+        m = deepsvg_amd.SVGTransformer(cfg)
+        m.load_state_dict(det_state_dict(m, seed=1))
+        return m.to(device).set_compute_dtype(torch.bfloat16)
+    out = {}
+    cfg = C.OneStageOneShot()
+    cfg.max_total_len = 50
+    cfg.use_vae = False
+    m = model_for(cfg).train()
+    c, a = make_batch_onestage(512, total_len=50, seed=1)
+    c, a = c.to(device), a.to(device)
+    ts = TrainStep(m, deepsvg_amd.SVGLoss(cfg).to(device), lr=1e-3, use_graph=True)
+    for _ in range(4):
+        ts.step(c, a)
+    sec = timed(lambda: ts.step(c, a), 20)
+    out["c4_one_stage_train"] = {"ms_per_step": round(sec * 1e3, 3), "icons_per_s": round(512 / sec, 1),
+                                 "workload": "OneStageOneShot max_total_len=50, 512 icons x 52 tokens, bf16, hipGraph"}
+    del ts, m
+    cfg = C.HierarchicalOrdered()
+    m = model_for(cfg).eval()
+    z = (torch.randn(8192, 1, 1, cfg.dim_z, generator=torch.Generator().manual_seed(0)) * 0.3).to(device)
+    sec = timed(lambda: m.greedy_sample(z=z, concat_groups=False, temperature=0), 3)
+    out["c5_one_shot_decode"] = {"ms": round(sec * 1e3, 2), "icons_per_s": round(8192 / sec, 1),
+                                 "workload": "hierarchical_ordered greedy_sample from 8192 latents, temperature 0 (head + arg-max fused)"}
+    del m
+    cfg = C.Sketchformer()
+    cfg.max_total_len = 50
+    cfg.use_vae = False
+    m = model_for(cfg).eval()
+    z = torch.randn(8192, 1, 1, cfg.dim_z, generator=torch.Generator().manual_seed(1)).to(device)
+    sec = timed(lambda: m.greedy_sample(z=z, concat_groups=False), 2)
+    out["c5_autoregressive_decode"] = {"ms": round(sec * 1e3, 1), "icons_per_s": round(8192 / sec, 1),
+                                       "tokens_per_s": round(8192 * 50 / sec, 1),
+                                       "workload": "Sketchformer max_total_len=50, 8192 icons x 50 tokens, batched sampling over the q|k|v cache"}
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
+class SclkSampler:
+    """sysfs sclk of this GPU (hwmon freq1_input), sampled every 5 ms by a thread while the timed loop runs.  What it reports
+    is the power-management TARGET clock; the clock the waves of a kernel actually see is lower under full-chip load (see
+    `in_kernel_clock_probe`: s_memtime ticks per s_memrealtime microsecond inside ffn_fwd)."""
+
+    def __init__(self, index):
+        import glob
+        import threading
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        self.path = cards[index] if index < len(cards) else None
+        self.samples, self.stop = [], False
+        self.thread = threading.Thread(target=self._run, daemon=True) if self.path else None
+
+    def _run(self):
+        while not self.stop:
+            try:
+                self.samples.append(float(open(self.path).read()) / 1e6)
+            except (OSError, ValueError):
+                pass
+            time.sleep(0.005)
+
+    def __enter__(self):
+        if self.thread:
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        if self.thread:
+            self.thread.join(timeout=1.0)
+
+    def summary(self):
+        v = sorted(self.samples)
+        if not v:
+            return None
+        return {"source": self.path, "samples": len(v), "min_mhz": round(v[0]), "median_mhz": round(v[len(v) // 2]),
+                "max_mhz": round(v[-1])}
+
+
+def in_kernel_clock_probe(rows, device):
+    """shader clock INSIDE ffn_fwd's training variant at the step's largest launch: one launch stamped with s_memtime (shader
+    cycles) and one with s_memrealtime (the constant 100 MHz counter) at wave start, LayerNorm done, chunk loop done, stores
+    issued (development hook dsvg_ffn_debug_clock); ticks / microseconds per phase = the clock the waves ran at.  The chip
+    clocks to its power budget: 2.4 GHz with a few workgroups, 1.45-1.65 GHz in the chunk loop with all 256 CUs busy
+    (profiles/r04_ffn_timeline_probe.log)."""
+    from deepsvg_amd import ops, lib
+    g = torch.Generator(device="cpu").manual_seed(0)
+    flat = torch.zeros(8 + 131072 + 512 + 131072 + 256 + 256 + 8)
+    o = 8
+    offs = [[o, o + 131072, o + 131072 + 512, o + 262144 + 512, o + 262144 + 768]]
+    flat[o:o + 131072] = torch.randn(131072, generator=g) * 0.06
+    flat[o + 131072 + 512:o + 262144 + 512] = torch.randn(131072, generator=g) * 0.06
+    flat[o + 262144 + 512:o + 262144 + 768] = 1.0
+    flat = flat.to(device)
+    pf, _pb, b1f = ops.ffn_pack(flat, torch.tensor(offs, dtype=torch.int64, device=device), 1)
+    pl = pf[:ops.FFN_FWD_LAYER_ELEMS]
+    b2 = torch.zeros(256, device=device)
+    seed = torch.tensor([1234567], dtype=torch.int64, device=device)
+    x = torch.randn(rows, 256, generator=g).to(device).to(torch.bfloat16)
+    nwg = (rows + 255) // 256
+    L = lib.load()
+    run = lambda: ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 3, 4, seed, train=True, stages=4)
+    for _ in range(20):
+        run()
+    ph = {}
+    for mode in (1, 0):
+        buf = torch.zeros(nwg * 8 * 4, dtype=torch.int64, device=device)
+        lib.check(L.dsvg_ffn_debug_clock(buf.data_ptr() | mode), "dsvg_ffn_debug_clock")
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        lib.check(L.dsvg_ffn_debug_clock(None), "dsvg_ffn_debug_clock")
+        t = buf.view(nwg * 8, 4).double().cpu()
+        t = t[(t > 0).all(1)]
+        ph[mode] = torch.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t[:, 0]], -1).median(0).values
+    us = ph[1] * 0.01          # 100 MHz ticks -> microseconds
+    mhz = [float(ph[0][i] / max(us[i].item(), 1e-9)) for i in range(4)]
+    return {"kernel": "ffn_fwd_kernel<4, true>", "rows": rows, "workgroups": nwg,
+            "wave_life_us": round(us[3].item(), 1), "prologue_us": round(us[0].item(), 1), "chunk_loop_us": round(us[1].item(), 1),
+            "epilogue_us": round(us[2].item(), 1),
+            "shader_clock_mhz": {"prologue": round(mhz[0]), "chunk_loop": round(mhz[1]), "epilogue": round(mhz[2]),
+                                 "whole_wave": round(mhz[3])},
+            "cycles_per_chunk": round(float(ph[0][1]) / 16),
+            "method": "s_memtime ticks / s_memrealtime (100 MHz) microseconds, median over the launch's waves"}
 
 
 def replay_ffn(specs, n, device):
@@ -348,6 +530,9 @@ def main():
     sync()
     captured_before = ts.graphs_captured
     keys_seen, switches, last_key = set(), 0, None
+    sclk = SclkSampler(local_rank) if (rank == 0 and not emulate) else None
+    if sclk is not None:
+        sclk.__enter__()
     t0 = time.perf_counter()
     for i in range(a.steps):
         ld = ts.step(*batches[(a.warmup + i) % n_b])
@@ -361,6 +546,8 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    if sclk is not None:
+        sclk.__exit__()
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -556,16 +743,26 @@ def main():
             if os.path.exists(tj):
                 t = json.load(open(tj))
                 if t.get("dtype") == a.dtype and "MB_per_launch" in t:
+                    import hashlib
+                    src = os.path.join(ROOT, "deepsvg_amd", "csrc", "ffn_fused.hip")
+                    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
                     roofline["traffic"] = t["MB_per_launch"]
                     roofline["traffic_source"] = "committed: " + t["source"]
                     roofline["traffic_over_fused_algorithmic"] = t.get("over_fused_algorithmic")
-            gcsv = os.path.join(ROOT, "profiles", "r03_graph_kernel_stats.csv")
+                    # the committed measurement names the commit and the kernel source it was taken on; a kernel edited since
+                    # then makes the number stale (tests/test_bench_gpu.py fails on it)
+                    roofline["traffic_collected_at"] = {"commit": t.get("commit"), "ffn_fused_hip_sha256_16": t.get("ffn_fused_hip_sha256_16"),
+                                                        "current_ffn_fused_hip_sha256_16": sha,
+                                                        "kernel_source_unchanged": t.get("ffn_fused_hip_sha256_16") == sha}
+            gcsv = os.path.join(ROOT, "profiles", "r04_graph_kernel_stats.csv")
+            if not os.path.exists(gcsv):
+                gcsv = os.path.join(ROOT, "profiles", "r03_graph_kernel_stats.csv")
             if os.path.exists(gcsv) and fused_fwd is not None:
                 for line in open(gcsv):
                     if "ffn_fwd_kernel" in line:
                         f = line.strip().split(",")
                         roofline["graph_mode_check"] = {
-                            "kernel": "ffn_fwd_kernel", "source": "committed: profiles/r03_graph_kernel_stats.csv (rocprofv3 "
+                            "kernel": "ffn_fwd_kernel", "source": "committed: profiles/" + os.path.basename(gcsv) + " (rocprofv3 "
                             "--kernel-trace of `bench.py --graph 1`, scripts/gpu_prof_graph.sh)",
                             "graph_replay_avg_us": float(f[3]), "launches_profiled": int(f[1]),
                             "live_event_avg_us": round(fk_ms * 1e3 / max(len(fk), 1), 1)}
@@ -598,6 +795,36 @@ def main():
                 "note": "fp32 storage, exact-fp32 MFMA (157.3 TFLOP/s peak): the path the 1e-3 parity tests run on"}
         del m32, t32
         log(f"fp32 leg done: {fp32}")
+    dense = secondary = clock = None
+    if rank == 0 and world == 1 and a.dtype == "bf16" and not a.no_extra_legs and not emulate:
+        try:
+            dense = dense_layout_leg(cfg, sd_cpu, batches, device)
+        except Exception as e:      # reported, never fatal for the bench line
+            dense = {"error": f"{type(e).__name__}: {e}"[:300]}
+        log(f"dense-layout leg done: {dense}")
+        try:
+            secondary = secondary_legs(device)
+        except Exception as e:
+            secondary = {"error": f"{type(e).__name__}: {e}"[:300]}
+        log(f"secondary legs done: {secondary}")
+        try:
+            big = 63488
+            if roofline and roofline.get("fused_fwd_kernel"):
+                big = int(roofline["fused_fwd_kernel"]["largest_launch"]["rows"])
+            clock = in_kernel_clock_probe(big, device)
+        except Exception as e:
+            clock = {"error": f"{type(e).__name__}: {e}"[:300]}
+        log(f"in-kernel clock probe done: {clock}")
+        if roofline and clock and "shader_clock_mhz" in clock and roofline.get("fused_fwd_kernel"):
+            # the same fractions against the MFMA peak AT THE CLOCK THE KERNEL RAN AT (2.5 PFLOP/s is the peak at 2.4 GHz; the
+            # chip clocks to its power budget): what the kernel's schedule leaves on the table, apart from the clock
+            mhz = clock["shader_clock_mhz"]["whole_wave"]
+            scale = 2400.0 / max(mhz, 1.0)
+            ff = roofline["fused_fwd_kernel"]
+            ff["frac_at_measured_clock"] = round(ff["largest_launch"]["frac"] * scale, 4)
+            ff["measured_clock_mhz"] = mhz
+            ff["chunk_loop_frac_at_its_clock"] = round(
+                16 * 2 * 32 * 32.0 / max(clock["cycles_per_chunk"], 1.0), 4)    # matrix-pipe cycles of a SIMD's two waves / cycles per chunk
     torch_ref = None
     if rank == 0 and world == 1 and not a.no_torch_ref and not emulate:
         try:
@@ -627,9 +854,14 @@ def main():
                        # every DSVG_* environment switch that was set for this run (A/B knobs, opt-in kernels): a record taken
                        # with a non-default kernel selection says so
                        "env_overrides": {k: v for k, v in sorted(os.environ.items())
-                                         if k.startswith("DSVG_") and not k.startswith("DSVG_BENCH_")}},
+                                         if k.startswith("DSVG_") and not k.startswith("DSVG_BENCH_")},
+                       # sysfs sclk while the timed loop ran (the power-management target; stationary from the first step on:
+                       # profiles/r04_clock_probe.log) and the shader clock measured inside the dominant kernel
+                       "clock_mhz": {"sclk_sysfs": (sclk.summary() if sclk is not None else None),
+                                     "in_kernel": (clock or {}).get("shader_clock_mhz") if clock else None}},
             "graphs": graphs, "rccl_ranks": rccl_ranks,
-            "roofline": roofline, "fp32": fp32, "torch_rocm_reference": torch_ref, "cpu_baseline": cpu,
+            "roofline": roofline, "fp32": fp32, "dense_layout": dense, "secondary": secondary, "in_kernel_clock": clock,
+            "torch_rocm_reference": torch_ref, "cpu_baseline": cpu,
         }
         print(json.dumps(rec), flush=True)
     if dist.is_available() and dist.is_initialized():

@@ -137,14 +137,17 @@ __device__ __forceinline__ void row32_store(bf16_t* p, const float (&v)[32]) {
 // pass regenerates the forward mask instead of storing it; `seed` lives in device memory so that a
 // captured hipGraph sees a new value on every replay.
 //   group g = id >> 3 :  h  = (hash32(lo(g) ^ s0) ^ s1) + hi(g)*C                  (once per 8 elements)
-//   word  i = 0..3    :  w  = mix(h + (i+1)*0x9e3779b9),  mix(w): w ^= w >> 16; w *= 0x7feb352d; w ^= w >> 15
-//                                                                                  (two 16-bit draws each)
+//   word  i = 0..3    :  w  = fold(h * C_i),  C_i = ((0x7feb352d * (i + 1)) ^ (0x846ca68b >> i)) | 1,  fold(p) = lo32(p) ^ hi32(p)
+//                                             of the 64-bit product                   (two 16-bit draws each)
 //   element slot = id & 7 uses the low (even slot) / high (odd slot) half of word slot>>1 and is dropped
 //   when draw16 < round(p * 65536); survivors are scaled by 65536 / (65536 - thresh16).
-// One full hash round per group and a one-multiply finaliser per word (round 3; before: two rounds per group and a full
-// round per word, 59 instructions per 8 elements - in the kernels whose epilogues are instruction-issue-bound the draws
-// were up to 2/3 of the epilogue, 40 % of the group-stage layer kernel).  Restated bit-for-bit with int64 torch ops in
-// tests/torch_ops_ref.py.
+// One full hash round per group, then ONE multiply-fold with a per-word multiplier per pair of draws: v_mul_lo + v_mul_hi +
+// v_xor.  (Round 3's word function - h + (i + 1) * 0x9e3779b9 through ONE xorshift-multiply round, 6 instructions - left a
+// 0.5 % correlation between the draws of neighbouring words: tests/test_dropout_stats.py, chi-square 160 on 2^23 pairs.  The
+// multiply-fold with multipliers that do NOT form an arithmetic progression - C_i = A + i B passes the pairwise tests but
+// fails the per-group drop-count distribution by a wide margin: the products h C_i are then a lattice - passes every test
+// there: neighbours at 1 .. 256, sites, consecutive seeds, binomial counts per group of 8 / 16 / 32 and per row; it is half the
+// instructions where i is a compile-time constant.)  Restated bit-for-bit with int64 torch ops in tests/torch_ops_ref.py.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t dsvg_hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -175,10 +178,10 @@ __device__ __forceinline__ uint32_t drop_group(const DropCtx& c, uint64_t g) {
     const uint32_t h = dsvg_hash32((uint32_t)g ^ c.s0);
     return (h ^ c.s1) + (uint32_t)(g >> 32) * 0x9e3779b1u;
 }
+// word i (< 16) of a group / row hash: two 16-bit draws
 __device__ __forceinline__ uint32_t drop_word(uint32_t h, uint32_t i) {
-    uint32_t w = h + (i + 1u) * 0x9e3779b9u;
-    w ^= w >> 16; w *= 0x7feb352du; w ^= w >> 15;
-    return w;
+    const uint32_t c = ((0x7feb352du * (i + 1u)) ^ (0x846ca68bu >> i)) | 1u;
+    return (h * c) ^ __umulhi(h, c);
 }
 // multiplier (0 or scale) for element idx
 __device__ __forceinline__ float drop_mult(const DropCtx& c, uint64_t idx) {
@@ -215,8 +218,7 @@ __device__ __forceinline__ uint32_t attn_drop_row(const DropCtx& c, uint64_t row
 }
 __device__ __forceinline__ float attn_drop_key(const DropCtx& c, uint32_t hrow, uint32_t key) {
     if (!c.on) return 1.f;
-    uint32_t w = hrow + (((key & 31u) >> 1) + 1u) * 0x9e3779b9u;
-    w ^= w >> 16; w *= 0x7feb352du; w ^= w >> 15;
+    const uint32_t w = drop_word(hrow, (key & 31u) >> 1);
     const uint32_t draw = (key & 1u) ? (w >> 16) : (w & 0xffffu);
     return draw < c.thresh ? 0.f : c.scale;
 }

@@ -141,11 +141,7 @@ __device__ __forceinline__ uint32_t drop2_group(const DropCtx& c, uint64_t g16) 
     const uint32_t h = dsvg_hash32((uint32_t)g16 ^ c.s0);
     return (h ^ c.s1) + (uint32_t)(g16 >> 32) * 0x9e3779b1u;
 }
-__device__ __forceinline__ uint32_t drop2_word(uint32_t h, uint32_t i) {
-    uint32_t w = h + (i + 1u) * 0x9e3779b9u;
-    w ^= w >> 16; w *= 0x7feb352du; w ^= w >> 15;
-    return w;
-}
+__device__ __forceinline__ uint32_t drop2_word(uint32_t h, uint32_t i) { return drop_word(h, i); }   // (dsvg_common.h)
 // multipliers of the 8 ids 16 g16 + 8 hi .. + 7 (hi = 0, 1) given the group hash
 __device__ __forceinline__ void drop2_mult8(const DropCtx& c, uint32_t h, int hi, float (&m)[8]) {
 #pragma unroll

@@ -39,6 +39,23 @@ def _hash32_t(x):
     return x
 
 
+def _mulhi32(a, b):
+    """high 32 bits of the 64-bit product of two tensors / ints < 2^32 (int64 arithmetic without overflow)"""
+    a0, a1 = a & 0xFFFF, a >> 16
+    b0, b1 = b & 0xFFFF, b >> 16
+    lo_lo, hi_lo, lo_hi, hi_hi = a0 * b0, a1 * b0, a0 * b1, a1 * b1
+    cross = (lo_lo >> 16) + (hi_lo & 0xFFFF) + lo_hi
+    return ((hi_lo >> 16) + (cross >> 16) + hi_hi) & M32
+
+
+def _drop_word(h, i):
+    """word i (< 16) of a group / row hash (dsvg_common.h drop_word): fold(h * C_i) = lo32 ^ hi32 of the 64-bit product,
+    C_i = ((0x7feb352d * (i + 1)) ^ (0x846ca68b >> i)) | 1"""
+    c = (((0x7FEB352D * (i + 1)) & M32) ^ (0x846CA68B >> i)) | 1
+    lo = ((h & 0xFFFF) * c + (((h >> 16) * c) & 0xFFFF) * 65536) & M32
+    return lo ^ _mulhi32(h, c)
+
+
 def drop_mult(p, seed, site, idx):
     """multiplier tensor (0 or 65536/(65536-thresh16)) for int64 element ids `idx` (dsvg_common.h drop_mult)"""
     if p <= 0 or seed is None:
@@ -54,10 +71,7 @@ def drop_mult(p, seed, site, idx):
     lo, hi = g & M32, (g >> 32) & M32
     h = _hash32_t(lo ^ s0)
     h = ((h ^ s1) + hi * 0x9E3779B1) & M32
-    w = (h + ((slot >> 1) + 1) * 0x9E3779B9) & M32
-    w = w ^ (w >> 16)
-    w = (w * 0x7FEB352D) & M32
-    w = w ^ (w >> 15)
+    w = _drop_word(h, slot >> 1)
     draw = torch.where((slot & 1) == 1, w >> 16, w & 0xFFFF)
     return torch.where(draw < thresh, torch.zeros((), dtype=torch.float32, device=idx.device),
                        torch.full((), scale, dtype=torch.float32, device=idx.device))
@@ -79,10 +93,7 @@ def drop2_mult(p, seed, site, idx):
     lo, hi = g & M32, (g >> 32) & M32
     h = _hash32_t(lo ^ s0)
     h = ((h ^ s1) + hi * 0x9E3779B1) & M32
-    w = (h + ((slot >> 1) + 1) * 0x9E3779B9) & M32
-    w = w ^ (w >> 16)
-    w = (w * 0x7FEB352D) & M32
-    w = w ^ (w >> 15)
+    w = _drop_word(h, slot >> 1)
     draw = torch.where((slot & 1) == 1, w >> 16, w & 0xFFFF)
     return torch.where(draw < thresh, torch.zeros((), dtype=torch.float32, device=idx.device),
                        torch.full((), scale, dtype=torch.float32, device=idx.device))
@@ -209,7 +220,7 @@ def _attn_probs(qkv, key_mask, n_seq, S, H, scale, causal=False):
 
 def attn_drop_mult(p, seed, site, row, key):
     """dropout of the attention probabilities (dsvg_common.h attn_drop_row / attn_drop_key): one counter hash per
-    (row = (sequence * heads + head) * S + query, block of 32 keys), a one-multiply finaliser per pair of keys"""
+    (row = (sequence * heads + head) * S + query, block of 32 keys), a multiply-fold per pair of keys"""
     shape = torch.broadcast_shapes(row.shape, key.shape)
     if p <= 0 or seed is None:
         return torch.ones(shape, dtype=torch.float32, device=row.device)
@@ -223,10 +234,7 @@ def attn_drop_mult(p, seed, site, row, key):
     lo, hi = g & M32, (g >> 32) & M32
     h = _hash32_t(lo ^ s0)
     h = _hash32_t((h + hi * 0x9E3779B1 + s1) & M32)
-    w = (h + (((key & 31) >> 1) + 1) * 0x9E3779B9) & M32
-    w = w ^ (w >> 16)
-    w = (w * 0x7FEB352D) & M32
-    w = w ^ (w >> 15)
+    w = _drop_word(h, (key & 31) >> 1)
     draw = torch.where((key & 1) == 1, w >> 16, w & 0xFFFF)
     return torch.where(draw < thresh, torch.zeros((), dtype=torch.float32, device=row.device),
                        torch.full((), scale, dtype=torch.float32, device=row.device))
