@@ -824,7 +824,7 @@ def main():
             ff["frac_at_measured_clock"] = round(ff["largest_launch"]["frac"] * scale, 4)
             ff["measured_clock_mhz"] = mhz
             ff["chunk_loop_frac_at_its_clock"] = round(
-                16 * 2 * 32 * 32.0 / max(clock["cycles_per_chunk"], 1.0), 4)    # matrix-pipe cycles of a SIMD's two waves / cycles per chunk
+                2 * 32 * 32.0 / max(clock["cycles_per_chunk"], 1.0), 4)     # matrix-pipe cycles of a SIMD's two waves (2 x 32 MFMAs x 32) / cycles per chunk
     torch_ref = None
     if rank == 0 and world == 1 and not a.no_torch_ref and not emulate:
         try:
