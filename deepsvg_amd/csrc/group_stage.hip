@@ -1043,6 +1043,193 @@ __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a)
     store_image(a.dx + row0 * GD, GD, HI, LDX, 0, S, GD);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The latent chain between the two group stages (round 4): the ResNet on the pooled encoder output and the bottleneck linear,
+//     z_i = z_{i-1} + relu(W_i z_{i-1} + b_i), i = 1 .. n_res;     out = W_b z_{n_res} + b_b
+// (deepsvg/model/basic_blocks.py:59-65 ResNet, deepsvg/model/model.py:193-198 Bottleneck; N = one row per icon).  As separate
+// launches this is 2 per block forward (GEMM, add) and 3 per block backward (gate, input-gradient GEMM, weight-gradient GEMM)
+// on 512 rows: 9 + 15 launches of 5-15 us, ~0.25 ms of a 6.4 ms step for 0.2 % of its FLOPs.  Here: ONE forward and ONE
+// backward launch (+ one grouped launch for the five weight gradients), a workgroup per 32 rows, its 8 waves split the 256
+// output features; the running row tile never leaves LDS.
+//   forward   A operands = weight fragments read straight from the row-major bf16 weight image (a lane's 8 consecutive k of
+//             one output feature are 16 contiguous bytes: no packing pass), 8 fragments ahead; B operands = the tile's rows.
+//   backward  dz = dpre . W needs W TRANSPOSED fragments: the weight matrix passes through LDS in slabs of 32 rows (coalesced
+//             16-byte loads, one slab ahead in registers) and comes back through hardware-transposed reads (col_frag); the K
+//             order of those reads is rowmap-permuted, so the B operand takes the tile's row pieces in the same order.
+// Every intermediate is rounded to bf16 where the unfused launches store bf16 (r_i, z_i, dpre_i, dz_i): same values.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int LC_MAX = 5;              // matrices of a chain: up to 4 residual blocks + the final linear
+struct LatentFwdArgs {
+    const bf16_t* z0; const bf16_t* w[LC_MAX]; const float* b[LC_MAX];
+    bf16_t* z[LC_MAX - 1]; bf16_t* r[LC_MAX - 1];       // training: z_1 .. z_n and the ReLU outputs r_1 .. r_n (else null)
+    bf16_t* out;
+    int n_rows, n_res;
+};
+struct LatentBwdArgs {
+    const bf16_t* dout; const bf16_t* w[LC_MAX]; const bf16_t* r[LC_MAX - 1];
+    bf16_t* dpre[LC_MAX - 1];           // dpre_i = dz_i where r_i > 0 (the token-major operand of dW_i)
+    bf16_t* dz0;
+    int n_rows, n_res;
+};
+constexpr int LC_IMG = 32 * LDX * 2;                    // bytes of one [32][LDX] image
+constexpr int LC_FWD_LDS = 4 * LC_IMG + LC_MAX * GD * 4;            // Z[2] | R[2] | biases
+constexpr int LC_BWD_LDS = 5 * LC_IMG;                              // G[2] | DP | WS[2]
+
+__global__ __launch_bounds__(512, 2) void latent_chain_fwd_kernel(const LatentFwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    auto Zi = [&](int i) -> bf16_t* { return reinterpret_cast<bf16_t*>(smem + i * LC_IMG); };           // Z[0], Z[1]
+    auto Ri = [&](int i) -> bf16_t* { return reinterpret_cast<bf16_t*>(smem + (2 + i) * LC_IMG); };     // R[0], R[1]
+    float* sb = reinterpret_cast<float*>(smem + 4 * LC_IMG);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, h2 = lane >> 5;
+    const long long row0 = (long long)blockIdx.x * 32;
+    const int S = (int)min((long long)32, a.n_rows - row0);
+    const int oc = wave * 32;                            // this wave's output-feature block
+    const bool train = a.z[0] != nullptr;
+    load_image(Zi(0), LDX, 0, a.z0 + row0 * GD, GD, S, GD);
+    for (int i = 0; i <= a.n_res; ++i)
+        if (tid < GD) sb[i * GD + tid] = a.b[i][tid];
+    lds_barrier();
+    int cur = 0;
+    for (int blk = 0; blk <= a.n_res; ++blk) {
+        const char* wrow = reinterpret_cast<const char*>(a.w[blk]) + ((size_t)(oc + li) * GD + 8 * h2) * 2;
+        uint4 ring[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ring[i] = *reinterpret_cast<const uint4*>(wrow + 32 * i);
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            Frag8 wf;
+            wf.u = ring[ks & 7];
+            if (ks + 8 < 16) ring[ks & 7] = *reinterpret_cast<const uint4*>(wrow + 32 * (ks + 8));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.v, row_frag(Zi(cur), LDX, li, 0, ks, h2), acc, 0, 0, 0);
+        }
+        const float* bb = sb + blk * GD + oc;
+        float t[16];
+        if (blk < a.n_res) {
+            float zv[16], rv[16];
+            load_rows(Zi(cur), LDX, li, oc, h2, zv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                rv[r] = bf2f(f2bf(fmaxf(acc[r] + bb[rowmap(r, h2)], 0.f)));     // (the unfused GEMM stores r as bf16)
+                t[r] = zv[r] + rv[r];
+            }
+            stage_rows(Zi(cur ^ 1), LDX, li, oc, h2, t);
+            if (train) stage_rows(Ri(blk & 1), LDX, li, oc, h2, rv);
+            lds_barrier();
+            if (train) {
+                store_image(a.z[blk] + row0 * GD, GD, Zi(cur ^ 1), LDX, 0, S, GD);
+                store_image(a.r[blk] + row0 * GD, GD, Ri(blk & 1), LDX, 0, S, GD);
+            }
+            cur ^= 1;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = acc[r] + bb[rowmap(r, h2)];
+            stage_rows(Zi(cur ^ 1), LDX, li, oc, h2, t);
+            lds_barrier();
+            store_image(a.out + row0 * GD, GD, Zi(cur ^ 1), LDX, 0, S, GD);
+        }
+    }
+}
+
+// B operand of the transposed-weight products: B[k slot e of lane half h2][n = row] = img[row][col0 + rowmap(8 ks + e, h2)]
+// (the K order col_frag delivers its A operand in): the two 8-byte pieces at columns 16 ks + 4 h2 and 16 ks + 8 + 4 h2
+__device__ __forceinline__ bf16x8 row_frag_perm(const bf16_t* img, int ld, int row, int col0, int ks, int h2) {
+    Frag8 f;
+    const uint2 lo = *reinterpret_cast<const uint2*>(&img[row * ld + col0 + 16 * ks + 4 * h2]);
+    const uint2 hi = *reinterpret_cast<const uint2*>(&img[row * ld + col0 + 16 * ks + 8 + 4 * h2]);
+    f.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    return f.v;
+}
+
+__global__ __launch_bounds__(512, 2) void latent_chain_bwd_kernel(const LatentBwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    auto Gi = [&](int i) -> bf16_t* { return reinterpret_cast<bf16_t*>(smem + i * LC_IMG); };           // G[0], G[1]
+    bf16_t* DP = reinterpret_cast<bf16_t*>(smem + 2 * LC_IMG);
+    auto WSi = [&](int i) -> bf16_t* { return reinterpret_cast<bf16_t*>(smem + (3 + i) * LC_IMG); };    // WS[0], WS[1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, h2 = lane >> 5;
+    const long long row0 = (long long)blockIdx.x * 32;
+    const int S = (int)min((long long)32, a.n_rows - row0);
+    const int oc = wave * 32;
+    const int er = tid >> 4, ec = (tid & 15) * 16;       // elementwise mapping: row er, columns ec .. ec + 15
+    const long long erow = row0 + min(er, S - 1);
+    load_image(DP, LDX, 0, a.dout + row0 * GD, GD, S, GD);
+    int cur = 0;
+    for (int step = 0; step <= a.n_res; ++step) {
+        const int mi = a.n_res - step;                  // matrix of this step: the final linear first, then the blocks backwards
+        const bf16_t* W = a.w[mi];
+        // slab s = rows 32 s .. 32 s + 31 of W (the reduced index j), 16 elements per thread, one slab ahead in registers
+        const bf16_t* wsrc = W + (size_t)er * GD + ec;
+        uint4 sa = *reinterpret_cast<const uint4*>(wsrc), sb = *reinterpret_cast<const uint4*>(wsrc + 8);
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int s = 0; s < 8; ++s) {
+            bf16_t* ws = WSi(s & 1);
+            *reinterpret_cast<uint4*>(&ws[er * LDX + ec]) = sa;
+            *reinterpret_cast<uint4*>(&ws[er * LDX + ec + 8]) = sb;
+            if (s + 1 < 8) {
+                sa = *reinterpret_cast<const uint4*>(wsrc + (size_t)(s + 1) * 32 * GD);
+                sb = *reinterpret_cast<const uint4*>(wsrc + (size_t)(s + 1) * 32 * GD + 8);
+            }
+            lds_barrier();          // slab s (and, for s = 0, the DP image) complete; everybody is past slab s - 1's buffer... of 2 ago
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(ws, LDX, oc, ks, lane),
+                                                             row_frag_perm(DP, LDX, li, 32 * s, ks, h2), acc, 0, 0, 0);
+        }
+        // acc[r] = (DP . W)[row li][column oc + rowmap(r, h2)]
+        float t[16];
+        if (step == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = acc[r];
+        } else {
+            float gv[16];
+            load_rows(Gi(cur), LDX, li, oc, h2, gv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = gv[r] + acc[r];
+        }
+        stage_rows(Gi(cur ^ 1), LDX, li, oc, h2, t);
+        cur ^= 1;
+        lds_barrier();              // dz of this step complete; every wave is done with DP
+        if (mi > 0) {
+            // dpre_{mi} = dz where r_{mi} > 0: elementwise, into DP (the next product's B operand) and to memory
+            const bf16_t* rr = a.r[mi - 1] + erow * GD + ec;
+            const uint4 ra = *reinterpret_cast<const uint4*>(rr), rb = *reinterpret_cast<const uint4*>(rr + 8);
+            const uint4 ga = *reinterpret_cast<const uint4*>(&Gi(cur)[er * LDX + ec]);
+            const uint4 gb = *reinterpret_cast<const uint4*>(&Gi(cur)[er * LDX + ec + 8]);
+            auto gate = [](uint4 g, uint4 r) -> uint4 {
+                const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, rw[4] = {r.x, r.y, r.z, r.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // bf16 halves: keep where r > 0 (sign clear and non-zero)
+                    const uint32_t lo_on = ((rw[e] & 0x8000u) == 0u && (rw[e] & 0x7fffu) != 0u) ? 0x0000ffffu : 0u;
+                    const uint32_t hi_on = ((rw[e] & 0x80000000u) == 0u && (rw[e] & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
+                    o[e] = gw[e] & (lo_on | hi_on);
+                }
+                return make_uint4(o[0], o[1], o[2], o[3]);
+            };
+            const uint4 pa = gate(ga, ra), pb = gate(gb, rb);
+            *reinterpret_cast<uint4*>(&DP[er * LDX + ec]) = pa;
+            *reinterpret_cast<uint4*>(&DP[er * LDX + ec + 8]) = pb;
+            if (er < S) {
+                bf16_t* dd = a.dpre[mi - 1] + (row0 + er) * GD + ec;
+                *reinterpret_cast<uint4*>(dd) = pa;
+                *reinterpret_cast<uint4*>(dd + 8) = pb;
+            }
+            // (the next step's first slab barrier orders these DP writes in front of its reads)
+        } else {
+            store_image(a.dz0 + row0 * GD, GD, Gi(cur), LDX, 0, S, GD);
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1165,5 +1352,64 @@ extern "C" int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, 
         const int rc = dsvg_reduce_partials_strided((const float*)workspace + 256 * k, nb, 1024, 256, outs[k], 0, st);
         if (rc) return rc;
     }
+    return 0;
+}
+
+/* the latent chain (see latent_chain_fwd_kernel): weights = n_res + 1 row-major bf16 [256, 256] matrices (residual blocks, then
+ * the final linear), biases fp32 [256] each; z_out / r_out: n_res training outputs each (or NULL pointers arrays' entries) */
+extern "C" int dsvg_latent_chain_fwd(const void* z0, const void* const* weights, const float* const* biases, int32_t n_res,
+                                     void* const* z_out, void* const* r_out, void* out, int64_t rows, void* stream) {
+    DSVG_CHECK_ARG(z0 && weights && biases && out, "latent_chain_fwd: null pointer");
+    DSVG_CHECK_ARG(n_res >= 0 && n_res < LC_MAX, "latent_chain_fwd: at most %d residual blocks (got %d)", LC_MAX - 1, n_res);
+    DSVG_CHECK_ARG(rows > 0 && rows < (1ll << 31), "latent_chain_fwd: bad row count");
+    LatentFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.z0 = (const bf16_t*)z0; a.out = (bf16_t*)out; a.n_rows = (int)rows; a.n_res = n_res;
+    uintptr_t al = (uintptr_t)z0 | (uintptr_t)out;
+    for (int i = 0; i <= n_res; ++i) {
+        DSVG_CHECK_ARG(weights[i] && biases[i], "latent_chain_fwd: null weight / bias %d", i);
+        a.w[i] = (const bf16_t*)weights[i]; a.b[i] = biases[i];
+        al |= (uintptr_t)weights[i];
+    }
+    const bool train = n_res > 0 && z_out && r_out && z_out[0];
+    for (int i = 0; i < n_res; ++i) {
+        a.z[i] = train ? (bf16_t*)z_out[i] : nullptr;
+        a.r[i] = train ? (bf16_t*)r_out[i] : nullptr;
+        DSVG_CHECK_ARG(!train || (z_out[i] && r_out[i]), "latent_chain_fwd: the training outputs come together");
+        al |= (uintptr_t)a.z[i] | (uintptr_t)a.r[i];
+    }
+    DSVG_CHECK_ARG((al & 15) == 0, "latent_chain_fwd: operands must be 16-byte aligned");
+    DSVG_ENSURE_LDS(latent_chain_fwd_kernel, LC_FWD_LDS);
+    hipLaunchKernelGGL(latent_chain_fwd_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(512), LC_FWD_LDS, (hipStream_t)stream, a);
+    DSVG_LAUNCH_CHECK("latent_chain_fwd");
+    return 0;
+}
+
+/* backward of the chain's input path: dout = dL/dout [rows, 256]; r = the n_res ReLU outputs of the forward pass; outputs:
+ * dpre_out[i] = dz_{i+1} where r_{i+1} > 0 (the token-major operand of dW_{i+1}; dW of the final linear takes dout itself) and
+ * dz0 = dL/dz0 */
+extern "C" int dsvg_latent_chain_bwd(const void* dout, const void* const* weights, const void* const* r, int32_t n_res,
+                                     void* const* dpre_out, void* dz0, int64_t rows, void* stream) {
+    DSVG_CHECK_ARG(dout && weights && dz0 && (n_res == 0 || (r && dpre_out)), "latent_chain_bwd: null pointer");
+    DSVG_CHECK_ARG(n_res >= 0 && n_res < LC_MAX, "latent_chain_bwd: at most %d residual blocks (got %d)", LC_MAX - 1, n_res);
+    DSVG_CHECK_ARG(rows > 0 && rows < (1ll << 31), "latent_chain_bwd: bad row count");
+    LatentBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dout = (const bf16_t*)dout; a.dz0 = (bf16_t*)dz0; a.n_rows = (int)rows; a.n_res = n_res;
+    uintptr_t al = (uintptr_t)dout | (uintptr_t)dz0;
+    for (int i = 0; i <= n_res; ++i) {
+        DSVG_CHECK_ARG(weights[i], "latent_chain_bwd: null weight %d", i);
+        a.w[i] = (const bf16_t*)weights[i];
+        al |= (uintptr_t)weights[i];
+    }
+    for (int i = 0; i < n_res; ++i) {
+        DSVG_CHECK_ARG(r[i] && dpre_out[i], "latent_chain_bwd: null r / dpre %d", i);
+        a.r[i] = (const bf16_t*)r[i]; a.dpre[i] = (bf16_t*)dpre_out[i];
+        al |= (uintptr_t)r[i] | (uintptr_t)dpre_out[i];
+    }
+    DSVG_CHECK_ARG((al & 15) == 0, "latent_chain_bwd: operands must be 16-byte aligned");
+    DSVG_ENSURE_LDS(latent_chain_bwd_kernel, LC_BWD_LDS);
+    hipLaunchKernelGGL(latent_chain_bwd_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(512), LC_BWD_LDS, (hipStream_t)stream, a);
+    DSVG_LAUNCH_CHECK("latent_chain_bwd");
     return 0;
 }

@@ -223,6 +223,47 @@ class ResBlockFn(torch.autograd.Function):
         return None, dz, dw, db
 
 
+# the latent ResNet + the bottleneck linear as one launch per direction (csrc/group_stage.hip latent_chain_*; DSVG_LATENT_FUSED=0:
+# a GEMM + an add per block forward, gate + two GEMMs per block backward)
+LATENT_FUSED = os.environ.get("DSVG_LATENT_FUSED", "1") != "0"
+
+
+class LatentChainFn(torch.autograd.Function):
+    """z_i = z_{i-1} + relu(W_i z_{i-1} + b_i) for the n residual blocks, then out = W_out z_n + b_out (deepsvg/model/
+    basic_blocks.py:59-65, model.py:193-198) - bf16, 256 features.  wb = (W_1, b_1, ..., W_n, b_n, W_out, b_out)."""
+
+    @staticmethod
+    def forward(ctx, rt, z, *wb):
+        ws = [rt.w(w) for w in wb[0::2]]
+        bs = [b.detach() for b in wb[1::2]]
+        ctx.rt, ctx.n = rt, len(ws) - 1
+        z = z.contiguous()
+        if any(ctx.needs_input_grad):
+            out, zs, rs = ops.latent_chain_fwd(z, ws, bs, train=True)
+            ctx.save_for_backward(z, *zs, *rs, *wb)
+        else:
+            out = ops.latent_chain_fwd(z, ws, bs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        rt, n = ctx.rt, ctx.n
+        saved = ctx.saved_tensors
+        zin = [saved[0]] + list(saved[1:1 + n])          # the input of block i + 1; zin[n] feeds the final linear
+        rs = list(saved[1 + n:1 + 2 * n])
+        wb = saved[1 + 2 * n:]
+        dout = dout.contiguous()
+        dz0, dpre = ops.latent_chain_bwd(dout, [rt.w(w) for w in wb[0::2]], rs)
+        # the n + 1 weight gradients (512 rows each): independent, a handful of workgroups each - one grouped launch
+        grads = []
+        with rt.grouping():
+            for i in range(n + 1):
+                w, b = wb[2 * i], wb[2 * i + 1]
+                blocks = (8 * -(-w.shape[0] // 128) * -(-w.shape[1] // 128)) if GROUP_WGRAD else None
+                grads += list(_wbgrad(rt, w, b, dpre[i] if i < n else dout, zin[i], blocks))
+        return (None, dz0, *grads)
+
+
 # --------------------------------------------------------------------------------------------------
 class LivePrefix(tuple):
     """(n_live_sequences, n_live_rows) of a stage whose backward MAY be restricted to that row prefix: the rest of

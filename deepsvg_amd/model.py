@@ -822,6 +822,13 @@ class SVGTransformer(nn.Module):
     def _bottleneck(self, rt, z):
         cfg = self.cfg
         mu = logsigma = None
+        if (Fn.LATENT_FUSED and cfg.use_resnet and not cfg.use_vae and z.dtype == torch.bfloat16 and z.shape[1] == 256
+                and tuple(self.bottleneck.bottleneck.weight.shape) == (256, 256) and rt.store is not None):
+            # the four residual blocks and the bottleneck linear in one launch per direction (csrc/group_stage.hip)
+            wb = [t for i in range(1, 5) for t in (getattr(self.resnet, f"linear{i}")[0].weight,
+                                                   getattr(self.resnet, f"linear{i}")[0].bias)]
+            wb += [self.bottleneck.bottleneck.weight, self.bottleneck.bottleneck.bias]
+            return Fn.LatentChainFn.apply(rt, z, *wb), mu, logsigma
         if cfg.use_resnet:
             for i in range(1, 5):
                 lin = getattr(self.resnet, f"linear{i}")[0]

@@ -1394,6 +1394,50 @@ def keep_scale(p):
     return 65536.0 / (65536 - t)
 
 
+def _ptr_array(tensors):
+    """host array of device pointers (ctypes void*[n]) for the C entry points that take pointer lists"""
+    import ctypes
+    arr = (ctypes.c_void_p * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def latent_chain_fwd(z, weights, biases, train=False):
+    """the latent ResNet + the final linear in ONE launch (include/dsvg.h dsvg_latent_chain_fwd): z bf16 [rows, 256]; weights =
+    n_res + 1 row-major bf16 [256, 256] matrices (the final linear last), biases fp32 [256] each.
+    -> out, or (out, [z_1 .. z_n], [r_1 .. r_n]) with train=True (r_i = relu(W_i z_{i-1} + b_i))"""
+    _chk(z, *weights, *biases)
+    n_res = len(weights) - 1
+    assert z.dtype == torch.bfloat16 and z.dim() == 2 and z.shape[1] == 256 and z.is_contiguous()
+    assert len(biases) == len(weights) and 0 <= n_res <= 4
+    for w, b in zip(weights, biases):
+        assert w.dtype == torch.bfloat16 and tuple(w.shape) == (256, 256) and w.is_contiguous()
+        assert b.dtype == torch.float32 and b.numel() == 256 and b.is_contiguous()
+    out = torch.empty_like(z)
+    zs = [torch.empty_like(z) for _ in range(n_res)] if train else []
+    rs = [torch.empty_like(z) for _ in range(n_res)] if train else []
+    _l.check(_l.load().dsvg_latent_chain_fwd(z.data_ptr(), _ptr_array(weights), _ptr_array(biases), n_res,
+                                             _ptr_array(zs) if train and n_res else None,
+                                             _ptr_array(rs) if train and n_res else None, out.data_ptr(), z.shape[0],
+                                             _stream()), "dsvg_latent_chain_fwd")
+    return (out, zs, rs) if train else out
+
+
+def latent_chain_bwd(dout, weights, rs):
+    """backward of latent_chain_fwd's input path -> (dz0, [dpre_1 .. dpre_n]); dpre_i = dz_i where r_i > 0"""
+    _chk(dout, *weights, *rs)
+    n_res = len(weights) - 1
+    assert dout.dtype == torch.bfloat16 and dout.dim() == 2 and dout.shape[1] == 256 and dout.is_contiguous()
+    assert len(rs) == n_res and all(r.shape == dout.shape and r.dtype == dout.dtype and r.is_contiguous() for r in rs)
+    dz0 = torch.empty_like(dout)
+    dpre = [torch.empty_like(dout) for _ in range(n_res)]
+    _l.check(_l.load().dsvg_latent_chain_bwd(dout.data_ptr(), _ptr_array(weights), _ptr_array(rs) if n_res else None, n_res,
+                                             _ptr_array(dpre) if n_res else None, dz0.data_ptr(), dout.shape[0], _stream()),
+             "dsvg_latent_chain_bwd")
+    return dz0, dpre
+
+
 def gate_mul(dy, y, scale=1.0):
     """out = dy * scale where y > 0 else 0   (backward of relu [+ dropout] from the saved output)"""
     _chk(dy, y)

@@ -31,8 +31,9 @@ extern "C" {
 /* ABI version: bumped on EVERY change of an exported signature (round 4: 2 - dsvg_ffn_bwd_one and
  * dsvg_attn_block_fwd_stages removed, round 3's signature changes of dsvg_defer_scope / dsvg_gather_groups /
  * dsvg_bcast_add_bwd / dsvg_loss_targets / dsvg_scatter_rows counted).  dsvg_version() returns the value the library was
- * built with; a caller compiled against another header must refuse to run (deepsvg_amd/lib.py does). */
-#define DSVG_ABI_VERSION 2
+ * built with; a caller compiled against another header must refuse to run (deepsvg_amd/lib.py does).
+ * 3: dsvg_latent_chain_fwd / dsvg_latent_chain_bwd added. */
+#define DSVG_ABI_VERSION 3
 
 const char* dsvg_last_error(void);
 int dsvg_version(void);
@@ -581,6 +582,21 @@ int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, const void*
                       void* workspace, int64_t workspace_bytes, void* stream);
 /* test hook: raw ds_read_b64_tr_b16 on a 4 KiB LDS image img[i]=i, lane l reads at byte offset off[l] */
 int dsvg_probe_trread(const int* off, short* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The latent chain between the encoder and the decoder as ONE launch per direction (csrc/group_stage.hip):
+ *     z_i = z_{i-1} + relu(W_i z_{i-1} + b_i), i = 1 .. n_res   (ResNet, deepsvg/model/basic_blocks.py:59-65)
+ *     out = W_b z_{n_res} + b_b                                  (Bottleneck, deepsvg/model/model.py:193-198)
+ * bf16, d_model = dim_z = 256, one row per icon.  weights / biases: host arrays of n_res + 1 device pointers (row-major bf16
+ * [256, 256] / fp32 [256]; the final linear last); z_out / r_out: host arrays of n_res device pointers for the training
+ * outputs z_1 .. z_n and the ReLU outputs r_1 .. r_n (bf16 [rows, 256]; pass NULL arrays for inference).
+ * Backward: dout = dL/dout; dpre_out[i] = dz_{i+1} where r_{i+1} > 0 (the token-major operand of dW_{i+1} = dpre^T z_i; the
+ * final linear's dW takes dout and z_n), dz0 = dL/dz0.  Replaces 2 launches per block forward and 3 backward (the autograd
+ * backward of the same lines). */
+int dsvg_latent_chain_fwd(const void* z0, const void* const* weights, const float* const* biases, int32_t n_res,
+                          void* const* z_out, void* const* r_out, void* out, int64_t rows, void* stream);
+int dsvg_latent_chain_bwd(const void* dout, const void* const* weights, const void* const* r, int32_t n_res,
+                          void* const* dpre_out, void* dz0, int64_t rows, void* stream);
 
 #ifdef __cplusplus
 }

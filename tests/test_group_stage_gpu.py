@@ -308,3 +308,51 @@ def test_gs_layer_is_interchangeable_with_the_unfused_launches(gpu_device, n_seq
             tol = 2.5e-2 if not name.startswith(("dgamma", "dbeta")) else 1e-2
             _diff(f"backward {name} ({label}: fused vs unfused backward)", a, b, tol, bad)
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("rows", [512, 37, 1000])
+@pytest.mark.parametrize("n_res", [4, 0, 1])
+def test_latent_chain_kernels_match_the_unfused_launches(gpu_device, rows, n_res):
+    """dsvg_latent_chain_fwd / bwd (the latent ResNet + the bottleneck linear, one launch per direction) against the launches
+    they replace - GEMM + add per block forward; gate, input-gradient GEMM per block backward - and against the fp32 torch
+    restatement of the same chain (tests/torch_ops_ref.py)"""
+    from deepsvg_amd import ops
+    import tests.torch_ops_ref as R
+    g = torch.Generator().manual_seed(rows + n_res)
+    dev = gpu_device
+    z = (torch.randn(rows, 256, generator=g) * 0.8).to(dev).to(torch.bfloat16)
+    ws = [(torch.randn(256, 256, generator=g) * 0.06).to(dev).to(torch.bfloat16) for _ in range(n_res + 1)]
+    bs = [(torch.randn(256, generator=g) * 0.1).to(dev) for _ in range(n_res + 1)]
+    dout = torch.randn(rows, 256, generator=g).to(dev).to(torch.bfloat16)
+    out, zs, rs = ops.latent_chain_fwd(z, ws, bs, train=True) if n_res else (ops.latent_chain_fwd(z, ws, bs), [], [])
+    assert torch.equal(out, ops.latent_chain_fwd(z, ws, bs)), "inference and training variants differ"
+    # the unfused launches
+    cur, zs_u, rs_u = z, [], []
+    for i in range(n_res):
+        r = ops.gemm(cur, ws[i], bias=bs[i], act=ops.RELU)
+        cur = ops.add(cur, r)
+        zs_u.append(cur)
+        rs_u.append(r)
+    out_u = ops.gemm(cur, ws[n_res], bias=bs[n_res])
+    tol = dict(rtol=2e-2, atol=2e-2)
+    for a_, b_, what in [(out, out_u, "out")] + [(x, y, f"z{i + 1}") for i, (x, y) in enumerate(zip(zs, zs_u))] + \
+            [(x, y, f"r{i + 1}") for i, (x, y) in enumerate(zip(rs, rs_u))]:
+        assert torch.allclose(a_.float(), b_.float(), **tol), (what, (a_.float() - b_.float()).abs().max().item())
+    ro, rzs, rrs = R.latent_chain_fwd(z.cpu(), [w.cpu() for w in ws], [b.cpu() for b in bs], train=True)
+    assert torch.allclose(out.float().cpu(), ro.float(), **tol)
+    # backward on the FUSED forward's r (gates must be the same for a meaningful comparison)
+    dz0, dpre = ops.latent_chain_bwd(dout, ws, rs)
+    gcur = ops.gemm(dout, ws[n_res], b_kc=False)
+    dpre_u = [None] * n_res
+    for i in range(n_res - 1, -1, -1):
+        dp = ops.gate_mul(gcur, rs[i], 1.0)
+        dpre_u[i] = dp
+        gcur = ops.gemm(dp, ws[i], b_kc=False, res=gcur)
+    assert torch.allclose(dz0.float(), gcur.float(), **tol), (dz0.float() - gcur.float()).abs().max().item()
+    for i in range(n_res):
+        assert torch.allclose(dpre[i].float(), dpre_u[i].float(), **tol), (i, (dpre[i].float() - dpre_u[i].float()).abs().max().item())
+        assert torch.equal(dpre[i] == 0, (rs[i] <= 0) | (dpre[i] == 0))
+    rdz, rdp = R.latent_chain_bwd(dout.cpu(), [w.cpu() for w in ws], [r.cpu() for r in rs])
+    assert torch.allclose(dz0.float().cpu(), rdz.float(), **tol)
+    same = [torch.equal(out, out_u), torch.equal(dz0, gcur)]
+    print(f"latent chain rows {rows} n_res {n_res}: bit-identical to the unfused launches (out, dz0): {same}")

@@ -467,6 +467,37 @@ def test_fused_ffn_path_matches_unfused_with_emulated_ops(emulated_ops):
     assert med < 0.05, med
 
 
+def test_latent_chain_wiring_matches_the_unfused_blocks_with_emulated_ops(emulated_ops, monkeypatch):
+    """bf16 compute: the latent ResNet + bottleneck through functional.LatentChainFn (one launch per direction on the GPU) -
+    with the emulated ops the fused call restates the unfused launches with their bf16 roundings, so loss and gradients must be
+    IDENTICAL to the per-block path (DSVG_LATENT_FUSED=0): this pins the wiring (which z / r / dpre feeds which weight gradient)"""
+    from deepsvg_amd.synthetic import make_batch
+    import deepsvg_amd.functional as Fn
+    cfg = H.build_cfg("hier")
+    cfg.n_layers = cfg.n_layers_decode = 1
+    c, a = make_batch(6, seed=3)
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 4)
+    res, used = {}, {}
+    for fused in (True, False):
+        monkeypatch.setattr(Fn, "LATENT_FUSED", fused)
+        calls = []
+        real = Fn.LatentChainFn.apply
+        monkeypatch.setattr(Fn.LatentChainFn, "apply", lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1])
+        model = deepsvg_amd.SVGTransformer(cfg).eval()
+        model.load_state_dict(sd)
+        model.set_compute_dtype(torch.bfloat16)
+        out = model(c, a, c, a, params={})
+        ld = deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
+        ld["loss"].backward()
+        monkeypatch.setattr(Fn.LatentChainFn, "apply", real)
+        used[fused] = len(calls)
+        res[fused] = (float(ld["loss"].detach()), {n: p.grad.clone() for n, p in model.named_parameters()})
+    assert used == {True: 1, False: 0}
+    assert res[True][0] == res[False][0]
+    for n in res[True][1]:
+        assert torch.equal(res[True][1][n], res[False][1][n]), n
+
+
 def test_fused_attention_path_matches_unfused_with_emulated_ops(emulated_ops):
     """bf16 compute, every layer's attention sub-block through attn_pack / attn_block_fwd (packed tiles of the first
     encoder stage, dense key-masked group stages, the live-prefix decoder stage): with the emulated ops the fused call is

@@ -1039,6 +1039,31 @@ def keep_scale(p):
     return 65536.0 / (65536 - t)
 
 
+def latent_chain_fwd(z, weights, biases, train=False):
+    """csrc/group_stage.hip latent_chain_fwd_kernel: the unfused launches it replaces, with their bf16 roundings"""
+    n_res = len(weights) - 1
+    zs, rs = [], []
+    cur = z
+    for i in range(n_res):
+        r = torch.relu(_f(cur) @ _f(weights[i]).t() + biases[i]).to(z.dtype)
+        cur = (_f(cur) + _f(r)).to(z.dtype)
+        zs.append(cur)
+        rs.append(r)
+    out = (_f(cur) @ _f(weights[n_res]).t() + biases[n_res]).to(z.dtype)
+    return (out, zs, rs) if train else out
+
+
+def latent_chain_bwd(dout, weights, rs):
+    n_res = len(weights) - 1
+    g = (_f(dout) @ _f(weights[n_res])).to(dout.dtype)
+    dpre = [None] * n_res
+    for i in range(n_res - 1, -1, -1):
+        dp = torch.where(_f(rs[i]) > 0, _f(g), torch.zeros_like(_f(g))).to(dout.dtype)
+        dpre[i] = dp
+        g = (_f(g) + _f(dp) @ _f(weights[i])).to(dout.dtype)
+    return g, dpre
+
+
 def gate_mul(dy, y, scale=1.0):
     return torch.where(_f(y) > 0, _f(dy) * scale, torch.zeros_like(_f(dy))).to(dy.dtype)
 
