@@ -1052,9 +1052,9 @@ __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a)
 // backward launch (+ one grouped launch for the five weight gradients), a workgroup per 32 rows, its 8 waves split the 256
 // output features; the running row tile never leaves LDS.
 //   forward   A operands = weight fragments read straight from the row-major bf16 weight image (a lane's 8 consecutive k of
-//             one output feature are 16 contiguous bytes: no packing pass), 8 fragments ahead; B operands = the tile's rows.
+//             one output feature are 16 contiguous bytes: no packing pass), a whole block ahead; B operands = the tile's rows.
 //   backward  dz = dpre . W needs W TRANSPOSED fragments: the weight matrix passes through LDS in slabs of 32 rows (coalesced
-//             16-byte loads, one slab ahead in registers) and comes back through hardware-transposed reads (col_frag); the K
+//             16-byte loads, a whole matrix ahead in registers) and comes back through hardware-transposed reads (col_frag); the K
 //             order of those reads is rowmap-permuted, so the B operand takes the tile's row pieces in the same order.
 // Every intermediate is rounded to bf16 where the unfused launches store bf16 (r_i, z_i, dpre_i, dz_i): same values.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1071,6 +1071,18 @@ struct LatentBwdArgs {
     bf16_t* dz0;
     int n_rows, n_res;
 };
+// entry i of a small pointer array that lives in the kernel arguments (a run-time index into the by-value struct would move the
+// array to scratch memory: a chain of scalar selects instead)
+template <typename T>
+__device__ __forceinline__ T lc_pick(T const (&v)[LC_MAX], int i) {
+    return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : i == 3 ? v[3] : v[4];
+}
+template <typename T>
+__device__ __forceinline__ T lc_pick4(T const (&v)[LC_MAX - 1], int i) {
+    return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3];
+}
+typedef uint32_t lc_u32x4 __attribute__((ext_vector_type(4)));      // (a native vector: arrays of HIP's uint4 STRUCT are copied by
+                                                                    // memcpy, which keeps register arrays in scratch memory)
 constexpr int LC_IMG = 32 * LDX * 2;                    // bytes of one [32][LDX] image
 constexpr int LC_FWD_LDS = 4 * LC_IMG + LC_MAX * GD * 4;            // Z[2] | R[2] | biases
 constexpr int LC_BWD_LDS = 5 * LC_IMG;                              // G[2] | DP | WS[2]
@@ -1087,24 +1099,31 @@ __global__ __launch_bounds__(512, 2) void latent_chain_fwd_kernel(const LatentFw
     const int S = (int)min((long long)32, a.n_rows - row0);
     const int oc = wave * 32;                            // this wave's output-feature block
     const bool train = a.z[0] != nullptr;
+    // the weights do not depend on the activations: the 16 fragments of block blk + 1 are fetched while block blk computes (the
+    // launch is 16 workgroups deep in cold-memory latency, ~2.5 us per dependent round trip: one per block instead of three)
+    auto wfetch = [&](int blk, uint4 (&f)[16]) __attribute__((always_inline)) {
+        const char* wrow = reinterpret_cast<const char*>(lc_pick(a.w, blk)) + ((size_t)(oc + li) * GD + 8 * h2) * 2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) f[i] = *reinterpret_cast<const uint4*>(wrow + 32 * i);
+    };
+    uint4 wcur[16], wnext[16];
+    wfetch(0, wnext);
     load_image(Zi(0), LDX, 0, a.z0 + row0 * GD, GD, S, GD);
     for (int i = 0; i <= a.n_res; ++i)
-        if (tid < GD) sb[i * GD + tid] = a.b[i][tid];
+        if (tid < GD) sb[i * GD + tid] = lc_pick(a.b, i)[tid];
     lds_barrier();
     int cur = 0;
     for (int blk = 0; blk <= a.n_res; ++blk) {
-        const char* wrow = reinterpret_cast<const char*>(a.w[blk]) + ((size_t)(oc + li) * GD + 8 * h2) * 2;
-        uint4 ring[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ring[i] = *reinterpret_cast<const uint4*>(wrow + 32 * i);
+        for (int i = 0; i < 16; ++i) wcur[i] = wnext[i];
+        if (blk < a.n_res) wfetch(blk + 1, wnext);
         floatx16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             Frag8 wf;
-            wf.u = ring[ks & 7];
-            if (ks + 8 < 16) ring[ks & 7] = *reinterpret_cast<const uint4*>(wrow + 32 * (ks + 8));
+            wf.u = wcur[ks];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.v, row_frag(Zi(cur), LDX, li, 0, ks, h2), acc, 0, 0, 0);
         }
         const float* bb = sb + blk * GD + oc;
@@ -1121,8 +1140,8 @@ __global__ __launch_bounds__(512, 2) void latent_chain_fwd_kernel(const LatentFw
             if (train) stage_rows(Ri(blk & 1), LDX, li, oc, h2, rv);
             lds_barrier();
             if (train) {
-                store_image(a.z[blk] + row0 * GD, GD, Zi(cur ^ 1), LDX, 0, S, GD);
-                store_image(a.r[blk] + row0 * GD, GD, Ri(blk & 1), LDX, 0, S, GD);
+                store_image(lc_pick4(a.z, blk) + row0 * GD, GD, Zi(cur ^ 1), LDX, 0, S, GD);
+                store_image(lc_pick4(a.r, blk) + row0 * GD, GD, Ri(blk & 1), LDX, 0, S, GD);
             }
             cur ^= 1;
         } else {
@@ -1158,31 +1177,50 @@ __global__ __launch_bounds__(512, 2) void latent_chain_bwd_kernel(const LatentBw
     const int oc = wave * 32;
     const int er = tid >> 4, ec = (tid & 15) * 16;       // elementwise mapping: row er, columns ec .. ec + 15
     const long long erow = row0 + min(er, S - 1);
+    // a thread's 16 elements of every 32-row slab of a matrix: 8 slabs x 2 pieces; the NEXT step's matrix is fetched while this
+    // step's products run (the weights do not depend on the chain), so a step costs LDS traffic and barriers, not memory latency
+    auto mfetch = [&](int mi, lc_u32x4 (&fa)[8], lc_u32x4 (&fb)[8]) __attribute__((always_inline)) {
+        const bf16_t* wsrc = lc_pick(a.w, mi) + (size_t)er * GD + ec;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            fa[s] = *reinterpret_cast<const lc_u32x4*>(wsrc + (size_t)s * 32 * GD);
+            fb[s] = *reinterpret_cast<const lc_u32x4*>(wsrc + (size_t)s * 32 * GD + 8);
+        }
+    };
+    // two register sets, A and B, that swap roles from step to step (no copies: a copy loop between arrays makes the compiler keep
+    // all four in scratch memory); the step loop is fully unrolled over the at most LC_MAX steps
+    lc_u32x4 A0[8], A1[8], B0[8], B1[8];
+    mfetch(a.n_res, A0, A1);
     load_image(DP, LDX, 0, a.dout + row0 * GD, GD, S, GD);
     int cur = 0;
-    for (int step = 0; step <= a.n_res; ++step) {
+    auto do_step = [&](int step, lc_u32x4 (&ca)[8], lc_u32x4 (&cb)[8], lc_u32x4 (&na)[8], lc_u32x4 (&nb)[8]) __attribute__((always_inline)) {
         const int mi = a.n_res - step;                  // matrix of this step: the final linear first, then the blocks backwards
-        const bf16_t* W = a.w[mi];
-        // slab s = rows 32 s .. 32 s + 31 of W (the reduced index j), 16 elements per thread, one slab ahead in registers
-        const bf16_t* wsrc = W + (size_t)er * GD + ec;
-        uint4 sa = *reinterpret_cast<const uint4*>(wsrc), sb = *reinterpret_cast<const uint4*>(wsrc + 8);
+        if (mi > 0) {
+            const bf16_t* wsrc = lc_pick(a.w, mi - 1) + (size_t)er * GD + ec;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                na[s] = *reinterpret_cast<const lc_u32x4*>(wsrc + (size_t)s * 32 * GD);
+                nb[s] = *reinterpret_cast<const lc_u32x4*>(wsrc + (size_t)s * 32 * GD + 8);
+            }
+        }
         floatx16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int s = 0; s < 8; ++s) {
-            bf16_t* ws = WSi(s & 1);
-            *reinterpret_cast<uint4*>(&ws[er * LDX + ec]) = sa;
-            *reinterpret_cast<uint4*>(&ws[er * LDX + ec + 8]) = sb;
-            if (s + 1 < 8) {
-                sa = *reinterpret_cast<const uint4*>(wsrc + (size_t)(s + 1) * 32 * GD);
-                sb = *reinterpret_cast<const uint4*>(wsrc + (size_t)(s + 1) * 32 * GD + 8);
-            }
-            lds_barrier();          // slab s (and, for s = 0, the DP image) complete; everybody is past slab s - 1's buffer... of 2 ago
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(ws, LDX, oc, ks, lane),
-                                                             row_frag_perm(DP, LDX, li, 32 * s, ks, h2), acc, 0, 0, 0);
+        // (the 8 slabs written out: a loop with a barrier inside is unrolled too late for the register arrays to be split into
+        // registers - they would live in scratch memory)
+#define DSVG_LC_SLAB(s)                                                                                                \
+        {                                                                                                              \
+            bf16_t* ws = WSi((s) & 1);                                                                                 \
+            *reinterpret_cast<lc_u32x4*>(&ws[er * LDX + ec]) = ca[s];                                                  \
+            *reinterpret_cast<lc_u32x4*>(&ws[er * LDX + ec + 8]) = cb[s];                                              \
+            lds_barrier();      /* slab s (and, for s = 0, the DP image) complete; the buffer was last read two slabs ago */ \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(ws, LDX, oc, 0, lane),                               \
+                                                         row_frag_perm(DP, LDX, li, 32 * (s), 0, h2), acc, 0, 0, 0);     \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(ws, LDX, oc, 1, lane),                               \
+                                                         row_frag_perm(DP, LDX, li, 32 * (s), 1, h2), acc, 0, 0, 0);     \
         }
+        DSVG_LC_SLAB(0) DSVG_LC_SLAB(1) DSVG_LC_SLAB(2) DSVG_LC_SLAB(3) DSVG_LC_SLAB(4) DSVG_LC_SLAB(5) DSVG_LC_SLAB(6) DSVG_LC_SLAB(7)
+#undef DSVG_LC_SLAB
         // acc[r] = (DP . W)[row li][column oc + rowmap(r, h2)]
         float t[16];
         if (step == 0) {
@@ -1199,7 +1237,7 @@ __global__ __launch_bounds__(512, 2) void latent_chain_bwd_kernel(const LatentBw
         lds_barrier();              // dz of this step complete; every wave is done with DP
         if (mi > 0) {
             // dpre_{mi} = dz where r_{mi} > 0: elementwise, into DP (the next product's B operand) and to memory
-            const bf16_t* rr = a.r[mi - 1] + erow * GD + ec;
+            const bf16_t* rr = lc_pick4(a.r, mi - 1) + erow * GD + ec;
             const uint4 ra = *reinterpret_cast<const uint4*>(rr), rb = *reinterpret_cast<const uint4*>(rr + 8);
             const uint4 ga = *reinterpret_cast<const uint4*>(&Gi(cur)[er * LDX + ec]);
             const uint4 gb = *reinterpret_cast<const uint4*>(&Gi(cur)[er * LDX + ec + 8]);
@@ -1219,13 +1257,26 @@ __global__ __launch_bounds__(512, 2) void latent_chain_bwd_kernel(const LatentBw
             *reinterpret_cast<uint4*>(&DP[er * LDX + ec]) = pa;
             *reinterpret_cast<uint4*>(&DP[er * LDX + ec + 8]) = pb;
             if (er < S) {
-                bf16_t* dd = a.dpre[mi - 1] + (row0 + er) * GD + ec;
+                bf16_t* dd = lc_pick4(a.dpre, mi - 1) + (row0 + er) * GD + ec;
                 *reinterpret_cast<uint4*>(dd) = pa;
                 *reinterpret_cast<uint4*>(dd + 8) = pb;
             }
             // (the next step's first slab barrier orders these DP writes in front of its reads)
         } else {
             store_image(a.dz0 + row0 * GD, GD, Gi(cur), LDX, 0, S, GD);
+        }
+    };
+    // (written out: a loop over `step`, even a fully unrolled one, selects the arrays through pointers and they stay in scratch)
+    static_assert(LC_MAX == 5, "the step sequence below is written out for at most 5 matrices");
+    do_step(0, A0, A1, B0, B1);
+    if (a.n_res >= 1) {
+        do_step(1, B0, B1, A0, A1);
+        if (a.n_res >= 2) {
+            do_step(2, A0, A1, B0, B1);
+            if (a.n_res >= 3) {
+                do_step(3, B0, B1, A0, A1);
+                if (a.n_res >= 4) do_step(4, A0, A1, B0, B1);
+            }
         }
     }
 }

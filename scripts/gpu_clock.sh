@@ -12,7 +12,7 @@ echo "clock probe rc=$?"; cat gpurun_out/clock_probe.log | cut -c1-400
 cd /tmp
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv \
     -d $GRAFT_REPO_ROOT/gpurun_out/clockpmc -o p -- python $GRAFT_REPO_ROOT/bench.py --graph 0 --steps 6 --warmup 3 \
-    --no-cpu-baseline --no-fp32 --no-torch-ref --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/clock_pmc.log 2>&1
+    --no-cpu-baseline --no-fp32 --no-torch-ref --no-roofline --no-extra-legs > $GRAFT_REPO_ROOT/gpurun_out/clock_pmc.log 2>&1
 echo "pmc rc=$?"; tail -n 3 $GRAFT_REPO_ROOT/gpurun_out/clock_pmc.log | cut -c1-300
 cd $GRAFT_REPO_ROOT
 python - > gpurun_out/clock_pmc_summary.csv 2>&1 <<'PY'

@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
 TAG="${1:-steppmc}"
 cd /tmp
-run() { timeout 600 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG$1 -o p -- python $GRAFT_REPO_ROOT/bench.py --graph 0 --steps 3 --warmup 2 --no-cpu-baseline --no-fp32 --no-torch-ref --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/$TAG$1.log 2>&1; }
+run() { timeout 600 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG$1 -o p -- python $GRAFT_REPO_ROOT/bench.py --graph 0 --steps 3 --warmup 2 --no-cpu-baseline --no-fp32 --no-torch-ref --no-roofline --no-extra-legs > $GRAFT_REPO_ROOT/gpurun_out/$TAG$1.log 2>&1; }
 run a "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES"
 run b "FETCH_SIZE"
 run c "WRITE_SIZE"
