@@ -287,8 +287,32 @@ class ParamStore:
     def __setstate__(self, state):
         self.__init__(state["module"])
 
+    @staticmethod
+    def _grouped_order(module):
+        """module.parameters() with the linear_global weights (then biases) of every decoder stack moved next to each other, at
+        the position of the stack's first one: the stack's four weights are then ONE [4 * 256, 256] matrix in the flat
+        buffers - their gradients one weight-gradient GEMM (functional.GlobalCondFn).  Everything else keeps its order."""
+        params = [p for p in module.parameters()]
+        pos = {id(p): i for i, p in enumerate(params)}
+        for m in module.modules():
+            layers = getattr(m, "layers", None)
+            if layers is None or len(layers) < 2 or not all(hasattr(L, "linear_global") for L in layers):
+                continue
+            ws = [L.linear_global.weight for L in layers]
+            bs = [L.linear_global.bias for L in layers]
+            if any(b is None for b in bs) or len({tuple(w.shape) for w in ws}) != 1:
+                continue
+            group = ws + bs
+            ids = {id(p) for p in group}
+            first = min(pos[id(p)] for p in group)
+            rest = [p for p in params if id(p) not in ids]
+            n_before = sum(1 for p in params[:first] if id(p) not in ids)
+            params = rest[:n_before] + group + rest[n_before:]
+            pos = {id(p): i for i, p in enumerate(params)}
+        return params
+
     def _flatten(self, device):
-        params = [p for p in self.module.parameters()]
+        params = self._grouped_order(self.module)
         off = 0
         index = {}
         for p in params:

@@ -498,6 +498,44 @@ def test_latent_chain_wiring_matches_the_unfused_blocks_with_emulated_ops(emulat
         assert torch.equal(res[True][1][n], res[False][1][n]), n
 
 
+def test_decoder_conditioning_gradients_as_one_product_with_emulated_ops(emulated_ops, monkeypatch):
+    """functional.GlobalCondFn: the four linear_global weights of a decoder stack sit next to each other in the flat buffers
+    (ParamStore._grouped_order), so their gradients come from ONE weight-gradient product of the concatenated dg and dz from ONE
+    product over the concatenated reduction dimension (DSVG_GLOBAL_COND_CAT=0: one launch per layer).  Same numbers up to the
+    bf16 rounding of dz (one rounding instead of one per accumulating launch); state_dict order and values are untouched."""
+    from deepsvg_amd.synthetic import make_batch
+    import deepsvg_amd.functional as Fn
+    cfg = H.build_cfg("hier")
+    c, a = make_batch(6, seed=3)
+    ref = deepsvg_amd.SVGTransformer(cfg)
+    sd = H.weights_for(ref, 4)
+    res = {}
+    for cat in (True, False):
+        monkeypatch.setattr(Fn, "GLOBAL_COND_CAT", cat)
+        model = deepsvg_amd.SVGTransformer(cfg).eval()
+        model.load_state_dict(sd)
+        model.set_compute_dtype(torch.bfloat16)
+        out = model(c, a, c, a, params={})
+        ld = deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
+        ld["loss"].backward()
+        res[cat] = (float(ld["loss"].detach()), {n: p.grad.clone() for n, p in model.named_parameters()})
+        st = model.store
+        for stack in (model.decoder.decoder, model.decoder.hierarchical_decoder):
+            ws = [st.index[id(L.linear_global.weight)] for L in stack.layers]
+            bs = [st.index[id(L.linear_global.bias)] for L in stack.layers]
+            assert all(ws[i + 1][0] == ws[i][0] + ws[i][1] for i in range(len(ws) - 1)), "weights not adjacent"
+            assert all(bs[i + 1][0] == bs[i][0] + bs[i][1] for i in range(len(bs) - 1)), "biases not adjacent"
+        assert list(model.state_dict().keys()) == list(ref.state_dict().keys())
+        for k, v in model.state_dict().items():
+            assert torch.equal(v.cpu().float(), sd[k].float()), k
+    assert res[True][0] == res[False][0]
+    for n in res[True][1]:
+        if "linear_global" in n:        # the conditioning linears themselves: same products, fp32 sums (their dg inputs differ by dz's rounding upstream)
+            assert H.rel_l2(res[True][1][n], res[False][1][n]) < 1e-2, n
+    worst, name = max((H.rel_l2(res[True][1][n], res[False][1][n]), n) for n in res[True][1])
+    assert worst < 3e-2, (worst, name)
+
+
 def test_fused_attention_path_matches_unfused_with_emulated_ops(emulated_ops):
     """bf16 compute, every layer's attention sub-block through attn_pack / attn_block_fwd (packed tiles of the first
     encoder stage, dense key-masked group stages, the live-prefix decoder stage): with the emulated ops the fused call is
