@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
         int n_seq, int Smax, long long total_rows, bf16_t* __restrict__ x1, bf16_t* __restrict__ xn_out,
         bf16_t* __restrict__ qkv_out, bf16_t* __restrict__ ao_out, float* __restrict__ mean_out,
         float* __restrict__ rstd_out, float eps, float scale, float drop_p, const uint64_t* __restrict__ seed,
-        uint32_t site_p, uint32_t site_r, const bf16_t* __restrict__ gadd, uint32_t site_g) {
+        uint32_t site_p, uint32_t site_r, const bf16_t* __restrict__ gadd, long long gadd_ld, uint32_t site_g) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];   // [NBUF slots | biases, gamma, beta | 8 staging tiles]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
     const char* xres = reinterpret_cast<const char*>(x) + (size_t)my_row * (AD * 2);
     // optional per-sequence conditioning row (the decoder's linear_global(z), improved_transformer.py:131-136): x1 += drop(g)
     // with one mask element per (sequence, channel) - ids seq * 256 + column - as dsvg_bcast_add_fwd draws them
-    const char* grow = gadd ? reinterpret_cast<const char*>(gadd) + (size_t)my_seq * (AD * 2) : nullptr;
+    const char* grow = gadd ? reinterpret_cast<const char*>(gadd) + (size_t)my_seq * (size_t)gadd_ld * 2 : nullptr;
     char* yrow = reinterpret_cast<char*>(x1) + (size_t)my_row * (AD * 2);
 #pragma unroll 1
     for (int u = 0; u < 4; ++u) {
@@ -569,7 +569,7 @@ extern "C" int dsvg_attn_block_fwd(const void* x, const void* packed_layer, cons
                                    const int32_t* tile_first, int64_t n_seq, int32_t S, int64_t rows, void* x1, void* xn_out,
                                    void* qkv_out, void* ao_out, float* mean_out, float* rstd_out, float eps, float scale,
                                    float drop_p, uint32_t site_probs, uint32_t site_res, const void* seed,
-                                   const void* seq_add, uint32_t site_seq_add, void* stream) {
+                                   const void* seq_add, int64_t seq_add_ld, uint32_t site_seq_add, void* stream) {
     DSVG_CHECK_ARG(x && packed_layer && in_bias && out_bias && gamma && beta && x1, "attn_block_fwd: null pointer");
     DSVG_CHECK_ARG(S >= 1 && S <= 32, "attn_block_fwd: sequences of at most 32 tokens (got %d)", S);
     DSVG_CHECK_ARG(n_seq > 0 && rows > 0 && rows < (1ll << 31), "attn_block_fwd: bad sizes");
@@ -583,6 +583,7 @@ extern "C" int dsvg_attn_block_fwd(const void* x, const void* packed_layer, cons
     DSVG_CHECK_ARG((((uintptr_t)x | (uintptr_t)x1 | (uintptr_t)packed_layer | (uintptr_t)xn_out | (uintptr_t)qkv_out |
                      (uintptr_t)ao_out | (uintptr_t)seq_add) & 15) == 0, "attn_block_fwd: operands must be 16-byte aligned");
     DSVG_CHECK_ARG(!seq_add || !tiled, "attn_block_fwd: the per-sequence add is wired for the dense layouts");
+    DSVG_CHECK_ARG(!seq_add || (seq_add_ld >= AD && seq_add_ld % 8 == 0), "attn_block_fwd: bad seq_add row stride %lld", (long long)seq_add_ld);
     // waves: one per attention tile + one per 32 rows of bucket padding behind the last sequence.  Adjacent tiles of the
     // packed layout hold more than 32 rows together, so there are at most rows / 16 + 1 of them (and at most n_seq)
     long long waves;
@@ -603,7 +604,7 @@ extern "C" int dsvg_attn_block_fwd(const void* x, const void* packed_layer, cons
                            (const bf16_t*)packed_layer, in_bias, out_bias, gamma, beta, key_mask, seq_off, tile_first, \
                            (int)n_seq, (int)S, (long long)rows, (bf16_t*)x1, (bf16_t*)xn_out, (bf16_t*)qkv_out,        \
                            (bf16_t*)ao_out, mean_out, rstd_out, eps, scale, drop_p, (const uint64_t*)seed, site_probs, \
-                           site_res, (const bf16_t*)seq_add, site_seq_add);                                            \
+                           site_res, (const bf16_t*)seq_add, (long long)seq_add_ld, site_seq_add);                                            \
     } while (0)
     if (train) { if (tiled) DSVG_ATTN_FWD(true, true); else DSVG_ATTN_FWD(true, false); }
     else { if (tiled) DSVG_ATTN_FWD(false, true); else DSVG_ATTN_FWD(false, false); }

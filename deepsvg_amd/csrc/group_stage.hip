@@ -225,6 +225,7 @@ struct GsFwdArgs {
     const float* in_bias; const float* out_bias; const float* b1; const float* b2;
     const float* g1; const float* be1; const float* g2; const float* be2;
     const uint64_t* key_mask; const bf16_t* gadd; const uint64_t* seed;
+    long long gadd_ld;      // row stride (elements) of gadd
     bf16_t* x2;
     float* mean1; float* rstd1; bf16_t* xn1; bf16_t* qkv; bf16_t* ao; bf16_t* x1;
     float* mean2; float* rstd2; bf16_t* xn2; bf16_t* h;
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             xr[c] = *reinterpret_cast<const uint2*>(a.x + mrow * GD + qc + 8 * c + 4 * h2);
-            if (a.gadd) gr4[c] = *reinterpret_cast<const uint2*>(a.gadd + (long long)my_seq * GD + qc + 8 * c + 4 * h2);
+            if (a.gadd) gr4[c] = *reinterpret_cast<const uint2*>(a.gadd + (long long)my_seq * a.gadd_ld + qc + 8 * c + 4 * h2);
         }
         floatx16 ya;
 #pragma unroll
@@ -1311,7 +1312,7 @@ extern "C" int dsvg_gs_debug_clock(void* buf) {
 extern "C" int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, const float* in_bias, const float* out_bias,
                                  const float* b1, const float* b2, const float* gamma1, const float* beta1,
                                  const float* gamma2, const float* beta2, const uint64_t* key_mask, const void* seq_add,
-                                 int64_t n_seq, int32_t S, void* x2, float* mean1, float* rstd1, void* xn1, void* qkv,
+                                 int64_t seq_add_ld, int64_t n_seq, int32_t S, void* x2, float* mean1, float* rstd1, void* xn1, void* qkv,
                                  void* ao, void* x1, float* mean2, float* rstd2, void* xn2, void* h, float eps,
                                  float scale, float drop_p, uint32_t site0, const void* seed, int64_t seq_base,
                                  int32_t ffn_format, void* stream) {
@@ -1321,6 +1322,7 @@ extern "C" int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, co
     DSVG_CHECK_ARG(seq_base >= 0 && (seq_base + n_seq) * S < (1ll << 31), "gs_layer_fwd: bad sequence offset");
     DSVG_CHECK_ARG(n_seq > 0 && n_seq * S < (1ll << 31), "gs_layer_fwd: bad sizes");
     DSVG_CHECK_ARG(!(drop_p > 0.f) || seed, "gs_layer_fwd: dropout needs a seed");
+    DSVG_CHECK_ARG(!seq_add || (seq_add_ld >= GD && seq_add_ld % 8 == 0), "gs_layer_fwd: bad seq_add row stride %lld", (long long)seq_add_ld);
     const bool train = xn1 != nullptr;
     DSVG_CHECK_ARG(!train || (mean1 && rstd1 && qkv && ao && x1 && mean2 && rstd2 && xn2 && h),
                    "gs_layer_fwd: the training outputs come together");
@@ -1332,6 +1334,7 @@ extern "C" int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, co
     a.in_bias = in_bias; a.out_bias = out_bias; a.b1 = b1; a.b2 = b2;
     a.g1 = gamma1; a.be1 = beta1; a.g2 = gamma2; a.be2 = beta2;
     a.key_mask = key_mask; a.gadd = (const bf16_t*)seq_add; a.seed = (const uint64_t*)seed;
+    a.gadd_ld = seq_add ? (long long)seq_add_ld : GD;
     a.x2 = (bf16_t*)x2; a.mean1 = mean1; a.rstd1 = rstd1; a.xn1 = (bf16_t*)xn1; a.qkv = (bf16_t*)qkv; a.ao = (bf16_t*)ao;
     a.x1 = (bf16_t*)x1; a.mean2 = mean2; a.rstd2 = rstd2; a.xn2 = (bf16_t*)xn2; a.h = (bf16_t*)h;
     a.n_seq = (int)n_seq; a.S = S; a.eps = eps; a.scale = scale; a.drop_p = drop_p; a.site0 = site0;

@@ -491,6 +491,21 @@ class GlobalCondFn(torch.autograd.Function):
         pairs = list(zip(wb[0::2], wb[1::2]))
         ctx.rt, ctx.n = rt, len(pairs)
         ctx.save_for_backward(z, *wb)
+        st = rt.store
+        if (GLOBAL_COND_CAT and z.dtype == torch.bfloat16 and len(pairs) > 1 and st is not None
+                and all(id(t) in st.index for pr in pairs for t in pr) and len({tuple(w.shape) for w, _b in pairs}) == 1):
+            # the stack's weights / biases are adjacent in the flat buffers (ParamStore._grouped_order): ONE product
+            # z [rows, 256] x Wcat [n * 256, 256]^T -> [rows, n * 256]; layer l reads its column block (row stride n * 256:
+            # the fused kernels take it as seq_add_ld)
+            ow = [st.index[id(w)] for w, _b in pairs]
+            ob = [st.index[id(b)] for _w, b in pairs]
+            w0, b0 = rt.w(pairs[0][0]), pairs[0][1].detach()
+            if (all(ow[i + 1][0] == ow[i][0] + ow[i][1] and ob[i + 1][0] == ob[i][0] + ob[i][1] for i in range(len(pairs) - 1))
+                    and w0.is_contiguous() and b0.is_contiguous()):
+                n_out, k_in = sum(w.shape[0] for w, _b in pairs), w0.shape[1]
+                gcat = ops.gemm(z, torch.as_strided(w0, (n_out, k_in), (k_in, 1)), bias=torch.as_strided(b0, (n_out,), (1,)))
+                d = w0.shape[0]
+                return tuple(gcat[:, i * d:(i + 1) * d] for i in range(len(pairs)))
         return tuple(ops.gemm(z, rt.w(w), bias=b.detach()) for w, b in pairs)
 
     @staticmethod
@@ -670,7 +685,7 @@ class LayerFn(torch.autograd.Function):
             x1 = ops.gemm(ao, rt.w(wo), bias=bo.detach(), res=x, drop_p=p, drop_site=site0 + 1, seed=rt.seed)
         ctx.tiles, ctx.causal = tiles, causal
         if z is not None and not z_fused:
-            g = z if wg is None else ops.gemm(z, rt.w(wg), bias=bg.detach())
+            g = z.contiguous() if wg is None else ops.gemm(z, rt.w(wg), bias=bg.detach())      # (z: maybe a column block)
             ops.bcast_add_fwd_(x1, g, n_seq, S, p, site0 + 2, rt.seed)
         if l is not None:
             g2 = ops.gemm(l, rt.w(wg2), bias=bg2.detach())

@@ -14,7 +14,7 @@ DSVG_F32 = 0
 DSVG_BF16 = 1
 # == DSVG_ABI_VERSION of include/dsvg.h at the time SIGNATURES below was written: load() refuses a library built from another
 # header (a stale .so with the old argument lists would otherwise be called with a stream where a size is expected)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_i32, c_i64, c_u32, c_f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_float
 vp = C.c_void_p
@@ -130,10 +130,10 @@ SIGNATURES = {
     "dsvg_attn_pack_bytes": (c_i64, [c_i32]),
     "dsvg_attn_pack": (c_i32, [vp, vp, c_i32, c_i32, c_i32, vp, vp]),
     "dsvg_attn_block_fwd": (c_i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_i64, vp, vp, vp, vp, vp, vp,
-                                    c_f32, c_f32, c_f32, c_u32, c_u32, vp, vp, c_u32, vp]),
+                                    c_f32, c_f32, c_f32, c_u32, c_u32, vp, vp, c_i64, c_u32, vp]),
     "dsvg_gs_pack_bytes": (c_i64, [c_i32]),
     "dsvg_gs_pack": (c_i32, [vp, vp, c_i32, c_i32, c_i32, c_i32, vp, vp, vp]),
-    "dsvg_gs_layer_fwd": (c_i32, [vp] * 12 + [c_i64, c_i32] + [vp] * 11 + [c_f32, c_f32, c_f32, c_u32, vp, c_i64, c_i32, vp]),
+    "dsvg_gs_layer_fwd": (c_i32, [vp] * 12 + [c_i64, c_i64, c_i32] + [vp] * 11 + [c_f32, c_f32, c_f32, c_u32, vp, c_i64, c_i32, vp]),
     "dsvg_gs_bwd_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "dsvg_latent_chain_fwd": (c_i32, [vp, vp, vp, c_i32, vp, vp, vp, c_i64, vp]),
     "dsvg_latent_chain_bwd": (c_i32, [vp, vp, vp, c_i32, vp, vp, c_i64, vp]),

@@ -1234,7 +1234,9 @@ def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_
     assert (seq_off is None) == (tiles is None) and (seq_off is None or key_mask is None)
     if seq_add is not None:
         _chk(seq_add)
-        assert seq_off is None and seq_add.dtype == x.dtype and seq_add.is_contiguous() and tuple(seq_add.shape) == (n_seq, 256)
+        # (row stride free: a column block of the stack's [n_seq, layers * 256] conditioning matrix, functional.GlobalCondFn)
+        assert seq_off is None and seq_add.dtype == x.dtype and tuple(seq_add.shape) == (n_seq, 256)
+        assert seq_add.stride(1) == 1 and seq_add.stride(0) % 8 == 0 and seq_add.data_ptr() % 16 == 0
     xn = qkv = ao = mean = rstd = None
     if into is not None:        # (x1, xn, qkv, ao, mean, rstd) given: row slices of longer buffers
         assert train and len(into) == 6 and all(t.is_contiguous() and t.shape[0] == rows for t in into)
@@ -1252,7 +1254,8 @@ def attn_block_fwd(x, packed_layer, in_bias, out_bias, gamma, beta, key_mask, n_
                                            gamma.data_ptr(), beta.data_ptr(), _p(key_mask), _p(seq_off), _p(tiles), n_seq,
                                            S, rows, x1.data_ptr(), _p(xn), _p(qkv), _p(ao), _p(mean), _p(rstd), float(eps),
                                            float(scale), float(drop_p), int(site_probs), int(site_res),
-                                           _p(seed) if drop_p > 0 else None, _p(seq_add), int(site_seq_add), _stream()),
+                                           _p(seed) if drop_p > 0 else None, _p(seq_add),
+                                           int(seq_add.stride(0)) if seq_add is not None else 256, int(site_seq_add), _stream()),
              "dsvg_attn_block_fwd")
     _prof_end(ev, 2.0 * rows * 256 * 1024 + 4.0 * rows * 32 * 256, 1024.0 * rows + (2560.0 * rows if train else 0.0),
               dict(op="attn_block_fwd", rows=rows, train=bool(train)))
@@ -1300,7 +1303,8 @@ def gs_layer_fwd(x, packed_fwd_layer, in_bias, out_bias, b1, b2, gamma1, beta1, 
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
     assert key_mask is None or (key_mask.dtype == torch.int64 and key_mask.numel() >= n_seq)
     if seq_add is not None:
-        assert seq_add.dtype == x.dtype and seq_add.is_contiguous() and tuple(seq_add.shape) == (n_seq, 256)
+        assert seq_add.dtype == x.dtype and tuple(seq_add.shape) == (n_seq, 256)
+        assert seq_add.stride(1) == 1 and seq_add.stride(0) % 8 == 0 and seq_add.data_ptr() % 16 == 0
     dev = x.device
     if into is not None:
         assert train and len(into) == 11
@@ -1318,7 +1322,8 @@ def gs_layer_fwd(x, packed_fwd_layer, in_bias, out_bias, b1, b2, gamma1, beta1, 
     ev = _prof_begin()
     _l.check(_l.load().dsvg_gs_layer_fwd(x.data_ptr(), packed_fwd_layer.data_ptr(), in_bias.data_ptr(), out_bias.data_ptr(),
                                          b1.data_ptr(), b2.data_ptr(), gamma1.data_ptr(), beta1.data_ptr(),
-                                         gamma2.data_ptr(), beta2.data_ptr(), _p(key_mask), _p(seq_add), n_seq, S,
+                                         gamma2.data_ptr(), beta2.data_ptr(), _p(key_mask), _p(seq_add),
+                                         int(seq_add.stride(0)) if seq_add is not None else 256, n_seq, S,
                                          x2.data_ptr(), *[_p(t) for t in sv], float(eps), float(scale), float(drop_p),
                                          int(site0), _p(seed) if drop_p > 0 else None, int(seq_base), int(bool(ffn_format)),
                                          _stream()), "dsvg_gs_layer_fwd")

@@ -32,8 +32,8 @@ extern "C" {
  * dsvg_attn_block_fwd_stages removed, round 3's signature changes of dsvg_defer_scope / dsvg_gather_groups /
  * dsvg_bcast_add_bwd / dsvg_loss_targets / dsvg_scatter_rows counted).  dsvg_version() returns the value the library was
  * built with; a caller compiled against another header must refuse to run (deepsvg_amd/lib.py does).
- * 3: dsvg_latent_chain_fwd / dsvg_latent_chain_bwd added. */
-#define DSVG_ABI_VERSION 3
+ * 3: dsvg_latent_chain_fwd / dsvg_latent_chain_bwd added.  4: seq_add_ld argument of dsvg_attn_block_fwd / dsvg_gs_layer_fwd. */
+#define DSVG_ABI_VERSION 4
 
 const char* dsvg_last_error(void);
 int dsvg_version(void);
@@ -517,7 +517,8 @@ int dsvg_gs_debug_clock(void* buf);
  *   block-diagonal attention inside each tile of <= 32 rows).  Rows behind the last sequence (bucket padding up to
  *   `rows`) get finite values.  Dropout: site_probs on the probabilities (same element ids as dsvg_attention_fwd),
  *   site_res on the residual branch (ids row*256 + col, replayable by dsvg_drop_apply).
- *   seq_add (optional, dense layouts): bf16 [n_seq, 256], x1 += drop(seq_add[sequence]) with one mask element per
+ *   seq_add (optional, dense layouts): bf16 [n_seq, 256] with row stride seq_add_ld elements (256 = contiguous; a column block
+ *   of a wider matrix otherwise: the conditioning rows of all the layers of a stack come from ONE GEMM), x1 += drop(seq_add[sequence]) with one mask element per
  *   (sequence, channel), site_seq_add - the decoder's linear_global(z) term (improved_transformer.py:131-136), same draws
  *   as dsvg_bcast_add_fwd, whose backward (dsvg_bcast_add_bwd) applies unchanged.
  *   Training outputs (all NULL for inference, all set otherwise) are what the unfused backward reads:
@@ -532,7 +533,7 @@ int dsvg_attn_block_fwd(const void* x, const void* packed_layer, const float* in
                         const int32_t* tile_first, int64_t n_seq, int32_t S, int64_t rows, void* x1, void* xn_out,
                         void* qkv_out, void* ao_out, float* mean_out, float* rstd_out, float eps, float scale,
                         float drop_p, uint32_t site_probs, uint32_t site_res, const void* seed,
-                        const void* seq_add, uint32_t site_seq_add, void* stream);
+                        const void* seq_add, int64_t seq_add_ld, uint32_t site_seq_add, void* stream);
 /* ------------------------------------------------------------------------------------------
  * One launch per layer and direction for the short-sequence ("group") stages: the whole pre-LN block
  *     x1 = x  + drop( out_proj( MHA( LayerNorm1(x) ) ) ) [+ drop( seq_add[sequence] )]
@@ -569,7 +570,7 @@ int dsvg_gs_pack(const float* flat_f32, const int64_t* offs, int32_t n_layers, i
                  int32_t n_heads, void* packed_fwd, void* packed_bwd, void* stream);
 int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, const float* in_bias, const float* out_bias,
                       const float* b1, const float* b2, const float* gamma1, const float* beta1, const float* gamma2,
-                      const float* beta2, const uint64_t* key_mask, const void* seq_add, int64_t n_seq, int32_t S,
+                      const float* beta2, const uint64_t* key_mask, const void* seq_add, int64_t seq_add_ld, int64_t n_seq, int32_t S,
                       void* x2, float* mean1, float* rstd1, void* xn1, void* qkv, void* ao, void* x1, float* mean2,
                       float* rstd2, void* xn2, void* h, float eps, float scale, float drop_p, uint32_t site0,
                       const void* seed, int64_t seq_base, int32_t ffn_format, void* stream);
