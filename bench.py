@@ -293,17 +293,18 @@ class SclkSampler:
     def __init__(self, index):
         import glob
         import threading
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
-        self.path = cards[index] if index < len(cards) else None
-        self.samples, self.stop = [], False
-        self.thread = threading.Thread(target=self._run, daemon=True) if self.path else None
+        # (the drm card index of torch's device `index` is not known here: every GPU's file is sampled, the busiest one reported)
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        self.samples, self.stop = {p: [] for p in self.paths}, False
+        self.thread = threading.Thread(target=self._run, daemon=True) if self.paths else None
 
     def _run(self):
         while not self.stop:
-            try:
-                self.samples.append(float(open(self.path).read()) / 1e6)
-            except (OSError, ValueError):
-                pass
+            for p in self.paths:
+                try:
+                    self.samples[p].append(float(open(p).read()) / 1e6)
+                except (OSError, ValueError):
+                    pass
             time.sleep(0.005)
 
     def __enter__(self):
@@ -317,11 +318,16 @@ class SclkSampler:
             self.thread.join(timeout=1.0)
 
     def summary(self):
-        v = sorted(self.samples)
-        if not v:
+        best = None
+        for p, vals in self.samples.items():
+            v = sorted(vals)
+            if v and (best is None or v[len(v) // 2] > best[1][len(best[1]) // 2]):
+                best = (p, v)
+        if best is None:
             return None
-        return {"source": self.path, "samples": len(v), "min_mhz": round(v[0]), "median_mhz": round(v[len(v) // 2]),
-                "max_mhz": round(v[-1])}
+        p, v = best
+        return {"source": p, "gpus_sampled": len(self.paths), "samples": len(v), "min_mhz": round(v[0]),
+                "median_mhz": round(v[len(v) // 2]), "max_mhz": round(v[-1])}
 
 
 def in_kernel_clock_probe(rows, device):
