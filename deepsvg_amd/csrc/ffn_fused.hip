@@ -441,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
 // every SIMD of half the CUs (1,000 rows: 28 us against 39; at full size the two kernels are equal, and delaying the second
 // workgroup of a CU so that its prologue runs beside its partner's chunk loop - tried with a per-CU turn counter keyed by
 // HW_ID / XCC_ID, removed again - gained nothing: two 128-row workgroups stream the weights twice, which saturates the
-// L2 -> LDS path).
+// L2 -> LDS path, see HISTORY.md "Round 3").
 //   sync(hc) in front of every G: half chunk hc + 1 has landed (the A ring runs on into it), half chunk hc + 3 is issued
 //   into the slot half chunk hc - 1 has left; hc + 2 stays in flight across the barrier (counted wait: 4 pieces per wave).
 // ---------------------------------------------------------------------------------------------------------------------

@@ -3,7 +3,7 @@ forward(output, labels, weights) -> {"loss", "loss_cmd", "loss_args"[, "loss_vis
 
 The three cross-entropies run in the masked-CE HIP kernels (no boolean-mask gathers, no host syncs, static
 shapes -> hipGraph-capturable).  Mask semantics: the `extended` padding mask uses the non-aliased reading of
-deepsvg/model/utils.py:25-28 (mask | mask shifted by 3), see DESIGN.md "loss_cmd mask".
+deepsvg/model/utils.py:25-28 (mask | mask shifted by 3), see DESIGN.md section 5, "loss_cmd mask".
 """
 import os
 

@@ -388,7 +388,7 @@ def test_full_size_properties_512_icons(gpu_device):
     for n in n1:
         if n.endswith("arg_embed.weight"):
             # the one schedule-dependent sum of the path: LDS float atomics inside a workgroup of the argument-embedding
-            # scatter (DESIGN.md "Determinism"); everything else reduces in a fixed order
+            # scatter ("Determinism"); everything else reduces in a fixed order
             assert H.rel_l2(n1[n], n2[n]) < 1e-6, n
         else:
             assert torch.equal(n1[n], n2[n]), f"gradient of {n} is not bit-reproducible"
