@@ -196,6 +196,18 @@ def torch_rocm_reference(cfg, sd, batch, device, dropout, steps=5):
                     "it by tests/golden) with torch.optim.AdamW and clip_grad_norm_, stock aten kernels on this GPU"}
 
 
+def kernel_source_hash(path):
+    """SHA-256 (16 hex digits) of a kernel source with comments and whitespace removed: what a committed PMC measurement names
+    as the code it was taken on (an edited comment does not make it stale, an edited kernel does)"""
+    import hashlib
+    import re
+    t = open(path).read()
+    t = re.sub(r"/\*.*?\*/", "", t, flags=re.S)
+    t = re.sub(r"//[^\n]*", "", t)
+    t = re.sub(r"\s+", " ", t)
+    return hashlib.sha256(t.encode()).hexdigest()[:16]
+
+
 def dense_layout_leg(cfg, sd_cpu, batches, device, steps=5):
     """the same train step with every exact work-skipping layout switched OFF (padded encoder rows, all 8 groups of the
     second decoder stage forward and backward, dense argument head): the like-for-like number against the reference's padded
@@ -749,17 +761,15 @@ def main():
             if os.path.exists(tj):
                 t = json.load(open(tj))
                 if t.get("dtype") == a.dtype and "MB_per_launch" in t:
-                    import hashlib
-                    src = os.path.join(ROOT, "deepsvg_amd", "csrc", "ffn_fused.hip")
-                    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+                    sha = kernel_source_hash(os.path.join(ROOT, "deepsvg_amd", "csrc", "ffn_fused.hip"))
                     roofline["traffic"] = t["MB_per_launch"]
                     roofline["traffic_source"] = "committed: " + t["source"]
                     roofline["traffic_over_fused_algorithmic"] = t.get("over_fused_algorithmic")
                     # the committed measurement names the commit and the kernel source it was taken on; a kernel edited since
                     # then makes the number stale (tests/test_bench_gpu.py fails on it)
-                    roofline["traffic_collected_at"] = {"commit": t.get("commit"), "ffn_fused_hip_sha256_16": t.get("ffn_fused_hip_sha256_16"),
-                                                        "current_ffn_fused_hip_sha256_16": sha,
-                                                        "kernel_source_unchanged": t.get("ffn_fused_hip_sha256_16") == sha}
+                    roofline["traffic_collected_at"] = {"commit": t.get("commit"), "ffn_fused_hip_code_sha256_16": t.get("ffn_fused_hip_code_sha256_16"),
+                                                        "current_ffn_fused_hip_code_sha256_16": sha,
+                                                        "kernel_source_unchanged": t.get("ffn_fused_hip_code_sha256_16") == sha}
             gcsv = os.path.join(ROOT, "profiles", "r04_graph_kernel_stats.csv")
             if not os.path.exists(gcsv):
                 gcsv = os.path.join(ROOT, "profiles", "r03_graph_kernel_stats.csv")

@@ -14,7 +14,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 cd $GRAFT_REPO_ROOT
 python - > gpurun_out/ffn_traffic.json <<'PY'
-import csv, glob, hashlib, json, subprocess
+import csv, glob, json, subprocess, sys
+sys.path.insert(0, ".")
+from bench import kernel_source_hash
 def per_dispatch(counter):
     f = glob.glob(f"gpurun_out/ffntr_{counter}/**/*counter_collection.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and "ffn_fwd_kernel" in r["Kernel_Name"]]
@@ -54,7 +56,7 @@ out.update({
     "over_fused_algorithmic": round(big["MB_per_launch"] / big["fused_algorithmic_MB"], 2),
     "expected_MB_training_variant": big["algorithmic_MB_training_variant"],
     "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None,
-    "ffn_fused_hip_sha256_16": hashlib.sha256(open("deepsvg_amd/csrc/ffn_fused.hip", "rb").read()).hexdigest()[:16],
+    "ffn_fused_hip_code_sha256_16": kernel_source_hash("deepsvg_amd/csrc/ffn_fused.hip"),
     "source": "scripts/gpu_ffn_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over scripts/ffn_traffic_run.py; "
               "FETCH_SIZE calibrated on the inference variant of the same kernel: known read bytes / reported)"})
 print(json.dumps(out, indent=1))

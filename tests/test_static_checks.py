@@ -25,3 +25,14 @@ def test_no_spill_inside_a_loop(tmp_path, src):
     inside = [l for l in rows if int(re.search(r"inside loops\s+(\d+)", l).group(1)) > 0]
     assert not inside, "\n".join(inside)
     assert any("mfma" in l for l in r.stdout.splitlines())          # the scan found the kernels' loops
+
+
+def test_committed_ffn_traffic_was_measured_on_this_kernel_source():
+    """profiles/ffn_traffic.json (bench.py's roofline.traffic, a committed rocprofv3 --pmc measurement) names the code of
+    csrc/ffn_fused.hip it was collected on: an edited kernel makes the number stale - re-run scripts/gpu_ffn_traffic.sh"""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    t = json.load(open(os.path.join(ROOT, "profiles", "ffn_traffic.json")))
+    assert t["ffn_fused_hip_code_sha256_16"] == bench.kernel_source_hash(os.path.join(ROOT, "deepsvg_amd", "csrc", "ffn_fused.hip"))
+    assert t.get("commit")
