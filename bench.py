@@ -305,8 +305,17 @@ class SclkSampler:
     def __init__(self, index):
         import glob
         import threading
-        # (the drm card index of torch's device `index` is not known here: every GPU's file is sampled, the busiest one reported)
+        # the drm card of torch's device `index`, by PCI address; every GPU's file otherwise (then the one whose clock MOVES most
+        # is reported: an idle neighbour sits at a constant clock)
         self.paths = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            mine = [p for p in self.paths if addr in os.path.realpath(p.split("/hwmon/")[0])]
+            if mine:
+                self.paths = mine[:1]
+        except Exception:       # noqa: BLE001  (older torch: no PCI fields)
+            pass
         self.samples, self.stop = {p: [] for p in self.paths}, False
         self.thread = threading.Thread(target=self._run, daemon=True) if self.paths else None
 
@@ -333,7 +342,7 @@ class SclkSampler:
         best = None
         for p, vals in self.samples.items():
             v = sorted(vals)
-            if v and (best is None or v[len(v) // 2] > best[1][len(best[1]) // 2]):
+            if v and (best is None or (v[-1] - v[0]) > (best[1][-1] - best[1][0])):
                 best = (p, v)
         if best is None:
             return None
