@@ -792,6 +792,27 @@ def main():
                             "graph_replay_avg_us": float(f[3]), "launches_profiled": int(f[1]),
                             "live_event_avg_us": round(fk_ms * 1e3 / max(len(fk), 1), 1)}
                         break
+            if os.path.exists(gcsv) and fused_fwd is not None and wgrad is not None:
+                # the same family inside the replayed graph (the leg above times eager launches, each with its launch latency
+                # exposed): per-step totals of the committed rocprofv3 trace of `bench.py --graph 1`, the deferred reductions
+                # shared out as in the live leg
+                tot = {}
+                for line in open(gcsv):
+                    f = line.strip().split(",")
+                    if len(f) > 3 and f[1].isdigit():
+                        tot[f[0]] = (int(f[1]), float(f[2]))
+                steps_prof = sum(c for k, (c, _) in tot.items() if "ffn_fwd_kernel" in k) / max(fused_fwd["launches_per_step"], 1)
+                if steps_prof > 0:
+                    g_ms = sum(ms for k, (_, ms) in tot.items()
+                               if ("gemm_bf16_glds_kernelILb0ELb0ELi5" in k or "gemm_bf16_wgrad_group_kernel" in k)) / steps_prof
+                    g_red = sum(ms for k, (_, ms) in tot.items() if "reduce_deferred_kernel" in k) / steps_prof
+                    g_ms += g_red * (wg_red_ms / red_ms if red_ms > 0 else 0.0)
+                    wgrad["graph_replay"] = {"ms_per_step": round(g_ms, 3), "achieved_GBps": round(wg_bytes / (g_ms * 1e-3) / 1e9, 1),
+                                             "frac": round(wg_bytes / (g_ms * 1e-3) / 1e9 / 8000.0, 4),
+                                             "steps_profiled": round(steps_prof, 1),
+                                             "source": "committed: profiles/" + os.path.basename(gcsv) + " (split-K products + grouped "
+                                                       "launches + their share of reduce_deferred, rocprofv3 --kernel-trace of the "
+                                                       "replayed graph)"}
             if a.ffn_replay > 0:
                 specs = [r[5] for r in ffn[:n_ffn] if "a" in r[5]]
                 replay_ffn(specs, a.ffn_replay, device)
