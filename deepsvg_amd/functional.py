@@ -567,7 +567,19 @@ class GlobalCondFn(torch.autograd.Function):
                 # dz = sum_l dg_l W_l as ONE product over the concatenated reduction dimension, [rows, n * 256] x [n * 256, 256]:
                 # two concatenations + one LDS-DMA GEMM instead of n accumulating launches of the register-staged kernel
                 # (13-21 us each on <= 4096 rows: 65 us per stack in the round-4 trace)
-                dz = ops.gemm(dgcat, torch.cat([rt.w(w) for w, _b in pairs], 0), b_kc=False)
+                # (the bf16 images of the stack's weights are adjacent like the masters: the [n * 256, 256] operand is a view)
+                w0 = rt.w(pairs[0][0])
+                wcat = None
+                if st is not None and all(id(w) in st.index for w, _b in pairs) and w0.is_contiguous():
+                    ow = [st.index[id(w)] for w, _b in pairs]
+                    ws = [rt.w(w) for w, _b in pairs]
+                    if (all(ow[i + 1][0] == ow[i][0] + ow[i][1] for i in range(len(pairs) - 1))
+                            and all(ws[i + 1].data_ptr() == ws[i].data_ptr() + ws[i].numel() * ws[i].element_size()
+                                    for i in range(len(pairs) - 1))):
+                        wcat = torch.as_strided(w0, (sum(w.shape[0] for w, _b in pairs), w0.shape[1]), (w0.shape[1], 1))
+                if wcat is None:
+                    wcat = torch.cat([rt.w(w) for w, _b in pairs], 0)
+                dz = ops.gemm(dgcat, wcat, b_kc=False)
             else:
                 dz = torch.empty_like(z)
                 for i, ((w, _b), dg) in enumerate(zip(pairs, dgs)):
