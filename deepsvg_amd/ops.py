@@ -351,17 +351,26 @@ def gemm(a, b, *, a_kc=True, b_kc=True, bias=None, res=None, res_pre=False, act=
 # (three K steps in flight per workgroup), which keeps the HBM rate of 512 single-stage workgroups with half the slices to
 # write and reduce (step 8.39 -> 8.32 ms; before the 4-stage variant existed 512 was the better setting)
 _SPLITK_BLOCKS = int(os.environ.get("DSVG_SPLITK_BLOCKS", "256"))
+_SPLITK_REFILL = int(os.environ.get("DSVG_SPLITK_REFILL", "480"))     # workgroups for products whose tiles under-fill the chip (0: off)
 
 
 def split_k_for(M, N, K, target_blocks=None):
     """split factor for the weight-gradient GEMMs (small M x N output, K = #tokens): a multiple of 8 so that the
     K slices are grouped per XCD (see gemm_bf16.hip), about `target_blocks` workgroups in total."""
+    default_target = target_blocks is None
     target_blocks = target_blocks or _SPLITK_BLOCKS
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     s = max(1, target_blocks // tiles)
     s = min(s, max(1, K // 128))
     if s >= 8:
         s = s // 8 * 8
+        # 12 tiles (the 768 x 256 in_proj product): 16 slices = 192 workgroups leave a quarter of the CUs without one on the
+        # one-workgroup-per-CU variant, 24 = 288 do not fit it.  ~480 workgroups on the high-occupancy variant are 20 % faster
+        # (profiles/r04_wgrad_split_probe.log: 54.5 -> 43.8 us at 63 k rows, 40.0 -> 35.7 at 41 k)
+        if default_target and _SPLITK_REFILL > 0 and K >= 16384 and tiles * s < 0.8 * target_blocks:
+            s2 = min((_SPLITK_REFILL // tiles) // 8 * 8, max(1, K // 128) // 8 * 8)
+            if s2 > s:
+                s = s2
     return s
 
 
