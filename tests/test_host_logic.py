@@ -745,3 +745,16 @@ def test_remainder_sequences_on_the_group_stage_kernel_with_emulated_ops(emulate
     assert abs(res[7][0] - res[0][0]) <= 2e-3 * abs(res[0][0])
     for n in res[7][1]:
         assert H.rel_l2(res[7][1][n], res[0][1][n]) < 3e-2, n
+
+
+def test_split_k_policy_fills_the_chip():
+    """ops.split_k_for: ~256 workgroups (one per CU, slices in multiples of 8 = grouped per XCD); products whose tile count
+    leaves more than a fifth of the CUs without a workgroup at that target (12 tiles: 16 slices = 192) go to ~480 workgroups on
+    the high-occupancy variant instead (large stages only; an explicit target is taken as given)."""
+    from deepsvg_amd import ops
+    assert ops.split_k_for(512, 256, 63488) == 32 and ops.split_k_for(256, 512, 40960) == 32
+    assert ops.split_k_for(256, 256, 63488) == 64
+    assert ops.split_k_for(768, 256, 63488) == 40 and ops.split_k_for(768, 256, 40960) == 40
+    assert ops.split_k_for(768, 256, 63488, target_blocks=256) == 16
+    assert ops.split_k_for(768, 256, 4096) == 16           # the 4096-row stages keep the one-workgroup-per-CU schedule
+    assert ops.split_k_for(1024, 256, 4096) == 16 and ops.split_k_for(256, 256, 512) == 4
