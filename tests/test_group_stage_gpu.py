@@ -283,6 +283,13 @@ def test_gs_layer_is_interchangeable_with_the_unfused_launches(gpu_device, n_seq
     scale, s0 = 32 ** -0.5, 208
     bad = []
     fu = ops.gs_layer_fwd(x, pf, *_params(p), key_mask, n_seq, S, scale, 1e-5, drop_p, s0, seed, seq_add=seq_add, train=True)
+    if seq_add is not None:
+        # conditioning rows as a column block of a wider tensor (row stride 1024, GlobalCondFn's layout): bit-identical
+        wide = torch.zeros(seq_add.shape[0], 1024, dtype=seq_add.dtype, device=seq_add.device)
+        wide[:, 256:512] = seq_add
+        fs = ops.gs_layer_fwd(x, pf, *_params(p), key_mask, n_seq, S, scale, 1e-5, drop_p, s0, seed, seq_add=wide[:, 256:512],
+                              train=True)
+        assert all(torch.equal(a, b) for a, b in zip(fs, fu) if torch.is_tensor(a)), "strided conditioning rows"
     un = _unfused_fwd(x, W, p, key_mask, n_seq, S, scale, drop_p, s0, seed, seq_add)
     for name, a, b in zip(FWD_NAMES, fu, un):
         if name == "h":

@@ -1321,6 +1321,13 @@ def test_attn_block_fwd_equals_unfused_kernels(gpu_device, kind, p):
                                  1e-5, p, 7, 8, seed, train=False, seq_add=g, site_seq_add=9)
         _close(x1g, want_g, 2e-2, "x1 with the per-sequence add")
         assert not torch.equal(x1g, x1)
+        # the same rows as a column block of a [n_seq, 1024] tensor (row stride 1024: how GlobalCondFn hands the rows of one
+        # layer of a decoder stack over): bit-identical to the contiguous copy
+        wide = (_rand(n_seq, 1024, seed=43) * 0.7).to(torch.bfloat16)
+        wide[:, 512:768] = g
+        x1s = ops.attn_block_fwd(x, packed, prm["in_bias"], prm["out_bias"], prm["gamma"], prm["beta"], km, n_seq, S, scale,
+                                 1e-5, p, 7, 8, seed, train=False, seq_add=wide[:, 512:768], site_seq_add=9)
+        assert wide[:, 512:768].stride(0) == 1024 and torch.equal(x1s, x1g), "strided conditioning rows"
 
 
 def test_copy_many_and_bcast_add_bwd_tail(gpu_device):
