@@ -317,7 +317,7 @@ def test_gs_layer_is_interchangeable_with_the_unfused_launches(gpu_device, n_seq
     assert not bad, "\n".join(bad)
 
 
-@pytest.mark.parametrize("rows", [512, 37, 1000])
+@pytest.mark.parametrize("rows", [512, 37, 1000, 1, 4096])
 @pytest.mark.parametrize("n_res", [4, 0, 1])
 def test_latent_chain_kernels_match_the_unfused_launches(gpu_device, rows, n_res):
     """dsvg_latent_chain_fwd / bwd (the latent ResNet + the bottleneck linear, one launch per direction) against the launches
