@@ -183,7 +183,10 @@ __device__ __forceinline__ void drop2_mult8(const DropCtx& c, uint32_t h, int hi
 __device__ __forceinline__ void ffn_stamp(unsigned long long* d, int slot) {
     if (d && (threadIdx.x & 63) == 0) {
         const bool real = (reinterpret_cast<uintptr_t>(d) & 1) != 0;
-        unsigned long long* b = reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(d) & ~(uintptr_t)1);
+        // (an explicit GLOBAL pointer: the integer round trip would make this a flat_store, and a flat operation pending in
+        // vmcnt - these waves never wait on it - turns every LDS wait of the kernel into lgkmcnt(0), LLVM SIInsertWaitcnts)
+        typedef unsigned long long __attribute__((address_space(1))) * gptr_t;
+        gptr_t b = (gptr_t)(reinterpret_cast<uintptr_t>(d) & ~(uintptr_t)1);
         b[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + slot] = real ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
     }
 }
@@ -1032,6 +1035,393 @@ __global__ __launch_bounds__(256) void ffn_wgrad_finish_many_kernel(const Finish
                           t.out[layer][0], t.out[layer][1], t.out[layer][2], t.out[layer][3], t.out[layer][4], block);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward, role-specialised (round 5).  profiles/r04_coissue_probe.log: a wave that issues only MFMAs and a wave that issues
+// only VALU instructions share a SIMD without slowing each other (32.2 cycles per MFMA beside ~6 cycles per VALU
+// instruction), while two waves that MIX the two kinds serialise (ffn_fwd_kernel: 3,600-3,800 cycles per chunk for 2,048
+// cycles of matrix work).  So the roles are split.  A 512-thread workgroup owns 128 rows:
+//   * waves 0-3 ("matrix waves", one per SIMD) own 32 rows each and issue nothing but MFMAs, the ds_read_b128 of their A
+//     fragments and the two small hand-offs below.  The wave computes the hidden tile of chunk i (G1(i), 16 MFMAs) INTERLEAVED
+//     with the second product of chunk i - 2 (G2(i - 2), 16 MFMAs into the 8 output accumulators), so two MFMAs on the same
+//     accumulator are never adjacent and the activation of chunk i - 1 is computed elsewhere at the same time;
+//   * waves 4-7 ("vector waves", wave w + 4 sits on the SIMD of wave w) do everything else: the weight stream (LDS-DMA of
+//     iteration block i + 3 = [W1' chunk i + 3 | W2 chunk i + 1], 8 pieces per wave), the activation E1(i - 1) of their
+//     partner's hidden tile (scale, bf16, ReLU, dropout - all on PACKED pairs: v_pk_mul_f32, v_cvt_pk_bf16_f32,
+//     v_pk_max_i16, and the dropout as two saturating 16-bit subtractions), the h stores of the training variant, and half
+//     of the epilogue.
+//   * hand-offs through LDS, lane to lane (the hidden tile's accumulator layout IS the B-operand layout of G2, see the file
+//     header): hid (fp32, 4 KiB per pair) matrix -> vector at the end of an iteration, hf (bf16, 2 KiB) vector -> matrix.
+//     Two s_barrier per iteration keep both single-buffered:   [A] both sides READ their hand-off  [B] both sides WRITE.
+//     b1' is the initial value of the hidden accumulator and b2 of the output accumulators (no bias adds anywhere).
+//   * weight ring: 4 slots of one 32 KiB iteration block; block i + 3 is issued behind A(i) into the slot block i - 1 has
+//     left; at the end of iteration i a vector wave waits with vmcnt(8) - its 8 pieces of block i + 3 may stay in flight, so
+//     blocks <= i + 2 have landed (loads return in order; the h stores in flight can only make the wait stricter) - so that
+//     behind A(i + 1) the matrix waves may read blocks i + 1 AND i + 2: their A-fragment ring runs across the barrier.
+//     The stream is cyclic (chunk & 15): the blocks past the last one are harmless re-reads that keep the counts uniform.
+//   * 18 iterations per 128-row tile (2 to fill, 2 to drain the G1 -> E1 -> G2 pipeline); epilogue: the matrix wave hands
+//     output tiles 4-7 to its partner through LDS (the ring is free by then) and finishes tiles 0-3 itself.
+// Results: h / y differ from ffn_fwd_kernel's by fp32 summation order only (the bias is the accumulator's initial value
+// and the dropout scale is applied before instead of after the ReLU): rounding-level, checked in tests/test_kernels_gpu.py.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int RS_ROWS = 128;
+constexpr int RS_BLOCK = 32 * FRAG;                 // [W1' chunk i | W2 chunk i - 2]
+constexpr int RS_NB = 4;
+constexpr int RS_HID = RS_NB * RS_BLOCK;            // 4 x 4 KiB
+constexpr int RS_HF = RS_HID + 4 * 4096;            // 4 x 2 KiB
+constexpr int RS_B1 = RS_HF + 4 * 2048;
+constexpr int RS_B2 = RS_B1 + FF * 4;
+constexpr int RS_LDS = RS_B2 + FD * 4;              // 158,720 B
+constexpr int RS_DUMP_ROW = 128 * 4 + 16;           // epilogue hand-off: 128 fp32 columns per row, padded (bank spread)
+constexpr int RS_ITERS = NCH + 2;
+
+// iteration kinds: G1 only (fill), G1 + G2, G2 only (drain)
+constexpr int RS_T1 = 1, RS_T2 = 2, RS_T12 = 3, RS_END = 0;
+__host__ __device__ constexpr int rs_len(int ty) { return ty == RS_T12 ? 32 : (ty == RS_END ? 0 : 16); }
+// position p of an iteration: which product (0 = G1, 1 = G2) and which of its 16 MFMAs.  G1 + G2: four G1 first (G2 waits
+// for its B operand), then alternating, four G2 last (they cover the latency of the last G1 and the hid hand-off)
+__host__ __device__ constexpr int rs_kind(int ty, int p) {
+    return ty == RS_T1 ? 0 : ty == RS_T2 ? 1 : (p < 4 ? 0 : p >= 28 ? 1 : ((p & 1) ? 0 : 1));
+}
+__host__ __device__ constexpr int rs_idx(int ty, int p) {
+    return ty != RS_T12 ? p : (p < 4 ? p : p >= 28 ? p - 16 : ((p & 1) ? 4 + (p - 5) / 2 : (p - 4) / 2));
+}
+// fragment of the 32-fragment block that position p multiplies (G2 position n: output tile n & 7, K step n >> 3)
+__host__ __device__ constexpr int rs_frag(int ty, int p) {
+    return rs_kind(ty, p) == 0 ? rs_idx(ty, p) : 16 + 2 * (rs_idx(ty, p) & 7) + (rs_idx(ty, p) >> 3);
+}
+__host__ __device__ constexpr bool rs_has1(int ty) { return ty == RS_T1 || ty == RS_T12; }
+__host__ __device__ constexpr bool rs_has2(int ty) { return ty == RS_T2 || ty == RS_T12; }
+
+typedef unsigned short rs_u16x2 __attribute__((ext_vector_type(2)));
+typedef short rs_s16x2 __attribute__((ext_vector_type(2)));
+typedef float rs_f2 __attribute__((ext_vector_type(2)));
+
+// development probe of the role-specialised kernel (dsvg_ffn_debug_clock): 16 stamps per wave at dbg[(block * 8 + wave) * 16 ..]:
+// 0 start, 1 before A(0), 2 / 3 / 4 behind iterations 1 / 8 / 15, 5 behind E_A, 6 behind E_B, 7 end (bit 0 of the address:
+// s_memrealtime, see ffn_stamp); 8 .. 13: inside iteration 8 - behind A, before / behind B, work done, before / behind the next A
+__device__ __forceinline__ void rs_stamp(unsigned long long* d, int slot) {
+    if (d && (threadIdx.x & 63) == 0) {
+        const bool real = (reinterpret_cast<uintptr_t>(d) & 1) != 0;
+        typedef unsigned long long __attribute__((address_space(1))) * gptr_t;
+        gptr_t b = (gptr_t)(reinterpret_cast<uintptr_t>(d) & ~(uintptr_t)1);
+        b[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + slot] = real ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+    }
+}
+
+// one iteration of a matrix wave (behind barrier A(i); ends with barrier A(i + 1))
+template <int TY, int NX>
+__device__ __forceinline__ void rs_matrix_iter(int i, const char* lbase, const bf16x8 (&xf)[16], floatx16 (&yacc)[8],
+                                               floatx16& hid, uint4 (&ring)[4], char* hid_buf, const char* hf_buf,
+                                               const float* sb1h, unsigned long long* dbg = nullptr) {
+    const bool st8 = dbg != nullptr && i == 8;
+    if (st8) rs_stamp(dbg, 8);
+    constexpr int L = rs_len(TY);
+    constexpr int PB = 4;                                   // barrier B behind this position (the first G2 has its operand)
+    constexpr int PW = TY == RS_T12 ? 29 : 15;              // hid hand-off behind this position (2 MFMAs behind the last G1)
+    const char* cur = lbase + (i & (RS_NB - 1)) * RS_BLOCK;
+    const char* nxt = lbase + ((i + 1) & (RS_NB - 1)) * RS_BLOCK;
+    Frag8 hf0, hf1;
+    if (rs_has2(TY)) {
+        hf0.u = *reinterpret_cast<const uint4*>(hf_buf);
+        hf1.u = *reinterpret_cast<const uint4*>(hf_buf + FRAG);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < L; ++p) {
+        Frag8 a;
+        a.u = ring[p & 3];
+        const int n = rs_idx(TY, p);
+        if (rs_kind(TY, p) == 0) hid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, xf[n], hid, 0, 0, 0);
+        else yacc[n & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, (n >> 3) ? hf1.v : hf0.v, yacc[n & 7], 0, 0, 0);
+        if (p + 4 < L) ring[p & 3] = *reinterpret_cast<const uint4*>(cur + rs_frag(TY, p + 4) * FRAG);
+        else if (NX != RS_END) ring[p & 3] = *reinterpret_cast<const uint4*>(nxt + rs_frag(NX, p + 4 - L) * FRAG);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p == PB) {
+            // both hf reads have returned: LDS operations of a wave return in order and exactly PB + 1 fragment reads were
+            // issued behind them
+            if (rs_has2(TY)) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+            if (st8) rs_stamp(dbg, 9);
+            __builtin_amdgcn_s_barrier();                   // B(i): every hand-off buffer has been read
+            if (st8) rs_stamp(dbg, 10);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (rs_has1(TY) && p == PW) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(hid_buf + q * FRAG) = make_float4(hid[4 * q], hid[4 * q + 1], hid[4 * q + 2], hid[4 * q + 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rs_has1(NX)) {                              // the next hidden tile starts from b1'
+                const float* b = sb1h + CH * (i + 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bb = *reinterpret_cast<const float4*>(b + 8 * q);
+                    hid[4 * q] = bb.x; hid[4 * q + 1] = bb.y; hid[4 * q + 2] = bb.z; hid[4 * q + 3] = bb.w;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (st8) rs_stamp(dbg, 11);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (st8) rs_stamp(dbg, 12);
+    __builtin_amdgcn_s_barrier();                           // A(i + 1)
+    if (st8) rs_stamp(dbg, 13);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(512, 2) void ffn_fwd_rs_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ img,
+                                                            const float* __restrict__ b1, const float* __restrict__ b2,
+                                                            bf16_t* __restrict__ y, bf16_t* __restrict__ h_out,
+                                                            bf16_t* __restrict__ xh_out, float* __restrict__ rstd_out,
+                                                            int M, float eps, float drop_p,
+                                                            const uint64_t* __restrict__ seed, uint32_t site_h,
+                                                            uint32_t site_r, unsigned long long* dbg, int probe) {
+    // probe (DSVG_FFN_RS_PROBE, timing experiments only - the results are wrong): 1 no activation arithmetic, 2 no weight
+    // DMA inside the loop, 4 no h stores
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    rs_stamp(dbg, 0);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pw = wave & 3;                                // the pair's 32-row tile
+    const int tok = lane & 31, half = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)DSVG_LDS_PTR(smem);
+    float* sb1 = reinterpret_cast<float*>(smem + RS_B1);
+    float* sb2 = reinterpret_cast<float*>(smem + RS_B2);
+    sb1[tid] = b1[tid];
+    if (tid < FD) sb2[tid] = b2[tid];
+    const int row0 = blockIdx.x * RS_ROWS + pw * 32;
+    const int m = row0 + tok;
+    const bool live = m < M;
+    const int my_row = min(m, M - 1);                       // rows past M are computed on a clamped copy, never stored
+    const char* lbase = smem + lane * 16;
+    char* hid_buf = smem + RS_HID + pw * 4096 + lane * 16;
+    char* hf_buf = smem + RS_HF + pw * 2048 + lane * 16;
+    char* dump = smem + pw * (32 * RS_DUMP_ROW);            // epilogue: the pair's output tiles 4-7, fp32 [32 rows][128]
+    const DropCtx dr = drop_make(drop_p, seed, site_r);
+    char* yrow = reinterpret_cast<char*>(y) + (size_t)my_row * (FD * 2);
+
+    if (wave < 4) {
+        // ================================================ matrix wave ================================================
+        bf16x8 xf[16];
+        ffn_ln_rows<TRAIN, false>(x, my_row, half, TRAIN && live, xh_out, rstd_out, eps, xf);
+        // (the normalised fragments are first USED in the chunk loop: without an opaque use here the compiler sinks their
+        // computation behind the accumulators' initial values, with 128 unpacked row values live across them - spills)
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            Frag8 f;
+            f.v = xf[ks];
+            asm volatile("" : "+v"(f.u.x), "+v"(f.u.y), "+v"(f.u.z), "+v"(f.u.w));
+            xf[ks] = f.v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                    // P: b1' / b2 staged
+        __builtin_amdgcn_sched_barrier(0);
+        floatx16 yacc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(sb2 + 32 * t + 8 * q + 4 * half);
+                yacc[t][4 * q] = bb.x; yacc[t][4 * q + 1] = bb.y; yacc[t][4 * q + 2] = bb.z; yacc[t][4 * q + 3] = bb.w;
+            }
+        floatx16 hid;
+        const float* sb1h = sb1 + 4 * half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bb = *reinterpret_cast<const float4*>(sb1h + 8 * q);
+            hid[4 * q] = bb.x; hid[4 * q + 1] = bb.y; hid[4 * q + 2] = bb.z; hid[4 * q + 3] = bb.w;
+        }
+        uint4 ring[4];
+        __builtin_amdgcn_sched_barrier(0);
+        rs_stamp(dbg, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // A(0): blocks 0 .. 2 have landed
+#pragma unroll
+        for (int p = 0; p < 4; ++p) ring[p] = *reinterpret_cast<const uint4*>(lbase + rs_frag(RS_T1, p) * FRAG);
+        __builtin_amdgcn_sched_barrier(0);
+        rs_matrix_iter<RS_T1, RS_T1>(0, lbase, xf, yacc, hid, ring, hid_buf, hf_buf, sb1h);
+        rs_matrix_iter<RS_T1, RS_T12>(1, lbase, xf, yacc, hid, ring, hid_buf, hf_buf, sb1h);
+        rs_stamp(dbg, 2);
+        for (int i = 2; i < NCH - 1; ++i) {
+            rs_matrix_iter<RS_T12, RS_T12>(i, lbase, xf, yacc, hid, ring, hid_buf, hf_buf, sb1h, dbg);
+            if (i == 8) rs_stamp(dbg, 3);
+        }
+        rs_matrix_iter<RS_T12, RS_T2>(NCH - 1, lbase, xf, yacc, hid, ring, hid_buf, hf_buf, sb1h);
+        rs_stamp(dbg, 4);
+        // the residual rows of the tiles this wave finishes itself (the B-operand registers are free now)
+        const char* xres = reinterpret_cast<const char*>(x) + (size_t)my_row * (FD * 2);
+        uint4 res[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            res[2 * t] = *reinterpret_cast<const uint4*>(xres + (32 * t + 16 * half) * 2);
+            res[2 * t + 1] = *reinterpret_cast<const uint4*>(xres + (32 * t + 16 * half + 8) * 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        rs_matrix_iter<RS_T2, RS_T2>(NCH, lbase, xf, yacc, hid, ring, hid_buf, hf_buf, sb1h);
+        rs_matrix_iter<RS_T2, RS_END>(NCH + 1, lbase, xf, yacc, hid, ring, hid_buf, hf_buf, sb1h);     // ends with E_A
+        rs_stamp(dbg, 5);
+        // ---- epilogue: tiles 4-7 to the partner (fp32, row `tok`, column 32 (t - 4) + 8 q + 4 half + e) ----------------
+#pragma unroll
+        for (int t = 4; t < 8; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(dump + tok * RS_DUMP_ROW + (32 * (t - 4) + 8 * q + 4 * half) * 4) =
+                    make_float4(yacc[t][4 * q], yacc[t][4 * q + 1], yacc[t][4 * q + 2], yacc[t][4 * q + 3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // E_B
+        rs_stamp(dbg, 6);
+        // tiles 0-3: dropout, + residual, bf16 rows (as ffn_fwd_kernel's epilogue, b2 is already inside)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint32_t xc[4][4];
+            tile_to_cols16(yacc[t], xc);
+            const int n16 = 32 * t + 16 * half;
+            uint4 pk[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                float v[8], rv[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(xc[2 * cb][e]); v[4 + e] = __uint_as_float(xc[2 * cb + 1][e]); }
+                unpack8(res[2 * t + cb], rv);
+                if (dr.on) {
+                    float dm[8];
+                    drop_mult8(dr, (uint64_t)m * FD + n16 + 8 * cb, dm);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], dm[e], rv[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                }
+                pk[cb] = pack8(v);
+            }
+            if (live) {
+                *reinterpret_cast<uint4*>(yrow + n16 * 2) = pk[0];
+                *reinterpret_cast<uint4*>(yrow + n16 * 2 + 16) = pk[1];
+            }
+        }
+        rs_stamp(dbg, 7);
+    } else {
+        // ================================================ vector wave ================================================
+        // weight stream: this wave moves bytes [8 KiB v, 8 KiB (v + 1)) of every 32 KiB block: v = 0, 1 the W1' half of
+        // chunk `block`, v = 2, 3 the W2 half of chunk `block - 2` (cyclic)
+        const char* my_src = reinterpret_cast<const char*>(img) + pw * 8192 + lane * 16;
+        const uint32_t my_dst = __builtin_amdgcn_readfirstlane(lds0 + pw * 8192);
+        const int lag = pw < 2 ? 0 : 2;
+        auto issue = [&](int blk) {
+            const char* s = my_src + (size_t)((blk - lag) & (NCH - 1)) * FWD_CHUNK;
+            const uint32_t d = my_dst + (uint32_t)(blk & (RS_NB - 1)) * RS_BLOCK;
+            dma4(s, d);
+            dma4(s + 4096, d + 4096);
+        };
+        issue(0);
+        issue(1);
+        issue(2);
+        // the residual rows of the output tiles this wave finishes (columns 16 ks + 8 half .. + 7, ks = 8 .. 15)
+        const char* xr = reinterpret_cast<const char*>(x) + (size_t)my_row * (FD * 2) + half * 16;
+        uint4 res[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) res[k] = *reinterpret_cast<const uint4*>(xr + 32 * (8 + k));
+        const DropCtx dh = drop_make(drop_p, seed, site_h);
+        // hidden-site draws: group of 16 ids = (row0 + tok) * 512 + 32 c + 16 half .. + 15 -> g = (row0 + tok) * 32 + 2 c + half
+        const uint64_t g0 = (uint64_t)m * 32 + half;
+        const uint32_t g0lo = (uint32_t)g0, ghi_term = (uint32_t)(g0 >> 32) * 0x9e3779b1u;
+        const rs_u16x2 tpair = {(unsigned short)dh.thresh, (unsigned short)dh.thresh};
+        const rs_f2 sc2 = {dh.scale, dh.scale};
+        char* hrow = TRAIN ? reinterpret_cast<char*>(h_out) + (size_t)my_row * (FF * 2) + half * 16 : nullptr;
+        __syncthreads();                                    // P
+        rs_stamp(dbg, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // A(0)
+        for (int i = 0; i < RS_ITERS; ++i) {
+            const bool act = i >= 1 && i <= NCH;            // E1(i - 1)
+            const bool st8 = dbg != nullptr && i == 8;
+            if (st8) rs_stamp(dbg, 8);
+            uint4 hv[4];
+            if (act) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const uint4*>(hid_buf + q * FRAG);
+            }
+            if (i < NCH && !(probe & 2)) issue(i + 3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (st8) rs_stamp(dbg, 9);
+            __builtin_amdgcn_s_barrier();                   // B(i)
+            if (st8) rs_stamp(dbg, 10);
+            if (act && !(probe & 1)) {
+                const int c = i - 1;
+                uint32_t pk[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const rs_f2 lo = {__uint_as_float(hv[q].x), __uint_as_float(hv[q].y)};
+                    const rs_f2 hi = {__uint_as_float(hv[q].z), __uint_as_float(hv[q].w)};
+                    const rs_f2 a = lo * sc2, b = hi * sc2;
+                    const rs_s16x2 zero = {0, 0};
+                    pk[2 * q] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
+                        __builtin_bit_cast(rs_s16x2, f2bf_pk(a[0], a[1])), zero));
+                    pk[2 * q + 1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
+                        __builtin_bit_cast(rs_s16x2, f2bf_pk(b[0], b[1])), zero));
+                }
+                if (dh.on) {
+                    // word k = the draws of elements 2 k (low half) and 2 k + 1: drop when draw < thresh.  r = sat(thresh -
+                    // draw) is 0 for a kept element, else 0 - r >= 65536 - thresh >= 0x8000 > any non-negative bf16 pattern
+                    // (thresh <= 32768, checked by the host), so one more saturating subtraction clears exactly the dropped
+                    const uint32_t hh = (dsvg_hash32((g0lo + 2u * (uint32_t)c) ^ dh.s0) ^ dh.s1) + ghi_term;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const rs_u16x2 d = __builtin_bit_cast(rs_u16x2, drop2_word(hh, k));
+                        const rs_u16x2 r = __builtin_elementwise_sub_sat(tpair, d);
+                        const rs_u16x2 z = {0, 0};
+                        const rs_u16x2 big = z - r;
+                        pk[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(rs_u16x2, pk[k]), big));
+                    }
+                }
+                const uint4 f0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), f1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                *reinterpret_cast<uint4*>(hf_buf) = f0;
+                *reinterpret_cast<uint4*>(hf_buf + FRAG) = f1;
+                if (TRAIN && live && !(probe & 4)) {
+                    *reinterpret_cast<uint4*>(hrow + (CH * c) * 2) = f0;
+                    *reinterpret_cast<uint4*>(hrow + (CH * c + 16) * 2) = f1;
+                }
+            }
+            if (st8) rs_stamp(dbg, 11);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (i < NCH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (i == RS_ITERS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (st8) rs_stamp(dbg, 12);
+            __builtin_amdgcn_s_barrier();                   // A(i + 1); the last one is E_A
+            if (st8) rs_stamp(dbg, 13);
+            if (i == 1) rs_stamp(dbg, 2);
+            else if (i == 8) rs_stamp(dbg, 3);
+            else if (i == NCH - 1) rs_stamp(dbg, 4);
+        }
+        rs_stamp(dbg, 5);
+        __builtin_amdgcn_s_barrier();                       // E_B: the partner's tiles 4-7 are in LDS
+        rs_stamp(dbg, 6);
+        // output columns 32 t + 16 p + 8 half .. + 7 (t = 4 .. 7, p = 0, 1): the lane's LayerNorm-layout piece ks = 2 t + p
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int col = 16 * (8 + k) + 8 * half;
+            const char* d = dump + tok * RS_DUMP_ROW + (16 * k + 8 * half) * 4;
+            const float4 a0 = *reinterpret_cast<const float4*>(d), a1 = *reinterpret_cast<const float4*>(d + 16);
+            float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, rv[8];
+            unpack8(res[k], rv);
+            if (dr.on) {
+                float dm[8];
+                drop_mult8(dr, (uint64_t)m * FD + col, dm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], dm[e], rv[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            }
+            if (live) *reinterpret_cast<uint4*>(yrow + col * 2) = pack8(v);
+        }
+        rs_stamp(dbg, 7);
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1075,7 +1465,7 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
     const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
     hipStream_t st = (hipStream_t)stream;
     const int stages_arg = stages;       // 0 default, 2 half-size workgroups, 3 / 4 ring slots of the 256-row kernel
-    if (stages == 0 || stages == 2) stages = 4;
+    if (stages == 0 || stages == 2 || stages == 5) stages = 4;
     // training variant: 4 slots (chunk k + 2's DMA in flight across the syncs, counted waits) or 3 (every sync drains the
     // wave's h stores too); DSVG_FFN_TRAIN_STAGES for the A/B
     static const int train_stages = getenv("DSVG_FFN_TRAIN_STAGES") ? atoi(getenv("DSVG_FFN_TRAIN_STAGES")) : 4;
@@ -1109,6 +1499,24 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
         else DSVG_FFN_FWD_HALF(false);
 #undef DSVG_FFN_FWD_HALF
         DSVG_LAUNCH_CHECK("ffn_fwd (half-size workgroups)");
+        return 0;
+    }
+    if (stages_arg == 5) {      // role-specialised 128-row workgroups (matrix waves + vector waves)
+        DSVG_CHECK_ARG(!(drop_p > 0.5f), "ffn_fwd: the role-specialised kernel takes dropout rates up to 0.5");
+        const int nbr = (int)((rows + RS_ROWS - 1) / RS_ROWS);
+        static const int rs_probe = getenv("DSVG_FFN_RS_PROBE") ? atoi(getenv("DSVG_FFN_RS_PROBE")) : 0;
+#define DSVG_FFN_FWD_RS(TR)                                                                                           \
+    do {                                                                                                              \
+        DSVG_ENSURE_LDS((ffn_fwd_rs_kernel<TR>), RS_LDS);                                                             \
+        hipLaunchKernelGGL((ffn_fwd_rs_kernel<TR>), dim3(nbr), dim3(512), RS_LDS, st, (const bf16_t*)x,                \
+                           (const bf16_t*)packed_fwd_layer, b1_folded, b2, (bf16_t*)y, (bf16_t*)h_out, (bf16_t*)xh_out,\
+                           rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res,              \
+                           g_ffn_dbg_host, rs_probe);                                                                 \
+    } while (0)
+        if (train) DSVG_FFN_FWD_RS(true);
+        else DSVG_FFN_FWD_RS(false);
+#undef DSVG_FFN_FWD_RS
+        DSVG_LAUNCH_CHECK("ffn_fwd (role-specialised)");
         return 0;
     }
     if (train && stages == 3) DSVG_FFN_FWD(3, true);
