@@ -435,6 +435,22 @@ def replay_ffn(specs, n, device):
     log(f"replayed {len(calls)} FFN launches x {n}")
 
 
+def self_launch(n):
+    """re-run this script under torch.distributed.run with n ranks on this node; returns the launcher's exit code"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -444,6 +460,11 @@ def main():
     if a.cpu_leg > 0:
         cpu_leg_main(a.cpu_leg, a.cpu_batch, a.dropout)
         return
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
+        # 127.0.0.1) - the same command line the driver's torchrun form runs, so both forms report the same line
+        # (replaces the single-process nn.DataParallel of /root/reference/deepsvg/train.py:74)
+        sys.exit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -181,7 +181,8 @@ __device__ __forceinline__ uint32_t drop_group(const DropCtx& c, uint64_t g) {
 // word i (< 16) of a group / row hash: two 16-bit draws
 __device__ __forceinline__ uint32_t drop_word(uint32_t h, uint32_t i) {
     const uint32_t c = ((0x7feb352du * (i + 1u)) ^ (0x846ca68bu >> i)) | 1u;
-    return (h * c) ^ __umulhi(h, c);
+    const uint64_t p = (uint64_t)h * c;         // one v_mad_u64_u32 instead of v_mul_lo_u32 + v_mul_hi_u32
+    return (uint32_t)p ^ (uint32_t)(p >> 32);
 }
 // multiplier (0 or scale) for element idx
 __device__ __forceinline__ float drop_mult(const DropCtx& c, uint64_t idx) {

@@ -152,6 +152,56 @@ __device__ __forceinline__ void drop2_mult8(const DropCtx& c, uint32_t h, int hi
     }
 }
 
+typedef unsigned short rs_u16x2 __attribute__((ext_vector_type(2)));
+typedef short rs_s16x2 __attribute__((ext_vector_type(2)));
+typedef float rs_f2 __attribute__((ext_vector_type(2)));
+
+// Activation of a hidden tile on PACKED pairs (round 5; 5.5 instructions per pair instead of 19): the 16 accumulator values
+// of a lane -> the two B-operand fragments of G2.
+//   scale (v_pk_mul_f32) -> bf16 pair (v_cvt_pk_bf16_f32) -> ReLU as a signed 16-bit maximum with 0 (v_pk_max_i16: a negative
+//   bf16 is a negative int16) -> dropout: word k of the lane's group hash holds the draws of elements 2 k (low half) and
+//   2 k + 1, drop when draw < thresh: r = sat(thresh - draw) is 0 for a kept element, else 0 - r >= 65536 - thresh >= 0x8000
+//   exceeds every non-negative bf16 pattern (thresh <= 32768: dropout rates up to 0.5, checked by the host), so one more
+//   saturating subtraction clears exactly the dropped halves (2 x v_pk_sub_u16 clamp + v_pk_sub_u16).
+// The same draws as drop2_mult8 (ids in lane order); the scale is applied before instead of after the ReLU: results differ
+// from the scalar form by fp32 rounding order only.
+// bs (BIAS): the lane's 16 bias values ALREADY MULTIPLIED BY THE SCALE, element 4 q + e at bs[8 q + e] (LDS): the
+// token-stationary kernels start their hidden accumulator from zero (an initial value would be 16 more live registers under
+// G2) and add the bias here, fused with the scale: v_pk_fma_f32.
+template <bool BIAS>
+__device__ __forceinline__ void ffn_act_packed(const float (&v)[16], const DropCtx& dh, uint32_t hh, uint32_t (&pk)[8],
+                                               const float* bs = nullptr) {
+    const rs_f2 sc2 = {dh.scale, dh.scale};
+    const rs_s16x2 zero = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (BIAS) bb = *reinterpret_cast<const float4*>(bs + 8 * q);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = 2 * q + j;
+            rs_f2 a = rs_f2{v[2 * k], v[2 * k + 1]};
+            if (BIAS) a = __builtin_elementwise_fma(a, sc2, j ? rs_f2{bb.z, bb.w} : rs_f2{bb.x, bb.y});
+            else a = a * sc2;
+            pk[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(rs_s16x2, f2bf_pk(a[0], a[1])), zero));
+        }
+    }
+    if (dh.on) {
+        const rs_u16x2 tpair = {(unsigned short)dh.thresh, (unsigned short)dh.thresh};
+        const rs_u16x2 z = {0, 0};
+        // (stage by stage over the 8 words, not word by word: back-to-back dependent packed operations cost a wait state each)
+        rs_u16x2 r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = __builtin_bit_cast(rs_u16x2, drop2_word(hh, k));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = __builtin_elementwise_sub_sat(tpair, r[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = z - r[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pk[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(rs_u16x2, pk[k]), r[k]));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
@@ -223,7 +273,7 @@ __device__ __forceinline__ void ffn_ln_rows(const bf16_t* __restrict__ x, int my
     }
 }
 
-template <int NBUF, bool TRAIN>
+template <int NBUF, bool TRAIN, bool PK>
 __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ img,
                                                          const float* __restrict__ b1, const float* __restrict__ b2,
                                                          bf16_t* __restrict__ y, bf16_t* __restrict__ h_out,
@@ -243,16 +293,17 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
     float* sb2 = sb1 + FF;
 
     // ---- weight stream: this wave moves pieces 4 wave .. 4 wave + 3 of every chunk -----------------------------------
-    const char* my_src = reinterpret_cast<const char*>(img) + wave * 4096 + lane * 16;
+    const char* my_src = reinterpret_cast<const char*>(img) + wave * 4096;         // (wave-uniform; + lane * 16 per lane)
     const uint32_t my_dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);
-    auto issue = [&](int c) { dma4(my_src + (size_t)c * FWD_CHUNK, my_dst + (uint32_t)(c % NBUF) * FWD_CHUNK); };
+    auto issue = [&](int c) { dma4s(my_src + (size_t)c * FWD_CHUNK, (uint32_t)lane * 16u, my_dst + (uint32_t)(c % NBUF) * FWD_CHUNK); };
     // DMA distance: DIST = NBUF - 1 chunks ahead of the compute (NBUF = 3: 2, NBUF = 4: 3)
     constexpr int DIST = NBUF - 1;
 #pragma unroll
     for (int c = 0; c < DIST; ++c)
         if (c < n_chunks) issue(c);
 
-    sb1[tid] = b1[tid];
+    // (PK: b1' is staged multiplied by the dropout scale, see ffn_act_packed)
+    sb1[tid] = PK ? b1[tid] * drop_make(drop_p, seed, site_h).scale : b1[tid];
     if (tid < FD) sb2[tid] = b2[tid];
 
     // ---- the wave's 32 rows: LayerNorm in registers -> 16 B-operand fragments ------------------------------------------
@@ -323,6 +374,19 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
     auto E1 = [&](int c) {
         const uint64_t id0 = (uint64_t)(row0 + tok) * FF + (uint32_t)(CH * c + 16 * half);
         const uint32_t hh = dh.on ? drop2_group(dh, id0 >> 4) : 0u;
+        if (PK) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = hid[r];
+            uint32_t pk[8];
+            ffn_act_packed<true>(v, dh, hh, pk, sb1 + CH * c + 4 * half);
+            Frag8 f0, f1;
+            f0.u = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            f1.u = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            hf[0] = f0.v; hf[1] = f1.v;
+            if (TRAIN) { stash[0] = f0.u; stash[1] = f1.u; stash_c = c; }
+            return;
+        }
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
             float v[8];
@@ -451,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
 constexpr int HSLOT = 16 * FRAG;        // half chunk: 16 fragments = 16 KiB
 constexpr int HNBUF = 4;
 
-template <bool TRAIN>
+template <bool TRAIN, bool PK>
 __global__ __launch_bounds__(256, 2) void ffn_fwd_half_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ img,
                                                               const float* __restrict__ b1, const float* __restrict__ b2,
                                                               bf16_t* __restrict__ y, bf16_t* __restrict__ h_out,
@@ -471,15 +535,18 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_half_kernel(const bf16_t* __re
     const int n_half = 2 * n_chunks;
 
     // ---- weight stream: this wave moves pieces 4 wave .. 4 wave + 3 of every half chunk ------------------------------
-    const char* my_src = reinterpret_cast<const char*>(img) + wave * 4096 + lane * 16;
+    const char* my_src = reinterpret_cast<const char*>(img) + wave * 4096;
     const uint32_t my_dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);
-    auto issue = [&](int hc) { dma4(my_src + (size_t)hc * HSLOT, my_dst + (uint32_t)(hc % HNBUF) * HSLOT); };
+    auto issue = [&](int hc) { dma4s(my_src + (size_t)hc * HSLOT, (uint32_t)lane * 16u, my_dst + (uint32_t)(hc % HNBUF) * HSLOT); };
 #pragma unroll
     for (int hc = 0; hc < 3; ++hc)
         if (hc < n_half) issue(hc);
 
-    sb1[tid] = b1[tid];
-    sb1[tid + 256] = b1[tid + 256];
+    {
+        const float bsc = PK ? drop_make(drop_p, seed, site_h).scale : 1.f;
+        sb1[tid] = b1[tid] * bsc;
+        sb1[tid + 256] = b1[tid + 256] * bsc;
+    }
     sb2[tid] = b2[tid];
 
     // ---- the wave's 32 rows: LayerNorm in registers -> 16 B-operand fragments (as in ffn_fwd_kernel) -----------------
@@ -544,6 +611,19 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_half_kernel(const bf16_t* __re
     auto E1 = [&](int c) {
         const uint64_t id0 = (uint64_t)(row0 + tok) * FF + (uint32_t)(CH * c + 16 * half);
         const uint32_t hh = dh.on ? drop2_group(dh, id0 >> 4) : 0u;
+        if (PK) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = hid[r];
+            uint32_t pk[8];
+            ffn_act_packed<true>(v, dh, hh, pk, sb1 + CH * c + 4 * half);
+            Frag8 f0, f1;
+            f0.u = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            f1.u = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            hf[0] = f0.v; hf[1] = f1.v;
+            if (TRAIN) { stash[0] = f0.u; stash[1] = f1.u; stash_c = c; }
+            return;
+        }
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
             float v[8];
@@ -1093,13 +1173,9 @@ __host__ __device__ constexpr int rs_frag(int ty, int p) {
 __host__ __device__ constexpr bool rs_has1(int ty) { return ty == RS_T1 || ty == RS_T12; }
 __host__ __device__ constexpr bool rs_has2(int ty) { return ty == RS_T2 || ty == RS_T12; }
 
-typedef unsigned short rs_u16x2 __attribute__((ext_vector_type(2)));
-typedef short rs_s16x2 __attribute__((ext_vector_type(2)));
-typedef float rs_f2 __attribute__((ext_vector_type(2)));
-
 // development probe of the role-specialised kernel (dsvg_ffn_debug_clock): 16 stamps per wave at dbg[(block * 8 + wave) * 16 ..]:
 // 0 start, 1 before A(0), 2 / 3 / 4 behind iterations 1 / 8 / 15, 5 behind E_A, 6 behind E_B, 7 end (bit 0 of the address:
-// s_memrealtime, see ffn_stamp); 8 .. 13: inside iteration 8 - behind A, before / behind B, work done, before / behind the next A
+// s_memrealtime, see ffn_stamp)
 __device__ __forceinline__ void rs_stamp(unsigned long long* d, int slot) {
     if (d && (threadIdx.x & 63) == 0) {
         const bool real = (reinterpret_cast<uintptr_t>(d) & 1) != 0;
@@ -1113,9 +1189,7 @@ __device__ __forceinline__ void rs_stamp(unsigned long long* d, int slot) {
 template <int TY, int NX>
 __device__ __forceinline__ void rs_matrix_iter(int i, const char* lbase, const bf16x8 (&xf)[16], floatx16 (&yacc)[8],
                                                floatx16& hid, uint4 (&ring)[4], char* hid_buf, const char* hf_buf,
-                                               const float* sb1h, unsigned long long* dbg = nullptr) {
-    const bool st8 = dbg != nullptr && i == 8;
-    if (st8) rs_stamp(dbg, 8);
+                                               const float* sb1h) {
     constexpr int L = rs_len(TY);
     constexpr int PB = 4;                                   // barrier B behind this position (the first G2 has its operand)
     constexpr int PW = TY == RS_T12 ? 29 : 15;              // hid hand-off behind this position (2 MFMAs behind the last G1)
@@ -1141,9 +1215,7 @@ __device__ __forceinline__ void rs_matrix_iter(int i, const char* lbase, const b
             // both hf reads have returned: LDS operations of a wave return in order and exactly PB + 1 fragment reads were
             // issued behind them
             if (rs_has2(TY)) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
-            if (st8) rs_stamp(dbg, 9);
             __builtin_amdgcn_s_barrier();                   // B(i): every hand-off buffer has been read
-            if (st8) rs_stamp(dbg, 10);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (rs_has1(TY) && p == PW) {
@@ -1162,11 +1234,8 @@ __device__ __forceinline__ void rs_matrix_iter(int i, const char* lbase, const b
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (st8) rs_stamp(dbg, 11);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (st8) rs_stamp(dbg, 12);
     __builtin_amdgcn_s_barrier();                           // A(i + 1)
-    if (st8) rs_stamp(dbg, 13);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -1246,7 +1315,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_rs_kernel(const bf16_t* __rest
         rs_matrix_iter<RS_T1, RS_T12>(1, lbase, xf, yacc, hid, ring, hid_buf, hf_buf, sb1h);
         rs_stamp(dbg, 2);
         for (int i = 2; i < NCH - 1; ++i) {
-            rs_matrix_iter<RS_T12, RS_T12>(i, lbase, xf, yacc, hid, ring, hid_buf, hf_buf, sb1h, dbg);
+            rs_matrix_iter<RS_T12, RS_T12>(i, lbase, xf, yacc, hid, ring, hid_buf, hf_buf, sb1h);
             if (i == 8) rs_stamp(dbg, 3);
         }
         rs_matrix_iter<RS_T12, RS_T2>(NCH - 1, lbase, xf, yacc, hid, ring, hid_buf, hf_buf, sb1h);
@@ -1307,14 +1376,14 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_rs_kernel(const bf16_t* __rest
         // ================================================ vector wave ================================================
         // weight stream: this wave moves bytes [8 KiB v, 8 KiB (v + 1)) of every 32 KiB block: v = 0, 1 the W1' half of
         // chunk `block`, v = 2, 3 the W2 half of chunk `block - 2` (cyclic)
-        const char* my_src = reinterpret_cast<const char*>(img) + pw * 8192 + lane * 16;
+        const char* my_src = reinterpret_cast<const char*>(img) + pw * 8192;
         const uint32_t my_dst = __builtin_amdgcn_readfirstlane(lds0 + pw * 8192);
         const int lag = pw < 2 ? 0 : 2;
         auto issue = [&](int blk) {
             const char* s = my_src + (size_t)((blk - lag) & (NCH - 1)) * FWD_CHUNK;
             const uint32_t d = my_dst + (uint32_t)(blk & (RS_NB - 1)) * RS_BLOCK;
-            dma4(s, d);
-            dma4(s + 4096, d + 4096);
+            dma4s(s, (uint32_t)lane * 16u, d);
+            dma4s(s + 4096, (uint32_t)lane * 16u, d + 4096);
         };
         issue(0);
         issue(1);
@@ -1328,8 +1397,6 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_rs_kernel(const bf16_t* __rest
         // hidden-site draws: group of 16 ids = (row0 + tok) * 512 + 32 c + 16 half .. + 15 -> g = (row0 + tok) * 32 + 2 c + half
         const uint64_t g0 = (uint64_t)m * 32 + half;
         const uint32_t g0lo = (uint32_t)g0, ghi_term = (uint32_t)(g0 >> 32) * 0x9e3779b1u;
-        const rs_u16x2 tpair = {(unsigned short)dh.thresh, (unsigned short)dh.thresh};
-        const rs_f2 sc2 = {dh.scale, dh.scale};
         char* hrow = TRAIN ? reinterpret_cast<char*>(h_out) + (size_t)my_row * (FF * 2) + half * 16 : nullptr;
         __syncthreads();                                    // P
         rs_stamp(dbg, 1);
@@ -1337,8 +1404,6 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_rs_kernel(const bf16_t* __rest
         __builtin_amdgcn_s_barrier();                       // A(0)
         for (int i = 0; i < RS_ITERS; ++i) {
             const bool act = i >= 1 && i <= NCH;            // E1(i - 1)
-            const bool st8 = dbg != nullptr && i == 8;
-            if (st8) rs_stamp(dbg, 8);
             uint4 hv[4];
             if (act) {
 #pragma unroll
@@ -1346,37 +1411,18 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_rs_kernel(const bf16_t* __rest
             }
             if (i < NCH && !(probe & 2)) issue(i + 3);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (st8) rs_stamp(dbg, 9);
             __builtin_amdgcn_s_barrier();                   // B(i)
-            if (st8) rs_stamp(dbg, 10);
             if (act && !(probe & 1)) {
                 const int c = i - 1;
-                uint32_t pk[8];
+                float v[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const rs_f2 lo = {__uint_as_float(hv[q].x), __uint_as_float(hv[q].y)};
-                    const rs_f2 hi = {__uint_as_float(hv[q].z), __uint_as_float(hv[q].w)};
-                    const rs_f2 a = lo * sc2, b = hi * sc2;
-                    const rs_s16x2 zero = {0, 0};
-                    pk[2 * q] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
-                        __builtin_bit_cast(rs_s16x2, f2bf_pk(a[0], a[1])), zero));
-                    pk[2 * q + 1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(
-                        __builtin_bit_cast(rs_s16x2, f2bf_pk(b[0], b[1])), zero));
+                    v[4 * q] = __uint_as_float(hv[q].x); v[4 * q + 1] = __uint_as_float(hv[q].y);
+                    v[4 * q + 2] = __uint_as_float(hv[q].z); v[4 * q + 3] = __uint_as_float(hv[q].w);
                 }
-                if (dh.on) {
-                    // word k = the draws of elements 2 k (low half) and 2 k + 1: drop when draw < thresh.  r = sat(thresh -
-                    // draw) is 0 for a kept element, else 0 - r >= 65536 - thresh >= 0x8000 > any non-negative bf16 pattern
-                    // (thresh <= 32768, checked by the host), so one more saturating subtraction clears exactly the dropped
-                    const uint32_t hh = (dsvg_hash32((g0lo + 2u * (uint32_t)c) ^ dh.s0) ^ dh.s1) + ghi_term;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const rs_u16x2 d = __builtin_bit_cast(rs_u16x2, drop2_word(hh, k));
-                        const rs_u16x2 r = __builtin_elementwise_sub_sat(tpair, d);
-                        const rs_u16x2 z = {0, 0};
-                        const rs_u16x2 big = z - r;
-                        pk[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(rs_u16x2, pk[k]), big));
-                    }
-                }
+                uint32_t pk[8];
+                const uint32_t hh = dh.on ? (dsvg_hash32((g0lo + 2u * (uint32_t)c) ^ dh.s0) ^ dh.s1) + ghi_term : 0u;
+                ffn_act_packed<false>(v, dh, hh, pk);
                 const uint4 f0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), f1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
                 *reinterpret_cast<uint4*>(hf_buf) = f0;
                 *reinterpret_cast<uint4*>(hf_buf + FRAG) = f1;
@@ -1385,13 +1431,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_rs_kernel(const bf16_t* __rest
                     *reinterpret_cast<uint4*>(hrow + (CH * c + 16) * 2) = f1;
                 }
             }
-            if (st8) rs_stamp(dbg, 11);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (i < NCH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if (i == RS_ITERS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (st8) rs_stamp(dbg, 12);
             __builtin_amdgcn_s_barrier();                   // A(i + 1); the last one is E_A
-            if (st8) rs_stamp(dbg, 13);
             if (i == 1) rs_stamp(dbg, 2);
             else if (i == 8) rs_stamp(dbg, 3);
             else if (i == NCH - 1) rs_stamp(dbg, 4);
@@ -1465,38 +1508,44 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
     const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
     hipStream_t st = (hipStream_t)stream;
     const int stages_arg = stages;       // 0 default, 2 half-size workgroups, 3 / 4 ring slots of the 256-row kernel
-    if (stages == 0 || stages == 2 || stages == 5) stages = 4;
+    if (stages == 0 || stages == 2 || stages >= 5) stages = 4;
     // training variant: 4 slots (chunk k + 2's DMA in flight across the syncs, counted waits) or 3 (every sync drains the
     // wave's h stores too); DSVG_FFN_TRAIN_STAGES for the A/B
     static const int train_stages = getenv("DSVG_FFN_TRAIN_STAGES") ? atoi(getenv("DSVG_FFN_TRAIN_STAGES")) : 4;
     if (train) stages = train_stages == 3 ? 3 : 4;
     // timing probe only (results are wrong below 16): number of hidden chunks actually processed
     static const int dbg_chunks = getenv("DSVG_FFN_DBG_CHUNKS") ? atoi(getenv("DSVG_FFN_DBG_CHUNKS")) : NCH;
-#define DSVG_FFN_FWD(NB, TR)                                                                                          \
+#define DSVG_FFN_FWD(NB, TR, PK)                                                                                      \
     do {                                                                                                              \
         const size_t lds = (size_t)NB * FWD_CHUNK + 3072;                                                             \
-        DSVG_ENSURE_LDS((ffn_fwd_kernel<NB, TR>), lds);                                                               \
-        hipLaunchKernelGGL((ffn_fwd_kernel<NB, TR>), dim3(nb), dim3(512), lds, st, (const bf16_t*)x,                   \
+        DSVG_ENSURE_LDS((ffn_fwd_kernel<NB, TR, PK>), lds);                                                           \
+        hipLaunchKernelGGL((ffn_fwd_kernel<NB, TR, PK>), dim3(nb), dim3(512), lds, st, (const bf16_t*)x,               \
                            (const bf16_t*)packed_fwd_layer, b1_folded, b2, (bf16_t*)y, (bf16_t*)h_out, (bf16_t*)xh_out,\
                            rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res, dbg_chunks,    \
                            g_ffn_dbg_host);                                                                           \
     } while (0)
     // half-size workgroups (stages 2, or by default up to 32,768 rows; DSVG_FFN_HALF=0 / 1 forces the choice)
     static const int half_env = getenv("DSVG_FFN_HALF") ? atoi(getenv("DSVG_FFN_HALF")) : -1;
-    const bool half_on = stages_arg == 2 || (stages_arg == 0 && (half_env >= 0 ? half_env != 0 : rows <= 32768));
+    // packed activation (ffn_act_packed; dropout rates up to 0.5): stages 6 / 7 = the 256-row / half-size workgroups with it,
+    // 0 = the library's choice (DSVG_FFN_PACKED=0 / 1 forces it for the default)
+    static const int pk_env = getenv("DSVG_FFN_PACKED") ? atoi(getenv("DSVG_FFN_PACKED")) : 1;
+    const bool pk = !(drop_p > 0.5f) && (stages_arg == 6 || stages_arg == 7 || (stages_arg == 0 && pk_env != 0));
+    const bool half_on = stages_arg == 2 || stages_arg == 7 || (stages_arg == 0 && (half_env >= 0 ? half_env != 0 : rows <= 32768));
     if (half_on) {
         const int nbh = (int)((rows + 127) / 128);
         const size_t lds = (size_t)HNBUF * HSLOT + 3072;
-#define DSVG_FFN_FWD_HALF(TR)                                                                                         \
+#define DSVG_FFN_FWD_HALF(TR, PK)                                                                                     \
     do {                                                                                                              \
-        DSVG_ENSURE_LDS((ffn_fwd_half_kernel<TR>), lds);                                                              \
-        hipLaunchKernelGGL((ffn_fwd_half_kernel<TR>), dim3(nbh), dim3(256), lds, st, (const bf16_t*)x,                 \
+        DSVG_ENSURE_LDS((ffn_fwd_half_kernel<TR, PK>), lds);                                                          \
+        hipLaunchKernelGGL((ffn_fwd_half_kernel<TR, PK>), dim3(nbh), dim3(256), lds, st, (const bf16_t*)x,             \
                            (const bf16_t*)packed_fwd_layer, b1_folded, b2, (bf16_t*)y, (bf16_t*)h_out, (bf16_t*)xh_out,\
                            rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res, dbg_chunks,    \
                            g_ffn_dbg_host);                                                                           \
     } while (0)
-        if (train) DSVG_FFN_FWD_HALF(true);
-        else DSVG_FFN_FWD_HALF(false);
+        if (train && pk) DSVG_FFN_FWD_HALF(true, true);
+        else if (train) DSVG_FFN_FWD_HALF(true, false);
+        else if (pk) DSVG_FFN_FWD_HALF(false, true);
+        else DSVG_FFN_FWD_HALF(false, false);
 #undef DSVG_FFN_FWD_HALF
         DSVG_LAUNCH_CHECK("ffn_fwd (half-size workgroups)");
         return 0;
@@ -1519,11 +1568,14 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
         DSVG_LAUNCH_CHECK("ffn_fwd (role-specialised)");
         return 0;
     }
-    if (train && stages == 3) DSVG_FFN_FWD(3, true);
-    else if (train) DSVG_FFN_FWD(4, true);
-    else if (stages == 3) DSVG_FFN_FWD(3, false);
-    else if (stages == 4) DSVG_FFN_FWD(4, false);
-    else { dsvg_set_error("ffn_fwd: stages must be 0 (default), 2 (half-size workgroups), 3 or 4"); return -1; }
+    if (stages != 3 && stages != 4) { dsvg_set_error("ffn_fwd: stages must be 0 (default), 2 / 7 (half-size workgroups), 3, 4, 5 or 6"); return -1; }
+    if (pk) {
+        if (train) DSVG_FFN_FWD(4, true, true);
+        else DSVG_FFN_FWD(4, false, true);
+    } else if (train && stages == 3) DSVG_FFN_FWD(3, true, false);
+    else if (train) DSVG_FFN_FWD(4, true, false);
+    else if (stages == 3) DSVG_FFN_FWD(3, false, false);
+    else DSVG_FFN_FWD(4, false, false);
 #undef DSVG_FFN_FWD
     DSVG_LAUNCH_CHECK("ffn_fwd");
     return 0;

@@ -92,6 +92,22 @@ __device__ __forceinline__ void dma4(const void* src, uint32_t lds) {
         : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
 }
 
+// the same with the global address as (wave-uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): no 64-bit VGPR
+// address pair to keep alive across a loop, the per-chunk advance is scalar arithmetic
+__device__ __forceinline__ void dma4s(const void* base_uniform, uint32_t lane_off, uint32_t lds) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "v"(lane_off), "s"(base_uniform), "s"(lds) : "memory");
+}
+
 // One transposed 32 x 32 accumulator tile (lane: token row lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the
 // tile) -> the lane's 16 consecutive tile columns 16 (lane >> 5) .. + 15 as x[q][e] = column 4 q + e.
 __device__ __forceinline__ void tile_to_cols16(const floatx16& c, uint32_t (&x)[4][4]) {

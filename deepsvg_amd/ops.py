@@ -1093,8 +1093,10 @@ def ffn_fwd(x, packed_fwd_layer, b1f, b2, eps=1e-5, drop_p=0.0, site_hidden=0, s
     """y = x + drop_r(linear2(drop_h(relu(linear1(LayerNorm(x))))))  (x bf16 [rows, 256]; the LayerNorm's gamma / beta
     are inside packed_fwd_layer / b1f, see ffn_pack).  train: -> (y, h, xh, rstd) with h bf16 [rows, 512] in fragment
     order, xh = (x - mean) * rstd bf16, rstd fp32 [rows] (what the backward pass needs).
-    stages: None = the library's choice (half-size workgroups up to 32,768 rows), 2 = half-size workgroups, 3 / 4 = the
-    256-row workgroups with that many weight-ring slots (all bit-identical; tests and probes)"""
+    stages: None = the library's choice (half-size workgroups up to 32,768 rows, packed activation code), 2 = half-size
+    workgroups, 3 / 4 = the 256-row workgroups with that many weight-ring slots, all three with the scalar activation code and
+    bit-identical; 7 / 6 = half-size / 256-row workgroups with the packed activation code (bit-identical to each other and to
+    the default; rounding-level differences to 2 / 3 / 4), 5 = the role-specialised 128-row kernel (tests and probes)"""
     _chk(x, packed_fwd_layer, b1f, b2, seed, out)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
     assert packed_fwd_layer.numel() == FFN_FWD_LAYER_ELEMS and packed_fwd_layer.is_contiguous()

@@ -28,10 +28,31 @@ def test_bench_main_loop_two_ranks_gloo():
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout              # rank 0 only
-    rec = json.loads(lines[0])
+    _check_record(json.loads(lines[0]))
+
+
+def _check_record(rec):
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
     assert rec["config"]["global_batch"] == 6 and rec["config"]["parallelism"] == "dp2"
-    assert rec["value"] > 0 and abs(rec["value"] - 6 / (rec["ms_per_step"] * 1e-3)) < 0.01 * rec["value"]
+    # `value` is printed with one decimal and `ms_per_step` with three: on a slow host (0.4 icons/s) the rounding alone is
+    # more than 1 %
+    want = 6 / (rec["ms_per_step"] * 1e-3)
+    assert rec["value"] > 0 and abs(rec["value"] - want) <= max(0.01 * want, 0.06)
     assert rec["config"]["loss"] == rec["config"]["loss"]       # finite
     assert rec["rccl_ranks"] == 2, "rank 0 must report the number of ranks its collectives actually span"
     assert rec["graphs"]["batches_rotated"] == 8
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (the plain form of the driver's command): the script
+    starts its two ranks itself and still prints ONE line with n_gpus = rccl_ranks = 2"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DSVG_BENCH_EMULATE="1", PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="2",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3",
+           "--dtype", "fp32"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    _check_record(json.loads(lines[0]))

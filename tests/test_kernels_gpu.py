@@ -942,22 +942,61 @@ def test_ffn_fwd_matches_reference(gpu_device, rows, drop_p):
 @pytest.mark.parametrize("rows", [100, 4096 + 37, 40000])
 def test_ffn_fwd_workgroup_variants_agree(gpu_device, rows):
     """the 256-row workgroups (3- and 4-slot weight rings) and the half-size workgroups (128 rows, the default up to
-    32,768 rows) run the same per-wave program: every output is bit-identical, inference and training variants"""
+    32,768 rows) run the same per-wave program: every output is bit-identical, inference and training variants - once with the
+    scalar activation code (stages 2 / 3 / 4) and once with the packed one (stages 7 / 6 and the default)"""
     flat, offs, x, b2 = _ffn_setup(rows, seed=rows + 1)
     pf, _, b1f = ops.ffn_pack(flat, offs, 2)
     pl = pf[:ops.FFN_FWD_LAYER_ELEMS]
     seed = _seed_tensor(0x1122334455667788)
     for train in (False, True):
         outs = {}
-        for stages in (2, 3, 4):
+        for stages in (2, 3, 4, 6, 7, None):
             r = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 403, 404, seed, train=train, stages=stages)
             outs[stages] = r if train else (r,)
-        for stages in (3, 4):
-            for a, b in zip(outs[2], outs[stages]):
-                assert torch.equal(a, b), (rows, train, stages)
-        dflt = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 403, 404, seed, train=train)
-        for a, b in zip(outs[2], dflt if train else (dflt,)):
-            assert torch.equal(a, b)
+        for ref, others in ((2, (3, 4)), (7, (6, None))):
+            for stages in others:
+                for a, b in zip(outs[ref], outs[stages]):
+                    assert torch.equal(a, b), (rows, train, stages)
+
+
+def _bf16_steps(a, b):
+    """distance of two bf16 tensors in representable steps (order-preserving integer image of the bit patterns)"""
+    ai, bi = a.view(torch.int16).to(torch.int32), b.view(torch.int16).to(torch.int32)
+    ai = torch.where(ai < 0, -32768 - ai, ai)
+    bi = torch.where(bi < 0, -32768 - bi, bi)
+    return (ai - bi).abs()
+
+
+@pytest.mark.parametrize("rows", [100, 128, 1000, 4096 + 37, 40000])
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_ffn_fwd_packed_and_role_specialised_variants(gpu_device, rows, drop_p):
+    """round 5: the packed activation (stages 6) and the role-specialised 128-row kernel (stages 5: matrix waves + vector
+    waves) against the scalar 256-row kernel (stages 4).  Same dropout draws (the kept / dropped elements of h are the same
+    elements), same xh / rstd bits; h and y differ by fp32 summation order before the bf16 rounding: h within ONE bf16 step
+    wherever it is not within rounding of zero, y as close to the restatement as the scalar kernel is"""
+    flat, offs, x, b2 = _ffn_setup(rows, seed=rows + 7)
+    pf, _, b1f = ops.ffn_pack(flat, offs, 2)
+    epf, _, eb1f = R.ffn_pack(flat, offs, 2)
+    pl = pf[:ops.FFN_FWD_LAYER_ELEMS]
+    seed = _seed_tensor(0x0BADC0FFEE123457)
+    want = R.ffn_fwd(x, epf[:ops.FFN_FWD_LAYER_ELEMS], eb1f[0], b2, 1e-5, drop_p, 403, 404, seed)
+    y4, h4, xh4, rstd4 = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, drop_p, 403, 404, seed, train=True, stages=4)
+    e4 = (y4.float() - want.float()).abs().max().item()
+    scale = want.float().abs().max().item()
+    for stages in (5, 6):
+        y, h, xh, rstd = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, drop_p, 403, 404, seed, train=True, stages=stages)
+        yi = ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, drop_p, 403, 404, seed, stages=stages)
+        assert torch.equal(y, yi), "training and inference variants compute the same y"
+        assert torch.equal(xh, xh4) and torch.equal(rstd, rstd4)
+        same_gate = (h != 0) == (h4 != 0)
+        assert (~same_gate).float().mean().item() < 1e-4, stages        # pre-activations within fp32 rounding of zero
+        steps = _bf16_steps(h, h4)
+        big = (h4.float().abs() > 1e-2) & same_gate
+        assert int(steps[big].max().item()) <= 1, (stages, int(steps[big].max().item()))
+        assert (steps != 0).float().mean().item() < 2e-3
+        e = (y.float() - want.float()).abs().max().item()
+        assert e <= max(1.5e-2 * scale, 1.5 * e4), (stages, e, e4)
+        assert (y.float() - y4.float()).abs().mean().item() < 2e-4 * y4.float().abs().mean().item()
 
 
 def test_ffn_fwd_equals_unfused_kernels(gpu_device):
@@ -1109,7 +1148,11 @@ def test_ffn_training_path_matches_reference(gpu_device, drop_p):
     _close(dx, edx, 2e-2, "training path dx")
     # and against the fully fused backward (which recomputes h and replays the hidden mask itself)
     dx_f, h_f, dpre_f, xh_f, dym_f = ops.ffn_bwd(x, dy, pbl, b1f[0], 1e-5, drop_p, 403, 404, seed)
-    assert torch.equal(h_f, h) and torch.equal(xh_f, xh)
+    # (the backward kernel recomputes h with the scalar activation code, the forward default is the packed one: the same
+    # draws, values within fp32 summation order before the bf16 rounding)
+    assert torch.equal(xh_f, xh)
+    assert (((h_f != 0) != (h != 0)).float().mean().item()) < 1e-4
+    _close(h_f, h, 8e-3, "recomputed h vs the forward kernel's")
     if drop_p > 0:
         assert torch.equal(dym_f, dym)
     _close(dpre_f, dpre, 1.5e-2, "fused vs training-path dpre")
