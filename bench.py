@@ -282,6 +282,12 @@ def secondary_legs(device):
     sec = timed(lambda: m.greedy_sample(z=z, concat_groups=False, temperature=0), 3)
     out["c5_one_shot_decode"] = {"ms": round(sec * 1e3, 2), "icons_per_s": round(8192 / sec, 1),
                                  "workload": "hierarchical_ordered greedy_sample from 8192 latents, temperature 0 (head + arg-max fused)"}
+    # the reference's default temperature (1e-4, deepsvg/model/model.py:414): the categorical draw as a Gumbel arg-max fused
+    # into the argument head - the 8192 x 8 x 30 x 11 x 257 logits (23 GB in fp32) are never built
+    sec = timed(lambda: m.greedy_sample(z=z, concat_groups=False), 3)
+    out["c5_one_shot_decode_default_temperature"] = {
+        "ms": round(sec * 1e3, 2), "icons_per_s": round(8192 / sec, 1),
+        "workload": "the same at temperature 1e-4 (reference default): categorical draw on the device (head + Gumbel arg-max fused)"}
     del m
     cfg = C.Sketchformer()
     cfg.max_total_len = 50

@@ -1,7 +1,8 @@
 // The argument head (args_fcn: Linear(d_model 256 -> n_args * args_dim = 11 x 257 logits), deepsvg/model/model.py:228-246) fused
 // with what consumes its logits, so that the [tokens, 2827] logit tensor - the largest stream of the model - never reaches
 // HBM:
-//   MODE_ARGMAX   decoding at temperature 0 (deepsvg/model/utils.py:75-80 in the limit): arg-max per (token, slot)
+//   MODE_ARGMAX   decoding: arg-max per (token, slot) - the temperature-0 limit of deepsvg/model/utils.py:75-80 - or, with a
+//                 temperature > 0, the reference's categorical draw itself as a Gumbel arg-max (logit + T g, dsvg_gumbel)
 //   MODE_LSE      SVGLoss's cross-entropy forward (deepsvg/model/loss.py:51-57): log-sum-exp per (token, slot) and the
 //                 weighted sum / count of (lse - logit[target])
 //   MODE_DLOGITS  its backward: the logit tile is recomputed and leaves as dlogits = w g (softmax - onehot) in bf16, the
@@ -53,6 +54,9 @@ struct HeadArgs {
     const int32_t* tok_idx;
     // MODE_ARGMAX
     int32_t* out_idx;           // [rows * group]
+    float temperature;          // > 0: sample from softmax(logits / temperature) (Gumbel arg-max), 0: plain arg-max
+    const uint64_t* seed;
+    uint32_t site;
     // MODE_LSE
     float* lse;                 // [rows * group] (out; in for MODE_DLOGITS)
     float* part;                // [gridDim.x * 2]: (sum of w (lse - logit[target]), sum of w) per workgroup
@@ -105,6 +109,9 @@ __global__ __launch_bounds__(512, 1) void head_kernel(HeadArgs a) {
     const int C = a.C;
     float g = 0.f;
     if (MODE == MODE_DLOGITS) g = a.coef * (a.gscale ? *a.gscale : 1.f) / a.sum_count[1];
+    const bool noisy = MODE == MODE_ARGMAX && a.temperature > 0.f;
+    const DropCtx gctx = drop_make(noisy ? 0.5f : 0.f, a.seed, a.site);      // (only its mixed seed words are used)
+    const uint32_t k4 = (uint32_t)(a.n_out + 3) >> 2;
 
     // ---- running state of the slot this wave is in ----------------------------------------------------------------------------
     int slot = 0, slot_lo = 0, slot_hi = C;                         // columns [slot_lo, slot_hi)
@@ -182,6 +189,17 @@ __global__ __launch_bounds__(512, 1) void head_kernel(HeadArgs a) {
                 const float4 b = *reinterpret_cast<const float4*>(sbias + cb + 8 * q + 4 * h2);
                 v[4 * q + 0] = acc[t][4 * q + 0] + b.x; v[4 * q + 1] = acc[t][4 * q + 1] + b.y;
                 v[4 * q + 2] = acc[t][4 * q + 2] + b.z; v[4 * q + 3] = acc[t][4 * q + 3] + b.w;
+            }
+            if (noisy) {
+                // the lane's columns come in runs of 4 (cb + 8 q + 4 h2 + e): one key hash per run, one word per element
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t col0 = (uint32_t)(cb + 8 * q + 4 * h2);
+                    const uint32_t hk = drop_group(gctx, (uint64_t)row * k4 + (col0 >> 2));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[4 * q + e] = fmaf(a.temperature, dsvg_gumbel_from_word(drop_word(hk, (uint32_t)e)), v[4 * q + e]);
+                }
             }
             if (MODE == MODE_DLOGITS) {
                 // every column of the tile belongs to `slot` or - at and past slot_hi - to the next one
@@ -318,6 +336,16 @@ extern "C" int dsvg_head_argmax(const void* x, const void* packed, const float* 
     a.x = (const bf16_t*)x; a.img = (const bf16_t*)packed; a.bias = bias; a.rows = rows; a.n_out = n_out; a.C = C;
     a.group = n_out / C; a.out_idx = out_idx;
     return head_launch<MODE_ARGMAX>(a, (hipStream_t)stream, "head_argmax");
+}
+
+extern "C" int dsvg_head_sample(const void* x, const void* packed, const float* bias, int64_t rows, int32_t n_out, int32_t C,
+                                float temperature, const void* seed, uint32_t site, int32_t* out_idx, void* stream) {
+    if (head_check(x, packed, bias, rows, n_out, C, "head_sample")) return -1;
+    DSVG_CHECK_ARG(out_idx && seed && temperature > 0.f, "head_sample: needs an output, a seed and a temperature > 0");
+    HeadArgs a{};
+    a.x = (const bf16_t*)x; a.img = (const bf16_t*)packed; a.bias = bias; a.rows = rows; a.n_out = n_out; a.C = C;
+    a.group = n_out / C; a.out_idx = out_idx; a.temperature = temperature; a.seed = (const uint64_t*)seed; a.site = site;
+    return head_launch<MODE_ARGMAX>(a, (hipStream_t)stream, "head_sample");
 }
 
 extern "C" int64_t dsvg_head_lse_workspace_bytes(int64_t rows) { return ((rows + HTOK - 1) / HTOK) * 2 * (int64_t)sizeof(float); }

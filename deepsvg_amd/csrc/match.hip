@@ -236,17 +236,25 @@ extern "C" int dsvg_match_assign(const float* cost, const int32_t* visible, int6
 // logits, no softmax, no multinomial draw.  Ties go to the lowest class index.  One wave per row.
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
+// temperature > 0: a draw from softmax(logits / temperature) as a Gumbel arg-max (dsvg_gumbel, dsvg_common.h): the noise of
+// logical row r = (token r / group, slot r % group), class c is that of element (token, slot * C + c) of the token's
+// [group * C] logit row - the same element dsvg_head_sample perturbs, so both entry points draw the same sample
 template <typename T>
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const T* __restrict__ logits, long long ld, int group,
-                                                          long long rows, int C, int32_t* __restrict__ out) {
+                                                          long long rows, int C, int32_t* __restrict__ out,
+                                                          float temperature, const uint64_t* __restrict__ seed, uint32_t site) {
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const T* x = logits + (r / group) * ld + (r % group) * (long long)C;
+    const bool noisy = temperature > 0.f;
+    const DropCtx gctx = drop_make(noisy ? 0.5f : 0.f, seed, site);
+    const uint32_t k4 = (uint32_t)(group * C + 3) >> 2, col0 = (uint32_t)(r % group) * (uint32_t)C;
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int c = lane; c < C; c += 64) {
-        const float v = Elem<T>::ld(x + c);
+        float v = Elem<T>::ld(x + c);
+        if (noisy) v = fmaf(temperature, dsvg_gumbel(gctx, (uint64_t)(r / group), k4, col0 + (uint32_t)c), v);
         if (v > best) { best = v; bi = c; }          // ascending c per lane: the first maximum wins
     }
 #pragma unroll
@@ -259,16 +267,30 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const T* __restrict__ 
 }
 }  // namespace
 
-extern "C" int dsvg_argmax_rows(int32_t dtype, const void* logits, int64_t ld, int32_t group, int64_t rows, int32_t C,
-                                int32_t* out, void* stream) {
-    DSVG_CHECK_ARG(logits && out && rows > 0 && group > 0 && C > 0 && ld >= (int64_t)group * C, "argmax_rows: bad args");
+static int argmax_rows_launch(int32_t dtype, const void* logits, int64_t ld, int32_t group, int64_t rows, int32_t C,
+                              int32_t* out, float temperature, const void* seed, uint32_t site, void* stream, const char* who) {
     const unsigned grid = (unsigned)dsvg_cdiv(rows, 4);
     if (dtype == DSVG_BF16)
         hipLaunchKernelGGL(argmax_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)logits, (long long)ld, group, (long long)rows, C, out);
+                           (const bf16_t*)logits, (long long)ld, group, (long long)rows, C, out, temperature,
+                           (const uint64_t*)seed, site);
     else
         hipLaunchKernelGGL(argmax_rows_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)logits, (long long)ld, group, (long long)rows, C, out);
-    DSVG_LAUNCH_CHECK("argmax_rows");
+                           (const float*)logits, (long long)ld, group, (long long)rows, C, out, temperature,
+                           (const uint64_t*)seed, site);
+    DSVG_LAUNCH_CHECK(who);
     return 0;
+}
+
+extern "C" int dsvg_argmax_rows(int32_t dtype, const void* logits, int64_t ld, int32_t group, int64_t rows, int32_t C,
+                                int32_t* out, void* stream) {
+    DSVG_CHECK_ARG(logits && out && rows > 0 && group > 0 && C > 0 && ld >= (int64_t)group * C, "argmax_rows: bad args");
+    return argmax_rows_launch(dtype, logits, ld, group, rows, C, out, 0.f, nullptr, 0u, stream, "argmax_rows");
+}
+
+extern "C" int dsvg_sample_rows(int32_t dtype, const void* logits, int64_t ld, int32_t group, int64_t rows, int32_t C,
+                                float temperature, const void* seed, uint32_t site, int32_t* out, void* stream) {
+    DSVG_CHECK_ARG(logits && out && rows > 0 && group > 0 && C > 0 && ld >= (int64_t)group * C, "sample_rows: bad args");
+    DSVG_CHECK_ARG(seed && temperature > 0.f, "sample_rows: needs a seed and a temperature > 0");
+    return argmax_rows_launch(dtype, logits, ld, group, rows, C, out, temperature, seed, site, stream, "sample_rows");
 }

@@ -14,7 +14,7 @@ DSVG_F32 = 0
 DSVG_BF16 = 1
 # == DSVG_ABI_VERSION of include/dsvg.h at the time SIGNATURES below was written: load() refuses a library built from another
 # header (a stale .so with the old argument lists would otherwise be called with a stream where a size is expected)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_i32, c_i64, c_u32, c_f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_float
 vp = C.c_void_p
@@ -64,6 +64,7 @@ SIGNATURES = {
     "dsvg_head_pack_elems": (c_i64, [c_i32]),
     "dsvg_head_pack": (c_i32, [vp, c_i32, vp, vp]),
     "dsvg_head_argmax": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, vp, vp]),
+    "dsvg_head_sample": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, c_f32, vp, c_u32, vp, vp]),
     "dsvg_head_lse_workspace_bytes": (c_i64, [c_i64]),
     "dsvg_head_lse": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, vp, vp, c_i64, vp]),
     "dsvg_head_dlogits": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp, vp, vp, c_f32, vp, c_i64, vp]),
@@ -120,6 +121,7 @@ SIGNATURES = {
                                  c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, vp, vp, vp]),
     "dsvg_match_assign": (c_i32, [vp, vp, c_i64, c_i32, c_i32, vp, vp, vp, vp]),
     "dsvg_argmax_rows": (c_i32, [c_i32, vp, c_i64, c_i32, c_i64, c_i32, vp, vp]),
+    "dsvg_sample_rows": (c_i32, [c_i32, vp, c_i64, c_i32, c_i64, c_i32, c_f32, vp, c_u32, vp, vp]),
     "dsvg_ffn_pack_bytes": (c_i64, [c_i32, c_i32]),
     "dsvg_ffn_pack": (c_i32, [vp, vp, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp]),
     "dsvg_ffn_fwd": (c_i32, [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_f32, c_f32, c_u32, c_u32, vp, c_i32, vp]),

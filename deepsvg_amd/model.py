@@ -626,6 +626,9 @@ class SVGTransformer(nn.Module):
         self.hoist_global = os.environ.get("DSVG_HOIST_GLOBAL", "1") != "0"
         self.last_head_rows = None
         self.kv_cache = True         # autoregressive sampling: incremental decoding over a per-layer q|k|v cache
+        # temperature > 0 sampling as a Gumbel arg-max on the device (False: torch.distributions.Categorical over the dense
+        # logits, the reference's own call - deepsvg/model/utils.py:75-79)
+        self.device_sampling = True
         self.last_assignment = None  # self-matching configs: (N, Gp) int32 assignment of the last training forward
         self._forced_plan = None
         self._decoder_grads_ready = None    # callback of a data-parallel trainer (TrainStep), see forward()
@@ -991,9 +994,13 @@ class SVGTransformer(nn.Module):
         if out.dtype == torch.bfloat16 and out.shape[1] == 256 and args_dim >= 64 and n_args * args_dim <= 3008:
             # decoding at temperature 0: arg-max per (token, argument slot) with the head's logit tile on chip
             # (csrc/head_fused.hip) instead of the dense (N, G, S, n_args, args_dim) logits + an arg-max pass over them
-            def head_argmax():
+            def head_argmax(temperature=0.0, seed=None):
                 src = out if complete is None else complete()
                 img = ops.head_pack(rt.w(fcn.weight))
+                if temperature > 0:     # the reference's categorical draw, on the on-chip logit tile (Gumbel arg-max)
+                    return ops.head_sample(src.detach().contiguous(), img, fcn.bias.detach().float().contiguous(),
+                                           n_args * args_dim, args_dim, temperature, seed, ops.SITE_SAMPLE_ARGS) \
+                        .view(N, G, S, n_args)
                 return ops.head_argmax(src.detach().contiguous(), img, fcn.bias.detach().float().contiguous(),
                                        n_args * args_dim, args_dim).view(N, G, S, n_args)
             self._head_argmax = head_argmax
@@ -1176,9 +1183,10 @@ class SVGTransformer(nn.Module):
         else:
             res = self.forward(commands_enc, args_enc, commands_dec, args_dec, label=label, z=z,
                                hierarch_logits=hierarch_logits, return_tgt=False)
+            # restated from /root/reference/deepsvg/model/model.py:414-423,442-448 (one-shot decoding)
             arg_src = None
-            if temperature == 0 and res.is_pending("args_logits"):
-                arg_src = (dict.get(res, "_dsvg_head_argmax") or {}).get("fn")    # fused head + arg-max of this forward
+            if res.is_pending("args_logits") and (temperature == 0 or self.device_sampling):
+                arg_src = (dict.get(res, "_dsvg_head_argmax") or {}).get("fn")    # fused head + arg-max / draw of this forward
             commands_y, args_y = self._sample(res["command_logits"], arg_src if arg_src is not None else res["args_logits"],
                                               temperature)
             args_y -= 1   # shift due to -1 PAD_VAL
@@ -1206,6 +1214,22 @@ class SVGTransformer(nn.Module):
             cl = command_logits.reshape(-1, cs[-1])
             cmd = ops.argmax_rows(cl if cl.stride(-1) == 1 else cl.contiguous(), cs[-1]).long().view(cs[:-1])
             return cmd, args_logits().long().view(*cs[:-1], -1)
+        if temperature > 0 and self.device_sampling and (command_logits.is_cuda or ops.sample_rows.__module__ != ops.__name__):
+            # the categorical draw on the device: arg-max of logits + temperature * Gumbel noise (counter hash, seeded from
+            # torch's generator - torch.manual_seed makes it reproducible), fused into the argument head where the logits
+            # are still pending: the (N, G, S, n_args, args_dim) tensor (23 GB at 8192 icons) is never built
+            seed = torch.randint(-(1 << 62), 1 << 62, (1,), dtype=torch.int64).to(command_logits.device)
+            cs = command_logits.shape
+            cl = command_logits.reshape(-1, cs[-1])
+            cmd = ops.sample_rows(cl if cl.stride(-1) == 1 else cl.contiguous(), cs[-1], temperature, seed,
+                                  ops.SITE_SAMPLE_CMD).long().view(cs[:-1])
+            if callable(args_logits):
+                return cmd, args_logits(temperature, seed).long().view(*cs[:-1], -1)
+            as_ = args_logits.shape
+            al = args_logits.reshape(-1, as_[-2] * as_[-1])
+            arg = ops.sample_rows(al if al.stride(-1) == 1 else al.contiguous(), as_[-1], temperature, seed,
+                                  ops.SITE_SAMPLE_ARGS, group=as_[-2]).long().view(as_[:-1])
+            return cmd, arg
         if temperature == 0:
             cs, as_ = command_logits.shape, args_logits.shape
             cl = command_logits.reshape(-1, cs[-1])
@@ -1336,6 +1360,8 @@ class SVGTransformer(nn.Module):
         return args_y
 
     def _make_valid(self, commands_y, args_y, visibility_y=None, PAD_VAL=-1):
+        """restated from /root/reference/deepsvg/model/model.py:450-459 (output-defining host glue of the sampling path: invisible
+        groups become [m, EOS, ...] with padded arguments, argument slots a command does not use become PAD_VAL)"""
         if visibility_y is not None:
             S = commands_y.size(-1)
             commands_y[~visibility_y] = commands_y.new_tensor([M_ID, *[EOS_ID] * (S - 1)])

@@ -920,6 +920,22 @@ def argmax_rows(logits2d, C, group=1):
     return out
 
 
+SITE_SAMPLE_CMD, SITE_SAMPLE_ARGS = 7001, 7002     # noise streams of the two categorical draws of greedy_sample
+
+
+def sample_rows(logits2d, C, temperature, seed, site, group=1):
+    """a draw from softmax(row / temperature) per C-wide class slot (Gumbel arg-max on the device, include/dsvg.h) ->
+    int32 [n_tok * group]; seed: int64 [1] device tensor"""
+    _chk(logits2d, seed)
+    assert logits2d.dim() == 2 and logits2d.stride(1) == 1 and logits2d.shape[1] >= group * C and temperature > 0
+    rows = logits2d.shape[0] * group
+    out = torch.empty(rows, dtype=torch.int32, device=logits2d.device)
+    _l.check(_l.load().dsvg_sample_rows(_dt(logits2d), logits2d.data_ptr(), logits2d.stride(0), group, rows, C,
+                                        float(temperature), seed.data_ptr(), int(site), out.data_ptr(), _stream()),
+             "dsvg_sample_rows")
+    return out
+
+
 # ---- the argument head fused with its consumers (csrc/head_fused.hip) -------------------------------------------------------
 def head_pack(weight_lp):
     """bf16 [n_out, 256] rows of the head in use (contiguous) -> packed MFMA fragment image for the three head_* kernels"""
@@ -943,6 +959,18 @@ def head_argmax(x, packed, bias, n_out, C):
     out = torch.empty(x.shape[0] * (n_out // C), dtype=torch.int32, device=x.device)
     _l.check(_l.load().dsvg_head_argmax(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), x.shape[0], n_out, C,
                                         out.data_ptr(), _stream()), "dsvg_head_argmax")
+    return out
+
+
+def head_sample(x, packed, bias, n_out, C, temperature, seed, site):
+    """-> int32 [rows * (n_out // C)]: a draw from softmax(slot logits / temperature) per C-wide slot of x @ W^T + bias, the
+    logits never stored (same draws as sample_rows on the dense logits)"""
+    _head_args(x, packed, bias, n_out, C)
+    _chk(seed)
+    out = torch.empty(x.shape[0] * (n_out // C), dtype=torch.int32, device=x.device)
+    _l.check(_l.load().dsvg_head_sample(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), x.shape[0], n_out, C,
+                                        float(temperature), seed.data_ptr(), int(site), out.data_ptr(), _stream()),
+             "dsvg_head_sample")
     return out
 
 

@@ -32,8 +32,9 @@ extern "C" {
  * dsvg_attn_block_fwd_stages removed, round 3's signature changes of dsvg_defer_scope / dsvg_gather_groups /
  * dsvg_bcast_add_bwd / dsvg_loss_targets / dsvg_scatter_rows counted).  dsvg_version() returns the value the library was
  * built with; a caller compiled against another header must refuse to run (deepsvg_amd/lib.py does).
- * 3: dsvg_latent_chain_fwd / dsvg_latent_chain_bwd added.  4: seq_add_ld argument of dsvg_attn_block_fwd / dsvg_gs_layer_fwd. */
-#define DSVG_ABI_VERSION 4
+ * 3: dsvg_latent_chain_fwd / dsvg_latent_chain_bwd added.  4: seq_add_ld argument of dsvg_attn_block_fwd / dsvg_gs_layer_fwd.
+ * 5 (round 5): dsvg_sample_rows / dsvg_head_sample added (categorical sampling on the device). */
+#define DSVG_ABI_VERSION 5
 
 const char* dsvg_last_error(void);
 int dsvg_version(void);
@@ -395,6 +396,13 @@ int dsvg_match_assign(const float* cost, const int32_t* visible, int64_t N, int3
  * _sample_categorical (deepsvg/model/utils.py:75-80), used by greedy_sample(temperature=0). */
 int dsvg_argmax_rows(int32_t dtype, const void* logits, int64_t ld, int32_t group, int64_t rows, int32_t C,
                      int32_t* out, void* stream);
+/* out[r] = a draw from softmax(logits(r, :) / temperature), temperature > 0: _sample_categorical itself
+ * (deepsvg/model/utils.py:75-79, torch.distributions.Categorical(logits = logits / T).sample()) as a Gumbel arg-max
+ * arg-max_c (logit_c + T g_c) with the noise of the counter hash (seed: 8 bytes of device memory, site: stream id) - no
+ * softmax, no cumulative sum, no fp32 copy of the logits.  Same addressing as dsvg_argmax_rows; the noise of logical row r,
+ * class c is that of element (r / group, (r % group) * C + c), shared with dsvg_head_sample. */
+int dsvg_sample_rows(int32_t dtype, const void* logits, int64_t ld, int32_t group, int64_t rows, int32_t C,
+                     float temperature, const void* seed, uint32_t site, int32_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The argument head fused with its consumers (csrc/head_fused.hip): args_fcn = Linear(256 -> n_args *
@@ -404,6 +412,9 @@ int dsvg_argmax_rows(int32_t dtype, const void* logits, int64_t ld, int32_t grou
  *   dsvg_head_argmax   out_idx[row * group + slot] = argmax_c logits(row, slot, c), ties -> lowest class: the temperature
  *                      -> 0 limit of _sample_categorical (deepsvg/model/utils.py:75-80) without the logits (replaces
  *                      the head GEMM + dsvg_argmax_rows in greedy_sample(temperature=0)).
+ *   dsvg_head_sample   the same at a temperature > 0: out_idx = a draw from softmax(logits(row, slot, :) / temperature), the
+ *                      reference's default decoding (greedy_sample(temperature = 1e-4), deepsvg/model/model.py:414-418) as a
+ *                      Gumbel arg-max on the on-chip logit tile; draws identical to dsvg_sample_rows on the dense logits.
  *   dsvg_head_lse      the masked cross-entropy forward of SVGLoss (deepsvg/model/loss.py:51-57) on the compact token list:
  *                      lse[row * group + slot] (0 where the weight is 0) and sum_count = (sum of w (lse - logit[target]),
  *                      sum of w).  target / w are indexed tok * group + slot with tok = tok_idx ? tok_idx[row] : row
@@ -416,6 +427,8 @@ int64_t dsvg_head_pack_elems(int32_t n_out);
 int dsvg_head_pack(const void* weight_bf16, int32_t n_out, void* packed, void* stream);
 int dsvg_head_argmax(const void* x, const void* packed, const float* bias, int64_t rows, int32_t n_out, int32_t C,
                      int32_t* out_idx, void* stream);
+int dsvg_head_sample(const void* x, const void* packed, const float* bias, int64_t rows, int32_t n_out, int32_t C,
+                     float temperature, const void* seed, uint32_t site, int32_t* out_idx, void* stream);
 int64_t dsvg_head_lse_workspace_bytes(int64_t rows);
 int dsvg_head_lse(const void* x, const void* packed, const float* bias, int64_t rows, int32_t n_out, int32_t C,
                   const int32_t* target, const float* w, const int32_t* tok_idx, float* lse, float* sum_count,

@@ -30,6 +30,6 @@ for rows in (63488, 40960):
     for train in (False, True):
         for _ in range(5):
             junk.fill_(1.0)
-            ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 3, 4, seed, train=train, stages=4)
+            ops.ffn_fwd(x, pl, b1f[0], b2, 1e-5, 0.1, 3, 4, seed, train=train)
     torch.cuda.synchronize()
 print("done")

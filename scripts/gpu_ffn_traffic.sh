@@ -21,7 +21,8 @@ def per_dispatch(counter):
     f = glob.glob(f"gpurun_out/ffntr_{counter}/**/*counter_collection.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and "ffn_fwd_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    return [(("true" in r["Kernel_Name"].split("<")[1].split(">")[0]), float(r["Counter_Value"])) for r in rows]
+    # template arguments <ring slots, TRAIN, packed activation code>: the second one tells the variant
+    return [(r["Kernel_Name"].split("<")[1].split(">")[0].split(",")[1].strip() == "true", float(r["Counter_Value"])) for r in rows]
 def durations():
     f = glob.glob("gpurun_out/ffntr_FETCH_SIZE/**/*kernel_trace.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if "ffn_fwd_kernel" in r["Kernel_Name"]]
@@ -49,7 +50,7 @@ for k, rows in enumerate((63488, 40960)):
                      "fused_algorithmic_MB": round(rows * 1024 / 1e6, 1)}}
 big = out["rows_63488"]["training"]
 out.update({
-    "kernel": "ffn_fwd_kernel<4, true> (training variant: y + h + xh + rstd out), 63,488 rows = the largest launch of the step, "
+    "kernel": "ffn_fwd_kernel<4, true, true> (the default: 256-row workgroups, packed activation code; training variant: y + h + xh + rstd out), 63,488 rows = the largest launch of the step, "
               "the rows evicted from every cache before each launch",
     "MB_per_launch": big["MB_per_launch"], "fetch_MB": big["fetch_MB"], "write_MB": big["write_MB"],
     "avg_launch_us": big["avg_us"], "fused_algorithmic_MB": big["fused_algorithmic_MB"],

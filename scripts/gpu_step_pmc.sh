@@ -40,10 +40,17 @@ for k, v in agg.items():
     rows.append((sum(t), k[:90], n, avg, fetch_mb, write_mb, g("SQ_LDS_BANK_CONFLICT"), g("SQ_LDS_IDX_ACTIVE"),
                  g("SQ_INSTS_VALU"), g("SQ_INSTS_MFMA"), g("SQ_VALU_MFMA_BUSY_CYCLES"), g("SQ_BUSY_CYCLES")))
 rows.sort(reverse=True)
-print("kernel,launches,avg_us,fetch_MB_per_launch,write_MB_per_launch,GBps,lds_conflict_frac,valu_per_mfma,mfma_busy_frac")
+# SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe busy cycles summed over every SIMD of the chip (32 per 32x32x16 bf16 MFMA,
+# MI355X_MICROARCH.md); the fraction of the chip's matrix-pipe time = that / (1024 SIMDs x launch duration x clock).  The clock is
+# taken as 2.4 GHz, so under power management (1.5-2.3 GHz inside the fused kernels) the column UNDERSTATES the busy fraction at
+# the clock the launch ran at by up to the same ratio; round 4's column divided by 4 x SQ_BUSY_CYCLES (one count per SE, not
+# per SIMD) and came out above 1.
+def mfma_busy(cycles, avg_us):
+    return cycles / (1024 * avg_us * 2400.0) if avg_us else 0.0
+print("kernel,launches,avg_us,fetch_MB_per_launch,write_MB_per_launch,GBps,lds_conflict_frac,valu_per_mfma,mfma_busy_frac_at_2p4GHz")
 for tot, k, n, avg, fm, wm, bc, ia, nv, nm, mb, busy in rows[:60]:
     gbps = (fm + wm) / avg * 1e3 if avg else 0
-    print(f"{k},{n},{avg:.1f},{fm:.1f},{wm:.1f},{gbps:.0f},{(bc / ia if ia else 0):.3f},{(nv / nm if nm else 0):.1f},{(mb / (4 * busy) if busy else 0):.3f}")
+    print(f"{k},{n},{avg:.1f},{fm:.1f},{wm:.1f},{gbps:.0f},{(bc / ia if ia else 0):.3f},{(nv / nm if nm else 0):.1f},{mfma_busy(mb, avg):.3f}")
 PY
 cut -c1-220 gpurun_out/${TAG}_summary.txt | head -64
 rm -rf gpurun_out/${TAG}a gpurun_out/${TAG}b gpurun_out/${TAG}c

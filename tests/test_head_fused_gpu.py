@@ -117,3 +117,91 @@ def test_head_lse_and_dlogits_on_the_compact_token_list(gpu_device, group):
     lg = ops.gemm(x, w, bias=b)
     lse_u, sc_u = ops.masked_ce_fwd(lg, tgt, wt, C_, group, tok_idx=idx)
     assert abs(float(sc[0] / sc[1]) - float(sc_u[0] / sc_u[1])) <= 2e-3 * abs(float(sc_u[0] / sc_u[1]))
+
+
+# ---- categorical sampling on the device (round 5): Gumbel arg-max, deepsvg/model/utils.py:75-79 -----------------------------
+def _seed(v):
+    return torch.tensor([v], dtype=torch.int64, device=DEV)
+
+
+def _agree_up_to_ties(got, noisy, what, max_frac=2e-3):
+    """got: int32 [n]; noisy: fp32 [n, C] perturbed logits of the restatement.  Where the kernel picked another class than the
+    restatement's arg-max the two candidates must be tied within the rounding of the two implementations' logarithms / sums"""
+    want = noisy.argmax(-1)
+    diff = (got.long() != want).nonzero().squeeze(1)
+    if diff.numel():
+        a = noisy[diff, got[diff].long()]
+        b = noisy[diff, want[diff]]
+        scale = noisy.abs().max().item()
+        assert (a - b).abs().max().item() <= 3e-5 * scale, what
+        assert diff.numel() <= max(2, int(max_frac * got.numel())), (what, diff.numel(), got.numel())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,group,C,temperature", [(1000, 1, 7, 1.0), (333, 11, 257, 1.0), (257, 11, 257, 1e-4), (4100, 3, 70, 0.3)])
+def test_sample_rows_is_the_gumbel_argmax_of_the_restated_noise(gpu_device, dtype, rows, group, C, temperature):
+    lg = _rand(rows, group * C + 5, seed=rows + group, scale=2.0, dtype=dtype)
+    sd = _seed(0x1234ABCD5678 + rows)
+    got = ops.sample_rows(lg, C, temperature, sd, 7001, group=group)
+    noise = R.gumbel_noise(sd, 7001, rows, group * C, DEV)
+    assert torch.isfinite(noise).all() and noise.min().item() > -2.9 and noise.max().item() < 17.4
+    noisy = (lg[:, :group * C].float() + temperature * noise).reshape(rows * group, C)
+    _agree_up_to_ties(got, noisy, "sample_rows")
+    assert int(got.min()) >= 0 and int(got.max()) < C
+    # another seed / another site: other draws (at a temperature where the noise decides)
+    if temperature >= 0.3:
+        assert not torch.equal(got, ops.sample_rows(lg, C, temperature, _seed(99), 7001, group=group))
+        assert not torch.equal(got, ops.sample_rows(lg, C, temperature, sd, 7002, group=group))
+    assert torch.equal(got, ops.sample_rows(lg, C, temperature, sd, 7001, group=group))
+
+
+def test_sample_rows_draws_follow_the_softmax(gpu_device):
+    """2^18 independent draws from ONE 7-class and one 257-class distribution at T = 1 and T = 0.5: Pearson chi-square against
+    softmax(logits / T) (statistic below the 1 - 1e-5 quantile), and independence of the draws of neighbouring rows"""
+    import math
+    n = 1 << 18
+    for C, T, seed in ((7, 1.0, 1), (7, 0.5, 2), (257, 1.0, 3)):
+        g = torch.Generator().manual_seed(seed)
+        row = torch.randn(C, generator=g) * 1.5
+        lg = row.to(DEV).repeat(n, 1).contiguous()
+        got = ops.sample_rows(lg, C, T, _seed(4242 + seed), 7001).long()
+        p = torch.softmax(row.double() / T, 0)
+        cnt = torch.bincount(got.cpu(), minlength=C).double()
+        keep = p * n >= 5          # (classes with an expected count below 5 are pooled)
+        exp = torch.cat([p[keep] * n, (p[~keep] * n).sum().view(1)])
+        obs = torch.cat([cnt[keep], cnt[~keep].sum().view(1)])
+        if exp[-1] < 1e-9:
+            exp, obs = exp[:-1], obs[:-1]
+        chi = ((obs - exp) ** 2 / exp).sum().item()
+        dof = exp.numel() - 1
+        # Wilson-Hilferty bound of the chi-square quantile at 1 - 1e-5 (z = 4.265)
+        bound = dof * (1 - 2 / (9 * dof) + 4.265 * math.sqrt(2 / (9 * dof))) ** 3
+        assert chi < bound, (C, T, chi, bound)
+        if C == 7:      # neighbouring rows: 7 x 7 contingency table, independence
+            a, b = got[0::2].cpu(), got[1::2].cpu()
+            tab = torch.zeros(C, C, dtype=torch.float64)
+            tab.view(-1).index_add_(0, a * C + b, torch.ones(a.numel(), dtype=torch.float64))
+            e = tab.sum(1, keepdim=True) * tab.sum(0, keepdim=True) / tab.sum()
+            ok = e >= 5
+            chi2 = (((tab - e) ** 2 / e)[ok]).sum().item()
+            d2 = (C - 1) * (C - 1)
+            assert chi2 < d2 * (1 - 2 / (9 * d2) + 4.265 * math.sqrt(2 / (9 * d2))) ** 3, (chi2, d2)
+
+
+@pytest.mark.parametrize("rows,group,temperature", [(300, 11, 1.0), (1500, 6, 0.2), (4099, 11, 1e-4)])
+def test_head_sample_draws_what_sample_rows_draws_on_the_dense_logits(gpu_device, rows, group, temperature):
+    """the fused head perturbs element (row, slot * C + c) with the same noise as sample_rows on the [rows, group * C] logit
+    matrix: identical samples (up to numerical ties of the two logit computations), the logits never stored"""
+    x, w, b, n_out, img = _setup(rows, group, seed=rows + 3)
+    sd = _seed(0x777 + rows)
+    got = ops.head_sample(x, img, b, n_out, C_, temperature, sd, 7002)
+    lg = R._head_logits(x, w, b, n_out)
+    noisy = (lg + temperature * R.gumbel_noise(sd, 7002, rows, n_out, DEV)).reshape(rows * group, C_)
+    _agree_up_to_ties(got, noisy, "head_sample")
+    dense = ops.sample_rows(lg.contiguous(), C_, temperature, sd, 7002, group=group)
+    assert (dense != got).float().mean().item() < 2e-3
+    if temperature <= 1e-4:     # the reference's default temperature: the arg-max wherever the two best logits are 1e-3 apart
+        top2 = lg.view(rows * group, C_).topk(2, -1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 2e-3
+        am = ops.head_argmax(x, img, b, n_out, C_)
+        assert torch.equal(got[clear], am[clear]) and clear.float().mean().item() > 0.9

@@ -667,6 +667,38 @@ def argmax_rows(logits2d, C, group=1):
     return logits2d[:, :group * C].float().reshape(n * group, C).argmax(-1).to(torch.int32)
 
 
+def gumbel_noise(seed, site, rows, n_cols, device):
+    """[rows, n_cols] fp32 Gumbel noise of the device sampler (dsvg_common.h dsvg_gumbel): element (row, col) takes word
+    (col & 3) of the hash of key = row * ceil(n_cols / 4) + (col >> 2); u = (word >> 8 + 1/2) 2^-24, g = -log(-log(u)).  The
+    bits are restated exactly; the two logarithms are torch's (the kernel's are v_log_f32: equal to ~1e-6 relative)"""
+    s = int(seed.reshape(-1)[0].item()) & 0xFFFFFFFFFFFFFFFF
+    s0 = _hash32_int((s & M32) ^ ((site * 0x9E3779B1) & M32))
+    s1 = _hash32_int(((s >> 32) + site * 0x85EBCA77 + 0x165667B1) & M32)
+    k4 = (n_cols + 3) // 4
+    row = torch.arange(rows, dtype=torch.int64, device=device).view(-1, 1)
+    col = torch.arange(n_cols, dtype=torch.int64, device=device).view(1, -1)
+    key = row * k4 + (col >> 2)
+    lo, hi = key & M32, (key >> 32) & M32
+    h = _hash32_t(lo ^ s0)
+    h = ((h ^ s1) + hi * 0x9E3779B1) & M32
+    w = torch.zeros_like(key)
+    for i in range(4):
+        w = torch.where((col & 3) == i, _drop_word(h, i), w)
+    u = ((w >> 8).to(torch.float32) + 0.5) * (1.0 / 16777216.0)
+    return -torch.log(-torch.log(u))
+
+
+def sample_rows(logits2d, C, temperature, seed, site, group=1):
+    n = logits2d.shape[0]
+    g = gumbel_noise(seed, site, n, group * C, logits2d.device)
+    noisy = logits2d[:, :group * C].float() + float(temperature) * g
+    return noisy.reshape(n * group, C).argmax(-1).to(torch.int32)
+
+
+def head_sample(x, packed, bias, n_out, C, temperature, seed, site):
+    return sample_rows(_head_logits(x, packed, bias, n_out), C, temperature, seed, site, n_out // C)
+
+
 def match_assign(cost, vis):
     """scipy's Hungarian solver, as the reference (deepsvg/model/model.py:341-348)"""
     from scipy.optimize import linear_sum_assignment
