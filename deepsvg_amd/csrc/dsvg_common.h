@@ -232,10 +232,11 @@ __device__ __forceinline__ float attn_drop_mult(const DropCtx& c, uint64_t row, 
 // g_c = -log(-log(u_c)) with independent uniforms u_c - the reference's _sample_categorical (deepsvg/model/utils.py:75-79:
 // torch.distributions.Categorical(logits = logits / T).sample()) without the softmax, the cumulative sum, or the dense logits.
 // u comes from the dropout counter hash: element (row, col) of a [rows, n_cols] logit matrix has key = row * k4 + (col >> 2)
-// (k4 = ceil(n_cols / 4)) and takes word (col & 3) of that key's hash: 24 bits -> u = (bits + 1/2) 2^-24 in (0, 1), so
-// g in [-2.85, 17.3] is always finite.  ONE hash per 4 consecutive columns + one multiply-fold per element.
+// (k4 = ceil(n_cols / 4)) and takes word (col & 3) of that key's hash: 23 bits -> u = (bits + 1/2) 2^-23 in (0, 1), so
+// g in [-2.81, 16.7] is always finite.  ONE hash per 4 consecutive columns + one multiply-fold per element.
 __device__ __forceinline__ float dsvg_gumbel_from_word(uint32_t w) {
-    const float u = ((float)(w >> 8) + 0.5f) * (1.f / 16777216.f);
+    // 23 bits: (bits + 1/2) is exact in fp32 (24 bits would round 2^24 - 1/2 up to 2^24: u = 1, g = +inf once in 2^24 draws)
+    const float u = ((float)(w >> 9) + 0.5f) * (1.f / 8388608.f);
     return -__logf(-__logf(u));
 }
 __device__ __forceinline__ float dsvg_gumbel(const DropCtx& c, uint64_t row, uint32_t k4, uint32_t col) {

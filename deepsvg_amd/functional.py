@@ -499,9 +499,13 @@ class GlobalCondFn(torch.autograd.Function):
             # the fused kernels take it as seq_add_ld)
             ow = [st.index[id(w)] for w, _b in pairs]
             ob = [st.index[id(b)] for _w, b in pairs]
-            w0, b0 = rt.w(pairs[0][0]), pairs[0][1].detach()
+            ws = [rt.w(w) for w, _b in pairs]
+            w0, b0 = ws[0], pairs[0][1].detach()
+            # (adjacent master offsets AND adjacent views of the low-precision image: rt.w may hand out a private copy)
             if (all(ow[i + 1][0] == ow[i][0] + ow[i][1] and ob[i + 1][0] == ob[i][0] + ob[i][1] for i in range(len(pairs) - 1))
-                    and w0.is_contiguous() and b0.is_contiguous()):
+                    and all(w.is_contiguous() for w in ws) and b0.is_contiguous()
+                    and all(ws[i + 1].data_ptr() == ws[i].data_ptr() + ws[i].numel() * ws[i].element_size()
+                            for i in range(len(ws) - 1))):
                 n_out, k_in = sum(w.shape[0] for w, _b in pairs), w0.shape[1]
                 gcat = ops.gemm(z, torch.as_strided(w0, (n_out, k_in), (k_in, 1)), bias=torch.as_strided(b0, (n_out,), (1,)))
                 d = w0.shape[0]

@@ -90,9 +90,14 @@ class SVGLoss(nn.Module):
             names.append("loss_visibility")
 
         cl = command_logits.reshape(-1, cfg.n_commands)      # (the head input's rows: all N G S, or the sequences that ran)
+        if head is not None:
+            # the targets' row order and the head input's row order must be the SAME one (both the stage's visible-first order,
+            # or both the caller's group order) - the plan guarantees it, checked here on every call rather than assumed
+            assert bool(head.get("vf")) == bool(head.get("x_vf")), \
+                f"targets in {'visible-first' if head.get('vf') else 'caller'} order, head rows in " \
+                f"{'visible-first' if head.get('x_vf') else 'caller'} order"
         if cl.shape[0] != cmd_tgt.numel():
-            # logits of a row prefix (the visible sequences that ran): only meaningful when the targets are in the SAME
-            # (visible-first) order as the head input's rows - the plan guarantees it, checked here rather than assumed
+            # logits of a row prefix (the visible sequences that ran): only meaningful in the visible-first order
             assert head is not None and head.get("vf") and head.get("x_vf"), \
                 "command logits cover a row prefix but the targets are not in the stage's visible-first order"
         cmd_t, cmd_wt = cmd_tgt.view(-1)[:cl.shape[0]], cmd_w.view(-1)[:cl.shape[0]]

@@ -327,6 +327,7 @@ class ParamStore:
                 view.copy_(p.data)
                 p.data = view
         self.flat, self.index, self.params, self.total = flat, index, params, total
+        self.generation = getattr(self, "generation", 0) + 1        # (TrainStep drops what it cached per parameter id)
         self.flat_lp = None
         self.gbuf = [None, None]
         self._lp_views = {}
@@ -936,6 +937,7 @@ class SVGTransformer(nn.Module):
         # gets it through `complete` (lazy)
         vf_heads = bool(live is not None and plan is not None and plan.get("loss") and plan["loss"].get("vf")
                         and match is None and lazy_args)
+        self._head_vf = vf_heads    # the head input's rows are in the stage's visible-first order (what SVGLoss checks)
         complete = None
         if live is not None and (n_run < n_seq or vf_heads):
             out_vf = out
@@ -1159,7 +1161,7 @@ class SVGTransformer(nn.Module):
                                          targets_r=pl.get("targets_r"),
                                          # row order of `targets`: the stage's visible-first order (then `x` / `cmd_logits`
                                          # may cover only the sequences that ran) or the caller's group order
-                                         vf=bool(pl.get("vf")), x_vf=self._cmd_logits_live is not None)
+                                         vf=bool(pl.get("vf")), x_vf=bool(getattr(self, "_head_vf", False)))
                 self.last_head_rows = (pl["n_live"], T_dec)
             if getattr(self, "_live", None) is not None:
                 # the live-prefix backward of the second decoder stage is exact under SVGLoss only: deepsvg_amd.SVGLoss

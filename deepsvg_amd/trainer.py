@@ -39,8 +39,9 @@ DEFAULT_WEIGHTS = {   # configs/deepsvg/default_icons.py:65-73 at step 0
 # six queues against 6.71 for the single-GPU step).  The variable only takes effect when it is set before the HIP runtime
 # initialises, so it is a LAUNCH setting of the training process (bench.py sets it; `GPU_MAX_HW_QUEUES=6 python train.py`),
 # not something this library changes behind the caller's back.
-HW_QUEUES_NOTE = ("data-parallel hipGraph step: set GPU_MAX_HW_QUEUES=6 in the environment before the process touches the GPU "
-                  "(with the default of 4 hardware queues the host cannot run ahead of the device, ~+7 % per step)")
+HW_QUEUES_NOTE = ("data-parallel hipGraph step: export GPU_MAX_HW_QUEUES=6 BEFORE the process makes its first device call - the "
+                  "runtime reads it once, when it initialises - (with the default of 4 hardware queues the host cannot run ahead "
+                  "of the device, ~+7 % per step)")
 
 _SHARED_STREAMS = {}
 
@@ -58,6 +59,19 @@ def _shared_stream(role, device):
     return st
 
 
+class _StreamWork:
+    """a collective issued under a side stream: wait() = the work's own wait under that stream, then the main stream waits for
+    the side stream (the cast back of a bf16 all-reduce runs there too)"""
+    def __init__(self, work, side, main):
+        self.work, self.side, self.main = work, side, main
+
+    def wait(self):
+        with torch.cuda.stream(self.side):
+            if self.work is not None:
+                self.work.wait()
+        self.main.wait_stream(self.side)
+
+
 class TrainStep:
     def __init__(self, model, loss_fn, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_clip=1.0,
                  weights=None, process_group=None, use_graph=False, exact_global_mean=True, force_ddp=False):
@@ -72,7 +86,9 @@ class TrainStep:
         self.use_graph = use_graph
         if self.ddp and use_graph and "GPU_MAX_HW_QUEUES" not in os.environ:
             import warnings
-            warnings.warn(HW_QUEUES_NOTE)
+            late = torch.cuda.is_available() and torch.cuda.is_initialized()
+            warnings.warn(HW_QUEUES_NOTE + (" - the HIP runtime of THIS process is already initialised: setting the variable now "
+                                            "has no effect, restart the process with it exported" if late else ""))
         self.exact_global_mean = exact_global_mean and self.ddp
         self._counts = None             # graph + DDP: the global loss counts, filled before every replay
         self._in_own_step = False       # True only while this trainer's captured / replayed step is being enqueued
@@ -94,6 +110,16 @@ class TrainStep:
         # them, was measurable on a one-rank RCCL group only - 6.90 against 6.85 ms/step for the single graph, a 15 ms/step
         # pathology with GPU_MAX_HW_QUEUES=8 - and is removed: with hipGraph the gradient goes out in one all-reduce behind
         # the graph; the eager path keeps the overlapped decoder bucket)
+        # round 5, both off by default until a run on more than one GPU exists (no hardware claim):
+        #  * DSVG_DDP_GRAPH_OVERLAP=1: hipGraph mode too sends the decoder bucket out early - the captured backward records an
+        #    EXTERNAL event (an event-record node of the graph) where the decoder's gradients are final, a side stream waits
+        #    for it behind every replay and issues that bucket's all-reduce while the encoder's backward is still running in
+        #    the graph; no collective is captured, every rank issues the same collectives in the same order
+        #  * DSVG_DDP_BF16=1: the gradient travels as bf16 (20.6 MB instead of 41.2 MB): cast, all-reduce, cast back
+        self.graph_overlap = os.environ.get("DSVG_DDP_GRAPH_OVERLAP", "0") == "1"
+        self.allreduce_bf16 = os.environ.get("DSVG_DDP_BF16", "0") == "1"
+        self._dec_event = None
+        self._bf16_stage = None
         self._pending = None
         self._pool = None
         self._gradless_slots, self._gradless_ids = [], set()
@@ -120,19 +146,64 @@ class TrainStep:
         self.step_count = torch.zeros(1, dtype=torch.int64, device=device)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=device)
         self.seed = model.seed_tensor(device)
+        self._reset_gradless()
         self._ready = True
+
+    def _reset_gradless(self):
+        """forget which parameters had no gradient (keyed by id(p) / views of the flat gradient buffer): called when the
+        device state is created and whenever the ParamStore re-flattened.  The cached graphs go too: each baked in the slot set
+        and the buffers of its capture"""
+        self._gradless_slots, self._gradless_ids = [], set()
+        self._store_generation = getattr(self.model.store, "generation", 0)
+        if self._graphs:
+            self._graphs.clear()
 
     def set_lr(self, lr):
         self._lr_value = float(lr)
         if self._ready:
             self.lr.fill_(self._lr_value)
 
+    class _Bf16Work:
+        """an all-reduce that travels as bf16: `view` (fp32 slice of the flat gradient) was cast into `stage`, which is being
+        reduced; wait() = wait for the collective, cast back"""
+        def __init__(self, view, stage, work):
+            self.view, self.stage, self.work = view, stage, work
+
+        def wait(self):
+            if self.work is not None:
+                self.work.wait()
+            self.view.copy_(self.stage)
+
+    def _all_reduce(self, view, async_op=False):
+        """sum-all-reduce of a slice of the flat fp32 gradient buffer (in place) -> a work object with wait(), or None"""
+        if not self.allreduce_bf16:
+            return dist.all_reduce(view, group=self.pg, async_op=async_op)
+        flat_g = self.model.store.grad_buffer(0)
+        if self._bf16_stage is None or self._bf16_stage.numel() != flat_g.numel() or self._bf16_stage.device != flat_g.device:
+            self._bf16_stage = torch.empty(flat_g.numel(), dtype=torch.bfloat16, device=flat_g.device)
+        off = view.storage_offset() - flat_g.storage_offset()
+        stage = self._bf16_stage[off:off + view.numel()]
+        stage.copy_(view)
+        w = TrainStep._Bf16Work(view, stage, dist.all_reduce(stage, group=self.pg, async_op=async_op))
+        if async_op:
+            return w
+        w.wait()
+        return None
+
     def _launch_decoder_bucket(self):
         """called from the backward pass when every decoder gradient is final (model.forward registers the hook)"""
         lo, hi = self.model.decoder_param_range()
         ops.flush_deferred()                # the queued split-K / LayerNorm reductions of the decoder's gradients
         flat_g = self.model.store.grad_buffer(0)
-        self._pending = (lo, dist.all_reduce(flat_g[lo:hi], group=self.pg, async_op=True))
+        self._pending = (lo, self._all_reduce(flat_g[lo:hi], async_op=True))
+
+    def _mark_decoder_ready(self):
+        """hipGraph + DDP with DSVG_DDP_GRAPH_OVERLAP: the same point of the backward pass inside a capture (or its warm-up
+        runs): flush the decoder's queued reductions and record the external event the side stream waits for"""
+        ops.flush_deferred()
+        if self._dec_event is None:
+            self._dec_event = torch.cuda.Event(external=True)
+        self._dec_event.record(torch.cuda.current_stream())
 
     def _reduce_counts(self, counts):
         """[n] local selected-element counts of the cross-entropies -> global counts / world, in ONE all-reduce"""
@@ -186,16 +257,20 @@ class TrainStep:
         # must contribute zero, not its gradient of an earlier step.  Which parameters those are is known from the previous
         # step (no shipped config has one); their slots are zeroed BEFORE backward, i.e. before an overlapped decoder
         # all-reduce can be in flight over them (and inside the captured part of a graph step)
-        for v in self._gradless_slots:
-            v.zero_()
         if self.ddp and self.overlap_allreduce and not self.use_graph:
             model._decoder_grads_ready = self._launch_decoder_bucket    # hooked onto the bottleneck output in forward
+        elif self.ddp and self.use_graph and self.graph_overlap and commands.is_cuda:
+            model._decoder_grads_ready = self._mark_decoder_ready
         # the ~130 partial-sum reductions of the parameter gradients (split-K slices, LayerNorm gamma/beta partials) are
         # queued during backward and performed by ONE launch per 64 right after it (ops.flush_deferred): nothing reads a
         # gradient in between (the overlapped decoder bucket flushes first, see _launch_decoder_bucket)
         model._defer_wgrad = self.defer_reductions
         try:
             out = model(commands, args, cd, ad, label=label, params={})
+            if getattr(model.store, "generation", 0) != getattr(self, "_store_generation", 0):
+                self._reset_gradless()  # the forward re-flattened the store: ids and gradient views cached here are stale
+            for v in self._gradless_slots:      # (before backward: nothing is in flight over the gradient buffer yet)
+                v.zero_()
             ld = self.loss_fn(out, label, weights=self.weights)
             ld["loss"].backward(self._seed_grad(ld["loss"]))      # (a static 1: autograd would launch a fill for its own)
         finally:
@@ -226,10 +301,10 @@ class TrainStep:
             if self._pending is not None:
                 # two buckets: the decoder half went out while the encoder's backward was running
                 lo, work = self._pending
-                dist.all_reduce(flat_g[:lo], group=self.pg)
+                self._all_reduce(flat_g[:lo])
                 work.wait()
             else:
-                dist.all_reduce(flat_g, group=self.pg)
+                self._all_reduce(flat_g)
         ops.sumsq(flat_g, out=self.gnorm_sq)
         ops.adamw_step_(model.store.flat, flat_g, self.m, self.v, self.lr, self.step_count,
                         beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay,
@@ -332,6 +407,18 @@ class TrainStep:
         self._note_layout(plan, commands)
         self._pending = None
         entry[0].replay()
+        if self.ddp and self.graph_overlap and self._dec_event is not None:
+            # behind the launch of the graph: a side stream waits for the event node inside it and sends the decoder bucket
+            # out while the graph's encoder backward is still running; _step_back reduces the rest behind the graph
+            if getattr(self, "_comm_stream", None) is None:
+                self._comm_stream = _shared_stream("comm", commands.device)
+            cs = self._comm_stream
+            cs.wait_event(self._dec_event)
+            lo, hi = model.decoder_param_range()
+            flat_g = model.store.grad_buffer(0)
+            with torch.cuda.stream(cs):
+                work = self._all_reduce(flat_g[lo:hi], async_op=True)
+            self._pending = (lo, _StreamWork(work, cs, main))
         if t_trace is not None:
             t_trace.append(time.perf_counter())
             t_trace.append(t_plan)

@@ -38,9 +38,11 @@ def _labels(cfg, n):
     return torch.randint(0, cfg.n_labels, (n,), generator=torch.Generator().manual_seed(3))
 
 
-def _worker(rank, world, port, ret, kind):
+def _worker(rank, world, port, ret, kind, bf16_reduce=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if bf16_reduce:
+        os.environ["DSVG_DDP_BF16"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from tests.conftest import install_emulated_ops
@@ -53,7 +55,7 @@ def _worker(rank, world, port, ret, kind):
         per = commands.shape[0] // world
         c, a = commands[rank * per:(rank + 1) * per], args[rank * per:(rank + 1) * per]
         ts = TrainStep(model, loss_fn, lr=1e-2)
-        assert ts.overlap_allreduce
+        assert ts.overlap_allreduce and ts.allreduce_bf16 == bf16_reduce
         ld = ts.step(c, a, label=label[rank * per:(rank + 1) * per] if label is not None else None)
         # the decoder bucket went out from inside the backward pass (hook on the bottleneck output's gradient)
         assert ts._pending is not None and 0 < ts._pending[0] < model.store.flat.numel()
@@ -99,6 +101,36 @@ def test_two_rank_gloo_step_equals_single_process_step(kind):
     for k in ("loss", "loss_cmd", "loss_args", "loss_visibility"):
         avg = 0.5 * (ld0[k] + ld1[k])
         assert abs(avg - ld[k].item()) <= 1e-5 * max(1.0, abs(ld[k].item())), (k, avg, ld[k].item())
+
+
+def test_two_rank_gloo_step_with_the_gradient_reduced_in_bf16():
+    """DSVG_DDP_BF16=1 (20.6 MB instead of 41.2 MB on the wire): both buckets - the decoder's, sent from inside
+    the backward pass, and the rest - are cast to bf16, summed, cast back.  The ranks still end bit-identical to each other; the
+    averaged gradient equals the single-process one to bf16 rounding (2^-8 relative per element, far less in the norm)"""
+    world = 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, ret, "hier", True), nprocs=world, join=True)
+    from tests.conftest import install_emulated_ops, restore_ops
+    saved = install_emulated_ops()
+    try:
+        from deepsvg_amd.trainer import TrainStep
+        from deepsvg_amd.synthetic import make_batch
+        cfg, model, loss_fn = _make("hier")
+        commands, args = make_batch(8, seed=21)
+        ts = TrainStep(model, loss_fn, lr=1e-2)
+        assert not ts.allreduce_bf16
+        ts.step(commands, args)
+        gn_ref, grad_ref = ts.grad_norm(), model.store.grad_buffer(0).clone()
+    finally:
+        restore_ops(saved)
+    f0, gn0, _, g0 = ret[0]
+    f1, gn1, _, g1 = ret[1]
+    assert torch.equal(f0, f1) and torch.equal(g0, g1), "ranks diverged"
+    assert abs(gn0 - gn_ref) <= 2e-3 * gn_ref, (gn0, gn_ref)
+    rel = ((g0 - grad_ref).norm() / grad_ref.norm()).item()
+    assert 1e-5 < rel < 4e-3, rel              # bf16 rounding is there (the switch took effect) and is all there is
+    assert (g0 - grad_ref).abs().max().item() <= 2.0 ** -7 * grad_ref.abs().max().item()
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -144,7 +144,7 @@ def test_sample_rows_is_the_gumbel_argmax_of_the_restated_noise(gpu_device, dtyp
     sd = _seed(0x1234ABCD5678 + rows)
     got = ops.sample_rows(lg, C, temperature, sd, 7001, group=group)
     noise = R.gumbel_noise(sd, 7001, rows, group * C, DEV)
-    assert torch.isfinite(noise).all() and noise.min().item() > -2.9 and noise.max().item() < 17.4
+    assert torch.isfinite(noise).all() and noise.min().item() > -2.82 and noise.max().item() < 16.7
     noisy = (lg[:, :group * C].float() + temperature * noise).reshape(rows * group, C)
     _agree_up_to_ties(got, noisy, "sample_rows")
     assert int(got.min()) >= 0 and int(got.max()) < C

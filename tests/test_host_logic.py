@@ -758,3 +758,55 @@ def test_split_k_policy_fills_the_chip():
     assert ops.split_k_for(768, 256, 63488, target_blocks=256) == 16
     assert ops.split_k_for(768, 256, 4096) == 16           # the 4096-row stages keep the one-workgroup-per-CU schedule
     assert ops.split_k_for(1024, 256, 4096) == 16 and ops.split_k_for(256, 256, 512) == 4
+
+
+def test_trainer_gradless_slots_follow_call_shapes_and_reflattening(emulated_ops):
+    """TrainStep zeroes the flat-gradient slots of parameters that received no gradient (the norm / AdamW / all-reduce read the
+    whole buffer).  The bookkeeping is per parameter id and per view of the gradient buffer: it must survive alternating call
+    shapes (with / without separate decoder-side tensors) and must be rebuilt when the ParamStore re-flattens (a re-assigned
+    .data): a poisoned slot is zero after every step, and the buffer equals a fresh trainer's on the same call."""
+    from deepsvg_amd.synthetic import make_batch
+    from deepsvg_amd.trainer import TrainStep
+    cfg = H.build_cfg("hier")
+    cfg.n_layers = cfg.n_layers_decode = 1
+
+    def build():
+        torch.manual_seed(0)
+        m = deepsvg_amd.SVGTransformer(cfg)
+        m.load_state_dict(H.weights_for(m, 11))
+        m.unused_probe = torch.nn.Parameter(torch.ones(24))       # never reached by forward: gradless in every call shape
+        return m.eval()
+    c, a = make_batch(3, seed=4)
+    shapes = [dict(), dict(commands_dec=c.clone(), args_dec=a.clone()), dict(), dict(commands_dec=c.clone(), args_dec=a.clone())]
+    model = build()
+    ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg), lr=0.0)
+
+    def slot(m):
+        st = m.store
+        o, n, _ = st.index[id(m.unused_probe)]
+        return st.grad_buffer(0)[o:o + n]
+    bufs = []
+    for k, kw in enumerate(shapes):
+        if k:
+            slot(model).fill_(7.0)                      # a stale gradient of "an earlier step"
+        ts.step(c, a, **kw)
+        assert id(model.unused_probe) in ts._gradless_ids
+        assert float(slot(model).abs().max()) == 0.0, k
+        bufs.append(model.store.grad_buffer(0).clone())
+    fresh = build()
+    tf = TrainStep(fresh, deepsvg_amd.SVGLoss(cfg), lr=0.0)
+    tf.step(c, a, **shapes[3])
+    assert torch.equal(bufs[3], fresh.store.grad_buffer(0))
+    assert torch.equal(bufs[1], bufs[3]) and torch.equal(bufs[0], bufs[2])
+    # re-flatten: the ids and views cached by the trainer are stale and must be dropped, not reused
+    gen, old_ids = model.store.generation, set(ts._gradless_ids)
+    p = dict(model.named_parameters())["encoder.encoder.layers.0.linear1.weight"]
+    p.data = p.data.clone()
+    ts.step(c, a)
+    assert model.store.generation == gen + 1 and ts._store_generation == gen + 1
+    slot(model).fill_(7.0)
+    ts.step(c, a)
+    assert float(slot(model).abs().max()) == 0.0
+    assert ts._gradless_ids == old_ids                  # (same parameter objects; the VIEWS were rebuilt on the new buffer)
+    assert all(v.data_ptr() >= model.store.grad_buffer(0).data_ptr() for v in ts._gradless_slots)
+    assert torch.equal(model.store.grad_buffer(0), bufs[0])

@@ -527,18 +527,30 @@ def test_data_parallel_step_over_rccl_one_rank(gpu_device):
         sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 321)
         batches = [tuple(t.to(DEV) for t in make_batch(64, seed=s_)) for s_ in (5, 6, 5)]
         runs = {}
+        # ddp_graph_overlap (round 5, DSVG_DDP_GRAPH_OVERLAP): the captured backward records an external event where the
+        # decoder's gradients are final, a side stream sends that bucket out behind every replay; ddp_bf16: the gradient
+        # travels as bf16.  One rank: the collectives are identities, the streams / events / casts are real
         for name, kw in (("plain", dict(use_graph=True)), ("ddp_graph", dict(use_graph=True, force_ddp=True)),
-                         ("ddp_eager", dict(use_graph=False, force_ddp=True))):
+                         ("ddp_eager", dict(use_graph=False, force_ddp=True)),
+                         ("ddp_graph_overlap", dict(use_graph=True, force_ddp=True)),
+                         ("ddp_bf16", dict(use_graph=True, force_ddp=True))):
             torch.manual_seed(7)
             model = _hip_model(cfg, sd, torch.bfloat16).train()
             ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=1e-3, **kw)
+            ts.graph_overlap = name == "ddp_graph_overlap"
+            ts.allreduce_bf16 = name == "ddp_bf16"
             assert ts.ddp == ("force_ddp" in kw)
             losses = [float(ts.step(c, a)["loss"]) for c, a in batches]
             torch.cuda.synchronize()
             runs[name] = (losses, model.store.flat.detach().clone(), ts.grad_norm())
             if name.startswith("ddp_graph"):
                 assert len(ts._graphs) >= 1 and ts._counts is not None
-        for name in ("ddp_graph", "ddp_eager"):
+            if name == "ddp_graph_overlap":
+                assert ts._dec_event is not None and ts._pending is not None and 0 < ts._pending[0] < model.store.flat.numel()
+        # the overlapped graph step computes exactly what the plain DDP graph step computes
+        assert runs["ddp_graph_overlap"][0] == runs["ddp_graph"][0]
+        assert torch.equal(runs["ddp_graph_overlap"][1], runs["ddp_graph"][1])
+        for name in ("ddp_graph", "ddp_eager", "ddp_graph_overlap", "ddp_bf16"):
             for a, b in zip(runs[name][0], runs["plain"][0]):
                 assert abs(a - b) <= 2e-2 * abs(b), (name, runs[name][0], runs["plain"][0])
             d = (runs[name][1] - runs["plain"][1]).abs()

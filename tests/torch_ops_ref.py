@@ -669,7 +669,7 @@ def argmax_rows(logits2d, C, group=1):
 
 def gumbel_noise(seed, site, rows, n_cols, device):
     """[rows, n_cols] fp32 Gumbel noise of the device sampler (dsvg_common.h dsvg_gumbel): element (row, col) takes word
-    (col & 3) of the hash of key = row * ceil(n_cols / 4) + (col >> 2); u = (word >> 8 + 1/2) 2^-24, g = -log(-log(u)).  The
+    (col & 3) of the hash of key = row * ceil(n_cols / 4) + (col >> 2); u = (word >> 9 + 1/2) 2^-23, g = -log(-log(u)).  The
     bits are restated exactly; the two logarithms are torch's (the kernel's are v_log_f32: equal to ~1e-6 relative)"""
     s = int(seed.reshape(-1)[0].item()) & 0xFFFFFFFFFFFFFFFF
     s0 = _hash32_int((s & M32) ^ ((site * 0x9E3779B1) & M32))
@@ -684,7 +684,7 @@ def gumbel_noise(seed, site, rows, n_cols, device):
     w = torch.zeros_like(key)
     for i in range(4):
         w = torch.where((col & 3) == i, _drop_word(h, i), w)
-    u = ((w >> 8).to(torch.float32) + 0.5) * (1.0 / 16777216.0)
+    u = ((w >> 9).to(torch.float32) + 0.5) * (1.0 / 8388608.0)
     return -torch.log(-torch.log(u))
 
 
