@@ -181,8 +181,10 @@ __device__ __forceinline__ uint32_t drop_group(const DropCtx& c, uint64_t g) {
 // word i (< 16) of a group / row hash: two 16-bit draws
 __device__ __forceinline__ uint32_t drop_word(uint32_t h, uint32_t i) {
     const uint32_t c = ((0x7feb352du * (i + 1u)) ^ (0x846ca68bu >> i)) | 1u;
-    const uint64_t p = (uint64_t)h * c;         // one v_mad_u64_u32 instead of v_mul_lo_u32 + v_mul_hi_u32
-    return (uint32_t)p ^ (uint32_t)(p >> 32);
+    // (NOT `uint64_t p = (uint64_t)h * c; lo ^ hi`: hipcc 7.0 turns that into v_mad_u64_u32, and with it the bf16 training step
+    // stopped being bit-reproducible from run to run on gfx950 - losses differing in the 6th digit, gradients by 5e-4, between
+    // two identical steps of one process; round 5, scripts/determinism_probe.py.  v_mul_lo_u32 + v_mul_hi_u32 is reproducible.)
+    return (h * c) ^ __umulhi(h, c);
 }
 // multiplier (0 or scale) for element idx
 __device__ __forceinline__ float drop_mult(const DropCtx& c, uint64_t idx) {

@@ -59,19 +59,6 @@ def _shared_stream(role, device):
     return st
 
 
-class _StreamWork:
-    """a collective issued under a side stream: wait() = the work's own wait under that stream, then the main stream waits for
-    the side stream (the cast back of a bf16 all-reduce runs there too)"""
-    def __init__(self, work, side, main):
-        self.work, self.side, self.main = work, side, main
-
-    def wait(self):
-        with torch.cuda.stream(self.side):
-            if self.work is not None:
-                self.work.wait()
-        self.main.wait_stream(self.side)
-
-
 class TrainStep:
     def __init__(self, model, loss_fn, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_clip=1.0,
                  weights=None, process_group=None, use_graph=False, exact_global_mean=True, force_ddp=False):
@@ -110,15 +97,14 @@ class TrainStep:
         # them, was measurable on a one-rank RCCL group only - 6.90 against 6.85 ms/step for the single graph, a 15 ms/step
         # pathology with GPU_MAX_HW_QUEUES=8 - and is removed: with hipGraph the gradient goes out in one all-reduce behind
         # the graph; the eager path keeps the overlapped decoder bucket)
-        # round 5, both off by default until a run on more than one GPU exists (no hardware claim):
-        #  * DSVG_DDP_GRAPH_OVERLAP=1: hipGraph mode too sends the decoder bucket out early - the captured backward records an
-        #    EXTERNAL event (an event-record node of the graph) where the decoder's gradients are final, a side stream waits
-        #    for it behind every replay and issues that bucket's all-reduce while the encoder's backward is still running in
-        #    the graph; no collective is captured, every rank issues the same collectives in the same order
-        #  * DSVG_DDP_BF16=1: the gradient travels as bf16 (20.6 MB instead of 41.2 MB): cast, all-reduce, cast back
-        self.graph_overlap = os.environ.get("DSVG_DDP_GRAPH_OVERLAP", "0") == "1"
+        # round 5: DSVG_DDP_BF16=1 - the gradient travels as bf16 (20.6 MB instead of 41.2 MB): cast, all-reduce,
+        # cast back; off by default until a run on more than one GPU exists (no hardware claim).
+        # (Tried and not possible on this stack: sending the decoder bucket out early in hipGraph mode too, from an EXTERNAL
+        # event-record node inside the captured backward that a side stream waits for behind every replay - HIP 7.0 answers
+        # hipEventRecordWithFlags(..., hipEventRecordExternal) on a capturing stream with "invalid argument", and
+        # torch.cuda.Event(external=True) refuses on ROCm for the same reason.  In graph mode the gradient therefore still goes
+        # out in one all-reduce behind the graph; the eager path keeps the overlapped decoder bucket.)
         self.allreduce_bf16 = os.environ.get("DSVG_DDP_BF16", "0") == "1"
-        self._dec_event = None
         self._bf16_stage = None
         self._pending = None
         self._pool = None
@@ -197,14 +183,6 @@ class TrainStep:
         flat_g = self.model.store.grad_buffer(0)
         self._pending = (lo, self._all_reduce(flat_g[lo:hi], async_op=True))
 
-    def _mark_decoder_ready(self):
-        """hipGraph + DDP with DSVG_DDP_GRAPH_OVERLAP: the same point of the backward pass inside a capture (or its warm-up
-        runs): flush the decoder's queued reductions and record the external event the side stream waits for"""
-        ops.flush_deferred()
-        if self._dec_event is None:
-            self._dec_event = torch.cuda.Event(external=True)
-        self._dec_event.record(torch.cuda.current_stream())
-
     def _reduce_counts(self, counts):
         """[n] local selected-element counts of the cross-entropies -> global counts / world, in ONE all-reduce"""
         if self._in_own_step and self.use_graph and self._counts is not None:
@@ -259,8 +237,6 @@ class TrainStep:
         # all-reduce can be in flight over them (and inside the captured part of a graph step)
         if self.ddp and self.overlap_allreduce and not self.use_graph:
             model._decoder_grads_ready = self._launch_decoder_bucket    # hooked onto the bottleneck output in forward
-        elif self.ddp and self.use_graph and self.graph_overlap and commands.is_cuda:
-            model._decoder_grads_ready = self._mark_decoder_ready
         # the ~130 partial-sum reductions of the parameter gradients (split-K slices, LayerNorm gamma/beta partials) are
         # queued during backward and performed by ONE launch per 64 right after it (ops.flush_deferred): nothing reads a
         # gradient in between (the overlapped decoder bucket flushes first, see _launch_decoder_bucket)
@@ -407,18 +383,6 @@ class TrainStep:
         self._note_layout(plan, commands)
         self._pending = None
         entry[0].replay()
-        if self.ddp and self.graph_overlap and self._dec_event is not None:
-            # behind the launch of the graph: a side stream waits for the event node inside it and sends the decoder bucket
-            # out while the graph's encoder backward is still running; _step_back reduces the rest behind the graph
-            if getattr(self, "_comm_stream", None) is None:
-                self._comm_stream = _shared_stream("comm", commands.device)
-            cs = self._comm_stream
-            cs.wait_event(self._dec_event)
-            lo, hi = model.decoder_param_range()
-            flat_g = model.store.grad_buffer(0)
-            with torch.cuda.stream(cs):
-                work = self._all_reduce(flat_g[lo:hi], async_op=True)
-            self._pending = (lo, _StreamWork(work, cs, main))
         if t_trace is not None:
             t_trace.append(time.perf_counter())
             t_trace.append(t_plan)
