@@ -27,6 +27,8 @@
 #include "../../include/dsvg.h"
 
 typedef short shortx4 __attribute__((ext_vector_type(4)));
+typedef float af2 __attribute__((ext_vector_type(2)));
+typedef unsigned short au16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -318,6 +320,32 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
 
     bf16x8 aof[16];         // the out_proj operand queue: every head shifts it by two fragments and appends its own
 
+    // ---- per-lane constants of the softmax + dropout code (round 5: the head loop is bound by VALU issue, 21-27 instructions
+    // per MFMA) ----------------------------------------------------------------------------------------------------------------
+    //   * the key mask as an additive bias (0 / -inf), the score scale with log2(e) folded in: p = exp2(fma(st, sc2, mb) - m),
+    //     one v_pk_fma + v_exp per element instead of bit test + multiply + select + compare + select + multiply + exp;
+    //   * the dropout words of the probabilities: the lane's 16 keys are 4 runs of 4 consecutive ones (8 q + 4 h2 .. + 3); counted
+    //     from the start of the lane's sequence, run q begins at ko = (8 q + 4 h2 - my_start) & 31 and takes the three words
+    //     ko >> 1 .. + 2 of the row hash.  Their multipliers do not depend on the head: 12 registers, set once.  A pair of
+    //     adjacent keys takes its two 16-bit draws from ONE word when ko is even, from the high half of one word and the low half
+    //     of the next when it is odd: v_alignbit_b32 by 0 / 16 bits; the mask is then applied to the PACKED bf16 pair as in
+    //     ffn_act_packed (two saturating 16-bit subtractions) - the same draws attn_drop_key hands the backward pass.
+    float mb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mb[r] = ((km >> rowmap(r, h2)) & 1u) ? 0.f : -INFINITY;
+    const float sc2 = scale * 1.4426950408889634f;
+    uint32_t cw[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t ko = (uint32_t)(8 * q + 4 * h2 - my_start) & 31u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t j = ((ko >> 1) + (uint32_t)i) & 15u;
+            cw[q][i] = ((0x7feb352du * (j + 1u)) ^ (0x846ca68bu >> j)) | 1u;
+        }
+    }
+    const uint32_t odd_sh = (my_start & 1) ? 16u : 0u;
+
     // ---- heads -----------------------------------------------------------------------------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();           // chunks 0 and 1 are in LDS
@@ -390,31 +418,53 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
                 if (n + 4 < 16) ring[n & 3] = ld(sl + (n + 4) * FRAG);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // softmax over the keys of the lane's query row
+            // softmax over the keys of the lane's query row (constants: see above the head loop)
             float p[16];
             float m = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = rowmap(r, h2);
-                p[r] = ((km >> key) & 1u) ? st[r] * scale : -INFINITY;
-                m = fmaxf(m, p[r]);
+            for (int r = 0; r < 16; r += 2) {
+                const af2 t = __builtin_elementwise_fma(af2{st[r], st[r + 1]}, af2{sc2, sc2}, af2{mb[r], mb[r + 1]});
+                p[r] = t[0]; p[r + 1] = t[1];
+                m = fmaxf(m, fmaxf(t[0], t[1]));
             }
             m = fmaxf(m, __shfl_xor(m, 32, 64));
+            m = fmaxf(m, -1e30f);                   // (an all-masked row: exp2(-inf + 1e30) = 0, never -inf - -inf)
             float l = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                p[r] = (p[r] == -INFINITY) ? 0.f : __expf(p[r] - m);
+                p[r] = __builtin_amdgcn_exp2f(p[r] - m);
                 l += p[r];
             }
             l += __shfl_xor(l, 32, 64);
-            const float inv = 1.f / l;
-            // dropout row of (sequence s, head h, query i) = (s H + h) Smax + i; i and the keys counted inside the sequence
-            const uint32_t hrow = attn_drop_row(dp, ((uint64_t)my_seq * AH + h) * Smax + (li - my_start), 0);
+            // normalisation and the dropout scale in one factor; padded query rows -> 0 (keeps the NaN of an all-masked row out
+            // of the MFMA)
+            const float cnorm = row_live ? dp.scale / l : 0.f;
+            uint32_t ppk[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = p[r] * inv * attn_drop_key(dp, hrow, (uint32_t)(rowmap(r, h2) - my_start));
+            for (int k = 0; k < 8; ++k) {
+                const af2 t = af2{p[2 * k], p[2 * k + 1]} * af2{cnorm, cnorm};
+                ppk[k] = f2bf_pk(t[0], t[1]);
+            }
             if (!row_live) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) p[r] = 0.f;     // padded query row: keep the NaNs of an all-masked row out of the MFMA
+                for (int k = 0; k < 8; ++k) ppk[k] = 0u;
+            }
+            if (dp.on) {
+                // dropout row of (sequence s, head h, query i) = (s H + h) Smax + i; i and the keys counted inside the sequence
+                const uint32_t hrow = attn_drop_row(dp, ((uint64_t)my_seq * AH + h) * Smax + (li - my_start), 0);
+                const au16x2 tp = {(unsigned short)dp.thresh, (unsigned short)dp.thresh}, z2 = {0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t w[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) w[i] = (hrow * cw[q][i]) ^ __umulhi(hrow, cw[q][i]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint32_t d = __builtin_amdgcn_alignbit(w[j + 1], w[j], odd_sh);
+                        const au16x2 rr = z2 - __builtin_elementwise_sub_sat(tp, __builtin_bit_cast(au16x2, d));
+                        ppk[2 * q + j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(au16x2, ppk[2 * q + j]), rr));
+                    }
+                }
             }
             // v^T + bias -> staging tile (token-major), read back transposed as the A operand of O^T = V^T P^T
             Frag8 vf[2];
@@ -438,8 +488,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 Frag8 pf;
-                pf.u = make_uint4(f2bf_pk(p[8 * ks + 0], p[8 * ks + 1]), f2bf_pk(p[8 * ks + 2], p[8 * ks + 3]),
-                                  f2bf_pk(p[8 * ks + 4], p[8 * ks + 5]), f2bf_pk(p[8 * ks + 6], p[8 * ks + 7]));
+                pf.u = make_uint4(ppk[4 * ks + 0], ppk[4 * ks + 1], ppk[4 * ks + 2], ppk[4 * ks + 3]);
                 ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag_swz(stg, ks, lane), pf.v, ot, 0, 0, 0);
             }
             // ot[r] = O[token li][dim rowmap(r, h2)] -> packed, appended to the out_proj operand queue (oldest head first)
@@ -574,6 +623,7 @@ extern "C" int dsvg_attn_block_fwd(const void* x, const void* packed_layer, cons
     DSVG_CHECK_ARG(S >= 1 && S <= 32, "attn_block_fwd: sequences of at most 32 tokens (got %d)", S);
     DSVG_CHECK_ARG(n_seq > 0 && rows > 0 && rows < (1ll << 31), "attn_block_fwd: bad sizes");
     DSVG_CHECK_ARG(!(drop_p > 0.f) || seed, "attn_block_fwd: dropout needs a seed");
+    DSVG_CHECK_ARG(!(drop_p > 0.5f), "attn_block_fwd: dropout rates up to 0.5 (the packed mask code)");
     const bool tiled = seq_off != nullptr;
     DSVG_CHECK_ARG(!tiled || (tile_first && !key_mask), "attn_block_fwd: the packed layout needs its tile list and no key mask");
     DSVG_CHECK_ARG(tiled || rows >= n_seq * S, "attn_block_fwd: %lld rows for %lld sequences of %d", (long long)rows,
