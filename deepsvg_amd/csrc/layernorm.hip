@@ -79,7 +79,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* __res
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const T* res,
                                                      T* dx, float* __restrict__ part,
-                                                     long long rows, int d) {
+                                                     long long rows, int d, T* dxm, float drop_p,
+                                                     const uint64_t* __restrict__ seed, uint32_t site) {
+    // dxm (optional): a second output, dx as stored (rounded to T) with the dropout mask of `site` replayed on it - what
+    // dsvg_drop_apply would make of dx: the consumer of this gradient (the FFN half of the layer below multiplies it with the
+    // mask of its residual dropout) then needs no launch of its own for it (round 5)
+    const DropCtx dmc = drop_make(dxm ? drop_p : 0.f, seed, site);
     // [wave][dg/db][d/4 + 1 vectors][4]: sized by d at launch (8 KiB at d = 256) so that LDS does not cap the number of
     // resident workgroups - the kernel hides HBM latency with waves, each wave walks its rows one after the other
     extern __shared__ float red_raw[];
@@ -140,6 +145,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* __res
                     for (int e = 0; e < 4; ++e) o[e] += rv[i][e];
                 }
                 Elem<T>::st4(dx + row * d + c, o);
+                if (dxm) {
+                    // element ids row * d + c + e (groups of 8: this lane's 4 are one half of a group)
+                    const uint64_t id4 = (uint64_t)row * (uint64_t)d + (uint64_t)c;
+                    float mm[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (dmc.on) {
+                        const uint32_t hg = drop_group(dmc, id4 >> 3);
+                        const uint32_t wb = ((uint32_t)id4 & 4u) ? 2u : 0u;
+                        const uint32_t w0 = drop_word(hg, wb), w1 = drop_word(hg, wb + 1u);
+                        mm[0] = (w0 & 0xffffu) < dmc.thresh ? 0.f : dmc.scale;
+                        mm[1] = (w0 >> 16) < dmc.thresh ? 0.f : dmc.scale;
+                        mm[2] = (w1 & 0xffffu) < dmc.thresh ? 0.f : dmc.scale;
+                        mm[3] = (w1 >> 16) < dmc.thresh ? 0.f : dmc.scale;
+                    }
+                    float om[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        T t;
+                        Elem<T>::st(&t, o[e]);                      // the value as dx holds it
+                        om[e] = Elem<T>::ld(&t) * mm[e];
+                    }
+                    Elem<T>::st4(dxm + row * d + c, om);
+                }
             }
         }
     }
@@ -200,10 +227,36 @@ extern "C" int64_t dsvg_layernorm_bwd_workspace_bytes(int64_t rows, int32_t d) {
     return (int64_t)ln_grid(rows) * 2 * d * (int64_t)sizeof(float);
 }
 
+static int ln_bwd_launch(int32_t dtype, const void* dy, const void* x, const float* mean, const float* rstd,
+                         const float* gamma, const void* res, void* dx, float* dgamma, float* dbeta,
+                         int32_t accumulate, int64_t rows, int32_t d, float* workspace,
+                         int64_t workspace_bytes, void* dx_masked, float drop_p, uint32_t drop_site, const void* seed,
+                         void* stream);
+
 extern "C" int dsvg_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* mean, const float* rstd,
                                   const float* gamma, const void* res, void* dx, float* dgamma, float* dbeta,
                                   int32_t accumulate, int64_t rows, int32_t d, float* workspace,
                                   int64_t workspace_bytes, void* stream) {
+    return ln_bwd_launch(dtype, dy, x, mean, rstd, gamma, res, dx, dgamma, dbeta, accumulate, rows, d, workspace,
+                         workspace_bytes, nullptr, 0.f, 0u, nullptr, stream);
+}
+
+extern "C" int dsvg_layernorm_bwd_masked(int32_t dtype, const void* dy, const void* x, const float* mean, const float* rstd,
+                                         const float* gamma, const void* res, void* dx, float* dgamma, float* dbeta,
+                                         int32_t accumulate, int64_t rows, int32_t d, float* workspace,
+                                         int64_t workspace_bytes, void* dx_masked, float drop_p, uint32_t drop_site,
+                                         const void* seed, void* stream) {
+    DSVG_CHECK_ARG(dx_masked && dx_masked != dx, "layernorm_bwd_masked: needs a second output buffer");
+    DSVG_CHECK_ARG(!(drop_p > 0.f) || seed, "layernorm_bwd_masked: dropout needs a seed");
+    return ln_bwd_launch(dtype, dy, x, mean, rstd, gamma, res, dx, dgamma, dbeta, accumulate, rows, d, workspace,
+                         workspace_bytes, dx_masked, drop_p, drop_site, seed, stream);
+}
+
+static int ln_bwd_launch(int32_t dtype, const void* dy, const void* x, const float* mean, const float* rstd,
+                         const float* gamma, const void* res, void* dx, float* dgamma, float* dbeta,
+                         int32_t accumulate, int64_t rows, int32_t d, float* workspace,
+                         int64_t workspace_bytes, void* dx_masked, float drop_p, uint32_t drop_site, const void* seed,
+                         void* stream) {
     DSVG_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
     DSVG_CHECK_ARG(rows > 0 && d > 0 && (d % 4) == 0 && d <= 1024, "layernorm_bwd: bad shape");
     DSVG_CHECK_ARG(workspace && workspace_bytes >= dsvg_layernorm_bwd_workspace_bytes(rows, d),
@@ -213,7 +266,7 @@ extern "C" int dsvg_layernorm_bwd(int32_t dtype, const void* dy, const void* x, 
     const size_t lds = (size_t)4 * 2 * (d / 4 + 1) * 4 * sizeof(float);
 #define DSVG_LNB(TT, NV) hipLaunchKernelGGL((ln_bwd_kernel<TT, NV>), dim3(nb), dim3(256), lds, st, (const TT*)dy, \
                                             (const TT*)x, mean, rstd, gamma, (const TT*)res, (TT*)dx, workspace,  \
-                                            (long long)rows, d)
+                                            (long long)rows, d, (TT*)dx_masked, drop_p, (const uint64_t*)seed, drop_site)
     if (dtype == DSVG_F32) { if (d <= 256) DSVG_LNB(float, 1); else if (d <= 512) DSVG_LNB(float, 2); else DSVG_LNB(float, 4); }
     else if (dtype == DSVG_BF16) { if (d <= 256) DSVG_LNB(bf16_t, 1); else if (d <= 512) DSVG_LNB(bf16_t, 2); else DSVG_LNB(bf16_t, 4); }
     else { dsvg_set_error("layernorm_bwd: bad dtype %d", dtype); return -1; }

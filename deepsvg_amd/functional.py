@@ -39,6 +39,9 @@ FFN_BWD_MASKED = os.environ.get("DSVG_FFN_BWD_MASKED", "0") != "0"
 GROUP_WGRAD = os.environ.get("DSVG_GROUP_WGRAD", "1") != "0"
 # the decoder layers' bcast_add_bwd also writes the masked copy of dx1 the attention half needs (one read of dx1, no drop_apply launch)
 BCAST_MASKED = os.environ.get("DSVG_BCAST_MASKED", "1") != "0"
+# round 5: the LayerNorm backward that produces a layer's incoming gradient also writes that gradient with the residual-dropout
+# mask of the layer BELOW replayed on it (what that layer's FFN half reads): 9 drop_apply launches per step less
+LN_BWD_MASKED = os.environ.get("DSVG_LN_BWD_MASKED", "1") != "0"
 # attention backward of the large stages with the out_proj backward inside (no `dao = dx1m @ Wo` GEMM launch)
 ATTN_BWD_OUTPROJ = os.environ.get("DSVG_ATTN_BWD_OUTPROJ", "1") != "0"
 # ... which only exists on the MFMA attention kernels: the library's A/B knobs that route attention to the VALU kernels
@@ -68,6 +71,10 @@ class Runtime:
         self.seed = seed          # int64[1] device tensor holding the dropout seed of this step
         self.store = store        # ParamStore or None
         self.training = training
+        # gradient tensor (data_ptr) -> (masked copy, p, site): handed from the launch that produced the gradient of a layer's
+        # OUTPUT to that layer's backward, which would otherwise re-read it once more only to apply the mask (LN_BWD_MASKED)
+        self.masked = {}
+        self.last_layer_gs = False
 
     def deferring(self):
         """context manager around launches whose reductions write parameter gradients"""
@@ -140,6 +147,25 @@ def _bgrad(rt, param, dy, *, drop_p=0.0, drop_site=0):
     with rt.deferring():
         ops.colsum(dy, out=out, drop_p=drop_p, drop_site=drop_site, seed=rt.seed)
     return out
+
+
+def _hand_masked(rt, dx, dxm, p, site):
+    """producer side of the masked-gradient hand-off"""
+    if len(rt.masked) > 8:          # (never consumed: a caller that differentiates something else; do not grow)
+        rt.masked.clear()
+    rt.masked[dx.data_ptr()] = (dxm, p, site)
+
+
+def _take_masked(rt, dx, p, site, rows=None):
+    """consumer side: the masked copy of `dx` for exactly this (p, site), or None"""
+    hit = rt.masked.pop(dx.data_ptr(), None)
+    if hit is None:
+        return None
+    dxm, hp, hsite = hit
+    n = dx.shape[0] if rows is None else rows
+    if hp != p or hsite != site or dxm.dtype != dx.dtype or dxm.shape[0] < n or dxm.shape[1:] != dx.shape[1:]:
+        return None
+    return dxm[:n]
 
 
 def _aligned2d(t, mult):
@@ -290,9 +316,11 @@ def _armed(live):
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rt, x, gamma, beta, eps, live=None):
+    def forward(ctx, rt, x, gamma, beta, eps, live=None, mask_below=None):
+        """mask_below = (dropout rate, site): the producer of `x` reads its incoming gradient through this mask"""
         y, mean, rstd = ops.layernorm_fwd(x, gamma.detach(), beta.detach(), eps)
         ctx.rt, ctx.live = rt, _live_rows(live, x.shape[0])
+        ctx.mask_below = mask_below if (LN_BWD_MASKED and mask_below is not None and rt.p(mask_below[0]) > 0) else None
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         return y
 
@@ -302,16 +330,23 @@ class LayerNormFn(torch.autograd.Function):
         x, mean, rstd, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
         live = _armed(ctx.live)
+        mk = None
+        if ctx.mask_below is not None:
+            mk = (rt.p(ctx.mask_below[0]), ctx.mask_below[1], rt.seed)
         with rt.deferring():
             if live is None:
-                dx, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, gamma.detach(),
-                                               dgamma=rt.grad_out(gamma), dbeta=rt.grad_out(beta))
+                out = ops.layernorm_bwd(dy, x, mean, rstd, gamma.detach(),
+                                        dgamma=rt.grad_out(gamma), dbeta=rt.grad_out(beta), masked=mk)
+                dx, dg, db = out[:3]
             else:
                 R = live[1]
                 dx = torch.empty_like(x)
-                _, dg, db = ops.layernorm_bwd(dy[:R], x[:R], mean[:R], rstd[:R], gamma.detach(), dx=dx[:R],
-                                              dgamma=rt.grad_out(gamma), dbeta=rt.grad_out(beta))
-        return None, dx, dg, db, None, None
+                out = ops.layernorm_bwd(dy[:R], x[:R], mean[:R], rstd[:R], gamma.detach(), dx=dx[:R],
+                                        dgamma=rt.grad_out(gamma), dbeta=rt.grad_out(beta), masked=mk)
+                dg, db = out[1:3]
+        if mk is not None:
+            _hand_masked(rt, dx, out[3], mk[0], mk[1])
+        return None, dx, dg, db, None, None, None
 
 
 # --------------------------------------------------------------------------------------------------
@@ -602,8 +637,11 @@ class LayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rt, x, key_mask, z, l, n_seq, S, n_heads, drop_rate, site0,
                 n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off=None, live=None,
-                tiles=None, causal=False):
+                tiles=None, causal=False, mask_below=None):
+        """mask_below: site of the FFN residual dropout of the layer that produced `x` (same rate), or None"""
         p = rt.p(drop_rate)
+        ctx.mask_below = mask_below if (LN_BWD_MASKED and mask_below is not None and p > 0) else None
+        rt.last_layer_gs = False
         d = x.shape[1]
         scale = float(d // n_heads) ** -0.5
         want_bwd = any(ctx.needs_input_grad)         # (grad mode itself is off inside Function.forward)
@@ -628,6 +666,7 @@ class LayerFn(torch.autograd.Function):
             else:
                 x2, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h = (res,) + (None,) * 10
             ctx.gs, ctx.ffn_fused, ctx.tiles, ctx.causal, ctx.live = True, False, None, False, None
+            rt.last_layer_gs = True     # (its backward kernel applies the mask itself: nobody upstream needs to prepare one)
             ctx.rt, ctx.n_seq, ctx.S, ctx.n_heads, ctx.p, ctx.site0, ctx.scale = rt, n_seq, S, n_heads, p, site0, scale
             ctx.save_for_backward(x, key_mask, z, l, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h,
                                   n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off)
@@ -743,6 +782,8 @@ class LayerFn(torch.autograd.Function):
         dx2 = dx2.contiguous()
         full_rows, n_seq_full = x.shape[0], n_seq
         live = _armed(ctx.live)
+        # the incoming gradient with this layer's FFN-residual mask already on it, if its producer made one (LN_BWD_MASKED)
+        dx2_masked = _take_masked(rt, dx2, p, s0 + 4, rows=(live[1] if live is not None else None)) if p > 0 else None
         if live is not None:            # backward over the live row prefix only (visible-first decoder order)
             n_seq, R = live
             (dx2, x, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h) = (
@@ -778,7 +819,7 @@ class LayerFn(torch.autograd.Function):
                 dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1, gb(win))
             return (None, dx, None, dz, None, None, None, None, None, None,
                     dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, None, None, None, None, None,
-                    None)
+                    None, None)
         # (round 3 measured, round 4 removed: the layer's four token-reducing weight-gradient GEMMs as one grouped launch at the
         # end of its backward pass - slower, each product right behind the launch that wrote its operand hits the memory-side
         # cache - and the same GEMMs queued onto a second stream beside the group stages - slower inside the step's hipGraph)
@@ -825,7 +866,7 @@ class LayerFn(torch.autograd.Function):
                     # were bit-identical and 13 % faster in isolation (93 -> 80 us at 63 k rows) but 0.4 % SLOWER inside the
                     # step, where dym already comes from the masked bcast_add_bwd and dpre is read back from the memory-side
                     # cache; removed.  profiles/r04_experimental_ffn_bwd_one.log, r04_experimental_ab.log)
-                    dym = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
+                    dym = dx2_masked if dx2_masked is not None else ops.drop_apply(dx2, p, s0 + 4, rt.seed)
                     if FFN_BWD_ORDER:
                         wgrad2(dym, hp)
                     dpre = ops.gemm(dym, w2p, b_kc=False, gate=hp, gate_scale=inv_keep)
@@ -854,7 +895,7 @@ class LayerFn(torch.autograd.Function):
             # ---- FFN: x2 = x1 + drop4(h W2^T + b2),  h = drop3(relu(xn2 W1^T + b1)) ----
             # the mask of the residual dropout is replayed ONCE into dx2m; the three consumers read plain data
             with ops.tag("ffn"):
-                dx2m = ops.drop_apply(dx2, p, s0 + 4, rt.seed)
+                dx2m = dx2_masked if dx2_masked is not None else ops.drop_apply(dx2, p, s0 + 4, rt.seed)
                 dw2, db2 = _wbgrad(rt, w2, b2, dx2m, h)
                 dh = ops.gemm(dx2m, rt.w(w2), b_kc=False, gate=h, gate_scale=inv_keep)   # (h > 0) <=> relu passed AND kept
                 dw1, db1 = _wbgrad(rt, w1, b1, dh, xn2)
@@ -912,14 +953,18 @@ class LayerFn(torch.autograd.Function):
         if live is not None:
             dx_full = torch.empty((full_rows, x.shape[1]), dtype=x.dtype, device=x.device)
             dx_out = dx_full[:x.shape[0]]
+        mk = (p, ctx.mask_below, rt.seed) if (ctx.mask_below is not None and p > 0) else None
         with rt.deferring():
-            dx, dn1w, dn1b = ops.layernorm_bwd(dxn1, x, mean1, rstd1, n1w.detach(), res=dx1, dx=dx_out,
-                                               dgamma=rt.grad_out(n1w), dbeta=rt.grad_out(n1b))
+            out = ops.layernorm_bwd(dxn1, x, mean1, rstd1, n1w.detach(), res=dx1, dx=dx_out,
+                                    dgamma=rt.grad_out(n1w), dbeta=rt.grad_out(n1b), masked=mk)
+            dx, dn1w, dn1b = out[:3]
         if live is not None:
             dx = dx_full
+        if mk is not None:
+            _hand_masked(rt, dx, out[3], p, ctx.mask_below)     # (the layer below takes it by dx's address)
         return (None, dx, None, dz, dl, None, None, None, None, None,
                 dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, dwg2, dbg2, None, None, None,
-                None)
+                None, None)
 
 
 # --------------------------------------------------------------------------------------------------

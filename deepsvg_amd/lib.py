@@ -56,6 +56,8 @@ SIGNATURES = {
     "dsvg_layernorm_fwd": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, c_i64, c_i32, c_f32, vp]),
     "dsvg_layernorm_bwd": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i32, c_i64, c_i32, vp, c_i64, vp]),
     "dsvg_layernorm_bwd_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "dsvg_layernorm_bwd_masked": (c_i32, [c_i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i32, c_i64, c_i32, vp, c_i64, vp, c_f32,
+                                          c_u32, vp, vp]),
     "dsvg_attention_fwd": (c_i32, [c_i32, vp, vp, vp, c_i64, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
     "dsvg_attention_bwd": (c_i32, [c_i32, vp, vp, vp, c_i64, vp, vp, vp, c_i64, c_i32, c_i32, c_f32, c_f32, c_u32, vp, vp]),
     "dsvg_attention_tiles": (c_i32, [vp, c_i64, c_i32, vp, vp, vp]),

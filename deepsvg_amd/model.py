@@ -697,8 +697,12 @@ class SVGTransformer(nn.Module):
                 L.linear_global.weight if (has_g and not hoisted) else None,
                 L.linear_global.bias if (has_g and not hoisted) else None,
                 L.linear_global2.weight if has_l else None, L.linear_global2.bias if has_l else None,
-                seq_off, live, tiles, causal)
-        return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps, live)
+                seq_off, live, tiles, causal,
+                # the layer below reads this layer's input gradient through the mask of ITS FFN residual dropout (site + 4)
+                (site + 8 * (i - 1) + 4) if i > 0 else None)
+        n = len(stack.layers)
+        return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps, live,
+                                    (cfg.dropout, site + 8 * (n - 1) + 4) if (n > 0 and not rt.last_layer_gs) else None)
 
     def make_plan(self, commands_enc, args_enc, commands_dec, want_grad=True, args_dec=None):
         """the data-dependent layout plan of one forward (see _plan), for callers that replay captured hipGraphs"""

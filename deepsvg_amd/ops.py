@@ -408,8 +408,9 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, *, res=None, dgamma=None, dbeta=None, accumulate=False, dx=None):
-    """returns dx = [res +] LN'(dy), dgamma, dbeta (fp32)."""
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, res=None, dgamma=None, dbeta=None, accumulate=False, dx=None, masked=None):
+    """returns dx = [res +] LN'(dy), dgamma, dbeta (fp32).  masked = (p, site, seed): -> (dx, dgamma, dbeta, dxm) with
+    dxm = drop_apply(dx, p, site, seed) from the same launch."""
     _chk(dy, x, mean, rstd, gamma, res, dgamma, dbeta)
     assert dy.is_contiguous() and x.is_contiguous() and dy.shape == x.shape
     rows, d = x.shape
@@ -424,6 +425,16 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, res=None, dgamma=None, dbeta=None
     L = _l.load()
     ws = _ws(L.dsvg_layernorm_bwd_workspace_bytes(rows, d), x.device)
     ev = _prof_begin()
+    if masked is not None:
+        mp, msite, mseed = masked
+        dxm = torch.empty_like(dx)
+        _l.check(L.dsvg_layernorm_bwd_masked(_dt(x), dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                             gamma.data_ptr(), _p(res), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                             int(accumulate), rows, d, ws.data_ptr(), ws.numel() * 4, dxm.data_ptr(),
+                                             float(mp), int(msite), _p(mseed) if mp > 0 else None, _stream()),
+                 "dsvg_layernorm_bwd_masked")
+        _prof_end(ev, 0.0, 0.0, dict(op="layernorm_bwd"))
+        return dx, dgamma, dbeta, dxm
     _l.check(L.dsvg_layernorm_bwd(_dt(x), dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                   gamma.data_ptr(), _p(res), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                   int(accumulate), rows, d, ws.data_ptr(), ws.numel() * 4, _stream()),

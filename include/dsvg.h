@@ -33,7 +33,7 @@ extern "C" {
  * dsvg_bcast_add_bwd / dsvg_loss_targets / dsvg_scatter_rows counted).  dsvg_version() returns the value the library was
  * built with; a caller compiled against another header must refuse to run (deepsvg_amd/lib.py does).
  * 3: dsvg_latent_chain_fwd / dsvg_latent_chain_bwd added.  4: seq_add_ld argument of dsvg_attn_block_fwd / dsvg_gs_layer_fwd.
- * 5 (round 5): dsvg_sample_rows / dsvg_head_sample added (categorical sampling on the device). */
+ * 5 (round 5): dsvg_sample_rows / dsvg_head_sample (categorical sampling on the device), dsvg_layernorm_bwd_masked added. */
 #define DSVG_ABI_VERSION 5
 
 const char* dsvg_last_error(void);
@@ -128,6 +128,13 @@ int dsvg_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float
                        float* dgamma, float* dbeta, int32_t accumulate, int64_t rows, int32_t d,
                        float* workspace, int64_t workspace_bytes, void* stream);
 int64_t dsvg_layernorm_bwd_workspace_bytes(int64_t rows, int32_t d);
+/* the same with a second output: dx_masked = dsvg_drop_apply(dx, drop_p, drop_site) - the stored (rounded) dx with that
+ * site's dropout mask replayed on it - from the same pass over the row (round 5: the FFN half of the layer below reads its
+ * incoming gradient only through the mask of its residual dropout, deepsvg/model/layers/improved_transformer.py:53,140) */
+int dsvg_layernorm_bwd_masked(int32_t dtype, const void* dy, const void* x, const float* mean, const float* rstd,
+                              const float* gamma, const void* res, void* dx, float* dgamma, float* dbeta,
+                              int32_t accumulate, int64_t rows, int32_t d, float* workspace, int64_t workspace_bytes,
+                              void* dx_masked, float drop_p, uint32_t drop_site, const void* seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head self-attention core on packed QKV (after the in-projection):

@@ -322,6 +322,13 @@ def test_layernorm(gpu_device, dtype, rows, d):
     r2 = res.clone()
     ops.layernorm_bwd(dy, x, mean, rstd, gamma, res=r2, dx=r2)
     _close(r2, dxr, tol, "ln dx in place")
+    # second output (round 5): dx with a dropout mask replayed on it - bit-identical to drop_apply on the stored dx, the
+    # other three results bit-identical to the plain launch
+    seed = _seed_tensor(0x77AA55)
+    for p_ in (0.1, 0.0):
+        dx2, dg2, db2, dxm = ops.layernorm_bwd(dy, x, mean, rstd, gamma, res=res, masked=(p_, 417, seed))
+        assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
+        assert torch.equal(dxm, ops.drop_apply(dx, p_, 417, seed) if p_ > 0 else dx)
 
 
 def _key_masks(n_seq, S, seed, all_valid=False):

@@ -175,7 +175,10 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y.to(x.dtype), mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, *, res=None, dgamma=None, dbeta=None, accumulate=False, dx=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, res=None, dgamma=None, dbeta=None, accumulate=False, dx=None, masked=None):
+    if masked is not None:
+        o, dg, db = layernorm_bwd(dy, x, mean, rstd, gamma, res=res, dgamma=dgamma, dbeta=dbeta, accumulate=accumulate, dx=dx)
+        return o, dg, db, drop_apply(o, masked[0], masked[1], masked[2])
     dyf, xf = _f(dy), _f(x)
     xh = (xf - mean.unsqueeze(-1)) * rstd.unsqueeze(-1)
     gd = dyf * gamma
