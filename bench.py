@@ -806,9 +806,8 @@ def main():
                     roofline["traffic_collected_at"] = {"commit": t.get("commit"), "ffn_fused_hip_code_sha256_16": t.get("ffn_fused_hip_code_sha256_16"),
                                                         "current_ffn_fused_hip_code_sha256_16": sha,
                                                         "kernel_source_unchanged": t.get("ffn_fused_hip_code_sha256_16") == sha}
-            gcsv = os.path.join(ROOT, "profiles", "r04_graph_kernel_stats.csv")
-            if not os.path.exists(gcsv):
-                gcsv = os.path.join(ROOT, "profiles", "r03_graph_kernel_stats.csv")
+            gcsv = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_graph_kernel_stats.csv") for r in (5, 4, 3))
+                         if os.path.exists(q)), "")       # the newest committed trace of the replayed graph
             if os.path.exists(gcsv) and fused_fwd is not None:
                 for line in open(gcsv):
                     if "ffn_fwd_kernel" in line:
