@@ -153,7 +153,7 @@ def _hand_masked(rt, dx, dxm, p, site):
     """producer side of the masked-gradient hand-off"""
     if len(rt.masked) > 8:          # (never consumed: a caller that differentiates something else; do not grow)
         rt.masked.clear()
-    rt.masked[dx.data_ptr()] = (dxm, p, site)
+    rt.masked[dx.data_ptr()] = (dxm, p, site, dx._version)
 
 
 def _take_masked(rt, dx, p, site, rows=None):
@@ -161,9 +161,12 @@ def _take_masked(rt, dx, p, site, rows=None):
     hit = rt.masked.pop(dx.data_ptr(), None)
     if hit is None:
         return None
-    dxm, hp, hsite = hit
+    dxm, hp, hsite, ver = hit
     n = dx.shape[0] if rows is None else rows
-    if hp != p or hsite != site or dxm.dtype != dx.dtype or dxm.shape[0] < n or dxm.shape[1:] != dx.shape[1:]:
+    # (an in-place change of the gradient since the hand-off - autograd accumulating a second contribution into the same buffer -
+    # shows in the version counter: the masked copy would be stale)
+    if (hp != p or hsite != site or dxm.dtype != dx.dtype or dxm.shape[0] < n or dxm.shape[1:] != dx.shape[1:]
+            or dx._version != ver):
         return None
     return dxm[:n]
 

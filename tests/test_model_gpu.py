@@ -610,6 +610,41 @@ def test_training_step_is_bit_reproducible(gpu_device):
         assert torch.equal(grad, runs[0][1])
 
 
+def test_masked_gradient_hand_off_is_taken_and_changes_nothing(gpu_device):
+    """functional.LN_BWD_MASKED (round 5): the LayerNorm backward that produces a layer's incoming gradient also writes it with
+    the consumer's residual-dropout mask replayed (bit-identical to drop_apply), the consumer takes it by the gradient's address.
+    With the switch on the step launches fewer drop_apply kernels and produces bit-identical losses and gradients."""
+    import deepsvg_amd.functional as Fn
+    from deepsvg_amd.trainer import TrainStep
+    cfg = H.build_cfg("hier")
+    cfg.dropout = 0.1
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 31)
+    c, a = (t.to(DEV) for t in make_batch(320, seed=9))
+    runs = {}
+    saved = Fn.LN_BWD_MASKED
+    try:
+        for on in (False, True):
+            Fn.LN_BWD_MASKED = on
+            torch.manual_seed(5)
+            model = _hip_model(cfg, sd, torch.bfloat16).train()
+            ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=0.0, use_graph=False)
+            ops.PROFILE.clear()
+            ops.PROFILE_ON = True
+            try:
+                ld = ts.step(c, a)
+                torch.cuda.synchronize()
+            finally:
+                ops.PROFILE_ON = False
+            n_drop = sum(1 for r in ops.PROFILE if r[5].get("op") == "drop_apply")
+            ops.PROFILE.clear()
+            runs[on] = ({k: float(v) for k, v in ld.items()}, model.store.grad_buffer(0).detach().clone(), n_drop)
+    finally:
+        Fn.LN_BWD_MASKED = saved
+        ops.PROFILE_ON = False
+    assert runs[True][0] == runs[False][0] and torch.equal(runs[True][1], runs[False][1])
+    assert runs[True][2] <= runs[False][2] - 6, (runs[True][2], runs[False][2])       # 8 large layers: 6+ hand-offs taken
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_self_matching_training_step(gpu_device, use_graph):
     """HierarchicalSelfMatching through TrainStep (costs + exhaustive assignment + row permutation have no host round
