@@ -280,13 +280,24 @@ def secondary_legs(device):
     m = model_for(cfg).eval()
     z = (torch.randn(8192, 1, 1, cfg.dim_z, generator=torch.Generator().manual_seed(0)) * 0.3).to(device)
     sec = timed(lambda: m.greedy_sample(z=z, concat_groups=False, temperature=0), 3)
-    out["c5_one_shot_decode"] = {"ms": round(sec * 1e3, 2), "icons_per_s": round(8192 / sec, 1),
+    # algorithmic FLOPs of the one-shot decode (MACs x 2): group decoder on 8192 x 8 rows, path decoder on 8192 x 8 x S rows -
+    # per token-layer in_proj 3 d^2 + scores / context 2 S d + out_proj d^2 + FFN 2 d ff - plus the heads (d x (n_args x args_dim
+    # + n_commands)); the fused head never stores its logits, so its FLOPs are all the traffic it has
+    d_, ff_, S_ = cfg.d_model, cfg.dim_feedforward, cfg.max_seq_len + 1
+    per_tok_layer = 2.0 * (4 * d_ * d_ + 2 * d_ * ff_)
+    rows2, rows1 = 8192 * cfg.max_num_groups * S_, 8192 * cfg.max_num_groups
+    flop_c5 = (cfg.n_layers_decode * (rows2 * (per_tok_layer + 2.0 * 2 * S_ * d_) + rows1 * (per_tok_layer + 2.0 * 2 * cfg.max_num_groups * d_))
+               + rows2 * 2.0 * d_ * (cfg.n_args * (cfg.args_dim + 1) + cfg.n_commands))
+    def c5_roof(sec_):
+        return {"bound": "mfma", "algorithmic_TFLOP": round(flop_c5 / 1e12, 2), "achieved_TFLOPs": round(flop_c5 / sec_ / 1e12, 1),
+                "peak_TFLOPs": 2500.0, "frac": round(flop_c5 / sec_ / 2.5e15, 4)}
+    out["c5_one_shot_decode"] = {"ms": round(sec * 1e3, 2), "icons_per_s": round(8192 / sec, 1), "roofline": c5_roof(sec),
                                  "workload": "hierarchical_ordered greedy_sample from 8192 latents, temperature 0 (head + arg-max fused)"}
     # the reference's default temperature (1e-4, deepsvg/model/model.py:414): the categorical draw as a Gumbel arg-max fused
     # into the argument head - the 8192 x 8 x 30 x 11 x 257 logits (23 GB in fp32) are never built
     sec = timed(lambda: m.greedy_sample(z=z, concat_groups=False), 3)
     out["c5_one_shot_decode_default_temperature"] = {
-        "ms": round(sec * 1e3, 2), "icons_per_s": round(8192 / sec, 1),
+        "ms": round(sec * 1e3, 2), "icons_per_s": round(8192 / sec, 1), "roofline": c5_roof(sec),
         "workload": "the same at temperature 1e-4 (reference default): categorical draw on the device (head + Gumbel arg-max fused)"}
     del m
     cfg = C.Sketchformer()
