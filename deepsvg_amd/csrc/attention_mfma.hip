@@ -16,6 +16,7 @@
 // (attention.hip, kept for fp32 and for the 8-token group stages); the kernel is HBM-bound.
 // Replaces deepsvg/model/layers/functional.py:168,197-248 and its autograd backward.
 #include "dsvg_common.h"
+#include "pack_images.h"
 #include "../../include/dsvg.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -530,19 +531,7 @@ int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const int
 // dO^T = Wo^T-columns x dx1m^T per head (offs[layer][1] = element offset of out_proj.weight [256, 256] in `flat`)
 __global__ __launch_bounds__(256) void attn_pack_bwd_kernel(const float* __restrict__ flat, const int64_t* __restrict__ offs,
                                                             int n_layers, bf16_t* __restrict__ img) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;       // one thread per 16-byte lane slot
-    if (gid >= (long long)n_layers * 128 * 64) return;
-    const int layer = (int)(gid / (128 * 64));
-    const int s = (int)(gid % (128 * 64));
-    const int l = s & 63, f = s >> 6, hh = f >> 4, ks = f & 15;
-    const float* Wo = flat + offs[layer * 2 + 1];
-    uint32_t w[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int k = 16 * ks + 8 * (l >> 5) + 2 * e;
-        w[e] = f2bf_pk(Wo[(size_t)k * 256 + 32 * hh + (l & 31)], Wo[(size_t)(k + 1) * 256 + 32 * hh + (l & 31)]);
-    }
-    *reinterpret_cast<uint4*>(img + gid * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    dsvg_pack::attn_bwd_slot((long long)blockIdx.x * 256 + threadIdx.x, flat, offs, n_layers, img);      // (pack_images.h)
 }
 int dsvg_attn_pack_bwd_launch(const float* flat, const int64_t* offs, int n_layers, void* img, hipStream_t st) {
     const long long n = (long long)n_layers * 128 * 64;

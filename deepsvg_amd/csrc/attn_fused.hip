@@ -24,6 +24,7 @@
 //     the stores of a stage are held in registers and issued right behind the next ring synchronisation (vmcnt counts
 //     stores, out of order with respect to loads: the only safe DMA wait is vmcnt(0), so stores need a stage to drain).
 #include "fused_common.h"
+#include "pack_images.h"
 #include "../../include/dsvg.h"
 
 typedef short shortx4 __attribute__((ext_vector_type(4)));
@@ -43,41 +44,17 @@ constexpr int VLD = 32;                 // row stride (elements) of the per-wave
 constexpr int SMALL_LDS = (768 + 256 + 256 + 256) * 4;      // in_proj bias | out_proj bias | gamma | beta
 constexpr int STAGE_LDS = TILES_PER_WG * 32 * VLD * 2;
 
-__host__ __device__ inline int rowmap(int r, int h2) { return (r & 3) + 8 * (r >> 2) + 4 * h2; }
+using dsvg_pack::rowmap;
+static_assert(dsvg_pack::ATTN_IMG_FRAGS == IMG_FRAGS && dsvg_pack::D == AD && dsvg_pack::H == AH, "pack_images.h restates these");
 // byte offset of chunk c in the layer image; chunks 2 h + 1 (v of head h) have 16 fragments, all others 32
 __device__ __forceinline__ int chunk_off(int c) {
     return c < 16 ? ((c >> 1) * 48 + (c & 1) * 32) * FRAG : (384 + (c - 16) * 32) * FRAG;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// weight packing: fp32 master parameters -> bf16 fragment images.  offs[layer][0..1] = element offsets of in_proj_weight
-// [768, 256] and out_proj.weight [256, 256] in `flat`.  Fragment f of a layer, lane l = (i = l & 31, half = l >> 5), slot e:
-//   f = 48 h + 16 sel + ks  (sel = 0 q, 1 k, 2 v):  Win[256 sel + 32 h + i][16 ks + 8 half + e]
-//   f = 384 + 16 t + 2 h + ks2:                      Wo[32 t + i][32 h + rowmap(8 ks2 + e, half)]
-// ---------------------------------------------------------------------------------------------------------------------
+// weight packing (dsvg_attn_pack): fp32 master parameters -> bf16 fragment images, body and layout in pack_images.h
 __global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict__ flat, const int64_t* __restrict__ offs,
                                                         int n_layers, bf16_t* __restrict__ img) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (long long)n_layers * IMG_FRAGS * 64) return;
-    const int layer = (int)(gid / (IMG_FRAGS * 64));
-    const int s = (int)(gid % (IMG_FRAGS * 64));
-    const int l = s & 63, f = s >> 6;
-    const int i = l & 31, half = l >> 5;
-    float v[8];
-    if (f < 384) {
-        const float* Win = flat + offs[layer * 2 + 0];
-        const int h = f / 48, g = f % 48, sel = g >> 4, ks = g & 15;
-        const float* row = Win + (size_t)(256 * sel + 32 * h + i) * AD + 16 * ks + 8 * half;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = row[e];
-    } else {
-        const float* Wo = flat + offs[layer * 2 + 1];
-        const int g = f - 384, t = g >> 4, h = (g & 15) >> 1, ks2 = g & 1;
-        const float* row = Wo + (size_t)(32 * t + i) * AD + 32 * h;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = row[rowmap(8 * ks2 + e, half)];
-    }
-    *reinterpret_cast<uint4*>(img + ((size_t)layer * IMG_FRAGS + f) * 512 + l * 8) = pack8(v);
+    dsvg_pack::attn_slot((long long)blockIdx.x * 256 + threadIdx.x, flat, offs, n_layers, img);
 }
 
 // A[i = column c (lane & 31)][K slot e] = img[row rowmap(8 ks + e, lane >> 5)][col0 + c]: two hardware-transposed 4 x 16

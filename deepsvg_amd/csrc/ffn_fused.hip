@@ -29,6 +29,7 @@
 //     (lane >> 5) + r); the backward pass never re-draws them, it reads the gate off the stored h (h > 0 <=> the unit
 //     passed the ReLU and was kept).  The residual site uses the library's standard draws (dsvg_drop_apply replays it).
 #include "fused_common.h"
+#include "pack_images.h"
 #include "../../include/dsvg.h"
 
 namespace {
@@ -41,97 +42,27 @@ constexpr int FWD_CHUNK = 32 * FRAG;    // [W1 chunk: 16 fragments | W2 chunk: 1
 constexpr int BWD_CHUNK = 48 * FRAG;    // [W1 chunk | W2^T chunk | W1^T chunk]
 constexpr int TOK_PER_WG = 256;
 
-// hidden unit (inside its chunk) that K slot (ks2, half, e) of GEMM 2 carries = the unit accumulator register
-// r = 8 ks2 + e of GEMM 1's transposed tile holds in lane half `half`
-__host__ __device__ inline int hidden_of(int ks2, int half, int e) { return (e & 3) + 8 * (2 * ks2 + (e >> 2)) + 4 * half; }
+using dsvg_pack::hidden_of;         // hidden unit (inside its chunk) that K slot (ks2, half, e) of GEMM 2 carries
+using dsvg_pack::frag_pos;          // position of hidden unit j in the fragment-ordered h / dpre matrices (an involution)
+static_assert(dsvg_pack::D == FD && dsvg_pack::F == FF && dsvg_pack::FFN_CH == CH && dsvg_pack::FFN_FWD_CHUNK == FWD_CHUNK &&
+              dsvg_pack::FFN_BWD_CHUNK == BWD_CHUNK && dsvg_pack::FRAG_BYTES == FRAG, "pack_images.h restates these");
 
 // ---------------------------------------------------------------------------------------------------------------------
-// weight packing: fp32 master parameters -> bf16 fragment-major chunk images (one thread per lane slot of 8 elements).
-// The affine part of the LayerNorm in front of linear1 is folded into it:
-//     linear1(gamma * xh + beta) = (W1 diag(gamma)) xh + (b1 + W1 beta) = W1' xh + b1'
-// so the kernels only normalise (xh = (x - mean) * rstd) and never touch gamma / beta; the backward kernel gets the
-// gradient with respect to xh straight from W1'^T, and dW1 / dgamma / dbeta are finished from G = dpre^T xh and
-// db1 = sum_t dpre by dsvg_ffn_wgrad_finish (dW1 = G diag(gamma) + db1 beta^T, dgamma = colsum(W1 * G), dbeta = W1^T db1).
-// offs[layer][0..4] = element offsets of linear1.weight, linear1.bias, linear2.weight, norm.weight, norm.bias in `flat`.
+// weight packing: fp32 master parameters -> bf16 fragment-major chunk images (one thread per lane slot of 8 elements),
+// the LayerNorm affine folded into linear1 (W1' = W1 diag(gamma), b1' = b1 + W1 beta): bodies in pack_images.h, which the
+// one-launch refresh of a training step (dsvg_pack_images) shares
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__ flat, const int64_t* __restrict__ offs,
                                                        int n_layers, bf16_t* __restrict__ fwd, bf16_t* __restrict__ bwd) {
-    const int slots_per_layer = NCH * 80 * 64;        // 32 forward + 48 backward fragments per chunk
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (long long)n_layers * slots_per_layer) return;
-    const int layer = (int)(gid / slots_per_layer);
-    int s = (int)(gid % slots_per_layer);
-    const int l = s & 63; s >>= 6;
-    const int f = s % 80, c = s / 80;
-    const int i = l & 31, half = l >> 5;
-    const float* W1 = flat + offs[layer * 5 + 0];     // [512, 256] row-major
-    const float* W2 = flat + offs[layer * 5 + 2];     // [256, 512] row-major
-    const float* ga = flat + offs[layer * 5 + 3];
-    float v[8];
-    bf16_t* dst;
-    if (f < 32) {
-        dst = fwd + ((size_t)layer * NCH + c) * (FWD_CHUNK / 2) + (size_t)f * 512 + l * 8;
-        if (f < 16) {               // W1' chunk, K step f: A[i = hidden 32 c + i][k = 16 f + 8 half + e]
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const int k = 16 * f + 8 * half + e; v[e] = W1[(size_t)(CH * c + i) * FD + k] * ga[k]; }
-        } else {                    // W2 chunk, output tile t, K step ks2: A[i = out 32 t + i][k -> hidden_of(ks2, half, e)]
-            const int t = (f - 16) >> 1, ks2 = (f - 16) & 1;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = W2[(size_t)(32 * t + i) * FF + CH * c + hidden_of(ks2, half, e)];
-        }
-    } else {
-        const int g = f - 32;
-        dst = bwd + ((size_t)layer * NCH + c) * (BWD_CHUNK / 2) + (size_t)g * 512 + l * 8;
-        if (g < 16) {               // W1' chunk again (recomputation of the hidden tile)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const int k = 16 * g + 8 * half + e; v[e] = W1[(size_t)(CH * c + i) * FD + k] * ga[k]; }
-        } else if (g < 32) {        // W2^T chunk, K step ks over the 256 outputs: A[i = hidden 32 c + i][k = out 16 ks + 8 half + e]
-            const int ks = g - 16;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = W2[(size_t)(16 * ks + 8 * half + e) * FF + CH * c + i];
-        } else {                    // W1'^T chunk, d tile t, K step ks2 over the chunk's hidden units (same K order as W2's)
-            const int t = (g - 32) >> 1, ks2 = (g - 32) & 1;
-            const float gd = ga[32 * t + i];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = W1[(size_t)(CH * c + hidden_of(ks2, half, e)) * FD + 32 * t + i] * gd;
-        }
-    }
-    *reinterpret_cast<uint4*>(dst) = pack8(v);
+    dsvg_pack::ffn_slot((long long)blockIdx.x * 256 + threadIdx.x, flat, offs, n_layers, fwd, bwd);
 }
-
-// position of hidden unit j in the fragment-ordered h / dpre matrices (and back: an involution): bits 2 and 3 swapped
-__host__ __device__ inline int frag_pos(int j) { return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1); }
-
-// w2p[layer][o][p] = bf16(W2[o][frag_pos(p)]): linear2.weight with fragment-ordered columns, a plain row-major matrix for
-// the unfused input-gradient GEMM (dpre = dym . W2p, gated by the fragment-ordered h)
 __global__ __launch_bounds__(256) void ffn_w2p_kernel(const float* __restrict__ flat, const int64_t* __restrict__ offs,
                                                       int n_layers, bf16_t* __restrict__ w2p) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;        // one thread per 8 output elements
-    if (gid >= (long long)n_layers * (FD * FF / 8)) return;
-    const int layer = (int)(gid / (FD * FF / 8));
-    const int r = (int)(gid % (FD * FF / 8));
-    const int o = r / (FF / 8), p0 = (r % (FF / 8)) * 8;
-    const float* W2 = flat + offs[layer * 5 + 2] + (size_t)o * FF;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = W2[frag_pos(p0 + e)];
-    *reinterpret_cast<uint4*>(w2p + (size_t)layer * FD * FF + (size_t)o * FF + p0) = pack8(v);
+    dsvg_pack::ffn_w2p_slot((long long)blockIdx.x * 256 + threadIdx.x, flat, offs, n_layers, w2p);
 }
-
-// b1'[layer][j] = b1[j] + sum_k W1[j][k] beta[k]: one wave per hidden unit
 __global__ __launch_bounds__(256) void ffn_fold_bias_kernel(const float* __restrict__ flat, const int64_t* __restrict__ offs,
                                                             int n_layers, float* __restrict__ b1f) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);          // layer * 512 + j
-    if (row >= n_layers * FF) return;
-    const int layer = row / FF, j = row % FF;
-    const float* W1 = flat + offs[layer * 5 + 0] + (size_t)j * FD;
-    const float* be = flat + offs[layer * 5 + 4];
-    float s = 0.f;
-#pragma unroll
-    for (int k = lane; k < FD; k += 64) s += W1[k] * be[k];
-    s = wave_sum(s);
-    if (lane == 0) b1f[row] = flat[offs[layer * 5 + 1] + j] + s;
+    dsvg_pack::ffn_fold_bias_row(blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, flat, offs, n_layers, b1f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -22,6 +22,7 @@
 // Dropout draws are the library's standard ones at every site, so the fused and the unfused launches are
 // interchangeable between forward and backward (tests/test_kernels_gpu.py runs all four combinations).
 #include "fused_common.h"
+#include "pack_images.h"
 #include "../../include/dsvg.h"
 
 typedef short shortx4 __attribute__((ext_vector_type(4)));
@@ -37,55 +38,14 @@ constexpr int LDH = GF + 8;             // hidden image: 1040 B = 65 x 16 B
 constexpr int GS_FRAGS = 128;           // weight fragments per wave and layer (both directions)
 constexpr int GS_PF_DEFAULT = 12;       // prefetch distance of the weight stream (fragments = KiB in flight per wave)
 
-__host__ __device__ inline int rowmap(int r, int h2) { return (r & 3) + 8 * (r >> 2) + 4 * h2; }
+using dsvg_pack::rowmap;
+static_assert(dsvg_pack::GS_FRAGS == GS_FRAGS && dsvg_pack::D == GD && dsvg_pack::F == GF && dsvg_pack::H == GH, "pack_images.h restates these");
 
-// ---------------------------------------------------------------------------------------------------------------------
-// weight packing: fp32 master parameters -> bf16 MFMA A fragments, wave-major, in consumption order.
-// offs[layer][0..3] = element offsets of in_proj_weight [768,256], out_proj.weight [256,256], linear1.weight [512,256],
-// linear2.weight [256,512] in `flat`.  Fragment i of wave w, lane l = (row = l & 31, half = l >> 5), slot e; k = 16 ks + 8
-// half + e is always the NATURAL index of the reduced dimension (the B operands come from row-major images):
-//   forward image                                      backward image (the transposed products)
-//   i <  48: Win[256 (i%3) + 32 w + row][k], ks = i/3   i <  32: W2[k][64 w + 32 (i&1) + row],  ks = i>>1   (dh  = dym . W2)
-//   i <  64: Wo [32 w + row][k],            ks = i-48   i <  64: W1[k][32 w + row],             ks = i-32   (dxn2 = dpre . W1)
-//   i <  96: W1 [64 w + 32 (i&1) + row][k], ks = (i-64)>>1   i <  80: Wo[k][32 w + row],         ks = i-64   (dao = dx1m . Wo)
-//   i < 128: W2 [32 w + row][k],            ks = i-96   i < 128: Win[k][32 w + row],            ks = i-80   (dxn1 = dqkv . Win)
-// ---------------------------------------------------------------------------------------------------------------------
+// weight packing (dsvg_gs_pack): fp32 master parameters -> bf16 MFMA A fragments, wave-major, in consumption order; body
+// and layout in pack_images.h
 __global__ __launch_bounds__(256) void gs_pack_kernel(const float* __restrict__ flat, const int64_t* __restrict__ offs,
                                                       int n_layers, bf16_t* __restrict__ fwd, bf16_t* __restrict__ bwd) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;       // one thread per 16-byte lane slot
-    const long long per_layer = 2ll * GH * GS_FRAGS * 64;
-    if (gid >= (long long)n_layers * per_layer) return;
-    const int layer = (int)(gid / per_layer);
-    int s = (int)(gid % per_layer);
-    const int dir = s / (GH * GS_FRAGS * 64);
-    s %= GH * GS_FRAGS * 64;
-    const int l = s & 63, i = (s >> 6) % GS_FRAGS, w = s / (64 * GS_FRAGS);
-    const int row = l & 31, half = l >> 5;
-    const float* Win = flat + offs[layer * 4 + 0];
-    const float* Wo = flat + offs[layer * 4 + 1];
-    const float* W1 = flat + offs[layer * 4 + 2];
-    const float* W2 = flat + offs[layer * 4 + 3];
-    float v[8];
-    if (dir == 0) {
-        const float* src;
-        if (i < 48) src = Win + (size_t)(256 * (i % 3) + 32 * w + row) * GD + 16 * (i / 3) + 8 * half;
-        else if (i < 64) src = Wo + (size_t)(32 * w + row) * GD + 16 * (i - 48) + 8 * half;
-        else if (i < 96) src = W1 + (size_t)(64 * w + 32 * (i & 1) + row) * GD + 16 * ((i - 64) >> 1) + 8 * half;
-        else src = W2 + (size_t)(32 * w + row) * GF + 16 * (i - 96) + 8 * half;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = src[e];
-    } else {
-        const float* src;
-        size_t ld;
-        if (i < 32) { src = W2 + (size_t)(16 * (i >> 1) + 8 * half) * GF + 64 * w + 32 * (i & 1) + row; ld = GF; }
-        else if (i < 64) { src = W1 + (size_t)(16 * (i - 32) + 8 * half) * GD + 32 * w + row; ld = GD; }
-        else if (i < 80) { src = Wo + (size_t)(16 * (i - 64) + 8 * half) * GD + 32 * w + row; ld = GD; }
-        else { src = Win + (size_t)(16 * (i - 80) + 8 * half) * GD + 32 * w + row; ld = GD; }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = src[(size_t)e * ld];
-    }
-    bf16_t* dst = (dir == 0 ? fwd : bwd) + (((size_t)layer * GH + w) * GS_FRAGS + i) * 512 + l * 8;
-    *reinterpret_cast<uint4*>(dst) = pack8(v);
+    dsvg_pack::gs_slot((long long)blockIdx.x * 256 + threadIdx.x, flat, offs, n_layers, fwd, bwd);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

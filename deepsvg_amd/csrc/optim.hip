@@ -4,6 +4,7 @@
 // seed advance.  Everything reads its scalars (lr, step, norm) from device memory so the whole step can
 // be replayed from a captured hipGraph.
 #include "dsvg_common.h"
+#include "pack_images.h"
 #include "../../include/dsvg.h"
 
 constexpr int SQ_BLOCKS = 1024;
@@ -108,12 +109,8 @@ __global__ void cast_weights_kernel(const float* __restrict__ src, T* __restrict
 // flat fp32 -> bf16 image of the whole parameter buffer: 8 elements per thread, 16-byte stores
 __global__ __launch_bounds__(256) void cast_flat_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                                              long long n8) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
-        const float4 a = reinterpret_cast<const float4*>(src)[2 * i];
-        const float4 b = reinterpret_cast<const float4*>(src)[2 * i + 1];
-        reinterpret_cast<uint4*>(dst)[i] =
-            make_uint4(f2bf_pk(a.x, a.y), f2bf_pk(a.z, a.w), f2bf_pk(b.x, b.y), f2bf_pk(b.z, b.w));
-    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256)
+        dsvg_pack::cast8(i, src, dst);
 }
 
 extern "C" int dsvg_cast_weights(int32_t dtype, const float* src, void* dst, void* dst_t, int64_t rows, int64_t cols,
@@ -140,18 +137,7 @@ extern "C" int dsvg_cast_weights(int32_t dtype, const float* src, void* dst, voi
     return 0;
 }
 
-__global__ void advance_step_kernel(long long* counter, uint64_t* seed) {
-    if (counter) *counter += 1;
-    if (seed) {
-        uint64_t s = *seed;
-        s += 0x9e3779b97f4a7c15ull;           // splitmix64
-        uint64_t z = s;
-        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-        z = z ^ (z >> 31);
-        *seed = z;
-    }
-}
+__global__ void advance_step_kernel(long long* counter, uint64_t* seed) { dsvg_pack::advance(counter, seed); }
 extern "C" int dsvg_advance_step(int64_t* counter, uint64_t* seed, void* stream) {
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)counter, seed);
     DSVG_LAUNCH_CHECK("advance_step");

@@ -14,7 +14,7 @@ DSVG_F32 = 0
 DSVG_BF16 = 1
 # == DSVG_ABI_VERSION of include/dsvg.h at the time SIGNATURES below was written: load() refuses a library built from another
 # header (a stale .so with the old argument lists would otherwise be called with a stream where a size is expected)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_i32, c_i64, c_u32, c_f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_float
 vp = C.c_void_p
@@ -103,6 +103,7 @@ SIGNATURES = {
     "dsvg_adamw_step": (c_i32, [vp, vp, vp, vp, c_i64, vp, c_f32, c_f32, c_f32, c_f32, vp, vp, c_f32, c_f32, vp]),
     "dsvg_cast_weights": (c_i32, [c_i32, vp, vp, vp, c_i64, c_i64, vp]),
     "dsvg_advance_step": (c_i32, [vp, vp, vp]),
+    "dsvg_pack_images": (c_i32, [vp, vp, c_i64, vp, c_i32, vp, vp, vp, vp, vp, c_i32, vp, vp, vp, c_i32, vp, vp, vp, vp, vp]),
     "dsvg_copy_many": (c_i32, [vp, vp, vp, c_i32, vp]),
     "dsvg_loss_combine_fwd": (c_i32, [vp, vp, c_i32, vp, vp]),
     "dsvg_loss_combine_bwd": (c_i32, [vp, vp, vp, c_i32, vp, vp]),

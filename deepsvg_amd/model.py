@@ -18,6 +18,9 @@ from . import ops
 from . import functional as Fn
 from .svgtensor import CMD_ARGS_MASK, EOS_ID, M_ID, SOS_ID
 
+# bf16 copy + every fused-kernel weight image (+ the step's seed advance) in one launch (ops.pack_images); 0 = the 7 (+ 1)
+# stand-alone launches, bit-identical (A/B knob)
+PACK_ONE_LAUNCH = os.environ.get("DSVG_PACK_ONE", "1") != "0"
 PE_DROPOUT = 0.1  # hard-wired in PositionalEncodingLUT (deepsvg/model/layers/positional_encoding.py:26-28)
 
 
@@ -274,6 +277,7 @@ class ParamStore:
         self._hooks = []
         self._ffn = None         # fused-FFN weight images (see _ffn_setup)
         self._attn = None        # fused attention-block weight images (see _attn_setup)
+        self.pending_advance = None     # (step counter, seed) TrainStep wants advanced at the start of the next forward
 
     # a copied / unpickled module gets an empty store that re-flattens lazily on its first forward: the index is keyed
     # by id(param) and the views point into THIS module's buffers (copy.deepcopy(model) for EMA / best-model snapshots,
@@ -476,7 +480,7 @@ class ParamStore:
         return (f["fwd"][i * ops.FFN_FWD_LAYER_ELEMS:(i + 1) * ops.FFN_FWD_LAYER_ELEMS],
                 f["bwd"][i * ops.FFN_BWD_LAYER_ELEMS:(i + 1) * ops.FFN_BWD_LAYER_ELEMS], f["b1f"][i], f["w2p"][i])
 
-    def ensure(self, device, dtype):
+    def ensure(self, device, dtype, advance=None):
         params = self.params
         stale = self.flat is None or self.flat.device != device or not params
         if not stale:
@@ -493,10 +497,23 @@ class ParamStore:
         if stale:
             self._flatten(device)
         self._in_flight.clear()     # a forward starts a new graph: nothing handed out earlier can still be pending
+        # the step counter / dropout seed advance of a training step (TrainStep hands it over, `pending_advance`; a model that
+        # owns its seed passes it): it rides on the one-launch image refresh when there is one
+        advance = advance if advance is not None else self.pending_advance
+        self.pending_advance = None
         if dtype != torch.float32:
             if self.flat_lp is None or self.flat_lp.dtype != dtype:
                 self.flat_lp = torch.empty(self.flat.numel(), dtype=dtype, device=device)
                 self._lp_views = {}
+            if dtype == torch.bfloat16 and PACK_ONE_LAUNCH and ops.pack_images_ok(self.flat, self.flat_lp):
+                # bf16 copy + every fragment image (+ the advance) = ONE launch instead of 7 (+ 1): dsvg_pack_images
+                c, sd = advance if advance is not None else (None, None)
+                ops.pack_images(self.flat, self.flat_lp, self._ffn, self._attn, self._gs,
+                                attn_bwd=torch.is_grad_enabled(), counter=c, seed=sd)
+                return
+            if advance is not None:
+                ops.advance_step_(*advance)
+                advance = None
             ops.cast_weights(self.flat, self.flat_lp)
             if dtype == torch.bfloat16 and self._ffn is not None:
                 f = self._ffn
@@ -509,6 +526,8 @@ class ParamStore:
             if dtype == torch.bfloat16 and self._gs is not None:
                 g = self._gs
                 ops.gs_pack(self.flat, g["offs"], g["n"], g["fwd"], g["bwd"])
+        if advance is not None:
+            ops.advance_step_(*advance)
 
     def lp(self, param):
         v = self._lp_views.get(id(param))
@@ -664,11 +683,9 @@ class SVGTransformer(nn.Module):
         return self._seed
 
     def _runtime(self, device):
-        self._store.ensure(device, self.compute_dtype)
         training = self.training
         seed = self.seed_tensor(device) if training else None
-        if training and self._own_seed:
-            ops.advance_step_(None, seed)
+        self._store.ensure(device, self.compute_dtype, advance=(None, seed) if training and self._own_seed else None)
         self._rt = Fn.Runtime(self.compute_dtype, seed, self._store, training,
                               defer=self._defer_wgrad and (not ops.PROFILE_ON or ops.PROFILE_KEEP_DEFER))
         return self._rt

@@ -1546,6 +1546,29 @@ def advance_step_(counter, seed):
     _l.check(_l.load().dsvg_advance_step(_p(counter), _p(seed), _stream()), "dsvg_advance_step")
 
 
+def pack_images(flat, flat_lp, ffn=None, attn=None, gs=None, attn_bwd=True, counter=None, seed=None):
+    """every per-step weight image of a bf16 model in ONE launch (dsvg_pack_images): the bf16 copy of the flat buffer
+    (cast_weights), ffn = dict(offs, n, fwd, bwd, b1f, w2p) (ffn_pack), attn = dict(offs, n, img, bwd) (attn_pack and, with
+    attn_bwd, attn_pack_bwd), gs = dict(offs, n, fwd, bwd) (gs_pack) - the stores' own image tables - and, when given, the
+    step counter / dropout seed advance (advance_step_).  Bit-identical to those launches."""
+    _chk(flat, flat_lp, counter, seed)
+    assert flat.dtype == torch.float32 and flat_lp.dtype == torch.bfloat16 and flat.numel() == flat_lp.numel()
+    assert flat.is_contiguous() and flat_lp.is_contiguous()
+    f, a, g = ffn or {}, attn or {}, gs or {}
+    _l.check(_l.load().dsvg_pack_images(
+        flat.data_ptr(), flat_lp.data_ptr(), flat.numel(),
+        _p(f.get("offs")), f.get("n", 0), _p(f.get("fwd")), _p(f.get("bwd")), _p(f.get("b1f")), _p(f.get("w2p")),
+        _p(a.get("offs")), a.get("n", 0), _p(a.get("img")), _p(a.get("bwd")) if attn_bwd else None,
+        _p(g.get("offs")), g.get("n", 0), _p(g.get("fwd")), _p(g.get("bwd")),
+        _p(counter), _p(seed), _stream()), "dsvg_pack_images")
+
+
+def pack_images_ok(flat, flat_lp):
+    """the one-launch refresh needs 16-byte aligned flat buffers with a multiple of 8 elements"""
+    return (flat.is_cuda and flat_lp is not None and flat_lp.dtype == torch.bfloat16 and flat.numel() % 8 == 0
+            and flat.data_ptr() % 16 == 0 and flat_lp.data_ptr() % 16 == 0)
+
+
 def probe_trread(off):
     _chk(off)
     assert off.dtype == torch.int32 and off.numel() == 64

@@ -227,7 +227,7 @@ class TrainStep:
         targets: model_args = [commands, args, commands, args_rel], deepsvg/model/config.py:52-53)"""
         model = self.model
         cd, ad = dec if dec is not None else (commands, args)
-        ops.advance_step_(self.step_count, self.seed)
+        model.store.pending_advance = (self.step_count, self.seed)    # launched with the weight images of the forward below
         for p in model.store.params:
             p.grad = None
         self._pending = None

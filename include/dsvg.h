@@ -33,8 +33,9 @@ extern "C" {
  * dsvg_bcast_add_bwd / dsvg_loss_targets / dsvg_scatter_rows counted).  dsvg_version() returns the value the library was
  * built with; a caller compiled against another header must refuse to run (deepsvg_amd/lib.py does).
  * 3: dsvg_latent_chain_fwd / dsvg_latent_chain_bwd added.  4: seq_add_ld argument of dsvg_attn_block_fwd / dsvg_gs_layer_fwd.
- * 5 (round 5): dsvg_sample_rows / dsvg_head_sample (categorical sampling on the device), dsvg_layernorm_bwd_masked added. */
-#define DSVG_ABI_VERSION 5
+ * 5 (round 5): dsvg_sample_rows / dsvg_head_sample (categorical sampling on the device), dsvg_layernorm_bwd_masked added.
+ * 6: dsvg_pack_images added. */
+#define DSVG_ABI_VERSION 6
 
 const char* dsvg_last_error(void);
 int dsvg_version(void);
@@ -320,6 +321,17 @@ int dsvg_cast_weights(int32_t dtype, const float* src, void* dst, void* dst_t, i
                       int64_t cols, void* stream);
 /* *counter += 1 ; *seed = hash(*seed)  — per-step dropout seed advance, graph-capturable */
 int dsvg_advance_step(int64_t* counter, uint64_t* seed, void* stream);
+/* Every per-step weight image of a bf16 model in ONE launch (csrc/pack_images.hip): what dsvg_cast_weights(DSVG_BF16, flat)
+ * + dsvg_ffn_pack + dsvg_attn_pack + dsvg_attn_pack_bwd + dsvg_gs_pack + dsvg_advance_step write, bit for bit (the same
+ * device code, csrc/pack_images.h), i.e. the `.to(bf16)` copies of the parameters an autocast forward of
+ * deepsvg/model/model.py makes, laid out for the fused kernels.  n = elements of the flat buffers (a multiple of 8, both
+ * 16-byte aligned).  A family with 0 layers is skipped; ffn_w2p, attn_bwd (only a backward pass reads it), counter and seed
+ * may each be NULL.  offs tables as in the stand-alone calls. */
+int dsvg_pack_images(const float* flat_f32, void* flat_bf16, int64_t n,
+                     const int64_t* ffn_offs, int32_t ffn_layers, void* ffn_fwd, void* ffn_bwd, float* ffn_b1f, void* ffn_w2p,
+                     const int64_t* attn_offs, int32_t attn_layers, void* attn_img, void* attn_bwd,
+                     const int64_t* gs_offs, int32_t gs_layers, void* gs_fwd, void* gs_bwd,
+                     int64_t* counter, uint64_t* seed, void* stream);
 /* n device-to-device copies dst[i][0 .. bytes[i]) = src[i][...] in one launch per 32 entries (the table travels in the kernel
  * arguments: capturable, no staging).  deepsvg_amd/trainer.py refreshes the static inputs and the layout plan of a hipGraph
  * step with it between two replays (they were ~20 separate copy launches). */

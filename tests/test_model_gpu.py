@@ -645,6 +645,48 @@ def test_masked_gradient_hand_off_is_taken_and_changes_nothing(gpu_device):
     assert runs[True][2] <= runs[False][2] - 6, (runs[True][2], runs[False][2])       # 8 large layers: 6+ hand-offs taken
 
 
+def test_one_launch_weight_images_equal_the_stand_alone_launches(gpu_device):
+    """model.PACK_ONE_LAUNCH (round 5): the bf16 flat copy, the fused FFN / attention / attention-backward / group-stage weight
+    images and the seed advance of a training step come from ONE launch (dsvg_pack_images) - bit-identical to the 7 + 1 stand-alone
+    launches it replaces, image by image, and in the losses / gradients of two training steps (eager and replayed)."""
+    import deepsvg_amd.model as M
+    from deepsvg_amd.trainer import TrainStep
+    cfg = H.build_cfg("hier")
+    cfg.dropout = 0.1
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 13)
+    batches = [tuple(t.to(DEV) for t in make_batch(320, seed=sd_)) for sd_ in (3, 4)]
+    saved = M.PACK_ONE_LAUNCH
+    images, runs = {}, {}
+    try:
+        for on in (False, True):
+            M.PACK_ONE_LAUNCH = on
+            torch.manual_seed(5)
+            model = _hip_model(cfg, sd, torch.bfloat16).train()
+            st = model.store
+            seed = model.seed_tensor(torch.device(DEV)).clone()
+            step = torch.zeros((), dtype=torch.int64, device=DEV)
+            st.ensure(torch.device(DEV), torch.bfloat16, advance=(step, seed))
+            assert ops.pack_images_ok(st.flat, st.flat_lp) and st._ffn["n"] == 16 and st._attn["n"] == 16 and st._gs["n"] == 12
+            torch.cuda.synchronize()
+            images[on] = [t.clone() for t in (st.flat_lp, st._ffn["fwd"], st._ffn["bwd"], st._ffn["b1f"], st._ffn["w2p"],
+                                              st._attn["img"], st._attn["bwd"], st._gs["fwd"], st._gs["bwd"], seed, step)]
+            for use_graph in (False, True):
+                torch.manual_seed(6)
+                m2 = _hip_model(cfg, sd, torch.bfloat16).train()
+                ts = TrainStep(m2, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=1e-3, use_graph=use_graph)
+                losses = [{k: float(v) for k, v in ts.step(c, a).items()} for c, a in batches + batches[:1]]
+                torch.cuda.synchronize()
+                runs[on, use_graph] = (losses, m2.store.flat.detach().clone(), int(ts.step_count))
+    finally:
+        M.PACK_ONE_LAUNCH = saved
+    assert int(images[True][-1]) == 1 and not torch.equal(images[True][-2], model.seed_tensor(torch.device(DEV)))
+    for a, b in zip(images[False], images[True]):
+        assert a.dtype == b.dtype and torch.equal(a.reshape(-1).view(torch.uint8), b.reshape(-1).view(torch.uint8))
+    for use_graph in (False, True):
+        assert runs[True, use_graph][0] == runs[False, use_graph][0]
+        assert torch.equal(runs[True, use_graph][1], runs[False, use_graph][1]) and runs[True, use_graph][2] == 3
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_self_matching_training_step(gpu_device, use_graph):
     """HierarchicalSelfMatching through TrainStep (costs + exhaustive assignment + row permutation have no host round
