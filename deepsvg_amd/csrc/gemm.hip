@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void reduce_deferred_kernel(const DeferTable t
     const float* __restrict__ part = t.s[s].part;
     const long long stride = t.s[s].stride;
     const int n = t.s[s].n, n_bf16 = t.s[s].n_bf16, P = t.s[s].P;
-    if (t.s[s].wide) {          // (uniform over the workgroup)
+    if (t.s[s].wide == 1) {          // (uniform over the workgroup)
         const int j = (((int)blockIdx.x - t.s[s].first_block) * 256 + (int)threadIdx.x) * 8;
         if (j >= n) return;
         float acc[8];
@@ -489,6 +489,22 @@ __global__ __launch_bounds__(256) void reduce_deferred_kernel(const DeferTable t
             if (t.s[s].accumulate) { const float4 a = o[0]; r0.x += a.x; r0.y += a.y; r0.z += a.z; r0.w += a.w; }
             o[0] = r0;
         }
+        return;
+    }
+    if (t.s[s].wide == 2) {     // unaligned fp32 segments (a width that is no multiple of 4: the heads' 7 / 2827 output rows): a column per thread
+        const int j = ((int)blockIdx.x - t.s[s].first_block) * 256 + (int)threadIdx.x;
+        if (j >= n) return;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int q = 0;
+        for (; q + 4 <= P; q += 4) {
+            const float v0 = part[(q + 0) * stride + j], v1 = part[(q + 1) * stride + j];
+            const float v2 = part[(q + 2) * stride + j], v3 = part[(q + 3) * stride + j];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; q < P; ++q) a0 += part[q * stride + j];
+        float r = (a0 + a1) + (a2 + a3);
+        if (t.s[s].accumulate) r += t.s[s].out[j];
+        t.s[s].out[j] = r;
         return;
     }
     const int tx = threadIdx.x % DF_TX, ty = threadIdx.x / DF_TX;
@@ -544,9 +560,10 @@ int defer_flush_locked(DeferQueue& d, hipStream_t st) {
             t.s[k].first_block = blocks;
             // wide layout: 16-byte accesses of 8 columns (slices and destination 16-byte aligned, the bf16 / fp32 boundary on a
             // group boundary); few slices, many columns
-            t.s[k].wide = (t.s[k].n >= DF_WIDE_COLS && t.s[k].P <= 64 && !(t.s[k].stride & 3) &&
-                           !((uintptr_t)t.s[k].part & 15) && !((uintptr_t)t.s[k].out & 15) && !(t.s[k].n_bf16 & 7)) ? 1 : 0;
-            blocks += t.s[k].wide ? dsvg_cdiv(t.s[k].n, DF_WIDE_COLS) : dsvg_cdiv(t.s[k].n, DF_TX * 4);
+            const bool vec = !(t.s[k].n & 3) && !(t.s[k].stride & 3) && !((uintptr_t)t.s[k].part & 15) &&
+                             !((uintptr_t)t.s[k].out & 15) && !(t.s[k].n_bf16 & 3);
+            t.s[k].wide = !vec ? 2 : (t.s[k].n >= DF_WIDE_COLS && t.s[k].P <= 64 && !(t.s[k].n_bf16 & 7)) ? 1 : 0;
+            blocks += t.s[k].wide == 2 ? dsvg_cdiv(t.s[k].n, 256) : t.s[k].wide ? dsvg_cdiv(t.s[k].n, DF_WIDE_COLS) : dsvg_cdiv(t.s[k].n, DF_TX * 4);
         }
         t.n_seg = k;
         hipLaunchKernelGGL(reduce_deferred_kernel, dim3(blocks), dim3(256), 0, st, t);
@@ -604,7 +621,10 @@ int dsvg_reduce_partials_mixed(const float* part, int64_t P, int64_t stride, int
                 int rc = defer_flush_locked(d, st);
                 if (rc) return rc;
             }
-            if (d.scope && vec && n < (1ll << 30) && P < (1ll << 30)) {
+            // (segments that are no 16-byte multiples - the heads' 7 / 2827 output rows - take the kernel's column-per-thread path;
+            // DSVG_DEFER_MORE=0: reduced on the spot as before round 5, an A/B knob)
+            static const bool unaligned_ok = !(getenv("DSVG_DEFER_MORE") && atoi(getenv("DSVG_DEFER_MORE")) == 0);
+            if (d.scope && (vec || (unaligned_ok && n_bf16 == 0)) && n < (1ll << 30) && P < (1ll << 30)) {
                 d.q.push_back(DeferSeg{part, out, (long long)stride, (int)n, (int)n_bf16, (int)P, 0, accumulate, 0});
                 return 0;
             }

@@ -42,6 +42,9 @@ BCAST_MASKED = os.environ.get("DSVG_BCAST_MASKED", "1") != "0"
 # round 5: the LayerNorm backward that produces a layer's incoming gradient also writes that gradient with the residual-dropout
 # mask of the layer BELOW replayed on it (what that layer's FFN half reads): 9 drop_apply launches per step less
 LN_BWD_MASKED = os.environ.get("DSVG_LN_BWD_MASKED", "1") != "0"
+# round 5: the position / embedding tables' gradient reductions (add_pos_bwd, embed_scatter: 6 launches) join the deferred queue,
+# and the library queues segments of any width (csrc/gemm.hip: the heads' 7- and 2827-row gradients: 2 launches); 0 = as before
+DEFER_MORE = os.environ.get("DSVG_DEFER_MORE", "1") != "0"
 # attention backward of the large stages with the out_proj backward inside (no `dao = dx1m @ Wo` GEMM launch)
 ATTN_BWD_OUTPROJ = os.environ.get("DSVG_ATTN_BWD_OUTPROJ", "1") != "0"
 # ... which only exists on the MFMA attention kernels: the library's A/B knobs that route attention to the VALU kernels
@@ -79,6 +82,10 @@ class Runtime:
     def deferring(self):
         """context manager around launches whose reductions write parameter gradients"""
         return ops.DEFER if self.defer else _NULL_CTX
+
+    def deferring_tables(self):
+        """the same around the embedding / position tables' gradients (round 5; DSVG_DEFER_MORE=0: reduced on the spot)"""
+        return ops.DEFER if self.defer and DEFER_MORE else _NULL_CTX
 
     def grouping(self):
         """context manager around a run of independent weight-gradient GEMMs: one launch for all of them (ops.GROUP)"""
@@ -377,8 +384,9 @@ class AddPosFn(torch.autograd.Function):
         live = _armed(ctx.live)
         n_seq = live[0] if live is not None else ctx.n_seq
         dy = dy.contiguous()[:n_seq * ctx.S]
-        dx = ops.add_pos_bwd(dy, n_seq, ctx.S, dpos[:ctx.S], want_dx=ctx.has_x, drop_p=ctx.p,
-                             drop_site=ctx.site, seed=rt.seed)
+        with rt.deferring_tables():     # (the table's column sums are a parameter gradient: reduced with the others at the flush)
+            dx = ops.add_pos_bwd(dy, n_seq, ctx.S, dpos[:ctx.S], want_dx=ctx.has_x, drop_p=ctx.p,
+                                 drop_site=ctx.site, seed=rt.seed)
         return None, dx, dpos, None, None, None, None, None
 
 
@@ -422,14 +430,16 @@ class EmbedFn(torch.autograd.Function):
         dpos = rt.grad_out(pos_weight)
         if pos_weight.shape[0] > ctx.S:
             dpos[ctx.S:].zero_()
-        dpre = ops.add_pos_bwd(dsrc.contiguous(), ctx.n_seq, ctx.S, dpos[:ctx.S], want_dx=True, drop_p=ctx.p,
-                               drop_site=ctx.site, seed=rt.seed)
+        with rt.deferring_tables():
+            dpre = ops.add_pos_bwd(dsrc.contiguous(), ctx.n_seq, ctx.S, dpos[:ctx.S], want_dx=True, drop_p=ctx.p,
+                                   drop_site=ctx.site, seed=rt.seed)
         dw, db = _wbgrad(rt, fcn_w, fcn_b, dpre, A)
         dA = ops.gemm(dpre, rt.w(fcn_w), b_kc=False)
         d_arg = rt.grad_out(arg_embed)
         d_cmd = rt.grad_out(command_embed)
         d_grp = rt.grad_out(group_embed) if group_embed is not None else None
-        ops.embed_scatter(commands, args, dA, dpre, d_arg, d_cmd, groups, d_grp)
+        with rt.deferring_tables():     # (three table gradients from per-workgroup partials)
+            ops.embed_scatter(commands, args, dA, dpre, d_arg, d_cmd, groups, d_grp)
         return (None, None, None, None, None, None, None, None, d_cmd, d_arg, dw, db, dpos, d_grp)
 
 
@@ -510,7 +520,8 @@ class PackedEmbedFn(torch.autograd.Function):
         dpos = rt.grad_out(pos_weight)
         if pos_weight.shape[0] > ctx.S:
             dpos[ctx.S:].zero_()
-        ops.embed_scatter(commands, args, dA, dpre, d_arg, d_cmd, pos_idx, dpos[:ctx.S])
+        with rt.deferring_tables():
+            ops.embed_scatter(commands, args, dA, dpre, d_arg, d_cmd, pos_idx, dpos[:ctx.S])
         return (None, None, None, None, None, None, None, d_cmd, d_arg, dw, db, dpos)
 
 
