@@ -606,6 +606,31 @@ extern "C" int dsvg_flush_deferred(void* stream) {
     return rc;
 }
 
+extern "C" int dsvg_defer_zero(float* out, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    DSVG_CHECK_ARG(out && n < (1ll << 30), "defer_zero: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    {
+        DeferTableOfQueues& t = defer_queues();
+        std::lock_guard<std::mutex> lk(t.mu);
+        auto it = t.by_stream.find(st);
+        if (it != t.by_stream.end()) {
+            DeferQueue& d = it->second;
+            if (!d.q.empty() && defer_overlaps(d, out, n)) {
+                int rc = defer_flush_locked(d, st);
+                if (rc) return rc;
+            }
+            if (d.scope) {      // a reduction over ZERO partial rows writes zeros: the fill rides on the flush's launches
+                d.q.push_back(DeferSeg{out, out, 0ll, (int)n, 0, 0, 0, 0, 0});
+                return 0;
+            }
+        }
+    }
+    if (int rc = dsvg_gemm_group_flush(st)) return rc;
+    if (hipMemsetAsync(out, 0, (size_t)n * sizeof(float), st) != hipSuccess) { dsvg_set_error("defer_zero: hipMemsetAsync failed"); return -1; }
+    return 0;
+}
+
 int dsvg_reduce_partials_mixed(const float* part, int64_t P, int64_t stride, int64_t n, int64_t n_bf16, float* out,
                                int32_t accumulate, hipStream_t st) {
     if (n <= 0) return 0;

@@ -1115,9 +1115,10 @@ class ArgsHeadLossFn(torch.autograd.Function):
         else:
             # only the output rows [r0, r1) of the head saw a loss term: their gradient comes from the GEMMs, the rest is 0
             dw, db = rt.grad_out(weight), rt.grad_out(bias)
-            dw[:r0].zero_(); dw[r1:].zero_(); db[:r0].zero_(); db[r1:].zero_()
             split = ops.split_k_for(r1 - r0, weight.shape[1], dl.shape[0])
             with rt.deferring(), _wgrad_tag():
+                for t in (dw[:r0], dw[r1:], db[:r0], db[r1:]):       # (inside the scope: the fills ride on the flush)
+                    ops.zero_(t) if DEFER_MORE else t.zero_()
                 if split > 1:
                     ops.gemm(dl, xc, a_kc=False, b_kc=False, out=dw[r0:r1], split_k=split, rowsum=db[r0:r1])
                 else:

@@ -50,6 +50,7 @@ SIGNATURES = {
     "dsvg_reduce_partials": (c_i32, [vp, c_i64, c_i64, vp, c_i32, vp]),
     "dsvg_defer_scope": (c_i32, [c_i32, vp]),
     "dsvg_flush_deferred": (c_i32, [vp]),
+    "dsvg_defer_zero": (c_i32, [vp, c_i64, vp]),
     "dsvg_gemm_group_scope": (c_i32, [c_i32, vp]),
     "dsvg_colsum": (c_i32, [c_i32, vp, c_i64, c_i64, c_i32, vp, c_i32, c_f32, c_u32, vp, vp, c_i64, vp]),
     "dsvg_colsum_workspace_bytes": (c_i64, [c_i64, c_i32]),

@@ -144,6 +144,17 @@ def defer_active():
     return st is not None and st.depth > 0
 
 
+def zero_(t):
+    """t.zero_() for a contiguous fp32 tensor; inside an open deferral scope on this stream the fill joins the queued reductions
+    (dsvg_defer_zero: no launch of its own, valid after flush_deferred() like their outputs)"""
+    if t.numel() == 0:
+        return t
+    if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and defer_active():
+        _l.check(_l.load().dsvg_defer_zero(t.data_ptr(), t.numel(), _stream()), "dsvg_defer_zero")
+        return t
+    return t.zero_()
+
+
 def defer_post(fn):
     """run fn() right after the queued reductions at the next flush_deferred() on this stream (work that reads their
     outputs); without an open scope on this stream nothing is queued, so fn runs now"""

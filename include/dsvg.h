@@ -34,7 +34,7 @@ extern "C" {
  * built with; a caller compiled against another header must refuse to run (deepsvg_amd/lib.py does).
  * 3: dsvg_latent_chain_fwd / dsvg_latent_chain_bwd added.  4: seq_add_ld argument of dsvg_attn_block_fwd / dsvg_gs_layer_fwd.
  * 5 (round 5): dsvg_sample_rows / dsvg_head_sample (categorical sampling on the device), dsvg_layernorm_bwd_masked added.
- * 6: dsvg_pack_images added. */
+ * 6: dsvg_pack_images, dsvg_defer_zero added. */
 #define DSVG_ABI_VERSION 6
 
 const char* dsvg_last_error(void);
@@ -99,6 +99,10 @@ int dsvg_reduce_partials(const float* partial, int64_t P, int64_t n, float* out,
  * produced the queued partials, ordered behind them.  No state besides these per-stream queues is kept.
  * dsvg_defer_scope returns the number of reductions currently queued on that stream. */
 int dsvg_defer_scope(int32_t on, void* stream);
+/* out[0 .. n) = 0 (fp32): queued as a reduction over zero partial rows while a scope is open on the stream (the fill then costs
+ * no launch of its own: the rows of a head's weight gradient that saw no loss term, functional.ArgsHeadLossFn), a plain
+ * asynchronous memset otherwise.  Same ordering rules as the queued reductions. */
+int dsvg_defer_zero(float* out, int64_t n, void* stream);
 int dsvg_flush_deferred(void* stream);
 /* Grouped weight-gradient launches.  While a group scope is open on a stream (dsvg_gemm_group_scope(1, s) ... (0, s)) every
  * split-K weight-gradient dsvg_gemm on that stream that would take the 4-stage LDS-DMA kernel (bf16, both operands
