@@ -588,6 +588,7 @@ struct GsBwdArgs {
     const float* g1; const float* g2;
     const uint64_t* key_mask; const uint64_t* seed;
     bf16_t* dx; bf16_t* dx1; bf16_t* dym; bf16_t* dpre; bf16_t* dx1m; bf16_t* dqkv;
+    bf16_t* dg;             // [n_seq][256] or NULL: the per-sequence term's gradient (what dsvg_bcast_add_bwd makes of dx1)
     float* ln_part;         // [tiles][4][256]: dgamma2, dbeta2, dgamma1, dbeta1
     int n_seq, S;
     float scale, drop_p;
@@ -835,6 +836,40 @@ __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a)
     col_sums(DO, A1, qc, lane, part);                    // dgamma2 | dbeta2, columns of block w
     store_image(a.dx1m + row0 * GD, GD, A0, LDX, 0, S, GD);
     if (a.dx1) store_image(a.dx1 + row0 * GD, GD, HI, LDX, 0, S, GD);
+    if (a.dg) {
+        // dg[sequence] = mask(site0 + 2) * sum over the sequence's rows of dx1 - the tile holds whole sequences, so the launch of
+        // dsvg_bcast_add_bwd behind this kernel (and, for its sake, the dx1 store) is not needed.  Same summation order as that
+        // kernel (rows i = q mod 4 in increasing order, then ((s0 + s1) + s2) + s3) and same draws: bit-identical
+        const DropCtx dgc = drop_make_v(a.drop_p, has_seed, seedv, a.site0 + 2);
+        for (int idx = tid; idx < n_in * 32; idx += 512) {
+            const int sq = idx >> 5, c8 = (idx & 31) * 8;
+            float sp[4][8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sp[q][e] = 0.f;
+            for (int i0 = 0; i0 < Smax; i0 += 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (i0 + q >= Smax) break;
+                    float v[8];
+                    unpack8(*reinterpret_cast<const uint4*>(&HI[(sq * Smax + i0 + q) * LDX + c8]), v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sp[q][e] += v[e];
+                }
+            }
+            float sv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sv[e] = ((sp[0][e] + sp[1][e]) + sp[2][e]) + sp[3][e];
+            if (dgc.on) {
+                float dm[8];
+                drop_mult8(dgc, (uint64_t)(s_first + sq) * GD + c8, dm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sv[e] *= dm[e];
+            }
+            *reinterpret_cast<uint4*>(a.dg + (long long)(s_first + sq) * GD + c8) = pack8(sv);
+        }
+    }
 
     // ---- phase 3: dao = dx1m . Wo (the dims of head w) + attention backward of head w -----------------------------------------
     {
@@ -1326,7 +1361,7 @@ extern "C" int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, 
                                  const uint64_t* key_mask, int64_t n_seq, int32_t S, void* dx, void* dx1, void* dym,
                                  void* dpre, void* dx1m, void* dqkv, float* dgamma2, float* dbeta2, float* dgamma1,
                                  float* dbeta1, float scale, float drop_p, uint32_t site0, const void* seed,
-                                 void* workspace, int64_t workspace_bytes, void* stream) {
+                                 void* workspace, int64_t workspace_bytes, void* dg, void* stream) {
     DSVG_CHECK_ARG(dx2 && packed_bwd_layer && x && mean1 && rstd1 && qkv && x1 && mean2 && rstd2 && h && gamma1 && gamma2,
                    "gs_layer_bwd: null input pointer");
     DSVG_CHECK_ARG(dx && dym && dpre && dx1m && dqkv && dgamma2 && dbeta2 && dgamma1 && dbeta1 && workspace,
@@ -1337,7 +1372,7 @@ extern "C" int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, 
     DSVG_CHECK_ARG(workspace_bytes >= dsvg_gs_bwd_workspace_bytes(n_seq, S), "gs_layer_bwd: workspace too small");
     DSVG_CHECK_ARG((((uintptr_t)dx2 | (uintptr_t)x | (uintptr_t)qkv | (uintptr_t)x1 | (uintptr_t)h | (uintptr_t)dx |
                      (uintptr_t)dx1 | (uintptr_t)dym | (uintptr_t)dpre | (uintptr_t)dx1m | (uintptr_t)dqkv |
-                     (uintptr_t)packed_bwd_layer | (uintptr_t)workspace) & 15) == 0,
+                     (uintptr_t)packed_bwd_layer | (uintptr_t)workspace | (uintptr_t)dg) & 15) == 0,
                    "gs_layer_bwd: operands must be 16-byte aligned");
     GsBwdArgs a;
     a.dx2 = (const bf16_t*)dx2; a.img = (const bf16_t*)packed_bwd_layer;
@@ -1345,7 +1380,7 @@ extern "C" int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, 
     a.x1 = (const bf16_t*)x1; a.mean2 = mean2; a.rstd2 = rstd2; a.h = (const bf16_t*)h;
     a.g1 = gamma1; a.g2 = gamma2; a.key_mask = key_mask; a.seed = (const uint64_t*)seed;
     a.dx = (bf16_t*)dx; a.dx1 = (bf16_t*)dx1; a.dym = (bf16_t*)dym; a.dpre = (bf16_t*)dpre; a.dx1m = (bf16_t*)dx1m;
-    a.dqkv = (bf16_t*)dqkv; a.ln_part = (float*)workspace;
+    a.dqkv = (bf16_t*)dqkv; a.dg = (bf16_t*)dg; a.ln_part = (float*)workspace;
     a.n_seq = (int)n_seq; a.S = S; a.scale = scale; a.drop_p = drop_p; a.site0 = site0;
     const int per = 32 / S;
     const int nb = (int)((n_seq + per - 1) / per);

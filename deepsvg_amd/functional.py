@@ -45,6 +45,8 @@ LN_BWD_MASKED = os.environ.get("DSVG_LN_BWD_MASKED", "1") != "0"
 # round 5: the position / embedding tables' gradient reductions (add_pos_bwd, embed_scatter: 6 launches) join the deferred queue,
 # and the library queues segments of any width (csrc/gemm.hip: the heads' 7- and 2827-row gradients: 2 launches); 0 = as before
 DEFER_MORE = os.environ.get("DSVG_DEFER_MORE", "1") != "0"
+# round 5: the group-stage backward kernel also emits the conditioning term's gradient (4 bcast_add_bwd launches + 4 dx1 stores less)
+GS_BWD_DG = os.environ.get("DSVG_GS_BWD_DG", "1") != "0"
 # attention backward of the large stages with the out_proj backward inside (no `dao = dx1m @ Wo` GEMM launch)
 ATTN_BWD_OUTPROJ = os.environ.get("DSVG_ATTN_BWD_OUTPROJ", "1") != "0"
 # ... which only exists on the MFMA attention kernels: the library's A/B knobs that route attention to the VALU kernels
@@ -808,14 +810,15 @@ class LayerFn(torch.autograd.Function):
             # one launch for the whole input-gradient chain of the block (csrc/group_stage.hip); it hands over the token-major
             # operands of the four weight-gradient GEMMs and the LayerNorm parameter gradients
             gs = rt.store.gs(win)
+            fuse_dg = GS_BWD_DG and z is not None      # the conditioning term's gradient from the same launch (no dx1 round trip)
             with rt.deferring(), ops.tag("gs"):
-                (dx, dx1, dym, dpre, dx1m, dqkv, dn2w, dn2b, dn1w, dn1b) = ops.gs_layer_bwd(
+                (dx, dx1, dym, dpre, dx1m, dqkv, dn2w, dn2b, dn1w, dn1b, *dg_) = ops.gs_layer_bwd(
                     dx2, gs[1], x, mean1, rstd1, qkv, x1, mean2, rstd2, h, n1w.detach(), n2w.detach(), key_mask, n_seq, S,
-                    ctx.scale, p, s0, rt.seed, want_dx1=z is not None, dgamma2=rt.grad_out(n2w), dbeta2=rt.grad_out(n2b),
-                    dgamma1=rt.grad_out(n1w), dbeta1=rt.grad_out(n1b))
+                    ctx.scale, p, s0, rt.seed, want_dx1=z is not None and not fuse_dg, dgamma2=rt.grad_out(n2w),
+                    dbeta2=rt.grad_out(n2b), dgamma1=rt.grad_out(n1w), dbeta1=rt.grad_out(n1b), want_dg=fuse_dg)
             dz = dwg = dbg = dg = None
             if z is not None:
-                dg = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed)
+                dg = dg_[0] if fuse_dg else ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed)
                 if wg is None:
                     dz = dg                 # `z` was the projected row itself: its gradient goes to GlobalCondFn
                 elif ctx.needs_input_grad[3]:

@@ -143,7 +143,7 @@ SIGNATURES = {
     "dsvg_gs_bwd_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "dsvg_latent_chain_fwd": (c_i32, [vp, vp, vp, c_i32, vp, vp, vp, c_i64, vp]),
     "dsvg_latent_chain_bwd": (c_i32, [vp, vp, vp, c_i32, vp, vp, c_i64, vp]),
-    "dsvg_gs_layer_bwd": (c_i32, [vp] * 13 + [c_i64, c_i32] + [vp] * 10 + [c_f32, c_f32, c_u32, vp, vp, c_i64, vp]),
+    "dsvg_gs_layer_bwd": (c_i32, [vp] * 13 + [c_i64, c_i32] + [vp] * 10 + [c_f32, c_f32, c_u32, vp, vp, c_i64, vp, vp]),
 }
 
 _lib = None

@@ -1398,9 +1398,11 @@ def gs_layer_fwd(x, packed_fwd_layer, in_bias, out_bias, b1, b2, gamma1, beta1, 
 
 def gs_layer_bwd(dx2, packed_bwd_layer, x, mean1, rstd1, qkv, x1, mean2, rstd2, h, gamma1, gamma2, key_mask, n_seq, S,
                  scale, drop_p=0.0, site0=0, seed=None, want_dx1=False, dgamma2=None, dbeta2=None, dgamma1=None,
-                 dbeta1=None):
+                 dbeta1=None, want_dg=False):
     """backward of gs_layer_fwd with respect to x (include/dsvg.h) -> (dx, dx1 or None, dym, dpre, dx1m, dqkv, dgamma2,
-    dbeta2, dgamma1, dbeta1): dym / dpre / dx1m / dqkv are the token-major operands of the four weight-gradient GEMMs."""
+    dbeta2, dgamma1, dbeta1): dym / dpre / dx1m / dqkv are the token-major operands of the four weight-gradient GEMMs.
+    want_dg: one more result at the end, dg [n_seq, 256] = bcast_add_bwd(dx1, n_seq, S, drop_p, site0 + 2, seed) bit for bit
+    (the per-sequence term's gradient, formed in the same launch)."""
     _chk(dx2, packed_bwd_layer, x, mean1, rstd1, qkv, x1, mean2, rstd2, h, gamma1, gamma2, key_mask, seed)
     rows = n_seq * S
     assert dx2.dtype == torch.bfloat16 and dx2.is_contiguous() and tuple(dx2.shape) == (rows, 256) and 32 % S == 0
@@ -1414,6 +1416,7 @@ def gs_layer_bwd(dx2, packed_bwd_layer, x, mean1, rstd1, qkv, x1, mean2, rstd2, 
     dx1 = torch.empty_like(dx2) if want_dx1 else None
     dpre = torch.empty((rows, 512), dtype=dx2.dtype, device=dev)
     dqkv = torch.empty((rows, 768), dtype=dx2.dtype, device=dev)
+    dg = torch.empty((n_seq, 256), dtype=dx2.dtype, device=dev) if want_dg else None
     outs = []
     for t in (dgamma2, dbeta2, dgamma1, dbeta1):
         if t is None:
@@ -1428,11 +1431,11 @@ def gs_layer_bwd(dx2, packed_bwd_layer, x, mean1, rstd1, qkv, x1, mean2, rstd2, 
                                  h.data_ptr(), gamma1.data_ptr(), gamma2.data_ptr(), _p(key_mask), n_seq, S, dx.data_ptr(),
                                  _p(dx1), dym.data_ptr(), dpre.data_ptr(), dx1m.data_ptr(), dqkv.data_ptr(),
                                  *[t.data_ptr() for t in outs], float(scale), float(drop_p), int(site0),
-                                 _p(seed) if drop_p > 0 else None, ws.data_ptr(), ws.numel() * 4, _stream()),
+                                 _p(seed) if drop_p > 0 else None, ws.data_ptr(), ws.numel() * 4, _p(dg), _stream()),
              "dsvg_gs_layer_bwd")
     _prof_end(ev, 2.0 * rows * 256 * (768 + 256 + 1024) + 8.0 * rows * S * 256, 1536.0 * rows,
               dict(op="gs_layer_bwd", rows=rows, ffn_flops=4.0 * 256 * 512 * rows))
-    return (dx, dx1, dym, dpre, dx1m, dqkv, *outs)
+    return (dx, dx1, dym, dpre, dx1m, dqkv, *outs, dg) if want_dg else (dx, dx1, dym, dpre, dx1m, dqkv, *outs)
 
 
 def _prof_begin():

@@ -34,7 +34,7 @@ extern "C" {
  * built with; a caller compiled against another header must refuse to run (deepsvg_amd/lib.py does).
  * 3: dsvg_latent_chain_fwd / dsvg_latent_chain_bwd added.  4: seq_add_ld argument of dsvg_attn_block_fwd / dsvg_gs_layer_fwd.
  * 5 (round 5): dsvg_sample_rows / dsvg_head_sample (categorical sampling on the device), dsvg_layernorm_bwd_masked added.
- * 6: dsvg_pack_images, dsvg_defer_zero added. */
+ * 6: dsvg_pack_images, dsvg_defer_zero added; dg argument of dsvg_gs_layer_bwd. */
 #define DSVG_ABI_VERSION 6
 
 const char* dsvg_last_error(void);
@@ -600,6 +600,8 @@ int dsvg_attn_block_fwd(const void* x, const void* packed_layer, const float* in
  *   gradients - dx1 (optional, for dsvg_bcast_add_bwd of the per-sequence term) and the four LayerNorm parameter
  *   gradients (fp32 [256] each; reduced from per-tile partials in `workspace`, dsvg_gs_bwd_workspace_bytes(n_seq, S)
  *   bytes, through the deferred-reduction queue when a scope is open on the stream).
+ *   dg (optional, bf16 [n_seq, 256]; ABI 6): the gradient of the per-sequence term, = dsvg_bcast_add_bwd(dx1, site0 + 2) bit
+ *   for bit, formed from the tile while dx1 is on chip - that launch and the dx1 store (pass dx1 = NULL) are then not needed.
  * ------------------------------------------------------------------------------------------ */
 int64_t dsvg_gs_pack_bytes(int32_t n_layers);
 int dsvg_gs_pack(const float* flat_f32, const int64_t* offs, int32_t n_layers, int32_t d_model, int32_t d_ff,
@@ -616,7 +618,7 @@ int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, const void*
                       const float* gamma1, const float* gamma2, const uint64_t* key_mask, int64_t n_seq, int32_t S,
                       void* dx, void* dx1, void* dym, void* dpre, void* dx1m, void* dqkv, float* dgamma2, float* dbeta2,
                       float* dgamma1, float* dbeta1, float scale, float drop_p, uint32_t site0, const void* seed,
-                      void* workspace, int64_t workspace_bytes, void* stream);
+                      void* workspace, int64_t workspace_bytes, void* dg, void* stream);
 /* test hook: raw ds_read_b64_tr_b16 on a 4 KiB LDS image img[i]=i, lane l reads at byte offset off[l] */
 int dsvg_probe_trread(const int* off, short* out, void* stream);
 

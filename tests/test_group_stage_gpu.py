@@ -228,6 +228,14 @@ def test_gs_layer_bwd_matches_reference(gpu_device, n_seq, S, masked, with_add, 
                 300 + 8 * layer, seed)
         got = ops.gs_layer_bwd(dx2, pb[sl], *args, want_dx1=True)
         want = R.gs_layer_bwd(dx2, eb[sl], *args, want_dx1=True)
+        # round 5: the per-sequence term's gradient from the same launch = the bcast_add_bwd launch on the kernel's own dx1, bit
+        # for bit (same summation order, same draws), with and without the dx1 store; nothing else changes
+        for want_dx1 in (True, False):
+            both = ops.gs_layer_bwd(dx2, pb[sl], *args, want_dx1=want_dx1, want_dg=True)
+            assert len(both) == len(got) + 1 and (both[1] is None) == (not want_dx1)
+            assert torch.equal(both[-1], ops.bcast_add_bwd(got[1], n_seq, S, drop_p, 300 + 8 * layer + 2, seed)), "dg"
+            for name, a, b in zip(BWD_NAMES, both, got):
+                assert (a is None and name == "dx1") or torch.equal(a, b), name
         torch.cuda.synchronize()
         for name, a, b in zip(BWD_NAMES, got, want):
             _diff(f"layer {layer} {name}", a, b, 2e-2 if not name.startswith(("dgamma", "dbeta")) else 1e-2, bad,

@@ -1052,7 +1052,7 @@ def gs_layer_fwd(x, packed_fwd_layer, in_bias, out_bias, b1, b2, gamma1, beta1, 
 
 def gs_layer_bwd(dx2, packed_bwd_layer, x, mean1, rstd1, qkv, x1, mean2, rstd2, h, gamma1, gamma2, key_mask, n_seq, S,
                  scale, drop_p=0.0, site0=0, seed=None, want_dx1=False, dgamma2=None, dbeta2=None, dgamma1=None,
-                 dbeta1=None):
+                 dbeta1=None, want_dg=False):
     win, wo, w1, w2 = _gs_weights(packed_bwd_layer)
     inv_keep = keep_scale(drop_p)
     dym = drop_apply(dx2, drop_p, site0 + 4, seed)
@@ -1064,7 +1064,8 @@ def gs_layer_bwd(dx2, packed_bwd_layer, x, mean1, rstd1, qkv, x1, mean2, rstd2, 
     dqkv = attention_bwd(qkv, key_mask, dao, n_seq, S, 8, scale, drop_p, site0, seed)
     dxn1 = gemm(dqkv, win, b_kc=False)
     dx, dg1, db1 = layernorm_bwd(dxn1, x, mean1, rstd1, gamma1, res=dx1, dgamma=dgamma1, dbeta=dbeta1)
-    return dx, (dx1 if want_dx1 else None), dym, dpre, dx1m, dqkv, dg2, db2, dg1, db1
+    res = (dx, (dx1 if want_dx1 else None), dym, dpre, dx1m, dqkv, dg2, db2, dg1, db1)
+    return res + (bcast_add_bwd(dx1, n_seq, S, drop_p, site0 + 2, seed),) if want_dg else res
 
 
 def keep_scale(p):
