@@ -47,6 +47,8 @@ LN_BWD_MASKED = os.environ.get("DSVG_LN_BWD_MASKED", "1") != "0"
 DEFER_MORE = os.environ.get("DSVG_DEFER_MORE", "1") != "0"
 # round 5: the group-stage backward kernel also emits the conditioning term's gradient (4 bcast_add_bwd launches + 4 dx1 stores less)
 GS_BWD_DG = os.environ.get("DSVG_GS_BWD_DG", "1") != "0"
+# round 5: the argument head's input-gradient product with its reduced dimension padded to the LDS-DMA GEMM's K step
+HEAD_KPAD = os.environ.get("DSVG_HEAD_KPAD", "1") != "0"
 # attention backward of the large stages with the out_proj backward inside (no `dao = dx1m @ Wo` GEMM launch)
 ATTN_BWD_OUTPROJ = os.environ.get("DSVG_ATTN_BWD_OUTPROJ", "1") != "0"
 # ... which only exists on the MFMA attention kernels: the library's A/B knobs that route attention to the VALU kernels
@@ -1106,15 +1108,34 @@ class ArgsHeadLossFn(torch.autograd.Function):
             dsc, = dscs
         g = dsc[0:1].to(torch.float32).contiguous()
         r0, r1 = ctx.rows_used
+        w_ext = None
         if ctx.head_img is not None:
             dl = ops.head_dlogits(xc, ctx.head_img, ctx.b_used, r1 - r0, ctx.C_, target, w, lse, sc, g, 1.0, tok_idx=idx)
         else:
             mult = 4 if logits_c.dtype == torch.float32 else 8
+            # The input-gradient product dl [R, n_out] x W [n_out, 256] reduces over n_out = 257 * slots, no multiple of the LDS-DMA
+            # GEMM's 64-wide K step (it then runs on the register-staged kernel: 67 us of the step).  With the dlogits rows padded to
+            # a multiple of 64 - the pad columns are written as exact zeros - and the weight view extended over the rows that follow
+            # it in the bf16 image (finite numbers times zeros), K is a multiple of 64 and the product is the same sum.
+            wl = rt.w(weight)
+            kp = (r1 - r0 + 63) // 64 * 64
+            st = rt.store
+            # (only the wave-per-token kernel of dsvg_masked_ce_bwd zero-fills the pad columns: its conditions, csrc/loss.hip)
+            tok_kernel = (1 < ctx.group <= 64 and ctx.C_ >= 8 and logits_c.stride(0) % 8 == 0
+                          and logits_c.stride(0) >= r1 - r0 and logits_c.data_ptr() % 16 == 0)
+            if (HEAD_KPAD and tok_kernel and mult == 8 and kp != r1 - r0 and st is not None and st.flat_lp is not None and wl.is_contiguous()
+                    and wl.untyped_storage().data_ptr() == st.flat_lp.untyped_storage().data_ptr()
+                    and wl.storage_offset() + (r0 + kp) * wl.shape[1] <= st.flat_lp.numel()):
+                mult = 64
+                w_ext = torch.as_strided(wl, (kp, wl.shape[1]), (wl.shape[1], 1), wl.storage_offset() + r0 * wl.shape[1])
             dl = ops.masked_ce_bwd(logits_c, target, w, lse, sc, g, 1.0, ctx.C_, ctx.group, pad_to=mult, tok_idx=idx,
                                    logits_compact=True)
         if (r0, r1) == (0, weight.shape[0]):
             dw, db = _wbgrad(rt, weight, bias, dl, xc)
-            dxc = ops.gemm(dl, rt.w(weight), b_kc=False)
+            if w_ext is not None:
+                dxc = ops.gemm(torch.as_strided(dl, (dl.shape[0], w_ext.shape[0]), (dl.stride(0), 1)), w_ext, b_kc=False)
+            else:
+                dxc = ops.gemm(dl, rt.w(weight), b_kc=False)
         else:
             # only the output rows [r0, r1) of the head saw a loss term: their gradient comes from the GEMMs, the rest is 0
             dw, db = rt.grad_out(weight), rt.grad_out(bias)
@@ -1127,7 +1148,10 @@ class ArgsHeadLossFn(torch.autograd.Function):
                 else:
                     ops.gemm(dl, xc, a_kc=False, b_kc=False, out=dw[r0:r1])
                     ops.colsum(dl, out=db[r0:r1])
-            dxc = ops.gemm(dl, rt.w(weight)[r0:r1], b_kc=False)
+            if w_ext is not None:       # (dl's buffer over its whole padded width)
+                dxc = ops.gemm(torch.as_strided(dl, (dl.shape[0], w_ext.shape[0]), (dl.stride(0), 1)), w_ext, b_kc=False)
+            else:
+                dxc = ops.gemm(dl, rt.w(weight)[r0:r1], b_kc=False)
         if dx is None:
             dx = torch.zeros((ctx.rows_full, xc.shape[1]), dtype=xc.dtype, device=xc.device)
             ops.scatter_rows(dxc, idx, dx)

@@ -323,7 +323,9 @@ class ParamStore:
             index[id(p)] = (off, p.numel(), tuple(p.shape))
             off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         total = off
-        flat = torch.zeros(total + 64, dtype=torch.float32, device=device)
+        # slack behind the last parameter (zeros, never trained: their gradient is zero): 64 elements for 16-byte tails, and 63
+        # rows of 256 so that a [k, 256] weight view may be read up to the next multiple of 64 rows (functional.HEAD_KPAD)
+        flat = torch.zeros(total + 64 + 63 * 256, dtype=torch.float32, device=device)
         with torch.no_grad():
             for p in params:
                 o, n, shape = index[id(p)]
