@@ -1065,7 +1065,7 @@ class ArgsHeadLossFn(torch.autograd.Function):
             logits_c = None
             lse, sc = ops.head_lse(xc, ctx.head_img, b_used, n_out, C_, target, w, tok_idx=idx)
         else:
-            mult = 4 if xc.dtype == torch.float32 else 8
+            mult = 4 if xc.dtype == torch.float32 else (64 if HEAD_KPAD else 8)    # (bf16 rows start on 128-byte lines)
             ld = (n_out + mult - 1) // mult * mult
             buf = torch.empty((R, ld), dtype=xc.dtype, device=xc.device)
             logits_c = buf[:, :n_out]
