@@ -216,6 +216,37 @@ def test_gemm_lds_dma_weight_grad(gpu_device, stages, T, n_out, k_in, split):
     _close(outs[stages][1], outs[2][1], 1e-5, "row sums: dot2 vs MFMA-against-ones")
 
 
+def test_deferred_zero_fills_ride_on_the_flush(gpu_device):
+    """ops.zero_ (dsvg_defer_zero, round 5): inside an open deferral scope a fill is queued as a reduction over zero partial rows -
+    the tensor keeps its old contents until flush_deferred() and is zero afterwards, whatever its width and alignment (16-byte
+    multiples, odd widths, a single element); a reduction into an overlapping destination afterwards still wins; outside a scope
+    it is a plain fill."""
+    base = torch.full((3 * 4096 + 64,), 7.0, device=DEV, dtype=torch.float32)
+    views = [base[0:4096], base[4096 + 1:4096 + 1 + 2827], base[2 * 4096 + 3:2 * 4096 + 4], base[3 * 4096:3 * 4096 + 8]]
+    dy, x = _rand(512, 64, dtype=torch.bfloat16, seed=1), _rand(512, 32, dtype=torch.bfloat16, seed=2)
+    want = torch.empty(64, 32, device=DEV, dtype=torch.float32)
+    ops.gemm(dy, x, a_kc=False, b_kc=False, out=want, split_k=4)
+    over = torch.full((64 * 32,), 3.0, device=DEV, dtype=torch.float32)
+    with ops.DEFER:
+        for v in views:
+            assert ops.zero_(v) is v
+        torch.cuda.synchronize()
+        assert all(bool((v == 7.0).all()) for v in views), "a queued fill must not run before the flush"
+        ops.zero_(over)
+        ops.gemm(dy, x, a_kc=False, b_kc=False, out=over.view(64, 32), split_k=4)       # overlapping destination: the queue runs first
+    ops.flush_deferred()
+    torch.cuda.synchronize()
+    assert all(bool((v == 0).all()) for v in views)
+    touched = torch.zeros_like(base, dtype=torch.bool)
+    for lo, n in ((0, 4096), (4097, 2827), (2 * 4096 + 3, 1), (3 * 4096, 8)):
+        touched[lo:lo + n] = True
+    assert bool((base[~touched] == 7.0).all()), "a fill wrote outside its tensor"
+    _close(over.view(64, 32), want, 2e-6, "reduction into a destination with a queued fill")
+    t = torch.ones(100, device=DEV)
+    ops.zero_(t[1:])
+    assert float(t.sum()) == 1.0 and not ops._DEFER.state
+
+
 def test_deferred_reductions_match_immediate_ones(gpu_device):
     """ops.DEFER queues the partial-sum reductions (bf16 / fp32 split-K slices with and without fused row sums, ragged M,
     LayerNorm gamma/beta partials, bias column sums); flush_deferred() performs them, 64 per launch (a 150-entry queue =
