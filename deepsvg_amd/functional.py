@@ -45,6 +45,10 @@ LN_BWD_MASKED = os.environ.get("DSVG_LN_BWD_MASKED", "1") != "0"
 # round 5: the position / embedding tables' gradient reductions (add_pos_bwd, embed_scatter: 6 launches) join the deferred queue,
 # and the library queues segments of any width (csrc/gemm.hip: the heads' 7- and 2827-row gradients: 2 launches); 0 = as before
 DEFER_MORE = os.environ.get("DSVG_DEFER_MORE", "1") != "0"
+# round 5: ONE grouped weight-gradient launch per group-stage STACK (4 layers x 4 products) instead of one per layer
+STACK_GROUP = os.environ.get("DSVG_STACK_GROUP", "1") != "0"
+STACK_GROUP_SLICES = int(os.environ.get("DSVG_STACK_GROUP_SLICES", "8"))    # token slices per output tile of a product in that launch (8 =
+# the per-layer launches' partition: the bf16 slice sums, hence the gradients, are then the same numbers; 4 measured 0.1 % faster)
 # round 5: the group-stage backward kernel also emits the conditioning term's gradient (4 bcast_add_bwd launches + 4 dx1 stores less)
 GS_BWD_DG = os.environ.get("DSVG_GS_BWD_DG", "1") != "0"
 # round 5: the argument head's input-gradient product with its reduced dimension padded to the LDS-DMA GEMM's K step
@@ -82,10 +86,24 @@ class Runtime:
         # OUTPUT to that layer's backward, which would otherwise re-read it once more only to apply the mask (LN_BWD_MASKED)
         self.masked = {}
         self.last_layer_gs = False
+        self.stack_group = None
 
     def deferring(self):
         """context manager around launches whose reductions write parameter gradients"""
         return ops.DEFER if self.defer else _NULL_CTX
+
+    def stack_group_begin(self):
+        """open ONE grouped weight-gradient launch over the group-stage layers of a stack (closed by the stack's first layer,
+        the last one of the backward pass) -> the list that keeps the queued products' operands alive until the launch"""
+        if self.stack_group is None:
+            ops.GROUP.__enter__()
+            self.stack_group = []
+        return self.stack_group
+
+    def stack_group_end(self):
+        if self.stack_group is not None:
+            ops.GROUP.__exit__(None, None, None)        # the launch; the operands may go now
+            self.stack_group = None
 
     def deferring_tables(self):
         """the same around the embedding / position tables' gradients (round 5; DSVG_DEFER_MORE=0: reduced on the spot)"""
@@ -655,10 +673,12 @@ class LayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rt, x, key_mask, z, l, n_seq, S, n_heads, drop_rate, site0,
                 n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off=None, live=None,
-                tiles=None, causal=False, mask_below=None):
-        """mask_below: site of the FFN residual dropout of the layer that produced `x` (same rate), or None"""
+                tiles=None, causal=False, mask_below=None, first_in_stack=True):
+        """mask_below: site of the FFN residual dropout of the layer that produced `x` (same rate), or None;
+        first_in_stack: layer 0 of its stack (the last one of the backward pass: it closes the stack's grouped launch)"""
         p = rt.p(drop_rate)
         ctx.mask_below = mask_below if (LN_BWD_MASKED and mask_below is not None and p > 0) else None
+        ctx.first_in_stack = bool(first_in_stack)
         rt.last_layer_gs = False
         d = x.shape[1]
         scale = float(d // n_heads) ** -0.5
@@ -827,8 +847,13 @@ class LayerFn(torch.autograd.Function):
                     dz = ops.gemm(dg, rt.w(wg), b_kc=False)
             # the layer's weight-gradient GEMMs: independent of each other, 64-256 workgroups each - one grouped launch
             # (32 - 36 output tiles of 128 x 128 between them: 8 token slices each fill the chip once, together)
-            gb = (lambda w_: 8 * -(-w_.shape[0] // 128) * -(-w_.shape[1] // 128)) if GROUP_WGRAD else (lambda w_: None)
-            with rt.grouping():
+            nsl = STACK_GROUP_SLICES if (STACK_GROUP and GROUP_WGRAD and rt.defer) else 8
+            gb = (lambda w_: nsl * -(-w_.shape[0] // 128) * -(-w_.shape[1] // 128)) if GROUP_WGRAD else (lambda w_: None)
+            # STACK_GROUP (round 5): the products of ALL the stack's layers wait for one launch (16 of them for 4 layers: the
+            # launch's table size) instead of one launch per layer.  Their results are only read after the trainer's flush
+            # (rt.defer), their operands are kept alive by the list until the launch
+            keep = rt.stack_group_begin() if (STACK_GROUP and GROUP_WGRAD and rt.defer) else None
+            with (rt.grouping() if keep is None else _NULL_CTX):
                 with ops.tag("ffn"):
                     dw2, db2 = _wbgrad(rt, w2, b2, dym, h, gb(w2))
                     dw1, db1 = _wbgrad(rt, w1, b1, dpre, xn2, gb(w1))
@@ -836,9 +861,13 @@ class LayerFn(torch.autograd.Function):
                     dwg, dbg = _wbgrad(rt, wg, bg, dg, z, gb(wg))
                 dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao, gb(wo))
                 dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1, gb(win))
+            if keep is not None:
+                keep += [dym, h, dpre, xn2, dx1m, ao, dqkv, xn1, dg, z]
+                if ctx.first_in_stack:
+                    rt.stack_group_end()
             return (None, dx, None, dz, None, None, None, None, None, None,
                     dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, None, None, None, None, None,
-                    None, None)
+                    None, None, None)
         # (round 3 measured, round 4 removed: the layer's four token-reducing weight-gradient GEMMs as one grouped launch at the
         # end of its backward pass - slower, each product right behind the launch that wrote its operand hits the memory-side
         # cache - and the same GEMMs queued onto a second stream beside the group stages - slower inside the step's hipGraph)
@@ -983,7 +1012,7 @@ class LayerFn(torch.autograd.Function):
             _hand_masked(rt, dx, out[3], p, ctx.mask_below)     # (the layer below takes it by dx's address)
         return (None, dx, None, dz, dl, None, None, None, None, None,
                 dn1w, dn1b, dwin, dbin, dwo, dbo, dn2w, dn2b, dw1, db1, dw2, db2, dwg, dbg, dwg2, dbg2, None, None, None,
-                None, None)
+                None, None, None)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -718,7 +718,7 @@ class SVGTransformer(nn.Module):
                 L.linear_global2.weight if has_l else None, L.linear_global2.bias if has_l else None,
                 seq_off, live, tiles, causal,
                 # the layer below reads this layer's input gradient through the mask of ITS FFN residual dropout (site + 4)
-                (site + 8 * (i - 1) + 4) if i > 0 else None)
+                (site + 8 * (i - 1) + 4) if i > 0 else None, i == 0)
         n = len(stack.layers)
         return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps, live,
                                     (cfg.dropout, site + 8 * (n - 1) + 4) if (n > 0 and not rt.last_layer_gs) else None)

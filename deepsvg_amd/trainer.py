@@ -252,6 +252,9 @@ class TrainStep:
         finally:
             model._decoder_grads_ready = None
             model._defer_wgrad = False
+            rt = getattr(model, "_rt", None)
+            if rt is not None:
+                rt.stack_group_end()        # (a stack's grouped weight-gradient launch left open by an interrupted backward)
             ops.flush_deferred()
         # parameters without a gradient in THIS call (torch's AdamW skips them; which ones can depend on the call shape - with /
         # without label, relative targets): checked on every eager step and inside every capture (a replay runs no Python).
