@@ -11,6 +11,6 @@ bash scripts/gpu_step_pmc.sh r05_step_pmc > gpurun_out/r05_step_pmc.txt 2>&1; he
 bash scripts/gpu_clock.sh > gpurun_out/r05_clock.txt 2>&1; head -8 gpurun_out/clock_pmc_summary.csv | cut -c1-200
 ( time timeout 600 env DSVG_FORCE_DDP=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29713 bench.py --gpus 1 --no-cpu-baseline --no-fp32 --no-roofline ) > gpurun_out/r05_bench_rccl_one_rank.log 2>&1
 grep '^{' gpurun_out/r05_bench_rccl_one_rank.log | cut -c1-200
-# net effect of the round's launch-count changes on this box (all four knobs back to the round-4 behaviour vs the defaults)
-bash scripts/ab.sh "DSVG_PACK_ONE=0 DSVG_DEFER_MORE=0 DSVG_GS_BWD_DG=0 DSVG_LN_BWD_MASKED=0" "DSVG_PACK_ONE=1" > gpurun_out/r05_ab_round5_launch_changes.log 2>&1
+# net effect of the round's step-level changes on this box (all six knobs back to the round-4 behaviour vs the defaults)
+bash scripts/ab.sh "DSVG_PACK_ONE=0 DSVG_DEFER_MORE=0 DSVG_GS_BWD_DG=0 DSVG_LN_BWD_MASKED=0 DSVG_STACK_GROUP=0 DSVG_HEAD_KPAD=0" "DSVG_PACK_ONE=1" > gpurun_out/r05_ab_round5_launch_changes.log 2>&1
 cat gpurun_out/r05_ab_round5_launch_changes.log
