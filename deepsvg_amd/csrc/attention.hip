@@ -512,7 +512,7 @@ extern "C" int dsvg_attention_bwd_outproj(const void* qkv, const uint64_t* key_m
                                    8, scale, drop_p, drop_site, seed, (hipStream_t)stream, wo_packed_bwd);
 }
 
-extern "C" int64_t dsvg_attn_pack_bwd_elems(int32_t n_layers) { return (int64_t)n_layers * 128 * 512; }
+extern "C" int64_t dsvg_attn_pack_bwd_elems(int32_t n_layers) { return (int64_t)n_layers * 512 * 512; }
 extern "C" int dsvg_attn_pack_bwd(const float* flat_f32, const int64_t* offs, int32_t n_layers, void* packed_bwd, void* stream) {
     DSVG_CHECK_ARG(flat_f32 && offs && packed_bwd && n_layers > 0 && ((uintptr_t)packed_bwd & 15) == 0, "attn_pack_bwd: bad args");
     return dsvg_attn_pack_bwd_launch(flat_f32, offs, n_layers, packed_bwd, (hipStream_t)stream);

@@ -527,14 +527,15 @@ int dsvg_attention_bwd_mfma(const void* qkv, const uint64_t* key_mask, const int
     return 0;
 }
 
-// packed_bwd[layer][head 8][K step 16][lane l][e] = Wo[16 ks + 8 (l >> 5) + e][32 head + (l & 31)]: the A fragments of
-// dO^T = Wo^T-columns x dx1m^T per head (offs[layer][1] = element offset of out_proj.weight [256, 256] in `flat`)
+// packed_bwd[layer]: fragments 0 .. 127 = [head 8][K step 16][lane l][e] = Wo[16 ks + 8 (l >> 5) + e][32 head + (l & 31)], the A
+// fragments of dO^T = Wo^T-columns x dx1m^T per head (offs[layer][1] = element offset of out_proj.weight [256, 256] in `flat`);
+// fragments 128 .. 511 = in_proj_weight^T for attn_bwd_dx.hip (layouts: pack_images.h)
 __global__ __launch_bounds__(256) void attn_pack_bwd_kernel(const float* __restrict__ flat, const int64_t* __restrict__ offs,
                                                             int n_layers, bf16_t* __restrict__ img) {
     dsvg_pack::attn_bwd_slot((long long)blockIdx.x * 256 + threadIdx.x, flat, offs, n_layers, img);      // (pack_images.h)
 }
 int dsvg_attn_pack_bwd_launch(const float* flat, const int64_t* offs, int n_layers, void* img, hipStream_t st) {
-    const long long n = (long long)n_layers * 128 * 64;
+    const long long n = (long long)n_layers * dsvg_pack::ATTN_BWD_SLOTS;
     hipLaunchKernelGGL(attn_pack_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat, offs, n_layers,
                        (bf16_t*)img);
     DSVG_LAUNCH_CHECK("attn_pack_bwd");

@@ -6,7 +6,7 @@ OUT=../_lib
 mkdir -p "$OUT" obj
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -Wno-unused-value"
 pids=()
-for f in gemm gemm_bf16 gemm_bf16_glds layernorm attention attention_mfma embed loss optim assemble match long_seq ffn_fused attn_fused group_stage head_fused pack_images; do
+for f in gemm gemm_bf16 gemm_bf16_glds layernorm attention attention_mfma embed loss optim assemble match long_seq ffn_fused attn_fused attn_bwd_dx group_stage head_fused pack_images; do
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ dsvg_common.h -nt obj/$f.o ] || [ gemm_common.h -nt obj/$f.o ] || [ gemm_bf16.h -nt obj/$f.o ] || [ fused_common.h -nt obj/$f.o ] || [ pack_images.h -nt obj/$f.o ] || [ ../../include/dsvg.h -nt obj/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o obj/$f.o &
     pids+=($!)

@@ -142,22 +142,38 @@ __device__ __forceinline__ void attn_slot(long long gid, const float* __restrict
     *reinterpret_cast<uint4*>(img + ((size_t)layer * ATTN_IMG_FRAGS + f) * 512 + l * 8) = pack8(v);
 }
 
-// ---- attention backward with the out_proj backward inside (attention_mfma.hip) ----------------------------------------
-// packed_bwd[layer][head 8][K step 16][lane l][e] = Wo[16 ks + 8 (l >> 5) + e][32 head + (l & 31)]: the A fragments of
-// dO^T = Wo^T-columns x dx1m^T per head (offs[layer][1] = element offset of out_proj.weight [256, 256] in `flat`)
-constexpr int ATTN_BWD_SLOTS = 128 * 64;
+// ---- attention backward (attention_mfma.hip, attn_bwd_dx.hip) ---------------------------------------------------------
+// fragments 0 .. 127: packed_bwd[layer][head 8][K step 16][lane l][e] = Wo[16 ks + 8 (l >> 5) + e][32 head + (l & 31)]: the A
+// fragments of dO^T = Wo^T-columns x dx1m^T per head (offs[layer][1] = element offset of out_proj.weight [256, 256] in `flat`)
+// fragments 128 .. 511 (round 6): in_proj_weight^T as the K-step-major A fragments of dxn1^T = Win^T x dqkv^T
+// (attn_bwd_dx_kernel): fragment 128 + 16 c + 2 t + ks2 (K step c of 32 = 24 steps, output tile t of 32 columns),
+// lane l = (i = l & 31, half = l >> 5), slot e:  Win[32 c + 16 ks2 + 8 half + e][32 t + i]   (offs[layer][0] = in_proj_weight)
+constexpr int ATTN_BWD_FRAGS = 512;
+constexpr int ATTN_BWD_WO_FRAGS = 128;
+constexpr int ATTN_BWD_SLOTS = ATTN_BWD_FRAGS * 64;
 __device__ __forceinline__ void attn_bwd_slot(long long gid, const float* __restrict__ flat, const int64_t* __restrict__ offs,
                                               int n_layers, bf16_t* __restrict__ img) {
     if (gid >= (long long)n_layers * ATTN_BWD_SLOTS) return;
     const int layer = (int)(gid / ATTN_BWD_SLOTS);
     const int s = (int)(gid % ATTN_BWD_SLOTS);
-    const int l = s & 63, f = s >> 6, hh = f >> 4, ks = f & 15;
-    const float* Wo = flat + offs[layer * 2 + 1];
+    const int l = s & 63, f = s >> 6;
     uint32_t w[4];
+    if (f < ATTN_BWD_WO_FRAGS) {
+        const int hh = f >> 4, ks = f & 15;
+        const float* Wo = flat + offs[layer * 2 + 1];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int k = 16 * ks + 8 * (l >> 5) + 2 * e;
-        w[e] = f2bf_pk(Wo[(size_t)k * 256 + 32 * hh + (l & 31)], Wo[(size_t)(k + 1) * 256 + 32 * hh + (l & 31)]);
+        for (int e = 0; e < 4; ++e) {
+            const int k = 16 * ks + 8 * (l >> 5) + 2 * e;
+            w[e] = f2bf_pk(Wo[(size_t)k * 256 + 32 * hh + (l & 31)], Wo[(size_t)(k + 1) * 256 + 32 * hh + (l & 31)]);
+        }
+    } else {
+        const int g = f - ATTN_BWD_WO_FRAGS, c = g >> 4, t = (g & 15) >> 1, ks2 = g & 1;
+        const float* Win = flat + offs[layer * 2 + 0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 32 * c + 16 * ks2 + 8 * (l >> 5) + 2 * e;
+            w[e] = f2bf_pk(Win[(size_t)k * 256 + 32 * t + (l & 31)], Win[(size_t)(k + 1) * 256 + 32 * t + (l & 31)]);
+        }
     }
     *reinterpret_cast<uint4*>(img + gid * 8) = make_uint4(w[0], w[1], w[2], w[3]);
 }

@@ -59,6 +59,10 @@ ATTN_BWD_OUTPROJ = os.environ.get("DSVG_ATTN_BWD_OUTPROJ", "1") != "0"
 # (dsvg_attention_mfma_ok, csrc/attention_mfma.hip) must switch it off too instead of failing the backward pass
 _ATTN_VALU = os.environ.get("DSVG_ATTN_VALU") is not None
 _ATTN_MFMA_MIN_S = int(os.environ.get("DSVG_ATTN_MFMA_MIN_S", "2"))
+# round 6: the attention half's input gradient (dqkv . W_in + LayerNorm backward + residual) as one launch, csrc/attn_bwd_dx.hip
+# (0: the GEMM + dsvg_layernorm_bwd pair of round 5); below ATTN_BWD_DX_MIN_ROWS rows the pair stays
+ATTN_BWD_DX = os.environ.get("DSVG_ATTN_BWD_DX", "0") != "0"
+ATTN_BWD_DX_MIN_ROWS = int(os.environ.get("DSVG_ATTN_BWD_DX_MIN_ROWS", "8192"))
 # training forward of a large dense stage: sequences beyond a multiple of SEQ_ROUND (one round of the chip for the fused
 # attention kernel: 256 CUs x 8 sequences) run on the group-stage layer kernel when there are at most this many (0: never)
 GS_REMAINDER = int(os.environ.get("DSVG_GS_REMAINDER", "512"))
@@ -996,15 +1000,26 @@ class LayerFn(torch.autograd.Function):
                                          tiles=ctx.tiles)
         del dx1m
         dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1)
-        dxn1 = ops.gemm(dqkv, rt.w(win), b_kc=False)
         dx_out = None
         if live is not None:
             dx_full = torch.empty((full_rows, x.shape[1]), dtype=x.dtype, device=x.device)
             dx_out = dx_full[:x.shape[0]]
         mk = (p, ctx.mask_below, rt.seed) if (ctx.mask_below is not None and p > 0) else None
+        wib = None
+        if (ATTN_BWD_DX and rt.store is not None and x.dtype == torch.bfloat16 and x.shape[1] == 256 and H == 8
+                and x.shape[0] >= ATTN_BWD_DX_MIN_ROWS and mean1 is not None and dx1.is_contiguous()):
+            wib = rt.store.attn_bwd(win)
         with rt.deferring():
-            out = ops.layernorm_bwd(dxn1, x, mean1, rstd1, n1w.detach(), res=dx1, dx=dx_out,
-                                    dgamma=rt.grad_out(n1w), dbeta=rt.grad_out(n1b), masked=mk)
+            if wib is not None:
+                # round 6: dxn1 = dqkv . W_in, the LayerNorm backward and the residual add in ONE launch (csrc/attn_bwd_dx.hip):
+                # the [rows, 256] intermediate is never written, one launch less per layer
+                with ops.tag("attn"):
+                    out = ops.attn_bwd_dx(dqkv, x, mean1, rstd1, n1w.detach(), dx1, wib, dx=dx_out,
+                                          dgamma=rt.grad_out(n1w), dbeta=rt.grad_out(n1b), masked=mk)
+            else:
+                dxn1 = ops.gemm(dqkv, rt.w(win), b_kc=False)
+                out = ops.layernorm_bwd(dxn1, x, mean1, rstd1, n1w.detach(), res=dx1, dx=dx_out,
+                                        dgamma=rt.grad_out(n1w), dbeta=rt.grad_out(n1b), masked=mk)
             dx, dn1w, dn1b = out[:3]
         if live is not None:
             dx = dx_full

@@ -14,7 +14,7 @@ DSVG_F32 = 0
 DSVG_BF16 = 1
 # == DSVG_ABI_VERSION of include/dsvg.h at the time SIGNATURES below was written: load() refuses a library built from another
 # header (a stale .so with the old argument lists would otherwise be called with a stream where a size is expected)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_i32, c_i64, c_u32, c_f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_float
 vp = C.c_void_p
@@ -130,6 +130,8 @@ SIGNATURES = {
     "dsvg_ffn_pack": (c_i32, [vp, vp, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp]),
     "dsvg_ffn_fwd": (c_i32, [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_f32, c_f32, c_u32, c_u32, vp, c_i32, vp]),
     "dsvg_ffn_bwd": (c_i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_f32, c_f32, c_u32, c_u32, vp, vp]),
+    "dsvg_attn_bwd_dx_workspace_bytes": (c_i64, [c_i64]),
+    "dsvg_attn_bwd_dx": (c_i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i32, c_i64, vp, c_i64, vp, c_f32, c_u32, vp, vp]),
     "dsvg_ffn_bwd_dx": (c_i32, [vp, vp, vp, vp, vp, c_i64, c_f32, vp, c_f32, c_u32, vp, vp]),
     "dsvg_ffn_wgrad_finish": (c_i32, [vp] * 12),
     "dsvg_probe_trread": (c_i32, [vp, vp, vp]),

@@ -528,7 +528,7 @@ def attention_bwd(qkv, key_mask, dout, n_seq, S, n_heads, scale, drop_p=0.0, dro
     return dqkv
 
 
-ATTN_BWD_LAYER_ELEMS = 128 * 512    # bf16 elements of one layer's packed out_proj^T image (attn_pack_bwd)
+ATTN_BWD_LAYER_ELEMS = 512 * 512    # bf16 elements of one layer's backward image (attn_pack_bwd): out_proj^T | in_proj^T fragments
 
 
 def attn_pack_bwd(flat, offs, n_layers, packed=None):
@@ -565,6 +565,45 @@ def attention_bwd_outproj(qkv, key_mask, dx1m, wo_packed_bwd, n_seq, S, scale, d
 # ------------------------------------------------------------------------------------------------
 # masks / embedding / positional / pooling
 # ------------------------------------------------------------------------------------------------
+def attn_bwd_dx(dqkv, x, mean, rstd, gamma, res, packed_bwd_layer, *, dx=None, dgamma=None, dbeta=None, accumulate=False,
+                masked=None):
+    """dx = res + LayerNorm'(dqkv . in_proj_weight), dgamma, dbeta in ONE launch (csrc/attn_bwd_dx.hip): what
+    gemm(dqkv, W_in, b_kc=False) + layernorm_bwd(..., res=res) compute, without the [rows, 256] intermediate.
+    masked = (p, site, seed): -> (dx, dgamma, dbeta, dxm) with dxm = drop_apply(dx, p, site, seed) from the same launch."""
+    _chk(dqkv, x, mean, rstd, gamma, res, packed_bwd_layer, dx, dgamma, dbeta)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
+    rows = x.shape[0]
+    assert dqkv.dtype == x.dtype and tuple(dqkv.shape) == (rows, 768) and dqkv.is_contiguous()
+    assert res.dtype == x.dtype and res.shape == x.shape and res.is_contiguous()
+    assert mean.dtype == torch.float32 and rstd.dtype == torch.float32 and mean.numel() >= rows and rstd.numel() >= rows
+    assert gamma.dtype == torch.float32 and gamma.numel() == 256
+    assert packed_bwd_layer.numel() == ATTN_BWD_LAYER_ELEMS and packed_bwd_layer.is_contiguous()
+    if dx is None:
+        dx = torch.empty_like(x)
+    assert dx.dtype == x.dtype and dx.shape == x.shape and dx.is_contiguous()
+    if dgamma is None:
+        dgamma = torch.empty(256, dtype=torch.float32, device=x.device)
+    if dbeta is None:
+        dbeta = torch.empty(256, dtype=torch.float32, device=x.device)
+    dxm, mp, msite, mseed = None, 0.0, 0, None
+    if masked is not None:
+        mp, msite, mseed = float(masked[0]), int(masked[1]), masked[2]
+        _chk(mseed)
+        dxm = torch.empty_like(dx)
+    L = _l.load()
+    ws = _ws(L.dsvg_attn_bwd_dx_workspace_bytes(rows), x.device)
+    ev = _prof_begin()
+    _l.check(L.dsvg_attn_bwd_dx(dqkv.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                res.data_ptr(), packed_bwd_layer.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                int(accumulate), rows, ws.data_ptr(), ws.numel() * 4, _p(dxm), mp, msite,
+                                _p(mseed) if mp > 0 else None, _stream()), "dsvg_attn_bwd_dx")
+    _prof_end(ev, 2.0 * 768 * 256 * rows, (1536.0 + 3 * 512 + (512 if dxm is not None else 0)) * rows,
+              dict(op="attn_bwd_dx", rows=rows))
+    if masked is not None:
+        return dx, dgamma, dbeta, dxm
+    return dx, dgamma, dbeta
+
+
 def seq_lens(commands, S, eos_id=4):
     """commands float32 [n_seq, S] -> int32 [n_seq]: index of the first EOS (S if none) = number of valid keys"""
     _chk(commands)

@@ -34,8 +34,10 @@ extern "C" {
  * built with; a caller compiled against another header must refuse to run (deepsvg_amd/lib.py does).
  * 3: dsvg_latent_chain_fwd / dsvg_latent_chain_bwd added.  4: seq_add_ld argument of dsvg_attn_block_fwd / dsvg_gs_layer_fwd.
  * 5 (round 5): dsvg_sample_rows / dsvg_head_sample (categorical sampling on the device), dsvg_layernorm_bwd_masked added.
- * 6: dsvg_pack_images, dsvg_defer_zero added; dg argument of dsvg_gs_layer_bwd. */
-#define DSVG_ABI_VERSION 6
+ * 6: dsvg_pack_images, dsvg_defer_zero added; dg argument of dsvg_gs_layer_bwd.
+ * 7 (round 6): dsvg_attn_bwd_dx added; a layer of dsvg_attn_pack_bwd grew from 128 to 512 fragments (in_proj_weight^T behind
+ *    out_proj.weight^T). */
+#define DSVG_ABI_VERSION 7
 
 const char* dsvg_last_error(void);
 int dsvg_version(void);
@@ -359,11 +361,27 @@ int dsvg_attention_causal_fwd(int32_t dtype, const void* qkv, const uint64_t* ke
  * dO = dx1m . Wo is formed per tile on chip: replaces the `dao = dx1m @ out_proj.weight` GEMM launch (its 512 B / token
  * written and re-read) in front of dsvg_attention_bwd (autograd of layers/functional.py:248-249 + :197-247).
  * dsvg_attn_pack_bwd: offs[layer][1] = element offset of out_proj.weight in flat_f32 (the offs table of dsvg_attn_pack);
- * packed_bwd: dsvg_attn_pack_bwd_elems(n_layers) bf16 elements. */
+ * packed_bwd: dsvg_attn_pack_bwd_elems(n_layers) bf16 elements (512 x 512 per layer: 128 fragments of out_proj.weight^T, then
+ * 384 fragments of in_proj_weight^T for dsvg_attn_bwd_dx; offs[layer][0] = element offset of in_proj_weight). */
 int dsvg_attention_bwd_outproj(const void* qkv, const uint64_t* key_mask, const int32_t* seq_off, int64_t total_rows,
                                const int32_t* tile_first, const void* dx1m, const void* wo_packed_bwd, void* dqkv,
                                int64_t n_seq, int32_t S, float scale, float drop_p, uint32_t drop_site,
                                const uint64_t* seed, void* stream);
+/* Input gradient of the attention sub-block in ONE launch (bf16, d_model 256; csrc/attn_bwd_dx.hip):
+ *     dx = res + LayerNorm'( dqkv . in_proj_weight ),   dgamma = sum_t dxn1 * xh,   dbeta = sum_t dxn1
+ * with dxn1 = dqkv . in_proj_weight [rows, 256] never written: replaces the input-gradient dsvg_gemm behind dsvg_attention_bwd
+ * / dsvg_attention_bwd_outproj and the dsvg_layernorm_bwd (_masked) of norm1 behind it - autograd of
+ * deepsvg/model/layers/improved_transformer.py:43-45 / :127-129 (norm1 + in_proj of layers/functional.py:92).
+ * dqkv [rows, 768], x / res / dx [rows, 256] bf16 row-major; mean / rstd: the statistics dsvg_attn_block_fwd /
+ * dsvg_layernorm_fwd stored; gamma fp32 [256]; packed_bwd_layer: one layer of dsvg_attn_pack_bwd (fragments 128 .. 511 =
+ * in_proj_weight^T); dgamma / dbeta fp32 [256], written (accumulate = 0) or added to, through the deterministic partial
+ * reduction (queued inside a dsvg_defer_scope); workspace: dsvg_attn_bwd_dx_workspace_bytes(rows).
+ * dx_masked (optional): second output = dsvg_drop_apply(dx, drop_p, drop_site) as in dsvg_layernorm_bwd_masked. */
+int64_t dsvg_attn_bwd_dx_workspace_bytes(int64_t rows);
+int dsvg_attn_bwd_dx(const void* dqkv, const void* x, const float* mean, const float* rstd, const float* gamma,
+                     const void* res, const void* packed_bwd_layer, void* dx, float* dgamma, float* dbeta,
+                     int32_t accumulate, int64_t rows, float* workspace, int64_t workspace_bytes, void* dx_masked,
+                     float drop_p, uint32_t drop_site, const void* seed, void* stream);
 int64_t dsvg_attn_pack_bwd_elems(int32_t n_layers);
 int dsvg_attn_pack_bwd(const float* flat_f32, const int64_t* offs, int32_t n_layers, void* packed_bwd, void* stream);
 int dsvg_attention_causal_bwd(int32_t dtype, const void* qkv, const uint64_t* key_mask, const void* dout, void* dqkv,

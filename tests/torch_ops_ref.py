@@ -915,24 +915,35 @@ def attn_pack(flat, offs, n_layers, packed=None):
     return packed
 
 
-ATTN_BWD_LAYER_ELEMS = 128 * 512
+ATTN_BWD_LAYER_ELEMS = 512 * 512    # emulated image: out_proj.weight [256, 256] | in_proj_weight [768, 256], bf16
 
 
 def attn_pack_bwd(flat, offs, n_layers, packed=None):
-    """emulated image of a layer: out_proj.weight itself (bf16, row-major [256, 256])"""
+    """emulated image of a layer: out_proj.weight (bf16, row-major [256, 256]) followed by in_proj_weight ([768, 256])"""
     if packed is None:
         packed = torch.empty(n_layers * ATTN_BWD_LAYER_ELEMS, dtype=torch.bfloat16, device=flat.device)
     for i in range(n_layers):
-        oo = int(offs[i][1])
-        packed[i * ATTN_BWD_LAYER_ELEMS:(i + 1) * ATTN_BWD_LAYER_ELEMS] = flat[oo:oo + 65536].to(torch.bfloat16)
+        oi, oo = int(offs[i][0]), int(offs[i][1])
+        lay = packed[i * ATTN_BWD_LAYER_ELEMS:(i + 1) * ATTN_BWD_LAYER_ELEMS]
+        lay[:65536] = flat[oo:oo + 65536].to(torch.bfloat16)
+        lay[65536:] = flat[oi:oi + 768 * 256].to(torch.bfloat16)
     return packed
 
 
 def attention_bwd_outproj(qkv, key_mask, dx1m, wo_packed_bwd, n_seq, S, scale, drop_p=0.0, drop_site=0, seed=None, seq_off=None,
                           tiles=None):
     """the two launches it replaces: dao = dx1m @ Wo (rounded to the storage dtype), then attention_bwd"""
-    dao = (_f(dx1m) @ _f(wo_packed_bwd.view(256, 256))).to(qkv.dtype)
+    dao = (_f(dx1m) @ _f(wo_packed_bwd[:65536].view(256, 256))).to(qkv.dtype)
     return attention_bwd(qkv, key_mask, dao, n_seq, S, 8, scale, drop_p, drop_site, seed, seq_off=seq_off, tiles=tiles)
+
+
+def attn_bwd_dx(dqkv, x, mean, rstd, gamma, res, packed_bwd_layer, *, dx=None, dgamma=None, dbeta=None, accumulate=False,
+                masked=None):
+    """the two launches it replaces, without the bf16 rounding of the intermediate: dxn1 = dqkv @ W_in (fp32), then layernorm_bwd"""
+    rows = x.shape[0]
+    dxn1 = _f(dqkv) @ _f(packed_bwd_layer[65536:].view(768, 256))
+    return layernorm_bwd(dxn1, _f(x), mean[:rows], rstd[:rows], gamma, res=_f(res), dgamma=dgamma, dbeta=dbeta,
+                         accumulate=accumulate, dx=dx if dx is not None else torch.empty_like(x), masked=masked)
 
 
 # ------------------------------------------------------------------------------------------------
