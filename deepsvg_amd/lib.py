@@ -131,6 +131,7 @@ SIGNATURES = {
     "dsvg_ffn_fwd": (c_i32, [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_f32, c_f32, c_u32, c_u32, vp, c_i32, vp]),
     "dsvg_ffn_bwd": (c_i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_f32, c_f32, c_u32, c_u32, vp, vp]),
     "dsvg_attn_bwd_dx_workspace_bytes": (c_i64, [c_i64]),
+    "dsvg_attn_bwd_dx_debug_clock": (c_i32, [vp]),
     "dsvg_attn_bwd_dx": (c_i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i32, c_i64, vp, c_i64, vp, c_f32, c_u32, vp, vp]),
     "dsvg_ffn_bwd_dx": (c_i32, [vp, vp, vp, vp, vp, c_i64, c_f32, vp, c_f32, c_u32, vp, vp]),
     "dsvg_ffn_wgrad_finish": (c_i32, [vp] * 12),

@@ -378,6 +378,10 @@ int dsvg_attention_bwd_outproj(const void* qkv, const uint64_t* key_mask, const 
  * reduction (queued inside a dsvg_defer_scope); workspace: dsvg_attn_bwd_dx_workspace_bytes(rows).
  * dx_masked (optional): second output = dsvg_drop_apply(dx, drop_p, drop_site) as in dsvg_layernorm_bwd_masked. */
 int64_t dsvg_attn_bwd_dx_workspace_bytes(int64_t rows);
+/* development probe of dsvg_attn_bwd_dx: buf = device buffer of (workgroups x 4 waves x 8) uint64 stamps of the 100 MHz
+ * counter (wave start, first rows staged, K loop done, pass 1 done, sums published, stores issued) or NULL (off);
+ * scripts/attn_bwd_dx_probe.py */
+int dsvg_attn_bwd_dx_debug_clock(void* buf);
 int dsvg_attn_bwd_dx(const void* dqkv, const void* x, const float* mean, const float* rstd, const float* gamma,
                      const void* res, const void* packed_bwd_layer, void* dx, float* dgamma, float* dbeta,
                      int32_t accumulate, int64_t rows, float* workspace, int64_t workspace_bytes, void* dx_masked,
