@@ -155,7 +155,16 @@ def cpu_baseline(cfg, sd, batch, dropout):
                                         "the build container; the port on that host and batch: 195.9 ms/step)")
     except Exception:
         pass
+    # kind "reference" would need the reference's own deepsvg package on this host: it is mounted in the build container only
+    # (the bench may not read /root/reference at run time, and no copy of its sources travels); the port is bit-identical to it
+    # (tests/golden/make_golden.py: logits, losses and gradients of the real reference == the port's, distance 0)
+    have_ref = os.path.isdir("/root/reference/deepsvg")
     return {"value": round(best[0], 2), "unit": "icons/s", "cores": best[1], "host_cores": ncores, "kind": "port",
+            "note": ("kind is 'port': the unmodified reference is not on this host (" +
+                     ("/root/reference exists here but the bench contract forbids reading it at run time" if have_ref
+                      else "/root/reference does not exist on the GPU box") +
+                     "); the port is pinned bit-for-bit to the reference by the golden fixtures, and the reference's own "
+                     "train.py at BASELINE configs[0] was timed in the build container: c1_batch2.reference_train_py"),
             "dropout": dropout, "by_threads": legs,
             "c1_batch2": {"value": round(v2, 2), "unit": "icons/s", "cores": c2, "steps": n2,
                           "ms_per_step": round(dt2 * 1e3, 1),
@@ -240,6 +249,48 @@ def dense_layout_leg(cfg, sd_cpu, batches, device, steps=5):
             "what": "every row of the reference's padded (N, G, S) layout is computed, forward and backward"}
 
 
+def ddp_one_rank_leg(cfg, sd_cpu, batches, device, a, use_graph, steps=20):
+    """TrainStep's data-parallel path over a one-rank RCCL process group on this GPU: ms/step and the exposed time of the
+    gradient all-reduce (HIP events, deepsvg_amd/trainer.py `time_allreduce`)"""
+    import socket
+    import deepsvg_amd
+    from deepsvg_amd.trainer import TrainStep
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+    try:
+        m = deepsvg_amd.SVGTransformer(cfg)
+        m.load_state_dict(sd_cpu)
+        m.to(device).set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+        m.pack_encoder = bool(a.pack_encoder)
+        m.train()
+        t = TrainStep(m, deepsvg_amd.SVGLoss(cfg).to(device), lr=1e-3, grad_clip=1.0, use_graph=use_graph, force_ddp=True)
+        t.inputs_resident = True
+        t.time_allreduce = True
+        n_b = len(batches)
+        for k in range(n_b):
+            t.step(*batches[k])
+        for i in range(3):
+            t.step(*batches[i % n_b])
+        torch.cuda.synchronize()
+        t.allreduce_events.clear()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            t.step(*batches[(3 + i) % n_b])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        evs = t.allreduce_events[-steps:]
+        ar = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(len(evs), 1)
+        return {"ranks": t.rccl_ranks(), "allreduce_ms": round(ar, 4), "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+                "gradient_bytes": int(m.store.grad_buffer(0).numel()) * (2 if t.allreduce_bf16 else 4),
+                "launch": "hipGraph replay, collectives outside the graph" if use_graph else "eager, overlapped decoder bucket",
+                "measured_on": "one-rank RCCL group on this GPU (the data-parallel code path of an N-GPU rank, without the wire); "
+                               "allreduce_ms = HIP events around the gradient all-reduce, mean of the timed steps"}
+    finally:
+        dist.destroy_process_group()
+
+
 def secondary_legs(device):
     """BASELINE configs[3] and [4] as short legs (scripts/secondary_bench.py has the long form): C4 one-stage train step
     (OneStageOneShot, max_total_len 50, 512 icons), C5 decode-only of 8192 latents - one-shot arg-max (hierarchical_ordered)
@@ -273,7 +324,23 @@ def secondary_legs(device):
     for _ in range(4):
         ts.step(c, a)
     sec = timed(lambda: ts.step(c, a), 20)
+    # algorithmic FLOPs of the step in the dense (padded) layout, forward x 3 (backward = input + weight gradients): per token-layer
+    # in_proj 3 d^2 + out_proj d^2 + FFN 2 d ff (MACs x 2) + scores / context 2 S d; encoder on 512 x 52 rows, decoder on
+    # 512 x 51 rows + the heads (d x (n_args x args_dim + n_commands) per decoder token).  The step skips padding exactly
+    # (packed encoder, loss-carrying head rows), so the EXECUTED FLOPs are fewer: this fraction is an upper bound
+    d4, ff4 = cfg.d_model, cfg.dim_feedforward
+    S_e, S_d = cfg.max_total_len + 2, cfg.max_total_len + 1
+    ptl4 = 2.0 * (4 * d4 * d4 + 2 * d4 * ff4)
+    fwd4 = (cfg.n_layers * 512 * S_e * (ptl4 + 2.0 * 2 * S_e * d4) + cfg.n_layers_decode * 512 * S_d * (ptl4 + 2.0 * 2 * S_d * d4)
+            + 512 * S_d * 2.0 * d4 * (cfg.n_args * (cfg.args_dim + 1) + cfg.n_commands))
+    flop_c4 = 3.0 * fwd4
     out["c4_one_stage_train"] = {"ms_per_step": round(sec * 1e3, 3), "icons_per_s": round(512 / sec, 1),
+                                 "roofline": {"bound": "mfma", "algorithmic_TFLOP_dense_layout": round(flop_c4 / 1e12, 3),
+                                              "achieved_TFLOPs": round(flop_c4 / sec / 1e12, 1), "peak_TFLOPs": 2500.0,
+                                              "frac": round(flop_c4 / sec / 2.5e15, 4),
+                                              "note": "dense-layout FLOPs / measured time: an upper bound of the executed fraction "
+                                                      "(padding is skipped exactly); 26,624 + 26,112 rows are one round of 104 "
+                                                      "256-row workgroups: launch-latency-bound, not MFMA-bound"},
                                  "workload": "OneStageOneShot max_total_len=50, 512 icons x 52 tokens, bf16, hipGraph"}
     del ts, m
     cfg = C.HierarchicalOrdered()
@@ -545,6 +612,7 @@ def main():
     force_ddp = os.environ.get("DSVG_FORCE_DDP") == "1" and dist.is_available() and dist.is_initialized()
     ts = TrainStep(model, loss_fn, lr=1e-3 * world, grad_clip=1.0, use_graph=use_graph, force_ddp=force_ddp)
     ts.inputs_resident = True       # the synthetic batches sit in HBM before the timed region (bench contract)
+    ts.time_allreduce = not emulate
     try:
         ts.step(commands, args)
     except Exception as e:          # graph capture can fail (e.g. collective not capturable): fall back to eager
@@ -635,6 +703,17 @@ def main():
               "graphs_captured_inside_timed_region": ts.graphs_captured - captured_before,
               "distinct_buckets_in_timed_region": len(keys_seen), "bucket_switches_in_timed_region": switches,
               "graphs_evicted": ts.graphs_evicted, "cache_limit": ts.max_graphs}
+
+    def allreduce_ms(tstep, last_n):
+        evs = tstep.allreduce_events[-last_n:]
+        return round(sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs), 4) if evs else None
+    ddp = None
+    if ts.ddp and rank == 0:
+        ddp = {"ranks": rccl_ranks, "allreduce_ms": allreduce_ms(ts, a.steps) if not emulate else None,
+               "gradient_bytes": int(model.store.grad_buffer(0).numel()) * (2 if ts.allreduce_bf16 else 4),
+               "measured_on": "this run: HIP events around the gradient all-reduce behind the replayed graph, rank 0, mean of the "
+                              "timed steps (exposed time: nothing overlaps it in hipGraph mode)",
+               "ms_per_step": round(ms_per_step, 3)}
 
     roofline = None
     if rank == 0 and not a.no_roofline and not emulate:
@@ -857,25 +936,61 @@ def main():
     log(f"roofline leg done: {roofline}")
     fp32 = None
     if rank == 0 and world == 1 and a.dtype == "bf16" and not a.no_fp32 and not emulate:
-        # the parity path (what the 1e-3 tolerance of the north star is tested on): same step, same batch, eager launches
+        # the parity path (what the 1e-3 tolerance of the north star is tested on): the same step over the same rotating batches,
+        # timed by the same loop as the headline (round 6: hipGraph replay like the bf16 step; eager if a capture fails)
         m32 = deepsvg_amd.SVGTransformer(cfg)
         m32.load_state_dict(sd_cpu)
         m32.to(device).set_compute_dtype(torch.float32)
         m32.pack_encoder = bool(a.pack_encoder)
         m32.train()
-        t32 = TrainStep(m32, deepsvg_amd.SVGLoss(cfg).to(device), lr=1e-3, grad_clip=1.0, use_graph=False)
-        for _ in range(2):
-            ld32 = t32.step(commands, args)
+        g32 = bool(use_graph)
+        t32 = TrainStep(m32, deepsvg_amd.SVGLoss(cfg).to(device), lr=1e-3, grad_clip=1.0, use_graph=g32)
+        t32.inputs_resident = True
+        try:
+            for k in range(n_b):
+                ld32 = t32.step(*batches[k])
+        except Exception as e:
+            if not g32:
+                raise
+            log(f"fp32 leg: hipGraph capture failed ({type(e).__name__}: {e}); eager")
+            g32 = False
+            m32 = deepsvg_amd.SVGTransformer(cfg)
+            m32.load_state_dict(sd_cpu)
+            m32.to(device).set_compute_dtype(torch.float32)
+            m32.pack_encoder = bool(a.pack_encoder)
+            m32.train()
+            t32 = TrainStep(m32, deepsvg_amd.SVGLoss(cfg).to(device), lr=1e-3, grad_clip=1.0, use_graph=False)
+            t32.inputs_resident = True
+            for k in range(n_b):
+                ld32 = t32.step(*batches[k])
+        for i in range(3):
+            ld32 = t32.step(*batches[i % n_b])
         sync()
         t1 = time.perf_counter()
-        n32 = 5
-        for _ in range(n32):
-            ld32 = t32.step(commands, args)
+        n32 = a.steps
+        for i in range(n32):
+            ld32 = t32.step(*batches[(3 + i) % n_b])
         sync()
         dt32 = (time.perf_counter() - t1) / n32
         fp32 = {"ms_per_step": round(dt32 * 1e3, 3), "icons_per_s": round(a.batch / dt32, 1), "steps": n32,
-                "launch": "eager", "loss": round(float(ld32["loss"]), 4),
+                "launch": "hipGraph replay" if g32 else "eager", "loss": round(float(ld32["loss"]), 4),
                 "note": "fp32 storage, exact-fp32 MFMA (157.3 TFLOP/s peak): the path the 1e-3 parity tests run on"}
+        # bf16 storage against this fp32 path on the SAME (trained-for-a-few-steps) weights, evaluation mode, one batch: how
+        # far the timed dtype is from the parity dtype on the quantities the north star names
+        try:
+            mb = deepsvg_amd.SVGTransformer(cfg)
+            mb.load_state_dict({k: v.detach().float().cpu() for k, v in m32.state_dict().items()})
+            mb.to(device).set_compute_dtype(torch.bfloat16).eval()
+            m32.eval()
+            with torch.no_grad():
+                o32 = m32(commands, args, commands, args, params={})
+                o16 = mb(commands, args, commands, args, params={})
+            c32, c16 = o32["command_logits"].float(), o16["command_logits"].float()
+            fp32["bf16_vs_fp32"] = {"cmd_argmax_agreement": round((c32.argmax(-1) == c16.argmax(-1)).float().mean().item(), 5),
+                                    "cmd_logit_max_abs_err": round((c32 - c16).abs().max().item(), 5)}
+            del mb, o32, o16
+        except Exception as e:      # reported, never fatal for the bench line
+            fp32["bf16_vs_fp32"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         del m32, t32
         log(f"fp32 leg done: {fp32}")
     dense = secondary = clock = None
@@ -908,6 +1023,16 @@ def main():
             ff["measured_clock_mhz"] = mhz
             ff["chunk_loop_frac_at_its_clock"] = round(
                 2 * 32 * 32.0 / max(clock["cycles_per_chunk"], 1.0), 4)     # matrix-pipe cycles of a SIMD's two waves (2 x 32 MFMAs x 32) / cycles per chunk
+    if ddp is None and rank == 0 and world == 1 and not a.no_extra_legs and not emulate and not (dist.is_available() and dist.is_initialized()):
+        # the data-parallel path on a ONE-rank RCCL group (no multi-GPU lease is available to the builder): the same step with the
+        # 3-count loss all-reduce in front of the graph and the 41 MB gradient all-reduce behind it - what a rank of an N-GPU
+        # run executes, minus the wire.  `allreduce_ms` = the exposed time of that exchange on one GPU (RCCL's local copy path);
+        # on N GPUs add 2 (N - 1) / N x bytes / link bandwidth (ring, xGMI: ~0.1-0.5 ms for 41 MB at N = 8)
+        try:
+            ddp = ddp_one_rank_leg(cfg, sd_cpu, batches, device, a, use_graph)
+        except Exception as e:      # reported, never fatal for the bench line
+            ddp = {"error": f"{type(e).__name__}: {e}"[:300]}
+        log(f"one-rank RCCL leg done: {ddp}")
     torch_ref = None
     if rank == 0 and world == 1 and not a.no_torch_ref and not emulate:
         try:
@@ -941,8 +1066,16 @@ def main():
                        # sysfs sclk while the timed loop ran (the power-management target; stationary from the first step on:
                        # profiles/r04_clock_probe.log) and the shader clock measured inside the dominant kernel
                        "clock_mhz": {"sclk_sysfs": (sclk.summary() if sclk is not None else None),
-                                     "in_kernel": (clock or {}).get("shader_clock_mhz") if clock else None}},
-            "graphs": graphs, "rccl_ranks": rccl_ranks,
+                                     "in_kernel": (clock or {}).get("shader_clock_mhz") if clock else None},
+                       # the numbers that must be quoted beside `value` (round 6: short scalar keys the driver's parser keeps):
+                       # the parity dtype's throughput, the like-for-like dense layout, bf16's arg-max agreement with fp32
+                       "fp32_ms_per_step": (fp32 or {}).get("ms_per_step"),
+                       "fp32_icons_per_s": (fp32 or {}).get("icons_per_s"),
+                       "fp32_launch": (fp32 or {}).get("launch"),
+                       "dense_ms_per_step": (dense or {}).get("ms_per_step") if isinstance(dense, dict) else None,
+                       "bf16_cmd_argmax_agreement": ((fp32 or {}).get("bf16_vs_fp32") or {}).get("cmd_argmax_agreement"),
+                       "bf16_cmd_logit_max_abs_err": ((fp32 or {}).get("bf16_vs_fp32") or {}).get("cmd_logit_max_abs_err")},
+            "graphs": graphs, "rccl_ranks": rccl_ranks, "ddp": ddp,
             "roofline": roofline, "fp32": fp32, "dense_layout": dense, "secondary": secondary, "in_kernel_clock": clock,
             "torch_rocm_reference": torch_ref, "cpu_baseline": cpu,
         }

@@ -714,8 +714,9 @@ class LayerFn(torch.autograd.Function):
                                   n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2, wg, bg, wg2, bg2, seq_off)
             return x2
         att = None
+        # (p <= 0.5: the fused kernel's packed 16-bit dropout code, csrc/attn_fused.hip; a higher rate takes the unfused launches)
         if (rt.store is not None and x.dtype == torch.bfloat16 and x.shape[0] >= ATTN_MIN_ROWS and S <= 32 and not causal
-                and n_heads == 8 and d == 256 and (seq_off is None or tiles is not None)
+                and n_heads == 8 and d == 256 and (seq_off is None or tiles is not None) and p <= 0.5
                 and (key_mask is None or key_mask.dtype == torch.int64)):
             att = rt.store.attn(win)
         z_fused = False
@@ -1075,6 +1076,22 @@ class LossCombineFn(torch.autograd.Function):
         return (None,) + tuple(dsc.unbind(0))
 
 
+def _tail_is_own_bias_or_slack(st, weight, bias, n_read):
+    """HEAD_KPAD reads `n_read` elements from the start of `weight` in the bf16 flat image, i.e. past its end: allowed only when
+    everything behind the weight up to there is this head's own bias or the store's zero slack (never trained) - `0 x value`
+    must not meet another, possibly diverged (Inf / NaN) parameter.  True for every shipped config (args_fcn.weight and
+    args_fcn.bias are the last two parameters); anything else takes the register-staged GEMM."""
+    ent, entb = st.index.get(id(weight)), st.index.get(id(bias))
+    if ent is None:
+        return False
+    end_read = ent[0] + n_read
+    for p in st.params:
+        o, n, _shape = st.index[id(p)]
+        if o >= ent[0] + ent[1] and o < end_read and p is not bias:
+            return False
+    return entb is None or entb[0] >= ent[0] + ent[1]
+
+
 class ArgsHeadLossFn(torch.autograd.Function):
     """(sum, count) of the masked CE over the argument logits (-> loss_args by LossCombineFn), with the argument head (args_fcn, deepsvg/model/model.py:228-246)
     folded in: forward AND backward run on the tokens that carry argument loss only.  Every other token's logits do
@@ -1169,7 +1186,8 @@ class ArgsHeadLossFn(torch.autograd.Function):
                           and logits_c.stride(0) >= r1 - r0 and logits_c.data_ptr() % 16 == 0)
             if (HEAD_KPAD and tok_kernel and mult == 8 and kp != r1 - r0 and st is not None and st.flat_lp is not None and wl.is_contiguous()
                     and wl.untyped_storage().data_ptr() == st.flat_lp.untyped_storage().data_ptr()
-                    and wl.storage_offset() + (r0 + kp) * wl.shape[1] <= st.flat_lp.numel()):
+                    and wl.storage_offset() + (r0 + kp) * wl.shape[1] <= st.flat_lp.numel()
+                    and _tail_is_own_bias_or_slack(st, weight, bias, (r0 + kp) * wl.shape[1])):
                 mult = 64
                 w_ext = torch.as_strided(wl, (kp, wl.shape[1]), (wl.shape[1], 1), wl.storage_offset() + r0 * wl.shape[1])
             dl = ops.masked_ce_bwd(logits_c, target, w, lse, sc, g, 1.0, ctx.C_, ctx.group, pad_to=mult, tok_idx=idx,

@@ -908,6 +908,7 @@ class SVGTransformer(nn.Module):
         dec = self.decoder
         vis_logits = None
         l = l_seq = None
+        self._head_vf = False       # (set below by the one-shot path only: an autoregressive call must not inherit the last call's)
         if cfg.decode_stages == 2:
             G = cfg.num_groups_proposal
             N = z.shape[0] if hierarch_logits is None else z.shape[0] // G

@@ -208,15 +208,28 @@ class _GroupScope:
     the block is left (include/dsvg.h: dsvg_gemm_group_scope).  Their operands must stay alive until then - they do when
     they are locals of the code inside the block."""
     active = None       # profiling only: {tag: [flops, bytes]} of the members queued in the open scope
+    depth = {}          # stream key -> nesting depth: only the outermost block opens / closes the library's scope (a block
+                        # inside a stack-level scope - functional.STACK_GROUP - must not launch the stack's queue early)
 
     def __enter__(self):
-        self._key = _stream_key()
+        self._key = key = _stream_key()
+        d = _GroupScope.depth.get(key, 0)
+        _GroupScope.depth[key] = d + 1
+        if d:
+            return
         if torch.cuda.is_available():
-            _l.check(_l.load().dsvg_gemm_group_scope(1, self._key), "dsvg_gemm_group_scope")
+            _l.check(_l.load().dsvg_gemm_group_scope(1, key), "dsvg_gemm_group_scope")
         if PROFILE_ON:
             _GroupScope.active = {}
 
     def __exit__(self, *exc):
+        key = _stream_key()
+        d = _GroupScope.depth.get(key, 1) - 1
+        if d > 0:
+            _GroupScope.depth[key] = d
+            return False
+        _GroupScope.depth.pop(key, None)
+        self._key = key
         members, _GroupScope.active = _GroupScope.active, None
         ev = None
         if PROFILE_ON and members:

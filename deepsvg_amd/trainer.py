@@ -105,6 +105,8 @@ class TrainStep:
         # torch.cuda.Event(external=True) refuses on ROCm for the same reason.  In graph mode the gradient therefore still goes
         # out in one all-reduce behind the graph; the eager path keeps the overlapped decoder bucket.)
         self.allreduce_bf16 = os.environ.get("DSVG_DDP_BF16", "0") == "1"
+        self.time_allreduce = False         # record HIP events around the gradient all-reduce of every step (allreduce_events)
+        self.allreduce_events = []
         self._bf16_stage = None
         self._pending = None
         self._pool = None
@@ -152,13 +154,15 @@ class TrainStep:
     class _Bf16Work:
         """an all-reduce that travels as bf16: `view` (fp32 slice of the flat gradient) was cast into `stage`, which is being
         reduced; wait() = wait for the collective, cast back"""
-        def __init__(self, view, stage, work):
-            self.view, self.stage, self.work = view, stage, work
+        def __init__(self, view, stage, work, world=1.0):
+            self.view, self.stage, self.work, self.world = view, stage, work, world
 
         def wait(self):
             if self.work is not None:
                 self.work.wait()
             self.view.copy_(self.stage)
+            if self.world != 1.0:
+                self.view.mul_(self.world)
 
     def _all_reduce(self, view, async_op=False):
         """sum-all-reduce of a slice of the flat fp32 gradient buffer (in place) -> a work object with wait(), or None"""
@@ -169,8 +173,11 @@ class TrainStep:
             self._bf16_stage = torch.empty(flat_g.numel(), dtype=torch.bfloat16, device=flat_g.device)
         off = view.storage_offset() - flat_g.storage_offset()
         stage = self._bf16_stage[off:off + view.numel()]
-        stage.copy_(view)
-        w = TrainStep._Bf16Work(view, stage, dist.all_reduce(stage, group=self.pg, async_op=async_op))
+        # (the rank AVERAGE travels as bf16, not the rank sum: the 1 / world scale sits in front of the lossy cast - exact for
+        # power-of-two worlds - and is undone behind the cast back, so the flat buffer keeps its "sum over ranks" meaning for
+        # the norm, the clip and AdamW's grad_scale)
+        torch.mul(view, 1.0 / self.world, out=stage)
+        w = TrainStep._Bf16Work(view, stage, dist.all_reduce(stage, group=self.pg, async_op=async_op), float(self.world))
         if async_op:
             return w
         w.wait()
@@ -252,6 +259,9 @@ class TrainStep:
         finally:
             model._decoder_grads_ready = None
             model._defer_wgrad = False
+            # (a forward that raised before ParamStore.ensure() consumed it must not leave the advance behind for the next,
+            # unrelated forward - an evaluation, a sampling call - to apply)
+            model.store.pending_advance = None
             rt = getattr(model, "_rt", None)
             if rt is not None:
                 rt.stack_group_end()        # (a stack's grouped weight-gradient launch left open by an interrupted backward)
@@ -277,6 +287,10 @@ class TrainStep:
         model = self.model
         flat_g = model.store.grad_buffer(0)
         if self.ddp:
+            ev = None
+            if self.time_allreduce and flat_g.is_cuda:      # (bench.py: the exposed time of the gradient exchange, `ddp.allreduce_ms`)
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             if self._pending is not None:
                 # two buckets: the decoder half went out while the encoder's backward was running
                 lo, work = self._pending
@@ -284,6 +298,10 @@ class TrainStep:
                 work.wait()
             else:
                 self._all_reduce(flat_g)
+            if ev is not None:
+                ev[1].record()
+                self.allreduce_events.append(ev)
+                del self.allreduce_events[:-256]
         ops.sumsq(flat_g, out=self.gnorm_sq)
         ops.adamw_step_(model.store.flat, flat_g, self.m, self.v, self.lr, self.step_count,
                         beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay,

@@ -31,16 +31,20 @@ def test_bench_main_loop_two_ranks_gloo():
     _check_record(json.loads(lines[0]))
 
 
-def _check_record(rec):
-    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
-    assert rec["config"]["global_batch"] == 6 and rec["config"]["parallelism"] == "dp2"
+def _check_record(rec, n=2, batch=3, batches=8):
+    assert rec["n_gpus"] == n and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch"] == n * batch and rec["config"]["parallelism"] == f"dp{n}"
+    assert rec["config"]["batch_per_gpu"] == batch
     # `value` is printed with one decimal and `ms_per_step` with three: on a slow host (0.4 icons/s) the rounding alone is
     # more than 1 %
-    want = 6 / (rec["ms_per_step"] * 1e-3)
+    want = n * batch / (rec["ms_per_step"] * 1e-3)
     assert rec["value"] > 0 and abs(rec["value"] - want) <= max(0.01 * want, 0.06)
     assert rec["config"]["loss"] == rec["config"]["loss"]       # finite
-    assert rec["rccl_ranks"] == 2, "rank 0 must report the number of ranks its collectives actually span"
-    assert rec["graphs"]["batches_rotated"] == 8
+    assert rec["rccl_ranks"] == n, "rank 0 must report the number of ranks its collectives actually span"
+    assert rec["graphs"]["batches_rotated"] == batches
+    # the data-parallel record (round 6): the ranks the gradient exchange spans and its size; the exposed time is a GPU
+    # measurement (HIP events) and stays empty in this CPU emulation
+    assert rec["ddp"]["ranks"] == n and rec["ddp"]["gradient_bytes"] > 4e7 and rec["ddp"]["allreduce_ms"] is None
 
 
 def test_bench_launches_its_own_ranks():
@@ -56,3 +60,29 @@ def test_bench_launches_its_own_ranks():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     _check_record(json.loads(lines[0]))
+
+
+def test_bench_eight_ranks_gloo_the_drivers_scaling_command():
+    """the exact command of the driver's 8-GPU scaling leg - `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W` - in gloo emulation on this host's 8 cores
+    (one icon per rank, two rotating batches so that the run stays within a minute or two): ONE line from rank 0 with
+    n_gpus = 8, collectives that span 8 ranks, global batch = 8 x per-rank batch, per-rank seeds (the ranks' batches differ:
+    bench.py seeds rank r's batch k with 1000 + r + 97 k)"""
+    env = dict(os.environ, DSVG_BENCH_EMULATE="1", PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--batch", "1", "--batches", "2", "--dtype", "fp32"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout              # rank 0 only
+    _check_record(json.loads(lines[0]), n=8, batch=1, batches=2)
+
+
+def test_per_rank_batches_differ():
+    """bench.py's per-rank synthetic batches: seed 1000 + rank + 97 k - two ranks never train on the same icons"""
+    from deepsvg_amd.synthetic import make_batch
+    c0, a0 = make_batch(2, G=8, S=30, seed=1000 + 0)
+    c1, a1 = make_batch(2, G=8, S=30, seed=1000 + 1)
+    assert not (c0 == c1).all() or not (a0 == a1).all()

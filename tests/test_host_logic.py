@@ -810,3 +810,36 @@ def test_trainer_gradless_slots_follow_call_shapes_and_reflattening(emulated_ops
     assert ts._gradless_ids == old_ids                  # (same parameter objects; the VIEWS were rebuilt on the new buffer)
     assert all(v.data_ptr() >= model.store.grad_buffer(0).data_ptr() for v in ts._gradless_slots)
     assert torch.equal(model.store.grad_buffer(0), bufs[0])
+
+
+def test_group_scope_nests():
+    """ops.GROUP (one grouped weight-gradient launch per block): a block inside an open block - a per-layer scope inside the
+    stack-level scope of functional.STACK_GROUP - must not close the outer one; only the outermost exit launches"""
+    from deepsvg_amd import ops
+    key = ops._stream_key()
+    assert ops._GroupScope.depth.get(key, 0) == 0
+    with ops.GROUP:
+        assert ops._GroupScope.depth[key] == 1
+        with ops.GROUP:
+            assert ops._GroupScope.depth[key] == 2
+        assert ops._GroupScope.depth[key] == 1          # still open
+    assert ops._GroupScope.depth.get(key, 0) == 0
+
+
+def test_head_kpad_tail_guard():
+    """functional._tail_is_own_bias_or_slack: the extended head-weight view may only run over the head's own bias and the zero
+    slack behind the last parameter"""
+    import torch
+    from deepsvg_amd import functional as Fn
+
+    class St:
+        pass
+    w, b, other = torch.nn.Parameter(torch.zeros(10, 4)), torch.nn.Parameter(torch.zeros(10)), torch.nn.Parameter(torch.zeros(64))
+    st = St()
+    st.params = [other, w, b]
+    st.index = {id(other): (0, 64, (64,)), id(w): (64, 40, (10, 4)), id(b): (104, 10, (10,))}
+    assert Fn._tail_is_own_bias_or_slack(st, w, b, 40 + 24)          # runs over its own bias and the slack
+    st.params = [w, b, other]
+    st.index = {id(w): (0, 40, (10, 4)), id(b): (40, 10, (10,)), id(other): (56, 64, (64,))}
+    assert Fn._tail_is_own_bias_or_slack(st, w, b, 40 + 12)          # ends inside the bias
+    assert not Fn._tail_is_own_bias_or_slack(st, w, b, 40 + 24)      # would read another parameter
