@@ -160,6 +160,38 @@ __device__ __forceinline__ void drop_mult4(const DropCtx& c, uint64_t idx8, int 
     }
 }
 
+// The layer's weight image (1 MiB per direction) is cold in this XCD's L2 when the launch starts - inside a training step every
+// layer's image is touched once per step - and every workgroup of the XCD walks it in lockstep from the same address on: each
+// wave's prefetch ring (PF KiB in flight) then runs at the latency of an HBM miss all the way.  So the workgroups of an XCD
+// (block b runs on XCD b % 8) request the WHOLE image up front, 64 KiB each: LDS-DMA into a 1 KiB dump area per wave (no
+// registers, nothing to wait for: the bytes are never read - the point is the line in L2).  warm = 0: off (A/B knob DSVG_GS_WARM)
+constexpr int GS_WARM_LDS = 8 * 1024;
+__device__ __forceinline__ void gs_warm_l2(const bf16_t* img, int wave, int lane, uint32_t lds_dump, int warm) {
+    if (!warm) return;
+    const uint32_t slice = ((uint32_t)blockIdx.x >> 3) & 15u;
+    // per-lane addresses (the saddr form wants a provably wave-uniform base: hipcc hands it VGPRs here)
+    const char* b0 = reinterpret_cast<const char*>(img) + ((size_t)slice * 64 + (size_t)wave * 8) * 1024 + (size_t)lane * 16;
+    const char* b1 = b0 + 1024; const char* b2 = b0 + 2048; const char* b3 = b0 + 3072;
+    const char* b4 = b0 + 4096; const char* b5 = b0 + 5120; const char* b6 = b0 + 6144; const char* b7 = b0 + 7168;
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %9\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "global_load_lds_dwordx4 %3, off\n\t"
+        "global_load_lds_dwordx4 %4, off\n\t"
+        "global_load_lds_dwordx4 %5, off\n\t"
+        "global_load_lds_dwordx4 %6, off\n\t"
+        "global_load_lds_dwordx4 %7, off\n\t"
+        "global_load_lds_dwordx4 %8, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4), "v"(b5), "v"(b6), "v"(b7), "s"(lds_dump)
+        : "memory");
+}
+
 // the per-wave weight stream: fragment i of the layer is `ring[i % PF]` once `take(i)` has been called in order
 // PF: prefetch distance of the weight stream (fragments = KiB in flight per wave)
 template <int PF>
@@ -190,6 +222,8 @@ struct GsFwdArgs {
     float* mean1; float* rstd1; bf16_t* xn1; bf16_t* qkv; bf16_t* ao; bf16_t* x1;
     float* mean2; float* rstd2; bf16_t* xn2; bf16_t* h;
     int n_seq, S;
+    int per;                // whole sequences per tile (<= 32 / S; fewer: see gs_per)
+    int warm;               // request the whole weight image into L2 up front (gs_warm_l2)
     float eps, scale, drop_p;
     uint32_t site0;
     long long seq_base;     // the launch covers sequences seq_base .. seq_base + n_seq - 1 of a longer buffer: the pointers are
@@ -250,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, h2 = lane >> 5;
     const int Smax = a.S;
-    const int per = 32 / Smax;                          // whole sequences per tile
+    const int per = a.per;                              // whole sequences per tile
     const int s_first = blockIdx.x * per;
     const int n_in = min(per, a.n_seq - s_first);
     const int S = n_in * Smax;                          // live rows of this tile
@@ -270,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         sbo[tid] = a.out_bias[tid]; sb2[tid] = a.b2[tid];
         sg1[tid] = a.g1[tid]; sbe1[tid] = a.be1[tid]; sg2[tid] = a.g2[tid]; sbe2[tid] = a.be2[tid];
     }
+    gs_warm_l2(a.img, wave, lane, __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)DSVG_LDS_PTR(smem) + F_LDS + wave * 1024), a.warm);
     WStream<PF> ws;
     ws.start(a.img, wave, lane);
 
@@ -591,6 +626,8 @@ struct GsBwdArgs {
     bf16_t* dg;             // [n_seq][256] or NULL: the per-sequence term's gradient (what dsvg_bcast_add_bwd makes of dx1)
     float* ln_part;         // [tiles][4][256]: dgamma2, dbeta2, dgamma1, dbeta1
     int n_seq, S;
+    int per;                // whole sequences per tile (see gs_per)
+    int warm;               // request the whole weight image into L2 up front (gs_warm_l2)
     float scale, drop_p;
     uint32_t site0;
 };
@@ -681,7 +718,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, h2 = lane >> 5;
     const int Smax = a.S;
-    const int per = 32 / Smax;
+    const int per = a.per;
     const int s_first = blockIdx.x * per;
     const int n_in = min(per, a.n_seq - s_first);
     const int S = n_in * Smax;
@@ -721,6 +758,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a)
     const int qi = min(li / Smax, n_in - 1);
     const int my_seq = s_first + qi, my_start = qi * Smax;
     const uint32_t kmask_raw = a.key_mask ? (uint32_t)a.key_mask[my_seq] : ~0u;
+    gs_warm_l2(a.img, wave, lane, __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)DSVG_LDS_PTR(smem) + B_LDS + wave * 1024), a.warm);
     WStream<PF> ws;
     ws.start(a.img, wave, lane);
 
@@ -1297,6 +1335,24 @@ extern "C" int dsvg_gs_pack(const float* flat_f32, const int64_t* offs, int32_t 
     return 0;
 }
 
+// Whole sequences per 32-row tile.  32 / S fills the MFMA tiles, but a 4096-row stage is then 128 workgroups on 256 CUs, each
+// bound by streaming the layer's 1-1.5 MiB of weights through ONE CU (~50 GB/s of the ~110 a CU ingests; the matrix pipe is busy
+// 5 % of the time).  Round 6: while the launch would leave half of the CUs idle, a tile takes half the sequences - the other
+// MFMA rows idle, twice the CUs stream.  Results per row do not depend on the tiling (dropout draws are indexed by row); the
+// LayerNorm parameter gradients are sums of per-tile partials in tile order (another grouping of the same terms).
+// DSVG_GS_FILL=0: always 32 / S (A/B knob).
+static int gs_per(int64_t n_seq, int S) {
+    static const int fill = getenv("DSVG_GS_FILL") ? atoi(getenv("DSVG_GS_FILL")) : 0;
+    int per = 32 / S;
+    while (fill && per >= 2 && (n_seq + per - 1) / per <= 128) per /= 2;
+    return per;
+}
+
+static int gs_warm() {
+    static const int w = getenv("DSVG_GS_WARM") ? atoi(getenv("DSVG_GS_WARM")) : 1;
+    return w;
+}
+
 static unsigned long long* g_gs_dbg_host = nullptr;
 /* development probe: buf = device buffer of (workgroups * 8 waves * 8) uint64 or NULL (off); see gs_stamp */
 extern "C" int dsvg_gs_debug_clock(void* buf) {
@@ -1334,14 +1390,16 @@ extern "C" int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, co
     a.x1 = (bf16_t*)x1; a.mean2 = mean2; a.rstd2 = rstd2; a.xn2 = (bf16_t*)xn2; a.h = (bf16_t*)h;
     a.n_seq = (int)n_seq; a.S = S; a.eps = eps; a.scale = scale; a.drop_p = drop_p; a.site0 = site0;
     a.seq_base = seq_base; a.ffn_format = ffn_format; a.dbg = g_gs_dbg_host;
-    const int per = 32 / S;
+    const int per = gs_per(n_seq, S);
+    a.per = per;
+    a.warm = gs_warm();
     const int nb = (int)((n_seq + per - 1) / per);
     hipStream_t st = (hipStream_t)stream;
     static const int pf = getenv("DSVG_GS_PF") ? atoi(getenv("DSVG_GS_PF")) : GS_PF_DEFAULT;       // tuning knob
 #define DSVG_GS_FWD(TR, P)                                                                       \
     do {                                                                                         \
-        DSVG_ENSURE_LDS((gs_layer_fwd_kernel<TR, P>), F_LDS);                                    \
-        hipLaunchKernelGGL((gs_layer_fwd_kernel<TR, P>), dim3(nb), dim3(512), F_LDS, st, a);     \
+        DSVG_ENSURE_LDS((gs_layer_fwd_kernel<TR, P>), F_LDS + GS_WARM_LDS);                                    \
+        hipLaunchKernelGGL((gs_layer_fwd_kernel<TR, P>), dim3(nb), dim3(512), F_LDS + GS_WARM_LDS, st, a);     \
     } while (0)
     if (train) { if (pf == 8) DSVG_GS_FWD(true, 8); else if (pf == 24) DSVG_GS_FWD(true, 24); else if (pf == 16) DSVG_GS_FWD(true, 16); else DSVG_GS_FWD(true, 12); }
     else { if (pf == 8) DSVG_GS_FWD(false, 8); else if (pf == 24) DSVG_GS_FWD(false, 24); else if (pf == 16) DSVG_GS_FWD(false, 16); else DSVG_GS_FWD(false, 12); }
@@ -1351,7 +1409,7 @@ extern "C" int dsvg_gs_layer_fwd(const void* x, const void* packed_fwd_layer, co
 }
 
 extern "C" int64_t dsvg_gs_bwd_workspace_bytes(int64_t n_seq, int32_t S) {
-    const int per = 32 / (S > 0 ? S : 1);
+    const int per = gs_per(n_seq, S > 0 ? S : 1);
     return ((n_seq + per - 1) / per) * 1024 * (int64_t)sizeof(float);
 }
 
@@ -1382,14 +1440,16 @@ extern "C" int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, 
     a.dx = (bf16_t*)dx; a.dx1 = (bf16_t*)dx1; a.dym = (bf16_t*)dym; a.dpre = (bf16_t*)dpre; a.dx1m = (bf16_t*)dx1m;
     a.dqkv = (bf16_t*)dqkv; a.dg = (bf16_t*)dg; a.ln_part = (float*)workspace;
     a.n_seq = (int)n_seq; a.S = S; a.scale = scale; a.drop_p = drop_p; a.site0 = site0;
-    const int per = 32 / S;
+    const int per = gs_per(n_seq, S);
+    a.per = per;
+    a.warm = gs_warm();
     const int nb = (int)((n_seq + per - 1) / per);
     hipStream_t st = (hipStream_t)stream;
     static const int pf = getenv("DSVG_GS_PF") ? atoi(getenv("DSVG_GS_PF")) : GS_PF_DEFAULT;       // tuning knob
 #define DSVG_GS_BWD(P)                                                                       \
     do {                                                                                     \
-        DSVG_ENSURE_LDS((gs_layer_bwd_kernel<P>), B_LDS);                                    \
-        hipLaunchKernelGGL((gs_layer_bwd_kernel<P>), dim3(nb), dim3(512), B_LDS, st, a);     \
+        DSVG_ENSURE_LDS((gs_layer_bwd_kernel<P>), B_LDS + GS_WARM_LDS);                                    \
+        hipLaunchKernelGGL((gs_layer_bwd_kernel<P>), dim3(nb), dim3(512), B_LDS + GS_WARM_LDS, st, a);     \
     } while (0)
     if (pf == 8) DSVG_GS_BWD(8); else if (pf == 16) DSVG_GS_BWD(16); else DSVG_GS_BWD(12);
 #undef DSVG_GS_BWD
