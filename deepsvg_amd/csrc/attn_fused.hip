@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
         int n_seq, int Smax, long long total_rows, bf16_t* __restrict__ x1, bf16_t* __restrict__ xn_out,
         bf16_t* __restrict__ qkv_out, bf16_t* __restrict__ ao_out, float* __restrict__ mean_out,
         float* __restrict__ rstd_out, float eps, float scale, float drop_p, const uint64_t* __restrict__ seed,
-        uint32_t site_p, uint32_t site_r, const bf16_t* __restrict__ gadd, long long gadd_ld, uint32_t site_g) {
+        uint32_t site_p, uint32_t site_r, const bf16_t* __restrict__ gadd, long long gadd_ld, uint32_t site_g, int warm) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];   // [NBUF slots | biases, gamma, beta | 8 staging tiles]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -132,6 +132,13 @@ __global__ __launch_bounds__(512, 2) void attn_block_fwd_kernel(
     // 3 ring slots, the DMA two chunks ahead; every sync drains the wave's memory operations (vmcnt(0)).  (Round 4 measured a
     // 4-slot ring with counted waits - the training stores no longer drained at the 20 syncs - on MI355X: bit-identical, but 2 %
     // SLOWER per launch (176 vs 173 us at 127 k rows) and no change of the step; removed.  profiles/r04_experimental_attn_bench.log)
+    // Round 6: the layer's image (512 KiB) is cold in this XCD's L2 when the launch starts and the workgroups walk it in
+    // lockstep - every chunk would begin with an HBM miss all of them wait for.  The workgroups of an XCD (block b runs on XCD
+    // b % 8) request it up front, 32 KiB each, into this wave's own 4 KiB of the ring slot its DMA of chunk 2 overwrites later
+    // (same wave: in order); nobody reads that slot before chunk 2 has landed.
+    if (warm)
+        dma4(img_b + (size_t)((blockIdx.x >> 3) & 15u) * (32 * 1024) + wave * 4096,
+             __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)DIST * SLOT + wave * 4096));
     issue(0);
     issue(1);
 
@@ -623,6 +630,7 @@ extern "C" int dsvg_attn_block_fwd(const void* x, const void* packed_layer, cons
     }
     const int nb = (int)((waves + TILES_PER_WG - 1) / TILES_PER_WG);
     hipStream_t st = (hipStream_t)stream;
+    static const int w_warm = getenv("DSVG_W_WARM") ? atoi(getenv("DSVG_W_WARM")) : 1;      // A/B knob: weight image into L2 up front
 #define DSVG_ATTN_FWD(TR, TI)                                                                                          \
     do {                                                                                                               \
         const size_t lds = (size_t)NBUF * SLOT + SMALL_LDS + STAGE_LDS;                                                \
@@ -631,7 +639,7 @@ extern "C" int dsvg_attn_block_fwd(const void* x, const void* packed_layer, cons
                            (const bf16_t*)packed_layer, in_bias, out_bias, gamma, beta, key_mask, seq_off, tile_first, \
                            (int)n_seq, (int)S, (long long)rows, (bf16_t*)x1, (bf16_t*)xn_out, (bf16_t*)qkv_out,        \
                            (bf16_t*)ao_out, mean_out, rstd_out, eps, scale, drop_p, (const uint64_t*)seed, site_probs, \
-                           site_res, (const bf16_t*)seq_add, (long long)seq_add_ld, site_seq_add);                                            \
+                           site_res, (const bf16_t*)seq_add, (long long)seq_add_ld, site_seq_add, w_warm);                                   \
     } while (0)
     if (train) { if (tiled) DSVG_ATTN_FWD(true, true); else DSVG_ATTN_FWD(true, false); }
     else { if (tiled) DSVG_ATTN_FWD(false, true); else DSVG_ATTN_FWD(false, false); }

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
                                                          bf16_t* __restrict__ xh_out, float* __restrict__ rstd_out,
                                                          int M, float eps, float drop_p,
                                                          const uint64_t* __restrict__ seed, uint32_t site_h,
-                                                         uint32_t site_r, int n_chunks, unsigned long long* dbg) {
+                                                         uint32_t site_r, int n_chunks, unsigned long long* dbg, int warm) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // [NBUF chunk slots | b1 (2 KiB) | b2 (1 KiB)]
     ffn_stamp(dbg, 0);
     const int tid = threadIdx.x;
@@ -229,6 +229,15 @@ __global__ __launch_bounds__(512, 2) void ffn_fwd_kernel(const bf16_t* __restric
     auto issue = [&](int c) { dma4s(my_src + (size_t)c * FWD_CHUNK, (uint32_t)lane * 16u, my_dst + (uint32_t)(c % NBUF) * FWD_CHUNK); };
     // DMA distance: DIST = NBUF - 1 chunks ahead of the compute (NBUF = 3: 2, NBUF = 4: 3)
     constexpr int DIST = NBUF - 1;
+    // Round 6: the layer's chunk image (512 KiB) is cold in this XCD's L2 when the launch starts (inside a training step every
+    // layer's image is touched once per step) and the workgroups walk it in lockstep: every chunk would begin with one HBM miss
+    // that all of them wait for.  So the workgroups of an XCD (block b runs on XCD b % 8) request the chunks behind the first
+    // DIST up front, one each: an ordinary chunk DMA into the ring's last slot - this wave's own pieces of it, which its
+    // own, later DMA of chunk DIST overwrites in order; nobody reads the slot before that one has landed.
+    if (warm && NBUF == 4 && n_chunks > DIST) {
+        const int wc = DIST + (int)((blockIdx.x >> 3) % (unsigned)(n_chunks - DIST));
+        dma4s(my_src + (size_t)wc * FWD_CHUNK, (uint32_t)lane * 16u, my_dst + (uint32_t)DIST * FWD_CHUNK);
+    }
 #pragma unroll
     for (int c = 0; c < DIST; ++c)
         if (c < n_chunks) issue(c);
@@ -824,7 +833,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ dy, const bf16_t* __restrict__ img,
                                                             bf16_t* __restrict__ dx, int M, float eps,
                                                             bf16_t* __restrict__ dxm, float drop_p,
-                                                            const uint64_t* __restrict__ seed, uint32_t site_m) {
+                                                            const uint64_t* __restrict__ seed, uint32_t site_m, int warm) {
     constexpr int NBUF = 4, SLOT = 16 * FRAG;
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // [4 x 16 KiB]
     const int tid = threadIdx.x;
@@ -836,6 +845,9 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
     const char* my_src = reinterpret_cast<const char*>(img) + 32 * FRAG + wave * 2048 + lane * 16;
     const uint32_t my_dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 2048);
     auto issue = [&](int c) { dma2(my_src + (size_t)c * BWD_CHUNK, my_dst + (uint32_t)(c % NBUF) * SLOT); };
+    // (round 6, as in ffn_fwd_kernel: the W1'^T chunks are cold in this XCD's L2 and walked in lockstep - the workgroups of an
+    // XCD request the chunks behind the first two up front, one each, into this wave's own pieces of ring slot 3)
+    if (warm) dma2(my_src + (size_t)(2 + (blockIdx.x >> 3) % (unsigned)(NCH - 2)) * BWD_CHUNK, my_dst + 3u * SLOT);
     issue(0);
     issue(1);
 
@@ -1446,6 +1458,7 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
     if (train) stages = train_stages == 3 ? 3 : 4;
     // timing probe only (results are wrong below 16): number of hidden chunks actually processed
     static const int dbg_chunks = getenv("DSVG_FFN_DBG_CHUNKS") ? atoi(getenv("DSVG_FFN_DBG_CHUNKS")) : NCH;
+    static const int w_warm = getenv("DSVG_W_WARM") ? atoi(getenv("DSVG_W_WARM")) : 1;      // A/B knob: weight image into L2 up front
 #define DSVG_FFN_FWD(NB, TR, PK)                                                                                      \
     do {                                                                                                              \
         const size_t lds = (size_t)NB * FWD_CHUNK + 3072;                                                             \
@@ -1453,7 +1466,7 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
         hipLaunchKernelGGL((ffn_fwd_kernel<NB, TR, PK>), dim3(nb), dim3(512), lds, st, (const bf16_t*)x,               \
                            (const bf16_t*)packed_fwd_layer, b1_folded, b2, (bf16_t*)y, (bf16_t*)h_out, (bf16_t*)xh_out,\
                            rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res, dbg_chunks,    \
-                           g_ffn_dbg_host);                                                                           \
+                           g_ffn_dbg_host, w_warm);                                                                   \
     } while (0)
     // half-size workgroups (stages 2, or by default up to 32,768 rows; DSVG_FFN_HALF=0 / 1 forces the choice)
     static const int half_env = getenv("DSVG_FFN_HALF") ? atoi(getenv("DSVG_FFN_HALF")) : -1;
@@ -1536,7 +1549,7 @@ extern "C" int dsvg_ffn_bwd(const void* x, const void* dy, const void* packed_bw
     DSVG_LAUNCH_CHECK("ffn_bwd (hidden)");
     hipLaunchKernelGGL(ffn_bwd_dx_kernel, dim3(nb), dim3(512), lds2, st, (const bf16_t*)dpre, (const bf16_t*)x,
                        (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps, (bf16_t*)nullptr, 0.f,
-                       (const uint64_t*)nullptr, 0u);
+                       (const uint64_t*)nullptr, 0u, 0);
     DSVG_LAUNCH_CHECK("ffn_bwd (dx)");
     return 0;
 }
@@ -1552,9 +1565,10 @@ extern "C" int dsvg_ffn_bwd_dx(const void* dpre, const void* x, const void* dy, 
                    "ffn_bwd_dx: operands must be 16-byte aligned");
     const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
     const size_t lds2 = 4 * 16 * FRAG;
+    static const int w_warm = getenv("DSVG_W_WARM") ? atoi(getenv("DSVG_W_WARM")) : 1;      // A/B knob
     hipLaunchKernelGGL(ffn_bwd_dx_kernel, dim3(nb), dim3(512), lds2, (hipStream_t)stream, (const bf16_t*)dpre,
                        (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps,
-                       (bf16_t*)dx_masked, drop_p, (const uint64_t*)seed, drop_site);
+                       (bf16_t*)dx_masked, drop_p, (const uint64_t*)seed, drop_site, w_warm);
     DSVG_LAUNCH_CHECK("ffn_bwd_dx");
     return 0;
 }
