@@ -187,6 +187,27 @@ __device__ __forceinline__ void glds_body(const dsvg_gemm_desc& p, int tiles_n, 
         return f.v;
     };
 
+    // Round 6: the weight operand B of a forward / input-gradient GEMM (<= 1.4 MB, read by every workgroup) is cold in this
+    // XCD's L2 when the launch starts - inside a training step every layer's weights are touched a few times per step - and
+    // the workgroups walk it in lockstep, K step by K step: each step would begin with an HBM miss they all wait for.  The
+    // workgroups of an XCD (workgroup b runs on XCD b % 8) request all of it up front, 4 KiB each, by LDS-DMA into this wave's
+    // own first piece of stage 0 (its own first real DMA overwrites it, in order; nothing reads it before).
+    if (EPI != EPI_PARTIAL && (part_bf16 & 16)) {        // (bit 4 of this launch argument: dsvg_gemm_bf16_glds launch())
+        const size_t span = (BKC ? (size_t)p.N * p.ldb : (size_t)p.K * p.ldb) * 2;
+        const unsigned n_pc = (unsigned)((span + 4095) >> 12);
+        const size_t off = (size_t)(((unsigned)bid >> 3) % n_pc) * 4096 + (size_t)wave * 1024 + (size_t)lane * 16;
+        const char* src = (const char*)p.B + (off + 16 <= span ? off : span - 16);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)DSVG_LDS_PTR(smem) + (uint32_t)wave * 4096u);
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+
     // acc[jn][im]: transposed 32x32 tiles, D[i = output column][j = token row]
     floatx16 acc00, acc01, acc10, acc11;
 #pragma unroll
@@ -300,7 +321,7 @@ __device__ __forceinline__ void glds_body(const dsvg_gemm_desc& p, int tiles_n, 
                     *reinterpret_cast<uint4*>(base + (size_t)m * p.N + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
             }
         };
-        if (part_bf16) { put_bf16(acc00, 0, 0); put_bf16(acc01, 0, 1); put_bf16(acc10, 1, 0); put_bf16(acc11, 1, 1); }
+        if (part_bf16 & 1) { put_bf16(acc00, 0, 0); put_bf16(acc01, 0, 1); put_bf16(acc10, 1, 0); put_bf16(acc11, 1, 1); }
         else { put(acc00, 0, 0); put(acc01, 0, 1); put(acc10, 1, 0); put(acc11, 1, 1); }
         if (do_rs) {                // lanes l and l+32 hold the two k halves of token row (lane & 31)
             rs0 += __shfl_xor(rs0, 32, 64);
@@ -516,6 +537,8 @@ template <bool AKC, bool BKC, int EPI>
 void launch(const dsvg_gemm_desc& d, dim3 grid, int tiles_n, int nwg, int k_chunk, float* part, float* rs_part, int mode,
             int nst, hipStream_t st, int pbf = 0) {
     static const int occ = getenv("DSVG_GEMM_OCC") ? atoi(getenv("DSVG_GEMM_OCC")) : 4;
+    static const int w_warm = getenv("DSVG_GEMM_WARM") ? atoi(getenv("DSVG_GEMM_WARM")) : 0;      // A/B knob (round 6: measured without effect on the step, off): weight operand into L2 up front
+    if (EPI != EPI_PARTIAL && w_warm) pbf |= 16;
     if (nst == 4) {
         const size_t lds = (size_t)4 * 2 * IMG * sizeof(bf16_t);
         static bool once = false;
