@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_half_kernel(const bf16_t* __re
                                                               bf16_t* __restrict__ xh_out, float* __restrict__ rstd_out,
                                                               int M, float eps, float drop_p,
                                                               const uint64_t* __restrict__ seed, uint32_t site_h,
-                                                              uint32_t site_r, int n_chunks, unsigned long long* dbg) {
+                                                              uint32_t site_r, int n_chunks, unsigned long long* dbg, int warm) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // [4 half-chunk slots | b1 (2 KiB) | b2 (1 KiB)]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -478,6 +478,9 @@ __global__ __launch_bounds__(256, 2) void ffn_fwd_half_kernel(const bf16_t* __re
     const char* my_src = reinterpret_cast<const char*>(img) + wave * 4096;
     const uint32_t my_dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);
     auto issue = [&](int hc) { dma4s(my_src + (size_t)hc * HSLOT, (uint32_t)lane * 16u, my_dst + (uint32_t)(hc % HNBUF) * HSLOT); };
+    // (round 6, as in ffn_fwd_kernel: the half chunks behind the first three requested into this XCD's L2 up front, one per
+    // workgroup, into this wave's own pieces of the free ring slot)
+    if (warm && n_half > 3) dma4s(my_src + (size_t)(3 + (int)((blockIdx.x >> 3) % (unsigned)(n_half - 3))) * HSLOT, (uint32_t)lane * 16u, my_dst + 3u * HSLOT);
 #pragma unroll
     for (int hc = 0; hc < 3; ++hc)
         if (hc < n_half) issue(hc);
@@ -1484,7 +1487,7 @@ extern "C" int dsvg_ffn_fwd(const void* x, const void* packed_fwd_layer, const f
         hipLaunchKernelGGL((ffn_fwd_half_kernel<TR, PK>), dim3(nbh), dim3(256), lds, st, (const bf16_t*)x,             \
                            (const bf16_t*)packed_fwd_layer, b1_folded, b2, (bf16_t*)y, (bf16_t*)h_out, (bf16_t*)xh_out,\
                            rstd_out, (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res, dbg_chunks,    \
-                           g_ffn_dbg_host);                                                                           \
+                           g_ffn_dbg_host, w_warm);                                                                   \
     } while (0)
         if (train && pk) DSVG_FFN_FWD_HALF(true, true);
         else if (train) DSVG_FFN_FWD_HALF(true, false);

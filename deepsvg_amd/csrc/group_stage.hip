@@ -1121,8 +1121,30 @@ constexpr int LC_IMG = 32 * LDX * 2;                    // bytes of one [32][LDX
 constexpr int LC_FWD_LDS = 4 * LC_IMG + LC_MAX * GD * 4;            // Z[2] | R[2] | biases
 constexpr int LC_BWD_LDS = 5 * LC_IMG;                              // G[2] | DP | WS[2]
 
+// Round 6: the chain runs on 16 workgroups (2 per XCD) and walks 5 matrices (640 KiB) that are cold in L2 - one dependent HBM
+// round trip after the other through two CUs per XCD.  Workgroups past the row tiles are PREFETCHERS: 8 per matrix (block b
+// runs on XCD b % 8, so 8 consecutive blocks cover the 8 L2s), each reads its matrix once and exits; the chain's own loads
+// then find the lines in L2.
+__device__ __forceinline__ void lc_prefetch_matrix(const bf16_t* w) {
+    const uint4* p = reinterpret_cast<const uint4*>(w) + threadIdx.x;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < GD * GD * 2 / (512 * 16); ++i) {
+        const uint4 v = p[i * 512];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    asm volatile("" ::"v"(acc));
+}
+
 __global__ __launch_bounds__(512, 2) void latent_chain_fwd_kernel(const LatentFwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
+    {
+        const int n_tiles = (a.n_rows + 31) / 32;
+        if ((int)blockIdx.x >= n_tiles) {
+            lc_prefetch_matrix(a.w[((int)blockIdx.x - n_tiles) >> 3]);
+            return;
+        }
+    }
     auto Zi = [&](int i) -> bf16_t* { return reinterpret_cast<bf16_t*>(smem + i * LC_IMG); };           // Z[0], Z[1]
     auto Ri = [&](int i) -> bf16_t* { return reinterpret_cast<bf16_t*>(smem + (2 + i) * LC_IMG); };     // R[0], R[1]
     float* sb = reinterpret_cast<float*>(smem + 4 * LC_IMG);
@@ -1200,6 +1222,13 @@ __device__ __forceinline__ bf16x8 row_frag_perm(const bf16_t* img, int ld, int r
 
 __global__ __launch_bounds__(512, 2) void latent_chain_bwd_kernel(const LatentBwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
+    {
+        const int n_tiles = (a.n_rows + 31) / 32;
+        if ((int)blockIdx.x >= n_tiles) {       // prefetcher workgroups (see lc_prefetch_matrix)
+            lc_prefetch_matrix(a.w[((int)blockIdx.x - n_tiles) >> 3]);
+            return;
+        }
+    }
     auto Gi = [&](int i) -> bf16_t* { return reinterpret_cast<bf16_t*>(smem + i * LC_IMG); };           // G[0], G[1]
     bf16_t* DP = reinterpret_cast<bf16_t*>(smem + 2 * LC_IMG);
     auto WSi = [&](int i) -> bf16_t* { return reinterpret_cast<bf16_t*>(smem + (3 + i) * LC_IMG); };    // WS[0], WS[1]
@@ -1464,6 +1493,12 @@ extern "C" int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, 
     return 0;
 }
 
+// prefetcher workgroups of a latent-chain launch: 8 per matrix while the row tiles leave most of the chip idle (DSVG_LC_WARM=0: none)
+static unsigned lc_prefetchers(int64_t rows, int n_mats) {
+    static const int on = getenv("DSVG_LC_WARM") ? atoi(getenv("DSVG_LC_WARM")) : 0;     // (round 6: measured without effect on the step, off)
+    return (on && (rows + 31) / 32 <= 64) ? 8u * (unsigned)n_mats : 0u;
+}
+
 /* the latent chain (see latent_chain_fwd_kernel): weights = n_res + 1 row-major bf16 [256, 256] matrices (residual blocks, then
  * the final linear), biases fp32 [256] each; z_out / r_out: n_res training outputs each (or NULL pointers arrays' entries) */
 extern "C" int dsvg_latent_chain_fwd(const void* z0, const void* const* weights, const float* const* biases, int32_t n_res,
@@ -1489,7 +1524,7 @@ extern "C" int dsvg_latent_chain_fwd(const void* z0, const void* const* weights,
     }
     DSVG_CHECK_ARG((al & 15) == 0, "latent_chain_fwd: operands must be 16-byte aligned");
     DSVG_ENSURE_LDS(latent_chain_fwd_kernel, LC_FWD_LDS);
-    hipLaunchKernelGGL(latent_chain_fwd_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(512), LC_FWD_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(latent_chain_fwd_kernel, dim3((unsigned)((rows + 31) / 32) + lc_prefetchers(rows, n_res + 1)), dim3(512), LC_FWD_LDS, (hipStream_t)stream, a);
     DSVG_LAUNCH_CHECK("latent_chain_fwd");
     return 0;
 }
@@ -1518,7 +1553,7 @@ extern "C" int dsvg_latent_chain_bwd(const void* dout, const void* const* weight
     }
     DSVG_CHECK_ARG((al & 15) == 0, "latent_chain_bwd: operands must be 16-byte aligned");
     DSVG_ENSURE_LDS(latent_chain_bwd_kernel, LC_BWD_LDS);
-    hipLaunchKernelGGL(latent_chain_bwd_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(512), LC_BWD_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(latent_chain_bwd_kernel, dim3((unsigned)((rows + 31) / 32) + lc_prefetchers(rows, n_res + 1)), dim3(512), LC_BWD_LDS, (hipStream_t)stream, a);
     DSVG_LAUNCH_CHECK("latent_chain_bwd");
     return 0;
 }
