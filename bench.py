@@ -896,7 +896,7 @@ def main():
                     roofline["traffic_collected_at"] = {"commit": t.get("commit"), "ffn_fused_hip_code_sha256_16": t.get("ffn_fused_hip_code_sha256_16"),
                                                         "current_ffn_fused_hip_code_sha256_16": sha,
                                                         "kernel_source_unchanged": t.get("ffn_fused_hip_code_sha256_16") == sha}
-            gcsv = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_graph_kernel_stats.csv") for r in (5, 4, 3))
+            gcsv = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_graph_kernel_stats.csv") for r in (6, 5, 4, 3))
                          if os.path.exists(q)), "")       # the newest committed trace of the replayed graph
             if os.path.exists(gcsv) and fused_fwd is not None:
                 for line in open(gcsv):
@@ -929,6 +929,27 @@ def main():
                                              "source": "committed: profiles/" + os.path.basename(gcsv) + " (split-K products + grouped "
                                                        "launches + their share of reduce_deferred, rocprofv3 --kernel-trace of the "
                                                        "replayed graph)"}
+            # HBM traffic of the WHOLE step from the committed per-kernel PMC summary (scripts/gpu_step_pmc.sh: rocprofv3 --pmc
+            # FETCH_SIZE / WRITE_SIZE in separate passes over 3 eager steps; FETCH doubled as the micro-architecture guide
+            # prescribes for gfx950): sum over kernels of (fetch + write) MB per launch x launches per step
+            pcsv = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_step_pmc_summary.csv") for r in (6, 5, 4, 3))
+                         if os.path.exists(q)), "")
+            if os.path.exists(pcsv):
+                tot_mb, n_ffn_launches = 0.0, 0
+                for line in open(pcsv):
+                    f = line.strip().rsplit(",", 8)         # (kernel names contain commas: the 8 numeric columns from the right)
+                    if len(f) != 9 or not f[1].isdigit():
+                        continue
+                    tot_mb += (float(f[3]) + float(f[4])) * int(f[1])
+                    if "ffn_fwd_kernel" in f[0]:
+                        n_ffn_launches += int(f[1])
+                # (`launches` counts every step of the profiled command - set-up pass, warm-up, timed: 8 ffn_fwd launches per step)
+                steps_pmc = n_ffn_launches / 8.0
+                if steps_pmc > 0:
+                    roofline["step_traffic_GB"] = round(tot_mb / steps_pmc / 1e3, 2)
+                    roofline["step_traffic_source"] = ("committed: profiles/" + os.path.basename(pcsv) + " (sum over the 60 kernels "
+                                                       "with the most time of (fetch x 2 + write) MB per launch x launches, / "
+                                                       f"{steps_pmc:.0f} profiled steps; eager launches, scripts/gpu_step_pmc.sh)")
             if a.ffn_replay > 0:
                 specs = [r[5] for r in ffn[:n_ffn] if "a" in r[5]]
                 replay_ffn(specs, a.ffn_replay, device)
