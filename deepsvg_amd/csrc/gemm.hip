@@ -680,7 +680,7 @@ int dsvg_reduce_partials_mixed(const float* part, int64_t P, int64_t stride, int
 // chunks (16 bytes each); its 256 threads are (256/cpb) row groups x cpb column chunks, every thread streams
 // 16-byte row segments with independent accumulators; row groups are combined through LDS; one partial row
 // per block goes to the workspace and is reduced in a fixed order.
-constexpr int CS_ROWS_MIN = 64, CS_ROWS_MAX = 1024;
+constexpr int CS_ROWS_MIN = 16, CS_ROWS_MAX = 1024;      // (round 6: 16 instead of 64 - a 4096-row column sum was 64 workgroups walking 8 dependent row loads each: 12-16 us)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, long long lda, long long M, int N,
                                                      float* __restrict__ part, float drop_p, uint32_t site,
@@ -773,7 +773,7 @@ extern "C" int dsvg_colsum(int32_t dtype, const void* A, int64_t lda, int64_t M,
     while (cpb < 64 && cpb < chunks) cpb *= 2;
     const int vec_ok = !(lda % vec) && !((uintptr_t)A & 15);
     const int col_blocks = dsvg_cdiv(chunks, cpb);
-    // enough row blocks to fill the chip (~1024 workgroups), between 64 and 1024 rows each
+    // enough row blocks to fill the chip (~1024 workgroups), between 16 and 1024 rows each
     long long rpb = M / max(1, 1024 / col_blocks);
     rpb = rpb < CS_ROWS_MIN ? CS_ROWS_MIN : (rpb > CS_ROWS_MAX ? CS_ROWS_MAX : rpb);
     const int nb = dsvg_cdiv(M, rpb);
