@@ -172,6 +172,17 @@ __device__ __forceinline__ void ffn_stamp(unsigned long long* d, int slot) {
     }
 }
 
+// development probe of ffn_bwd_dx_kernel (dsvg_ffn_debug_clock with bit 1 of the buffer address set; scripts/ffn_bwd_dx_probe.py): 8
+// stamps of the chip-wide 100 MHz counter per wave - start, first chunk ready, K loop done, x rows landed + statistics, LayerNorm
+// math done, residual rows landed, stores issued, masked pass done
+__device__ __forceinline__ void bwd_stamp(unsigned long long* d, int slot) {
+    if (d && (threadIdx.x & 63) == 0) {
+        typedef unsigned long long __attribute__((address_space(1))) * gptr_t;
+        gptr_t b = (gptr_t)(reinterpret_cast<uintptr_t>(d) & ~(uintptr_t)3);
+        b[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 // The wave's 32 rows, one row per lane pair (lane half h owns the columns 16 ks + 8 h .. + 7 of every K step): LayerNorm
 // without the affine part (folded into W1' / b1') -> the 16 B-operand fragments xf; TRAIN also stores xh and rstd.
 // The statistics come from the packed words (ln_stats_packed, fused_common.h: the prologue is instruction-issue-bound).
@@ -832,12 +843,15 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_hidden_kernel(const bf16_t* __
 // KiB of every 48 KiB backward chunk) stream through a 4-slot LDS ring.  The LayerNorm backward needs no gamma (it is
 // inside W1'): dx = dy + rstd * (g - mean(g) - xh * mean(g * xh)), g = dxh, statistics over the row in registers.
 // ---------------------------------------------------------------------------------------------------------------------
+template <bool PROBE>       // (PROBE: the stamps below; the production instantiation carries none of their code - they cost it 33 spilled registers)
 __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __restrict__ dpre, const bf16_t* __restrict__ x,
                                                             const bf16_t* __restrict__ dy, const bf16_t* __restrict__ img,
                                                             bf16_t* __restrict__ dx, int M, float eps,
                                                             bf16_t* __restrict__ dxm, float drop_p,
-                                                            const uint64_t* __restrict__ seed, uint32_t site_m, int warm) {
+                                                            const uint64_t* __restrict__ seed, uint32_t site_m, int warm,
+                                                            unsigned long long* dbg) {
     constexpr int NBUF = 4, SLOT = 16 * FRAG;
+    if (PROBE) bwd_stamp(dbg, 0);
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // [4 x 16 KiB]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -878,6 +892,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
         else if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();       // chunk c landed for everybody; the slot of chunk c - 2 is free again
+        if (PROBE && c == 0) bwd_stamp(dbg, 1);
         if (c + 2 < NCH) issue(c + 2);
         const char* sc = lbase + (c % NBUF) * SLOT;
         Frag8 b0, b1;
@@ -897,7 +912,12 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
     chunk(NCH - 4, bq[0], false, 0); chunk(NCH - 3, bq[1], false, 2); chunk(NCH - 2, bq[2], false, 2);
     chunk(NCH - 1, bq[3], false, 0);
 
+    if (PROBE) bwd_stamp(dbg, 2);
     // ---- epilogue: LayerNorm backward on the rows in registers ------------------------------------------------------------
+    // (scripts/ffn_bwd_dx_probe.py, 63,488 rows: first chunk ready after 6 us, K loop 20 us, then three serialised bursts of the
+    // whole launch - x rows 9.5 us, residual rows 10.6 us, stores 10 us.  Round 6 tried to request the x rows before the loop:
+    // a wave's loads return IN ORDER, so as its oldest loads they delayed the first chunk by what the epilogue saved (first chunk
+    // ready after 16 us, x phase 2 us, step +1.5 %); behind the B operands of chunk c + 2 they can be at most 3 chunks early.)
     // tiles -> the lane's 16 consecutive columns per tile (in place), x row in the same layout
     const char* xrow = reinterpret_cast<const char*>(x) + (size_t)my_row * (FD * 2);
     uint4 xr[16];
@@ -918,6 +938,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
     float s, q, mean, rstd;
     ln_stats_packed(xr, s, q);
     ln_mean_rstd256(s, q, eps, mean, rstd);
+    if (PROBE) bwd_stamp(dbg, 3);
     const float shift = -mean * rstd;       // xh = x * rstd + shift
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -951,6 +972,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
         }
     // (the dy loads below must not be hoisted above the pass that frees the x registers: an address offset that is
     // opaque to the compiler - always 0 - and ordered behind the last value of that pass pins them here)
+    if (PROBE) bwd_stamp(dbg, 4);
     uint32_t zoff = 0;
     asm volatile("" : "+v"(zoff) : "v"(acc[7][15]), "v"(acc[0][0]));
     const char* dyrow = reinterpret_cast<const char*>(dy) + (size_t)my_row * (FD * 2) + zoff;
@@ -964,6 +986,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
         dr[2 * t] = *reinterpret_cast<const uint4*>(dyrow + (32 * t + 16 * half) * 2);
         dr[2 * t + 1] = *reinterpret_cast<const uint4*>(dyrow + (32 * t + 16 * half + 8) * 2);
     }
+    if (PROBE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); bwd_stamp(dbg, 5); }
     if (m < M) {
 #pragma unroll
         for (int t = 0; t < 8; ++t)
@@ -976,6 +999,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
                 *reinterpret_cast<uint4*>(orow + (32 * t + 16 * half + 8 * cb) * 2) = pack8(v);
             }
     }
+    if (PROBE) bwd_stamp(dbg, 6);
     if (mrow && m < M) {
         // second pass, from the rows this lane has just stored (L2-hot; the registers above are all in use in the first
         // pass): wait for the stores, then read back through an address the compiler cannot match with them
@@ -996,6 +1020,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dx_kernel(const bf16_t* __rest
             *reinterpret_cast<uint4*>(mrow + col * 2) = pack8(w);
         }
     }
+    if (PROBE) bwd_stamp(dbg, 7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1550,9 +1575,9 @@ extern "C" int dsvg_ffn_bwd(const void* x, const void* dy, const void* packed_bw
                        (const bf16_t*)packed_bwd_layer, b1_folded, (bf16_t*)h, (bf16_t*)dpre, (bf16_t*)xh, (bf16_t*)dym,
                        (int)rows, eps, drop_p, (const uint64_t*)seed, site_hidden, site_res);
     DSVG_LAUNCH_CHECK("ffn_bwd (hidden)");
-    hipLaunchKernelGGL(ffn_bwd_dx_kernel, dim3(nb), dim3(512), lds2, st, (const bf16_t*)dpre, (const bf16_t*)x,
+    hipLaunchKernelGGL(ffn_bwd_dx_kernel<false>, dim3(nb), dim3(512), lds2, st, (const bf16_t*)dpre, (const bf16_t*)x,
                        (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps, (bf16_t*)nullptr, 0.f,
-                       (const uint64_t*)nullptr, 0u, 0);
+                       (const uint64_t*)nullptr, 0u, 0, (unsigned long long*)nullptr);
     DSVG_LAUNCH_CHECK("ffn_bwd (dx)");
     return 0;
 }
@@ -1569,9 +1594,17 @@ extern "C" int dsvg_ffn_bwd_dx(const void* dpre, const void* x, const void* dy, 
     const int nb = (int)((rows + TOK_PER_WG - 1) / TOK_PER_WG);
     const size_t lds2 = 4 * 16 * FRAG;
     static const int w_warm = getenv("DSVG_W_WARM") ? atoi(getenv("DSVG_W_WARM")) : 1;      // A/B knob
-    hipLaunchKernelGGL(ffn_bwd_dx_kernel, dim3(nb), dim3(512), lds2, (hipStream_t)stream, (const bf16_t*)dpre,
+    unsigned long long* probe = ((uintptr_t)g_ffn_dbg_host & 2) ? g_ffn_dbg_host : nullptr;
+    if (probe)
+        hipLaunchKernelGGL(ffn_bwd_dx_kernel<true>, dim3(nb), dim3(512), lds2, (hipStream_t)stream, (const bf16_t*)dpre,
                        (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps,
-                       (bf16_t*)dx_masked, drop_p, (const uint64_t*)seed, drop_site, w_warm);
+                       (bf16_t*)dx_masked, drop_p, (const uint64_t*)seed, drop_site, w_warm,
+                       probe);
+    else
+        hipLaunchKernelGGL(ffn_bwd_dx_kernel<false>, dim3(nb), dim3(512), lds2, (hipStream_t)stream, (const bf16_t*)dpre,
+                       (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)packed_bwd_layer, (bf16_t*)dx, (int)rows, eps,
+                       (bf16_t*)dx_masked, drop_p, (const uint64_t*)seed, drop_site, w_warm,
+                       (unsigned long long*)nullptr);
     DSVG_LAUNCH_CHECK("ffn_bwd_dx");
     return 0;
 }
