@@ -258,7 +258,9 @@ def ddp_one_rank_leg(cfg, sd_cpu, batches, device, a, use_graph, steps=20):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+    import datetime
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device,
+                            timeout=datetime.timedelta(seconds=90))       # (a leg of the default run must never hang it)
     try:
         m = deepsvg_amd.SVGTransformer(cfg)
         m.load_state_dict(sd_cpu)
