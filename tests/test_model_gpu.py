@@ -645,6 +645,47 @@ def test_masked_gradient_hand_off_is_taken_and_changes_nothing(gpu_device):
     assert runs[True][2] <= runs[False][2] - 6, (runs[True][2], runs[False][2])       # 8 large layers: 6+ hand-offs taken
 
 
+def test_fused_attention_input_gradient_in_the_training_step(gpu_device):
+    """functional.ATTN_BWD_DX (round 6, opt-in: DSVG_ATTN_BWD_DX=1): the attention half's input gradient of the 8 large layers as one
+    launch each (dsvg_attn_bwd_dx) instead of the input-gradient GEMM + LayerNorm backward.  Same step, same dropout draws: the
+    losses are identical (the forward pass is untouched), every parameter gradient agrees in DIRECTION with the two-launch path to
+    bf16 rounding of one intermediate (the pair rounds dxn1 to bf16, the fused kernel does not): relative L2 distance of the
+    flat gradient < 1 %, and the fused path really ran (8 launches)."""
+    import deepsvg_amd.functional as Fn
+    from deepsvg_amd.trainer import TrainStep
+    cfg = H.build_cfg("hier")
+    cfg.dropout = 0.1
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 37)
+    c, a = (t.to(DEV) for t in make_batch(320, seed=11))
+    runs = {}
+    saved = Fn.ATTN_BWD_DX
+    try:
+        for on in (False, True):
+            Fn.ATTN_BWD_DX = on
+            torch.manual_seed(5)
+            model = _hip_model(cfg, sd, torch.bfloat16).train()
+            ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=0.0, use_graph=False)
+            ops.PROFILE.clear()
+            ops.PROFILE_ON = True
+            try:
+                ld = ts.step(c, a)
+                torch.cuda.synchronize()
+            finally:
+                ops.PROFILE_ON = False
+            n_fused = sum(1 for r in ops.PROFILE if r[5].get("op") == "attn_bwd_dx")
+            n_ln = sum(1 for r in ops.PROFILE if r[5].get("op") == "layernorm_bwd")
+            ops.PROFILE.clear()
+            runs[on] = ({k: float(v) for k, v in ld.items()}, model.store.grad_buffer(0).detach().clone(), n_fused, n_ln)
+    finally:
+        Fn.ATTN_BWD_DX = saved
+        ops.PROFILE_ON = False
+    assert runs[True][0] == runs[False][0]
+    assert runs[False][2] == 0 and runs[True][2] == 8, (runs[True][2:], runs[False][2:])       # the 4 + 4 large layers
+    g1, g0 = runs[True][1], runs[False][1]
+    rel = ((g1 - g0).norm() / g0.norm()).item()
+    assert g1.isfinite().all() and rel < 1e-2, rel
+
+
 def test_one_launch_weight_images_equal_the_stand_alone_launches(gpu_device):
     """model.PACK_ONE_LAUNCH (round 5): the bf16 flat copy, the fused FFN / attention / attention-backward / group-stage weight
     images and the seed advance of a training step come from ONE launch (dsvg_pack_images) - bit-identical to the 7 + 1 stand-alone
