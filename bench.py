@@ -801,8 +801,9 @@ def main():
             unf_fwd_rows = sum(r[5]["a"][0] for r in ffn if r[5].get("act") == 1) / n_prof      # linear1 of an unfused layer
             bwd_rows = sum(r[5].get("rows", 0) for r in ffn if r[5].get("op") in ("ffn_bwd_dx", "ffn_bwd")) / n_prof
             unf_bwd_rows = sum(r[5]["a"][0] for r in ffn if r[5].get("gate")) / n_prof - bwd_rows   # gated dX GEMM: all layers
-            gs_fwd_rows = sum(r[5]["rows"] for r in gsr if r[5]["op"] == "gs_layer_fwd")
-            gs_bwd_rows = sum(r[5]["rows"] for r in gsr if r[5]["op"] == "gs_layer_bwd")
+            # (a stack launch, round 6, carries its rows through `layers` layers)
+            gs_fwd_rows = sum(r[5]["rows"] * r[5].get("layers", 1) for r in gsr if r[5]["op"] in ("gs_layer_fwd", "gs_stack_fwd"))
+            gs_bwd_rows = sum(r[5]["rows"] * r[5].get("layers", 1) for r in gsr if r[5]["op"] in ("gs_layer_bwd", "gs_stack_bwd"))
             fused_bytes = 1024.0 * (fwd_rows + unf_fwd_rows + gs_fwd_rows) + 1536.0 * (bwd_rows + max(unf_bwd_rows, 0.0) + gs_bwd_rows)
             gbs = fused_bytes / (ffn_ms * 1e-3) / 1e9
             # like-for-like with round 1's definition (matrix launches only: norm2, dropout replay, finishing kernel left out)
@@ -870,9 +871,11 @@ def main():
                         "matrix_launches_only": {"ms_per_step": round(mm_ms, 3),
                                                  "frac": round(flop_exec / (mm_ms * 1e-3) / 1e12 / peak_tf, 4),
                                                  "note": "round 1's accounting: launches that execute FLOPs only"},
-                        "group_stage_layers": {"kernel": "gs_layer_fwd / gs_layer_bwd (one launch per layer and direction for the "
-                                                         "4096-row stages: LN + in_proj + attention + out_proj + LN + FFN)",
+                        "group_stage_layers": {"kernel": "gs_stack_fwd / gs_stack_bwd (ONE launch per 4-layer stack and direction for the "
+                                                         "4096-row stages) + gs_layer_fwd (the remainder rows of the second decoder "
+                                                         "stage, one launch per layer): LN + in_proj + attention + out_proj + LN + FFN",
                                                "launches_per_step": len(gsr),
+                                               "layers_per_step": sum(r[5].get("layers", 1) for r in gsr),
                                                "ms_per_step": round(sum(r[1].elapsed_time(r[2]) for r in gsr), 3),
                                                "ffn_share_ms": round(gs_ffn_ms, 3)} if gsr else None,
                         "fused_fwd_kernel": fused_fwd,

@@ -260,9 +260,12 @@ __device__ __forceinline__ float row_total(float part, float* stat, int wave, in
     return t;
 }
 
+// One layer of a tile.  `first`: the tile's rows come from a.x; otherwise (layers 1 .. of a STACK launch, gs_stack_fwd_kernel)
+// they are what the previous layer left on chip - its x2 image in XN and, for the residual, the same values at this lane's
+// result positions in `xc` (bf16-rounded, as a.x would hold them) - so a.x is not read at all.  On return xc holds this layer's x2.
 template <bool TRAIN, int PF>
-__global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
+__device__ __forceinline__ void gs_fwd_layer(const GsFwdArgs& a, char* smem, const bool first, float (&xc)[16],
+                                             const bf16_t* warm_next) {
     gs_stamp(a.dbg, 0);
     bf16_t* XN = reinterpret_cast<bf16_t*>(smem + F_XN);
     bf16_t* AO = reinterpret_cast<bf16_t*>(smem + F_AO);
@@ -279,7 +282,11 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
     float* sbe2 = sg2 + 256;
     float* stat = reinterpret_cast<float*>(smem + F_STAT);
 
-    const int tid = threadIdx.x;
+    // (opaque per call: inside a stack launch's layer loop nothing derived from the thread index is hoisted out of the loop and
+    // kept in registers across the whole layer)
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, h2 = lane >> 5;
@@ -294,8 +301,15 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
     // prefetch ring could only be waited for together with the whole ring
     const int r0 = wave * 4 + (lane >> 4), c00 = (lane & 15) * 16;
     const long long gr0 = row0 + min(r0, S - 1);
-    const uint4 ra = *reinterpret_cast<const uint4*>(a.x + gr0 * GD + c00);
-    const uint4 rb = *reinterpret_cast<const uint4*>(a.x + gr0 * GD + c00 + 8);
+    uint4 ra, rb;
+    if (first) {
+        ra = *reinterpret_cast<const uint4*>(a.x + gr0 * GD + c00);
+        rb = *reinterpret_cast<const uint4*>(a.x + gr0 * GD + c00 + 8);
+    } else {
+        // (the previous layer's barrier B4 is behind every wave: the image is complete; phase 0 overwrites it behind a barrier)
+        ra = *reinterpret_cast<const uint4*>(&XN[r0 * LDX + c00]);
+        rb = *reinterpret_cast<const uint4*>(&XN[r0 * LDX + c00 + 8]);
+    }
     const bool has_seed = a.seed != nullptr && a.drop_p > 0.f;
     const uint64_t seedv = has_seed ? *a.seed : 0ull;
     for (int i = tid; i < 768; i += 512) sbin[i] = a.in_bias[i];
@@ -304,7 +318,10 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         sbo[tid] = a.out_bias[tid]; sb2[tid] = a.b2[tid];
         sg1[tid] = a.g1[tid]; sbe1[tid] = a.be1[tid]; sg2[tid] = a.g2[tid]; sbe2[tid] = a.be2[tid];
     }
-    gs_warm_l2(a.img, wave, lane, __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)DSVG_LDS_PTR(smem) + F_LDS + wave * 1024), a.warm);
+    const uint32_t dump = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)DSVG_LDS_PTR(smem) + F_LDS + wave * 1024);
+    // warm (DSVG_GS_WARM): 1 = this layer's image up front - every layer of a stack launch, like the per-layer launches; 2 (stack launches,
+    // A/B) = layer 0's up front, the NEXT layer's before every layer's last phase; 3 = both
+    if ((a.warm & 1) || (first && a.warm)) gs_warm_l2(a.img, wave, lane, dump, 1);
     WStream<PF> ws;
     ws.start(a.img, wave, lane);
 
@@ -461,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         uint2 xr[4], gr4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            xr[c] = *reinterpret_cast<const uint2*>(a.x + mrow * GD + qc + 8 * c + 4 * h2);
+            if (first) xr[c] = *reinterpret_cast<const uint2*>(a.x + mrow * GD + qc + 8 * c + 4 * h2);
             if (a.gadd) gr4[c] = *reinterpret_cast<const uint2*>(a.gadd + (long long)my_seq * a.gadd_ld + qc + 8 * c + 4 * h2);
         }
         floatx16 ya;
@@ -483,8 +500,14 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
             float dm[4], gm[4];
             drop_mult4(dr1, drow * GD + qc + 8 * c, h2, dm);
             if (a.gadd) drop_mult4(dg, dseq * GD + qc + 8 * c, h2, gm);
-            const float xv[4] = {__uint_as_float(xr[c].x << 16), __uint_as_float(xr[c].x & 0xffff0000u),
-                                 __uint_as_float(xr[c].y << 16), __uint_as_float(xr[c].y & 0xffff0000u)};
+            float xv[4];
+            if (first) {
+                xv[0] = __uint_as_float(xr[c].x << 16); xv[1] = __uint_as_float(xr[c].x & 0xffff0000u);
+                xv[2] = __uint_as_float(xr[c].y << 16); xv[3] = __uint_as_float(xr[c].y & 0xffff0000u);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[e] = xc[4 * c + e];
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = (ya[4 * c + e] + sbo[qc + 8 * c + 4 * h2 + e]) * dm[e] + xv[e];
@@ -571,6 +594,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
     }
     lds_barrier();                                       // B3: the hidden activations of the tile are in LDS
     gs_stamp(a.dbg, 4);
+    if (warm_next && (a.warm & 2)) gs_warm_l2(warm_next, wave, lane, dump, 1);
     if (TRAIN) {
         if (a.ffn_format) store_image_frag512(a.h + row0 * GF, HI, LDH, S);
         else store_image(a.h + row0 * GF, GF, HI, LDH, 0, S, GF);
@@ -602,11 +626,78 @@ __global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a)
         }
         // every wave is past B3: nobody reads XN (linear1) any more
         stage_rows(XN, LDX, li, qc, h2, t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xc[r] = bf2f(f2bf(t[r]));          // (what the stored x2 holds)
     }
     lds_barrier();                                       // B4
     gs_stamp(a.dbg, 5);
-    store_image(a.x2 + row0 * GD, GD, XN, LDX, 0, S, GD);
+    if (a.x2) store_image(a.x2 + row0 * GD, GD, XN, LDX, 0, S, GD);     // (NULL: an inner layer of an inference stack launch)
     gs_stamp(a.dbg, 6);
+}
+
+// Block l of an array of argument structs that starts the kernel's argument list.  (A run-time index into the by-value argument
+// would move it to scratch memory: the words are read from the kernel argument segment itself - scalar loads, constant memory.)
+typedef const __attribute__((address_space(4))) unsigned long long* gs_kargs_t;
+template <typename T>
+__device__ __forceinline__ T gs_karg(int l) {
+    static_assert(sizeof(T) % 8 == 0, "whole 8-byte words");
+    constexpr int W = sizeof(T) / 8;
+    gs_kargs_t kw = (gs_kargs_t)__builtin_amdgcn_kernarg_segment_ptr() + (size_t)l * W;
+    union U { T a; unsigned long long w[W]; __device__ U() {} } u;
+#pragma unroll
+    for (int i = 0; i < W; ++i) u.w[i] = kw[i];
+    return u.a;
+}
+// A pointer that was read as a plain word is a GENERIC pointer to the compiler: every access through it becomes a flat_load /
+// flat_store, which counts on vmcnt AND lgkmcnt and may return out of order with LDS traffic - the counted waits of the weight
+// prefetch ring degrade to "wait for everything" (measured: the stack launch 10 % slower than its layers launched one by one).
+// Rebuilt from the word as an address-space-1 pointer it is what a by-value kernel argument is implicitly: a global pointer.
+template <typename T>
+__device__ __forceinline__ T* gs_global(T* p) {
+    return (T*)(T __attribute__((address_space(1)))*)(unsigned long long)p;
+}
+__device__ __forceinline__ const bf16_t* gs_karg_ptr(size_t byte_off) {
+    gs_kargs_t kw = (gs_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    return gs_global(reinterpret_cast<const bf16_t*>(kw[byte_off / 8]));
+}
+__device__ __forceinline__ GsFwdArgs gs_globalize(GsFwdArgs a) {
+#define G(f) a.f = gs_global(a.f)
+    G(x); G(img); G(in_bias); G(out_bias); G(b1); G(b2); G(g1); G(be1); G(g2); G(be2); G(key_mask); G(gadd); G(seed);
+    G(x2); G(mean1); G(rstd1); G(xn1); G(qkv); G(ao); G(x1); G(mean2); G(rstd2); G(xn2); G(h); G(dbg);
+#undef G
+    return a;
+}
+
+template <bool TRAIN, int PF>
+__global__ __launch_bounds__(512, 2) void gs_layer_fwd_kernel(const GsFwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    float xc[16];
+    gs_fwd_layer<TRAIN, PF>(a, smem, true, xc, nullptr);
+}
+
+// A whole STACK of layers in one launch (round 6): the tiles are independent across the layers (a tile holds whole sequences), so
+// a workgroup carries its 32 rows through all of them - no launch ramp / drain per layer, the rows never come back from memory,
+// and layer l + 1's weight image is requested into L2 while layer l computes.  Everything a layer stores for the backward pass
+// is stored as by the per-layer launches: bit-identical results (tests/test_kernels_gpu.py).
+constexpr int GS_STACK_MAX = 4;
+struct GsFwdStackArgs {
+    GsFwdArgs layer[GS_STACK_MAX];
+    int n_layers;
+};
+template <bool TRAIN, int PF>
+__global__ __launch_bounds__(512, 2) void gs_stack_fwd_kernel(const GsFwdStackArgs A) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    // (a run-time index into the by-value argument would move it to scratch memory: the layer's block is read from the kernel
+    // argument segment itself - scalar loads from constant memory)
+    const int n = A.n_layers;
+    float xc[16];
+#pragma unroll 1
+    for (int l = 0; l < n; ++l) {
+        const GsFwdArgs a = gs_globalize(gs_karg<GsFwdArgs>(l));
+        const bf16_t* next = l + 1 < n ? gs_karg_ptr((size_t)(l + 1) * sizeof(GsFwdArgs) + offsetof(GsFwdArgs, img)) : nullptr;
+        gs_fwd_layer<TRAIN, PF>(a, smem, l == 0, xc, next);
+        // (the next layer's first LDS writes - parameter staging - touch nothing store_image reads; its phase 0 writes XN behind a barrier)
+    }
 }
 
 
@@ -623,7 +714,8 @@ struct GsBwdArgs {
     const float* g1; const float* g2;
     const uint64_t* key_mask; const uint64_t* seed;
     bf16_t* dx; bf16_t* dx1; bf16_t* dym; bf16_t* dpre; bf16_t* dx1m; bf16_t* dqkv;
-    bf16_t* dg;             // [n_seq][256] or NULL: the per-sequence term's gradient (what dsvg_bcast_add_bwd makes of dx1)
+    bf16_t* dg;             // [n_seq][dg_ld] or NULL: the per-sequence term's gradient (what dsvg_bcast_add_bwd makes of dx1)
+    long long dg_ld;        // row stride (elements) of dg: 256, or the stack's concatenated buffer (layer l = column block l)
     float* ln_part;         // [tiles][4][256]: dgamma2, dbeta2, dgamma1, dbeta1
     int n_seq, S;
     int per;                // whole sequences per tile (see gs_per)
@@ -700,9 +792,11 @@ __device__ __forceinline__ void unpack4(const uint2 t, float* v) {
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
 
+// One layer of a tile.  `first`: the incoming gradient comes from a.dx2; otherwise (a STACK launch, gs_stack_bwd_kernel, walking
+// the layers from the last to the first) it is the dx image the layer above left in HI.  a.dx may be NULL (nobody reads the
+// gradient between two layers of a stack launch).
 template <int PF>
-__global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
+__device__ __forceinline__ void gs_bwd_layer(const GsBwdArgs& a, char* smem, const bool first, const bf16_t* warm_next) {
     bf16_t* A0 = reinterpret_cast<bf16_t*>(smem + B_A0);
     bf16_t* A1 = reinterpret_cast<bf16_t*>(smem + B_A1);
     bf16_t* DO = reinterpret_cast<bf16_t*>(smem + B_DO);
@@ -711,11 +805,16 @@ __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a)
     float* sg1 = reinterpret_cast<float*>(smem + B_SMALL);
     float* sg2 = sg1 + 256;
     float* stat = reinterpret_cast<float*>(smem + B_STAT);
-    float* my_stat = reinterpret_cast<float*>(smem + B_ASTAT) + (threadIdx.x >> 6) * 96;
+    float* my_stat_base = reinterpret_cast<float*>(smem + B_ASTAT);
 
-    const int tid = threadIdx.x;
+    // (opaque per call: inside a stack launch's layer loop nothing derived from the thread index is hoisted out of the loop and
+    // kept in registers across the whole layer)
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* my_stat = my_stat_base + wave * 96;
     const int li = lane & 31, h2 = lane >> 5;
     const int Smax = a.S;
     const int per = a.per;
@@ -731,8 +830,15 @@ __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a)
     // ---- phase 0: everything the tile reads up front goes out before the weight stream starts ----------------------------------
     const int r0 = wave * 4 + (lane >> 4), c00 = (lane & 15) * 16;
     const long long gr0 = row0 + min(r0, S - 1);
-    const uint4 ra = *reinterpret_cast<const uint4*>(a.dx2 + gr0 * GD + c00);
-    const uint4 rb = *reinterpret_cast<const uint4*>(a.dx2 + gr0 * GD + c00 + 8);
+    uint4 ra, rb;
+    if (first) {
+        ra = *reinterpret_cast<const uint4*>(a.dx2 + gr0 * GD + c00);
+        rb = *reinterpret_cast<const uint4*>(a.dx2 + gr0 * GD + c00 + 8);
+    } else {
+        // (behind the layer above's barrier B4b; HI is next written behind this layer's barrier B0)
+        ra = *reinterpret_cast<const uint4*>(&HI[r0 * LDX + c00]);
+        rb = *reinterpret_cast<const uint4*>(&HI[r0 * LDX + c00 + 8]);
+    }
     // the q|k|v rows of the tile: 32 x 96 pieces of 16 bytes, 6 per thread (named registers: an array lands in scratch memory)
 #define GS_QV_SRC(k) (a.qkv + (row0 + min((tid + 512 * (k)) / 96, S - 1)) * (3 * GD) + 8 * ((tid + 512 * (k)) % 96))
     const uint4 qv0 = *reinterpret_cast<const uint4*>(GS_QV_SRC(0)), qv1 = *reinterpret_cast<const uint4*>(GS_QV_SRC(1));
@@ -758,7 +864,8 @@ __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a)
     const int qi = min(li / Smax, n_in - 1);
     const int my_seq = s_first + qi, my_start = qi * Smax;
     const uint32_t kmask_raw = a.key_mask ? (uint32_t)a.key_mask[my_seq] : ~0u;
-    gs_warm_l2(a.img, wave, lane, __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)DSVG_LDS_PTR(smem) + B_LDS + wave * 1024), a.warm);
+    const uint32_t dump = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)DSVG_LDS_PTR(smem) + B_LDS + wave * 1024);
+    if ((a.warm & 1) || (first && a.warm)) gs_warm_l2(a.img, wave, lane, dump, 1);
     WStream<PF> ws;
     ws.start(a.img, wave, lane);
 
@@ -905,7 +1012,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sv[e] *= dm[e];
             }
-            *reinterpret_cast<uint4*>(a.dg + (long long)(s_first + sq) * GD + c8) = pack8(sv);
+            *reinterpret_cast<uint4*>(a.dg + (long long)(s_first + sq) * a.dg_ld + c8) = pack8(sv);
         }
     }
 
@@ -1045,6 +1152,7 @@ __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a)
     }
     lds_barrier();                                       // B3: dq | dk | dv of all heads
     store_image(a.dqkv + row0 * (3 * GD), 3 * GD, QKV, LDQ, 0, S, 3 * GD);
+    if (warm_next && (a.warm & 2)) gs_warm_l2(warm_next, wave, lane, dump, 1);
 
     // ---- phase 4: dxn1 = dqkv . Win (column block w), LayerNorm 1 backward, + dx1 -> dx ---------------------------------------------
     {
@@ -1074,7 +1182,41 @@ __global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a)
     }
     lds_barrier();                                       // B4b
     col_sums(A0, A1, qc, lane, part + 512);              // dgamma1 | dbeta1
-    store_image(a.dx + row0 * GD, GD, HI, LDX, 0, S, GD);
+    if (a.dx) store_image(a.dx + row0 * GD, GD, HI, LDX, 0, S, GD);
+}
+
+__device__ __forceinline__ GsBwdArgs gs_globalize(GsBwdArgs a) {
+#define G(f) a.f = gs_global(a.f)
+    G(dx2); G(img); G(x); G(mean1); G(rstd1); G(qkv); G(x1); G(mean2); G(rstd2); G(h); G(g1); G(g2); G(key_mask); G(seed);
+    G(dx); G(dx1); G(dym); G(dpre); G(dx1m); G(dqkv); G(dg); G(ln_part);
+#undef G
+    return a;
+}
+
+template <int PF>
+__global__ __launch_bounds__(512, 2) void gs_layer_bwd_kernel(const GsBwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    gs_bwd_layer<PF>(a, smem, true, nullptr);
+}
+
+// the backward pass of a whole stack in one launch: layer[0] is the LAST layer of the stack (the first one walked), see
+// gs_stack_fwd_kernel
+struct GsBwdStackArgs {
+    GsBwdArgs layer[GS_STACK_MAX];
+    int n_layers;
+};
+template <int PF>
+__global__ __launch_bounds__(512, 2) void gs_stack_bwd_kernel(const GsBwdStackArgs A) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int n = A.n_layers;
+#pragma unroll 1
+    for (int l = 0; l < n; ++l) {
+        const GsBwdArgs a = gs_globalize(gs_karg<GsBwdArgs>(l));
+        const bf16_t* next = l + 1 < n ? gs_karg_ptr((size_t)(l + 1) * sizeof(GsBwdArgs) + offsetof(GsBwdArgs, img)) : nullptr;
+        gs_bwd_layer<PF>(a, smem, l == 0, next);
+        // the layer's last reads of A0 / A1 (col_sums) and HI (the dx store) sit behind its barrier B4b; the next layer's phase 0 overwrites A0 / A1
+        lds_barrier();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1467,7 +1609,7 @@ extern "C" int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, 
     a.x1 = (const bf16_t*)x1; a.mean2 = mean2; a.rstd2 = rstd2; a.h = (const bf16_t*)h;
     a.g1 = gamma1; a.g2 = gamma2; a.key_mask = key_mask; a.seed = (const uint64_t*)seed;
     a.dx = (bf16_t*)dx; a.dx1 = (bf16_t*)dx1; a.dym = (bf16_t*)dym; a.dpre = (bf16_t*)dpre; a.dx1m = (bf16_t*)dx1m;
-    a.dqkv = (bf16_t*)dqkv; a.dg = (bf16_t*)dg; a.ln_part = (float*)workspace;
+    a.dqkv = (bf16_t*)dqkv; a.dg = (bf16_t*)dg; a.dg_ld = GD; a.ln_part = (float*)workspace;
     a.n_seq = (int)n_seq; a.S = S; a.scale = scale; a.drop_p = drop_p; a.site0 = site0;
     const int per = gs_per(n_seq, S);
     a.per = per;
@@ -1489,6 +1631,112 @@ extern "C" int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, 
     for (int k = 0; k < 4; ++k) {
         const int rc = dsvg_reduce_partials_strided((const float*)workspace + 256 * k, nb, 1024, 256, outs[k], 0, st);
         if (rc) return rc;
+    }
+    return 0;
+}
+
+/* ---- one launch per STACK (round 6) ----------------------------------------------------------------------------------- */
+extern "C" int dsvg_gs_stack_fwd(const void* x, const dsvg_gs_fwd_layer* layers, int32_t n_layers, const uint64_t* key_mask,
+                                 int64_t seq_add_ld, int64_t n_seq, int32_t S, float eps, float scale, float drop_p,
+                                 const void* seed, void* stream) {
+    DSVG_CHECK_ARG(x && layers, "gs_stack_fwd: null pointer");
+    DSVG_CHECK_ARG(n_layers >= 1 && n_layers <= GS_STACK_MAX, "gs_stack_fwd: 1 .. %d layers per launch (got %d)", GS_STACK_MAX, n_layers);
+    DSVG_CHECK_ARG(S >= 1 && S <= 32, "gs_stack_fwd: sequences of 1 .. 32 rows (got %d)", S);
+    DSVG_CHECK_ARG(n_seq > 0 && n_seq * S < (1ll << 31), "gs_stack_fwd: bad sizes");
+    DSVG_CHECK_ARG(!(drop_p > 0.f) || seed, "gs_stack_fwd: dropout needs a seed");
+    const bool train = layers[0].xn1 != nullptr;
+    const int per = gs_per(n_seq, S);
+    GsFwdStackArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n_layers = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        const dsvg_gs_fwd_layer& L = layers[l];
+        DSVG_CHECK_ARG(L.packed_fwd_layer && L.in_bias && L.out_bias && L.b1 && L.b2 && L.gamma1 && L.beta1 && L.gamma2 && L.beta2,
+                       "gs_stack_fwd: null pointer in layer %d", l);
+        DSVG_CHECK_ARG((L.xn1 != nullptr) == train, "gs_stack_fwd: training outputs for every layer or for none");
+        DSVG_CHECK_ARG(!train || (L.x2 && L.mean1 && L.rstd1 && L.qkv && L.ao && L.x1 && L.mean2 && L.rstd2 && L.xn2 && L.h),
+                       "gs_stack_fwd: the training outputs of layer %d come together", l);
+        DSVG_CHECK_ARG(L.x2 || l + 1 < n_layers, "gs_stack_fwd: the last layer needs x2");
+        DSVG_CHECK_ARG(!L.seq_add || (seq_add_ld >= GD && seq_add_ld % 8 == 0), "gs_stack_fwd: bad seq_add row stride %lld", (long long)seq_add_ld);
+        DSVG_CHECK_ARG((((uintptr_t)x | (uintptr_t)L.x2 | (uintptr_t)L.packed_fwd_layer | (uintptr_t)L.xn1 | (uintptr_t)L.qkv |
+                         (uintptr_t)L.ao | (uintptr_t)L.x1 | (uintptr_t)L.xn2 | (uintptr_t)L.h | (uintptr_t)L.seq_add) & 15) == 0,
+                       "gs_stack_fwd: operands must be 16-byte aligned");
+        GsFwdArgs& a = A.layer[l];
+        a.x = (const bf16_t*)(l == 0 ? x : layers[l - 1].x2);       // (read by layer 0 only)
+        a.img = (const bf16_t*)L.packed_fwd_layer;
+        a.in_bias = L.in_bias; a.out_bias = L.out_bias; a.b1 = L.b1; a.b2 = L.b2;
+        a.g1 = L.gamma1; a.be1 = L.beta1; a.g2 = L.gamma2; a.be2 = L.beta2;
+        a.key_mask = key_mask; a.gadd = (const bf16_t*)L.seq_add; a.seed = (const uint64_t*)seed;
+        a.gadd_ld = L.seq_add ? (long long)seq_add_ld : GD;
+        a.x2 = (bf16_t*)L.x2; a.mean1 = L.mean1; a.rstd1 = L.rstd1; a.xn1 = (bf16_t*)L.xn1; a.qkv = (bf16_t*)L.qkv;
+        a.ao = (bf16_t*)L.ao; a.x1 = (bf16_t*)L.x1; a.mean2 = L.mean2; a.rstd2 = L.rstd2; a.xn2 = (bf16_t*)L.xn2; a.h = (bf16_t*)L.h;
+        a.n_seq = (int)n_seq; a.S = S; a.per = per; a.warm = gs_warm();
+        a.eps = eps; a.scale = scale; a.drop_p = drop_p; a.site0 = L.site0;
+        a.seq_base = 0; a.ffn_format = 0; a.dbg = nullptr;
+    }
+    const int nb = (int)((n_seq + per - 1) / per);
+    hipStream_t st = (hipStream_t)stream;
+    if (train) {
+        DSVG_ENSURE_LDS((gs_stack_fwd_kernel<true, GS_PF_DEFAULT>), F_LDS + GS_WARM_LDS);
+        hipLaunchKernelGGL((gs_stack_fwd_kernel<true, GS_PF_DEFAULT>), dim3(nb), dim3(512), F_LDS + GS_WARM_LDS, st, A);
+    } else {
+        DSVG_ENSURE_LDS((gs_stack_fwd_kernel<false, GS_PF_DEFAULT>), F_LDS + GS_WARM_LDS);
+        hipLaunchKernelGGL((gs_stack_fwd_kernel<false, GS_PF_DEFAULT>), dim3(nb), dim3(512), F_LDS + GS_WARM_LDS, st, A);
+    }
+    DSVG_LAUNCH_CHECK("gs_stack_fwd");
+    return 0;
+}
+
+extern "C" int dsvg_gs_stack_bwd(const void* dx2, const dsvg_gs_bwd_layer* layers, int32_t n_layers, const uint64_t* key_mask,
+                                 int64_t n_seq, int32_t S, float scale, float drop_p, const void* seed, int64_t workspace_bytes,
+                                 int64_t dg_ld, void* stream) {
+    DSVG_CHECK_ARG(dx2 && layers, "gs_stack_bwd: null pointer");
+    DSVG_CHECK_ARG(n_layers >= 1 && n_layers <= GS_STACK_MAX, "gs_stack_bwd: 1 .. %d layers per launch (got %d)", GS_STACK_MAX, n_layers);
+    DSVG_CHECK_ARG(S >= 1 && S <= 32 && (32 % S) == 0, "gs_stack_bwd: sequence length must divide 32 (got %d)", S);
+    DSVG_CHECK_ARG(n_seq > 0 && n_seq * S < (1ll << 31), "gs_stack_bwd: bad sizes");
+    DSVG_CHECK_ARG(!(drop_p > 0.f) || seed, "gs_stack_bwd: dropout needs a seed");
+    DSVG_CHECK_ARG(workspace_bytes >= dsvg_gs_bwd_workspace_bytes(n_seq, S), "gs_stack_bwd: workspaces too small");
+    DSVG_CHECK_ARG(dg_ld >= GD && dg_ld % 8 == 0, "gs_stack_bwd: bad dg row stride %lld", (long long)dg_ld);
+    const int per = gs_per(n_seq, S);
+    GsBwdStackArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n_layers = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        const dsvg_gs_bwd_layer& L = layers[l];                      // forward order
+        DSVG_CHECK_ARG(L.packed_bwd_layer && L.x && L.mean1 && L.rstd1 && L.qkv && L.x1 && L.mean2 && L.rstd2 && L.h && L.gamma1 && L.gamma2,
+                       "gs_stack_bwd: null input pointer in layer %d", l);
+        DSVG_CHECK_ARG(L.dym && L.dpre && L.dx1m && L.dqkv && L.dgamma2 && L.dbeta2 && L.dgamma1 && L.dbeta1 && L.workspace,
+                       "gs_stack_bwd: null output pointer in layer %d", l);
+        DSVG_CHECK_ARG(L.dx || l > 0, "gs_stack_bwd: layer 0 needs dx");
+        DSVG_CHECK_ARG((((uintptr_t)dx2 | (uintptr_t)L.x | (uintptr_t)L.qkv | (uintptr_t)L.x1 | (uintptr_t)L.h | (uintptr_t)L.dx |
+                         (uintptr_t)L.dx1 | (uintptr_t)L.dym | (uintptr_t)L.dpre | (uintptr_t)L.dx1m | (uintptr_t)L.dqkv |
+                         (uintptr_t)L.packed_bwd_layer | (uintptr_t)L.workspace | (uintptr_t)L.dg) & 15) == 0,
+                       "gs_stack_bwd: operands must be 16-byte aligned");
+        GsBwdArgs& a = A.layer[n_layers - 1 - l];                    // walked from the last layer to the first
+        a.dx2 = (const bf16_t*)dx2;                                  // (read by the first layer walked only)
+        a.img = (const bf16_t*)L.packed_bwd_layer;
+        a.x = (const bf16_t*)L.x; a.mean1 = L.mean1; a.rstd1 = L.rstd1; a.qkv = (const bf16_t*)L.qkv;
+        a.x1 = (const bf16_t*)L.x1; a.mean2 = L.mean2; a.rstd2 = L.rstd2; a.h = (const bf16_t*)L.h;
+        a.g1 = L.gamma1; a.g2 = L.gamma2; a.key_mask = key_mask; a.seed = (const uint64_t*)seed;
+        a.dx = (bf16_t*)L.dx; a.dx1 = (bf16_t*)L.dx1; a.dym = (bf16_t*)L.dym; a.dpre = (bf16_t*)L.dpre; a.dx1m = (bf16_t*)L.dx1m;
+        a.dqkv = (bf16_t*)L.dqkv; a.dg = (bf16_t*)L.dg; a.dg_ld = dg_ld; a.ln_part = (float*)L.workspace;
+        a.n_seq = (int)n_seq; a.S = S; a.per = per; a.warm = gs_warm();
+        a.scale = scale; a.drop_p = drop_p; a.site0 = L.site0;
+    }
+    const int nb = (int)((n_seq + per - 1) / per);
+    hipStream_t st = (hipStream_t)stream;
+    DSVG_ENSURE_LDS((gs_stack_bwd_kernel<GS_PF_DEFAULT>), B_LDS + GS_WARM_LDS);
+    hipLaunchKernelGGL((gs_stack_bwd_kernel<GS_PF_DEFAULT>), dim3(nb), dim3(512), B_LDS + GS_WARM_LDS, st, A);
+    DSVG_LAUNCH_CHECK("gs_stack_bwd");
+    // the LayerNorm parameter gradients of every layer: fixed-order sums of the per-tile partials, in the per-layer launches' order
+    // (last layer first; queued while a deferral scope is open on this stream)
+    for (int l = n_layers - 1; l >= 0; --l) {
+        const dsvg_gs_bwd_layer& L = layers[l];
+        float* outs[4] = {L.dgamma2, L.dbeta2, L.dgamma1, L.dbeta1};
+        for (int k = 0; k < 4; ++k) {
+            const int rc = dsvg_reduce_partials_strided((const float*)L.workspace + 256 * k, nb, 1024, 256, outs[k], 0, st);
+            if (rc) return rc;
+        }
     }
     return 0;
 }

@@ -53,6 +53,8 @@ STACK_GROUP_SLICES = int(os.environ.get("DSVG_STACK_GROUP_SLICES", "8"))    # to
 GS_BWD_DG = os.environ.get("DSVG_GS_BWD_DG", "1") != "0"
 # round 5: the argument head's input-gradient product with its reduced dimension padded to the LDS-DMA GEMM's K step
 HEAD_KPAD = os.environ.get("DSVG_HEAD_KPAD", "1") != "0"
+# round 6: the group-stage stacks as ONE launch per stack and direction (csrc/group_stage.hip gs_stack_*; 0: one launch per layer)
+GS_STACK = os.environ.get("DSVG_GS_STACK", "1") != "0"
 # attention backward of the large stages with the out_proj backward inside (no `dao = dx1m @ Wo` GEMM launch)
 ATTN_BWD_OUTPROJ = os.environ.get("DSVG_ATTN_BWD_OUTPROJ", "1") != "0"
 # ... which only exists on the MFMA attention kernels: the library's A/B knobs that route attention to the VALU kernels
@@ -555,6 +557,22 @@ class PackedEmbedFn(torch.autograd.Function):
 GLOBAL_COND_CAT = os.environ.get("DSVG_GLOBAL_COND_CAT", "1") != "0"
 
 
+def _adjacent_columns(ts):
+    """ts = the column blocks 0 .. n-1 of ONE row-major [rows, n * w] buffer (in order) -> that buffer as a tensor, else None"""
+    t0 = ts[0]
+    n = len(ts)
+    if t0.dim() != 2 or t0.stride(1) != 1:
+        return None
+    rows, w = t0.shape
+    es = t0.element_size()
+    for i, t in enumerate(ts):
+        if (t.dim() != 2 or tuple(t.shape) != (rows, w) or t.dtype != t0.dtype or t.stride(1) != 1 or t.stride(0) != n * w
+                or t.data_ptr() != t0.data_ptr() + i * w * es
+                or t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr()):
+            return None
+    return torch.as_strided(t0, (rows, n * w), (n * w, 1), t0.storage_offset())
+
+
 class GlobalCondFn(torch.autograd.Function):
     """The conditioning rows of a whole decoder stack at once: g_l = linear_global_l(z) for every layer l
     (layers/improved_transformer.py:131-132; z does not change between the layers).  Hoisted out of the layers so that the
@@ -592,11 +610,17 @@ class GlobalCondFn(torch.autograd.Function):
         rt = ctx.rt
         z, *wb = ctx.saved_tensors
         pairs = list(zip(wb[0::2], wb[1::2]))
-        dgs = [dg.contiguous() for dg in dgs]
         grads = []
         small = z.shape[0] < FFN_MIN_ROWS
         cat_ok = GLOBAL_COND_CAT and z.dtype == torch.bfloat16 and len(pairs) > 1 and all(dg.dtype == z.dtype for dg in dgs)
-        dgcat = torch.cat(dgs, 1) if cat_ok else None
+        # GsStackFn hands the gradients over as the column blocks of ONE buffer: that buffer is the concatenation (no launch)
+        dgcat = _adjacent_columns(dgs) if cat_ok else None
+        raw, dgs = dgs, None
+
+        def dg_blocks():            # the per-layer gradients as tensors of their own (the paths that do not use the concatenation)
+            return [dg.contiguous() for dg in raw]
+        if cat_ok and dgcat is None:
+            dgcat = torch.cat(dg_blocks(), 1)
         merged = None
         st = rt.store
         if cat_ok and st is not None and all(id(t) in st.index for pr in pairs for t in pr):
@@ -637,7 +661,7 @@ class GlobalCondFn(torch.autograd.Function):
             grads = merged
         else:
             with (rt.grouping() if small else _NULL_CTX):
-                for (w, b), dg in zip(pairs, dgs):
+                for (w, b), dg in zip(pairs, dg_blocks()):
                     blocks = (8 * -(-w.shape[0] // 128) * -(-w.shape[1] // 128)) if (small and GROUP_WGRAD) else None
                     grads += list(_wbgrad(rt, w, b, dg, z, blocks))
         dz = None
@@ -661,7 +685,7 @@ class GlobalCondFn(torch.autograd.Function):
                 dz = ops.gemm(dgcat, wcat, b_kc=False)
             else:
                 dz = torch.empty_like(z)
-                for i, ((w, _b), dg) in enumerate(zip(pairs, dgs)):
+                for i, ((w, _b), dg) in enumerate(zip(pairs, dg_blocks())):
                     ops.gemm(dg, rt.w(w), b_kc=False, out=dz, accumulate=i > 0)
         return (None, dz, *grads)
 
@@ -1032,6 +1056,96 @@ class LayerFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------------
+def gs_stack_eligible(rt, x, key_mask, n_seq, S, n_heads, n_layers, wins):
+    """the conditions of LayerFn's one-launch-per-layer route (csrc/group_stage.hip), for every layer of the stack"""
+    return (GS_STACK and rt.store is not None and x.dtype == torch.bfloat16 and n_heads == 8 and x.dim() == 2 and x.shape[1] == 256
+            and 32 % S == 0 and x.shape[0] == n_seq * S and x.shape[0] < min(ATTN_MIN_ROWS, FFN_MIN_ROWS)
+            and 1 <= n_layers <= ops.GS_STACK_MAX and (key_mask is None or key_mask.dtype == torch.int64)
+            and all(rt.store.gs(w) is not None for w in wins))
+
+
+class GsStackFn(torch.autograd.Function):
+    """A whole stack of pre-LN blocks of a short-sequence ("group") stage - the layer loops of
+    deepsvg/model/layers/transformer.py:168-188 / :214-242 over hierarchical_encoder / hierarchical_decoder
+    (deepsvg/model/model.py:153-161, :246-254) - as ONE launch forward and ONE backward (csrc/group_stage.hip: a workgroup
+    carries its 32 rows through all the layers).  Same stores, same draws, same gradients as LayerFn layer by layer (its `gs`
+    route); the conditioning rows g_l = linear_global_l(z) come projected (GlobalCondFn) and their gradients leave as the column
+    blocks of ONE [n_seq, n * 256] buffer - no concatenation launch in GlobalCondFn.backward.
+    tensors: per layer norm1.weight, norm1.bias, in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, norm2.weight,
+    norm2.bias, linear1.weight, linear1.bias, linear2.weight, linear2.bias [, g_l]; layer l draws at the sites site0 + 8 l + ..."""
+
+    @staticmethod
+    def forward(ctx, rt, x, key_mask, n_seq, S, n_heads, drop_rate, site0, n_layers, has_g, *tensors):
+        p = rt.p(drop_rate)
+        per = 13 if has_g else 12
+        assert len(tensors) == per * n_layers
+        scale = float(x.shape[1] // n_heads) ** -0.5
+        want_bwd = any(ctx.needs_input_grad)
+        layers = []
+        for i in range(n_layers):
+            n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2 = tensors[per * i:per * i + 12]
+            layers.append(dict(img=rt.store.gs(win)[0], in_bias=bin_.detach(), out_bias=bo.detach(), b1=b1.detach(), b2=b2.detach(),
+                               gamma1=n1w.detach(), beta1=n1b.detach(), gamma2=n2w.detach(), beta2=n2b.detach(),
+                               site0=site0 + 8 * i, seq_add=tensors[per * i + 12] if has_g else None))
+        with ops.tag("gs"):
+            res = ops.gs_stack_fwd(x, layers, key_mask, n_seq, S, scale, 1e-5, p, rt.seed, train=want_bwd)
+        rt.last_layer_gs = True
+        ctx.rt, ctx.n_seq, ctx.S, ctx.p, ctx.site0, ctx.scale, ctx.n, ctx.has_g = rt, n_seq, S, p, site0, scale, n_layers, has_g
+        if not want_bwd:
+            return res[-1]
+        saved = [x, key_mask]
+        for r in res:
+            saved += list(r)                # x2, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h
+        ctx.save_for_backward(*saved, *tensors)
+        return res[-1][0]
+
+    @staticmethod
+    def backward(ctx, dx2):
+        rt, n_seq, S, p, n, has_g = ctx.rt, ctx.n_seq, ctx.S, ctx.p, ctx.n, ctx.has_g
+        sv = ctx.saved_tensors
+        x, key_mask = sv[0], sv[1]
+        acts = [sv[2 + 11 * i:2 + 11 * (i + 1)] for i in range(n)]
+        tensors = sv[2 + 11 * n:]
+        per = 13 if has_g else 12
+        prm = [tensors[per * i:per * i + 12] for i in range(n)]
+        layers = []
+        for i in range(n):
+            x2, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h = acts[i]
+            n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2 = prm[i]
+            layers.append(dict(img=rt.store.gs(win)[1], x=x if i == 0 else acts[i - 1][0], mean1=mean1, rstd1=rstd1, qkv=qkv, x1=x1,
+                               mean2=mean2, rstd2=rstd2, h=h, gamma1=n1w.detach(), gamma2=n2w.detach(), site0=ctx.site0 + 8 * i,
+                               dgamma2=rt.grad_out(n2w), dbeta2=rt.grad_out(n2b), dgamma1=rt.grad_out(n1w),
+                               dbeta1=rt.grad_out(n1b)))
+        with rt.deferring(), ops.tag("gs"):
+            dx, ops_, dgcat = ops.gs_stack_bwd(dx2.contiguous(), layers, key_mask, n_seq, S, ctx.scale, p, rt.seed, want_dg=has_g)
+        # the weight-gradient products, queued exactly as LayerFn.backward queues them layer by layer (last layer first): ONE grouped
+        # launch for the stack (STACK_GROUP) or one per layer
+        stack = STACK_GROUP and GROUP_WGRAD and rt.defer
+        nsl = STACK_GROUP_SLICES if stack else 8
+        gb = (lambda w_: nsl * -(-w_.shape[0] // 128) * -(-w_.shape[1] // 128)) if GROUP_WGRAD else (lambda w_: None)
+        grads = [None] * (per * n)
+        for i in range(n - 1, -1, -1):
+            x2, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h = acts[i]
+            n1w, n1b, win, bin_, wo, bo, n2w, n2b, w1, b1, w2, b2 = prm[i]
+            dym, dpre, dx1m, dqkv = ops_[i]
+            keep = rt.stack_group_begin() if stack else None
+            with (rt.grouping() if keep is None else _NULL_CTX):
+                with ops.tag("ffn"):
+                    dw2, db2 = _wbgrad(rt, w2, b2, dym, h, gb(w2))
+                    dw1, db1 = _wbgrad(rt, w1, b1, dpre, xn2, gb(w1))
+                dwo, dbo = _wbgrad(rt, wo, bo, dx1m, ao, gb(wo))
+                dwin, dbin = _wbgrad(rt, win, bin_, dqkv, xn1, gb(win))
+            if keep is not None:
+                keep += [dym, h, dpre, xn2, dx1m, ao, dqkv, xn1]
+                if i == 0:
+                    rt.stack_group_end()
+            L = layers[i]
+            grads[per * i:per * i + 12] = [L["dgamma1"], L["dbeta1"], dwin, dbin, dwo, dbo, L["dgamma2"], L["dbeta2"], dw1, db1, dw2, db2]
+            if has_g:
+                grads[per * i + 12] = dgcat[:, 256 * i:256 * (i + 1)]
+        return (None, dx, None, None, None, None, None, None, None, None, *grads)
+
+
 class MaskedCEFn(torch.autograd.Function):
     """(sum, count) of CE(logits[row], target[row]) over the rows with w != 0 (fp32 [2]; the mean and the weighted total are
     taken by LossCombineFn); logits2d: [n_tok, group*C] row-major view."""

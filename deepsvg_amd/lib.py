@@ -14,7 +14,7 @@ DSVG_F32 = 0
 DSVG_BF16 = 1
 # == DSVG_ABI_VERSION of include/dsvg.h at the time SIGNATURES below was written: load() refuses a library built from another
 # header (a stale .so with the old argument lists would otherwise be called with a stream where a size is expected)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_i32, c_i64, c_u32, c_f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_float
 vp = C.c_void_p
@@ -39,6 +39,20 @@ class GemmDesc(C.Structure):
         ("rowsum", vp),
         ("impl", c_i32),
     ]
+
+
+class GsFwdLayer(C.Structure):
+    """mirror of ``dsvg_gs_fwd_layer`` (include/dsvg.h)"""
+    _fields_ = [(n, vp) for n in ("packed_fwd_layer", "in_bias", "out_bias", "b1", "b2", "gamma1", "beta1", "gamma2", "beta2",
+                                  "seq_add", "x2", "mean1", "rstd1", "xn1", "qkv", "ao", "x1", "mean2", "rstd2", "xn2", "h")] + [
+        ("site0", c_u32), ("reserved_", c_u32)]
+
+
+class GsBwdLayer(C.Structure):
+    """mirror of ``dsvg_gs_bwd_layer`` (include/dsvg.h)"""
+    _fields_ = [(n, vp) for n in ("packed_bwd_layer", "x", "mean1", "rstd1", "qkv", "x1", "mean2", "rstd2", "h", "gamma1", "gamma2",
+                                  "dx", "dx1", "dym", "dpre", "dx1m", "dqkv", "dg", "dgamma2", "dbeta2", "dgamma1", "dbeta1",
+                                  "workspace")] + [("site0", c_u32), ("reserved_", c_u32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/dsvg.h
@@ -147,6 +161,9 @@ SIGNATURES = {
     "dsvg_latent_chain_fwd": (c_i32, [vp, vp, vp, c_i32, vp, vp, vp, c_i64, vp]),
     "dsvg_latent_chain_bwd": (c_i32, [vp, vp, vp, c_i32, vp, vp, c_i64, vp]),
     "dsvg_gs_layer_bwd": (c_i32, [vp] * 13 + [c_i64, c_i32] + [vp] * 10 + [c_f32, c_f32, c_u32, vp, vp, c_i64, vp, vp]),
+    # (layers: pointer to an array of GsFwdLayer / GsBwdLayer below)
+    "dsvg_gs_stack_fwd": (c_i32, [vp, vp, c_i32, vp, c_i64, c_i64, c_i32, c_f32, c_f32, c_f32, vp, vp]),
+    "dsvg_gs_stack_bwd": (c_i32, [vp, vp, c_i32, vp, c_i64, c_i32, c_f32, c_f32, vp, c_i64, c_i64, vp]),
 }
 
 _lib = None

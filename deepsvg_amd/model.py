@@ -703,6 +703,21 @@ class SVGTransformer(nn.Module):
         if z is not None and all(hasattr(L, "linear_global") for L in stack.layers) and self.hoist_global:
             wb = [t for L in stack.layers for t in (L.linear_global.weight, L.linear_global.bias)]
             gl = Fn.GlobalCondFn.apply(rt, z, *wb)
+        n = len(stack.layers)
+        all_g = all(hasattr(L, "linear_global") for L in stack.layers)
+        if (n > 0 and not causal and seq_off is None and live is None and tiles is None and l is None
+                and (z is None or (gl is not None and all_g))
+                and Fn.gs_stack_eligible(rt, x, key_mask, n_seq, S, cfg.n_heads, n, [L.self_attn.in_proj_weight for L in stack.layers])):
+            # a short-sequence ("group") stage: the whole stack in ONE launch per direction (functional.GsStackFn)
+            ts = []
+            for i, L in enumerate(stack.layers):
+                ts += [L.norm1.weight, L.norm1.bias, L.self_attn.in_proj_weight, L.self_attn.in_proj_bias,
+                       L.self_attn.out_proj.weight, L.self_attn.out_proj.bias, L.norm2.weight, L.norm2.bias,
+                       L.linear1.weight, L.linear1.bias, L.linear2.weight, L.linear2.bias]
+                if z is not None:
+                    ts.append(gl[i])
+            x = Fn.GsStackFn.apply(rt, x, key_mask, n_seq, S, cfg.n_heads, cfg.dropout, site, n, z is not None, *ts)
+            return Fn.LayerNormFn.apply(rt, x, stack.norm.weight, stack.norm.bias, stack.norm.eps, live, None)
         for i, L in enumerate(stack.layers):
             has_g = hasattr(L, "linear_global")
             has_l = l is not None and hasattr(L, "linear_global2")

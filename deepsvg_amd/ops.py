@@ -1490,6 +1490,120 @@ def gs_layer_bwd(dx2, packed_bwd_layer, x, mean1, rstd1, qkv, x1, mean2, rstd2, 
     return (dx, dx1, dym, dpre, dx1m, dqkv, *outs, dg) if want_dg else (dx, dx1, dym, dpre, dx1m, dqkv, *outs)
 
 
+GS_STACK_MAX = 4        # layers per dsvg_gs_stack_fwd / dsvg_gs_stack_bwd launch (csrc/group_stage.hip)
+
+
+def gs_stack_fwd(x, layers, key_mask, n_seq, S, scale, eps=1e-5, drop_p=0.0, seed=None, train=False):
+    """a whole stack of pre-LN blocks in ONE launch (include/dsvg.h: dsvg_gs_stack_fwd; x bf16 [n_seq * S, 256]).
+    layers: per layer a dict(img=packed_fwd_layer, in_bias, out_bias, b1, b2, gamma1, beta1, gamma2, beta2, site0, seq_add=None);
+    every seq_add is a [n_seq, 256] view with the same row stride.  -> per layer what gs_layer_fwd returns: x2 (train=False;
+    the inner layers' x2 are not materialised: None) or the tuple (x2, mean1, rstd1, xn1, qkv, ao, x1, mean2, rstd2, xn2, h)."""
+    n = len(layers)
+    assert 1 <= n <= GS_STACK_MAX
+    rows = n_seq * S
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(x.shape) == (rows, 256) and 1 <= S <= 32
+    assert key_mask is None or (key_mask.dtype == torch.int64 and key_mask.numel() >= n_seq)
+    _chk(x, key_mask, seed)
+    dev = x.device
+    arr = (_l.GsFwdLayer * n)()
+    outs, keep = [], []
+    ld = None
+    for i, Ld in enumerate(layers):
+        img = Ld["img"]
+        assert img.numel() == GS_LAYER_ELEMS and img.is_contiguous()
+        small = [Ld[k] for k in ("in_bias", "out_bias", "b1", "b2", "gamma1", "beta1", "gamma2", "beta2")]
+        for t, nn in zip(small, (768, 256, 512, 256, 256, 256, 256, 256)):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == nn
+        sa = Ld.get("seq_add")
+        _chk(img, *small, sa)
+        if sa is not None:
+            assert sa.dtype == x.dtype and tuple(sa.shape) == (n_seq, 256) and sa.stride(1) == 1
+            assert sa.stride(0) % 8 == 0 and sa.data_ptr() % 16 == 0 and ld in (None, sa.stride(0))
+            ld = sa.stride(0)
+        last = i == n - 1
+        x2 = torch.empty_like(x) if (train or last) else None
+        sv = [None] * 10
+        if train:
+            f32 = lambda: torch.empty(rows, dtype=torch.float32, device=dev)
+            sv = [f32(), f32(), torch.empty_like(x), torch.empty((rows, 768), dtype=x.dtype, device=dev), torch.empty_like(x),
+                  torch.empty_like(x), f32(), f32(), torch.empty_like(x), torch.empty((rows, 512), dtype=x.dtype, device=dev)]
+        e = arr[i]
+        e.packed_fwd_layer = img.data_ptr()
+        for k, t in zip(("in_bias", "out_bias", "b1", "b2", "gamma1", "beta1", "gamma2", "beta2"), small):
+            setattr(e, k, t.data_ptr())
+        e.seq_add = _p(sa)
+        e.x2 = _p(x2)
+        for k, t in zip(("mean1", "rstd1", "xn1", "qkv", "ao", "x1", "mean2", "rstd2", "xn2", "h"), sv):
+            setattr(e, k, _p(t))
+        e.site0 = int(Ld["site0"])
+        keep.append((img, small, sa))
+        outs.append((x2, *sv) if train else x2)
+    ev = _prof_begin()
+    _l.check(_l.load().dsvg_gs_stack_fwd(x.data_ptr(), C.addressof(arr), n, _p(key_mask), int(ld) if ld is not None else 256,
+                                         n_seq, S, float(eps), float(scale), float(drop_p),
+                                         _p(seed) if drop_p > 0 else None, _stream()), "dsvg_gs_stack_fwd")
+    _prof_end(ev, n * (2.0 * rows * 256 * (768 + 256 + 1024) + 4.0 * rows * S * 256), n * 1024.0 * rows,
+              dict(op="gs_stack_fwd", rows=rows, layers=n, train=bool(train), ffn_flops=n * 4.0 * 256 * 512 * rows))
+    return outs
+
+
+def gs_stack_bwd(dx2, layers, key_mask, n_seq, S, scale, drop_p=0.0, seed=None, want_dg=False):
+    """backward of gs_stack_fwd with respect to x in ONE launch (include/dsvg.h: dsvg_gs_stack_bwd).  layers (forward order): per
+    layer a dict(img=packed_bwd_layer, x, mean1, rstd1, qkv, x1, mean2, rstd2, h, gamma1, gamma2, site0, dgamma2, dbeta2, dgamma1,
+    dbeta1) - the last four: fp32 [256] outputs.  -> (dx, per_layer, dgcat): per_layer[i] = (dym, dpre, dx1m, dqkv); dgcat
+    (want_dg) = bf16 [n_seq, n * 256], column block i = layer i's conditioning-term gradient (gs_layer_bwd's dg), else None."""
+    n = len(layers)
+    assert 1 <= n <= GS_STACK_MAX
+    rows = n_seq * S
+    assert dx2.dtype == torch.bfloat16 and dx2.is_contiguous() and tuple(dx2.shape) == (rows, 256) and 32 % S == 0
+    _chk(dx2, key_mask, seed)
+    dev = dx2.device
+    L = _l.load()
+    wsb = L.dsvg_gs_bwd_workspace_bytes(n_seq, S)
+    dx = torch.empty_like(dx2)
+    dgcat = torch.empty((n_seq, n * 256), dtype=dx2.dtype, device=dev) if want_dg else None
+    arr = (_l.GsBwdLayer * n)()
+    per, keep = [], []
+    for i, Ld in enumerate(layers):
+        img = Ld["img"]
+        assert img.numel() == GS_LAYER_ELEMS and img.is_contiguous()
+        for k, shape in (("x", (rows, 256)), ("x1", (rows, 256)), ("qkv", (rows, 768)), ("h", (rows, 512))):
+            t = Ld[k]
+            assert t.dtype == torch.bfloat16 and t.is_contiguous() and tuple(t.shape) == shape
+        for k in ("mean1", "rstd1", "mean2", "rstd2"):
+            t = Ld[k]
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == rows
+        for k in ("gamma1", "gamma2", "dgamma2", "dbeta2", "dgamma1", "dbeta1"):
+            t = Ld[k]
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == 256
+        _chk(img, *[Ld[k] for k in ("x", "x1", "qkv", "h", "mean1", "rstd1", "mean2", "rstd2", "gamma1", "gamma2", "dgamma2",
+                                    "dbeta2", "dgamma1", "dbeta1")])
+        dym, dx1m = torch.empty_like(dx2), torch.empty_like(dx2)
+        dpre = torch.empty((rows, 512), dtype=dx2.dtype, device=dev)
+        dqkv = torch.empty((rows, 768), dtype=dx2.dtype, device=dev)
+        ws = _ws(wsb, dev)
+        e = arr[i]
+        e.packed_bwd_layer = img.data_ptr()
+        for k in ("x", "mean1", "rstd1", "qkv", "x1", "mean2", "rstd2", "h", "gamma1", "gamma2", "dgamma2", "dbeta2", "dgamma1",
+                  "dbeta1"):
+            setattr(e, k, Ld[k].data_ptr())
+        e.dx = dx.data_ptr() if i == 0 else None
+        e.dx1 = None
+        e.dym, e.dpre, e.dx1m, e.dqkv = dym.data_ptr(), dpre.data_ptr(), dx1m.data_ptr(), dqkv.data_ptr()
+        e.dg = (dgcat.data_ptr() + i * 256 * dgcat.element_size()) if want_dg else None
+        e.workspace = ws.data_ptr()
+        e.site0 = int(Ld["site0"])
+        per.append((dym, dpre, dx1m, dqkv))
+        keep.append(ws)
+    ev = _prof_begin()
+    _l.check(L.dsvg_gs_stack_bwd(dx2.data_ptr(), C.addressof(arr), n, _p(key_mask), n_seq, S, float(scale), float(drop_p),
+                                 _p(seed) if drop_p > 0 else None, (keep[0].numel() - 1) * 4, n * 256 if want_dg else 256,
+                                 _stream()), "dsvg_gs_stack_bwd")
+    _prof_end(ev, n * (2.0 * rows * 256 * (768 + 256 + 1024) + 8.0 * rows * S * 256), n * 1536.0 * rows,
+              dict(op="gs_stack_bwd", rows=rows, layers=n, ffn_flops=n * 4.0 * 256 * 512 * rows))
+    return dx, per, dgcat
+
+
 def _prof_begin():
     if not (PROFILE_ON and _TAG is not None):
         return None

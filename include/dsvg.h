@@ -36,8 +36,9 @@ extern "C" {
  * 5 (round 5): dsvg_sample_rows / dsvg_head_sample (categorical sampling on the device), dsvg_layernorm_bwd_masked added.
  * 6: dsvg_pack_images, dsvg_defer_zero added; dg argument of dsvg_gs_layer_bwd.
  * 7 (round 6): dsvg_attn_bwd_dx added; a layer of dsvg_attn_pack_bwd grew from 128 to 512 fragments (in_proj_weight^T behind
- *    out_proj.weight^T). */
-#define DSVG_ABI_VERSION 7
+ *    out_proj.weight^T).
+ * 8 (round 6): dsvg_gs_stack_fwd / dsvg_gs_stack_bwd added (one launch per STACK of group-stage layers). */
+#define DSVG_ABI_VERSION 8
 
 const char* dsvg_last_error(void);
 int dsvg_version(void);
@@ -641,6 +642,51 @@ int dsvg_gs_layer_bwd(const void* dx2, const void* packed_bwd_layer, const void*
                       void* dx, void* dx1, void* dym, void* dpre, void* dx1m, void* dqkv, float* dgamma2, float* dbeta2,
                       float* dgamma1, float* dbeta1, float scale, float drop_p, uint32_t site0, const void* seed,
                       void* workspace, int64_t workspace_bytes, void* dg, void* stream);
+/* One launch per STACK and direction (ABI 8): the tiles (32 rows = whole sequences) are independent across the layers, so a
+ * workgroup carries its rows through up to 4 layers - reference: the layer loops of deepsvg/model/layers/transformer.py:168-188
+ * (TransformerEncoder.forward) and :214-242 (TransformerDecoder.forward) over the 4 layers of hierarchical_encoder /
+ * hierarchical_decoder.  Same arithmetic, same stores and same dropout draws as n_layers calls of dsvg_gs_layer_fwd /
+ * dsvg_gs_layer_bwd in a row (bit-identical; tests/test_kernels_gpu.py::test_gs_stack_*), minus the launch ramps, the
+ * reloads of the rows between the layers, and the gradient stores between the layers of the backward pass.
+ *   dsvg_gs_stack_fwd: x -> layers[n_layers - 1].x2.  Per layer: the arguments of dsvg_gs_layer_fwd; training outputs for every
+ *     layer or for none; x2 of an inner layer may be NULL for inference.  seq_add of every layer has the row stride seq_add_ld
+ *     (column blocks of one [n_seq, n_layers * 256] product).  seq_base = 0, ffn_format = 0.
+ *   dsvg_gs_stack_bwd: dx2 = dL/d(layers[n_layers - 1].x2) -> layers[0].dx; `layers` in FORWARD order, walked from the last
+ *     one.  Per layer: the arguments of dsvg_gs_layer_bwd; dx of layers 1 .. may be NULL (not stored); every layer's workspace
+ *     has workspace_bytes >= dsvg_gs_bwd_workspace_bytes(n_seq, S); dg (optional) has the row stride dg_ld (column blocks of one
+ *     [n_seq, n_layers * 256] buffer: the concatenated gradient of the conditioning product, no concatenation launch). */
+typedef struct dsvg_gs_fwd_layer {
+    const void* packed_fwd_layer;
+    const float *in_bias, *out_bias, *b1, *b2, *gamma1, *beta1, *gamma2, *beta2;
+    const void* seq_add;            /* or NULL */
+    void* x2;
+    float *mean1, *rstd1;
+    void *xn1, *qkv, *ao, *x1;
+    float *mean2, *rstd2;
+    void *xn2, *h;
+    uint32_t site0;
+    uint32_t reserved_;
+} dsvg_gs_fwd_layer;
+typedef struct dsvg_gs_bwd_layer {
+    const void* packed_bwd_layer;
+    const void* x;
+    const float *mean1, *rstd1;
+    const void *qkv, *x1;
+    const float *mean2, *rstd2;
+    const void* h;
+    const float *gamma1, *gamma2;
+    void *dx, *dx1, *dym, *dpre, *dx1m, *dqkv, *dg;
+    float *dgamma2, *dbeta2, *dgamma1, *dbeta1;
+    void* workspace;
+    uint32_t site0;
+    uint32_t reserved_;
+} dsvg_gs_bwd_layer;
+int dsvg_gs_stack_fwd(const void* x, const dsvg_gs_fwd_layer* layers, int32_t n_layers, const uint64_t* key_mask,
+                      int64_t seq_add_ld, int64_t n_seq, int32_t S, float eps, float scale, float drop_p, const void* seed,
+                      void* stream);
+int dsvg_gs_stack_bwd(const void* dx2, const dsvg_gs_bwd_layer* layers, int32_t n_layers, const uint64_t* key_mask,
+                      int64_t n_seq, int32_t S, float scale, float drop_p, const void* seed, int64_t workspace_bytes,
+                      int64_t dg_ld, void* stream);
 /* test hook: raw ds_read_b64_tr_b16 on a 4 KiB LDS image img[i]=i, lane l reads at byte offset off[l] */
 int dsvg_probe_trread(const int* off, short* out, void* stream);
 

@@ -371,3 +371,104 @@ def test_latent_chain_kernels_match_the_unfused_launches(gpu_device, rows, n_res
     assert torch.allclose(dz0.float().cpu(), rdz.float(), **tol)
     same = [torch.equal(out, out_u), torch.equal(dz0, gcur)]
     print(f"latent chain rows {rows} n_res {n_res}: bit-identical to the unfused launches (out, dz0): {same}")
+
+
+def _stack_setup(n_seq, S, n_layers, masked, with_add, seed):
+    """per-layer parameters (different for every layer), packed images, inputs"""
+    flat, offs, _p, x, key_mask, _sa, dx2 = _setup(n_seq, S, seed=seed, n_layers=n_layers, masked=masked)
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    ps = []
+    for _i in range(n_layers):
+        p = dict(
+            in_bias=0.2 * torch.randn(768, generator=g), out_bias=0.2 * torch.randn(256, generator=g),
+            b1=0.3 * torch.randn(512, generator=g), b2=0.3 * torch.randn(256, generator=g),
+            gamma1=1 + 0.2 * torch.randn(256, generator=g), beta1=0.2 * torch.randn(256, generator=g),
+            gamma2=1 + 0.2 * torch.randn(256, generator=g), beta2=0.2 * torch.randn(256, generator=g))
+        ps.append({k: v.to(DEV) for k, v in p.items()})
+    gcat = (torch.randn(n_seq, n_layers * 256, generator=g) * 0.5).to(DEV).to(torch.bfloat16) if with_add else None
+    return flat, offs, ps, x, key_mask, gcat, dx2
+
+
+STACK_CASES = [
+    # n_seq, S, layers, key masks, conditioning rows, dropout
+    (512, 8, 4, True, False, 0.1),       # hierarchical_encoder at batch 512 (deepsvg/model/model.py:153-161)
+    (512, 8, 4, False, True, 0.1),       # hierarchical_decoder: conditioning rows as column blocks of one product
+    (509, 8, 4, True, True, 0.1),        # a last tile with one sequence
+    (130, 8, 3, False, True, 0.0),
+    (6, 32, 2, False, False, 0.1),       # one sequence per tile
+    (3, 16, 1, True, True, 0.1),
+]
+
+
+@pytest.mark.parametrize("n_seq,S,n_layers,masked,with_add,drop_p", STACK_CASES)
+def test_gs_stack_launch_is_bit_identical_to_the_layer_launches(gpu_device, n_seq, S, n_layers, masked, with_add, drop_p):
+    """dsvg_gs_stack_fwd / dsvg_gs_stack_bwd (round 6: one launch per stack and direction, the rows stay on chip between the
+    layers) against the same layers launched one by one: every stored tensor of the forward pass, every operand of the
+    weight-gradient products, the LayerNorm parameter gradients, the conditioning rows' gradients and dx - bit for bit."""
+    flat, offs, ps, x, key_mask, gcat, dx2 = _stack_setup(n_seq, S, n_layers, masked, with_add, seed=40 + n_seq + n_layers)
+    pf, pb = ops.gs_pack(flat, offs, n_layers)
+    seed = _seed_tensor(0x0BADC0DE0DDBA11 + n_seq)
+    scale, s0 = (256 // 8) ** -0.5, 520
+    E = ops.GS_LAYER_ELEMS
+    sa = lambda i: None if gcat is None else gcat[:, 256 * i:256 * (i + 1)]
+    # ---- forward: layer by layer
+    want, cur = [], x
+    for i, p in enumerate(ps):
+        r = ops.gs_layer_fwd(cur, pf[i * E:(i + 1) * E], *_params(p), key_mask, n_seq, S, scale, 1e-5, drop_p, s0 + 8 * i, seed,
+                             seq_add=sa(i), train=True)
+        want.append(r)
+        cur = r[0]
+    layers = [dict(img=pf[i * E:(i + 1) * E], site0=s0 + 8 * i, seq_add=sa(i), **p) for i, p in enumerate(ps)]
+    got = ops.gs_stack_fwd(x, layers, key_mask, n_seq, S, scale, 1e-5, drop_p, seed, train=True)
+    torch.cuda.synchronize()
+    bad = []
+    for i in range(n_layers):
+        for name, a, b in zip(FWD_NAMES, got[i], want[i]):
+            if not torch.equal(a, b):
+                bad.append(f"forward layer {i} {name}: {int((a != b).sum())} elements differ")
+    inf = ops.gs_stack_fwd(x, layers, key_mask, n_seq, S, scale, 1e-5, drop_p, seed, train=False)
+    assert all(t is None for t in inf[:-1])
+    if not torch.equal(inf[-1], want[-1][0]):
+        bad.append("inference stack launch: x2 differs")
+    assert not bad, "\n".join(bad)
+    # ---- backward: layer by layer from the last one
+    def grads():
+        return {k: torch.full((256,), float("nan"), device=DEV) for k in ("dgamma2", "dbeta2", "dgamma1", "dbeta1")}
+    wl, g = [None] * n_layers, dx2
+    for i in range(n_layers - 1, -1, -1):
+        (_x2, mean1, rstd1, _xn1, qkv, _ao, x1, mean2, rstd2, _xn2, h) = want[i]
+        xin = x if i == 0 else want[i - 1][0]
+        wl[i] = ops.gs_layer_bwd(g, pb[i * E:(i + 1) * E], xin, mean1, rstd1, qkv, x1, mean2, rstd2, h, ps[i]["gamma1"],
+                                 ps[i]["gamma2"], key_mask, n_seq, S, scale, drop_p, s0 + 8 * i, seed, want_dg=with_add)
+        g = wl[i][0]
+    bl = []
+    for i in range(n_layers):
+        (_x2, mean1, rstd1, _xn1, qkv, _ao, x1, mean2, rstd2, _xn2, h) = want[i]
+        bl.append(dict(img=pb[i * E:(i + 1) * E], x=x if i == 0 else want[i - 1][0], mean1=mean1, rstd1=rstd1, qkv=qkv, x1=x1,
+                       mean2=mean2, rstd2=rstd2, h=h, gamma1=ps[i]["gamma1"], gamma2=ps[i]["gamma2"], site0=s0 + 8 * i, **grads()))
+    dx, per, dgcat = ops.gs_stack_bwd(dx2, bl, key_mask, n_seq, S, scale, drop_p, seed, want_dg=with_add)
+    torch.cuda.synchronize()
+    if not torch.equal(dx, g):
+        bad.append(f"dx: {int((dx != g).sum())} elements differ")
+    for i in range(n_layers):
+        for name, a, b in zip(("dym", "dpre", "dx1m", "dqkv"), per[i], wl[i][2:6]):
+            if not torch.equal(a, b):
+                bad.append(f"backward layer {i} {name}: {int((a != b).sum())} elements differ")
+        for k, name in enumerate(("dgamma2", "dbeta2", "dgamma1", "dbeta1")):
+            if not torch.equal(bl[i][name], wl[i][6 + k]):
+                bad.append(f"backward layer {i} {name} differs")
+        if with_add and not torch.equal(dgcat[:, 256 * i:256 * (i + 1)], wl[i][10]):
+            bad.append(f"backward layer {i} dg (column block of the concatenated buffer) differs")
+    assert not bad, "\n".join(bad)
+
+
+def test_gs_stack_launch_is_bit_reproducible(gpu_device):
+    flat, offs, ps, x, key_mask, gcat, dx2 = _stack_setup(512, 8, 4, True, True, seed=77)
+    pf, _pb = ops.gs_pack(flat, offs, 4)
+    seed = _seed_tensor(0x1234)
+    E = ops.GS_LAYER_ELEMS
+    layers = [dict(img=pf[i * E:(i + 1) * E], site0=8 * i, seq_add=gcat[:, 256 * i:256 * (i + 1)], **p) for i, p in enumerate(ps)]
+    a = ops.gs_stack_fwd(x, layers, key_mask, 512, 8, 32 ** -0.5, 1e-5, 0.1, seed, train=True)
+    b = ops.gs_stack_fwd(x, layers, key_mask, 512, 8, 32 ** -0.5, 1e-5, 0.1, seed, train=True)
+    torch.cuda.synchronize()
+    assert all(torch.equal(s, t) for ra, rb in zip(a, b) for s, t in zip(ra, rb))

@@ -593,20 +593,24 @@ def test_fused_group_stage_path_matches_unfused_with_emulated_ops(emulated_ops):
     cfg.dropout = 0.1
     c, a = make_batch(6, seed=5)
     sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 8)
+    import deepsvg_amd.functional as Fn
     res, calls = {}, {}
-    saved = (ops.gs_layer_fwd, ops.gs_layer_bwd)
+    names = ("gs_layer_fwd", "gs_layer_bwd", "gs_stack_fwd", "gs_stack_bwd")
+    saved = tuple(getattr(ops, n) for n in names)
+    saved_knob = Fn.GS_STACK
     try:
-        for fused in (True, False):
-            n_calls = [0, 0]
+        # "stack": ONE launch per stack and direction (round 6, functional.GsStackFn); "layer": one per layer (LayerFn's route)
+        for fused in ("stack", "layer", False):
+            n_calls = [0, 0, 0, 0]
 
-            def counted_f(*args, _f=saved[0], **kw):
-                n_calls[0] += 1
-                return _f(*args, **kw)
-
-            def counted_b(*args, _f=saved[1], **kw):
-                n_calls[1] += 1
-                return _f(*args, **kw)
-            ops.gs_layer_fwd, ops.gs_layer_bwd = counted_f, counted_b
+            def counted(k, f):
+                def g(*args, **kw):
+                    n_calls[k] += 1
+                    return f(*args, **kw)
+                return g
+            for k, n in enumerate(names):
+                setattr(ops, n, counted(k, saved[k]))
+            Fn.GS_STACK = fused == "stack"
             torch.manual_seed(3)
             model = deepsvg_amd.SVGTransformer(cfg).train()
             model.load_state_dict(sd)
@@ -614,18 +618,22 @@ def test_fused_group_stage_path_matches_unfused_with_emulated_ops(emulated_ops):
             if not fused:
                 model.store._gs_setup = lambda device: setattr(model.store, "_gs", None)
             out = model(c, a, c, a, params={})
-            assert (model.store._gs is not None) == fused
+            assert (model.store._gs is not None) == bool(fused)
             ld = deepsvg_amd.SVGLoss(cfg)(out, None, weights=O.DEFAULT_WEIGHTS)
             ld["loss"].backward()
             res[fused] = (float(ld["loss"]), {n: p.grad.clone() for n, p in model.named_parameters()})
             calls[fused] = tuple(n_calls)
     finally:
-        ops.gs_layer_fwd, ops.gs_layer_bwd = saved
-    assert calls[True] == (4, 4) and calls[False] == (0, 0)        # 2 group stacks x 2 layers, forward and backward
-    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
-    assert all(g is not None for g in res[True][1].values())
-    for n in res[True][1]:
-        assert torch.equal(res[True][1][n], res[False][1][n]), n
+        for n, f in zip(names, saved):
+            setattr(ops, n, f)
+        Fn.GS_STACK = saved_knob
+    # 2 group stacks x 2 layers, forward and backward
+    assert calls["stack"] == (0, 0, 2, 2) and calls["layer"] == (4, 4, 0, 0) and calls[False] == (0, 0, 0, 0)
+    for fused in ("stack", "layer"):
+        assert abs(res[fused][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+        assert all(g is not None for g in res[fused][1].values())
+        for n in res[fused][1]:
+            assert torch.equal(res[fused][1][n], res[False][1][n]), (fused, n)
     # inference call: one launch per layer as well, nothing saved
     model.eval()
     with torch.no_grad():

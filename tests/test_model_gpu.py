@@ -686,6 +686,57 @@ def test_fused_attention_input_gradient_in_the_training_step(gpu_device):
     assert g1.isfinite().all() and rel < 1e-2, rel
 
 
+def test_group_stage_stack_launches_in_the_training_step(gpu_device):
+    """functional.GS_STACK (round 6): the two group stages (hierarchical_encoder / hierarchical_decoder, 4 layers each) as ONE
+    launch per stack and direction (dsvg_gs_stack_fwd / dsvg_gs_stack_bwd) instead of one per layer.  Same arithmetic, same
+    stores, same draws, same order of the weight-gradient products: losses AND the flat gradient are bit-identical to the
+    per-layer launches, eagerly and replayed from the captured graph; 4 stack launches replace 16 layer launches."""
+    import deepsvg_amd.functional as Fn
+    from deepsvg_amd.trainer import TrainStep
+    cfg = H.build_cfg("hier")
+    cfg.dropout = 0.1
+    sd = H.weights_for(deepsvg_amd.SVGTransformer(cfg), 41)
+    c, a = (t.to(DEV) for t in make_batch(320, seed=12))
+    runs = {}
+    saved = Fn.GS_STACK
+    try:
+        for on in (False, True):
+            Fn.GS_STACK = on
+            torch.manual_seed(5)
+            model = _hip_model(cfg, sd, torch.bfloat16).train()
+            ts = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=0.0, use_graph=False)
+            ops.PROFILE.clear()
+            ops.PROFILE_ON = True
+            try:
+                ld = ts.step(c, a)
+                torch.cuda.synchronize()
+            finally:
+                ops.PROFILE_ON = False
+            count = lambda name: sum(1 for r in ops.PROFILE if r[5].get("op") == name)
+            n = (count("gs_stack_fwd"), count("gs_stack_bwd"), count("gs_layer_fwd"), count("gs_layer_bwd"))
+            ops.PROFILE.clear()
+            eager = ({k: float(v) for k, v in ld.items()}, model.store.grad_buffer(0).detach().clone())
+            # ... and replayed (lr 0: the parameters do not move, the seed advances: compare the two settings step by step)
+            torch.manual_seed(5)
+            model = _hip_model(cfg, sd, torch.bfloat16).train()
+            tg = TrainStep(model, deepsvg_amd.SVGLoss(cfg).to(DEV), lr=0.0, use_graph=True)
+            replay = []
+            for _ in range(3):
+                ld = tg.step(c, a)
+                torch.cuda.synchronize()
+                replay.append(({k: float(v) for k, v in ld.items()}, model.store.grad_buffer(0).detach().clone()))
+            runs[on] = (eager, n, replay)
+    finally:
+        Fn.GS_STACK = saved
+        ops.PROFILE_ON = False
+    assert runs[True][1][:2] == (2, 2) and runs[False][1][:2] == (0, 0), (runs[True][1], runs[False][1])
+    assert runs[False][1][2] - runs[True][1][2] == 8 and runs[False][1][3] - runs[True][1][3] == 8      # 2 stacks x 4 layers
+    assert runs[True][0][0] == runs[False][0][0]
+    assert torch.equal(runs[True][0][1], runs[False][0][1])
+    for (la, ga), (lb, gb) in zip(runs[True][2], runs[False][2]):
+        assert la == lb and torch.equal(ga, gb)
+
+
 def test_one_launch_weight_images_equal_the_stand_alone_launches(gpu_device):
     """model.PACK_ONE_LAUNCH (round 5): the bf16 flat copy, the fused FFN / attention / attention-backward / group-stage weight
     images and the seed advance of a training step come from ONE launch (dsvg_pack_images) - bit-identical to the 7 + 1 stand-alone

@@ -1079,6 +1079,33 @@ def gs_layer_bwd(dx2, packed_bwd_layer, x, mean1, rstd1, qkv, x1, mean2, rstd2, 
     return res + (bcast_add_bwd(dx1, n_seq, S, drop_p, site0 + 2, seed),) if want_dg else res
 
 
+def gs_stack_fwd(x, layers, key_mask, n_seq, S, scale, eps=1e-5, drop_p=0.0, seed=None, train=False):
+    """dsvg_gs_stack_fwd = its layers one after the other (csrc/group_stage.hip gs_stack_fwd_kernel)"""
+    outs, cur = [], x
+    for i, L in enumerate(layers):
+        res = gs_layer_fwd(cur, L["img"], L["in_bias"], L["out_bias"], L["b1"], L["b2"], L["gamma1"], L["beta1"], L["gamma2"],
+                           L["beta2"], key_mask, n_seq, S, scale, eps, drop_p, L["site0"], seed, seq_add=L.get("seq_add"),
+                           train=train)
+        cur = res[0] if train else res
+        outs.append(res if (train or i == len(layers) - 1) else None)
+    return outs
+
+
+def gs_stack_bwd(dx2, layers, key_mask, n_seq, S, scale, drop_p=0.0, seed=None, want_dg=False):
+    n = len(layers)
+    per, dgs, g = [None] * n, [None] * n, dx2
+    for i in range(n - 1, -1, -1):
+        L = layers[i]
+        res = gs_layer_bwd(g, L["img"], L["x"], L["mean1"], L["rstd1"], L["qkv"], L["x1"], L["mean2"], L["rstd2"], L["h"],
+                           L["gamma1"], L["gamma2"], key_mask, n_seq, S, scale, drop_p, L["site0"], seed, dgamma2=L["dgamma2"],
+                           dbeta2=L["dbeta2"], dgamma1=L["dgamma1"], dbeta1=L["dbeta1"], want_dg=want_dg)
+        g = res[0]
+        per[i] = (res[2], res[3], res[4], res[5])
+        if want_dg:
+            dgs[i] = res[10]
+    return g, per, (torch.cat(dgs, 1) if want_dg else None)
+
+
 def keep_scale(p):
     if p <= 0:
         return 1.0
