@@ -262,8 +262,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dx_kernel(const bf16_t* __res
     asm volatile("" ::: "memory");
     // the rows again for pass B (x from L2 this time, through a pointer the compiler cannot relate to pass A's: it would otherwise
     // keep the normalised values of pass A alive - in scratch memory) and the residual rows
-    const char* xrow2 = xrow;
-    asm volatile("" : "+v"(xrow2));
+    // (an opaque ZERO OFFSET, not an opaque pointer: a laundered pointer is a generic one - flat_load, whose waits cannot be counted)
+    unsigned zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    const char* xrow2 = xrow + zoff;
     uint4 xb[8][2], rb[8][2];
 #pragma unroll
     for (int t = 0; t < AHEAD2; ++t) { ld_tile(xrow2, t, xb[t]); ld_tile(rrow, t, rb[t]); }

@@ -349,6 +349,8 @@ __device__ __forceinline__ void glds_body(const dsvg_gemm_desc& p, int tiles_n, 
     constexpr bool may_drop = EPI == EPI_BIAS_RES_DROP || EPI == EPI_BIAS_RELU_DROP;
     const DropCtx dc = drop_make(may_drop ? p.drop_p : 0.f, p.seed, p.drop_site);
     const bool has_bias = !has_gate && p.bias != nullptr;
+    // (a bias that is a row range of a longer vector - the argument head's slots in use - need not start on a 16-byte boundary)
+    const bool bias_al = (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
     const bool n_aligned = !(p.N & 7);     // else: the last chunk of a row is partial and dropout ids are unaligned
 
     // One 32x32 accumulator tile -> 16 consecutive output columns of token row m per lane (two permlane32 exchange
@@ -386,7 +388,7 @@ __device__ __forceinline__ void glds_body(const dsvg_gemm_desc& p, int tiles_n, 
             nvalid[cb] = nv;
             if (nv == 0) { pk[cb] = make_uint4(0u, 0u, 0u, 0u); continue; }
             if (has_bias) {
-                if (nv == 8) {
+                if (nv == 8 && bias_al) {
                     const float4 b0 = *reinterpret_cast<const float4*>(p.bias + nb);
                     const float4 b1 = *reinterpret_cast<const float4*>(p.bias + nb + 4);
                     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
@@ -609,7 +611,7 @@ bool dsvg_gemm_bf16_glds_try(const dsvg_gemm_desc& d, int epi, dim3 grid, int ti
         }
         return false;
     }
-    if (d.bias && ((uintptr_t)d.bias & 15)) return false;
+    if (d.bias && ((uintptr_t)d.bias & 3)) return false;
     if (d.a_kc && d.b_kc) {
         if (epi == EPI_BIAS) launch<true, true, EPI_BIAS>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, nst, st);
         else if (epi == EPI_BIAS_RES_DROP) launch<true, true, EPI_BIAS_RES_DROP>(d, grid, tiles_n, nwg, k_chunk, part, rs_part, mode, nst, st);

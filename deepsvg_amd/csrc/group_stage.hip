@@ -1672,7 +1672,10 @@ extern "C" int dsvg_gs_stack_fwd(const void* x, const dsvg_gs_fwd_layer* layers,
         a.ao = (bf16_t*)L.ao; a.x1 = (bf16_t*)L.x1; a.mean2 = L.mean2; a.rstd2 = L.rstd2; a.xn2 = (bf16_t*)L.xn2; a.h = (bf16_t*)L.h;
         a.n_seq = (int)n_seq; a.S = S; a.per = per; a.warm = gs_warm();
         a.eps = eps; a.scale = scale; a.drop_p = drop_p; a.site0 = L.site0;
-        a.seq_base = 0; a.ffn_format = 0; a.dbg = nullptr;
+        a.seq_base = 0; a.ffn_format = 0;
+        // development probe (dsvg_gs_debug_clock): the stamps of ONE layer of the stack, DSVG_GS_DBG_LAYER (default: the last)
+        static const int dbg_layer = getenv("DSVG_GS_DBG_LAYER") ? atoi(getenv("DSVG_GS_DBG_LAYER")) : -1;
+        a.dbg = (l == (dbg_layer < 0 ? n_layers - 1 : dbg_layer)) ? g_gs_dbg_host : nullptr;
     }
     const int nb = (int)((n_seq + per - 1) / per);
     hipStream_t st = (hipStream_t)stream;

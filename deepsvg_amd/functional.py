@@ -1230,8 +1230,9 @@ class ArgsHeadLossFn(torch.autograd.Function):
         n_out = r1 - r0
         w_used = rt.w(weight)[r0:r1]
         b_used = bias.detach()[r0:r1]
-        if b_used.data_ptr() % 16:
-            b_used = b_used.clone()                                # (the GEMM epilogue reads the bias in 16-byte pieces)
+        if HEAD_FUSED and b_used.data_ptr() % 16:
+            b_used = b_used.clone()                                # (csrc/head_fused.hip reads the bias in 16-byte pieces; the GEMM
+                                                                   # epilogues take any 4-byte-aligned row range - round 6: no copy launch)
         ctx.head_img = None
         if HEAD_FUSED and xc.dtype == torch.bfloat16 and xc.shape[1] == 256 and C_ >= 64 and n_out <= 3008:
             # the logit tile stays on chip (csrc/head_fused.hip): log-sum-exp, target logit and the loss sums in one launch;

@@ -13,3 +13,8 @@ bash scripts/gpu_prof_graph.sh r06_graph > gpurun_out/r06_prof_graph.txt 2>&1; t
 bash scripts/gpu_step_pmc.sh r06_step_pmc > gpurun_out/r06_step_pmc.txt 2>&1; head -5 gpurun_out/r06_step_pmc_summary.txt | cut -c1-200
 timeout 400 bash scripts/ab.sh "DSVG_W_WARM=0 DSVG_GS_WARM=0" "DSVG_W_WARM=1" > gpurun_out/r06_ab_weight_warmup.log 2>&1
 cat gpurun_out/r06_ab_weight_warmup.log
+# ... and of the one-launch-per-stack group stages (second half of the round)
+timeout 400 bash scripts/ab.sh "DSVG_GS_STACK=0" "DSVG_GS_STACK=1" > gpurun_out/r06_ab_gs_stack_final.log 2>&1
+cat gpurun_out/r06_ab_gs_stack_final.log
+( timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -5 ) > gpurun_out/r06_pytest_gpu.log 2>&1; cat gpurun_out/r06_pytest_gpu.log
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ) > gpurun_out/r06_smoke.log 2>&1; cat gpurun_out/r06_smoke.log

@@ -179,6 +179,15 @@ def test_gemm_lds_dma_ragged_head_shapes(gpu_device, stages):
         outs.append(buf[:, :N].clone())
     assert torch.equal(outs[0], outs[1])
     _close(outs[0], R.gemm(x, w, bias=bias, out_dtype=torch.float32), _tol(dtype, K), "ragged-N forward")
+    # round 6: a bias that starts on a 4-byte, not a 16-byte, boundary (a row range of a longer vector: the argument head's slots in
+    # use, functional.ArgsHeadLossFn) goes through the LDS-DMA kernel as well - same numbers, no copy of the bias
+    for off in (1, 2, 3):
+        longer = torch.zeros(N + 8, device=DEV)
+        longer[off:off + N] = bias
+        buf = torch.full((T, ld), 7.0, device=DEV, dtype=dtype)
+        assert longer[off:off + N].data_ptr() % 16 == 4 * off
+        ops.gemm(x, w, bias=longer[off:off + N], out=buf[:, :N], impl=stages)
+        assert torch.equal(buf[:, :N], outs[0]) and torch.all(buf[:, N:] == 7.0), off
     dbuf = torch.zeros(T, ld, device=DEV, dtype=dtype)
     dbuf[:, :N] = _rand(T, N, dtype=dtype, seed=84)
     dy = dbuf[:, :N]
