@@ -266,48 +266,6 @@ class LinearFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------------
-class TwoLinearFn(torch.autograd.Function):
-    """(x W1^T + b1, x W2^T + b2): two plain linears on the SAME rows as one autograd node - HierarchFCN's visibility_fcn and z_fcn
-    (deepsvg/model/model.py:228-246 `HierarchFCN.forward`) - so that the second input-gradient product accumulates into the first
-    one's result instead of autograd adding two tensors (one aten launch of the replayed step, round 6)."""
-
-    @staticmethod
-    def forward(ctx, rt, x, w1, b1, w2, b2):
-        def lin(w, b):
-            n_out = w.shape[0]
-            mult = 4 if x.dtype == torch.float32 else 8
-            out = None
-            if n_out % mult:
-                ld = (n_out + mult - 1) // mult * mult
-                out = torch.empty((x.shape[0], ld), dtype=x.dtype, device=x.device)[:, :n_out]
-            return ops.gemm(x, rt.w(w), bias=b.detach(), out=out)
-        ctx.rt = rt
-        ctx.save_for_backward(x, w1, b1, w2, b2)
-        ctx.set_materialize_grads(False)
-        return lin(w1, b1), lin(w2, b2)
-
-    @staticmethod
-    def backward(ctx, dy1, dy2):
-        rt = ctx.rt
-        x, w1, b1, w2, b2 = ctx.saved_tensors
-        mult = 4 if rt.dtype == torch.float32 else 8
-        dx = None
-        grads = []
-        for dy, w, b in ((dy2, w2, b2), (dy1, w1, b1)):         # (the wide product first: the narrow one accumulates into it)
-            if dy is None:
-                grads.append((None, None))
-                continue
-            dy = _aligned2d(dy.to(rt.dtype) if dy.dtype != rt.dtype else dy, mult)
-            if ctx.needs_input_grad[1]:
-                if dx is None:
-                    dx = ops.gemm(dy, rt.w(w), b_kc=False)
-                else:
-                    ops.gemm(dy, rt.w(w), b_kc=False, out=dx, accumulate=True)
-            grads.append(_wbgrad(rt, w, b, dy, x))
-        (dw2, db2), (dw1, db1) = grads
-        return None, dx, dw1, db1, dw2, db2
-
-
 class ResBlockFn(torch.autograd.Function):
     """z + relu(z W^T + b): one block of the latent ResNet (deepsvg/model/basic_blocks.py:59-65)"""
 

@@ -934,9 +934,9 @@ class SVGTransformer(nn.Module):
                 src = Fn.AddPosFn.apply(rt, None, dec.hierarchical_embedding.PE.pos_embed.weight, N, G, PE_DROPOUT, 3)
                 out = self._run_stack(rt, dec.hierarchical_decoder, src, None, z, N, G, 300, l=l)
                 hf = dec.hierarchical_fcn
-                # (one node for both heads: their input gradients meet in one buffer, no autograd add)
-                vis_logits, z = Fn.TwoLinearFn.apply(rt, out, hf.visibility_fcn.weight, hf.visibility_fcn.bias,
-                                                     hf.z_fcn.weight, hf.z_fcn.bias)                      # z: [N*G, dim_z]
+                vis_logits = Fn.LinearFn.apply(rt, out, hf.visibility_fcn.weight, hf.visibility_fcn.bias, 0, None, 0.0,
+                                               0, None)
+                z = Fn.LinearFn.apply(rt, out, hf.z_fcn.weight, hf.z_fcn.bias, 0, None, 0.0, 0, None)  # [N*G, dim_z]
             else:
                 vis_logits = hierarch_logits
             if return_hierarch:
