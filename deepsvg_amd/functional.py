@@ -33,7 +33,8 @@ ATTN_MIN_ROWS = int(os.environ.get("DSVG_ATTN_MIN_ROWS", "16384"))
 FFN_BWD_ORDER = os.environ.get("DSVG_FFN_BWD_ORDER", "1") != "0"
 # dx and its dropout-masked copy from one ffn_bwd_dx launch instead of a drop_apply launch: measured SLOWER (8.52 vs 8.43
 # ms/step: the extra pass sits on the tail of a one-workgroup-per-CU kernel), so it is opt-in
-FFN_BWD_MASKED = os.environ.get("DSVG_FFN_BWD_MASKED", "0") != "0"
+FFN_BWD_MASKED = int(os.environ.get("DSVG_FFN_BWD_MASKED", "0"))    # 1: every layer; 2: only layers without a conditioning row
+# (their bcast_add_bwd launch writes the masked copy anyway, BCAST_MASKED)
 
 # the weight-gradient GEMMs of a layer of the 4096-row stages as one grouped launch (DSVG_GROUP_WGRAD=0: one by one)
 GROUP_WGRAD = os.environ.get("DSVG_GROUP_WGRAD", "1") != "0"
@@ -950,7 +951,7 @@ class LayerFn(torch.autograd.Function):
                     if FFN_BWD_ORDER:
                         wgrad1(dpre, xh)
                     # (the same launch also hands over dx1 with the attention residual's dropout mask replayed on it)
-                    if FFN_BWD_MASKED:
+                    if FFN_BWD_MASKED == 1 or (FFN_BWD_MASKED == 2 and z is None and p > 0):
                         dx1, dx1m = ops.ffn_bwd_dx(dpre, x1, dx2, pb, masked=(p, s0 + 1, rt.seed))
                     else:
                         dx1 = ops.ffn_bwd_dx(dpre, x1, dx2, pb)
