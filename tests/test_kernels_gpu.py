@@ -1560,3 +1560,49 @@ def test_loss_combine(gpu_device):
     got = ops.loss_combine_bwd(dt, [None, d1, None], w, torch.device(DEV))
     assert torch.allclose(got, R.loss_combine_bwd(dt, [None, d1, None], w, torch.device(DEV))) and tuple(got.shape) == (3, 2)
     assert torch.equal(ops.loss_combine_bwd(None, [None] * 3, w, torch.device(DEV)), torch.zeros(3, 2, device=DEV))
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_masked_mean_bf16_is_the_sequential_fp32_sum(gpu_device, packed):
+    """round 6: the bf16 forward pooling kernel reads 16 bytes per thread (a thread = 8 columns of one sequence); every column is
+    still summed over its valid rows in increasing order in fp32, scaled by 1 / count and rounded once - EXACTLY this restatement,
+    on both layouts (key masks / packed valid tokens); the backward pass: the scaled gradient row on the valid rows, zeros elsewhere
+    (incl. the bucket tail of the packed layout)."""
+    n_seq, S, d = 517, 32, 256
+    g = torch.Generator(device="cpu").manual_seed(9)
+    lens = torch.randint(1, S + 1, (n_seq,), generator=g)
+    if packed:
+        off = torch.zeros(n_seq + 1, dtype=torch.int32)
+        off[1:] = torch.cumsum(lens, 0).to(torch.int32)
+        total = int(off[-1])
+        rows = (total + 127) // 128 * 128 + 256
+        x = _rand(rows, d, dtype=torch.bfloat16, seed=1)
+        m = ops.masked_mean_fwd(x, None, n_seq, S, seq_off=off.to(DEV))
+        row0 = off[:-1].long()
+        bits = (torch.arange(S)[None, :] < lens[:, None])
+    else:
+        bits = torch.rand(n_seq, S, generator=g) < 0.6
+        bits[torch.arange(n_seq), torch.randint(0, S, (n_seq,), generator=g)] = True
+        km = (bits.to(torch.int64) << torch.arange(S, dtype=torch.int64)).sum(1).to(DEV)
+        x = _rand(n_seq * S, d, dtype=torch.bfloat16, seed=1)
+        m = ops.masked_mean_fwd(x, km, n_seq, S)
+        row0 = torch.arange(n_seq) * S
+    xf = x.float().cpu()
+    acc = torch.zeros(n_seq, d)
+    for i in range(S):
+        idx = (row0 + i).clamp(max=xf.shape[0] - 1)
+        acc = torch.where(bits[:, i:i + 1], acc + xf[idx], acc)
+    inv = (1.0 / bits.sum(1).float())[:, None]          # (the kernel multiplies by the fp32 reciprocal of the count)
+    want = (acc * inv).to(torch.bfloat16)
+    assert torch.equal(m.cpu(), want)
+    dm = _rand(n_seq, d, dtype=torch.bfloat16, seed=2)
+    gv = (dm.float().cpu() * inv).to(torch.bfloat16)
+    if packed:
+        dx = ops.masked_mean_bwd(dm, None, n_seq, S, seq_off=off.to(DEV), total_rows=rows).cpu()
+        exp = torch.zeros(rows, d, dtype=torch.bfloat16)
+        for b in range(n_seq):
+            exp[int(off[b]):int(off[b + 1])] = gv[b]
+    else:
+        dx = ops.masked_mean_bwd(dm, km, n_seq, S).cpu()
+        exp = torch.where(bits.reshape(-1, 1), gv.repeat_interleave(S, 0), torch.zeros((), dtype=torch.bfloat16))
+    assert torch.equal(dx, exp)
