@@ -949,7 +949,10 @@ constexpr int BA_SPLIT = 4;
 __global__ __launch_bounds__(256) void bcast_add_bwd8_kernel(const bf16_t* __restrict__ dx, bf16_t* __restrict__ dg,
                                                              long long n_seq, long long n_seq_out, int S, int d,
                                                              float drop_p, uint32_t site, const uint64_t* seed,
-                                                             bf16_t* __restrict__ dxm, uint32_t site_m, long long rows_m) {
+                                                             bf16_t* __restrict__ dxm, uint32_t site_m, long long rows_m,
+                                                             long long dg_ld) {
+    // dg_ld: row stride (elements) of dg - d, or wider: dg is a column block of a longer row (ABI 9: the conditioning gradients of a
+    // decoder stack's layers as the column blocks of ONE buffer, no concatenation launch)
     // rows_m (with dxm): dx / dxm have rows_m >= n_seq * S rows (a live row prefix rounded up): the rows past the summed
     // sequences are masked too, by the workgroups of the sequences they would belong to
     __shared__ float part[256][8];
@@ -1017,7 +1020,7 @@ __global__ __launch_bounds__(256) void bcast_add_bwd8_kernel(const bf16_t* __res
             for (int e = 0; e < 8; ++e) s[e] *= dm[e];
         }
     }
-    *reinterpret_cast<uint4*>(dg + b * d + c8) =
+    *reinterpret_cast<uint4*>(dg + b * dg_ld + c8) =
         make_uint4(f2bf_pk(s[0], s[1]), f2bf_pk(s[2], s[3]), f2bf_pk(s[4], s[5]), f2bf_pk(s[6], s[7]));
 }
 extern "C" int dsvg_bcast_add_fwd(int32_t dtype, void* x, const void* g, int64_t n_seq, int32_t S, int32_t d,
@@ -1036,8 +1039,11 @@ extern "C" int dsvg_bcast_add_fwd(int32_t dtype, void* x, const void* g, int64_t
     return 0;
 }
 extern "C" int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64_t n_seq, int64_t n_seq_out, int32_t S,
-                                  int32_t d, float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream) {
+                                  int32_t d, float drop_p, uint32_t drop_site, const uint64_t* seed, int64_t dg_ld, void* stream) {
     DSVG_CHECK_ARG(dx && dg && n_seq > 0 && n_seq_out >= n_seq && S > 0 && d > 0, "bcast_add_bwd: bad args");
+    DSVG_CHECK_ARG(dg_ld == d || (dtype == DSVG_BF16 && dg_ld > d && (dg_ld % 8) == 0 && (d % 8) == 0 && d <= 512 &&
+                                  (((uintptr_t)dx | (uintptr_t)dg) & 15) == 0),
+                   "bcast_add_bwd: a strided dg needs the bf16 kernel's conditions (d %% 8 == 0, d <= 512, 16-byte alignment)");
     DSVG_CHECK_ARG(drop_p <= 0.f || seed, "bcast_add_bwd: dropout needs a seed pointer");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DSVG_F32)
@@ -1047,7 +1053,7 @@ extern "C" int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64
         const int per = 256 / ((d / 8) * BA_SPLIT);
         hipLaunchKernelGGL(bcast_add_bwd8_kernel, dim3((unsigned)((n_seq_out + per - 1) / per)), dim3(256), 0, st,
                            (const bf16_t*)dx, (bf16_t*)dg, (long long)n_seq, (long long)n_seq_out, S, d, drop_p, drop_site,
-                           seed, (bf16_t*)nullptr, 0u, 0ll);
+                           seed, (bf16_t*)nullptr, 0u, 0ll, (long long)dg_ld);
     } else if (dtype == DSVG_BF16)
         hipLaunchKernelGGL(bcast_add_bwd_kernel<bf16_t>, dim3((unsigned)n_seq_out), dim3(256), 0, st, (const bf16_t*)dx,
                            (bf16_t*)dg, (long long)n_seq, S, d, drop_p, drop_site, seed);
@@ -1058,7 +1064,8 @@ extern "C" int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64
 
 extern "C" int dsvg_bcast_add_bwd_masked(const void* dx, void* dg, void* dx_masked, int64_t n_seq, int64_t n_seq_out, int32_t S,
                                          int32_t d, int64_t rows, float drop_p, uint32_t drop_site, uint32_t mask_site,
-                                         const uint64_t* seed, void* stream) {
+                                         const uint64_t* seed, int64_t dg_ld, void* stream) {
+    DSVG_CHECK_ARG(dg_ld >= d && (dg_ld % 8) == 0, "bcast_add_bwd_masked: bad dg row stride %lld", (long long)dg_ld);
     DSVG_CHECK_ARG(dx && dg && dx_masked && n_seq > 0 && n_seq_out >= n_seq && S > 0 && d > 0, "bcast_add_bwd_masked: bad args");
     DSVG_CHECK_ARG(rows >= n_seq * S && rows <= n_seq_out * S, "bcast_add_bwd_masked: rows must lie in [n_seq * S, n_seq_out * S]");
     DSVG_CHECK_ARG(drop_p > 0.f && seed, "bcast_add_bwd_masked: needs dropout and a seed pointer (use dsvg_bcast_add_bwd otherwise)");
@@ -1067,7 +1074,7 @@ extern "C" int dsvg_bcast_add_bwd_masked(const void* dx, void* dg, void* dx_mask
     const int per = 256 / ((d / 8) * BA_SPLIT);
     hipLaunchKernelGGL(bcast_add_bwd8_kernel, dim3((unsigned)((n_seq_out + per - 1) / per)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dx, (bf16_t*)dg, (long long)n_seq, (long long)n_seq_out, S, d, drop_p, drop_site, seed,
-                       (bf16_t*)dx_masked, mask_site, (long long)rows);
+                       (bf16_t*)dx_masked, mask_site, (long long)rows, (long long)dg_ld);
     DSVG_LAUNCH_CHECK("bcast_add_bwd_masked");
     return 0;
 }

@@ -54,6 +54,9 @@ STACK_GROUP_SLICES = int(os.environ.get("DSVG_STACK_GROUP_SLICES", "8"))    # to
 GS_BWD_DG = os.environ.get("DSVG_GS_BWD_DG", "1") != "0"
 # round 5: the argument head's input-gradient product with its reduced dimension padded to the LDS-DMA GEMM's K step
 HEAD_KPAD = os.environ.get("DSVG_HEAD_KPAD", "1") != "0"
+# round 6: the layers of a decoder stack write the gradients of their conditioning rows side by side into ONE buffer (the column
+# blocks GlobalCondFn's concatenated products read): no concatenation launch; 0 = one tensor per layer + torch.cat
+COND_GRAD_SHARED = os.environ.get("DSVG_COND_GRAD_SHARED", "1") != "0"
 # round 6: the group-stage stacks as ONE launch per stack and direction (csrc/group_stage.hip gs_stack_*; 0: one launch per layer)
 GS_STACK = os.environ.get("DSVG_GS_STACK", "1") != "0"
 # attention backward of the large stages with the out_proj backward inside (no `dao = dx1m @ Wo` GEMM launch)
@@ -94,6 +97,29 @@ class Runtime:
         self.masked = {}
         self.last_layer_gs = False
         self.stack_group = None
+        # base address of a stack's projected conditioning rows (GlobalCondFn's [n_seq, n * 256] product) -> the buffer its layers'
+        # backward passes write their gradients into, side by side (COND_GRAD_SHARED)
+        self.cond_grad = {}
+
+    def cond_grad_block(self, z, rows):
+        """z: the conditioning rows a layer received.  If they are column block i of a row-major [*, n * w] product (GlobalCondFn),
+        -> column block i of the stack's shared [rows, n * w] gradient buffer (created by the first layer that asks), else None"""
+        if not COND_GRAD_SHARED or z is None or z.dim() != 2 or z.stride(1) != 1 or z.dtype != torch.bfloat16:
+            return None
+        w, ld = z.shape[1], z.stride(0)
+        if ld <= w or ld % w or w % 8 or w > 512:
+            return None
+        i = (z.storage_offset() % ld) // w
+        if (z.storage_offset() % ld) % w:
+            return None
+        base = z.data_ptr() - i * w * z.element_size()
+        key = (base, rows, ld)
+        buf = self.cond_grad.get(key)
+        if buf is None:
+            if len(self.cond_grad) > 8:         # (never consumed: do not grow)
+                self.cond_grad.clear()
+            buf = self.cond_grad[key] = torch.empty((rows, ld), dtype=z.dtype, device=z.device)
+        return buf[:, i * w:(i + 1) * w]
 
     def deferring(self):
         """context manager around launches whose reductions write parameter gradients"""
@@ -617,6 +643,9 @@ class GlobalCondFn(torch.autograd.Function):
         # GsStackFn hands the gradients over as the column blocks of ONE buffer: that buffer is the concatenation (no launch)
         dgcat = _adjacent_columns(dgs) if cat_ok else None
         raw, dgs = dgs, None
+        if dgcat is not None:       # (the stack's shared buffer, if that is what this is, has done its job)
+            for k in [k for k, v in rt.cond_grad.items() if v.data_ptr() == dgcat.data_ptr()]:
+                del rt.cond_grad[k]
 
         def dg_blocks():            # the per-layer gradients as tensors of their own (the paths that do not use the concatenation)
             return [dg.contiguous() for dg in raw]
@@ -992,11 +1021,13 @@ class LayerFn(torch.autograd.Function):
         if z is not None:
             # (sequences past the live prefix: zero gradient rows, written by the same launch; and with dropout on, the launch
             # that reads every element of dx1 anyway also writes dx1m = drop1's mask replayed on dx1 for the attention half)
-            if (BCAST_MASKED and dx1m is None and p > 0 and dx1.dtype == torch.bfloat16 and dx1.is_contiguous()
-                    and n_seq * S <= dx1.shape[0] <= n_seq_full * S and dx1.shape[1] % 8 == 0 and dx1.shape[1] <= 512):
-                dg, dx1m = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed, n_seq_out=n_seq_full, mask_site=s0 + 1)
+            vec = dx1.dtype == torch.bfloat16 and dx1.is_contiguous() and dx1.shape[1] % 8 == 0 and dx1.shape[1] <= 512
+            # (hoisted conditioning rows: the gradient goes straight into this layer's column block of the stack's shared buffer)
+            dg_out = rt.cond_grad_block(z, n_seq_full) if (wg is None and vec and dx1.data_ptr() % 16 == 0) else None
+            if BCAST_MASKED and dx1m is None and p > 0 and vec and n_seq * S <= dx1.shape[0] <= n_seq_full * S:
+                dg, dx1m = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed, n_seq_out=n_seq_full, mask_site=s0 + 1, out=dg_out)
             else:
-                dg = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed, n_seq_out=n_seq_full)
+                dg = ops.bcast_add_bwd(dx1, n_seq, S, p, s0 + 2, rt.seed, n_seq_out=n_seq_full, out=dg_out)
             if wg is None:
                 dz = dg                     # `z` was the projected row itself: its gradient goes to GlobalCondFn
             else:

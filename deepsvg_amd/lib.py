@@ -14,7 +14,7 @@ DSVG_F32 = 0
 DSVG_BF16 = 1
 # == DSVG_ABI_VERSION of include/dsvg.h at the time SIGNATURES below was written: load() refuses a library built from another
 # header (a stale .so with the old argument lists would otherwise be called with a stream where a size is expected)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_i32, c_i64, c_u32, c_f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_float
 vp = C.c_void_p
@@ -104,8 +104,8 @@ SIGNATURES = {
     "dsvg_masked_mean_fwd": (c_i32, [c_i32, vp, vp, vp, vp, c_i64, c_i32, c_i32, vp]),
     "dsvg_masked_mean_bwd": (c_i32, [c_i32, vp, vp, vp, c_i64, vp, c_i64, c_i32, c_i32, vp]),
     "dsvg_bcast_add_fwd": (c_i32, [c_i32, vp, vp, c_i64, c_i32, c_i32, c_f32, c_u32, vp, vp]),
-    "dsvg_bcast_add_bwd": (c_i32, [c_i32, vp, vp, c_i64, c_i64, c_i32, c_i32, c_f32, c_u32, vp, vp]),
-    "dsvg_bcast_add_bwd_masked": (c_i32, [vp, vp, vp, c_i64, c_i64, c_i32, c_i32, c_i64, c_f32, c_u32, c_u32, vp, vp]),
+    "dsvg_bcast_add_bwd": (c_i32, [c_i32, vp, vp, c_i64, c_i64, c_i32, c_i32, c_f32, c_u32, vp, c_i64, vp]),
+    "dsvg_bcast_add_bwd_masked": (c_i32, [vp, vp, vp, c_i64, c_i64, c_i32, c_i32, c_i64, c_f32, c_u32, c_u32, vp, c_i64, vp]),
     "dsvg_loss_targets": (c_i32, [vp, vp, vp, c_i64, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, vp, vp]),
     "dsvg_masked_ce_fwd": (c_i32, [c_i32, vp, c_i64, c_i32, vp, vp, c_i64, c_i32, vp, vp, vp, c_i64, vp, vp]),
     "dsvg_masked_ce_workspace_bytes": (c_i64, [c_i64]),

@@ -809,7 +809,7 @@ def bcast_add_fwd_(x, g, n_seq, S, drop_p=0.0, drop_site=0, seed=None):
     return x
 
 
-def bcast_add_bwd(dx, n_seq, S, drop_p=0.0, drop_site=0, seed=None, n_seq_out=None, mask_site=None):
+def bcast_add_bwd(dx, n_seq, S, drop_p=0.0, drop_site=0, seed=None, n_seq_out=None, mask_site=None, out=None):
     """dg[b] = mask[b] * sum_s dx[b * S + s] for b < n_seq; with n_seq_out > n_seq the result has n_seq_out rows, the extra
     ones zero (sequences past a live prefix).
     mask_site (bf16, drop_p > 0): -> (dg, dxm) with dxm = drop_apply(dx, drop_p, mask_site, seed) from the same launch (one
@@ -818,17 +818,25 @@ def bcast_add_bwd(dx, n_seq, S, drop_p=0.0, drop_site=0, seed=None, n_seq_out=No
     assert dx.is_contiguous()
     d = dx.shape[1]
     n_out = n_seq if n_seq_out is None else int(n_seq_out)
-    dg = torch.empty((n_out, d), dtype=dx.dtype, device=dx.device)
+    if out is None:
+        dg = torch.empty((n_out, d), dtype=dx.dtype, device=dx.device)
+    else:
+        # a column block of a wider row-major buffer (the conditioning gradients of a stack's layers side by side)
+        assert (out.dtype == dx.dtype == torch.bfloat16 and tuple(out.shape) == (n_out, d) and out.stride(1) == 1
+                and out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0 and d % 8 == 0 and d <= 512 and dx.data_ptr() % 16 == 0)
+        _chk(out)
+        dg = out
+    ld = dg.stride(0)
     if mask_site is not None:
         assert dx.dtype == torch.bfloat16 and drop_p > 0 and n_seq * S <= dx.shape[0] <= n_out * S
         dxm = torch.empty_like(dx)
         _l.check(_l.load().dsvg_bcast_add_bwd_masked(dx.data_ptr(), dg.data_ptr(), dxm.data_ptr(), n_seq, n_out, S, d,
                                                      dx.shape[0], float(drop_p), int(drop_site), int(mask_site), _p(seed),
-                                                     _stream()),
+                                                     int(ld), _stream()),
                  "dsvg_bcast_add_bwd_masked")
         return dg, dxm
     _l.check(_l.load().dsvg_bcast_add_bwd(_dt(dx), dx.data_ptr(), dg.data_ptr(), n_seq, n_out, S, d, float(drop_p),
-                                          int(drop_site), _p(seed) if drop_p > 0 else None, _stream()),
+                                          int(drop_site), _p(seed) if drop_p > 0 else None, int(ld), _stream()),
              "dsvg_bcast_add_bwd")
     return dg
 

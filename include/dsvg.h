@@ -37,8 +37,9 @@ extern "C" {
  * 6: dsvg_pack_images, dsvg_defer_zero added; dg argument of dsvg_gs_layer_bwd.
  * 7 (round 6): dsvg_attn_bwd_dx added; a layer of dsvg_attn_pack_bwd grew from 128 to 512 fragments (in_proj_weight^T behind
  *    out_proj.weight^T).
- * 8 (round 6): dsvg_gs_stack_fwd / dsvg_gs_stack_bwd added (one launch per STACK of group-stage layers). */
-#define DSVG_ABI_VERSION 8
+ * 8 (round 6): dsvg_gs_stack_fwd / dsvg_gs_stack_bwd added (one launch per STACK of group-stage layers).
+ * 9 (round 6): dg_ld argument of dsvg_bcast_add_bwd / dsvg_bcast_add_bwd_masked (dg as a column block of a wider buffer). */
+#define DSVG_ABI_VERSION 9
 
 const char* dsvg_last_error(void);
 int dsvg_version(void);
@@ -257,14 +258,17 @@ int dsvg_masked_mean_bwd(int32_t dtype, const void* dout, const uint64_t* mask, 
  * ------------------------------------------------------------------------------------------ */
 int dsvg_bcast_add_fwd(int32_t dtype, void* x, const void* g, int64_t n_seq, int32_t S, int32_t d,
                        float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream);
+/* dg_ld (ABI 9): row stride (elements) of dg: d, or wider (bf16, d % 8 == 0, d <= 512, 16-byte aligned): dg is a column block of a
+ * longer row - the layers of a decoder stack write their conditioning gradients side by side into ONE [n_seq_out, n_layers * d]
+ * buffer, which is the concatenation GlobalCondFn's products read (no concatenation launch) */
 int dsvg_bcast_add_bwd(int32_t dtype, const void* dx, void* dg, int64_t n_seq, int64_t n_seq_out, int32_t S, int32_t d,
-                       float drop_p, uint32_t drop_site, const uint64_t* seed, void* stream);
+                       float drop_p, uint32_t drop_site, const uint64_t* seed, int64_t dg_ld, void* stream);
 /* bf16 only: dsvg_bcast_add_bwd AND dx_masked = dsvg_drop_apply(dx, drop_p, mask_site) over all `rows` rows of dx (n_seq * S <=
  * rows <= n_seq_out * S: a live row prefix may be rounded up past the summed sequences), from ONE read of dx (the large decoder
  * layers' backward needs both; d % 8 == 0, d <= 512, 16-byte aligned buffers, drop_p > 0) */
 int dsvg_bcast_add_bwd_masked(const void* dx, void* dg, void* dx_masked, int64_t n_seq, int64_t n_seq_out, int32_t S, int32_t d,
                               int64_t rows, float drop_p, uint32_t drop_site, uint32_t mask_site, const uint64_t* seed,
-                              void* stream);
+                              int64_t dg_ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * SVGLoss (deepsvg/model/loss.py:19-65).

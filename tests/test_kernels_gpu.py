@@ -915,6 +915,12 @@ def test_bcast_add_bwd_with_the_masked_copy(gpu_device):
         eg, em = R.bcast_add_bwd(dx, n_seq, S, 0.1, 402, seed, n_seq_out=n_out, mask_site=401)
         assert torch.equal(dm1, em)
         _close(dg1, eg, 1e-2, "bcast_add_bwd (masked variant) dg")
+        # ABI 9: dg as a column block of a wider buffer (the layers of a decoder stack write side by side: no concatenation launch)
+        wide = torch.full((n_out, 1024), 7.0, dtype=torch.bfloat16, device=DEV)
+        r2, m2 = ops.bcast_add_bwd(dx, n_seq, S, 0.1, 402, seed, n_seq_out=n_out, mask_site=401, out=wide[:, 512:768])
+        r3 = ops.bcast_add_bwd(dx, n_seq, S, 0.1, 402, seed, n_seq_out=n_out, out=wide[:, 256:512])
+        assert r2.data_ptr() == wide[:, 512:768].data_ptr() and torch.equal(wide[:, 512:768], dg0) and torch.equal(m2, dm0)
+        assert torch.equal(r3, dg0) and bool((wide[:, :256] == 7.0).all()) and bool((wide[:, 768:] == 7.0).all())
 
 
 def test_ffn_pack_layouts(gpu_device):

@@ -474,12 +474,15 @@ def bcast_add_fwd_(x, g, n_seq, S, drop_p=0.0, drop_site=0, seed=None):
     return x
 
 
-def bcast_add_bwd(dx, n_seq, S, drop_p=0.0, drop_site=0, seed=None, n_seq_out=None, mask_site=None):
+def bcast_add_bwd(dx, n_seq, S, drop_p=0.0, drop_site=0, seed=None, n_seq_out=None, mask_site=None, out=None):
     d = dx.shape[1]
     g = _f(dx[:n_seq * S]).view(n_seq, S, d).sum(1) * drop_mult(drop_p, seed, drop_site, _ids(n_seq, d, dx.device))
     g = g.to(dx.dtype)
     if n_seq_out is not None and n_seq_out > n_seq:
         g = torch.cat([g, g.new_zeros((n_seq_out - n_seq, d))])
+    if out is not None:
+        out.copy_(g)
+        g = out
     if mask_site is not None:
         return g, drop_apply(dx, drop_p, mask_site, seed)
     return g
